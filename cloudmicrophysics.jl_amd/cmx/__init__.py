@@ -1,0 +1,16 @@
+"""cmx — MI355X-native array evaluation of CloudMicrophysics.jl rate functions.
+
+Host-side mirror of the reference's module layout for the hot path:
+  cmx.parameters        ↔ CloudMicrophysics.Parameters (CMP)
+  cmx.bulk_tendencies   ↔ CloudMicrophysics.BulkMicrophysicsTendencies (BMT) + per-process CM2 rates
+  cmx.synthetic         ↔ the state generator of test/gpu_performance.jl:80-136
+  cmx.sharding          ↔ (no reference equivalent) one-process-per-GPU sharding + RCCL diagnostic sums
+All compute goes through libcmx.so (include/cmx.h); there is no CPU fallback.
+"""
+from . import _abi, parameters  # noqa: F401
+from ._lib import CmxLibraryError, CmxStatusError  # noqa: F401
+from .bulk_tendencies import (Chen2022VelTypeRain, Microphysics2Moment, SB2006ProcessRates,  # noqa: F401
+                              SB2006VelType, WarmRainTendencies2M, bulk_microphysics_tendencies,
+                              column_sums, sb2006_process_rates)
+
+__version__ = "0.1.0"

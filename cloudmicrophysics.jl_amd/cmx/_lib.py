@@ -1,0 +1,77 @@
+"""Loader for libcmx.so (the C-ABI shared library, include/cmx.h).
+
+There is no fallback: if the HIP extension is missing or fails to load, every
+product entry point raises `CmxLibraryError`.  Build it with
+`python __graft_entry__.py build` (or `make -C cloudmicrophysics.jl_amd/csrc`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+from . import _abi
+
+CSRC_DIR = Path(__file__).resolve().parent.parent / "csrc"
+LIB_PATH = Path(os.environ.get("CMX_LIB", CSRC_DIR / "libcmx.so"))
+
+
+class CmxLibraryError(RuntimeError):
+    pass
+
+
+class CmxStatusError(RuntimeError):
+    def __init__(self, fn, status, detail=""):
+        self.status = status
+        names = {_abi.CMX_ERR_BAD_ARG: "CMX_ERR_BAD_ARG", _abi.CMX_ERR_HIP: "CMX_ERR_HIP",
+                 _abi.CMX_ERR_UNSUPPORTED: "CMX_ERR_UNSUPPORTED"}
+        super().__init__(f"{fn} returned {names.get(status, status)}{': ' + detail if detail else ''}")
+
+
+_lib = None
+
+_FP = {"f32": C.POINTER(C.c_float), "f64": C.POINTER(C.c_double)}
+
+
+def _declare(lib):
+    vp, i32, i64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32
+    lib.cmx_version.restype = i32
+    lib.cmx_version.argtypes = []
+    lib.cmx_last_hip_error.restype = C.c_char_p
+    lib.cmx_last_hip_error.argtypes = []
+    for fam in (_abi.F32, _abi.F64):
+        s = fam.sfx
+        f = getattr(lib, f"cmx_sb2006_warm_rain_tendencies_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.warm_rain_2m), C.POINTER(fam.thermo), C.POINTER(fam.rain_vel), u32, i64] + [vp] * 13 + [vp]
+        f = getattr(lib, f"cmx_sb2006_process_rates_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.warm_rain_2m), C.POINTER(fam.thermo), C.POINTER(fam.rain_vel), u32, i64] + [vp] * 7 + [
+            C.POINTER(vp), vp]
+        f = getattr(lib, f"cmx_column_sums_{s}")
+        f.restype = i32
+        f.argtypes = [i32, C.POINTER(vp), i64, vp, vp]
+
+
+def lib():
+    """The loaded library; raises CmxLibraryError (never falls back) if it is unavailable."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise CmxLibraryError(
+                f"{LIB_PATH} not found: the HIP extension is not built. "
+                "Run `python __graft_entry__.py build` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        try:
+            handle = C.CDLL(str(LIB_PATH))
+        except OSError as e:  # missing libamdhip64 etc.
+            raise CmxLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+        _declare(handle)
+        _lib = handle
+    return _lib
+
+
+def check(fn_name, status):
+    if status < 0:
+        detail = lib().cmx_last_hip_error().decode() if status == _abi.CMX_ERR_HIP else ""
+        raise CmxStatusError(fn_name, status, detail)
+    return status

@@ -1,0 +1,162 @@
+"""Array entry points — host-side mirror of `CloudMicrophysics.BulkMicrophysicsTendencies` (BMT)
+and of the per-process `CloudMicrophysics.Microphysics2M` (CM2) functions, evaluated over device
+columns by the fused gfx950 kernels behind the C ABI (include/cmx.h).
+
+Reference call being replaced (test/type_stability_tests.jl:131-137):
+
+    BMT.bulk_microphysics_tendencies.(Ref(BMT.Microphysics2Moment()), Ref(mp), Ref(tps),
+                                      ρ, T, q_tot, q_lcl, n_lcl, q_rai, n_rai)
+
+Here:
+
+    bulk_microphysics_tendencies(Microphysics2Moment(), mp, tps, ρ, T, q_tot, q_lcl, n_lcl, q_rai, n_rai)
+
+with ρ… torch tensors resident in HBM; the result is a NamedTuple of columns (SoA) instead of the
+reference's array of NamedTuples, with the same field names.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import namedtuple
+from typing import Optional
+
+import torch
+
+from . import _abi, _lib
+from .parameters import Microphysics2MParams, WarmRainParams2M, rain_vel_params
+
+
+class Microphysics2Moment:
+    """BMT.Microphysics2Moment — scheme tag (src/BulkMicrophysicsTendencies.jl:59-63)."""
+
+
+class SB2006VelType:
+    """velocity-scheme tag: CM2.rain_terminal_velocity(sb, ::SB2006VelType, …)  CM2:685-702"""
+    flag = _abi.CMX_VEL_SB2006
+
+
+class Chen2022VelTypeRain:
+    """velocity-scheme tag: CM2.rain_terminal_velocity(sb, ::Chen2022VelTypeRain, …)  CM2:703-719"""
+    flag = _abi.CMX_VEL_CHEN2022
+
+
+WarmRainTendencies2M = namedtuple(
+    "WarmRainTendencies2M",
+    ["dq_lcl_dt", "dn_lcl_dt", "dq_rai_dt", "dn_rai_dt", "vt_rai_n", "vt_rai_m"])
+
+SB2006ProcessRates = namedtuple("SB2006ProcessRates", _abi.SB2006_PROCESS_COLUMNS)
+
+
+def _fam_of(t: torch.Tensor):
+    if t.dtype == torch.float32:
+        return _abi.F32
+    if t.dtype == torch.float64:
+        return _abi.F64
+    raise TypeError(f"state columns must be float32 or float64, got {t.dtype}")
+
+
+def _check_cols(cols, names):
+    ref = cols[0]
+    if not ref.is_cuda:
+        raise ValueError("state columns must be resident on the GPU (torch device 'cuda'); cmx has no CPU path")
+    for t, nm in zip(cols, names):
+        if t.dtype != ref.dtype or t.device != ref.device or t.shape != ref.shape:
+            raise ValueError(f"column {nm}: dtype/device/shape differ from {names[0]}")
+        if not t.is_contiguous():
+            raise ValueError(f"column {nm} must be contiguous (structure-of-arrays)")
+    return ref
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _warm_rain(mp):
+    if isinstance(mp, Microphysics2MParams):
+        return mp.warm_rain
+    if isinstance(mp, WarmRainParams2M):
+        return mp
+    raise TypeError("mp must be Microphysics2MParams or WarmRainParams2M")
+
+
+def _vel_flag(vel):
+    if vel is None:
+        return 0
+    flag = getattr(vel, "flag", None)
+    if flag is None:
+        raise TypeError("vel must be SB2006VelType, Chen2022VelTypeRain (class or instance) or None")
+    return flag
+
+
+def bulk_microphysics_tendencies(scheme, mp, tps, rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, *,
+                                 vel=None, out: Optional[WarmRainTendencies2M] = None, stream=None):
+    """2-moment warm-rain tendencies over columns — BMT:820-854 → warm_rain_tendencies_2m BMT:707-782.
+
+    `vel` (None | SB2006VelType | Chen2022VelTypeRain) additionally fuses
+    CM2.rain_terminal_velocity (CM2:685-719) into the same pass (two more output columns).
+    `out` lets the caller provide the output columns (KA-kernel style, test/gpu_tests.jl:407-415).
+    Asynchronous on `stream` (default: torch's current stream)."""
+    if not isinstance(scheme, Microphysics2Moment):
+        raise TypeError("only Microphysics2Moment() is on this path")
+    wr = _warm_rain(mp)
+    cols = (rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai)
+    ref = _check_cols(cols, ("rho", "T", "q_tot", "q_lcl", "n_lcl", "q_rai", "n_rai"))
+    fam = _fam_of(ref)
+    if fam is not wr.fam or not isinstance(tps, fam.thermo):
+        raise TypeError("parameter float type does not match the state columns")
+    vflag = _vel_flag(vel)
+    if out is None:
+        mk = lambda: torch.empty_like(ref)  # noqa: E731
+        out = WarmRainTendencies2M(mk(), mk(), mk(), mk(), mk() if vflag else None, mk() if vflag else None)
+    else:
+        _check_cols([ref] + [o for o in out if o is not None], ["rho"] + ["out"] * 6)
+    flags = (_abi.CMX_SB2006_LIMITED if wr.is_limited else 0) | vflag
+    velp = rain_vel_params(fam.sfx) if vflag else None
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_sb2006_warm_rain_tendencies_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(wr.c), C.byref(tps), C.byref(velp) if velp is not None else None, flags, ref.numel(),
+                *[_ptr(t) for t in cols], *[_ptr(o) for o in out], C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return out
+
+
+def sb2006_process_rates(mp, tps, q_tot, q_lcl, q_rai, N_lcl, N_rai, rho, T, *, vel=SB2006VelType, stream=None):
+    """The individual SB2006 process rates over columns — the reference's SB2006_2M_kernel
+    (test/gpu_tests.jl:220-235) + cond/evap (NonEq:117-140).  N_* are per m³ (CM2 convention)."""
+    wr = _warm_rain(mp)
+    cols = (q_tot, q_lcl, q_rai, N_lcl, N_rai, rho, T)
+    ref = _check_cols(cols, ("q_tot", "q_lcl", "q_rai", "N_lcl", "N_rai", "rho", "T"))
+    fam = _fam_of(ref)
+    if fam is not wr.fam or not isinstance(tps, fam.thermo):
+        raise TypeError("parameter float type does not match the state columns")
+    vflag = _vel_flag(vel)
+    outs = [torch.empty_like(ref) for _ in range(_abi.CMX_SB2006_NPROC)]
+    if not vflag:
+        outs[_abi.SB2006_PROCESS_COLUMNS.index("rain_vel_n")] = None
+        outs[_abi.SB2006_PROCESS_COLUMNS.index("rain_vel_m")] = None
+    arr = (C.c_void_p * _abi.CMX_SB2006_NPROC)(*[o.data_ptr() if o is not None else None for o in outs])
+    flags = (_abi.CMX_SB2006_LIMITED if wr.is_limited else 0) | vflag
+    velp = rain_vel_params(fam.sfx) if vflag else None
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_sb2006_process_rates_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(wr.c), C.byref(tps), C.byref(velp) if velp is not None else None, flags, ref.numel(),
+                *[_ptr(t) for t in cols], arr, C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return SB2006ProcessRates(*outs)
+
+
+def column_sums(cols, stream=None) -> torch.Tensor:
+    """Σ of each device column (double accumulation) → float64 tensor [len(cols)] on the device.
+    Building block of the optional diagnostic reduction; no communication here."""
+    ref = _check_cols(list(cols), [f"col{i}" for i in range(len(cols))])
+    fam = _fam_of(ref)
+    sums = torch.empty(len(cols), dtype=torch.float64, device=ref.device)
+    arr = (C.c_void_p * len(cols))(*[t.data_ptr() for t in cols])
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_column_sums_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(len(cols), arr, ref.numel(), _ptr(sums), C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return sums

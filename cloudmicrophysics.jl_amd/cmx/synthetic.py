@@ -1,0 +1,67 @@
+"""Synthetic atmospheric state columns for the benchmarks and the parity sweeps.
+
+Mirrors the reference's generator `generate_atmospheric_states`
+(test/gpu_performance.jl:80-136): a decaying temperature profile 300 K → 215 K over 0–15 km,
+relative humidity sweeping 0.05 → 1.05, condensate = supersaturation excess + small noise —
+randomised over the profile instead of a linear ramp, and extended with the number columns and
+the threshold / clamp edge cases the 2-moment scheme gates on.
+Pure torch, runs on any device; Julia's MersenneTwister stream is not reproducible outside Julia,
+so parity never depends on reproducing the reference's random numbers: the oracle is fed the very
+same arrays.
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+
+import torch
+
+from . import parameters as P
+
+State2M = namedtuple("State2M", ["rho", "T", "q_tot", "q_lcl", "n_lcl", "q_rai", "n_rai"])
+
+
+def _psat_liquid(T, td):
+    """Rankine–Kirchhoff p_sat over liquid (same closed form as the kernels; float64 torch)."""
+    R_v = td["gas_constant_vapor"]
+    dcp = td["isobaric_specific_heat_vapor"] - td["isobaric_specific_heat_liquid"]
+    T_tr, p_tr = td["temperature_triple_point"], td["pressure_triple_point"]
+    LH, T0 = td["latent_heat_vaporization_at_reference"], td["thermodynamics_temperature_reference"]
+    return p_tr * (T / T_tr) ** (dcp / R_v) * torch.exp((LH - dcp * T0) / R_v * (1.0 / T_tr - 1.0 / T))
+
+
+def sb2006_state(n: int, dtype=torch.float32, device="cpu", seed: int = 1234, chunk: int = 1 << 24) -> State2M:
+    """n random warm-rain states as 7 contiguous columns (ρ, T, q_tot, q_lcl, n_lcl, q_rai, n_rai)."""
+    td = P.DEFAULT_PARAMETERS
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    cols = [torch.empty(n, dtype=dtype, device=device) for _ in range(7)]
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        u = lambda: torch.rand(m, dtype=torch.float64, device=device, generator=g)  # noqa: E731
+        logu = lambda a, b: torch.exp(torch.log(torch.tensor(a, dtype=torch.float64, device=device)) +  # noqa: E731
+                                      u() * (torch.log(torch.tensor(b / a, dtype=torch.float64, device=device))))
+        z = 15000.0 * u()
+        T = torch.clamp(300.0 - 6.5e-3 * z, min=215.0) + (4.0 * u() - 2.0)
+        p = 1.0e5 * torch.exp(-z / 8000.0)
+        RH = 0.05 + u()
+        p_sat = _psat_liquid(T, td)
+        eps_m = td["gas_constant_dry_air"] / td["gas_constant_vapor"]
+        q_vap = RH * eps_m * p_sat / (p - (1 - eps_m) * RH * p_sat).clamp(min=1.0)
+        q_vap = q_vap.clamp(max=0.04)
+        rho = p / (td["gas_constant_dry_air"] * T * (1.0 + 0.61 * q_vap))
+        q_sat = p_sat / (rho * td["gas_constant_vapor"] * T)
+        q_lcl = (q_vap - q_sat).clamp(min=0.0) + 1e-4 * u() * (u() < 0.7)
+        q_rai = 1e-4 * u() * (u() < 0.5)
+        heavy = u() < 0.1
+        q_rai = torch.where(heavy, logu(1e-7, 5e-3), q_rai)
+        n_lcl = torch.where(u() < 0.2, torch.full_like(z, 1e8), logu(1e6, 1e9))
+        n_rai = logu(1e1, 1e7)
+        q_tot = q_vap + q_lcl + q_rai
+        # threshold / clamp edge cases: 1 % exact zeros and 0.5 % slightly negative per q/n column
+        for c in (q_lcl, q_rai, n_lcl, n_rai):
+            r = u()
+            c.masked_fill_(r < 0.010, 0.0)
+            c.copy_(torch.where((r >= 0.010) & (r < 0.015), -1e-9 * (1 + c.abs()), c))
+        for dst, src in zip(cols, (rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai)):
+            dst[lo:lo + m] = src.to(dtype)
+    return State2M(*cols)

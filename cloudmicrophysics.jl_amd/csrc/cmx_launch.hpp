@@ -1,0 +1,71 @@
+// cmx_launch.hpp — launch geometry, vector column access and error plumbing shared by the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+
+#include "../../include/cmx.h"
+
+namespace cmx {
+
+// --- error plumbing ------------------------------------------------------------------------
+void set_hip_error(hipError_t e, const char *where);   // cmx_common.hip
+#define CMX_HIP_TRY(expr)                                 \
+    do {                                                  \
+        hipError_t e_ = (expr);                           \
+        if (e_ != hipSuccess) {                           \
+            ::cmx::set_hip_error(e_, #expr);              \
+            return CMX_ERR_HIP;                           \
+        }                                                 \
+    } while (0)
+
+// --- geometry ------------------------------------------------------------------------------
+// MI355X: 256 CUs in 8 XCDs.  Pointwise streaming kernels use 256-thread workgroups (4 waves, one
+// per SIMD) and a grid-stride loop over a grid of CUs × k resident workgroups, so that every CU
+// keeps ≥16 waves of independent 16-byte loads in flight and the grid is a multiple of the 8 XCDs
+// (workgroup b lands on XCD b % 8: consecutive workgroups stream consecutive 4 KiB tiles, each XCD
+// L2 sees a disjoint, dense address set).
+constexpr int kBlock = 256;
+
+struct DeviceInfo { int cus; int blocks_per_cu; };
+DeviceInfo device_info();                                // cmx_common.hip (cached per device)
+
+inline int grid_for(int64_t work_items, int items_per_block = kBlock) {
+    const DeviceInfo di = device_info();
+    const int64_t need = (work_items + items_per_block - 1) / items_per_block;
+    const int64_t cap = (int64_t)di.cus * di.blocks_per_cu;
+    const int64_t g = need < cap ? need : cap;
+    return (int)(g < 1 ? 1 : g);
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// --- vector column access --------------------------------------------------------------------
+template <typename FT, int VEC> struct VecT;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+template <> struct VecT<float, 4> { using type = f32x4_t; };    // global_load_dwordx4: 16 B / lane
+template <> struct VecT<float, 1> { using type = float; };
+template <> struct VecT<double, 2> { using type = f64x2_t; };   // 16 B / lane as well
+template <> struct VecT<double, 1> { using type = double; };
+
+template <typename FT, int VEC>
+__device__ __forceinline__ void load_col(const FT *__restrict__ p, int64_t i, FT (&x)[VEC]) {
+    using V = typename VecT<FT, VEC>::type;
+    const V v = __builtin_nontemporal_load(reinterpret_cast<const V *>(p) + i);
+    const FT *e = reinterpret_cast<const FT *>(&v);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) x[k] = e[k];
+}
+template <typename FT, int VEC>
+__device__ __forceinline__ void store_col(FT *__restrict__ p, int64_t i, const FT (&x)[VEC]) {
+    using V = typename VecT<FT, VEC>::type;
+    V v;
+    FT *e = reinterpret_cast<FT *>(&v);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) e[k] = x[k];
+    __builtin_nontemporal_store(v, reinterpret_cast<V *>(p) + i);
+}
+
+}  // namespace cmx

@@ -1,0 +1,55 @@
+// cmx_math.hpp — per-lane special-function layer for gfx950 (CDNA4).
+//
+// The rate functions are pointwise and HBM-bound only if the transcendental work
+// stays on the hardware quarter-rate units: every pow/cbrt/exp/log of the
+// reference is rewritten in the log2 domain (x^y = exp2(y·log2 x)) so that the
+// Float32 path issues bare v_log_f32 / v_exp_f32 / v_rcp_f32 / v_sqrt_f32 and
+// shares one log2 between all powers of the same base.  Float64 uses the OCML
+// double routines (no hardware transcendental unit for f64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace cmx {
+
+template <typename FT> struct Math;
+
+template <> struct Math<float> {
+    static constexpr int VEC = 4;
+    static constexpr float eps() { return 1.1920928955078125e-07f; }          // eps(Float32)
+    static constexpr float eps_1m() { return 2.2737367544323206e-13f; }       // cbrt(floatmin(Float32))
+    static __device__ __forceinline__ float exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+    static __device__ __forceinline__ float log2(float x) { return __builtin_amdgcn_logf(x); }
+    static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+    static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+    static __device__ __forceinline__ float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+    static __device__ __forceinline__ float div(float a, float b) { return a * rcp(b); }
+    static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+    static __device__ __forceinline__ float max(float a, float b) { return __builtin_fmaxf(a, b); }
+    static __device__ __forceinline__ float min(float a, float b) { return __builtin_fminf(a, b); }
+    // Γ(z) for z in [1, 8]: shift into [2,3) and evaluate a minimax-quality polynomial
+    // (only used by the Chen-2022 rain velocity: z = b_i(ρ)+1 ∈ [2.0, 3.4], z+3).
+    static __device__ __forceinline__ float tgamma(float z) { return ::tgammaf(z); }
+};
+
+template <> struct Math<double> {
+    static constexpr int VEC = 2;
+    static constexpr double eps() { return 2.220446049250313e-16; }            // eps(Float64)
+    static constexpr double eps_1m() { return 2.8126442852362996e-103; }      // cbrt(floatmin(Float64))
+    static __device__ __forceinline__ double exp2(double x) { return ::exp2(x); }
+    static __device__ __forceinline__ double log2(double x) { return ::log2(x); }
+    static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
+    static __device__ __forceinline__ double div(double a, double b) { return a / b; }
+    static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+    static __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }
+    static __device__ __forceinline__ double min(double a, double b) { return __builtin_fmin(a, b); }
+    static __device__ __forceinline__ double tgamma(double z) { return ::tgamma(z); }
+};
+
+template <typename FT> __device__ __forceinline__ FT clampv(FT x, FT lo, FT hi) {
+    // Base.clamp: x < lo ? lo : (x > hi ? hi : x)
+    return Math<FT>::min(Math<FT>::max(x, lo), hi);
+}
+
+}  // namespace cmx

@@ -1,0 +1,374 @@
+// cmx_sb2006.hpp — Seifert–Beheng 2006 two-moment warm-rain point function.
+//
+// One evaluation of everything the reference computes per grid point on the path
+//   bulk_microphysics_tendencies(::Microphysics2Moment, mp{WR,Nothing}, …)   BMT:820-854
+//   └ warm_rain_tendencies_2m                                               BMT:707-782
+// (reference = /root/reference/src, BMT = BulkMicrophysicsTendencies.jl, CM2 = Microphysics2M.jl,
+// NonEq = MicrophysicsNonEq.jl, TDI = ThermodynamicsInterface.jl), restructured for the GPU:
+//   * the saturation vapour pressure (3× in the reference: cond/evap, supersaturation, G) and the
+//     rain PSD parameters (3×: evaporation, self-collection, breakup; 4× with velocities) are
+//     evaluated ONCE;
+//   * every cbrt / pow of the mean drop mass shares one log2(x̄_r); all powers run in the log2
+//     domain (cmx_math.hpp);
+//   * all parameter-only sub-expressions are folded on the host into SbConsts (double arithmetic,
+//     then rounded to FT) and arrive in SGPRs through the kernel-argument segment;
+//   * gates are branch-free selects, exactly the reference's `ifelse` predicates.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#include "../../include/cmx.h"
+#include "cmx_math.hpp"
+
+namespace cmx {
+
+enum : int { VEL_NONE = 0, VEL_SB = 1, VEL_CHEN = 2 };
+
+// ---------------------------------------------------------------------------------------------
+// Host-folded constants.  Plain FT members only (kernel argument → SGPRs).
+// ---------------------------------------------------------------------------------------------
+template <typename FT> struct SbConsts {
+    // thermodynamics (Thermodynamics.jl restatement, see oracle/cmx_oracle_impl.h)
+    FT T_0, LH_v0, dcp, R_v, inv_R_v;
+    FT ps_c0, ps_a, ps_b, inv_T_tr;     // log2 p_sat = c0 + a·log2(T/T_tr) + b·(1/T_tr − 1/T)
+    FT cp_d, cpm_qt, cpm_ql;            // cp_m = cp_d + cpm_qt·q_tot + cpm_ql·q_liq
+    FT tau_ce;                          // CondEvap2M.τ_relax
+    FT inv_K, Rv_over_D, eps_1m;        // G_func_liquid (Common.jl:47-63)
+    // rain PSD (CM2:67-110)
+    FT xr_min, xr_max, N0_min, N0_max, lam_min, lam_max, pi_rho_w;
+    // evaporation (CM2:780-828)
+    FT l2_6xstar, l2_Drc;               // log2(6 x*), log2(6/(π ρw))
+    FT ga_c1, ga_e1, ga_c2, ga_e2;      // Γ_incl(−1, t)   (CM2:746-753)
+    FT gb_c1, gb_e1, gb_c2, gb_e2;      // Γ_incl(β_vent_0, t)
+    FT a_vent_0_coeff, bSc_vent_0, a_vent_1, bSc_vent_1;   // b·∛Sc folded
+    FT sqrt_alpha_nu, beta, ev_rho0_q;  // √(α/ν_air), β, ρ0^(1/4)
+    FT two_pi, inv_xstar_ev;
+    // autoconversion / cloud self-collection (CM2:396-427, 488-501)
+    FT sqrt_kfac, x_star, inv_x_star, acnv_A, acnv_a, acnv_b, acnv_rho0, ksc;
+    // accretion (CM2:445-470)
+    FT kcr_s, tau_0, accr_c;            // kcr·√ρ0
+    // rain self-collection / breakup (CM2:545-601)
+    FT krr_s, kappa_rr, self_d, l2_6;   // krr·√ρ0(pdf_r)
+    FT Deq, Dr_th, kbr, kappa_br_l2e;
+    // number adjustment (CM2:882-891)
+    FT inv_tau_na, inv_xc_min, inv_xc_max, inv_xr_min, inv_xr_max;
+    // SB2006 rain velocity (CM2:685-702, 720-739)
+    FT vel_s, aR, bR, cR, rc2, e_rc2cR; // √ρ0(vel), …, 2·r_c, exp(−2 r_c c_R)
+    // Chen-2022 rain velocity (Common.jl:290-302, 414-422)
+    FT ch_rho0_l2e, ch_a[3], ch_a3_pow, ch_b[3], ch_b_rho, ch_c1000[3], l2_1000;
+};
+
+template <typename FT, typename WR, typename TH, typename VL>
+inline SbConsts<FT> make_sb_consts(const WR &wr, const TH &tp, const VL *vel, double eps_1m) {
+    SbConsts<FT> c{};
+    const auto &sb = wr.seifert_beheng;
+    const double pi = 3.14159265358979323846;
+    const double l2e = 1.4426950408889634074;
+    // thermo
+    const double dcp = (double)tp.cp_v - (double)tp.cp_l;
+    c.T_0 = (FT)tp.T_0;
+    c.LH_v0 = (FT)tp.LH_v0;
+    c.dcp = (FT)dcp;
+    c.R_v = (FT)tp.R_v;
+    c.inv_R_v = (FT)(1.0 / (double)tp.R_v);
+    c.ps_c0 = (FT)std::log2((double)tp.press_triple);
+    c.ps_a = (FT)(dcp / (double)tp.R_v);
+    c.ps_b = (FT)(((double)tp.LH_v0 - dcp * (double)tp.T_0) / (double)tp.R_v * l2e);
+    c.inv_T_tr = (FT)(1.0 / (double)tp.T_triple);
+    c.cp_d = (FT)tp.cp_d;
+    c.cpm_qt = (FT)((double)tp.cp_v - (double)tp.cp_d);
+    c.cpm_ql = (FT)((double)tp.cp_l - (double)tp.cp_v);
+    c.tau_ce = (FT)wr.condevap_tau_relax;
+    const double K_safe = std::fmax((double)wr.air_properties.K_therm, eps_1m);
+    const double D_safe = std::fmax((double)wr.air_properties.D_vapor, eps_1m);
+    c.inv_K = (FT)(1.0 / K_safe);
+    c.Rv_over_D = (FT)((double)tp.R_v / D_safe);
+    c.eps_1m = (FT)eps_1m;
+    // rain PSD
+    const auto &pr = sb.pdf_r;
+    c.xr_min = (FT)pr.xr_min;
+    c.xr_max = (FT)pr.xr_max;
+    c.N0_min = (FT)pr.N0_min;
+    c.N0_max = (FT)pr.N0_max;
+    c.lam_min = (FT)pr.lambda_min;
+    c.lam_max = (FT)pr.lambda_max;
+    c.pi_rho_w = (FT)(pi * (double)pr.rho_w);
+    // evaporation
+    const auto &ev = sb.evap;
+    const double x_star_ev = (double)pr.xr_min;  // CM2:795
+    c.l2_6xstar = (FT)std::log2(6.0 * x_star_ev);
+    c.l2_Drc = (FT)std::log2(6.0 / (pi * (double)pr.rho_w));
+    auto gincl = [](double a, FT &c1, FT &e1, FT &c2, FT &e2) {
+        c1 = (FT)(0.33 - 0.7 * a);
+        e1 = (FT)(0.08 - 0.93 * a);
+        c2 = (FT)(1.34 - 0.1 * a);
+        e2 = (FT)(0.8 - a);
+    };
+    gincl(-1.0, c.ga_c1, c.ga_e1, c.ga_c2, c.ga_e2);
+    gincl((double)ev.beta_vent_0, c.gb_c1, c.gb_e1, c.gb_c2, c.gb_e2);
+    const double cbrt_Sc = std::cbrt((double)wr.air_properties.nu_air / D_safe);
+    c.a_vent_0_coeff = (FT)ev.a_vent_0_coeff;
+    c.bSc_vent_0 = (FT)((double)ev.b_vent_0_coeff * cbrt_Sc);
+    c.a_vent_1 = (FT)ev.a_vent_1;
+    c.bSc_vent_1 = (FT)((double)ev.b_vent_1 * cbrt_Sc);
+    c.sqrt_alpha_nu = (FT)std::sqrt((double)ev.alpha / (double)wr.air_properties.nu_air);
+    c.beta = (FT)ev.beta;
+    c.ev_rho0_q = (FT)std::sqrt(std::sqrt((double)ev.rho_0));
+    c.two_pi = (FT)(2.0 * pi);
+    c.inv_xstar_ev = (FT)(1.0 / x_star_ev);
+    // autoconversion
+    const auto &ac = sb.acnv;
+    const double nu_c = (double)sb.pdf_c.nu_c;
+    const double kfac = (double)ac.kcc / 20.0 / (double)ac.x_star * (nu_c + 2) * (nu_c + 4) /
+                        ((nu_c + 1) * (nu_c + 1));
+    c.sqrt_kfac = (FT)std::sqrt(kfac);
+    c.x_star = (FT)ac.x_star;
+    c.inv_x_star = (FT)(1.0 / (double)ac.x_star);
+    c.acnv_A = (FT)ac.A;
+    c.acnv_a = (FT)ac.a;
+    c.acnv_b = (FT)ac.b;
+    c.acnv_rho0 = (FT)ac.rho_0;
+    c.ksc = (FT)((double)ac.kcc * (nu_c + 2) / (nu_c + 1) * (double)ac.rho_0);
+    // accretion
+    c.kcr_s = (FT)((double)sb.accr.kcr * std::sqrt((double)sb.accr.rho_0));
+    c.tau_0 = (FT)sb.accr.tau_0;
+    c.accr_c = (FT)sb.accr.c;
+    // rain self-collection / breakup
+    c.krr_s = (FT)((double)sb.self.krr * std::sqrt((double)pr.rho_0));
+    c.kappa_rr = (FT)sb.self.kappa_rr;
+    c.self_d = (FT)sb.self.d;
+    c.l2_6 = (FT)std::log2(6.0);
+    c.Deq = (FT)sb.brek.Deq;
+    c.Dr_th = (FT)sb.brek.Dr_th;
+    c.kbr = (FT)sb.brek.kbr;
+    c.kappa_br_l2e = (FT)((double)sb.brek.kappa_br * l2e);
+    // number adjustment
+    c.inv_tau_na = (FT)(1.0 / (double)sb.numadj.tau);
+    c.inv_xc_min = (FT)(1.0 / (double)sb.pdf_c.xc_min);
+    c.inv_xc_max = (FT)(1.0 / (double)sb.pdf_c.xc_max);
+    c.inv_xr_min = (FT)(1.0 / (double)pr.xr_min);
+    c.inv_xr_max = (FT)(1.0 / (double)pr.xr_max);
+    // velocities
+    if (vel) {
+        const auto &v = vel->sb2006;
+        c.vel_s = (FT)std::sqrt((double)v.rho_0);
+        c.aR = (FT)v.aR;
+        c.bR = (FT)v.bR;
+        c.cR = (FT)v.cR;
+        const double rc2 = -1.0 / (double)v.cR * std::log((double)v.aR / (double)v.bR);  // 2·r_c
+        c.rc2 = (FT)rc2;
+        c.e_rc2cR = (FT)std::exp(-rc2 * (double)v.cR);
+        const auto &ch = vel->chen2022;
+        c.ch_rho0_l2e = (FT)((double)ch.rho_0 * l2e);
+        for (int i = 0; i < 3; ++i) {
+            c.ch_a[i] = (FT)ch.a[i];
+            c.ch_b[i] = (FT)ch.b[i];
+            c.ch_c1000[i] = (FT)((double)ch.c[i] * 1000.0);
+        }
+        c.ch_a3_pow = (FT)ch.a3_pow;
+        c.ch_b_rho = (FT)ch.b_rho;
+        c.l2_1000 = (FT)std::log2(1000.0);
+    }
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-point result: every process rate of SB2006_2M_kernel (test/gpu_tests.jl:220-235) + cond/evap.
+// The fused kernel sums them (unused ones are dead-code-eliminated per instantiation).
+// ---------------------------------------------------------------------------------------------
+template <typename FT> struct SbRates {
+    FT cond;                                            // NonEq:117-140 [kg/kg/s]
+    FT au_dq_lcl, au_dN_lcl, au_dq_rai, au_dN_rai;      // CM2:396-427
+    FT lsc;                                             // CM2:488-501 [1/m3/s]
+    FT ac_dq_lcl, ac_dN_lcl, ac_dq_rai;                 // CM2:445-470
+    FT rsc, rbr;                                        // CM2:545-601 [1/m3/s]
+    FT evN, evq;                                        // CM2:780-828
+    FT na_lcl, na_rai;                                  // CM2:882-891 [1/kg/s]
+    FT vt_n, vt_m;                                      // CM2:685-719 [m/s]
+    FT inv_rho;
+};
+
+// `n_lcl`, `n_rai` are per-kg numbers (BMT), `N_*` = ρ n_* per m³ (CM2).  No input clamping here:
+// the fused entry clamps first (BMT:828-837), the per-process entry passes raw values like the
+// reference's KA wrapper does.
+template <typename FT, bool LIMITED, int VEL>
+__device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rho, FT T, FT q_tot,
+                                                    FT q_lcl, FT q_rai, FT N_lcl, FT N_rai,
+                                                    FT n_lcl, FT n_rai) {
+    using M = Math<FT>;
+    const FT eps = M::eps();  // ϵ_numerics_2M_M = ϵ_numerics_2M_N = eps(FT)  (Utilities.jl:325,332)
+    SbRates<FT> r;
+
+    const FT inv_rho = M::rcp(rho);
+    const FT rs_rho = M::rsqrt(rho);  // ρ^(-1/2); each √(ρ0/ρ) is (host √ρ0)·rs_rho
+    r.inv_rho = inv_rho;
+
+    // ---- thermodynamics: one p_sat(T) shared by cond/evap, S and G -----------------------------
+    const FT inv_T = M::rcp(T);
+    const FT L_v = M::fma(c.dcp, T - c.T_0, c.LH_v0);                       // TD.latent_heat_vapor
+    const FT l2_ps = M::fma(c.ps_a, M::log2(T * c.inv_T_tr), M::fma(c.ps_b, c.inv_T_tr - inv_T, c.ps_c0));
+    const FT p_sat = M::exp2(l2_ps);                                         // TD.saturation_vapor_pressure
+    const FT q_liq = q_lcl + q_rai;
+    const FT q_vap = M::max(FT(0), q_tot - q_liq);                           // TDI.q_vap (q_ice = q_sno = 0)
+    const FT rho_RvT = rho * (c.R_v * T);
+    const FT inv_p_sat = M::rcp(p_sat);
+    const FT q_sat = p_sat * M::rcp(rho_RvT);                                // TD.q_vap_saturation
+    const FT LoRT = L_v * c.inv_R_v * inv_T;                                 // L/(R_v T)
+    {   // _conv_q_vap_to_q_lcl_const  NonEq:117-140
+        const FT cp_air = M::fma(c.cpm_ql, q_liq, M::fma(c.cpm_qt, q_tot, c.cp_d));   // TD.cp_m
+        const FT dqsl_dT = q_sat * (LoRT * inv_T - inv_T);                   // dqcld_dT NonEq:74-76
+        const FT Gamma_l = M::fma(L_v * M::rcp(cp_air), dqsl_dT, FT(1));     // gamma_helper NonEq:88-90
+        const FT excess = q_vap - q_sat;
+        const FT inv_ts = M::rcp(c.tau_ce * Gamma_l);
+        const FT evap_lim = -M::min(-excess, M::max(FT(0), q_lcl));
+        r.cond = (excess < FT(0) ? evap_lim : excess) * inv_ts;
+    }
+    const FT S = M::fma(q_vap * rho_RvT, inv_p_sat, FT(-1));                 // TDI.supersaturation_over_liquid
+    // G_func_liquid  Common.jl:47-63
+    const FT inv_p_safe = (p_sat > c.eps_1m) ? inv_p_sat : M::rcp(c.eps_1m);
+    const FT G = M::rcp(M::fma(L_v * c.inv_K * inv_T, LoRT - FT(1), c.Rv_over_D * T * inv_p_safe));
+
+    // ---- cloud side: autoconversion, cloud self-collection, accretion --------------------------
+    const FT sq_lcl = M::max(q_lcl, eps);
+    const FT sN_lcl = M::max(N_lcl, eps);
+    const FT sq_rai = M::max(q_rai, eps);
+    const FT sN_rai = M::max(N_rai, eps);
+    const FT L_lcl = rho * sq_lcl;
+    const FT L_rai = rho * sq_rai;
+    const FT x_lcl_raw = L_lcl * M::rcp(sN_lcl);
+    const bool no_q_lcl = q_lcl < eps, no_N_lcl = N_lcl < eps, no_q_rai = q_rai < eps;
+    // τ = 1 − q_l/(q_l+q_r) (Eq. 5) in its cancellation-free form q_r/(q_l+q_r); 1−τ likewise.
+    // With q_rai < eps the reference's two τ (max(0,q_r) in CM2:407 vs max(q_r,eps) in :450) differ,
+    // but there ϕ_au ≡ 0 and accretion ≡ 0, so one τ serves both.
+    const FT inv_qsum = M::rcp(sq_lcl + sq_rai);
+    const FT tau = sq_rai * inv_qsum;
+    const FT one_m_tau = sq_lcl * inv_qsum;
+    const FT l2_tau = M::log2(tau);
+    {   // autoconversion CM2:396-427
+        const FT x_lcl = M::min(c.x_star, x_lcl_raw);
+        const FT tau_a = M::exp2(c.acnv_a * l2_tau);
+        const FT phi_au = no_q_rai ? FT(0) : c.acnv_A * tau_a * M::exp2(c.acnv_b * M::log2(FT(1) - tau_a));
+        const FT u = (L_lcl * x_lcl) * c.sqrt_kfac;   // √(kcc/20/x*·ν-terms)·L·x̄: keeps L²x̄² inside the f32 range
+        const FT inv_omt = M::rcp(one_m_tau);
+        const FT dL_rai = (u * u) * M::fma(phi_au, inv_omt * inv_omt, FT(1)) * (c.acnv_rho0 * inv_rho);
+        const FT dN_rai = dL_rai * c.inv_x_star;
+        const bool gate = no_q_lcl || no_N_lcl;
+        r.au_dq_rai = gate ? FT(0) : dL_rai * inv_rho;
+        r.au_dq_lcl = -r.au_dq_rai;
+        r.au_dN_rai = gate ? FT(0) : dN_rai;
+        r.au_dN_lcl = FT(-2) * r.au_dN_rai;
+    }
+    {   // cloud_liquid_self_collection CM2:488-501 (raw L_lcl = ρ q_lcl)
+        const FT Lr = rho * q_lcl;
+        const FT sc = -c.ksc * inv_rho * (Lr * Lr) - r.au_dN_lcl;
+        r.lsc = no_q_lcl ? FT(0) : sc;
+    }
+    {   // accretion CM2:445-470
+        const FT phi_ac = M::exp2(c.accr_c * (l2_tau - M::log2(tau + c.tau_0)));
+        const FT dL_rai = c.kcr_s * rs_rho * L_lcl * L_rai * phi_ac;
+        const bool gate = no_q_lcl || no_q_rai || no_N_lcl;
+        r.ac_dq_rai = gate ? FT(0) : dL_rai * inv_rho;
+        r.ac_dq_lcl = -r.ac_dq_rai;
+        r.ac_dN_lcl = gate ? FT(0) : -dL_rai * M::rcp(x_lcl_raw);
+    }
+
+    // ---- rain PSD parameters, once (CM2:67-110), from the safe values ----------
+    FT xr_mean, lam, Dr_mean;
+    if constexpr (LIMITED) {
+        const FT xt = clampv(L_rai * M::rcp(sN_rai), c.xr_min, c.xr_max);                      // Eq. 94
+        const FT cb = M::exp2(M::log2(c.pi_rho_w * M::rcp(xt)) * FT(1.0 / 3.0));
+        const FT N0 = clampv(sN_rai * cb, c.N0_min, c.N0_max);                                // Eq. 95
+        lam = clampv(M::sqrt(M::sqrt(c.pi_rho_w * N0 * M::rcp(L_rai))), c.lam_min, c.lam_max); // Eq. 96
+        xr_mean = clampv(L_rai * lam * M::rcp(N0), c.xr_min, c.xr_max);                       // Eq. 97
+        Dr_mean = M::rcp(lam);
+    } else {
+        xr_mean = L_rai * M::rcp(sN_rai);
+        lam = M::exp2(M::log2(c.pi_rho_w * M::rcp(xr_mean)) * FT(1.0 / 3.0));
+        Dr_mean = M::rcp(lam);
+    }
+    const FT l2_xr = M::log2(xr_mean);
+    const FT l2_Dr = (l2_xr + c.l2_Drc) * FT(1.0 / 3.0);
+    const FT Dr = M::exp2(l2_Dr);                       // ∛(6 x̄_r/(π ρw)): CM2:588 and :809
+    const bool no_N_rai = N_rai < eps;
+    {   // rain_self_collection CM2:545-560 + rain_breakup CM2:579-601
+        const FT inv_Br = M::exp2((l2_xr - c.l2_6) * FT(1.0 / 3.0));      // 1/∛(6/x̄_r)
+        const FT pw = M::exp2(c.self_d * M::log2(M::fma(c.kappa_rr, inv_Br, FT(1))));
+        const FT sc = -c.krr_s * rs_rho * N_rai * L_rai * pw;
+        const bool gate = no_q_rai || no_N_rai;
+        r.rsc = gate ? FT(0) : sc;
+        const FT dD = Dr - c.Deq;
+        const FT phi_br = (Dr < c.Dr_th) ? FT(-1)
+                                         : ((Dr <= c.Deq) ? c.kbr * dD : M::exp2(c.kappa_br_l2e * dD) - FT(1));
+        r.rbr = gate ? FT(0) : -(phi_br + FT(1)) * r.rsc;
+    }
+    {   // rain_evaporation CM2:780-828
+        const FT l2_t = (c.l2_6xstar - l2_xr) * FT(1.0 / 3.0);            // t* = ∛(6 x*/x̄_r)
+        const FT t_star = M::exp2(l2_t);
+        const FT e_t = M::exp2(t_star * FT(-1.4426950408889634));
+        const FT g_a = e_t * M::rcp(M::fma(c.ga_c1, M::exp2(c.ga_e1 * l2_t), c.ga_c2 * M::exp2(c.ga_e2 * l2_t)));
+        const FT g_b = e_t * M::rcp(M::fma(c.gb_c1, M::exp2(c.gb_e1 * l2_t), c.gb_c2 * M::exp2(c.gb_e2 * l2_t)));
+        // √N_Re = √(α/ν)·(ρ0/ρ)^¼·√(x̄^β·Dr)
+        const FT sqrt_N_Re = c.sqrt_alpha_nu * c.ev_rho0_q * M::sqrt(rs_rho) *
+                             M::exp2(FT(0.5) * M::fma(c.beta, l2_xr, l2_Dr));
+        const FT Fv0 = M::fma(c.bSc_vent_0 * g_b, sqrt_N_Re, c.a_vent_0_coeff * g_a);
+        const FT Fv1 = M::fma(c.bSc_vent_1, sqrt_N_Re, c.a_vent_1);
+        const FT common = c.two_pi * G * S * N_rai * Dr;
+        const FT inv_xr = M::rcp(xr_mean);
+        const FT dN = M::min(FT(0), common * Fv0 * inv_xr);
+        const FT dq = M::min(FT(0), common * Fv1 * inv_rho);
+        const bool gate_q = no_q_rai || (N_rai <= eps) || (S >= FT(0));
+        const bool gate_N = gate_q || (xr_mean * c.inv_xstar_ev < eps);
+        r.evN = gate_N ? FT(0) : dN;
+        r.evq = gate_q ? FT(0) : dq;
+    }
+    {   // number_tendency_from_mass_limits CM2:882-891 (cloud: xc_min/xc_max, rain: xr_min/xr_max)
+        const FT tl = no_q_lcl ? FT(0) : clampv(n_lcl, q_lcl * c.inv_xc_max, q_lcl * c.inv_xc_min);
+        r.na_lcl = (tl - n_lcl) * c.inv_tau_na;
+        const FT tr = no_q_rai ? FT(0) : clampv(n_rai, q_rai * c.inv_xr_max, q_rai * c.inv_xr_min);
+        r.na_rai = (tr - n_rai) * c.inv_tau_na;
+    }
+    // ---- rain terminal velocity (optional columns) ----------------------------------------------
+    r.vt_n = FT(0);
+    r.vt_m = FT(0);
+    if constexpr (VEL == VEL_SB) {   // CM2:685-702, helper :720-739
+        FT pa0 = FT(1), pb0 = FT(1), pa1 = FT(1), pb1 = FT(1);
+        if constexpr (!LIMITED) {
+            const FT ta = c.rc2 * lam, tb = c.rc2 * (lam + c.cR);
+            pa0 = M::exp2(ta * FT(-1.4426950408889634));
+            pb0 = pa0 * c.e_rc2cR;
+            pa1 = (((ta + FT(3)) * ta + FT(6)) * ta + FT(6)) * pa0 * FT(1.0 / 6.0);
+            pb1 = (((tb + FT(3)) * tb + FT(6)) * tb + FT(6)) * pb0 * FT(1.0 / 6.0);
+        }
+        const FT s = c.vel_s * rs_rho;
+        const FT inv_d1 = M::rcp(M::fma(c.cR, Dr_mean, FT(1)));
+        const FT inv_d2 = inv_d1 * inv_d1;
+        const FT vt0 = M::max(FT(0), s * (c.aR * pa0 - c.bR * pb0 * inv_d1));
+        const FT vt1 = M::max(FT(0), s * (c.aR * pa1 - c.bR * pb1 * (inv_d2 * inv_d2)));
+        r.vt_n = no_N_rai ? FT(0) : vt0;
+        r.vt_m = no_q_rai ? FT(0) : vt1;
+    } else if constexpr (VEL == VEL_CHEN) {   // CM2:703-719, Common.jl:290-302, 414-422
+        const FT rho_c = M::max(rho, FT(0));
+        const FT l2_q = c.ch_rho0_l2e * rho_c;                  // log2 exp(ρ0 ρ)
+        const FT l2_rho = M::log2(rho_c);
+        const FT l2_lam_inv = -M::log2(lam);                    // log2 Dr_mean
+        FT vt0 = FT(0), vt3 = FT(0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const FT bi = M::fma(-c.ch_b_rho, rho_c, c.ch_b[i]);
+            // aiu = a_i·q·(ρ^a3_pow for i = 3)·1000^b_i ; sign kept outside the log
+            FT l2_mag = l2_q + bi * c.l2_1000 + (i == 2 ? c.ch_a3_pow * l2_rho : FT(0));
+            const FT l2_den = M::log2(lam + c.ch_c1000[i]);     // log2(1/λ_inv + c)
+            const FT g1 = M::tgamma(bi + FT(1));
+            // k = 0: δ = 1;  k = 3: δ = 4, Γ(b+4) = (b+3)(b+2)(b+1)Γ(b+1), /3!
+            const FT e0 = M::exp2(l2_mag - l2_lam_inv - (bi + FT(1)) * l2_den);
+            const FT e3 = M::exp2(l2_mag - FT(4) * l2_lam_inv - (bi + FT(4)) * l2_den);
+            vt0 = M::fma(c.ch_a[i] * e0, g1, vt0);
+            vt3 = M::fma(c.ch_a[i] * e3, g1 * (bi + FT(3)) * (bi + FT(2)) * (bi + FT(1)) * FT(1.0 / 6.0), vt3);
+        }
+        r.vt_n = no_N_rai ? FT(0) : M::max(FT(0), vt0);
+        r.vt_m = no_q_rai ? FT(0) : M::max(FT(0), vt3);
+    }
+    return r;
+}
+
+}  // namespace cmx

@@ -1,0 +1,157 @@
+"""ctypes binding of the CPU oracle (oracle/libcmx_oracle.so).  TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
+module.  It reuses the ABI struct definitions of the product package
+(cloudmicrophysics.jl_amd/cmx/_abi.py ↔ include/cmx.h) — the oracle sees exactly
+the parameter bytes the device library sees — but nothing in the product imports
+anything from oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ORACLE_DIR = Path(__file__).resolve().parent
+REPO = ORACLE_DIR.parent
+sys.path.insert(0, str(REPO / "cloudmicrophysics.jl_amd"))
+from cmx import _abi  # noqa: E402
+
+LIB_PATH = ORACLE_DIR / "libcmx_oracle.so"
+_lib = None
+
+
+def build(force: bool = False):
+    """Compile the oracle with gcc (oracle/Makefile)."""
+    if force and LIB_PATH.exists():
+        LIB_PATH.unlink()
+    subprocess.run(["make", "-C", str(ORACLE_DIR)], check=True, capture_output=True)
+
+
+def _thresholds_type(fam):
+    return type(f"cmxo_thresholds_{fam.sfx}", (C.Structure,),
+                {"_fields_": [(n, fam.ft) for n in ("eps_m", "eps_n", "eps_1m", "eps_ft")]})
+
+
+TH = {"f32": _thresholds_type(_abi.F32), "f64": _thresholds_type(_abi.F64)}
+NP = {"f32": np.float32, "f64": np.float64}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            build()
+        _lib = C.CDLL(str(LIB_PATH))
+        for fam in (_abi.F32, _abi.F64):
+            s = fam.sfx
+            getattr(_lib, f"cmxo_psat_liquid_{s}").restype = fam.ft
+            getattr(_lib, f"cmxo_psat_liquid_{s}").argtypes = [C.POINTER(fam.thermo), fam.ft]
+            getattr(_lib, f"cmxo_psat_ice_{s}").restype = fam.ft
+            getattr(_lib, f"cmxo_psat_ice_{s}").argtypes = [C.POINTER(fam.thermo), fam.ft]
+            getattr(_lib, f"cmxo_gamma_incl_{s}").restype = fam.ft
+            getattr(_lib, f"cmxo_gamma_incl_{s}").argtypes = [fam.ft, fam.ft]
+    return _lib
+
+
+def thresholds(fam, float32_gates: bool):
+    """eps(FT)/cbrt(floatmin(FT)) gates (src/Utilities.jl:318-340) of Float32 or Float64, stored as fam.ft."""
+    th = TH[fam.sfx]()
+    getattr(lib(), f"cmxo_default_thresholds_{fam.sfx}")(C.byref(th), int(float32_gates))
+    return th
+
+
+def _col(fam, a):
+    a = np.ascontiguousarray(a, dtype=NP[fam.sfx])
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def sb2006_warm_rain_tendencies(fam, wr, tps, vel, flags, rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, *,
+                                float32_gates=None, nthreads=1, want_scale=True, branch_margin=1e-5):
+    """Oracle twin of cmx_sb2006_warm_rain_tendencies_*: numpy in → dict of numpy columns.
+
+    `fam` selects the ARITHMETIC (F64 = the reference's Float64 path); `float32_gates`
+    the THRESHOLDS (default: those of `fam`).  `scale[k]` = Σ|cancelling terms| of output k;
+    `near_branch` marks points within `branch_margin` (relative) of the Φ_br jump (CM2:596)."""
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    ins = [_col(fam, a) for a in (rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai)]
+    n = ins[0][0].size
+    names = ["dq_lcl_dt", "dn_lcl_dt", "dq_rai_dt", "dn_rai_dt", "vt_rai_n", "vt_rai_m"]
+    outs = {k: np.empty(n, dtype=NP[fam.sfx]) for k in names}
+    scale = [np.empty(n, dtype=NP[fam.sfx]) for _ in range(6)] if want_scale else None
+    scale_arr = (C.c_void_p * 6)(*[s.ctypes.data for s in scale]) if want_scale else None
+    near = np.zeros(n, dtype=np.uint8) if want_scale else None
+    fn = getattr(lib(), f"cmxo_sb2006_warm_rain_tendencies_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(wr), C.byref(tps), C.byref(vel) if vel is not None else None, C.c_uint32(flags), C.byref(th),
+       C.c_int64(n), *[p for _, p in ins], *[outs[k].ctypes.data_as(C.c_void_p) for k in names],
+       scale_arr, near.ctypes.data_as(C.c_void_p) if want_scale else None, fam.ft(branch_margin),
+       C.c_int32(nthreads))
+    if want_scale:
+        outs["scale"] = dict(zip(names, scale))
+        outs["near_branch"] = near.astype(bool)
+    return outs
+
+
+def sb2006_process_rates(fam, wr, tps, vel, flags, q_tot, q_lcl, q_rai, N_lcl, N_rai, rho, T, *, float32_gates=None):
+    """Oracle twin of cmx_sb2006_process_rates_* (SB2006_2M_kernel, test/gpu_tests.jl:220-235)."""
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    ins = [_col(fam, a) for a in (q_tot, q_lcl, q_rai, N_lcl, N_rai, rho, T)]
+    n = ins[0][0].size
+    outs = [np.empty(n, dtype=NP[fam.sfx]) for _ in range(_abi.CMX_SB2006_NPROC)]
+    arr = (C.c_void_p * _abi.CMX_SB2006_NPROC)(*[o.ctypes.data for o in outs])
+    fn = getattr(lib(), f"cmxo_sb2006_process_rates_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(wr), C.byref(tps), C.byref(vel) if vel is not None else None, C.c_uint32(flags), C.byref(th),
+       C.c_int64(n), *[p for _, p in ins], arr)
+    return dict(zip(_abi.SB2006_PROCESS_COLUMNS, outs))
+
+
+def psat_liquid(fam, tps, T):
+    return getattr(lib(), f"cmxo_psat_liquid_{fam.sfx}")(C.byref(tps), T)
+
+
+def psat_ice(fam, tps, T):
+    return getattr(lib(), f"cmxo_psat_ice_{fam.sfx}")(C.byref(tps), T)
+
+
+def gamma_incl(fam, a, x):
+    return getattr(lib(), f"cmxo_gamma_incl_{fam.sfx}")(a, x)
+
+
+def pdf_rain_parameters(fam, pdf_r, limited, q, rho, N, float32_gates=None):
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    out = (fam.ft * 3)()
+    fn = getattr(lib(), f"cmxo_pdf_rain_parameters_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(pdf_r), C.c_int(int(limited)), fam.ft(q), fam.ft(rho), fam.ft(N), C.byref(th), out)
+    return dict(N0r=out[0], Dr_mean=out[1], xr_mean=out[2])
+
+
+def cloud_terminal_velocity(fam, pdf_c, rho_w, grav, nu_air, q_liq, rho, N_liq, float32_gates=None):
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    out = (fam.ft * 2)()
+    fn = getattr(lib(), f"cmxo_cloud_terminal_velocity_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(pdf_c), fam.ft(rho_w), fam.ft(grav), fam.ft(nu_air), fam.ft(q_liq), fam.ft(rho), fam.ft(N_liq),
+       C.byref(th), out)
+    return out[0], out[1]
+
+
+def chen2022_rain_coeffs(fam, chen, rho):
+    out = (fam.ft * 9)()
+    fn = getattr(lib(), f"cmxo_chen2022_rain_coeffs_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(chen), fam.ft(rho), out)
+    return list(out[0:3]), list(out[3:6]), list(out[6:9])
