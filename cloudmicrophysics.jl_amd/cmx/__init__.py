@@ -7,7 +7,7 @@ Host-side mirror of the reference's module layout for the hot path:
   cmx.sharding          ↔ (no reference equivalent) one-process-per-GPU sharding + RCCL diagnostic sums
 All compute goes through libcmx.so (include/cmx.h); there is no CPU fallback.
 """
-from . import _abi, parameters  # noqa: F401
+from . import _abi, parameters, sharding, synthetic  # noqa: F401
 from ._lib import CmxLibraryError, CmxStatusError  # noqa: F401
 from .bulk_tendencies import (Chen2022VelTypeRain, Microphysics2Moment, SB2006ProcessRates,  # noqa: F401
                               SB2006VelType, WarmRainTendencies2M, bulk_microphysics_tendencies,

@@ -1,0 +1,106 @@
+"""CPU tests of the boundary: libcmx.so loads and exports every symbol include/cmx.h declares; the
+ctypes struct mirror matches the C layout; argument validation returns the documented status codes
+(no compute call is made without a GPU)."""
+import ctypes as C
+import re
+import subprocess
+from pathlib import Path
+
+import pytest
+
+from cmx import _abi, _lib
+from cmx import parameters as P
+
+REPO = Path(__file__).resolve().parent.parent
+HEADER = (REPO / "include" / "cmx.h").read_text()
+
+
+def declared_symbols():
+    # function declarations: `int32_t cmx_xxx(` or `const char *cmx_xxx(` at the start of a line
+    return sorted(set(re.findall(r"^(?:int32_t|const char \*)\s*(cmx_\w+)\s*\(", HEADER, flags=re.M)))
+
+
+def test_header_declares_the_hot_path():
+    syms = declared_symbols()
+    for s in ("cmx_sb2006_warm_rain_tendencies_f32", "cmx_sb2006_warm_rain_tendencies_f64",
+              "cmx_sb2006_process_rates_f32", "cmx_sb2006_process_rates_f64", "cmx_version"):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.lib()
+    for s in declared_symbols():
+        assert hasattr(lib, s), f"libcmx.so does not export {s}"
+    assert lib.cmx_version() == (0 << 16) | 1
+    assert lib.cmx_last_hip_error() == b""
+
+
+def test_struct_layout_matches_c(tmp_path):
+    """sizeof/offsetof from a C translation unit that includes the real header vs the ctypes mirror."""
+    probes = []
+    for fam in (_abi.F32, _abi.F64):
+        for name in ("cloud_pdf_sb2006", "rain_pdf_sb2006", "acnv_sb2006", "accr_sb2006", "selfcol_sb2006",
+                     "breakup_sb2006", "evap_sb2006", "numadj_horn2012", "sb2006", "air_properties", "warm_rain_2m",
+                     "thermo", "sb2006_vel", "chen2022_rain_vel", "rain_vel"):
+            st = getattr(fam, name)
+            probes.append((f"cmx_{name}_{fam.sfx}", st))
+    src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{REPO}/include/cmx.h"', "int main(void){"]
+    for cname, st in probes:
+        src.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in st._fields_:
+            src.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    src.append(f'printf("NPROC %d\\n", (int)CMX_SB2006_NPROC);')
+    src.append("return 0;}")
+    c = tmp_path / "probe.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-o", str(exe), str(c)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, st in probes:
+        assert int(out[cname]) == C.sizeof(st), cname
+        for fname, _ in st._fields_:
+            assert int(out[f"{cname}.{fname}"]) == getattr(st, fname).offset, f"{cname}.{fname}"
+    assert int(out["NPROC"]) == _abi.CMX_SB2006_NPROC
+    # Julia layout: 45 FT in SB2006 (limited), 50 in WarmRainParams2M
+    assert C.sizeof(_abi.F32.sb2006) == 45 * 4 and C.sizeof(_abi.F64.warm_rain_2m) == 50 * 8
+
+
+def test_argument_validation_without_gpu():
+    lib = _lib.lib()
+    wr, tps = P.WarmRainParams2M("f32"), P.ThermodynamicsParameters("f32")
+    f = lib.cmx_sb2006_warm_rain_tendencies_f32
+    null = [None] * 13
+    assert f(None, C.byref(tps), None, 1, 10, *null, None) == _abi.CMX_ERR_BAD_ARG
+    assert f(C.byref(wr.c), C.byref(tps), None, 1, -1, *null, None) == _abi.CMX_ERR_BAD_ARG
+    assert f(C.byref(wr.c), C.byref(tps), None, 1, 10, *null, None) == _abi.CMX_ERR_BAD_ARG   # null columns
+    assert f(C.byref(wr.c), C.byref(tps), None, 1, 0, *null, None) == _abi.CMX_OK            # empty input
+    g = lib.cmx_column_sums_f64
+    assert g(-1, None, 0, None, None) == _abi.CMX_ERR_BAD_ARG
+    assert g(0, None, 0, None, None) == _abi.CMX_OK
+
+
+def test_product_never_imports_the_oracle():
+    """The product package must not reference oracle/ (a CPU fallback would void parity claims)."""
+    for p in (REPO / "cloudmicrophysics.jl_amd").rglob("*"):
+        if p.suffix in (".py", ".hip", ".hpp", ".h", ".cpp") and p.is_file():
+            txt = p.read_text()
+            assert "oracle_binding" not in txt and "libcmx_oracle" not in txt and "cmxo_" not in txt, p
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(_lib.CmxLibraryError):
+        _lib.lib()
+
+
+def test_parameter_defaults_and_overrides():
+    sb = P.SB2006("f64")
+    assert sb.acnv.x_star == sb.pdf_r.xr_min == sb.pdf_c.xc_max == 2.6e-10     # one ClimaParams key, three fields
+    td = P.create_toml_dict("f64", P.SB2006_LIMITERS_OVERRIDE)
+    sb2 = P.SB2006(td)
+    assert sb2.acnv.x_star == sb2.pdf_r.xr_min == sb2.pdf_c.xc_max == 6.54e-11 and sb2.pdf_r.N0_max == 2e11
+    with pytest.raises(KeyError):
+        P.create_toml_dict("f64", {"not_a_parameter": 1.0})
+    with pytest.raises(NotImplementedError):
+        P.Microphysics2MParams("f32", with_ice=True)
