@@ -62,13 +62,19 @@ def cpu_baseline(args, state_cpu_sample):
     t0 = time.perf_counter()
     run(probe)
     rate = probe / (time.perf_counter() - t0)
-    m = int(min(cols[0].size, max(probe, rate * args.cpu_seconds)))
-    t0 = time.perf_counter()
-    run(m)
-    dt = time.perf_counter() - t0
-    return {"value": m / dt, "unit": "grid-points/s", "cores": cores, "kind": "port",
-            "sample": f"{m} of the same synthetic points, {args.dtype} arithmetic, oracle/libcmx_oracle.so "
-                      f"(gcc -O2, OpenMP {cores} threads), {dt:.1f} s"}
+    m = cols[0].size
+    run(m)                                         # first full pass: page in, spin up the thread team
+    passes, t0 = 0, time.perf_counter()
+    while True:
+        run(m)
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= args.cpu_seconds or passes >= 1000:
+            break
+    return {"value": passes * m / dt, "unit": "grid-points/s", "cores": cores, "kind": "port",
+            "sample": f"{passes} passes over {m} of the same synthetic points ({passes * m} point evaluations), "
+                      f"{args.dtype} arithmetic, oracle/libcmx_oracle.so (gcc -O2, OpenMP {cores} threads), {dt:.1f} s; "
+                      f"probe rate {rate:.3g}/s"}
 
 
 def main():

@@ -50,22 +50,26 @@ template <> struct VecT<float, 1> { using type = float; };
 template <> struct VecT<double, 2> { using type = f64x2_t; };   // 16 B / lane as well
 template <> struct VecT<double, 1> { using type = double; };
 
-template <typename FT, int VEC>
+// NT = non-temporal hint: every byte of a state column is touched exactly once per sweep.
+template <typename FT, int VEC, bool NT = true>
 __device__ __forceinline__ void load_col(const FT *__restrict__ p, int64_t i, FT (&x)[VEC]) {
     using V = typename VecT<FT, VEC>::type;
-    const V v = __builtin_nontemporal_load(reinterpret_cast<const V *>(p) + i);
+    V v;
+    if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const V *>(p) + i);
+    else v = reinterpret_cast<const V *>(p)[i];
     const FT *e = reinterpret_cast<const FT *>(&v);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) x[k] = e[k];
 }
-template <typename FT, int VEC>
+template <typename FT, int VEC, bool NT = true>
 __device__ __forceinline__ void store_col(FT *__restrict__ p, int64_t i, const FT (&x)[VEC]) {
     using V = typename VecT<FT, VEC>::type;
     V v;
     FT *e = reinterpret_cast<FT *>(&v);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) e[k] = x[k];
-    __builtin_nontemporal_store(v, reinterpret_cast<V *>(p) + i);
+    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<V *>(p) + i);
+    else reinterpret_cast<V *>(p)[i] = v;
 }
 
 }  // namespace cmx

@@ -1,103 +1,13 @@
-// cmx_sb2006_kernels.hip — fused SB2006 warm-rain kernels for gfx950 and their C-ABI entry points.
-//
-// Kernel shape: pointwise map over structure-of-arrays state columns, HBM-bound.
-// One lane owns VEC consecutive points (VEC·sizeof(FT) = 16 B), so each of the 7 input columns is
-// read with one global_load_dwordx4 per lane (1 KiB per wave-instruction, fully coalesced) and each
-// of the 4–6 output columns written with one global_store_dwordx4; loads and stores carry the
-// non-temporal hint (every byte is touched exactly once).  256-thread workgroups, grid-stride over
-// CUs × k workgroups.  No LDS, no MFMA: there is no data reuse and no contraction on this path.
+// cmx_sb2006_kernels.hip — C-ABI entry points (include/cmx.h) of the fused SB2006 warm-rain kernels:
+// argument validation, host-side constant folding, alignment dispatch, launches.
 #include <hip/hip_runtime.h>
 
-#include "cmx_launch.hpp"
-#include "cmx_sb2006.hpp"
+#include <algorithm>
+#include <type_traits>
+
+#include "cmx_sb2006_kernels.hpp"
 
 namespace cmx {
-
-template <typename FT> struct SbIn { const FT *rho, *T, *q_tot, *q_lcl, *n_lcl, *q_rai, *n_rai; };
-template <typename FT> struct SbOut { FT *dq_lcl, *dn_lcl, *dq_rai, *dn_rai, *vt_n, *vt_m; };
-template <typename FT> struct SbProcOut { FT *col[CMX_SB2006_NPROC]; };
-
-// bulk_microphysics_tendencies(::Microphysics2Moment, …) over columns — BMT:820-854 + :707-782
-template <typename FT, bool LIMITED, int VEL, int VEC>
-__global__ __launch_bounds__(kBlock) void sb2006_tendencies_kernel(const SbConsts<FT> c, const SbIn<FT> in,
-                                                                   const SbOut<FT> out, const int64_t nvec) {
-    using M = Math<FT>;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
-        FT rho[VEC], T[VEC], q_tot[VEC], q_lcl[VEC], n_lcl[VEC], q_rai[VEC], n_rai[VEC];
-        load_col<FT, VEC>(in.rho, i, rho);
-        load_col<FT, VEC>(in.T, i, T);
-        load_col<FT, VEC>(in.q_tot, i, q_tot);
-        load_col<FT, VEC>(in.q_lcl, i, q_lcl);
-        load_col<FT, VEC>(in.n_lcl, i, n_lcl);
-        load_col<FT, VEC>(in.q_rai, i, q_rai);
-        load_col<FT, VEC>(in.n_rai, i, n_rai);
-        FT dq_lcl[VEC], dn_lcl[VEC], dq_rai[VEC], dn_rai[VEC], vt_n[VEC], vt_m[VEC];
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            // clamp_to_nonneg — BMT:828-837 (T is not clamped)
-            const FT r_ = M::max(FT(0), rho[k]);
-            const FT qt = M::max(FT(0), q_tot[k]);
-            const FT ql = M::max(FT(0), q_lcl[k]);
-            const FT qr = M::max(FT(0), q_rai[k]);
-            const FT nl = M::max(FT(0), n_lcl[k]);
-            const FT nr = M::max(FT(0), n_rai[k]);
-            // N = ρ n — BMT:718-719
-            const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL>(c, r_, T[k], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
-            // accumulation order of warm_rain_tendencies_2m — BMT:738-779
-            dq_lcl[k] = (p.cond + p.au_dq_lcl) + p.ac_dq_lcl;
-            dn_lcl[k] = ((p.au_dN_lcl * p.inv_rho + p.lsc * p.inv_rho) + p.ac_dN_lcl * p.inv_rho) + p.na_lcl;
-            dq_rai[k] = (p.evq + p.au_dq_rai) + p.ac_dq_rai;
-            dn_rai[k] = (((p.evN * p.inv_rho + p.au_dN_rai * p.inv_rho) + p.rsc * p.inv_rho) + p.rbr * p.inv_rho) + p.na_rai;
-            vt_n[k] = p.vt_n;
-            vt_m[k] = p.vt_m;
-        }
-        store_col<FT, VEC>(out.dq_lcl, i, dq_lcl);
-        store_col<FT, VEC>(out.dn_lcl, i, dn_lcl);
-        store_col<FT, VEC>(out.dq_rai, i, dq_rai);
-        store_col<FT, VEC>(out.dn_rai, i, dn_rai);
-        if constexpr (VEL != VEL_NONE) {
-            if (out.vt_n) store_col<FT, VEC>(out.vt_n, i, vt_n);
-            if (out.vt_m) store_col<FT, VEC>(out.vt_m, i, vt_m);
-        }
-    }
-}
-
-// SB2006_2M_kernel (test/gpu_tests.jl:220-235): the individual process rates, N per m³, no clamping
-template <typename FT, bool LIMITED, int VEL>
-__global__ __launch_bounds__(kBlock) void sb2006_process_kernel(const SbConsts<FT> c, const FT *__restrict__ q_tot,
-                                                                const FT *__restrict__ q_lcl, const FT *__restrict__ q_rai,
-                                                                const FT *__restrict__ N_lcl, const FT *__restrict__ N_rai,
-                                                                const FT *__restrict__ rho, const FT *__restrict__ T,
-                                                                const SbProcOut<FT> out, const int64_t n) {
-    using M = Math<FT>;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const FT r_ = rho[i];
-        const FT inv_r = M::rcp(r_);
-        const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL>(c, r_, T[i], q_tot[i], q_lcl[i], q_rai[i], N_lcl[i],
-                                                             N_rai[i], N_lcl[i] * inv_r, N_rai[i] * inv_r);
-#define CMX_PUT(colid, v) if (out.col[colid]) out.col[colid][i] = (v)
-        CMX_PUT(CMX_SB_ACNV_DQ_LCL, p.au_dq_lcl);
-        CMX_PUT(CMX_SB_ACNV_DN_LCL, p.au_dN_lcl);
-        CMX_PUT(CMX_SB_ACNV_DQ_RAI, p.au_dq_rai);
-        CMX_PUT(CMX_SB_ACNV_DN_RAI, p.au_dN_rai);
-        CMX_PUT(CMX_SB_LCL_SELFCOL, p.lsc);
-        CMX_PUT(CMX_SB_ACCR_DQ_LCL, p.ac_dq_lcl);
-        CMX_PUT(CMX_SB_ACCR_DN_LCL, p.ac_dN_lcl);
-        CMX_PUT(CMX_SB_ACCR_DQ_RAI, p.ac_dq_rai);
-        CMX_PUT(CMX_SB_RAI_SELFCOL, p.rsc);
-        CMX_PUT(CMX_SB_RAI_BREAKUP, p.rbr);
-        CMX_PUT(CMX_SB_RAI_VEL_N, p.vt_n);
-        CMX_PUT(CMX_SB_RAI_VEL_M, p.vt_m);
-        CMX_PUT(CMX_SB_EVAP_DN_RAI, p.evN);
-        CMX_PUT(CMX_SB_EVAP_DQ_RAI, p.evq);
-        CMX_PUT(CMX_SB_NUMADJ_RAI, p.na_rai);
-        CMX_PUT(CMX_SB_NUMADJ_LCL, p.na_lcl);
-        CMX_PUT(CMX_SB_CONDEVAP, p.cond);
-#undef CMX_PUT
-    }
-}
 
 // ---- host side -----------------------------------------------------------------------------
 static int decode_vel(uint32_t flags, bool want) {
@@ -141,21 +51,32 @@ static int32_t tendencies_entry(const WR *wr, const TH *tps, const VL *vel, uint
     const SbConsts<FT> c = make_sb_consts<FT>(*wr, *tps, vel, (double)Math<FT>::eps_1m());
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     constexpr int VEC = Math<FT>::VEC;
+    // Alignment dispatch.  The 16-byte body needs every column at the same offset modulo 16 B (true for
+    // any common slice [lo:hi] of aligned columns): `head` points are peeled so the body starts aligned,
+    // the body runs VEC points per lane, the ragged tail one point per lane.  Columns with mixed
+    // misalignment take the one-point-per-lane kernel throughout.  All three compute the identical
+    // instruction sequence per point (-ffp-contract=off), so results do not depend on alignment.
     const void *ptrs[] = {rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, dq_lcl, dn_lcl, dq_rai, dn_rai, vt_n, vt_m};
-    bool vec_ok = true;
-    for (const void *p : ptrs) vec_ok = vec_ok && aligned16(p);
-    const int64_t nvec = vec_ok ? n / VEC : 0;
-    if (nvec > 0) {
-        SbIn<FT> in{rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai};
-        SbOut<FT> out{dq_lcl, dn_lcl, dq_rai, dn_rai, vt_n, vt_m};
-        launch_tendencies<FT, VEC>(limited, velk, c, in, out, nvec, s);
-    }
-    const int64_t done = nvec * VEC;
-    if (done < n) {   // unaligned columns, or the n % VEC tail: one point per lane
-        SbIn<FT> in{rho + done, T + done, q_tot + done, q_lcl + done, n_lcl + done, q_rai + done, n_rai + done};
-        SbOut<FT> out{dq_lcl + done, dn_lcl + done, dq_rai + done, dn_rai + done, vt_n ? vt_n + done : nullptr,
-                      vt_m ? vt_m + done : nullptr};
-        launch_tendencies<FT, 1>(limited, velk, c, in, out, n - done, s);
+    const uintptr_t mis0 = reinterpret_cast<uintptr_t>(rho) & 15u;
+    bool same_mis = (mis0 % sizeof(FT)) == 0;
+    for (const void *p : ptrs)
+        if (p) same_mis = same_mis && ((reinterpret_cast<uintptr_t>(p) & 15u) == mis0);
+    auto launch_range = [&](auto vec_tag, int64_t lo, int64_t count) {
+        constexpr int V = decltype(vec_tag)::value;
+        if (count <= 0) return;
+        SbIn<FT> in{rho + lo, T + lo, q_tot + lo, q_lcl + lo, n_lcl + lo, q_rai + lo, n_rai + lo};
+        SbOut<FT> out{dq_lcl + lo, dn_lcl + lo, dq_rai + lo, dn_rai + lo, vt_n ? vt_n + lo : nullptr,
+                      vt_m ? vt_m + lo : nullptr};
+        launch_tendencies<FT, V>(limited, velk, c, in, out, count / V, s);
+    };
+    if (same_mis) {
+        const int64_t head = std::min<int64_t>(n, mis0 ? (int64_t)((16 - mis0) / sizeof(FT)) : 0);
+        const int64_t body = ((n - head) / VEC) * VEC;
+        launch_range(std::integral_constant<int, 1>{}, 0, head);
+        launch_range(std::integral_constant<int, VEC>{}, head, body);
+        launch_range(std::integral_constant<int, 1>{}, head + body, n - head - body);
+    } else {
+        launch_range(std::integral_constant<int, 1>{}, 0, n);
     }
     CMX_HIP_TRY(hipGetLastError());
     return CMX_OK;

@@ -1,0 +1,104 @@
+// cmx_sb2006_kernels.hpp — the fused SB2006 warm-rain device kernels (templates), shared by the C-ABI
+// translation unit (cmx_sb2006_kernels.hip) and the roofline probe (tools/sb2006_probe.hip).
+//
+// Kernel shape: pointwise map over structure-of-arrays state columns, HBM-bound.
+// One lane owns VEC consecutive points (VEC·sizeof(FT) = 16 B), so each of the 7 input columns is
+// read with one global_load_dwordx4 per lane (1 KiB per wave-instruction, fully coalesced) and each
+// of the 4–6 output columns written with one global_store_dwordx4; loads and stores carry the
+// non-temporal hint (every byte is touched exactly once).  256-thread workgroups, grid-stride over
+// CUs × k workgroups.  No LDS, no MFMA: there is no data reuse and no contraction on this path.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "cmx_launch.hpp"
+#include "cmx_sb2006.hpp"
+
+namespace cmx {
+
+template <typename FT> struct SbIn { const FT *rho, *T, *q_tot, *q_lcl, *n_lcl, *q_rai, *n_rai; };
+template <typename FT> struct SbOut { FT *dq_lcl, *dn_lcl, *dq_rai, *dn_rai, *vt_n, *vt_m; };
+template <typename FT> struct SbProcOut { FT *col[CMX_SB2006_NPROC]; };
+
+// bulk_microphysics_tendencies(::Microphysics2Moment, …) over columns — BMT:820-854 + :707-782
+template <typename FT, bool LIMITED, int VEL, int VEC, bool NT = true>
+__global__ __launch_bounds__(kBlock) void sb2006_tendencies_kernel(const SbConsts<FT> c, const SbIn<FT> in,
+                                                                   const SbOut<FT> out, const int64_t nvec) {
+    using M = Math<FT>;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+        FT rho[VEC], T[VEC], q_tot[VEC], q_lcl[VEC], n_lcl[VEC], q_rai[VEC], n_rai[VEC];
+        load_col<FT, VEC, NT>(in.rho, i, rho);
+        load_col<FT, VEC, NT>(in.T, i, T);
+        load_col<FT, VEC, NT>(in.q_tot, i, q_tot);
+        load_col<FT, VEC, NT>(in.q_lcl, i, q_lcl);
+        load_col<FT, VEC, NT>(in.n_lcl, i, n_lcl);
+        load_col<FT, VEC, NT>(in.q_rai, i, q_rai);
+        load_col<FT, VEC, NT>(in.n_rai, i, n_rai);
+        FT dq_lcl[VEC], dn_lcl[VEC], dq_rai[VEC], dn_rai[VEC], vt_n[VEC], vt_m[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            // clamp_to_nonneg — BMT:828-837 (T is not clamped)
+            const FT r_ = M::max(FT(0), rho[k]);
+            const FT qt = M::max(FT(0), q_tot[k]);
+            const FT ql = M::max(FT(0), q_lcl[k]);
+            const FT qr = M::max(FT(0), q_rai[k]);
+            const FT nl = M::max(FT(0), n_lcl[k]);
+            const FT nr = M::max(FT(0), n_rai[k]);
+            // N = ρ n — BMT:718-719
+            const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL>(c, r_, T[k], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
+            // accumulation order of warm_rain_tendencies_2m — BMT:738-779
+            dq_lcl[k] = (p.cond + p.au_dq_lcl) + p.ac_dq_lcl;
+            dn_lcl[k] = ((p.au_dN_lcl * p.inv_rho + p.lsc * p.inv_rho) + p.ac_dN_lcl * p.inv_rho) + p.na_lcl;
+            dq_rai[k] = (p.evq + p.au_dq_rai) + p.ac_dq_rai;
+            dn_rai[k] = (((p.evN * p.inv_rho + p.au_dN_rai * p.inv_rho) + p.rsc * p.inv_rho) + p.rbr * p.inv_rho) + p.na_rai;
+            vt_n[k] = p.vt_n;
+            vt_m[k] = p.vt_m;
+        }
+        store_col<FT, VEC, NT>(out.dq_lcl, i, dq_lcl);
+        store_col<FT, VEC, NT>(out.dn_lcl, i, dn_lcl);
+        store_col<FT, VEC, NT>(out.dq_rai, i, dq_rai);
+        store_col<FT, VEC, NT>(out.dn_rai, i, dn_rai);
+        if constexpr (VEL != VEL_NONE) {
+            if (out.vt_n) store_col<FT, VEC, NT>(out.vt_n, i, vt_n);
+            if (out.vt_m) store_col<FT, VEC, NT>(out.vt_m, i, vt_m);
+        }
+    }
+}
+
+// SB2006_2M_kernel (test/gpu_tests.jl:220-235): the individual process rates, N per m³, no clamping
+template <typename FT, bool LIMITED, int VEL>
+__global__ __launch_bounds__(kBlock) void sb2006_process_kernel(const SbConsts<FT> c, const FT *__restrict__ q_tot,
+                                                                const FT *__restrict__ q_lcl, const FT *__restrict__ q_rai,
+                                                                const FT *__restrict__ N_lcl, const FT *__restrict__ N_rai,
+                                                                const FT *__restrict__ rho, const FT *__restrict__ T,
+                                                                const SbProcOut<FT> out, const int64_t n) {
+    using M = Math<FT>;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const FT r_ = rho[i];
+        const FT inv_r = M::rcp(r_);
+        const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL>(c, r_, T[i], q_tot[i], q_lcl[i], q_rai[i], N_lcl[i],
+                                                             N_rai[i], N_lcl[i] * inv_r, N_rai[i] * inv_r);
+#define CMX_PUT(colid, v) if (out.col[colid]) out.col[colid][i] = (v)
+        CMX_PUT(CMX_SB_ACNV_DQ_LCL, p.au_dq_lcl);
+        CMX_PUT(CMX_SB_ACNV_DN_LCL, p.au_dN_lcl);
+        CMX_PUT(CMX_SB_ACNV_DQ_RAI, p.au_dq_rai);
+        CMX_PUT(CMX_SB_ACNV_DN_RAI, p.au_dN_rai);
+        CMX_PUT(CMX_SB_LCL_SELFCOL, p.lsc);
+        CMX_PUT(CMX_SB_ACCR_DQ_LCL, p.ac_dq_lcl);
+        CMX_PUT(CMX_SB_ACCR_DN_LCL, p.ac_dN_lcl);
+        CMX_PUT(CMX_SB_ACCR_DQ_RAI, p.ac_dq_rai);
+        CMX_PUT(CMX_SB_RAI_SELFCOL, p.rsc);
+        CMX_PUT(CMX_SB_RAI_BREAKUP, p.rbr);
+        CMX_PUT(CMX_SB_RAI_VEL_N, p.vt_n);
+        CMX_PUT(CMX_SB_RAI_VEL_M, p.vt_m);
+        CMX_PUT(CMX_SB_EVAP_DN_RAI, p.evN);
+        CMX_PUT(CMX_SB_EVAP_DQ_RAI, p.evq);
+        CMX_PUT(CMX_SB_NUMADJ_RAI, p.na_rai);
+        CMX_PUT(CMX_SB_NUMADJ_LCL, p.na_lcl);
+        CMX_PUT(CMX_SB_CONDEVAP, p.cond);
+#undef CMX_PUT
+    }
+}
+
+}  // namespace cmx

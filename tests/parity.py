@@ -16,13 +16,20 @@ separately (they are counted and must stay a vanishing fraction).
 import numpy as np
 
 RTOL = {"f32": 1e-3, "f64": 1e-6}
+# magnitudes below this are "zero" for the kernel's float type (≈ floatmin(FT) with headroom for one product):
+# the hardware transcendental units flush subnormals, the reference's CPU arithmetic keeps them.
+FLOOR = {"f32": 1e-30, "f64": 1e-290}
+# …and magnitudes above this overflow the kernel's float type (exp(κbr ΔD) of a 20-cm "mean raindrop" in the
+# not-limited PSD is 1e197 in Float64 and Inf in Float32, in the reference's Float32 path too): an infinity of
+# the right sign is then the correct Float32 answer.
+CEIL = {"f32": 1e30, "f64": 1e300}
 OUT_NAMES = ["dq_lcl_dt", "dn_lcl_dt", "dq_rai_dt", "dn_rai_dt", "vt_rai_n", "vt_rai_m"]
 
 
-def scaled_err(x, ref, scale=None):
+def scaled_err(x, ref, scale=None, floor=0.0, ceil=np.inf):
     x = np.asarray(x, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
-    den = np.abs(ref)
+    den = np.maximum(np.abs(ref), floor)
     if scale is not None:
         den = np.maximum(den, np.asarray(scale, dtype=np.float64))
     both_zero = (x == 0) & (ref == 0)
@@ -31,18 +38,22 @@ def scaled_err(x, ref, scale=None):
     e = np.where(both_zero, 0.0, e)
     # identical non-finite values (inf == inf, nan ↔ nan) count as equal
     same_nonfinite = (~np.isfinite(x)) & (~np.isfinite(ref)) & ((x == ref) | (np.isnan(x) & np.isnan(ref)))
-    return np.where(same_nonfinite, 0.0, e)
+    overflow_ok = (np.abs(ref) > ceil) & np.isinf(x) & (np.sign(x) == np.sign(ref))
+    return np.where(same_nonfinite | overflow_ok, 0.0, e)
 
 
-def assert_parity(got: dict, ref: dict, rtol: float, names=OUT_NAMES, what=""):
+def assert_parity(got: dict, ref: dict, rtol: float, names=OUT_NAMES, what="", floor=None):
     """got/ref: name → array; ref carries 'scale' (name → array) and 'near_branch' (bool mask)."""
     near = ref.get("near_branch")
     keep = ~near if near is not None else slice(None)
     report = {}
+    if floor is None:
+        floor = FLOOR["f32"] if rtol >= 1e-4 else FLOOR["f64"]
+    ceil = CEIL["f32"] if rtol >= 1e-4 else CEIL["f64"]
     for k in names:
         if got.get(k) is None:
             continue
-        e = scaled_err(got[k], ref[k], ref.get("scale", {}).get(k))
+        e = scaled_err(got[k], ref[k], ref.get("scale", {}).get(k), floor, ceil)
         e = np.nan_to_num(e, nan=np.inf)
         worst = float(np.max(e[keep])) if e[keep].size else 0.0
         report[k] = worst

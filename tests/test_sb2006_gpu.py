@@ -181,7 +181,7 @@ def test_process_rates_match_oracle(dev, oracle, ft, limited):
         if k in ("numadj_rai", "numadj_lcl"):   # (n_target − n)/τ cancels when the clamp is inactive
             nn = (n_rai if k.endswith("rai") else n_lcl).numpy().astype(np.float64)
             scale = 2 * np.abs(nn) / 100.0
-        e = parity.scaled_err(got, ref[k], scale)[keep]
+        e = parity.scaled_err(got, ref[k], scale, parity.FLOOR[ft])[keep]
         worst[k] = float(np.nanmax(e))
         assert worst[k] <= tol, (k, worst[k])
     print(f"\n[process parity] {ft} limited={limited}: {worst}")
@@ -232,7 +232,7 @@ def test_degenerate_states(dev, oracle, ft):
         got = _np(_run_fused(ft, limited, "sb", [c.to(dev) for c in cols]))
         ref = _oracle_fused(oracle, ft, limited, "sb", [c.numpy() for c in cols])
         for k in parity.OUT_NAMES:
-            assert np.all(np.isfinite(got[k])), k
+            assert np.all(np.isfinite(got[k]) | (np.abs(ref[k]) > parity.CEIL[ft])), k
         parity.assert_parity(got, ref, parity.RTOL[ft], what=f"degenerate limited={limited}")
         zero_rain = (arr[5] < eps)
         assert np.all(got["vt_rai_m"][zero_rain] == 0) and np.all(got["dq_rai_dt"][zero_rain & (arr[3] < eps)] == 0)
