@@ -17,12 +17,16 @@ static int decode_vel(uint32_t flags, bool want) {
     return sb ? VEL_SB : VEL_CHEN;
 }
 
+constexpr int kTendBS = 256;
+
 template <typename FT, int VEC>
 static void launch_tendencies(bool limited, int vel, const SbConsts<FT> &c, const SbIn<FT> &in, const SbOut<FT> &out,
                               int64_t nvec, hipStream_t s) {
-    const int grid = grid_for(nvec);
-#define CMX_LAUNCH(L, V) \
-    hipLaunchKernelGGL((sb2006_tendencies_kernel<FT, L, V, VEC>), dim3(grid), dim3(kBlock), 0, s, c, in, out, nvec)
+    // one short-lived workgroup per tile of kTendBS lanes (see the kernel's header comment)
+    const int64_t grid = (nvec + kTendBS - 1) / kTendBS;
+#define CMX_LAUNCH(L, V)                                                                                              \
+    hipLaunchKernelGGL((sb2006_tendencies_kernel<FT, L, V, VEC, kTendBS>), dim3((unsigned)grid), dim3(kTendBS), 0, s, c, in, \
+                       out, nvec)
     if (limited) {
         if (vel == VEL_NONE) CMX_LAUNCH(true, VEL_NONE);
         else if (vel == VEL_SB) CMX_LAUNCH(true, VEL_SB);

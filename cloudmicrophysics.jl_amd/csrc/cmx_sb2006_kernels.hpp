@@ -20,32 +20,47 @@ template <typename FT> struct SbOut { FT *dq_lcl, *dn_lcl, *dq_rai, *dn_rai, *vt
 template <typename FT> struct SbProcOut { FT *col[CMX_SB2006_NPROC]; };
 
 // bulk_microphysics_tendencies(::Microphysics2Moment, …) over columns — BMT:820-854 + :707-782
-template <typename FT, bool LIMITED, int VEL, int VEC, bool NT = true>
-__global__ __launch_bounds__(kBlock) void sb2006_tendencies_kernel(const SbConsts<FT> c, const SbIn<FT> in,
-                                                                   const SbOut<FT> out, const int64_t nvec) {
+//
+// Launch shape: NON-persistent — workgroup b owns C consecutive tiles of BS lanes × VEC points, issues all of
+// its 7·C vector loads up front, computes, stores, retires.  Measured on MI355X (tools/sb2006_probe, 1e8 f32
+// points, 13 concurrent HBM streams): a grid-stride loop over CUs×k resident workgroups keeps every wave of the
+// chip in the same load→compute→store phase and sustains only ≈59 % of the 8 TB/s peak, the same bytes moved by
+// short-lived workgroups ≈70–73 % (new waves start loading while older ones store; profiles/r01_probe.txt).
+template <typename FT, bool LIMITED, int VEL, int VEC, int BS = kBlock, int C = 1, bool NT = true>
+__global__ __launch_bounds__(BS) void sb2006_tendencies_kernel(const SbConsts<FT> c, const SbIn<FT> in,
+                                                               const SbOut<FT> out, const int64_t nvec) {
     using M = Math<FT>;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
-        FT rho[VEC], T[VEC], q_tot[VEC], q_lcl[VEC], n_lcl[VEC], q_rai[VEC], n_rai[VEC];
-        load_col<FT, VEC, NT>(in.rho, i, rho);
-        load_col<FT, VEC, NT>(in.T, i, T);
-        load_col<FT, VEC, NT>(in.q_tot, i, q_tot);
-        load_col<FT, VEC, NT>(in.q_lcl, i, q_lcl);
-        load_col<FT, VEC, NT>(in.n_lcl, i, n_lcl);
-        load_col<FT, VEC, NT>(in.q_rai, i, q_rai);
-        load_col<FT, VEC, NT>(in.n_rai, i, n_rai);
+    const int64_t base = ((int64_t)blockIdx.x * C) * BS + threadIdx.x;
+    FT rho[C][VEC], T[C][VEC], q_tot[C][VEC], q_lcl[C][VEC], n_lcl[C][VEC], q_rai[C][VEC], n_rai[C][VEC];
+#pragma unroll
+    for (int t = 0; t < C; ++t) {
+        const int64_t i = base + (int64_t)t * BS;
+        if (i < nvec) {
+            load_col<FT, VEC, NT>(in.rho, i, rho[t]);
+            load_col<FT, VEC, NT>(in.T, i, T[t]);
+            load_col<FT, VEC, NT>(in.q_tot, i, q_tot[t]);
+            load_col<FT, VEC, NT>(in.q_lcl, i, q_lcl[t]);
+            load_col<FT, VEC, NT>(in.n_lcl, i, n_lcl[t]);
+            load_col<FT, VEC, NT>(in.q_rai, i, q_rai[t]);
+            load_col<FT, VEC, NT>(in.n_rai, i, n_rai[t]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < C; ++t) {
+        const int64_t i = base + (int64_t)t * BS;
+        if (i >= nvec) continue;
         FT dq_lcl[VEC], dn_lcl[VEC], dq_rai[VEC], dn_rai[VEC], vt_n[VEC], vt_m[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             // clamp_to_nonneg — BMT:828-837 (T is not clamped)
-            const FT r_ = M::max(FT(0), rho[k]);
-            const FT qt = M::max(FT(0), q_tot[k]);
-            const FT ql = M::max(FT(0), q_lcl[k]);
-            const FT qr = M::max(FT(0), q_rai[k]);
-            const FT nl = M::max(FT(0), n_lcl[k]);
-            const FT nr = M::max(FT(0), n_rai[k]);
+            const FT r_ = M::max(FT(0), rho[t][k]);
+            const FT qt = M::max(FT(0), q_tot[t][k]);
+            const FT ql = M::max(FT(0), q_lcl[t][k]);
+            const FT qr = M::max(FT(0), q_rai[t][k]);
+            const FT nl = M::max(FT(0), n_lcl[t][k]);
+            const FT nr = M::max(FT(0), n_rai[t][k]);
             // N = ρ n — BMT:718-719
-            const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL>(c, r_, T[k], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
+            const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL>(c, r_, T[t][k], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
             // accumulation order of warm_rain_tendencies_2m — BMT:738-779
             dq_lcl[k] = (p.cond + p.au_dq_lcl) + p.ac_dq_lcl;
             dn_lcl[k] = ((p.au_dN_lcl * p.inv_rho + p.lsc * p.inv_rho) + p.ac_dN_lcl * p.inv_rho) + p.na_lcl;

@@ -6,7 +6,7 @@
 // Times, with hipEvents on one stream over `reps` back-to-back launches at n points (default 1e8 f32):
 //   stream13      7 dwordx4 loads + 6 dwordx4 stores per lane, trivial math — the practical HBM ceiling of
 //                 this access pattern (13 concurrent streams), with and without the non-temporal hint;
-//   sb2006        the product kernel at several grid sizes (workgroups per CU) and hint settings.
+//   sb2006        the product kernel at several workgroup sizes / tiles per workgroup and hint settings.
 // Prints ms, GB/s at the ALGORITHMIC 52 B/point and the fraction of the 8 TB/s spec peak.
 #include <hip/hip_runtime.h>
 
@@ -203,25 +203,28 @@ int main(int argc, char **argv) {
         NP(64, 2, 4, true, true, "np13 BS=64 C=4", 52.0 * n)
 #undef NP
     }
-    for (int bpc : {2, 4, 6, 8, 12, 16, 32}) {
-        const int grid = cus * bpc;
-        report("sb2006 limited+vel nt", grid, time_ms([&] {
-                   hipLaunchKernelGGL((sb2006_tendencies_kernel<float, true, VEL_SB, 4, true>), dim3(grid), dim3(kBlock), 0, 0, c, in, out, nvec); }, reps));
+#define SB(L, V, VECN, BS, C, NT, label)                                                                               \
+    {                                                                                                                  \
+        const int64_t nv = (VECN == 4) ? nvec : n;                                                                     \
+        const int g = (int)((nv + (int64_t)BS * C - 1) / ((int64_t)BS * C));                                            \
+        report(label, g, time_ms([&] {                                                                                 \
+                   hipLaunchKernelGGL((sb2006_tendencies_kernel<float, L, V, VECN, BS, C, NT>), dim3(g), dim3(BS), 0, 0, c, in, \
+                                      out, nv); }, reps));                                                             \
     }
-    {
-        const int grid = cus * 8;
-        report("sb2006 limited+vel plain ld/st", grid, time_ms([&] {
-                   hipLaunchKernelGGL((sb2006_tendencies_kernel<float, true, VEL_SB, 4, false>), dim3(grid), dim3(kBlock), 0, 0, c, in, out, nvec); }, reps));
-        report("sb2006 limited, no vel", grid, time_ms([&] {
-                   hipLaunchKernelGGL((sb2006_tendencies_kernel<float, true, VEL_NONE, 4, true>), dim3(grid), dim3(kBlock), 0, 0, c, in, out, nvec); }, reps));
-        report("sb2006 notlimited+vel", grid, time_ms([&] {
-                   hipLaunchKernelGGL((sb2006_tendencies_kernel<float, false, VEL_SB, 4, true>), dim3(grid), dim3(kBlock), 0, 0, c, in, out, nvec); }, reps));
-        const int g1 = (int)((nvec + kBlock - 1) / kBlock);
-        report("sb2006 limited+vel, one vec/lane", g1, time_ms([&] {
-                   hipLaunchKernelGGL((sb2006_tendencies_kernel<float, true, VEL_SB, 4, true>), dim3(g1), dim3(kBlock), 0, 0, c, in, out, nvec); }, reps));
-        report("sb2006 limited+vel, 1 pt/lane", grid, time_ms([&] {
-                   hipLaunchKernelGGL((sb2006_tendencies_kernel<float, true, VEL_SB, 1, true>), dim3(grid), dim3(kBlock), 0, 0, c, in, out, n); }, reps));
-    }
+    SB(true, VEL_SB, 4, 64, 1, true, "sb2006 lim+vel BS=64")
+    SB(true, VEL_SB, 4, 128, 1, true, "sb2006 lim+vel BS=128")
+    SB(true, VEL_SB, 4, 256, 1, true, "sb2006 lim+vel BS=256")
+    SB(true, VEL_SB, 4, 512, 1, true, "sb2006 lim+vel BS=512")
+    SB(true, VEL_SB, 4, 1024, 1, true, "sb2006 lim+vel BS=1024")
+    SB(true, VEL_SB, 4, 64, 2, true, "sb2006 lim+vel BS=64 C=2")
+    SB(true, VEL_SB, 4, 128, 2, true, "sb2006 lim+vel BS=128 C=2")
+    SB(true, VEL_SB, 4, 256, 2, true, "sb2006 lim+vel BS=256 C=2")
+    SB(true, VEL_SB, 4, 256, 1, false, "sb2006 lim+vel BS=256 plain ld/st")
+    SB(true, VEL_NONE, 4, 256, 1, true, "sb2006 lim, no vel BS=256")
+    SB(false, VEL_SB, 4, 256, 1, true, "sb2006 notlim+vel BS=256")
+    SB(true, VEL_CHEN, 4, 256, 1, true, "sb2006 lim+chen BS=256")
+    SB(true, VEL_SB, 1, 256, 1, true, "sb2006 lim+vel 1 pt/lane")
+#undef SB
     for (auto &p : buf) CK(hipFree(p));
     return 0;
 }
