@@ -42,6 +42,35 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores() -> int:
+    """Host threads this process may actually run on: affinity mask ∩ cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:  # cgroup v2 quota ("max 100000" or "<quota> <period>")
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def pmc_traffic(dtype: str, n: int):
+    """HBM bytes per launch measured with rocprofv3 PMC counters (FETCH_SIZE, WRITE_SIZE; separate passes, gfx950
+    FETCH_SIZE ×2 correction of MI355X_MICROARCH.md §HBM) for this exact workload, if a committed profile matches;
+    PMC counters cannot be read from inside the benchmark process, so this is null otherwise."""
+    for p in sorted((REPO / "profiles").glob(f"r*_pmc_traffic_{dtype}.json"), reverse=True):
+        try:
+            d = json.loads(p.read_text())
+        except (OSError, ValueError):
+            continue
+        if d.get("points") == n and d.get("dtype") == dtype:
+            return d.get("hbm_bytes_per_launch")
+    return None
+
+
 def cpu_baseline(args, state_cpu_sample):
     """The oracle — a C restatement of the reference's scalar arithmetic (kind 'port'; the Julia reference cannot
     run here) — timed on the host cores over a bounded sample of the same synthetic workload."""
@@ -51,7 +80,7 @@ def cpu_baseline(args, state_cpu_sample):
     from cmx import _abi
     from cmx import parameters as P
     fam = _abi.family(args.dtype)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     wr, tps, vel = P.WarmRainParams2M(args.dtype).c, P.ThermodynamicsParameters(args.dtype), P.rain_vel_params(args.dtype)
     flags = _abi.CMX_SB2006_LIMITED | _abi.CMX_VEL_SB2006
     cols = [np.ascontiguousarray(c) for c in state_cpu_sample]
@@ -151,7 +180,7 @@ def main():
                                    "velocities, limited rain PSD", "points_per_gpu": n, "columns_in": 7, "columns_out": 6,
                        "parallelism": f"shard{world}" + ("+rccl-diag" if args.diagnostics else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.dtype, n),
                          "kernel": "sb2006_tendencies_kernel", "kernel_ms": kern_ms, "bytes_per_point": bpp},
         }
         if not args.no_cpu_baseline and world == 1:
