@@ -6,11 +6,13 @@ out) over the rank's resident batch of synthetic grid points (default 1e8 Float3
 configuration BASELINE.json quotes the metric on).  Inputs are generated on the device before the timed
 region; nothing crosses PCIe inside it.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--points P] [--dtype f32|f64]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--points P] [--dtype f32|f64] [--workload sb2006|icenuc]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (contract: see the task statement; DESIGN.md §5 explains every field).
+Rank 0 prints ONE JSON line (contract: see the task statement; DESIGN.md §6 explains every field).
+`--workload` selects one of the other hot-path kernels for roofline measurements (same JSON shape); the default,
+and the line the driver records, is the north-star SB2006 sweep.
 """
 from __future__ import annotations
 
@@ -25,7 +27,6 @@ REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO / "cloudmicrophysics.jl_amd"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ≈6.3 TB/s achievable)
-BYTES_PER_POINT = {"f32": 52, "f64": 104}   # 7 in + 4 tendencies + 2 velocities
 
 
 def parse():
@@ -35,10 +36,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=100_000_000, help="grid points per GPU")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--workload", choices=["sb2006", "icenuc"], default="sb2006")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the bounded baseline sample")
     ap.add_argument("--diagnostics", action="store_true",
-                    help="also reduce Σ of the 4 tendencies per step (block reduce + RCCL all-reduce of 4 doubles)")
+                    help="also reduce Σ of the output columns per step (block reduce + RCCL all-reduce of a few doubles)")
     return ap.parse_args()
 
 
@@ -57,11 +59,12 @@ def usable_cores() -> int:
     return n
 
 
-def pmc_traffic(dtype: str, n: int):
+def pmc_traffic(workload: str, dtype: str, n: int):
     """HBM bytes per launch measured with rocprofv3 PMC counters (FETCH_SIZE, WRITE_SIZE; separate passes, gfx950
     FETCH_SIZE ×2 correction of MI355X_MICROARCH.md §HBM) for this exact workload, if a committed profile matches;
     PMC counters cannot be read from inside the benchmark process, so this is null otherwise."""
-    for p in sorted((REPO / "profiles").glob(f"r*_pmc_traffic_{dtype}.json"), reverse=True):
+    tag = "" if workload == "sb2006" else f"_{workload}"
+    for p in sorted((REPO / "profiles").glob(f"r*_pmc_traffic{tag}_{dtype}.json"), reverse=True):
         try:
             d = json.loads(p.read_text())
         except (OSError, ValueError):
@@ -71,56 +74,104 @@ def pmc_traffic(dtype: str, n: int):
     return None
 
 
-def cpu_baseline(args, state_cpu_sample):
-    """The oracle — a C restatement of the reference's scalar arithmetic (kind 'port'; the Julia reference cannot
-    run here) — timed on the host cores over a bounded sample of the same synthetic workload."""
-    sys.path.insert(0, str(REPO / "oracle"))
-    import numpy as np
-    import oracle_binding as ob
+# ------------------------------------------------------------------------------------------------------------
+# workloads: each returns (state columns, step(), output columns, description dict, cpu_run(cols_np, m, threads))
+# ------------------------------------------------------------------------------------------------------------
+def setup_sb2006(args, dev, dtype, rank):
+    import cmx
     from cmx import _abi
     from cmx import parameters as P
-    fam = _abi.family(args.dtype)
-    cores = usable_cores()
-    wr, tps, vel = P.WarmRainParams2M(args.dtype).c, P.ThermodynamicsParameters(args.dtype), P.rain_vel_params(args.dtype)
-    flags = _abi.CMX_SB2006_LIMITED | _abi.CMX_VEL_SB2006
-    cols = [np.ascontiguousarray(c) for c in state_cpu_sample]
-    run = lambda m: ob.sb2006_warm_rain_tendencies(fam, wr, tps, vel, flags, *[c[:m] for c in cols],  # noqa: E731
-                                                   nthreads=cores, want_scale=False)
-    probe = min(200_000, cols[0].size)
-    run(probe)
-    t0 = time.perf_counter()
-    run(probe)
-    rate = probe / (time.perf_counter() - t0)
-    m = cols[0].size
-    run(m)                                         # first full pass: page in, spin up the thread team
+    from cmx import synthetic
+    state = synthetic.sb2006_state(args.points, dtype=dtype, device=dev, seed=1234 + rank)
+    mp, tps = P.Microphysics2MParams(args.dtype), P.ThermodynamicsParameters(args.dtype)
+    out = cmx.WarmRainTendencies2M(*[__import__("torch").empty_like(state.rho) for _ in range(6)])
+    scheme = cmx.Microphysics2Moment()
+
+    def step():
+        cmx.bulk_microphysics_tendencies(scheme, mp, tps, *state, vel=cmx.SB2006VelType, out=out)
+
+    def cpu_run(ob, cols, threads):
+        fam = _abi.family(args.dtype)
+        wr, t, vel = P.WarmRainParams2M(args.dtype).c, P.ThermodynamicsParameters(args.dtype), P.rain_vel_params(args.dtype)
+        flags = _abi.CMX_SB2006_LIMITED | _abi.CMX_VEL_SB2006
+        return lambda: ob.sb2006_warm_rain_tendencies(fam, wr, t, vel, flags, *cols, nthreads=threads, want_scale=False)
+
+    desc = {
+        "metric": "grid-points/sec SB2006 2M tendency sweep",
+        "bytes_per_point": {"f32": 52, "f64": 104}[args.dtype],     # 7 in + 4 tendencies + 2 velocities
+        "kernel": "sb2006_tendencies_kernel",
+        "workload": "Microphysics2M SB2006 fused warm-rain tendencies (cond/evap, autoconversion, accretion, "
+                    "self-collection, breakup, evaporation, number adjustment) + SB2006 rain terminal velocities, "
+                    "limited rain PSD",
+        "columns_in": 7, "columns_out": 6, "diag_cols": list(out[:4]),
+    }
+    return list(state), step, desc, cpu_run
+
+
+def setup_icenuc(args, dev, dtype, rank):
+    import cmx
+    from cmx import _abi
+    from cmx import parameters as P
+    from cmx import synthetic
+    state = synthetic.ice_nucleation_state(args.points, dtype=dtype, device=dev, seed=1234 + rank)
+    tps, dust, koop = P.ThermodynamicsParameters(args.dtype), P.Kaolinite(args.dtype), P.Koop2000(args.dtype)
+    holder = {}
+
+    holder["out"] = cmx.ice_nucleation_rates(tps, dust, koop, *state, count_domain_errors=True)
+
+    def step():   # reuse the output columns and the (accumulating) domain-error counter: no allocation in the loop
+        cmx.ice_nucleation_rates(tps, dust, koop, *state, out=holder["out"])
+
+    def cpu_run(ob, cols, threads):
+        fam = _abi.family(args.dtype)
+        return lambda: ob.ice_nucleation_rates(fam, tps, dust, koop, 0, *cols)   # scalar port: 1 thread
+
+    step()
+    desc = {
+        "metric": "grid-points/sec ABIFM + Koop2000 ice-nucleation rate sweep",
+        "bytes_per_point": {"f32": 20, "f64": 40}[args.dtype],      # 3 in + 2 out
+        "kernel": "ice_nucleation_kernel",
+        "workload": "IceNucleation ABIFM immersion (kaolinite) + Koop2000 cubic homogeneous rates over (T, a_w, r)",
+        "columns_in": 3, "columns_out": 2, "diag_cols": [holder["out"].rate_het],
+        "cpu_threads": 1,
+    }
+    return list(state), step, desc, cpu_run
+
+
+def cpu_baseline(args, cols_np, desc, cpu_run):
+    """The oracle — a C restatement of the reference's scalar arithmetic (kind 'port'; the Julia reference cannot
+    run here) — timed on the host cores over repeated passes of a bounded sample of the same synthetic workload."""
+    sys.path.insert(0, str(REPO / "oracle"))
+    import oracle_binding as ob
+    cores = desc.get("cpu_threads") or usable_cores()
+    run = cpu_run(ob, cols_np, cores)
+    run()                                          # first pass: page in, spin up the thread team
     passes, t0 = 0, time.perf_counter()
     while True:
-        run(m)
+        run()
         passes += 1
         dt = time.perf_counter() - t0
         if dt >= args.cpu_seconds or passes >= 1000:
             break
+    m = cols_np[0].size
     return {"value": passes * m / dt, "unit": "grid-points/s", "cores": cores, "kind": "port",
             "sample": f"{passes} passes over {m} of the same synthetic points ({passes * m} point evaluations), "
-                      f"{args.dtype} arithmetic, oracle/libcmx_oracle.so (gcc -O2, OpenMP {cores} threads), {dt:.1f} s; "
-                      f"probe rate {rate:.3g}/s"}
+                      f"{args.dtype} arithmetic, oracle/libcmx_oracle.so (gcc -O2, {cores} OpenMP thread(s)), {dt:.1f} s"}
 
 
 def main():
     args = parse()
+    import numpy as np
     import torch
     import torch.distributed as dist
 
-    import cmx
-    from cmx import parameters as P
-    from cmx import sharding, synthetic
+    from cmx import sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
+    if world == 1 and args.gpus > 1:
+        sys.exit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -129,15 +180,12 @@ def main():
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     n = args.points                                          # weak scaling: fixed work per GPU
     # rank r owns shard r of the global [0, world·n) index space: disjoint seeds, no exchange
-    state = synthetic.sb2006_state(n, dtype=dtype, device=dev, seed=1234 + rank)
-    mp, tps = P.Microphysics2MParams(args.dtype), P.ThermodynamicsParameters(args.dtype)
-    out = cmx.WarmRainTendencies2M(*[torch.empty_like(state.rho) for _ in range(6)])
-    scheme = cmx.Microphysics2Moment()
+    state, kernel_step, desc, cpu_run = {"sb2006": setup_sb2006, "icenuc": setup_icenuc}[args.workload](args, dev, dtype, rank)
 
     def step():
-        cmx.bulk_microphysics_tendencies(scheme, mp, tps, *state, vel=cmx.SB2006VelType, out=out)
+        kernel_step()
         if args.diagnostics:
-            sharding.global_diagnostics(list(out[:4]))
+            sharding.global_diagnostics(desc["diag_cols"])
 
     def fence():
         if world > 1:
@@ -165,27 +213,27 @@ def main():
 
     if rank == 0:
         total_points = n * world
-        bpp = BYTES_PER_POINT[args.dtype]
+        bpp = desc["bytes_per_point"]
         achieved = n * bpp / (kern_ms * 1e-3) / 1e9
         line = {
-            "metric": "grid-points/sec SB2006 2M tendency sweep",
+            "metric": desc["metric"],
             "value": total_points * args.steps / elapsed,
             "unit": "grid-points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "Microphysics2M SB2006 fused warm-rain tendencies (cond/evap, autoconversion, accretion, "
-                                   "self-collection, breakup, evaporation, number adjustment) + SB2006 rain terminal "
-                                   "velocities, limited rain PSD", "points_per_gpu": n, "columns_in": 7, "columns_out": 6,
+            "config": {"workload": desc["workload"], "points_per_gpu": n, "columns_in": desc["columns_in"],
+                       "columns_out": desc["columns_out"],
                        "parallelism": f"shard{world}" + ("+rccl-diag" if args.diagnostics else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.dtype, n),
-                         "kernel": "sb2006_tendencies_kernel", "kernel_ms": kern_ms, "bytes_per_point": bpp},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, args.dtype, n),
+                         "kernel": desc["kernel"], "kernel_ms": kern_ms, "bytes_per_point": bpp},
         }
         if not args.no_cpu_baseline and world == 1:
-            m = min(n, 20_000_000)
-            line["cpu_baseline"] = cpu_baseline(args, [c[:m].cpu().numpy() for c in state])
+            m = min(n, 20_000_000 if args.workload == "sb2006" else 4_000_000)
+            cols_np = [np.ascontiguousarray(c[:m].cpu().numpy()) for c in state]
+            line["cpu_baseline"] = cpu_baseline(args, cols_np, desc, cpu_run)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

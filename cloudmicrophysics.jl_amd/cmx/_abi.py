@@ -16,6 +16,8 @@ CMX_SB2006_LIMITED = 1 << 0
 CMX_VEL_SB2006 = 1 << 1
 CMX_VEL_CHEN2022 = 1 << 2
 
+CMX_ICENUC_HOM_LINEAR = 1 << 0
+
 CMX_OK = 0
 CMX_ERR_BAD_ARG = -1
 CMX_ERR_HIP = -2
@@ -70,6 +72,9 @@ def _family(ft, sfx):
     ns.chen2022_rain_vel = _struct(f"cmx_chen2022_rain_vel_{sfx}", [
         ("rho_0", ft), ("a", ft * 3), ("a3_pow", ft), ("b", ft * 3), ("b_rho", ft), ("c", ft * 3)])
     ns.rain_vel = _struct(f"cmx_rain_vel_{sfx}", [("sb2006", ns.sb2006_vel), ("chen2022", ns.chen2022_rain_vel)])
+    ns.koop2000 = _struct(f"cmx_koop2000_{sfx}",
+                          s("delta_a_w_min", "delta_a_w_max", "c1", "c2", "c3", "c4", "linear_c1", "linear_c2"))
+    ns.abifm_dust = _struct(f"cmx_abifm_dust_{sfx}", s("ABIFM_m", "ABIFM_c"))
     return ns
 
 

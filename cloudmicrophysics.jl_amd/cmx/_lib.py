@@ -48,6 +48,12 @@ def _declare(lib):
         f.restype = i32
         f.argtypes = [C.POINTER(fam.warm_rain_2m), C.POINTER(fam.thermo), C.POINTER(fam.rain_vel), u32, i64] + [vp] * 7 + [
             C.POINTER(vp), vp]
+        f = getattr(lib, f"cmx_ice_nucleation_rates_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.thermo), C.POINTER(fam.abifm_dust), C.POINTER(fam.koop2000), u32, i64] + [vp] * 8 + [vp, vp]
+        f = getattr(lib, f"cmx_water_activity_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.thermo), i64] + [vp] * 4 + [vp]
         f = getattr(lib, f"cmx_column_sums_{s}")
         f.restype = i32
         f.argtypes = [i32, C.POINTER(vp), i64, vp, vp]

@@ -1,0 +1,85 @@
+"""Ice-nucleation rates over columns — host-side mirror of `CloudMicrophysics.HetIceNucleation`
+(`ABIFM_J`), `HomIceNucleation` (`homogeneous_J_cubic`, `homogeneous_J_linear`) and the water-activity
+helpers of `CloudMicrophysics.Common` (`a_w_ice`, `a_w_eT`), evaluated by one fused gfx950 kernel
+(include/cmx.h §4).
+
+Reference broadcasts being replaced (KA wrappers test/gpu_tests.jl:294-362):
+
+    Δa_w  = a_w .- CO.a_w_ice.(Ref(tps), T)
+    J_het = CMI_het.ABIFM_J.(Ref(dust), Δa_w)
+    J_hom = CMI_hom.homogeneous_J_cubic.(Ref(ip.homogeneous), Δa_w)        # throws DomainError out of range
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import namedtuple
+
+import torch
+
+from . import _abi, _lib
+from .bulk_tendencies import _check_cols, _fam_of, _ptr
+
+IceNucleationRates = namedtuple("IceNucleationRates",
+                                ["delta_a_w", "J_het", "J_hom", "rate_het", "rate_hom", "n_domain_errors"])
+
+
+def ice_nucleation_rates(tps, dust, koop, T, a_w, r=None, *, linear=False, want=("rate_het", "rate_hom"),
+                         count_domain_errors=True, out=None, stream=None) -> IceNucleationRates:
+    """ABIFM immersion-freezing and Koop-2000 homogeneous-freezing rates for every (T, a_w, r) point.
+
+    `want` selects the output columns among delta_a_w, J_het [m⁻² s⁻¹], J_hom [m⁻³ s⁻¹], rate_het = J_het·4πr²,
+    rate_hom = J_hom·4/3πr³ [s⁻¹].  Where the reference's `homogeneous_J_cubic` would throw (Δa_w outside
+    [Δa_w_min, Δa_w_max], src/IceNucleation.jl:558-562) J_hom/rate_hom are NaN and the point is counted in the
+    device counter `n_domain_errors` (a 1-element int64 tensor; reading it synchronises, the call itself does not).
+    `linear=True` uses `homogeneous_J_linear` (:581-584), which has no domain restriction."""
+    cols = (T, a_w) if r is None else (T, a_w, r)
+    ref = _check_cols(cols, ("T", "a_w", "r"))
+    fam = _fam_of(ref)
+    if not (isinstance(tps, fam.thermo) and isinstance(dust, fam.abifm_dust) and isinstance(koop, fam.koop2000)):
+        raise TypeError("parameter float type does not match the state columns")
+    names = IceNucleationRates._fields[:5]
+    unknown = set(want) - set(names)
+    if unknown:
+        raise ValueError(f"unknown output column(s) {sorted(unknown)}")
+    if r is None and ({"rate_het", "rate_hom"} & set(want)):
+        raise ValueError("rate_het / rate_hom need the radius column r")
+    if out is not None:   # caller-provided columns (KA-kernel style); the counter ACCUMULATES across calls
+        outs = {k: getattr(out, k) for k in names}
+        _check_cols([ref] + [o for o in outs.values() if o is not None], ["T"] + ["out"] * 5)
+        nerr = out.n_domain_errors
+    else:
+        outs = {k: (torch.empty_like(ref) if k in want else None) for k in names}
+        nerr = torch.zeros(1, dtype=torch.int64, device=ref.device) if (count_domain_errors and not linear) else None
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_ice_nucleation_rates_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(tps), C.byref(dust), C.byref(koop), _abi.CMX_ICENUC_HOM_LINEAR if linear else 0, ref.numel(),
+                _ptr(T), _ptr(a_w), _ptr(r), *[_ptr(outs[k]) for k in names], _ptr(nerr), C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return IceNucleationRates(*[outs[k] for k in names], nerr)
+
+
+def a_w_ice(tps, T, stream=None) -> torch.Tensor:
+    """CO.a_w_ice.(Ref(tps), T) — src/Common.jl:267-271."""
+    return _water_activity(tps, T, None, stream)[0]
+
+
+def a_w_eT(tps, e, T, stream=None) -> torch.Tensor:
+    """CO.a_w_eT.(Ref(tps), e, T) — src/Common.jl:250-253."""
+    return _water_activity(tps, T, e, stream)[1]
+
+
+def _water_activity(tps, T, e, stream):
+    cols = (T,) if e is None else (T, e)
+    ref = _check_cols(cols, ("T", "e"))
+    fam = _fam_of(ref)
+    if not isinstance(tps, fam.thermo):
+        raise TypeError("parameter float type does not match the state columns")
+    ice = torch.empty_like(ref) if e is None else None
+    eT = torch.empty_like(ref) if e is not None else None
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_water_activity_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(tps), ref.numel(), _ptr(T), _ptr(e), _ptr(ice), _ptr(eT), C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return ice, eT

@@ -87,6 +87,24 @@ DEFAULT_PARAMETERS = {
     "Chen2022_table_B1_bi": (2.2955, 2.2955, 1.1451),
     "Chen2022_table_B1_b_rho_coeff": 0.038465,
     "Chen2022_table_B1_ci": (0.0, 0.184325, 0.184325),
+    # Koop et al. 2000 homogeneous freezing (src/parameters/IceNucleation.jl:57-68; docs/src/IceNucleation.md:214-217;
+    # cubic pinned by test/gpu_tests.jl:1067; window: 0.25 and 0.35 throw, test/homogeneous_ice_nucleation_tests.jl:22-23)
+    "Koop2000_min_delta_aw": 0.26,
+    "Koop2000_max_delta_aw": 0.34,
+    "Koop2000_J_hom_coeff1": -906.7,
+    "Koop2000_J_hom_coeff2": 8502.0,
+    "Koop2000_J_hom_coeff3": 26924.0,
+    "Koop2000_J_hom_coeff4": 29180.0,
+    # linear fit: in-tree values papers/ice_nucleation_2024/calibration_setup.jl:149, consistent with the KAT
+    # test/gpu_tests.jl:1069 (one KAT, two coefficients)
+    "Linear_J_hom_coeff1": -68.553283,
+    "Linear_J_hom_coeff2": 255.927125,
+    # ABIFM, Knopf & Alpert 2013 (src/parameters/AerosolKaolinite.jl:28-29, AerosolIllite.jl:27-28);
+    # pinned by test/gpu_tests.jl:987-997
+    "KnopfAlpert2013_J_ABIFM_m_Kaolinite": 54.58834,
+    "KnopfAlpert2013_J_ABIFM_c_Kaolinite": -10.54758,
+    "KnopfAlpert2013_J_ABIFM_m_Illite": 54.48075,
+    "KnopfAlpert2013_J_ABIFM_c_Illite": -10.66873,
 }
 
 # the reference's override file src/parameters/toml/SB2006_limiters.toml (used by its CPU tests,
@@ -268,6 +286,35 @@ class Microphysics2MParams:
         self.warm_rain = WarmRainParams2M(FT, is_limited)
         self.ice = None
         self.fam = self.warm_rain.fam
+
+
+def Koop2000(FT):
+    """CMP.Koop2000 — src/parameters/IceNucleation.jl:38-69."""
+    td = _td(FT)
+    return td.fam.koop2000(
+        delta_a_w_min=td["Koop2000_min_delta_aw"], delta_a_w_max=td["Koop2000_max_delta_aw"],
+        c1=td["Koop2000_J_hom_coeff1"], c2=td["Koop2000_J_hom_coeff2"], c3=td["Koop2000_J_hom_coeff3"],
+        c4=td["Koop2000_J_hom_coeff4"], linear_c1=td["Linear_J_hom_coeff1"], linear_c2=td["Linear_J_hom_coeff2"])
+
+
+def Kaolinite(FT):
+    """ABIFM fields of CMP.Kaolinite — src/parameters/AerosolKaolinite.jl:12-34."""
+    td = _td(FT)
+    return td.fam.abifm_dust(ABIFM_m=td["KnopfAlpert2013_J_ABIFM_m_Kaolinite"],
+                             ABIFM_c=td["KnopfAlpert2013_J_ABIFM_c_Kaolinite"])
+
+
+def Illite(FT):
+    """ABIFM fields of CMP.Illite — src/parameters/AerosolIllite.jl:12-32."""
+    td = _td(FT)
+    return td.fam.abifm_dust(ABIFM_m=td["KnopfAlpert2013_J_ABIFM_m_Illite"],
+                             ABIFM_c=td["KnopfAlpert2013_J_ABIFM_c_Illite"])
+
+
+def ABIFMDust(FT, ABIFM_m: float, ABIFM_c: float):
+    """Any other dust type (DesertDust, ArizonaTestDust, …): the caller supplies its ABIFM m, c (their ClimaParams
+    defaults are not in the reference tree and are pinned by no reference test)."""
+    return _abi.family(FT).abifm_dust(ABIFM_m=ABIFM_m, ABIFM_c=ABIFM_c)
 
 
 def rain_vel_params(FT):

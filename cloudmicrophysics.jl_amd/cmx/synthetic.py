@@ -29,6 +29,38 @@ def _psat_liquid(T, td):
     return p_tr * (T / T_tr) ** (dcp / R_v) * torch.exp((LH - dcp * T0) / R_v * (1.0 / T_tr - 1.0 / T))
 
 
+IceNucState = namedtuple("IceNucState", ["T", "a_w", "r"])
+
+
+def ice_nucleation_state(n: int, dtype=torch.float32, device="cpu", seed: int = 1234, chunk: int = 1 << 24,
+                         out_of_range: float = 0.05) -> IceNucState:
+    """(T, a_w, r) columns for BASELINE config 4: T ~ U[190, 240] K; Δa_w ~ U[0.26, 0.34] (the Koop
+    cubic's validity window) for 95 % of the points and U[0, 0.26) ∪ (0.34, 0.40] for `out_of_range` of them
+    (exercises the DomainError → NaN + count path); a_w = a_w_ice(T) + Δa_w; r ~ log-U[1e-8, 1e-5] m."""
+    td = P.DEFAULT_PARAMETERS
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    cols = [torch.empty(n, dtype=dtype, device=device) for _ in range(3)]
+    R_v, T_tr, T0 = td["gas_constant_vapor"], td["temperature_triple_point"], td["thermodynamics_temperature_reference"]
+    dcl = td["isobaric_specific_heat_vapor"] - td["isobaric_specific_heat_liquid"]
+    dci = td["isobaric_specific_heat_vapor"] - td["isobaric_specific_heat_ice"]
+    LHv, LHs = td["latent_heat_vaporization_at_reference"], td["latent_heat_sublimation_at_reference"]
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        u = lambda: torch.rand(m, dtype=torch.float64, device=device, generator=g)  # noqa: E731
+        T = 190.0 + 50.0 * u()
+        ln_a_ice = ((dci - dcl) / R_v) * torch.log(T / T_tr) + ((LHs - dci * T0) - (LHv - dcl * T0)) / R_v * (1 / T_tr - 1 / T)
+        d_in = 0.26 + 0.08 * u()
+        w = u()
+        d_out = torch.where(w < 0.8125, 0.26 * u(), 0.34 + 0.06 * u())      # |[0,0.26)| : |(0.34,0.40]| = 13 : 3
+        delta = torch.where(u() < out_of_range, d_out, d_in)
+        a_w = torch.exp(ln_a_ice) + delta
+        r = torch.exp(torch.log(torch.tensor(1e-8, dtype=torch.float64, device=device)) + u() * 6.907755278982137)
+        for dst, src in zip(cols, (T, a_w, r)):
+            dst[lo:lo + m] = src.to(dtype)
+    return IceNucState(*cols)
+
+
 def sb2006_state(n: int, dtype=torch.float32, device="cpu", seed: int = 1234, chunk: int = 1 << 24) -> State2M:
     """n random warm-rain states as 7 contiguous columns (ρ, T, q_tot, q_lcl, n_lcl, q_rai, n_rai)."""
     td = P.DEFAULT_PARAMETERS

@@ -1,0 +1,222 @@
+// cmx_icenuc_kernels.hip — ABIFM immersion-freezing + Koop-2000 homogeneous-freezing rates and the
+// water-activity helpers, fused per point, for gfx950; C-ABI entry points of include/cmx.h §(4).
+//
+// Reference (src = /root/reference/src): CO.a_w_ice / a_w_eT  Common.jl:250-271; CMI_het.ABIFM_J
+// IceNucleation.jl:124-134; CMI_hom.homogeneous_J_cubic / _linear  IceNucleation.jl:557-584; products with
+// the droplet area / volume as formed in parcel/ParcelTendencies.jl:120-133,194-205.
+//
+// HBM-bound pointwise map: 3 input columns, up to 5 output columns (20 B/point for the (T, a_w, r) →
+// (rate_het, rate_hom) configuration, f32).  Same launch shape as the SB2006 kernel: one 16-byte vector per
+// lane, one short-lived 256-lane workgroup per tile, non-temporal accesses.
+//
+// Numerics: a_w_ice = p_sat,ice / p_sat,liq is ONE exp2 of the difference of the two Rankine–Kirchhoff
+// exponents (host-folded coefficient differences), not a ratio of two exponentials.  The Koop cubic
+// log10 J = c1 + c2 Δ − c3 Δ² + c4 Δ³ cancels from O(2500) terms to O(6); in Float32 that alone would cost
+// ≈3e-4 relative on J, so the four-term Horner form is evaluated in double (4 FMAs per point on an
+// HBM-bound kernel) and only the result is rounded to FT.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <type_traits>
+
+#include "cmx_launch.hpp"
+#include "cmx_math.hpp"
+
+namespace cmx {
+
+template <typename FT> struct IceNucConsts {
+    // log2 a_w_ice(T) = d0 + da·log2(T/T_tr) + db·(1/T_tr − 1/T)
+    FT aw_d0, aw_da, aw_db, inv_T_tr;
+    // log2 p_sat,liq(T) = c0 + a·log2(T/T_tr) + b·(1/T_tr − 1/T)   (a_w_eT)
+    FT ps_c0, ps_a, ps_b;
+    FT abifm_m_l2, abifm_c_l2;        // (m Δ + c + 4)·log2(10)
+    double c1, c2, c3, c4;            // Koop cubic, evaluated in double
+    FT lin_c1_l2, lin_c2_l2;          // (linear_c2 Δ + linear_c1 + 6)·log2(10)
+    FT d_min, d_max;
+    FT four_pi, four_thirds_pi;
+};
+
+template <typename FT, typename TH, typename DU, typename KO>
+static IceNucConsts<FT> make_icenuc_consts(const TH &tp, const DU *dust, const KO *koop) {
+    IceNucConsts<FT> c{};
+    const double l2e = 1.4426950408889634074, l2_10 = 3.3219280948873623479, pi = 3.14159265358979323846;
+    const double Rv = tp.R_v, Ttr = tp.T_triple, T0 = tp.T_0;
+    const double dcp_l = (double)tp.cp_v - (double)tp.cp_l, dcp_i = (double)tp.cp_v - (double)tp.cp_i;
+    const double a_l = dcp_l / Rv, a_i = dcp_i / Rv;
+    const double b_l = ((double)tp.LH_v0 - dcp_l * T0) / Rv * l2e, b_i = ((double)tp.LH_s0 - dcp_i * T0) / Rv * l2e;
+    c.aw_d0 = (FT)0;                                   // same triple-point pressure for both phases
+    c.aw_da = (FT)(a_i - a_l);
+    c.aw_db = (FT)(b_i - b_l);
+    c.inv_T_tr = (FT)(1.0 / Ttr);
+    c.ps_c0 = (FT)std::log2((double)tp.press_triple);
+    c.ps_a = (FT)a_l;
+    c.ps_b = (FT)b_l;
+    if (dust) {
+        c.abifm_m_l2 = (FT)((double)dust->ABIFM_m * l2_10);
+        c.abifm_c_l2 = (FT)(((double)dust->ABIFM_c + 4.0) * l2_10);
+    }
+    if (koop) {
+        c.c1 = koop->c1; c.c2 = koop->c2; c.c3 = koop->c3; c.c4 = koop->c4;
+        c.lin_c1_l2 = (FT)(((double)koop->linear_c1 + 6.0) * l2_10);
+        c.lin_c2_l2 = (FT)((double)koop->linear_c2 * l2_10);
+        c.d_min = (FT)koop->delta_a_w_min;
+        c.d_max = (FT)koop->delta_a_w_max;
+    }
+    c.four_pi = (FT)(4.0 * pi);
+    c.four_thirds_pi = (FT)(4.0 / 3.0 * pi);
+    return c;
+}
+
+template <typename FT> struct IceNucIO {
+    const FT *T, *a_w, *r;
+    FT *delta_a_w, *J_het, *J_hom, *rate_het, *rate_hom;
+    unsigned long long *n_err;
+};
+
+template <typename FT> __device__ __forceinline__ FT a_w_ice_dev(const IceNucConsts<FT> &c, FT T, FT inv_T) {
+    using M = Math<FT>;
+    return M::exp2(M::fma(c.aw_da, M::log2(T * c.inv_T_tr), M::fma(c.aw_db, c.inv_T_tr - inv_T, c.aw_d0)));
+}
+
+template <typename FT, bool LINEAR, int VEC>
+__global__ __launch_bounds__(kBlock) void ice_nucleation_kernel(const IceNucConsts<FT> c, const IceNucIO<FT> io,
+                                                                const int64_t nvec) {
+    using M = Math<FT>;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nvec) return;
+    FT T[VEC], aw[VEC], r[VEC] = {};
+    load_col<FT, VEC>(io.T, i, T);
+    load_col<FT, VEC>(io.a_w, i, aw);
+    if (io.rate_het || io.rate_hom) load_col<FT, VEC>(io.r, i, r);
+    FT d[VEC], jh[VEC], jo[VEC], rh[VEC], ro[VEC];
+    int nerr = 0;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const FT inv_T = M::rcp(T[k]);
+        d[k] = aw[k] - a_w_ice_dev<FT>(c, T[k], inv_T);                            // Δa_w
+        jh[k] = M::exp2(M::fma(c.abifm_m_l2, d[k], c.abifm_c_l2));                // ABIFM_J  IceNucleation.jl:124-134
+        if constexpr (LINEAR) {
+            jo[k] = M::exp2(M::fma(c.lin_c2_l2, d[k], c.lin_c1_l2));              // homogeneous_J_linear :581-584
+        } else {
+            const double dd = (double)d[k];
+            const double logJ = __builtin_fma(dd, __builtin_fma(dd, __builtin_fma(dd, c.c4, -c.c3), c.c2), c.c1);
+            const bool ok = (c.d_min <= d[k]) && (d[k] <= c.d_max);                // DomainError → NaN  :558-562
+            jo[k] = ok ? M::exp2((FT)((logJ + 6.0) * 3.3219280948873623479)) : FT(__builtin_nan(""));
+            nerr += ok ? 0 : 1;
+        }
+        const FT r2 = r[k] * r[k];
+        rh[k] = jh[k] * (c.four_pi * r2);
+        ro[k] = jo[k] * (c.four_thirds_pi * (r2 * r[k]));
+    }
+    if (io.delta_a_w) store_col<FT, VEC>(io.delta_a_w, i, d);
+    if (io.J_het) store_col<FT, VEC>(io.J_het, i, jh);
+    if (io.J_hom) store_col<FT, VEC>(io.J_hom, i, jo);
+    if (io.rate_het) store_col<FT, VEC>(io.rate_het, i, rh);
+    if (io.rate_hom) store_col<FT, VEC>(io.rate_hom, i, ro);
+    if constexpr (!LINEAR) {
+        if (io.n_err) {   // one atomic per wave that saw an error (the compiler folds the per-lane adds)
+            if (nerr) atomicAdd(io.n_err, (unsigned long long)nerr);
+        }
+    }
+}
+
+template <typename FT> struct WaterActIO { const FT *T, *e; FT *a_w_ice, *a_w_eT; };
+
+template <typename FT>
+__global__ __launch_bounds__(kBlock) void water_activity_kernel(const IceNucConsts<FT> c, const WaterActIO<FT> io,
+                                                                const int64_t n) {
+    using M = Math<FT>;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const FT T = io.T[i], inv_T = M::rcp(T);
+    if (io.a_w_ice) io.a_w_ice[i] = a_w_ice_dev<FT>(c, T, inv_T);                  // Common.jl:267-271
+    if (io.a_w_eT) {                                                               // Common.jl:250-253
+        const FT l2_ps = M::fma(c.ps_a, M::log2(T * c.inv_T_tr), M::fma(c.ps_b, c.inv_T_tr - inv_T, c.ps_c0));
+        io.a_w_eT[i] = io.e[i] * M::exp2(-l2_ps);
+    }
+}
+
+template <typename FT, typename TH, typename DU, typename KO>
+static int32_t icenuc_entry(const TH *tps, const DU *dust, const KO *koop, uint32_t flags, int64_t n, const FT *T,
+                            const FT *a_w, const FT *r, FT *delta_a_w, FT *J_het, FT *J_hom, FT *rate_het, FT *rate_hom,
+                            int64_t *n_domain_errors, void *stream) {
+    if (!tps || !dust || !koop || n < 0 || (flags & ~CMX_ICENUC_HOM_LINEAR)) return CMX_ERR_BAD_ARG;
+    if (n == 0) return CMX_OK;
+    if (!T || !a_w || ((rate_het || rate_hom) && !r)) return CMX_ERR_BAD_ARG;
+    const IceNucConsts<FT> c = make_icenuc_consts<FT>(*tps, dust, koop);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    constexpr int VEC = Math<FT>::VEC;
+    const void *ptrs[] = {T, a_w, r, delta_a_w, J_het, J_hom, rate_het, rate_hom};
+    const uintptr_t mis0 = reinterpret_cast<uintptr_t>(T) & 15u;
+    bool same_mis = (mis0 % sizeof(FT)) == 0;
+    for (const void *p : ptrs)
+        if (p) same_mis = same_mis && ((reinterpret_cast<uintptr_t>(p) & 15u) == mis0);
+    const bool linear = flags & CMX_ICENUC_HOM_LINEAR;
+    auto off = [](auto *p, int64_t lo) { return p ? p + lo : p; };
+    auto launch_range = [&](auto vec_tag, int64_t lo, int64_t count) {
+        constexpr int V = decltype(vec_tag)::value;
+        if (count <= 0) return;
+        IceNucIO<FT> io{T + lo, a_w + lo, off(r, lo), off(delta_a_w, lo), off(J_het, lo), off(J_hom, lo),
+                        off(rate_het, lo), off(rate_hom, lo), reinterpret_cast<unsigned long long *>(n_domain_errors)};
+        const int64_t nv = count / V;
+        const unsigned grid = (unsigned)((nv + kBlock - 1) / kBlock);
+        if (linear) hipLaunchKernelGGL((ice_nucleation_kernel<FT, true, V>), dim3(grid), dim3(kBlock), 0, s, c, io, nv);
+        else hipLaunchKernelGGL((ice_nucleation_kernel<FT, false, V>), dim3(grid), dim3(kBlock), 0, s, c, io, nv);
+    };
+    if (same_mis) {
+        const int64_t head = std::min<int64_t>(n, mis0 ? (int64_t)((16 - mis0) / sizeof(FT)) : 0);
+        const int64_t body = ((n - head) / VEC) * VEC;
+        launch_range(std::integral_constant<int, 1>{}, 0, head);
+        launch_range(std::integral_constant<int, VEC>{}, head, body);
+        launch_range(std::integral_constant<int, 1>{}, head + body, n - head - body);
+    } else {
+        launch_range(std::integral_constant<int, 1>{}, 0, n);
+    }
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+
+template <typename FT, typename TH>
+static int32_t water_activity_entry(const TH *tps, int64_t n, const FT *T, const FT *e, FT *a_w_ice, FT *a_w_eT,
+                                    void *stream) {
+    if (!tps || n < 0) return CMX_ERR_BAD_ARG;
+    if (n == 0) return CMX_OK;
+    if (!T || (a_w_eT && !e)) return CMX_ERR_BAD_ARG;
+    const IceNucConsts<FT> c =
+        make_icenuc_consts<FT>(*tps, (const cmx_abifm_dust_f64 *)nullptr, (const cmx_koop2000_f64 *)nullptr);
+    WaterActIO<FT> io{T, e, a_w_ice, a_w_eT};
+    const unsigned grid = (unsigned)((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((water_activity_kernel<FT>), dim3(grid), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), c, io, n);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+
+}  // namespace cmx
+
+extern "C" {
+
+int32_t cmx_ice_nucleation_rates_f32(const cmx_thermo_f32 *tps, const cmx_abifm_dust_f32 *dust, const cmx_koop2000_f32 *koop,
+                                     uint32_t flags, int64_t n, const float *T, const float *a_w, const float *r,
+                                     float *delta_a_w, float *J_het, float *J_hom, float *rate_het, float *rate_hom,
+                                     int64_t *n_domain_errors, void *stream) {
+    return cmx::icenuc_entry<float>(tps, dust, koop, flags, n, T, a_w, r, delta_a_w, J_het, J_hom, rate_het, rate_hom,
+                                    n_domain_errors, stream);
+}
+int32_t cmx_ice_nucleation_rates_f64(const cmx_thermo_f64 *tps, const cmx_abifm_dust_f64 *dust, const cmx_koop2000_f64 *koop,
+                                     uint32_t flags, int64_t n, const double *T, const double *a_w, const double *r,
+                                     double *delta_a_w, double *J_het, double *J_hom, double *rate_het, double *rate_hom,
+                                     int64_t *n_domain_errors, void *stream) {
+    return cmx::icenuc_entry<double>(tps, dust, koop, flags, n, T, a_w, r, delta_a_w, J_het, J_hom, rate_het, rate_hom,
+                                     n_domain_errors, stream);
+}
+int32_t cmx_water_activity_f32(const cmx_thermo_f32 *tps, int64_t n, const float *T, const float *e, float *a_w_ice,
+                               float *a_w_eT, void *stream) {
+    return cmx::water_activity_entry<float>(tps, n, T, e, a_w_ice, a_w_eT, stream);
+}
+int32_t cmx_water_activity_f64(const cmx_thermo_f64 *tps, int64_t n, const double *T, const double *e, double *a_w_ice,
+                               double *a_w_eT, void *stream) {
+    return cmx::water_activity_entry<double>(tps, n, T, e, a_w_ice, a_w_eT, stream);
+}
+
+}  // extern "C"

@@ -129,7 +129,14 @@ typedef enum cmx_status {
     typedef struct cmx_rain_vel_##SFX {                                                        \
         cmx_sb2006_vel_##SFX sb2006;                                                           \
         cmx_chen2022_rain_vel_##SFX chen2022;                                                  \
-    } cmx_rain_vel_##SFX;
+    } cmx_rain_vel_##SFX;                                                                      \
+    /* Koop2000 — src/parameters/IceNucleation.jl:38-55 */                                     \
+    typedef struct cmx_koop2000_##SFX {                                                        \
+        FT delta_a_w_min, delta_a_w_max, c1, c2, c3, c4, linear_c1, linear_c2;                 \
+    } cmx_koop2000_##SFX;                                                                      \
+    /* the two ABIFM fields of a dust type (Kaolinite, Illite, DesertDust, …:                */ \
+    /* src/parameters/AerosolKaolinite.jl:19-21 etc.): log10 J = m·Δa_w + c  [cm⁻² s⁻¹]      */ \
+    typedef struct cmx_abifm_dust_##SFX { FT ABIFM_m, ABIFM_c; } cmx_abifm_dust_##SFX;
 
 CMX_DECLARE_PARAM_STRUCTS(float, f32)
 CMX_DECLARE_PARAM_STRUCTS(double, f64)
@@ -220,6 +227,44 @@ int32_t cmx_sb2006_process_rates_f64(
     const double *q_tot, const double *q_lcl, const double *q_rai, const double *N_lcl,
     const double *N_rai, const double *rho, const double *T,
     double *const out[CMX_SB2006_NPROC], void *stream);
+
+/* ---------------------------------------------------------------------------
+ * (4) Ice nucleation rates — ABIFM immersion freezing + Koop-2000 homogeneous freezing.
+ *
+ * Replaces the KA wrappers IceNucleation_ABIFM_J_kernel!, IceNucleation_homogeneous_J_kernel!,
+ * Common_a_w_ice_kernel! (test/gpu_tests.jl:294-362) and the per-droplet products the parcel
+ * model forms from them (parcel/ParcelTendencies.jl:120-133,194-205):
+ *   Δa_w    = a_w − CO.a_w_ice(tps, T)                         src/Common.jl:267-271
+ *   J_het   = CMI_het.ABIFM_J(dust, Δa_w)          [m⁻² s⁻¹]  src/IceNucleation.jl:124-134
+ *   J_hom   = CMI_hom.homogeneous_J_cubic(ip, Δa_w) [m⁻³ s⁻¹]  src/IceNucleation.jl:557-565
+ *             (or homogeneous_J_linear, :581-584, with CMX_ICENUC_HOM_LINEAR)
+ *   rate_het = J_het · 4π r²    rate_hom = J_hom · 4/3 π r³    [s⁻¹ per droplet]
+ * Inputs per point: T [K], a_w [-], r [m].  Any output column may be NULL.
+ * homogeneous_J_cubic THROWS DomainError outside [Δa_w_min, Δa_w_max]; a device kernel cannot:
+ * such points get J_hom = rate_hom = NaN and, if `n_domain_errors` (device, int64, caller-zeroed)
+ * is non-NULL, are counted into it atomically.
+ * ------------------------------------------------------------------------- */
+#define CMX_ICENUC_HOM_LINEAR   (1u << 0)   /* homogeneous_J_linear instead of homogeneous_J_cubic */
+
+int32_t cmx_ice_nucleation_rates_f32(
+    const cmx_thermo_f32 *tps, const cmx_abifm_dust_f32 *dust, const cmx_koop2000_f32 *koop,
+    uint32_t flags, int64_t n, const float *T, const float *a_w, const float *r,
+    float *delta_a_w, float *J_het, float *J_hom, float *rate_het, float *rate_hom,
+    int64_t *n_domain_errors, void *stream);
+
+int32_t cmx_ice_nucleation_rates_f64(
+    const cmx_thermo_f64 *tps, const cmx_abifm_dust_f64 *dust, const cmx_koop2000_f64 *koop,
+    uint32_t flags, int64_t n, const double *T, const double *a_w, const double *r,
+    double *delta_a_w, double *J_het, double *J_hom, double *rate_het, double *rate_hom,
+    int64_t *n_domain_errors, void *stream);
+
+/* CO.a_w_ice(tps, T) and CO.a_w_eT(tps, e, T) over columns — src/Common.jl:250-253,267-271
+ * (KA wrappers Common_a_w_ice_kernel!, Common_a_w_eT_kernel!, test/gpu_tests.jl:340-362).
+ * `e` may be NULL iff `a_w_eT` is NULL. */
+int32_t cmx_water_activity_f32(const cmx_thermo_f32 *tps, int64_t n, const float *T, const float *e,
+                               float *a_w_ice, float *a_w_eT, void *stream);
+int32_t cmx_water_activity_f64(const cmx_thermo_f64 *tps, int64_t n, const double *T, const double *e,
+                               double *a_w_ice, double *a_w_eT, void *stream);
 
 /* ---------------------------------------------------------------------------
  * (3) Optional diagnostic sums over one rank's shard: per-column

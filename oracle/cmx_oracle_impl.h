@@ -622,6 +622,65 @@ void FN(cmxo_sb2006_process_rates)(const TY(cmx_warm_rain_2m) * wr, const TY(cmx
 #undef PUT
 }
 
+/* ---- Common.jl water activities + IceNucleation.jl ------------------------ */
+/* CO.a_w_ice — src/Common.jl:267-271 */
+static inline FT FN(o_a_w_ice)(const TY(cmx_thermo) * tps, FT T) {
+    return FN(o_psat_ice)(tps, T) / FN(o_psat_liquid)(tps, T);
+}
+/* CO.a_w_eT — src/Common.jl:250-253 */
+static inline FT FN(o_a_w_eT)(const TY(cmx_thermo) * tps, FT e, FT T) {
+    return e / FN(o_psat_liquid)(tps, T);
+}
+/* CMI_het.ABIFM_J — src/IceNucleation.jl:124-134 */
+static inline FT FN(o_ABIFM_J)(const TY(cmx_abifm_dust) * dust, FT delta_a_w) {
+    FT logJ = dust->ABIFM_m * delta_a_w + dust->ABIFM_c;
+    return M_POW((FT)10, logJ + 4);
+}
+/* CMI_hom.homogeneous_J_cubic — src/IceNucleation.jl:557-565; the DomainError becomes NaN + *err = 1 */
+static inline FT FN(o_homogeneous_J_cubic)(const TY(cmx_koop2000) * ip, FT d, int *err) {
+    if (!(ip->delta_a_w_min <= d && d <= ip->delta_a_w_max)) {
+        *err = 1;
+        return (FT)NAN;
+    }
+    FT logJ = ip->c1 + ip->c2 * d - ip->c3 * (d * d) + ip->c4 * (d * d * d);
+    return M_POW((FT)10, logJ + 6);
+}
+/* CMI_hom.homogeneous_J_linear — src/IceNucleation.jl:581-584 */
+static inline FT FN(o_homogeneous_J_linear)(const TY(cmx_koop2000) * ip, FT d) {
+    FT logJ = ip->linear_c2 * d + ip->linear_c1;
+    return M_POW((FT)10, logJ + 6);
+}
+
+/* oracle twin of cmx_ice_nucleation_rates_* (include/cmx.h); returns the number of domain errors */
+int64_t FN(cmxo_ice_nucleation_rates)(const TY(cmx_thermo) * tps, const TY(cmx_abifm_dust) * dust,
+                                     const TY(cmx_koop2000) * koop, uint32_t flags, int64_t n,
+                                     const FT *T, const FT *a_w, const FT *r, FT *delta_a_w, FT *J_het,
+                                     FT *J_hom, FT *rate_het, FT *rate_hom) {
+    const FT pi = (FT)M_PI;
+    int64_t nerr = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        FT d = a_w[i] - FN(o_a_w_ice)(tps, T[i]);
+        FT jh = FN(o_ABIFM_J)(dust, d);
+        int err = 0;
+        FT jo = (flags & CMX_ICENUC_HOM_LINEAR) ? FN(o_homogeneous_J_linear)(koop, d)
+                                                : FN(o_homogeneous_J_cubic)(koop, d, &err);
+        nerr += err;
+        if (delta_a_w) delta_a_w[i] = d;
+        if (J_het) J_het[i] = jh;
+        if (J_hom) J_hom[i] = jo;
+        if (rate_het) rate_het[i] = jh * (4 * pi * (r[i] * r[i]));          /* J·A_aer   parcel/ParcelTendencies.jl:120-133 */
+        if (rate_hom) rate_hom[i] = jo * ((FT)4 / 3 * pi * (r[i] * r[i] * r[i])); /* J·V   parcel/ParcelTendencies.jl:194-205 */
+    }
+    return nerr;
+}
+void FN(cmxo_water_activity)(const TY(cmx_thermo) * tps, int64_t n, const FT *T, const FT *e, FT *a_w_ice,
+                            FT *a_w_eT) {
+    for (int64_t i = 0; i < n; ++i) {
+        if (a_w_ice) a_w_ice[i] = FN(o_a_w_ice)(tps, T[i]);
+        if (a_w_eT) a_w_eT[i] = FN(o_a_w_eT)(tps, e[i], T[i]);
+    }
+}
+
 /* scalar probes used by the known-answer tests */
 FT FN(cmxo_psat_liquid)(const TY(cmx_thermo) * p, FT T) { return FN(o_psat_liquid)(p, T); }
 FT FN(cmxo_psat_ice)(const TY(cmx_thermo) * p, FT T) { return FN(o_psat_ice)(p, T); }

@@ -114,6 +114,33 @@ def sb2006_process_rates(fam, wr, tps, vel, flags, q_tot, q_lcl, q_rai, N_lcl, N
     return dict(zip(_abi.SB2006_PROCESS_COLUMNS, outs))
 
 
+def ice_nucleation_rates(fam, tps, dust, koop, flags, T, a_w, r):
+    """Oracle twin of cmx_ice_nucleation_rates_*: dict of the five columns + 'n_domain_errors'."""
+    ins = [_col(fam, a) for a in (T, a_w, r)]
+    n = ins[0][0].size
+    names = ["delta_a_w", "J_het", "J_hom", "rate_het", "rate_hom"]
+    outs = {k: np.empty(n, dtype=NP[fam.sfx]) for k in names}
+    fn = getattr(lib(), f"cmxo_ice_nucleation_rates_{fam.sfx}")
+    fn.restype = C.c_int64
+    nerr = fn(C.byref(tps), C.byref(dust), C.byref(koop), C.c_uint32(flags), C.c_int64(n), *[p for _, p in ins],
+              *[outs[k].ctypes.data_as(C.c_void_p) for k in names])
+    outs["n_domain_errors"] = int(nerr)
+    return outs
+
+
+def water_activity(fam, tps, T, e=None):
+    Tn, Tp = _col(fam, T)
+    n = Tn.size
+    ice = np.empty(n, dtype=NP[fam.sfx])
+    eT = np.empty(n, dtype=NP[fam.sfx]) if e is not None else None
+    en, ep = _col(fam, e) if e is not None else (None, None)
+    fn = getattr(lib(), f"cmxo_water_activity_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(tps), C.c_int64(n), Tp, ep, ice.ctypes.data_as(C.c_void_p),
+       eT.ctypes.data_as(C.c_void_p) if eT is not None else None)
+    return ice, eT
+
+
 def psat_liquid(fam, tps, T):
     return getattr(lib(), f"cmxo_psat_liquid_{fam.sfx}")(C.byref(tps), T)
 
