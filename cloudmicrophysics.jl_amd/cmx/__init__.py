@@ -13,6 +13,7 @@ from .bulk_tendencies import (Chen2022VelTypeRain, Microphysics2Moment, SB2006Pr
                               SB2006VelType, WarmRainTendencies2M, bulk_microphysics_tendencies,
                               column_sums, sb2006_process_rates)
 
-from .ice_nucleation import IceNucleationRates, a_w_eT, a_w_ice, ice_nucleation_rates  # noqa: F401
+from .ice_nucleation import (IceNucleationRates, a_w_eT, a_w_ice, domain_error_count,  # noqa: F401
+                             ice_nucleation_rates)
 
 __version__ = "0.1.0"

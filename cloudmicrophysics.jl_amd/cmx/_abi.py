@@ -17,6 +17,8 @@ CMX_VEL_SB2006 = 1 << 1
 CMX_VEL_CHEN2022 = 1 << 2
 
 CMX_ICENUC_HOM_LINEAR = 1 << 0
+CMX_ICENUC_ERR_SLOTS = 64
+CMX_ICENUC_ERR_WORDS = 1024
 
 CMX_OK = 0
 CMX_ERR_BAD_ARG = -1

@@ -30,7 +30,8 @@ def ice_nucleation_rates(tps, dust, koop, T, a_w, r=None, *, linear=False, want=
     `want` selects the output columns among delta_a_w, J_het [m⁻² s⁻¹], J_hom [m⁻³ s⁻¹], rate_het = J_het·4πr²,
     rate_hom = J_hom·4/3πr³ [s⁻¹].  Where the reference's `homogeneous_J_cubic` would throw (Δa_w outside
     [Δa_w_min, Δa_w_max], src/IceNucleation.jl:558-562) J_hom/rate_hom are NaN and the point is counted in the
-    device counter `n_domain_errors` (a 1-element int64 tensor; reading it synchronises, the call itself does not).
+    device buffer `n_domain_errors` (CMX_ICENUC_ERR_WORDS int64 slot counters; `domain_error_count(result)` sums
+    them — that read synchronises, the call itself does not).
     `linear=True` uses `homogeneous_J_linear` (:581-584), which has no domain restriction."""
     cols = (T, a_w) if r is None else (T, a_w, r)
     ref = _check_cols(cols, ("T", "a_w", "r"))
@@ -49,7 +50,8 @@ def ice_nucleation_rates(tps, dust, koop, T, a_w, r=None, *, linear=False, want=
         nerr = out.n_domain_errors
     else:
         outs = {k: (torch.empty_like(ref) if k in want else None) for k in names}
-        nerr = torch.zeros(1, dtype=torch.int64, device=ref.device) if (count_domain_errors and not linear) else None
+        nerr = (torch.zeros(_abi.CMX_ICENUC_ERR_WORDS, dtype=torch.int64, device=ref.device)
+                if (count_domain_errors and not linear) else None)
     s = stream if stream is not None else torch.cuda.current_stream(ref.device)
     fn = getattr(_lib.lib(), f"cmx_ice_nucleation_rates_{fam.sfx}")
     with torch.cuda.device(ref.device):
@@ -57,6 +59,11 @@ def ice_nucleation_rates(tps, dust, koop, T, a_w, r=None, *, linear=False, want=
                 _ptr(T), _ptr(a_w), _ptr(r), *[_ptr(outs[k]) for k in names], _ptr(nerr), C.c_void_p(s.cuda_stream))
     _lib.check(fn.__name__, st)
     return IceNucleationRates(*[outs[k] for k in names], nerr)
+
+
+def domain_error_count(result: IceNucleationRates) -> int:
+    """Number of points where the reference would have thrown DomainError (sum of the slot counters)."""
+    return 0 if result.n_domain_errors is None else int(result.n_domain_errors.sum().item())
 
 
 def a_w_ice(tps, T, stream=None) -> torch.Tensor:

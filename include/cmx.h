@@ -241,10 +241,15 @@ int32_t cmx_sb2006_process_rates_f64(
  *   rate_het = J_het · 4π r²    rate_hom = J_hom · 4/3 π r³    [s⁻¹ per droplet]
  * Inputs per point: T [K], a_w [-], r [m].  Any output column may be NULL.
  * homogeneous_J_cubic THROWS DomainError outside [Δa_w_min, Δa_w_max]; a device kernel cannot:
- * such points get J_hom = rate_hom = NaN and, if `n_domain_errors` (device, int64, caller-zeroed)
- * is non-NULL, are counted into it atomically.
+ * such points get J_hom = rate_hom = NaN and, if `n_domain_errors` is non-NULL, are counted.
+ * `n_domain_errors` is a device array of CMX_ICENUC_ERR_WORDS int64, zeroed by the caller; the number of
+ * domain-error points is the SUM of all its words (counts accumulate across calls until re-zeroed).
+ * Only every (WORDS/SLOTS)-th word is written: one 128-byte line per slot, so that the ≈1e5 concurrent
+ * workgroups of a 1e8-point launch do not serialise on a single L2 atomic unit.
  * ------------------------------------------------------------------------- */
 #define CMX_ICENUC_HOM_LINEAR   (1u << 0)   /* homogeneous_J_linear instead of homogeneous_J_cubic */
+#define CMX_ICENUC_ERR_SLOTS    64
+#define CMX_ICENUC_ERR_WORDS    1024        /* int64 words in the n_domain_errors buffer (8 KiB) */
 
 int32_t cmx_ice_nucleation_rates_f32(
     const cmx_thermo_f32 *tps, const cmx_abifm_dust_f32 *dust, const cmx_koop2000_f32 *koop,
