@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=100_000_000, help="grid points per GPU")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--workload", choices=["sb2006", "icenuc"], default="sb2006")
+    ap.add_argument("--workload", choices=["sb2006", "icenuc", "mp1m"], default="sb2006")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the bounded baseline sample")
     ap.add_argument("--diagnostics", action="store_true",
@@ -138,6 +138,35 @@ def setup_icenuc(args, dev, dtype, rank):
     return list(state), step, desc, cpu_run
 
 
+def setup_mp1m(args, dev, dtype, rank):
+    import torch
+
+    import cmx
+    from cmx import _abi
+    from cmx import parameters as P
+    from cmx import synthetic
+    state = synthetic.mp1m_state(args.points, dtype=dtype, device=dev, seed=1234 + rank)
+    mp, tps = P.Microphysics1MParams(args.dtype), P.ThermodynamicsParameters(args.dtype)
+    out = cmx.Tendencies1M(*[torch.empty_like(state.rho) for _ in range(4)])
+    mode, scheme = cmx.Instantaneous(), cmx.Microphysics1Moment()
+
+    def step():
+        cmx.bulk_microphysics_tendencies_1m(mode, scheme, mp, tps, *state, out=out)
+
+    def cpu_run(ob, cols, threads):
+        fam = _abi.family(args.dtype)
+        return lambda: ob.mp1m(fam, mp.c, tps, mp.flags, *cols, nthreads=threads, want_sources=False)
+
+    desc = {
+        "metric": "grid-points/sec 1-moment (Marshall-Palmer) tendency sweep",
+        "bytes_per_point": {"f32": 44, "f64": 88}[args.dtype],      # 7 in + 4 out
+        "kernel": "mp1m_tendencies_kernel",
+        "workload": "Microphysics1M Instantaneous bulk tendencies, default Microphysics1MOptions (13 processes)",
+        "columns_in": 7, "columns_out": 4, "diag_cols": list(out),
+    }
+    return list(state), step, desc, cpu_run
+
+
 def cpu_baseline(args, cols_np, desc, cpu_run):
     """The oracle — a C restatement of the reference's scalar arithmetic (kind 'port'; the Julia reference cannot
     run here) — timed on the host cores over repeated passes of a bounded sample of the same synthetic workload."""
@@ -180,7 +209,8 @@ def main():
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     n = args.points                                          # weak scaling: fixed work per GPU
     # rank r owns shard r of the global [0, world·n) index space: disjoint seeds, no exchange
-    state, kernel_step, desc, cpu_run = {"sb2006": setup_sb2006, "icenuc": setup_icenuc}[args.workload](args, dev, dtype, rank)
+    setup = {"sb2006": setup_sb2006, "icenuc": setup_icenuc, "mp1m": setup_mp1m}[args.workload]
+    state, kernel_step, desc, cpu_run = setup(args, dev, dtype, rank)
 
     def step():
         kernel_step()

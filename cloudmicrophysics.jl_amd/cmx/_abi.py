@@ -20,6 +20,39 @@ CMX_ICENUC_HOM_LINEAR = 1 << 0
 CMX_ICENUC_ERR_SLOTS = 64
 CMX_ICENUC_ERR_WORDS = 1024
 
+# Microphysics1MOptions bits (include/cmx.h §5)
+CMX_1M_CLOUD_LIQUID_FORMATION = 1 << 0
+CMX_1M_CLOUD_ICE_FORMATION_CONST = 1 << 1
+CMX_1M_CLOUD_ICE_FORMATION_TDEP = 1 << 2
+CMX_1M_CLOUD_ICE_MELT = 1 << 3
+CMX_1M_RAIN_ACNV_KESSLER = 1 << 4
+CMX_1M_RAIN_ACNV_PRESCRIBED_ND = 1 << 5
+CMX_1M_SNOW_ACNV_NO_SUPERSAT = 1 << 6
+CMX_1M_SNOW_ACNV_WITH_SUPERSAT = 1 << 7
+CMX_1M_RAIN_EVAPORATION = 1 << 8
+CMX_1M_SNOW_SUBLIMATION_ONLY = 1 << 9
+CMX_1M_SNOW_DEP_AND_SUBL = 1 << 10
+CMX_1M_SNOW_MELT = 1 << 11
+CMX_1M_ACCR_LCL_RAI = 1 << 12
+CMX_1M_ACCR_LCL_SNO = 1 << 13
+CMX_1M_ACCR_ICL_RAI = 1 << 14
+CMX_1M_ACCR_ICL_SNO = 1 << 15
+CMX_1M_ACCR_RAI_SNO = 1 << 16
+CMX_1M_DEFAULT_OPTIONS = (CMX_1M_CLOUD_LIQUID_FORMATION | CMX_1M_CLOUD_ICE_FORMATION_CONST | CMX_1M_CLOUD_ICE_MELT |
+                          CMX_1M_RAIN_ACNV_KESSLER | CMX_1M_SNOW_ACNV_NO_SUPERSAT | CMX_1M_RAIN_EVAPORATION |
+                          CMX_1M_SNOW_DEP_AND_SUBL | CMX_1M_SNOW_MELT | CMX_1M_ACCR_LCL_RAI | CMX_1M_ACCR_LCL_SNO |
+                          CMX_1M_ACCR_ICL_RAI | CMX_1M_ACCR_ICL_SNO | CMX_1M_ACCR_RAI_SNO)
+
+# cmx_mp1m_source_column
+MP1M_SOURCE_COLUMNS = (
+    "S_phase_change_vap_lcl", "S_phase_change_vap_icl", "S_acnv_lcl_rai", "S_acnv_icl_sno",
+    "S_accr_lcl_rai", "S_accr_lcl_sno_cold", "S_accr_lcl_sno_warm", "S_accr_melt_lcl_sno",
+    "S_accr_icl_rai", "S_accr_freeze_icl_rai", "S_accr_icl_sno",
+    "S_accr_rai_sno_cold", "S_accr_rai_sno_warm", "S_accr_melt_rai_sno",
+    "S_phase_change_vap_rai", "S_phase_change_vap_sno", "S_melt_icl_lcl", "S_melt_sno_rai",
+)
+CMX_MP1M_NSRC = len(MP1M_SOURCE_COLUMNS)
+
 CMX_OK = 0
 CMX_ERR_BAD_ARG = -1
 CMX_ERR_HIP = -2
@@ -69,7 +102,7 @@ def _family(ft, sfx):
         ("condevap_tau_relax", ft), ("subdep_tau_relax", ft)])
     ns.thermo = _struct(f"cmx_thermo_{sfx}",
                         s("R_v", "R_d", "cp_d", "cp_v", "cp_l", "cp_i", "LH_v0", "LH_s0", "T_0",
-                          "T_triple", "press_triple", "T_freeze"))
+                          "T_triple", "press_triple", "T_freeze", "cv_l"))
     ns.sb2006_vel = _struct(f"cmx_sb2006_vel_{sfx}", s("rho_0", "aR", "bR", "cR", "rho_w", "nu_air", "grav"))
     ns.chen2022_rain_vel = _struct(f"cmx_chen2022_rain_vel_{sfx}", [
         ("rho_0", ft), ("a", ft * 3), ("a3_pow", ft), ("b", ft * 3), ("b_rho", ft), ("c", ft * 3)])
@@ -77,6 +110,33 @@ def _family(ft, sfx):
     ns.koop2000 = _struct(f"cmx_koop2000_{sfx}",
                           s("delta_a_w_min", "delta_a_w_max", "c1", "c2", "c3", "c4", "linear_c1", "linear_c2"))
     ns.abifm_dust = _struct(f"cmx_abifm_dust_{sfx}", s("ABIFM_m", "ABIFM_c"))
+    # ---- 1-moment scheme
+    ns.particle_mass = _struct(f"cmx_particle_mass_{sfx}", s("r0", "m0", "me", "delta_m", "chi_m", "gamma_coeff"))
+    ns.particle_area = _struct(f"cmx_particle_area_{sfx}", s("a0", "ae", "delta_a", "chi_a"))
+    ns.ventilation = _struct(f"cmx_ventilation_{sfx}", s("a", "b"))
+    ns.acnv_1m = _struct(f"cmx_acnv_1m_{sfx}", s("tau", "q_threshold", "k"))
+    ns.var_timescale_acnv = _struct(f"cmx_var_timescale_acnv_{sfx}", s("tau", "alpha", "Nc"))
+    ns.cloud_liquid = _struct(f"cmx_cloud_liquid_{sfx}", s("rho_w", "r_eff", "N_0"))
+    ns.cloud_ice = _struct(f"cmx_cloud_ice_{sfx}", [("n0", ft), ("mass", ns.particle_mass)] + s("rho_i", "r_eff", "N_0"))
+    ns.rain = _struct(f"cmx_rain_{sfx}", [("n0", ft), ("mass", ns.particle_mass), ("area", ns.particle_area),
+                                          ("vent", ns.ventilation)])
+    ns.snow = _struct(f"cmx_snow_{sfx}", s("mu", "nu") + [("mass", ns.particle_mass), ("area", ns.particle_area),
+                                                         ("vent", ns.ventilation)] +
+                      s("phi", "kappa", "rho_i", "gamma_aspect_oblate", "gamma_aspect_prolate"))
+    ns.blk1m_vel_rain = _struct(f"cmx_blk1m_vel_rain_{sfx}",
+                                s("r0", "ve", "delta_v", "chi_v", "rho_w", "C_drag", "grav", "gamma_vent", "gamma_term",
+                                  "gamma_accr", "gamma_accr_rain_sink"))
+    ns.blk1m_vel_snow = _struct(f"cmx_blk1m_vel_snow_{sfx}",
+                                s("r0", "ve", "delta_v", "chi_v", "v0", "gamma_vent", "gamma_term", "gamma_accr"))
+    ns.process_params_1m = _struct(f"cmx_process_params_1m_{sfx}", s(
+        "cloud_liquid_formation_tau_relax", "cloud_ice_formation_tau_relax") + [
+        ("rain_autoconversion", ns.acnv_1m), ("rain_autoconversion_nd", ns.var_timescale_acnv),
+        ("snow_autoconversion", ns.acnv_1m)] + s(
+        "r_ice_snow", "e_lcl_rai", "e_lcl_sno", "e_icl_rai", "e_icl_sno", "e_rai_sno", "coeff_disp"))
+    ns.microphysics_1m = _struct(f"cmx_microphysics_1m_{sfx}", [
+        ("process_params", ns.process_params_1m), ("cloud_liquid", ns.cloud_liquid), ("cloud_ice", ns.cloud_ice),
+        ("rain", ns.rain), ("snow", ns.snow), ("air_properties", ns.air_properties),
+        ("vel_rain", ns.blk1m_vel_rain), ("vel_snow", ns.blk1m_vel_snow)])
     return ns
 
 

@@ -54,6 +54,15 @@ def _declare(lib):
         f = getattr(lib, f"cmx_water_activity_{s}")
         f.restype = i32
         f.argtypes = [C.POINTER(fam.thermo), i64] + [vp] * 4 + [vp]
+        f = getattr(lib, f"cmx_mp1m_tendencies_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.microphysics_1m), C.POINTER(fam.thermo), u32, i64] + [vp] * 11 + [vp]
+        f = getattr(lib, f"cmx_mp1m_source_terms_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.microphysics_1m), C.POINTER(fam.thermo), u32, i64] + [vp] * 7 + [C.POINTER(vp), vp]
+        f = getattr(lib, f"cmx_mp1m_terminal_velocity_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.microphysics_1m), C.POINTER(fam.chen2022_rain_vel), i64] + [vp] * 6 + [vp]
         f = getattr(lib, f"cmx_column_sums_{s}")
         f.restype = i32
         f.argtypes = [i32, C.POINTER(vp), i64, vp, vp]

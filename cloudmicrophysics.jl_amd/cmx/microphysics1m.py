@@ -1,0 +1,104 @@
+"""One-moment (Marshall–Palmer) scheme over columns — host-side mirror of the 1M entry of
+`CloudMicrophysics.BulkMicrophysicsTendencies` and of `CloudMicrophysics.Microphysics1M.terminal_velocity`
+(include/cmx.h §5).
+
+Reference broadcasts being replaced:
+
+    BMT.bulk_microphysics_tendencies.(Ref(BMT.Instantaneous()), Ref(BMT.Microphysics1Moment()), Ref(mp), Ref(tps),
+                                      ρ, T, q_tot, q_lcl, q_icl, q_rai, q_sno)        # BMT:505-514
+    @. w = CM1.terminal_velocity(rain, vel, ρ, q)                                      # test/gpu_clima_core_test.jl:39-42
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import namedtuple
+
+import torch
+
+from . import _abi, _lib
+from .bulk_tendencies import _check_cols, _fam_of, _ptr
+from .parameters import Chen2022VelTypeRain, Microphysics1MParams
+
+
+class Microphysics1Moment:
+    """BMT.Microphysics1Moment — scheme tag (src/BulkMicrophysicsTendencies.jl:52-56)."""
+
+
+class Instantaneous:
+    """BMT.Instantaneous — tendency mode tag: raw point-wise tendencies (BMT:84-90).  `LinearizedAverage` is not on
+    this path yet."""
+
+
+Tendencies1M = namedtuple("Tendencies1M", ["dq_lcl_dt", "dq_icl_dt", "dq_rai_dt", "dq_sno_dt"])
+SourceTerms1M = namedtuple("SourceTerms1M", _abi.MP1M_SOURCE_COLUMNS)
+TerminalVelocities1M = namedtuple("TerminalVelocities1M", ["vt_rai_blk1m", "vt_sno_blk1m", "vt_rai_chen"])
+
+_NAMES = ("rho", "T", "q_tot", "q_lcl", "q_icl", "q_rai", "q_sno")
+
+
+def _prep(mp, tps, cols):
+    if not isinstance(mp, Microphysics1MParams):
+        raise TypeError("mp must be Microphysics1MParams")
+    ref = _check_cols(cols, _NAMES)
+    fam = _fam_of(ref)
+    if fam is not mp.fam or not isinstance(tps, fam.thermo):
+        raise TypeError("parameter float type does not match the state columns")
+    return ref, fam
+
+
+def bulk_microphysics_tendencies_1m(mode, scheme, mp, tps, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno, *, out=None,
+                                    stream=None) -> Tendencies1M:
+    """1-moment tendencies over columns (Instantaneous mode) — BMT:505-514 → :141-252."""
+    if not isinstance(mode, Instantaneous) or not isinstance(scheme, Microphysics1Moment):
+        raise TypeError("only (Instantaneous(), Microphysics1Moment()) is on this path")
+    cols = (rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno)
+    ref, fam = _prep(mp, tps, cols)
+    if out is None:
+        out = Tendencies1M(*[torch.empty_like(ref) for _ in range(4)])
+    else:
+        _check_cols([ref] + list(out), ["rho"] + ["out"] * 4)
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_mp1m_tendencies_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(mp.c), C.byref(tps), mp.flags, ref.numel(), *[_ptr(t) for t in cols], *[_ptr(o) for o in out],
+                C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return out
+
+
+def microphysics_source_terms_1m(mp, tps, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno, *, stream=None) -> SourceTerms1M:
+    """The 18 individual source terms of `_microphysics_source_terms` (BMT:141-217) over columns."""
+    cols = (rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno)
+    ref, fam = _prep(mp, tps, cols)
+    outs = [torch.empty_like(ref) for _ in range(_abi.CMX_MP1M_NSRC)]
+    arr = (C.c_void_p * _abi.CMX_MP1M_NSRC)(*[o.data_ptr() for o in outs])
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_mp1m_source_terms_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(mp.c), C.byref(tps), mp.flags, ref.numel(), *[_ptr(t) for t in cols], arr, C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return SourceTerms1M(*outs)
+
+
+def terminal_velocity_1m(mp, rho, q_rai=None, q_sno=None, *, chen=False, stream=None) -> TerminalVelocities1M:
+    """Mass-weighted 1M fall speeds — CM1.terminal_velocity (CM1:223-270): Blk1M rain (needs q_rai), Blk1M snow
+    (needs q_sno) and, with `chen=True`, Chen-2022 rain."""
+    if not isinstance(mp, Microphysics1MParams):
+        raise TypeError("mp must be Microphysics1MParams")
+    cols = [c for c in (rho, q_rai, q_sno) if c is not None]
+    ref = _check_cols(cols, ("rho", "q", "q"))
+    fam = _fam_of(ref)
+    if fam is not mp.fam:
+        raise TypeError("parameter float type does not match the state columns")
+    if chen and q_rai is None:
+        raise ValueError("the Chen-2022 rain velocity needs q_rai")
+    mk = lambda on: torch.empty_like(ref) if on else None  # noqa: E731
+    out = TerminalVelocities1M(mk(q_rai is not None), mk(q_sno is not None), mk(chen))
+    ch = Chen2022VelTypeRain(fam.sfx) if chen else None
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_mp1m_terminal_velocity_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(mp.c), C.byref(ch) if ch is not None else None, ref.numel(), _ptr(rho), _ptr(q_rai), _ptr(q_sno),
+                *[_ptr(o) for o in out], C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return out

@@ -105,6 +105,44 @@ DEFAULT_PARAMETERS = {
     "KnopfAlpert2013_J_ABIFM_c_Kaolinite": -10.54758,
     "KnopfAlpert2013_J_ABIFM_m_Illite": 54.48075,
     "KnopfAlpert2013_J_ABIFM_c_Illite": -10.66873,
+    # ---- 1-moment scheme (docs/src/Microphysics1M.md:71-87,130-135,191-207, TerminalVelocity.md:63-70; pinned by the
+    # accretion / velocity / melt KATs test/gpu_tests.jl:627-630,737-743,778 — SURVEY §8c)
+    "isochoric_specific_heat_liquid": 4181.0,   # cv_l (= cp_l in Thermodynamics.jl)
+    "rain_drop_length_scale": 1e-3, "rain_mass_size_relation_coefficient_me": 3.0,
+    "rain_mass_size_relation_coefficient_delm": 0.0, "rain_mass_size_relation_coefficient_chim": 1.0,
+    "rain_cross_section_size_relation_coefficient_ae": 2.0, "rain_cross_section_size_relation_coefficient_dela": 0.0,
+    "rain_cross_section_size_relation_coefficient_chia": 1.0,
+    "rain_terminal_velocity_size_relation_coefficient_ve": 0.5,
+    "rain_terminal_velocity_size_relation_coefficient_delv": 0.0,
+    "rain_terminal_velocity_size_relation_coefficient_chiv": 1.0,
+    "rain_drop_size_distribution_coefficient_n0": 16e6, "rain_drop_drag_coefficient": 0.55,
+    "rain_ventilation_coefficient_a": 1.5, "rain_ventilation_coefficient_b": 0.53,
+    "snow_flake_length_scale": 1e-3, "snow_mass_size_relation_coefficient_me": 2.0,
+    "snow_mass_size_relation_coefficient_delm": 0.0, "snow_mass_size_relation_coefficient_chim": 1.0,
+    "snow_cross_section_size_relation_coefficient": 2.0, "snow_cross_section_size_relation_coefficient_dela": 0.0,
+    "snow_cross_section_size_relation_coefficient_chia": 1.0,
+    "snow_terminal_velocity_size_relation_coefficient": 0.25,
+    "snow_terminal_velocity_size_relation_coefficient_delv": 0.0,
+    "snow_terminal_velocity_size_relation_coefficient_chiv": 1.0,
+    "snow_flake_size_distribution_coefficient_mu": 4.36e9, "snow_flake_size_distribution_coefficient_nu": 0.63,
+    "snow_ventilation_coefficient_a": 0.65, "snow_ventilation_coefficient_b": 0.44,
+    "snow_apparent_density": 100.0,            # only enters the Chen-2022 snow velocity (not on this path); unpinned
+    "snow_aspect_ratio": 0.15, "snow_aspect_ratio_coefficient": 1.0 / 3.0,   # idem (unpinned)
+    "cloud_ice_crystals_length_scale": 1e-5, "cloud_ice_mass_size_relation_coefficient_me": 3.0,
+    "cloud_ice_mass_size_relation_coefficient_delm": 0.0, "cloud_ice_mass_size_relation_coefficient_chim": 1.0,
+    "cloud_ice_size_distribution_coefficient_n0": 2e7,
+    "cloud_ice_apparent_density": 500.0,       # back-solved from the ice accretion KATs
+    "liquid_cloud_effective_radius": 14e-6, "ice_cloud_effective_radius": 25e-6,            # not used by the rates
+    "cloud_liquid_sedimentation_number_concentration": 5e8, "cloud_ice_sedimentation_number_concentration": 5e5,  # idem
+    "rain_autoconversion_timescale": 1e3, "snow_autoconversion_timescale": 1e2,
+    "cloud_liquid_water_specific_humidity_autoconversion_threshold": 5e-4,
+    "cloud_ice_specific_humidity_autoconversion_threshold": 1e-6,
+    "threshold_smooth_transition_steepness": 2.0,   # ClimaParams default; the reference tests only bound it loosely
+    "Variable_time_scale_autoconversion_coeff_alpha": 0.73, "prescribed_cloud_droplet_number_concentration": 1e8,
+    "ice_snow_threshold_radius": 62.5e-6,
+    "cloud_liquid_rain_collision_efficiency": 0.8, "cloud_liquid_snow_collision_efficiency": 0.1,
+    "cloud_ice_rain_collision_efficiency": 1.0, "cloud_ice_snow_collision_efficiency": 0.1,
+    "rain_snow_collision_efficiency": 1.0, "rain_snow_velocity_dispersion_coefficient": 0.2,
 }
 
 # the reference's override file src/parameters/toml/SB2006_limiters.toml (used by its CPU tests,
@@ -156,7 +194,8 @@ def ThermodynamicsParameters(FT):
         cp_l=td["isobaric_specific_heat_liquid"], cp_i=td["isobaric_specific_heat_ice"],
         LH_v0=td["latent_heat_vaporization_at_reference"], LH_s0=td["latent_heat_sublimation_at_reference"],
         T_0=td["thermodynamics_temperature_reference"], T_triple=td["temperature_triple_point"],
-        press_triple=td["pressure_triple_point"], T_freeze=td["temperature_water_freeze"])
+        press_triple=td["pressure_triple_point"], T_freeze=td["temperature_water_freeze"],
+        cv_l=td["isochoric_specific_heat_liquid"])
 
 
 def AirProperties(FT):
@@ -315,6 +354,158 @@ def ABIFMDust(FT, ABIFM_m: float, ABIFM_c: float):
     """Any other dust type (DesertDust, ArizonaTestDust, …): the caller supplies its ABIFM m, c (their ClimaParams
     defaults are not in the reference tree and are pinned by no reference test)."""
     return _abi.family(FT).abifm_dust(ABIFM_m=ABIFM_m, ABIFM_c=ABIFM_c)
+
+
+# ---------------------------------------------------------------------------
+# 1-moment scheme
+# ---------------------------------------------------------------------------
+class _Option:
+    """Base of the process-option singletons (CMP.MicrophysicsOption, Microphysics1MOptions.jl:34-41)."""
+    flag = 0
+
+    def __repr__(self):
+        return type(self).__name__ + "()"
+
+
+def _opt(name, flag, doc):
+    return type(name, (_Option,), {"flag": flag, "__doc__": doc})
+
+
+CloudLiquidFormation = _opt("CloudLiquidFormation", _abi.CMX_1M_CLOUD_LIQUID_FORMATION, "Microphysics1MOptions.jl:75-82")
+ConstantTimescale = _opt("ConstantTimescale", _abi.CMX_1M_CLOUD_ICE_FORMATION_CONST, ":84-91")
+TemperatureDependent = _opt("TemperatureDependent", _abi.CMX_1M_CLOUD_ICE_FORMATION_TDEP, ":93-100 (unsupported on this path)")
+CloudIceMelt = _opt("CloudIceMelt", _abi.CMX_1M_CLOUD_ICE_MELT, ":199")
+Kessler1M = _opt("Kessler1M", _abi.CMX_1M_RAIN_ACNV_KESSLER, ":102-109")
+PrescribedNd = _opt("PrescribedNd", _abi.CMX_1M_RAIN_ACNV_PRESCRIBED_ND, ":111-118")
+NoSupersaturation = _opt("NoSupersaturation", _abi.CMX_1M_SNOW_ACNV_NO_SUPERSAT, ":120-127")
+WithSupersaturation = _opt("WithSupersaturation", _abi.CMX_1M_SNOW_ACNV_WITH_SUPERSAT, ":129-136")
+RainEvaporation = _opt("RainEvaporation", _abi.CMX_1M_RAIN_EVAPORATION, ":197")
+SublimationOnly = _opt("SublimationOnly", _abi.CMX_1M_SNOW_SUBLIMATION_ONLY, ":193")
+DepositionAndSublimation = _opt("DepositionAndSublimation", _abi.CMX_1M_SNOW_DEP_AND_SUBL, ":195")
+SnowMelt = _opt("SnowMelt", _abi.CMX_1M_SNOW_MELT, ":201")
+CloudLiquidRainAccretion = _opt("CloudLiquidRainAccretion", _abi.CMX_1M_ACCR_LCL_RAI, ":138-145")
+CloudLiquidSnowAccretion = _opt("CloudLiquidSnowAccretion", _abi.CMX_1M_ACCR_LCL_SNO, ":147-155")
+CloudIceRainAccretion = _opt("CloudIceRainAccretion", _abi.CMX_1M_ACCR_ICL_RAI, ":157-165")
+CloudIceSnowAccretion = _opt("CloudIceSnowAccretion", _abi.CMX_1M_ACCR_ICL_SNO, ":167-174")
+RainSnowAccretion = _opt("RainSnowAccretion", _abi.CMX_1M_ACCR_RAI_SNO, ":176-184")
+
+
+class Microphysics1MOptions:
+    """CMP.Microphysics1MOptions(; …) — src/parameters/Microphysics1MOptions.jl:257-286.  `None` disables a process."""
+    _defaults = dict(
+        cloud_liquid_formation=CloudLiquidFormation, cloud_ice_formation=ConstantTimescale, cloud_ice_melt=CloudIceMelt,
+        rain_autoconversion=Kessler1M, snow_autoconversion=NoSupersaturation,
+        rain_condensation_evaporation=RainEvaporation, snow_deposition_sublimation=DepositionAndSublimation,
+        snow_melt=SnowMelt, cloud_liquid_rain_accretion=CloudLiquidRainAccretion,
+        cloud_liquid_snow_accretion=CloudLiquidSnowAccretion, cloud_ice_rain_accretion=CloudIceRainAccretion,
+        cloud_ice_snow_accretion=CloudIceSnowAccretion, rain_snow_accretion=RainSnowAccretion)
+    _allowed = dict(
+        cloud_liquid_formation=(CloudLiquidFormation,), cloud_ice_formation=(ConstantTimescale, TemperatureDependent),
+        cloud_ice_melt=(CloudIceMelt,), rain_autoconversion=(Kessler1M, PrescribedNd),
+        snow_autoconversion=(NoSupersaturation, WithSupersaturation), rain_condensation_evaporation=(RainEvaporation,),
+        snow_deposition_sublimation=(SublimationOnly, DepositionAndSublimation), snow_melt=(SnowMelt,),
+        cloud_liquid_rain_accretion=(CloudLiquidRainAccretion,), cloud_liquid_snow_accretion=(CloudLiquidSnowAccretion,),
+        cloud_ice_rain_accretion=(CloudIceRainAccretion,), cloud_ice_snow_accretion=(CloudIceSnowAccretion,),
+        rain_snow_accretion=(RainSnowAccretion,))
+
+    def __init__(self, **kw):
+        unknown = set(kw) - set(self._defaults)
+        if unknown:
+            raise TypeError(f"unknown option field(s) {sorted(unknown)}")
+        self.flags = 0
+        for name, default in self._defaults.items():
+            opt = kw.get(name, default())
+            if isinstance(opt, type):
+                opt = opt()
+            if opt is not None and not isinstance(opt, self._allowed[name]):
+                raise TypeError(f"{name}: expected one of {[c.__name__ for c in self._allowed[name]]} or None")
+            setattr(self, name, opt)
+            self.flags |= opt.flag if opt is not None else 0
+
+
+def _particle_mass(fam, r0, m0, me, dm, chim):
+    return fam.particle_mass(r0=r0, m0=m0, me=me, delta_m=dm, chi_m=chim, gamma_coeff=math.gamma(me + dm + 1))
+
+
+class Microphysics1MParams:
+    """CMP.Microphysics1MParams(FT; options…) — src/parameters/Microphysics1MParams.jl:63-103.
+
+    `.c` is the C struct `cmx_microphysics_1m`, `.processes` the Microphysics1MOptions (→ the `flags` word).
+    Host-derived fields follow the reference constructors: m0, a0, gamma_coeff (Microphysics1M.jl params :127-139,
+    180-206, 263-289), gamma_vent/term/accr/accr_rain_sink and snow v0 (TerminalVelocity.jl:57-63,121-126)."""
+
+    def __init__(self, FT, **options):
+        td = _td(FT)
+        fam = self.fam = td.fam
+        self.processes = Microphysics1MOptions(**options)
+        g = td.__getitem__
+        c = self.c = fam.microphysics_1m()
+        pi = math.pi
+        # Rain
+        r0, me, dm, chim = g("rain_drop_length_scale"), g("rain_mass_size_relation_coefficient_me"), g(
+            "rain_mass_size_relation_coefficient_delm"), g("rain_mass_size_relation_coefficient_chim")
+        ae, da, chia = g("rain_cross_section_size_relation_coefficient_ae"), g(
+            "rain_cross_section_size_relation_coefficient_dela"), g("rain_cross_section_size_relation_coefficient_chia")
+        ve, dv, chiv = g("rain_terminal_velocity_size_relation_coefficient_ve"), g(
+            "rain_terminal_velocity_size_relation_coefficient_delv"), g("rain_terminal_velocity_size_relation_coefficient_chiv")
+        c.rain.n0 = g("rain_drop_size_distribution_coefficient_n0")
+        c.rain.mass = _particle_mass(fam, r0, g("density_liquid_water") * r0 ** me * pi * 4 / 3, me, dm, chim)
+        c.rain.area = fam.particle_area(a0=pi * r0 ** ae, ae=ae, delta_a=da, chi_a=chia)
+        c.rain.vent = fam.ventilation(a=g("rain_ventilation_coefficient_a"), b=g("rain_ventilation_coefficient_b"))
+        # NB the reference reads r0 of Blk1MVelTypeRain from `snow_flake_length_scale` (TerminalVelocity.jl:39)
+        c.vel_rain = fam.blk1m_vel_rain(
+            r0=g("snow_flake_length_scale"), ve=ve, delta_v=dv, chi_v=chiv, rho_w=g("density_liquid_water"),
+            C_drag=g("rain_drop_drag_coefficient"), grav=g("gravitational_acceleration"),
+            gamma_vent=math.gamma((ve + dv + 5) / 2), gamma_term=math.gamma(me + ve + dm + dv + 1),
+            gamma_accr=math.gamma(ae + ve + da + dv + 1), gamma_accr_rain_sink=math.gamma(me + ae + ve + dm + da + dv + 1))
+        # Snow
+        r0, me, dm, chim = g("snow_flake_length_scale"), g("snow_mass_size_relation_coefficient_me"), g(
+            "snow_mass_size_relation_coefficient_delm"), g("snow_mass_size_relation_coefficient_chim")
+        ae, da, chia = g("snow_cross_section_size_relation_coefficient"), g(
+            "snow_cross_section_size_relation_coefficient_dela"), g("snow_cross_section_size_relation_coefficient_chia")
+        ve, dv, chiv = g("snow_terminal_velocity_size_relation_coefficient"), g(
+            "snow_terminal_velocity_size_relation_coefficient_delv"), g("snow_terminal_velocity_size_relation_coefficient_chiv")
+        c.snow.mu, c.snow.nu = g("snow_flake_size_distribution_coefficient_mu"), g("snow_flake_size_distribution_coefficient_nu")
+        c.snow.mass = _particle_mass(fam, r0, r0 ** me / 10, me, dm, chim)
+        c.snow.area = fam.particle_area(a0=0.3 * pi * r0 ** ae, ae=ae, delta_a=da, chi_a=chia)
+        c.snow.vent = fam.ventilation(a=g("snow_ventilation_coefficient_a"), b=g("snow_ventilation_coefficient_b"))
+        c.snow.phi, c.snow.kappa, c.snow.rho_i = g("snow_aspect_ratio"), g("snow_aspect_ratio_coefficient"), g("snow_apparent_density")
+        a_obl, a_pro = me + dm - 1.5 * (ae + da), 3 * (ae + da) - 2 * (me + dm)
+        c.snow.gamma_aspect_oblate = math.gamma(a_obl + 4) / math.gamma(4.0)
+        c.snow.gamma_aspect_prolate = math.gamma(a_pro + 4) / math.gamma(4.0)
+        c.vel_snow = fam.blk1m_vel_snow(
+            r0=r0, ve=ve, delta_v=dv, chi_v=chiv, v0=2 ** (9 / 4) * r0 ** ve, gamma_vent=math.gamma((ve + dv + 5) / 2),
+            gamma_term=math.gamma(me + ve + dm + dv + 1), gamma_accr=math.gamma(ae + ve + da + dv + 1))
+        # Cloud liquid / ice
+        c.cloud_liquid = fam.cloud_liquid(rho_w=g("density_liquid_water"), r_eff=g("liquid_cloud_effective_radius"),
+                                          N_0=g("cloud_liquid_sedimentation_number_concentration"))
+        r0, me, dm, chim = g("cloud_ice_crystals_length_scale"), g("cloud_ice_mass_size_relation_coefficient_me"), g(
+            "cloud_ice_mass_size_relation_coefficient_delm"), g("cloud_ice_mass_size_relation_coefficient_chim")
+        c.cloud_ice.n0 = g("cloud_ice_size_distribution_coefficient_n0")
+        c.cloud_ice.mass = _particle_mass(fam, r0, g("cloud_ice_apparent_density") * r0 ** me * pi * 4 / 3, me, dm, chim)
+        c.cloud_ice.rho_i, c.cloud_ice.r_eff = g("cloud_ice_apparent_density"), g("ice_cloud_effective_radius")
+        c.cloud_ice.N_0 = g("cloud_ice_sedimentation_number_concentration")
+        c.air_properties = AirProperties(td)
+        # process parameters (Microphysics1MOptions.jl:296-395)
+        pp = c.process_params
+        pp.cloud_liquid_formation_tau_relax = g("condensation_evaporation_timescale")
+        pp.cloud_ice_formation_tau_relax = g("sublimation_deposition_timescale")
+        k = g("threshold_smooth_transition_steepness")
+        pp.rain_autoconversion = fam.acnv_1m(tau=g("rain_autoconversion_timescale"), k=k, q_threshold=g(
+            "cloud_liquid_water_specific_humidity_autoconversion_threshold"))
+        pp.rain_autoconversion_nd = fam.var_timescale_acnv(
+            tau=g("rain_autoconversion_timescale"), alpha=g("Variable_time_scale_autoconversion_coeff_alpha"),
+            Nc=g("prescribed_cloud_droplet_number_concentration"))
+        pp.snow_autoconversion = fam.acnv_1m(tau=g("snow_autoconversion_timescale"), k=k, q_threshold=g(
+            "cloud_ice_specific_humidity_autoconversion_threshold"))
+        pp.r_ice_snow = g("ice_snow_threshold_radius")
+        pp.e_lcl_rai, pp.e_lcl_sno = g("cloud_liquid_rain_collision_efficiency"), g("cloud_liquid_snow_collision_efficiency")
+        pp.e_icl_rai, pp.e_icl_sno = g("cloud_ice_rain_collision_efficiency"), g("cloud_ice_snow_collision_efficiency")
+        pp.e_rai_sno, pp.coeff_disp = g("rain_snow_collision_efficiency"), g("rain_snow_velocity_dispersion_coefficient")
+
+    @property
+    def flags(self):
+        return self.processes.flags
 
 
 def rain_vel_params(FT):

@@ -29,6 +29,55 @@ def _psat_liquid(T, td):
     return p_tr * (T / T_tr) ** (dcp / R_v) * torch.exp((LH - dcp * T0) / R_v * (1.0 / T_tr - 1.0 / T))
 
 
+State1M = namedtuple("State1M", ["rho", "T", "q_tot", "q_lcl", "q_icl", "q_rai", "q_sno"])
+
+
+def _psat_ice(T, td):
+    R_v = td["gas_constant_vapor"]
+    dcp = td["isobaric_specific_heat_vapor"] - td["isobaric_specific_heat_ice"]
+    T_tr, p_tr = td["temperature_triple_point"], td["pressure_triple_point"]
+    LH, T0 = td["latent_heat_sublimation_at_reference"], td["thermodynamics_temperature_reference"]
+    return p_tr * (T / T_tr) ** (dcp / R_v) * torch.exp((LH - dcp * T0) / R_v * (1.0 / T_tr - 1.0 / T))
+
+
+def mp1m_state(n: int, dtype=torch.float32, device="cpu", seed: int = 1234, chunk: int = 1 << 24) -> State1M:
+    """n random 1-moment states (ρ, T, q_tot, q_lcl, q_icl, q_rai, q_sno): the reference's
+    `generate_atmospheric_states` (test/gpu_performance.jl:80-136) randomised — liquid / ice condensate =
+    supersaturation excess over liquid / ice + U[0,1e-4] noise, rain / snow = U[0,1e-4] noise, plus heavier
+    precipitation tails, exact zeros and slightly negative values (clamp path), both sides of T_freeze."""
+    td = P.DEFAULT_PARAMETERS
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    cols = [torch.empty(n, dtype=dtype, device=device) for _ in range(7)]
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        u = lambda: torch.rand(m, dtype=torch.float64, device=device, generator=g)  # noqa: E731
+        logu = lambda a, b: torch.exp(torch.log(torch.tensor(a, dtype=torch.float64, device=device)) +  # noqa: E731
+                                      u() * torch.log(torch.tensor(b / a, dtype=torch.float64, device=device)))
+        z = 15000.0 * u()
+        T = torch.clamp(300.0 - 6.5e-3 * z, min=215.0) + (4.0 * u() - 2.0)
+        p = 1.0e5 * torch.exp(-z / 8000.0)
+        RH = 0.05 + u()
+        p_sat = _psat_liquid(T, td)
+        eps_m = td["gas_constant_dry_air"] / td["gas_constant_vapor"]
+        q_vap = (RH * eps_m * p_sat / (p - (1 - eps_m) * RH * p_sat).clamp(min=1.0)).clamp(max=0.04)
+        rho = p / (td["gas_constant_dry_air"] * T * (1.0 + 0.61 * q_vap))
+        q_sat_l = p_sat / (rho * td["gas_constant_vapor"] * T)
+        q_sat_i = _psat_ice(T, td) / (rho * td["gas_constant_vapor"] * T)
+        q_lcl = (q_vap - q_sat_l).clamp(min=0.0) + 1e-4 * u() * (u() < 0.7)
+        q_icl = ((q_vap - q_sat_i).clamp(min=0.0) + 1e-4 * u()) * (u() < 0.6)
+        q_rai = torch.where(u() < 0.1, logu(1e-7, 5e-3), 1e-4 * u() * (u() < 0.5))
+        q_sno = torch.where(u() < 0.1, logu(1e-7, 5e-3), 1e-4 * u() * (u() < 0.5))
+        q_tot = q_vap + q_lcl + q_icl + q_rai + q_sno
+        for c in (q_lcl, q_icl, q_rai, q_sno):
+            r = u()
+            c.masked_fill_(r < 0.010, 0.0)
+            c.copy_(torch.where((r >= 0.010) & (r < 0.015), -1e-9 * (1 + c.abs()), c))
+        for dst, src in zip(cols, (rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno)):
+            dst[lo:lo + m] = src.to(dtype)
+    return State1M(*cols)
+
+
 IceNucState = namedtuple("IceNucState", ["T", "a_w", "r"])
 
 

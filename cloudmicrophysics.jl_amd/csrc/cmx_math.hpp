@@ -29,6 +29,9 @@ template <> struct Math<float> {
     // Γ(z) for z in [1, 8]: shift into [2,3) and evaluate a minimax-quality polynomial
     // (only used by the Chen-2022 rain velocity: z = b_i(ρ)+1 ∈ [2.0, 3.4], z+3).
     static __device__ __forceinline__ float tgamma(float z) { return ::tgammaf(z); }
+    // accurate near 0 (OCML): used where exp2(x)−1 / log2(1+x) through the hardware units would cancel
+    static __device__ __forceinline__ float log1p(float x) { return ::log1pf(x); }
+    static __device__ __forceinline__ float expm1(float x) { return ::expm1f(x); }
 };
 
 template <> struct Math<double> {
@@ -45,6 +48,8 @@ template <> struct Math<double> {
     static __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }
     static __device__ __forceinline__ double min(double a, double b) { return __builtin_fmin(a, b); }
     static __device__ __forceinline__ double tgamma(double z) { return ::tgamma(z); }
+    static __device__ __forceinline__ double log1p(double x) { return ::log1p(x); }
+    static __device__ __forceinline__ double expm1(double x) { return ::expm1(x); }
 };
 
 template <typename FT> __device__ __forceinline__ FT clampv(FT x, FT lo, FT hi) {

@@ -115,7 +115,7 @@ typedef enum cmx_status {
     /* reference itself uses (src/ThermodynamicsInterface.jl:9-25).                        */  \
     typedef struct cmx_thermo_##SFX {                                                          \
         FT R_v, R_d, cp_d, cp_v, cp_l, cp_i, LH_v0, LH_s0, T_0, T_triple, press_triple,        \
-            T_freeze;                                                                          \
+            T_freeze, cv_l;                                                                    \
     } cmx_thermo_##SFX;                                                                        \
     /* SB2006VelType — src/parameters/TerminalVelocity.jl:174-182 */                           \
     typedef struct cmx_sb2006_vel_##SFX { FT rho_0, aR, bR, cR, rho_w, nu_air, grav; }         \
@@ -136,7 +136,64 @@ typedef enum cmx_status {
     } cmx_koop2000_##SFX;                                                                      \
     /* the two ABIFM fields of a dust type (Kaolinite, Illite, DesertDust, …:                */ \
     /* src/parameters/AerosolKaolinite.jl:19-21 etc.): log10 J = m·Δa_w + c  [cm⁻² s⁻¹]      */ \
-    typedef struct cmx_abifm_dust_##SFX { FT ABIFM_m, ABIFM_c; } cmx_abifm_dust_##SFX;
+    typedef struct cmx_abifm_dust_##SFX { FT ABIFM_m, ABIFM_c; } cmx_abifm_dust_##SFX;          \
+    /* ---- 1-moment scheme: src/parameters/Microphysics1M.jl ---------------------------- */   \
+    /* ParticleMass — m(r) = m0 χm (r/r0)^(me+Δm); gamma_coeff = Γ(me+Δm+1) host-derived */     \
+    typedef struct cmx_particle_mass_##SFX { FT r0, m0, me, delta_m, chi_m, gamma_coeff; }     \
+        cmx_particle_mass_##SFX;                                                               \
+    /* ParticleArea — a(r) = a0 χa (r/r0)^(ae+Δa) */                                           \
+    typedef struct cmx_particle_area_##SFX { FT a0, ae, delta_a, chi_a; }                      \
+        cmx_particle_area_##SFX;                                                               \
+    typedef struct cmx_ventilation_##SFX { FT a, b; } cmx_ventilation_##SFX;                   \
+    /* Acnv1M (τ, q_threshold, k) and VarTimescaleAcnv (τ, α, Nc) */                           \
+    typedef struct cmx_acnv_1m_##SFX { FT tau, q_threshold, k; } cmx_acnv_1m_##SFX;            \
+    typedef struct cmx_var_timescale_acnv_##SFX { FT tau, alpha, Nc; }                         \
+        cmx_var_timescale_acnv_##SFX;                                                          \
+    /* CloudLiquid{ρw, r_eff, N_0}; CloudIce{pdf(n0), mass, ρᵢ, r_eff, N_0} */                 \
+    typedef struct cmx_cloud_liquid_##SFX { FT rho_w, r_eff, N_0; } cmx_cloud_liquid_##SFX;    \
+    typedef struct cmx_cloud_ice_##SFX {                                                       \
+        FT n0; cmx_particle_mass_##SFX mass; FT rho_i, r_eff, N_0;                             \
+    } cmx_cloud_ice_##SFX;                                                                     \
+    /* Rain{pdf(n0), mass, area, vent} */                                                      \
+    typedef struct cmx_rain_##SFX {                                                            \
+        FT n0; cmx_particle_mass_##SFX mass; cmx_particle_area_##SFX area;                     \
+        cmx_ventilation_##SFX vent;                                                            \
+    } cmx_rain_##SFX;                                                                          \
+    /* Snow{pdf(μ, ν), mass, area, vent, aspr(ϕ, κ), ρᵢ, gamma_aspect_oblate/prolate} */       \
+    typedef struct cmx_snow_##SFX {                                                            \
+        FT mu, nu; cmx_particle_mass_##SFX mass; cmx_particle_area_##SFX area;                 \
+        cmx_ventilation_##SFX vent; FT phi, kappa, rho_i, gamma_aspect_oblate,                 \
+            gamma_aspect_prolate;                                                              \
+    } cmx_snow_##SFX;                                                                          \
+    /* Blk1MVelTypeRain / Blk1MVelTypeSnow — src/parameters/TerminalVelocity.jl:12-30,76-85 */ \
+    typedef struct cmx_blk1m_vel_rain_##SFX {                                                  \
+        FT r0, ve, delta_v, chi_v, rho_w, C_drag, grav, gamma_vent, gamma_term, gamma_accr,    \
+            gamma_accr_rain_sink;                                                              \
+    } cmx_blk1m_vel_rain_##SFX;                                                                \
+    typedef struct cmx_blk1m_vel_snow_##SFX {                                                  \
+        FT r0, ve, delta_v, chi_v, v0, gamma_vent, gamma_term, gamma_accr;                     \
+    } cmx_blk1m_vel_snow_##SFX;                                                                \
+    /* process_params of Microphysics1MParams (src/parameters/Microphysics1MOptions.jl:296-   */ \
+    /* 395), flattened: every variant's parameters are present, `flags` says which are read */  \
+    typedef struct cmx_process_params_1m_##SFX {                                               \
+        FT cloud_liquid_formation_tau_relax, cloud_ice_formation_tau_relax;                    \
+        cmx_acnv_1m_##SFX rain_autoconversion;             /* Kessler1M          */            \
+        cmx_var_timescale_acnv_##SFX rain_autoconversion_nd; /* PrescribedNd     */            \
+        cmx_acnv_1m_##SFX snow_autoconversion;             /* NoSupersaturation  */            \
+        FT r_ice_snow;                                     /* WithSupersaturation */           \
+        FT e_lcl_rai, e_lcl_sno, e_icl_rai, e_icl_sno, e_rai_sno, coeff_disp;                  \
+    } cmx_process_params_1m_##SFX;                                                             \
+    /* Microphysics1MParams — src/parameters/Microphysics1MParams.jl:63-70 */                  \
+    typedef struct cmx_microphysics_1m_##SFX {                                                 \
+        cmx_process_params_1m_##SFX process_params;                                            \
+        cmx_cloud_liquid_##SFX cloud_liquid;                                                   \
+        cmx_cloud_ice_##SFX cloud_ice;                                                         \
+        cmx_rain_##SFX rain;                                                                   \
+        cmx_snow_##SFX snow;                                                                   \
+        cmx_air_properties_##SFX air_properties;                                               \
+        cmx_blk1m_vel_rain_##SFX vel_rain;                                                     \
+        cmx_blk1m_vel_snow_##SFX vel_snow;                                                     \
+    } cmx_microphysics_1m_##SFX;
 
 CMX_DECLARE_PARAM_STRUCTS(float, f32)
 CMX_DECLARE_PARAM_STRUCTS(double, f64)
@@ -270,6 +327,87 @@ int32_t cmx_water_activity_f32(const cmx_thermo_f32 *tps, int64_t n, const float
                                float *a_w_ice, float *a_w_eT, void *stream);
 int32_t cmx_water_activity_f64(const cmx_thermo_f64 *tps, int64_t n, const double *T, const double *e,
                                double *a_w_ice, double *a_w_eT, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * (5) One-moment (Marshall–Palmer) bulk scheme.
+ *
+ * `flags` = the reference's Microphysics1MOptions (src/parameters/Microphysics1MOptions.jl:257-286):
+ * one bit per process / variant; a cleared bit is the reference's `nothing` (process disabled).
+ * CMX_1M_DEFAULT_OPTIONS reproduces `Microphysics1MOptions()`.  TemperatureDependent cloud-ice formation
+ * (Frostenberg INP timescale) is not on this path: CMX_ERR_UNSUPPORTED.
+ * ------------------------------------------------------------------------- */
+#define CMX_1M_CLOUD_LIQUID_FORMATION     (1u << 0)   /* CloudLiquidFormation        NonEq:104-140 */
+#define CMX_1M_CLOUD_ICE_FORMATION_CONST  (1u << 1)   /* ConstantTimescale           NonEq:163-193 */
+#define CMX_1M_CLOUD_ICE_FORMATION_TDEP   (1u << 2)   /* TemperatureDependent — unsupported */
+#define CMX_1M_CLOUD_ICE_MELT             (1u << 3)   /* CloudIceMelt                CM1:1055-1077 */
+#define CMX_1M_RAIN_ACNV_KESSLER          (1u << 4)   /* Kessler1M                   CM1:354-358   */
+#define CMX_1M_RAIN_ACNV_PRESCRIBED_ND    (1u << 5)   /* PrescribedNd                CM1:359-364   */
+#define CMX_1M_SNOW_ACNV_NO_SUPERSAT      (1u << 6)   /* NoSupersaturation           CM1:414-418   */
+#define CMX_1M_SNOW_ACNV_WITH_SUPERSAT    (1u << 7)   /* WithSupersaturation         CM1:420-446   */
+#define CMX_1M_RAIN_EVAPORATION           (1u << 8)   /* RainEvaporation             CM1:917-960   */
+#define CMX_1M_SNOW_SUBLIMATION_ONLY      (1u << 9)   /* SublimationOnly             CM1:979-988   */
+#define CMX_1M_SNOW_DEP_AND_SUBL          (1u << 10)  /* DepositionAndSublimation    CM1:990-999   */
+#define CMX_1M_SNOW_MELT                  (1u << 11)  /* SnowMelt                    CM1:1094-1139 */
+#define CMX_1M_ACCR_LCL_RAI               (1u << 12)  /* CloudLiquidRainAccretion    CM1:709-732   */
+#define CMX_1M_ACCR_LCL_SNO               (1u << 13)  /* CloudLiquidSnowAccretion    CM1:734-760   */
+#define CMX_1M_ACCR_ICL_RAI               (1u << 14)  /* CloudIceRainAccretion (+ rain sink) CM1:762-785,872-897 */
+#define CMX_1M_ACCR_ICL_SNO               (1u << 15)  /* CloudIceSnowAccretion       CM1:787-810   */
+#define CMX_1M_ACCR_RAI_SNO               (1u << 16)  /* RainSnowAccretion           CM1:815-867   */
+#define CMX_1M_DEFAULT_OPTIONS                                                                            \
+    (CMX_1M_CLOUD_LIQUID_FORMATION | CMX_1M_CLOUD_ICE_FORMATION_CONST | CMX_1M_CLOUD_ICE_MELT |           \
+     CMX_1M_RAIN_ACNV_KESSLER | CMX_1M_SNOW_ACNV_NO_SUPERSAT | CMX_1M_RAIN_EVAPORATION |                  \
+     CMX_1M_SNOW_DEP_AND_SUBL | CMX_1M_SNOW_MELT | CMX_1M_ACCR_LCL_RAI | CMX_1M_ACCR_LCL_SNO |            \
+     CMX_1M_ACCR_ICL_RAI | CMX_1M_ACCR_ICL_SNO | CMX_1M_ACCR_RAI_SNO)
+
+/* Fused 1M tendencies.  Replaces the broadcast
+ *   BMT.bulk_microphysics_tendencies.(Ref(BMT.Instantaneous()), Ref(BMT.Microphysics1Moment()), Ref(mp), Ref(tps),
+ *                                     ρ, T, q_tot, q_lcl, q_icl, q_rai, q_sno)
+ * src/BulkMicrophysicsTendencies.jl:505-514 → _microphysics_source_terms :141-217 → _aggregate_tendencies
+ * :227-252 (KA wrapper benchmark_1m_bulk_tendencies_kernel!, test/gpu_performance.jl:39-47).
+ * 7 columns in, 4 out (dq_lcl_dt, dq_icl_dt, dq_rai_dt, dq_sno_dt [kg/kg/s]). */
+int32_t cmx_mp1m_tendencies_f32(const cmx_microphysics_1m_f32 *mp, const cmx_thermo_f32 *tps, uint32_t flags,
+                                int64_t n, const float *rho, const float *T, const float *q_tot, const float *q_lcl,
+                                const float *q_icl, const float *q_rai, const float *q_sno, float *dq_lcl_dt,
+                                float *dq_icl_dt, float *dq_rai_dt, float *dq_sno_dt, void *stream);
+int32_t cmx_mp1m_tendencies_f64(const cmx_microphysics_1m_f64 *mp, const cmx_thermo_f64 *tps, uint32_t flags,
+                                int64_t n, const double *rho, const double *T, const double *q_tot,
+                                const double *q_lcl, const double *q_icl, const double *q_rai, const double *q_sno,
+                                double *dq_lcl_dt, double *dq_icl_dt, double *dq_rai_dt, double *dq_sno_dt,
+                                void *stream);
+
+/* The individual 1M source terms — `_microphysics_source_terms` (BMT:141-217), same inputs (clamped the
+ * same way), `out` = host array of CMX_MP1M_NSRC device column pointers (NULL = skip). */
+typedef enum cmx_mp1m_source_column {
+    CMX_1M_S_PHASE_CHANGE_VAP_LCL = 0, CMX_1M_S_PHASE_CHANGE_VAP_ICL,
+    CMX_1M_S_ACNV_LCL_RAI, CMX_1M_S_ACNV_ICL_SNO,
+    CMX_1M_S_ACCR_LCL_RAI, CMX_1M_S_ACCR_LCL_SNO_COLD, CMX_1M_S_ACCR_LCL_SNO_WARM, CMX_1M_S_ACCR_MELT_LCL_SNO,
+    CMX_1M_S_ACCR_ICL_RAI, CMX_1M_S_ACCR_FREEZE_ICL_RAI, CMX_1M_S_ACCR_ICL_SNO,
+    CMX_1M_S_ACCR_RAI_SNO_COLD, CMX_1M_S_ACCR_RAI_SNO_WARM, CMX_1M_S_ACCR_MELT_RAI_SNO,
+    CMX_1M_S_PHASE_CHANGE_VAP_RAI, CMX_1M_S_PHASE_CHANGE_VAP_SNO,
+    CMX_1M_S_MELT_ICL_LCL, CMX_1M_S_MELT_SNO_RAI,
+    CMX_MP1M_NSRC
+} cmx_mp1m_source_column;
+int32_t cmx_mp1m_source_terms_f32(const cmx_microphysics_1m_f32 *mp, const cmx_thermo_f32 *tps, uint32_t flags,
+                                  int64_t n, const float *rho, const float *T, const float *q_tot, const float *q_lcl,
+                                  const float *q_icl, const float *q_rai, const float *q_sno,
+                                  float *const out[CMX_MP1M_NSRC], void *stream);
+int32_t cmx_mp1m_source_terms_f64(const cmx_microphysics_1m_f64 *mp, const cmx_thermo_f64 *tps, uint32_t flags,
+                                  int64_t n, const double *rho, const double *T, const double *q_tot,
+                                  const double *q_lcl, const double *q_icl, const double *q_rai, const double *q_sno,
+                                  double *const out[CMX_MP1M_NSRC], void *stream);
+
+/* Mass-weighted 1M fall speeds over (ρ, q) columns — BASELINE config 1 together with the autoconversion
+ * source term above.  Replaces `@. w = CM1.terminal_velocity(rain, vel, ρ, q)` (test/gpu_clima_core_test.jl:39-42):
+ *   vt_rai_blk1m = CM1.terminal_velocity(rain, Blk1MVelTypeRain, ρ, q_rai)       CM1:223-249
+ *   vt_sno_blk1m = CM1.terminal_velocity(snow, Blk1MVelTypeSnow, ρ, q_sno)       CM1:223-249
+ *   vt_rai_chen  = CM1.terminal_velocity(rain, Chen2022VelTypeRain, ρ, q_rai)    CM1:251-270
+ * Output columns may be NULL; q_sno may be NULL iff vt_sno_blk1m is; chen may be NULL iff vt_rai_chen is. */
+int32_t cmx_mp1m_terminal_velocity_f32(const cmx_microphysics_1m_f32 *mp, const cmx_chen2022_rain_vel_f32 *chen,
+                                       int64_t n, const float *rho, const float *q_rai, const float *q_sno,
+                                       float *vt_rai_blk1m, float *vt_sno_blk1m, float *vt_rai_chen, void *stream);
+int32_t cmx_mp1m_terminal_velocity_f64(const cmx_microphysics_1m_f64 *mp, const cmx_chen2022_rain_vel_f64 *chen,
+                                       int64_t n, const double *rho, const double *q_rai, const double *q_sno,
+                                       double *vt_rai_blk1m, double *vt_sno_blk1m, double *vt_rai_chen, void *stream);
 
 /* ---------------------------------------------------------------------------
  * (3) Optional diagnostic sums over one rank's shard: per-column

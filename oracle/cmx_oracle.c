@@ -34,6 +34,8 @@
 #define M_ABS fabs
 #define M_TGAMMA tgamma
 #define M_LGAMMA lgamma
+#define M_LOG1P log1p
+#define M_EXPM1 expm1
 #include "cmx_oracle_impl.h"
 #undef FT
 #undef SFX
@@ -45,6 +47,8 @@
 #undef M_ABS
 #undef M_TGAMMA
 #undef M_LGAMMA
+#undef M_LOG1P
+#undef M_EXPM1
 
 /* ---- Float32 instantiation (the reference's Float32 path: float arithmetic, float gates) ---- */
 #define FT float
@@ -57,4 +61,6 @@
 #define M_ABS fabsf
 #define M_TGAMMA tgammaf
 #define M_LGAMMA lgammaf
+#define M_LOG1P log1pf
+#define M_EXPM1 expm1f
 #include "cmx_oracle_impl.h"

@@ -699,6 +699,8 @@ void FN(cmxo_chen2022_rain_coeffs)(const TY(cmx_chen2022_rain_vel) * c, FT rho, 
     FN(o_chen2022_rain_coeffs)(c, rho, out, out + 3, out + 6);
 }
 
+#include "cmx_oracle_1m_impl.h"
+
 #undef CAT_
 #undef CAT
 #undef FN

@@ -141,6 +141,54 @@ def water_activity(fam, tps, T, e=None):
     return ice, eT
 
 
+def mp1m(fam, mp, tps, flags, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno, *, float32_gates=None, nthreads=1,
+         want_sources=True):
+    """Oracle twin of cmx_mp1m_tendencies_* + cmx_mp1m_source_terms_*: the 4 tendencies, their Σ|terms| scales and
+    (optionally) the 18 source terms of BMT:141-217."""
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    ins = [_col(fam, a) for a in (rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno)]
+    n = ins[0][0].size
+    tn = ["dq_lcl_dt", "dq_icl_dt", "dq_rai_dt", "dq_sno_dt"]
+    tend = [np.empty(n, dtype=NP[fam.sfx]) for _ in tn]
+    scale = [np.empty(n, dtype=NP[fam.sfx]) for _ in tn]
+    src = [np.empty(n, dtype=NP[fam.sfx]) for _ in range(_abi.CMX_MP1M_NSRC)] if want_sources else None
+    arr = lambda cols: (C.c_void_p * len(cols))(*[c.ctypes.data for c in cols])  # noqa: E731
+    fn = getattr(lib(), f"cmxo_mp1m_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(mp), C.byref(tps), C.c_uint32(flags), C.byref(th), C.c_int64(n), *[p for _, p in ins], arr(tend),
+       arr(scale), arr(src) if want_sources else None, C.c_int32(nthreads))
+    out = dict(zip(tn, tend))
+    out["scale"] = dict(zip(tn, scale))
+    if want_sources:
+        out["sources"] = dict(zip(_abi.MP1M_SOURCE_COLUMNS, src))
+    return out
+
+
+def mp1m_terminal_velocity(fam, mp, chen, rho, q_rai, q_sno, float32_gates=None):
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    ins = [_col(fam, a) for a in (rho, q_rai, q_sno)]
+    n = ins[0][0].size
+    outs = [np.empty(n, dtype=NP[fam.sfx]) for _ in range(3)]
+    fn = getattr(lib(), f"cmxo_mp1m_terminal_velocity_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(mp), C.byref(chen), C.byref(th), C.c_int64(n), *[p for _, p in ins],
+       *[o.ctypes.data_as(C.c_void_p) for o in outs])
+    return dict(zip(("vt_rai_blk1m", "vt_sno_blk1m", "vt_rai_chen"), outs))
+
+
+def logistic_function_integral(fam, x, x_0, k, eps=None):
+    if eps is None:
+        eps = thresholds(fam, fam.sfx == "f32").eps_1m
+    fn = getattr(lib(), f"cmxo_logistic_function_integral_{fam.sfx}")
+    fn.restype = fam.ft
+    fn.argtypes = [fam.ft] * 4
+    return fn(x, x_0, k, eps)
+
+
 def psat_liquid(fam, tps, T):
     return getattr(lib(), f"cmxo_psat_liquid_{fam.sfx}")(C.byref(tps), T)
 

@@ -45,7 +45,7 @@ def _compare(got, ref, ft, koop64, what):
         scale = None
         if k == "delta_a_w":
             scale = np.full_like(r, 1.0)          # Δa_w = a_w − a_w_ice: two O(1) terms
-        e = parity.scaled_err(g, r, scale, parity.FLOOR[ft], parity.CEIL[ft])
+        e = parity.scaled_err(g, r, scale, parity.FLOOR[ft], parity.CEIL[ft], parity.CTOL[ft] / parity.RTOL[ft])
         e = np.nan_to_num(e, nan=np.inf)
         if k in ("J_hom", "rate_hom"):
             e = e[~edge]

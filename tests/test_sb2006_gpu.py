@@ -181,7 +181,7 @@ def test_process_rates_match_oracle(dev, oracle, ft, limited):
         if k in ("numadj_rai", "numadj_lcl"):   # (n_target − n)/τ cancels when the clamp is inactive
             nn = (n_rai if k.endswith("rai") else n_lcl).numpy().astype(np.float64)
             scale = 2 * np.abs(nn) / 100.0
-        e = parity.scaled_err(got, ref[k], scale, parity.FLOOR[ft])[keep]
+        e = parity.scaled_err(got, ref[k], scale, parity.FLOOR[ft], parity.CEIL[ft], parity.CTOL[ft] / parity.RTOL[ft])[keep]
         worst[k] = float(np.nanmax(e))
         assert worst[k] <= tol, (k, worst[k])
     print(f"\n[process parity] {ft} limited={limited}: {worst}")
