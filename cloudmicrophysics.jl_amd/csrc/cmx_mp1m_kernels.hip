@@ -30,7 +30,7 @@ template <typename FT> struct Mp1mConsts {
     FT ps_c0, psl_a, psl_b, psi_a, psi_b, inv_T_tr;
     FT cp_d, cpm_qt, cpm_ql, cpm_qi;
     FT tau_l, tau_i;
-    FT inv_K, Rv_over_D, eps_1m, K_therm;
+    FT inv_K, Rv_over_D, eps_1m, l2_eps, K_therm;
     // Marshall–Palmer slopes: log2 λ⁻¹ = (log2(ρ q) + c [− log2 n0]) · e, floored at log2(r0·1e-5)
     FT lam_c_rai, lam_e_rai, lam_floor_rai;
     FT lam_c_sno, lam_e_sno, lam_floor_sno, sno_l2_mu, sno_nu;
@@ -74,7 +74,8 @@ static Mp1mConsts<FT> make_mp1m_consts(const MP &mp, const TH &tp, uint32_t flag
     c.tau_l = (FT)pp.cloud_liquid_formation_tau_relax; c.tau_i = (FT)pp.cloud_ice_formation_tau_relax;
     const double K_safe = std::fmax((double)mp.air_properties.K_therm, eps), D_safe = std::fmax((double)mp.air_properties.D_vapor, eps);
     const double nu_air = mp.air_properties.nu_air;
-    c.inv_K = (FT)(1.0 / K_safe); c.Rv_over_D = (FT)(Rv / D_safe); c.eps_1m = (FT)eps; c.K_therm = (FT)mp.air_properties.K_therm;
+    c.inv_K = (FT)(1.0 / K_safe); c.Rv_over_D = (FT)(Rv / D_safe); c.eps_1m = (FT)eps; c.l2_eps = (FT)std::log2(eps);
+    c.K_therm = (FT)mp.air_properties.K_therm;
     auto slope = [&](const auto &m, double n0, FT &cc, FT &ee, FT &fl) {   // CM1.lambda_inverse :126-152
         const double d = (double)m.me + (double)m.delta_m;
         const double denom_wo_n0 = (double)m.chi_m * (double)m.m0 * (double)m.gamma_coeff;
@@ -158,7 +159,11 @@ template <typename FT> __device__ __forceinline__ FT logistic_integral(FT x, FT 
     using M = Math<FT>;
     x = M::max(FT(0), x);
     const FT xs = M::max(x, eps), x0s = M::max(x0, eps);
-    const FT r = M::log1p(emk * M::expm1(k * xs * M::rcp(x0s))) * x0s * M::rcp(k);
+    // beyond y = k x/x0 = 60 the same quantity is (y − k) + log1p(e^{k−y} − e^{−y}) = y − k to 1e-25 (and expm1
+    // cannot overflow below it)
+    const FT y = k * xs * M::rcp(x0s);
+    const FT lg = M::log1p(emk * M::expm1(M::min(y, FT(60))));
+    const FT r = (y > FT(60) ? y - k : lg) * x0s * M::rcp(k);
     return x < eps ? FT(0) : (x0 < eps ? x : r);
 }
 
@@ -218,9 +223,10 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const Mp1mConsts<FT> &c, FT rh
     const FT l2_li_rai = M::max(c.lam_floor_rai, (l2_rq_rai + c.lam_c_rai) * c.lam_e_rai);
     const FT l2_li_icl = M::max(c.lam_floor_icl, (l2_rq_icl + c.lam_c_icl) * c.lam_e_icl);
     // snow: n0 = μ (ρ max(q, ϵ))^ν if q > ϵ else 0 (get_n0 :83-86); λ⁻¹ uses max(n0, ϵ)
-    const FT l2_n0_sno = has_sno ? M::fma(c.sno_nu, M::log2(rho * M::max(q_sno, eps)), c.sno_l2_mu) : M::log2(eps);
+    // (for q_sno > ϵ, ρ·max(q_sno, ϵ) = ρ q_sno: its log2 is l2_rq_sno)
+    const FT l2_n0_sno = has_sno ? M::fma(c.sno_nu, l2_rq_sno, c.sno_l2_mu) : c.l2_eps;
     const FT n0_sno = has_sno ? M::exp2(l2_n0_sno) : FT(0);
-    const FT l2_li_sno = M::max(c.lam_floor_sno, (l2_rq_sno + c.lam_c_sno - M::max(l2_n0_sno, M::log2(eps))) * c.lam_e_sno);
+    const FT l2_li_sno = M::max(c.lam_floor_sno, (l2_rq_sno + c.lam_c_sno - M::max(l2_n0_sno, c.l2_eps)) * c.lam_e_sno);
     const FT li_rai = M::exp2(l2_li_rai), li_sno = M::exp2(l2_li_sno), li_icl = M::exp2(l2_li_icl);
     const FT v0_rai = c.v0c_rai * M::sqrt(M::max(c.rho_w * inv_rho - FT(1), FT(0)));   // get_v0 :101-104
     const FT v0_sno = c.v0_sno;
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(kBlock) void mp1m_sources_kernel(const Mp1mConsts<F
 
 // ---- terminal velocities over (ρ, q) columns — CM1:223-270 --------------------------------------------------------
 template <typename FT> struct Vel1mConsts {
-    FT eps_1m, lam_c_rai, lam_e_rai, lam_floor_rai, lam_c_sno, lam_e_sno, lam_floor_sno, sno_l2_mu, sno_nu;
+    FT eps_1m, l2_eps, lam_c_rai, lam_e_rai, lam_floor_rai, lam_c_sno, lam_e_sno, lam_floor_sno, sno_l2_mu, sno_nu;
     FT v0c_rai, rho_w, v0_sno, vt_c_rai, vt_e_rai, vt_c_sno, vt_e_sno;
     FT ch_rho0_l2e, ch_a[3], ch_a3_pow, ch_b[3], ch_b_rho, ch_c1000[3], l2_1000;
 };
@@ -384,8 +390,9 @@ __global__ __launch_bounds__(kBlock) void mp1m_velocity_kernel(const Vel1mConsts
     if (io.vt_sno) {
         const FT q = io.q_sno[i];
         const bool has = q > eps;
-        const FT l2_n0 = has ? M::fma(c.sno_nu, M::log2(rho * M::max(q, eps)), c.sno_l2_mu) : M::log2(eps);
-        const FT l2_li = M::max(c.lam_floor_sno, (M::log2(rp * M::max(FT(0), q)) + c.lam_c_sno - M::max(l2_n0, M::log2(eps))) * c.lam_e_sno);
+        const FT l2_rq = M::log2(rp * M::max(FT(0), q));
+        const FT l2_n0 = has ? M::fma(c.sno_nu, l2_rq, c.sno_l2_mu) : c.l2_eps;
+        const FT l2_li = M::max(c.lam_floor_sno, (l2_rq + c.lam_c_sno - M::max(l2_n0, c.l2_eps)) * c.lam_e_sno);
         io.vt_sno[i] = has ? c.vt_c_sno * c.v0_sno * M::exp2(c.vt_e_sno * l2_li) : FT(0);
     }
 }
@@ -464,7 +471,7 @@ static int32_t velocity_1m_entry(const MP *mp, const CH *chen, int64_t n, const 
     cmx_thermo_f64 tp{461.5, 287.0, 1004.5, 1859.0, 4181.0, 2070.0, 2.5008e6, 2.8344e6, 273.16, 273.16, 611.657, 273.15, 4181.0};
     const Mp1mConsts<FT> m = make_mp1m_consts<FT>(*mp, tp, 0u, (double)Math<FT>::eps_1m());
     Vel1mConsts<FT> c{};
-    c.eps_1m = m.eps_1m; c.lam_c_rai = m.lam_c_rai; c.lam_e_rai = m.lam_e_rai; c.lam_floor_rai = m.lam_floor_rai;
+    c.eps_1m = m.eps_1m; c.l2_eps = m.l2_eps; c.lam_c_rai = m.lam_c_rai; c.lam_e_rai = m.lam_e_rai; c.lam_floor_rai = m.lam_floor_rai;
     c.lam_c_sno = m.lam_c_sno; c.lam_e_sno = m.lam_e_sno; c.lam_floor_sno = m.lam_floor_sno; c.sno_l2_mu = m.sno_l2_mu; c.sno_nu = m.sno_nu;
     c.v0c_rai = m.v0c_rai; c.rho_w = m.rho_w; c.v0_sno = m.v0_sno; c.vt_c_rai = m.vt_c_rai; c.vt_e_rai = m.vt_e_rai;
     c.vt_c_sno = m.vt_c_sno; c.vt_e_sno = m.vt_e_sno;

@@ -13,13 +13,16 @@ static inline FT FN(o_log1mexp)(FT x) {   /* x < 0 */
     return x > (FT)-0.6931471805599453 ? M_LOG(-M_EXPM1(x)) : M_LOG1P(-M_EXP(x));
 }
 /* CO.logistic_function_integral — src/Common.jl:157-173 */
-static inline FT FN(o_logistic_function_integral)(FT x, FT x_0, FT k, FT eps) {
+/* *scale (optional) receives the size of the two terms whose difference is returned: below the threshold the
+ * result is log1pexp(kt)/k − trnslt ≈ trnslt − trnslt, so its accuracy is that of trnslt·x_0, not of the result. */
+static inline FT FN(o_logistic_function_integral)(FT x, FT x_0, FT k, FT eps, FT *scale) {
     x = FN(o_max)((FT)0, x);
     FT x_safe = FN(o_max)(x, eps);
     FT x_0_safe = FN(o_max)(x_0, eps);
     FT trnslt = -FN(o_log1mexp)(-k) / k;
     FT kt = k * (x_safe / x_0_safe - 1 + trnslt);
     FT result = (FN(o_log1pexp)(kt) / k - trnslt) * x_0_safe;
+    if (scale) *scale = (x < eps || x_0 < eps) ? (FT)0 : (FN(o_log1pexp)(kt) / k + trnslt) * x_0_safe;
     return x < eps ? (FT)0 : (x_0 < eps ? x : result);
 }
 /* TD.latent_heat_fusion: L_f(T) = (LH_s0 − LH_v0) + (cp_l − cp_i)(T − T_0)  (TDI:19) */
@@ -144,6 +147,7 @@ typedef struct TY(cmxo_src_1m) {
     FT s[CMX_MP1M_NSRC];
     FT scale_vap_lcl, scale_vap_icl, scale_vap_rai, scale_vap_sno;
     FT scale_melt_icl, scale_melt_sno, scale_accr_melt_lcl_sno, scale_accr_melt_rai_sno;
+    FT scale_acnv_rai, scale_acnv_sno;   /* Kessler-type logistic integrals (0 for the other variants: |term| is used) */
 } TY(cmxo_src_1m);
 
 /* _microphysics_source_terms — src/BulkMicrophysicsTendencies.jl:141-217 */
@@ -158,6 +162,7 @@ static inline TY(cmxo_src_1m) FN(o_source_terms_1m)(const TY(cmx_microphysics_1m
     for (int k = 0; k < CMX_MP1M_NSRC; ++k) o.s[k] = 0;
     o.scale_vap_lcl = o.scale_vap_icl = o.scale_vap_rai = o.scale_vap_sno = 0;
     o.scale_melt_icl = o.scale_melt_sno = o.scale_accr_melt_lcl_sno = o.scale_accr_melt_rai_sno = 0;
+    o.scale_acnv_rai = o.scale_acnv_sno = 0;
     /* (|T| + T_freeze)/|T − T_freeze| carried through the melt prefactors: size of the operands of T − T_freeze */
     const FT dT_amp = M_ABS(T) + tps->T_freeze;
     rho = FN(o_max)((FT)0, rho);               /* BMT:147-152 */
@@ -184,19 +189,21 @@ static inline TY(cmxo_src_1m) FN(o_source_terms_1m)(const TY(cmx_microphysics_1m
         o.s[CMX_1M_S_PHASE_CHANGE_VAP_ICL] = FN(o_conv_q_vap_to_q_icl_const)(
             pp->cloud_ice_formation_tau_relax, tps, q_tot, q_lcl, q_icl, q_rai, q_sno, rho, T, &o.scale_vap_icl);
     /* rain autoconversion — CM1:354-364 */
-    if (flags & CMX_1M_RAIN_ACNV_KESSLER)
+    if (flags & CMX_1M_RAIN_ACNV_KESSLER) {
         o.s[CMX_1M_S_ACNV_LCL_RAI] = FN(o_logistic_function_integral)(q_lcl, pp->rain_autoconversion.q_threshold,
-                                                                     pp->rain_autoconversion.k, eps) /
+                                                                     pp->rain_autoconversion.k, eps, &o.scale_acnv_rai) /
                                      pp->rain_autoconversion.tau;
-    else if (flags & CMX_1M_RAIN_ACNV_PRESCRIBED_ND)
+        o.scale_acnv_rai /= pp->rain_autoconversion.tau;
+    } else if (flags & CMX_1M_RAIN_ACNV_PRESCRIBED_ND)
         o.s[CMX_1M_S_ACNV_LCL_RAI] = FN(o_max)((FT)0, q_lcl) /
                                      (pp->rain_autoconversion_nd.tau *
                                       M_POW(pp->rain_autoconversion_nd.Nc / 100000000, pp->rain_autoconversion_nd.alpha));
     /* snow autoconversion — CM1:414-446 */
     if (flags & CMX_1M_SNOW_ACNV_NO_SUPERSAT) {
         o.s[CMX_1M_S_ACNV_ICL_SNO] = FN(o_logistic_function_integral)(q_icl, pp->snow_autoconversion.q_threshold,
-                                                                     pp->snow_autoconversion.k, eps) /
+                                                                     pp->snow_autoconversion.k, eps, &o.scale_acnv_sno) /
                                      pp->snow_autoconversion.tau;
+        o.scale_acnv_sno /= pp->snow_autoconversion.tau;
     } else if (flags & CMX_1M_SNOW_ACNV_WITH_SUPERSAT) {
         FT S = FN(o_supersaturation_over_ice)(tps, q_tot, q_lcl + q_rai, q_icl + q_sno, rho, T);
         FT G = FN(o_G_func_ice)(aps, tps, T, th);
@@ -204,6 +211,8 @@ static inline TY(cmxo_src_1m) FN(o_source_terms_1m)(const TY(cmx_microphysics_1m
         FT rate = 4 * pi * S * G * sd.n0_icl / rho * M_EXP(-r_is / li) *
                   (r_is * r_is / (mp->cloud_ice.mass.me + mp->cloud_ice.mass.delta_m) + (r_is / li + 1) * (li * li));
         o.s[CMX_1M_S_ACNV_ICL_SNO] = (q_icl > eps && S > 0 && T < tps->T_freeze) ? rate : (FT)0;
+        /* ∝ S = p_v/p_sat − 1: operand-sized scale, as for the other supersaturation-driven terms */
+        o.scale_acnv_sno = (q_icl > eps && T < tps->T_freeze && S != 0) ? M_ABS(rate / S * (S + 2)) : (FT)0;
     }
     const int is_warm = T >= tps->T_freeze;    /* BMT:171 */
     const TY(cmx_blk1m_vel_rain) *vr = &mp->vel_rain;
@@ -312,15 +321,17 @@ static inline void FN(o_aggregate_1m)(const TY(cmxo_src_1m) * src, FT out[4], FT
              s[CMX_1M_S_PHASE_CHANGE_VAP_SNO] - s[CMX_1M_S_MELT_SNO_RAI];
     if (scale) {
 #define A(k) M_ABS(s[k])
-        scale[0] = src->scale_vap_lcl + A(CMX_1M_S_ACNV_LCL_RAI) + A(CMX_1M_S_ACCR_LCL_RAI) + A(CMX_1M_S_ACCR_LCL_SNO_COLD) +
+        const FT a_rai = FN(o_max)(A(CMX_1M_S_ACNV_LCL_RAI), src->scale_acnv_rai);
+        const FT a_sno = FN(o_max)(A(CMX_1M_S_ACNV_ICL_SNO), src->scale_acnv_sno);
+        scale[0] = src->scale_vap_lcl + a_rai + A(CMX_1M_S_ACCR_LCL_RAI) + A(CMX_1M_S_ACCR_LCL_SNO_COLD) +
                    A(CMX_1M_S_ACCR_LCL_SNO_WARM) + src->scale_melt_icl;
-        scale[1] = src->scale_vap_icl + A(CMX_1M_S_ACNV_ICL_SNO) + A(CMX_1M_S_ACCR_ICL_RAI) + A(CMX_1M_S_ACCR_ICL_SNO) +
+        scale[1] = src->scale_vap_icl + a_sno + A(CMX_1M_S_ACCR_ICL_RAI) + A(CMX_1M_S_ACCR_ICL_SNO) +
                    src->scale_melt_icl;
-        scale[2] = A(CMX_1M_S_ACNV_LCL_RAI) + A(CMX_1M_S_ACCR_LCL_RAI) + A(CMX_1M_S_ACCR_LCL_SNO_WARM) +
+        scale[2] = a_rai + A(CMX_1M_S_ACCR_LCL_RAI) + A(CMX_1M_S_ACCR_LCL_SNO_WARM) +
                    src->scale_accr_melt_lcl_sno + A(CMX_1M_S_ACCR_FREEZE_ICL_RAI) + A(CMX_1M_S_ACCR_RAI_SNO_COLD) +
                    A(CMX_1M_S_ACCR_RAI_SNO_WARM) + src->scale_accr_melt_rai_sno + src->scale_vap_rai +
                    src->scale_melt_sno;
-        scale[3] = A(CMX_1M_S_ACNV_ICL_SNO) + A(CMX_1M_S_ACCR_LCL_SNO_COLD) + src->scale_accr_melt_lcl_sno +
+        scale[3] = a_sno + A(CMX_1M_S_ACCR_LCL_SNO_COLD) + src->scale_accr_melt_lcl_sno +
                    A(CMX_1M_S_ACCR_ICL_RAI) + A(CMX_1M_S_ACCR_FREEZE_ICL_RAI) + A(CMX_1M_S_ACCR_ICL_SNO) +
                    A(CMX_1M_S_ACCR_RAI_SNO_COLD) + A(CMX_1M_S_ACCR_RAI_SNO_WARM) + src->scale_accr_melt_rai_sno +
                    src->scale_vap_sno + src->scale_melt_sno;
@@ -376,4 +387,4 @@ void FN(cmxo_mp1m_terminal_velocity)(const TY(cmx_microphysics_1m) * mp, const T
         if (vt_rai_chen) vt_rai_chen[i] = FN(o_terminal_velocity_rain_chen)(&mp->rain, chen, rho[i], q_rai[i], eps);
     }
 }
-FT FN(cmxo_logistic_function_integral)(FT x, FT x_0, FT k, FT eps) { return FN(o_logistic_function_integral)(x, x_0, k, eps); }
+FT FN(cmxo_logistic_function_integral)(FT x, FT x_0, FT k, FT eps) { return FN(o_logistic_function_integral)(x, x_0, k, eps, NULL); }
