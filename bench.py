@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=100_000_000, help="grid points per GPU")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--workload", choices=["sb2006", "icenuc", "mp1m"], default="sb2006")
+    ap.add_argument("--workload", choices=["sb2006", "icenuc", "mp1m", "arg2000"], default="sb2006")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the bounded baseline sample")
     ap.add_argument("--diagnostics", action="store_true",
@@ -167,6 +167,36 @@ def setup_mp1m(args, dev, dtype, rank):
     return list(state), step, desc, cpu_run
 
 
+def setup_arg2000(args, dev, dtype, rank):
+    import torch
+
+    import cmx
+    from cmx import _abi
+    from cmx import parameters as P
+    from cmx import synthetic
+    state = synthetic.arg_state(args.points, dtype=dtype, device=dev, seed=1234 + rank)
+    ap, aip, tps = P.AerosolActivationParameters(args.dtype), P.AirProperties(args.dtype), P.ThermodynamicsParameters(args.dtype)
+    ad = synthetic.arg_config3_distribution()
+    out = cmx.ActivationResult(tuple(torch.empty_like(state.T) for _ in range(5)), None, None)
+
+    def step():
+        cmx.aerosol_activation(ap, ad, aip, tps, *state, out=out)
+
+    def cpu_run(ob, cols, threads):
+        fam = _abi.family(args.dtype)
+        adc = ad.c_struct(ap, fam)
+        return lambda: ob.arg2000_activation(fam, ap, adc, aip, tps, *cols, nthreads=threads)
+
+    desc = {
+        "metric": "states/sec ARG2000 aerosol activation sweep (5 modes)",
+        "bytes_per_point": {"f32": 36, "f64": 72}[args.dtype],      # 4 in + 5 N_act out
+        "kernel": "arg_activation_kernel",
+        "workload": "AerosolActivation ARG2000 N_activated_per_mode, 5 shared lognormal kappa-modes x thermodynamic states",
+        "columns_in": 4, "columns_out": 5, "diag_cols": list(out.N_act),
+    }
+    return list(state), step, desc, cpu_run
+
+
 def cpu_baseline(args, cols_np, desc, cpu_run):
     """The oracle — a C restatement of the reference's scalar arithmetic (kind 'port'; the Julia reference cannot
     run here) — timed on the host cores over repeated passes of a bounded sample of the same synthetic workload."""
@@ -209,7 +239,7 @@ def main():
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     n = args.points                                          # weak scaling: fixed work per GPU
     # rank r owns shard r of the global [0, world·n) index space: disjoint seeds, no exchange
-    setup = {"sb2006": setup_sb2006, "icenuc": setup_icenuc, "mp1m": setup_mp1m}[args.workload]
+    setup = {"sb2006": setup_sb2006, "icenuc": setup_icenuc, "mp1m": setup_mp1m, "arg2000": setup_arg2000}[args.workload]
     state, kernel_step, desc, cpu_run = setup(args, dev, dtype, rank)
 
     def step():

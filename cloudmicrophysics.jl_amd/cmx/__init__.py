@@ -20,4 +20,6 @@ from .microphysics1m import (Instantaneous, Microphysics1Moment, SourceTerms1M, 
                              TerminalVelocities1M, bulk_microphysics_tendencies_1m,
                              microphysics_source_terms_1m, terminal_velocity_1m)
 
+from .aerosol import ActivationResult, AerosolDistribution, Mode_B, Mode_kappa, aerosol_activation  # noqa: F401
+
 __version__ = "0.1.0"

@@ -16,6 +16,8 @@ CMX_SB2006_LIMITED = 1 << 0
 CMX_VEL_SB2006 = 1 << 1
 CMX_VEL_CHEN2022 = 1 << 2
 
+CMX_ARG_MAX_MODES = 8
+
 CMX_ICENUC_HOM_LINEAR = 1 << 0
 CMX_ICENUC_ERR_SLOTS = 64
 CMX_ICENUC_ERR_WORDS = 1024
@@ -137,6 +139,12 @@ def _family(ft, sfx):
         ("process_params", ns.process_params_1m), ("cloud_liquid", ns.cloud_liquid), ("cloud_ice", ns.cloud_ice),
         ("rain", ns.rain), ("snow", ns.snow), ("air_properties", ns.air_properties),
         ("vel_rain", ns.blk1m_vel_rain), ("vel_snow", ns.blk1m_vel_snow)])
+    # ---- ARG2000 aerosol activation
+    ns.aerosol_activation_params = _struct(f"cmx_aerosol_activation_params_{sfx}",
+                                           s("M_w", "R", "rho_w", "rho_i", "sigma", "g", "f1", "f2", "g1", "g2", "p1", "p2"))
+    ns.aerosol_mode = _struct(f"cmx_aerosol_mode_{sfx}", s("r_dry", "stdev", "N", "hygroscopicity", "molar_mass_mix"))
+    ns.aerosol_distribution = _struct(f"cmx_aerosol_distribution_{sfx}", [
+        ("n_modes", C.c_int32), ("pad_", C.c_int32), ("modes", ns.aerosol_mode * CMX_ARG_MAX_MODES)])
     return ns
 
 

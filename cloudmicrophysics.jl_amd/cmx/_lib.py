@@ -63,6 +63,10 @@ def _declare(lib):
         f = getattr(lib, f"cmx_mp1m_terminal_velocity_{s}")
         f.restype = i32
         f.argtypes = [C.POINTER(fam.microphysics_1m), C.POINTER(fam.chen2022_rain_vel), i64] + [vp] * 6 + [vp]
+        f = getattr(lib, f"cmx_arg2000_activation_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.aerosol_activation_params), C.POINTER(fam.aerosol_distribution),
+                      C.POINTER(fam.air_properties), C.POINTER(fam.thermo), i64] + [vp] * 8 + [C.POINTER(vp), C.POINTER(vp), vp, vp]
         f = getattr(lib, f"cmx_column_sums_{s}")
         f.restype = i32
         f.argtypes = [i32, C.POINTER(vp), i64, vp, vp]

@@ -143,6 +143,25 @@ DEFAULT_PARAMETERS = {
     "cloud_liquid_rain_collision_efficiency": 0.8, "cloud_liquid_snow_collision_efficiency": 0.1,
     "cloud_ice_rain_collision_efficiency": 1.0, "cloud_ice_snow_collision_efficiency": 0.1,
     "rain_snow_collision_efficiency": 1.0, "rain_snow_velocity_dispersion_coefficient": 0.2,
+    # ---- ARG2000 aerosol activation (src/parameters/AerosolActivation.jl:38-53).  f/g/p: docs/src/AerosolActivation.md:
+    # 190-204; the physical constants are the ClimaParams defaults (not in the reference tree; pinned only to ≈5 % by the
+    # digitised ARG2000 Fig. 1 test, test/aerosol_activation_tests.jl:236-299 — "parity unpinned" beyond that)
+    "molar_mass_water": 0.01801528, "universal_gas_constant": 8.3144598, "density_ice_water": 916.7,
+    "surface_tension_water": 0.072,
+    "ARG2000_f_coeff_1": 0.5, "ARG2000_f_coeff_2": 2.5, "ARG2000_g_coeff_1": 1.0, "ARG2000_g_coeff_2": 0.25,
+    "ARG2000_pow_1": 1.5, "ARG2000_pow_2": 0.75,
+    # aerosol species used by the reference tests (test/gpu_tests.jl:563-571; src/parameters/AerosolSeasalt.jl, AerosolSulfate.jl)
+    "seasalt_aerosol_molar_mass": 0.058443, "seasalt_aerosol_density": 2170.0, "seasalt_aerosol_osmotic_coefficient": 0.9,
+    "seasalt_aerosol_ion_number": 2.0, "seasalt_aerosol_water_soluble_mass_fraction": 1.0, "seasalt_aerosol_kappa": 1.12,
+    "sulfate_aerosol_molar_mass": 0.132, "sulfate_aerosol_density": 1770.0, "sulfate_aerosol_osmotic_coefficient": 1.0,
+    "sulfate_aerosol_ion_number": 3.0, "sulfate_aerosol_water_soluble_mass_fraction": 1.0, "sulfate_aerosol_kappa": 0.53,
+}
+
+# the reference's calibrated override file src/parameters/toml/ARG2000.toml (PySDM-based calibration)
+ARG2000_CALIBRATED_OVERRIDE = {
+    "ARG2000_f_coeff_1": 0.26583888195264627, "ARG2000_f_coeff_2": 2.3851515425961853,
+    "ARG2000_g_coeff_1": 0.779519468021862, "ARG2000_g_coeff_2": 0.10571967167118024,
+    "ARG2000_pow_1": 1.6523365679298359, "ARG2000_pow_2": 0.7578626397779737,
 }
 
 # the reference's override file src/parameters/toml/SB2006_limiters.toml (used by its CPU tests,
@@ -506,6 +525,33 @@ class Microphysics1MParams:
     @property
     def flags(self):
         return self.processes.flags
+
+
+def AerosolActivationParameters(FT):
+    """CMP.AerosolActivationParameters — src/parameters/AerosolActivation.jl:12-55."""
+    td = _td(FT)
+    return td.fam.aerosol_activation_params(
+        M_w=td["molar_mass_water"], R=td["universal_gas_constant"], rho_w=td["density_liquid_water"],
+        rho_i=td["density_ice_water"], sigma=td["surface_tension_water"], g=td["gravitational_acceleration"],
+        f1=td["ARG2000_f_coeff_1"], f2=td["ARG2000_f_coeff_2"], g1=td["ARG2000_g_coeff_1"], g2=td["ARG2000_g_coeff_2"],
+        p1=td["ARG2000_pow_1"], p2=td["ARG2000_pow_2"])
+
+
+class _AerosolSpecies:
+    def __init__(self, td, name):
+        g = lambda k: td[f"{name}_aerosol_{k}"]  # noqa: E731
+        self.M, self.rho, self.phi = g("molar_mass"), g("density"), g("osmotic_coefficient")
+        self.nu, self.eps, self.kappa = g("ion_number"), g("water_soluble_mass_fraction"), g("kappa")
+
+
+def Seasalt(FT):
+    """CMP.Seasalt(FT): M, ρ, ϕ, ν, ϵ, κ (src/parameters/AerosolSeasalt.jl)."""
+    return _AerosolSpecies(_td(FT), "seasalt")
+
+
+def Sulfate(FT):
+    """CMP.Sulfate(FT) (src/parameters/AerosolSulfate.jl)."""
+    return _AerosolSpecies(_td(FT), "sulfate")
 
 
 def rain_vel_params(FT):

@@ -78,6 +78,42 @@ def mp1m_state(n: int, dtype=torch.float32, device="cpu", seed: int = 1234, chun
     return State1M(*cols)
 
 
+ArgState = namedtuple("ArgState", ["T", "p", "w", "q_tot"])
+
+
+def arg_state(n: int, dtype=torch.float32, device="cpu", seed: int = 1234, chunk: int = 1 << 24) -> ArgState:
+    """Thermodynamic states for BASELINE config 3: T ~ U[253, 303] K, p ~ U[5e4, 1.02e5] Pa,
+    w ~ log-U[0.01, 10] m/s, q_tot = q_vs(T, p)·U[0.98, 1] (q_vs as in test/aerosol_activation_tests.jl:33-34:
+    saturated, no condensate)."""
+    td = P.DEFAULT_PARAMETERS
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    cols = [torch.empty(n, dtype=dtype, device=device) for _ in range(4)]
+    rv_rd = td["gas_constant_vapor"] / td["gas_constant_dry_air"]
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        u = lambda: torch.rand(m, dtype=torch.float64, device=device, generator=g)  # noqa: E731
+        T = 253.0 + 50.0 * u()
+        p = 5e4 + 5.2e4 * u()
+        w = torch.exp(-4.605170185988091 + u() * 6.907755278982137)
+        p_vs = _psat_liquid(T, td)
+        q_vs = 1.0 / (1.0 - rv_rd * (p_vs - p) / p_vs)
+        q_tot = q_vs * (0.98 + 0.02 * u())
+        for dst, src in zip(cols, (T, p, w, q_tot)):
+            dst[lo:lo + m] = src.to(dtype)
+    return ArgState(*cols)
+
+
+def arg_config3_distribution():
+    """The 5 lognormal κ-modes of BASELINE config 3: r_dry = (0.01, 0.05, 0.1, 0.25, 1.5) µm,
+    σ = (1.6, 2.0, 1.8, 1.4, 2.1), N = (1e9, 1e8, 5e7, 1e8, 1e6) m⁻³, κ = (0.53, 0.53, 1.12, 1.12, 1.12)
+    (sulfate, sulfate, sea salt ×3), shared by all states."""
+    from .aerosol import AerosolDistribution, Mode_kappa
+    spec = [(0.01e-6, 1.6, 1e9, 0.53, 0.132), (0.05e-6, 2.0, 1e8, 0.53, 0.132), (0.1e-6, 1.8, 5e7, 1.12, 0.058443),
+            (0.25e-6, 1.4, 1e8, 1.12, 0.058443), (1.5e-6, 2.1, 1e6, 1.12, 0.058443)]
+    return AerosolDistribution([Mode_kappa(r, s, N, (1.0,), (1.0,), (M,), (k,)) for r, s, N, k, M in spec])
+
+
 IceNucState = namedtuple("IceNucState", ["T", "a_w", "r"])
 
 

@@ -1,0 +1,294 @@
+// cmx_arg_kernels.hip — Abdul-Razzak & Ghan (2000) aerosol activation, fused per thermodynamic state, for
+// gfx950; C-ABI entry points of include/cmx.h §(6).
+//
+// Reference (src = /root/reference/src): AerosolActivation.jl — coeff_of_curvature :35-40,
+// critical_supersaturation :107-118, max_supersaturation :138-200, N_activated_per_mode :235-259,
+// M_activated_per_mode :294-321 (which evaluates critical_supersaturation and the thermodynamics twice per call).
+//
+// HBM-bound pointwise map: 4 (up to 8) state columns in, n_modes (+n_modes +1) columns out — 36 B/state for the
+// BASELINE config (4 in, 5 modes out, f32).  The aerosol distribution is shared by all states, so everything that
+// depends only on a mode (f_i, g_i, ln σ_i terms, N_i, hygroscopicity, r_dry) is folded on the host into per-mode
+// constants and lives in SGPRs; per state the mode loop costs 2 exp2 + 1 log2 for the S_max sum and one erf
+// (Float32: Abramowitz–Stegun 7.1.26 on v_exp/v_rcp, |ε| ≤ 1.5e-7 absolute — the result is N_i·½·erfc, compared
+// against operands of size N_i) per requested output.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <type_traits>
+
+#include "cmx_launch.hpp"
+#include "cmx_math.hpp"
+
+namespace cmx {
+
+template <typename FT> struct ArgModeConsts {
+    FT l2_sm_c;      // log2 Sm_i = l2_sm_c + 1.5·log2 A          (Sm = 2/√B (A/(3 r_dry))^1.5)
+    FT f, g;         // f_i = f1 exp(f2 ln²σ), g_i = g1 + g2 ln σ
+    FT l2_N;         // log2 N_i      (η_i = X / N_i)
+    FT N, half_N;
+    FT u_c;          // u_i = u_c · (log2 Sm_i − log2 S_max),  u_c = 2 ln2 /(3√2 ln σ_i)
+    FT fac;          // 3 ln σ_i √2 / 2
+    FT half_M;       // Σ M_j w_j / 2
+};
+
+template <typename FT> struct ArgConsts {
+    int32_t n_modes;
+    // thermodynamics
+    FT R_v, R_d, Rv_over_Rd, inv_R_v, T_0, LH_v0, LH_s0, dcp_l, dcp_i, ps_c0, psl_a, psl_b, psi_a, psi_b, inv_T_tr;
+    FT cp_d, cpm_qt, cpm_ql, cpm_qi;
+    FT inv_K, Rv_over_D, eps_1m, eps_ft;
+    FT g, rho_w, inv_rho_w, rho_i, A_c, p1, p2, two_pi_rho_w, four_pi, inv_43pi_rho_w, inv_43pi_rho_i;
+    ArgModeConsts<FT> m[CMX_ARG_MAX_MODES];
+};
+
+template <typename FT, typename AP, typename AD, typename AI, typename TH>
+static ArgConsts<FT> make_arg_consts(const AP &ap, const AD &ad, const AI &aip, const TH &tp) {
+    ArgConsts<FT> c{};
+    const double l2e = 1.4426950408889634074, ln2 = 0.69314718055994530942, pi = 3.14159265358979323846;
+    const double eps = (double)Math<FT>::eps_1m();
+    c.n_modes = ad.n_modes;
+    const double Rv = tp.R_v, T0 = tp.T_0;
+    const double dcp_l = (double)tp.cp_v - (double)tp.cp_l, dcp_i = (double)tp.cp_v - (double)tp.cp_i;
+    c.R_v = (FT)Rv; c.R_d = (FT)tp.R_d; c.Rv_over_Rd = (FT)(Rv / (double)tp.R_d); c.inv_R_v = (FT)(1.0 / Rv);
+    c.T_0 = (FT)T0; c.LH_v0 = (FT)tp.LH_v0; c.LH_s0 = (FT)tp.LH_s0; c.dcp_l = (FT)dcp_l; c.dcp_i = (FT)dcp_i;
+    c.ps_c0 = (FT)std::log2((double)tp.press_triple);
+    c.psl_a = (FT)(dcp_l / Rv); c.psl_b = (FT)(((double)tp.LH_v0 - dcp_l * T0) / Rv * l2e);
+    c.psi_a = (FT)(dcp_i / Rv); c.psi_b = (FT)(((double)tp.LH_s0 - dcp_i * T0) / Rv * l2e);
+    c.inv_T_tr = (FT)(1.0 / (double)tp.T_triple);
+    c.cp_d = (FT)tp.cp_d; c.cpm_qt = (FT)((double)tp.cp_v - (double)tp.cp_d);
+    c.cpm_ql = (FT)((double)tp.cp_l - (double)tp.cp_v); c.cpm_qi = (FT)((double)tp.cp_i - (double)tp.cp_v);
+    c.inv_K = (FT)(1.0 / std::fmax((double)aip.K_therm, eps));
+    c.Rv_over_D = (FT)(Rv / std::fmax((double)aip.D_vapor, eps));
+    c.eps_1m = (FT)eps; c.eps_ft = Math<FT>::eps();
+    c.g = (FT)ap.g; c.rho_w = (FT)ap.rho_w; c.inv_rho_w = (FT)(1.0 / (double)ap.rho_w); c.rho_i = (FT)ap.rho_i;
+    c.A_c = (FT)(2.0 * (double)ap.sigma * (double)ap.M_w / (double)ap.rho_w / (double)ap.R);   // A = A_c / T
+    c.p1 = (FT)ap.p1; c.p2 = (FT)ap.p2;
+    c.two_pi_rho_w = (FT)(2.0 * pi * (double)ap.rho_w); c.four_pi = (FT)(4.0 * pi);
+    c.inv_43pi_rho_w = (FT)(1.0 / (4.0 / 3.0 * pi * (double)ap.rho_w));
+    c.inv_43pi_rho_i = (FT)(1.0 / (4.0 / 3.0 * pi * (double)ap.rho_i));
+    for (int k = 0; k < ad.n_modes && k < CMX_ARG_MAX_MODES; ++k) {
+        const auto &m = ad.modes[k];
+        const double ls = std::log((double)m.stdev);
+        ArgModeConsts<FT> &o = c.m[k];
+        o.l2_sm_c = (FT)(std::log2(2.0 / std::sqrt((double)m.hygroscopicity)) - 1.5 * std::log2(3.0 * (double)m.r_dry));
+        o.f = (FT)((double)ap.f1 * std::exp((double)ap.f2 * ls * ls));
+        o.g = (FT)((double)ap.g1 + (double)ap.g2 * ls);
+        o.l2_N = (FT)std::log2((double)m.N);
+        o.N = (FT)m.N; o.half_N = (FT)(0.5 * (double)m.N);
+        o.u_c = (FT)(2.0 * ln2 / (3.0 * std::sqrt(2.0) * ls));
+        o.fac = (FT)(3.0 * ls * std::sqrt(2.0) / 2.0);
+        o.half_M = (FT)((double)m.molar_mass_mix / 2.0);
+    }
+    return c;
+}
+
+// erfc for the activated fractions.  Float32: A&S 7.1.26 (|ε| ≤ 1.5e-7); Float64: OCML.
+template <typename FT> __device__ __forceinline__ FT erfc_dev(FT x);
+template <> __device__ __forceinline__ float erfc_dev<float>(float x) {
+    using M = Math<float>;
+    const float ax = __builtin_fabsf(x);
+    const float t = M::rcp(M::fma(0.3275911f, ax, 1.0f));
+    const float poly = t * M::fma(t, M::fma(t, M::fma(t, M::fma(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float e = poly * M::exp2(-(ax * ax) * 1.4426950408889634f);
+    return x >= 0.0f ? e : 2.0f - e;
+}
+template <> __device__ __forceinline__ double erfc_dev<double>(double x) { return ::erfc(x); }
+
+template <typename FT> struct ArgIO {
+    const FT *T, *p, *w, *q_tot, *q_liq, *q_ice, *N_liq, *N_ice;
+    FT *N_act[CMX_ARG_MAX_MODES], *M_act[CMX_ARG_MAX_MODES], *S_max;
+    bool want_N, want_M;
+};
+
+template <typename FT, int NM> struct ArgOut { FT smax; FT n[NM]; FT m[NM]; };
+
+// one thermodynamic state.  NM = compile-time mode count (1…8)
+template <typename FT, int NM, bool SINKS>
+__device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, FT T, FT p, FT w, FT q_tot, FT q_liq, FT q_ice,
+                                                    FT N_liq, FT N_ice, bool want_N, bool want_M) {
+    using M = Math<FT>;
+    ArgOut<FT, NM> o;
+    const FT inv_T = M::rcp(T);
+    // TD.gas_constant_air, cp_m, latent heat, air density, vapour pressures — AA:152-160
+    const FT R_m = c.R_d * (FT(1) + (c.Rv_over_Rd - FT(1)) * q_tot - c.Rv_over_Rd * (q_liq + q_ice));
+    const FT cp_m = M::fma(c.cpm_qi, q_ice, M::fma(c.cpm_ql, q_liq, M::fma(c.cpm_qt, q_tot, c.cp_d)));
+    const FT L_v = M::fma(c.dcp_l, T - c.T_0, c.LH_v0);
+    const FT inv_Rm = M::rcp(R_m), inv_cp = M::rcp(cp_m);
+    const FT rho_air = p * inv_Rm * inv_T;
+    const FT p_v = (q_tot - q_liq - q_ice) * rho_air * c.R_v * T;
+    const FT l2_TT = M::log2(T * c.inv_T_tr), dinvT = c.inv_T_tr - inv_T;
+    const FT l2_pvs = M::fma(c.psl_a, l2_TT, M::fma(c.psl_b, dinvT, c.ps_c0));
+    const FT p_vs = M::exp2(l2_pvs), inv_pvs = M::exp2(-l2_pvs);
+    const FT LoRT = L_v * c.inv_R_v * inv_T;
+    const FT G_liq = M::rcp(M::fma(L_v * c.inv_K * inv_T, LoRT - FT(1), c.Rv_over_D * T * M::rcp(M::max(p_vs, c.eps_1m))));
+    const FT G = G_liq * c.inv_rho_w;
+    const FT ratio = p_v * inv_pvs;
+    const FT alpha = ratio * (LoRT * c.g * inv_cp * inv_T - c.g * inv_Rm * inv_T);                       // AA:164
+    const FT gamma = M::fma(ratio * R_m * L_v, LoRT * inv_cp * M::rcp(p), c.R_v * T * inv_pvs);          // AA:165
+    const FT aw = alpha * w;
+    const FT aw_over_G = aw * M::rcp(G);
+    const FT sq = M::sqrt(aw_over_G);
+    const FT A = c.A_c * inv_T;                                                                          // AA:35-40
+    const FT zeta = FT(2.0 / 3.0) * A * sq;                                                               // AA:168
+    const FT l2_A15 = FT(1.5) * M::log2(A);
+    const FT l2_zeta = M::log2(zeta);
+    // η_i = sq³ / (2π ρw γ N_i)  →  log2 η_i = l2_X − log2 N_i
+    const FT X = sq * sq * sq * M::rcp(c.two_pi_rho_w * gamma);
+    const FT l2_X = M::log2(X);
+    FT tmp = FT(0);
+    FT l2_sm[NM];
+#pragma unroll
+    for (int k = 0; k < NM; ++k) {
+        l2_sm[k] = c.m[k].l2_sm_c + l2_A15;
+        const FT l2_eta = l2_X - c.m[k].l2_N;
+        const FT eta = M::exp2(l2_eta);
+        const FT t1 = c.m[k].f * M::exp2(c.p1 * (l2_zeta - l2_eta));                                      // f (ζ/η)^p1
+        const FT t2 = c.m[k].g * M::exp2(c.p2 * (FT(2) * l2_sm[k] - M::log2(M::fma(FT(3), zeta, eta))));  // g (Sm²/(η+3ζ))^p2
+        tmp = M::fma(M::exp2(FT(-2) * l2_sm[k]), t1 + t2, tmp);                                           // AA:181-183
+    }
+    const FT S_arg = M::rsqrt(tmp);                                                                        // AA:185
+    FT smax;
+    if constexpr (SINKS) {   // liquid / ice sink correction — AA:187-197
+        const FT L_s = M::fma(c.dcp_i, T - c.T_0, c.LH_s0);
+        const FT l2_pvi = M::fma(c.psi_a, l2_TT, M::fma(c.psi_b, dinvT, c.ps_c0));
+        const FT p_vi = M::exp2(l2_pvi);
+        const FT r_liq = N_liq < c.eps_ft ? FT(0) : M::exp2(M::log2(rho_air * q_liq * M::rcp(N_liq) * c.inv_43pi_rho_w) * FT(1.0 / 3.0));
+        const FT K_liq = c.four_pi * c.rho_w * N_liq * r_liq * G * gamma;
+        const FT gamma_i = M::fma(ratio * R_m * L_v, L_s * c.inv_R_v * inv_cp * inv_T * M::rcp(p), c.R_v * T * inv_pvs);
+        const FT r_ice = N_ice < c.eps_ft ? FT(0) : M::exp2(M::log2(rho_air * q_ice * M::rcp(N_ice) * c.inv_43pi_rho_i) * FT(1.0 / 3.0));
+        const FT LoRT_s = L_s * c.inv_R_v * inv_T;
+        const FT G_ice = M::rcp(M::fma(L_s * c.inv_K * inv_T, LoRT_s - FT(1), c.Rv_over_D * T * M::rcp(M::max(p_vi, c.eps_1m))));
+        const FT xi = p_vs * M::rcp(p_vi);
+        const FT K_ice = c.four_pi * N_ice * r_ice * G_ice * gamma_i;
+        smax = S_arg * (aw - K_ice * (xi - FT(1))) * M::rcp(M::fma(M::fma(K_ice, xi, K_liq), S_arg, aw));
+    } else {
+        smax = S_arg;   // N_liq = N_ice = 0: K_liq = K_ice = 0 ⇒ S_max = S_max_ARG·αw/αw
+    }
+    smax = M::max(FT(0), smax);                                                                            // AA:199
+    o.smax = smax;
+    const FT l2_smax = M::log2(smax);
+#pragma unroll
+    for (int k = 0; k < NM; ++k) {
+        const FT dl = l2_sm[k] - l2_smax;                       // log2(Sm_i / S_max)
+        const FT u = c.m[k].u_c * dl;                           // AA:255   (= ln(sm/smax)/fac, AA:316)
+        o.n[k] = want_N ? c.m[k].half_N * erfc_dev<FT>(u) : FT(0);                  // N ½ (1 − erf u)      AA:257
+        o.m[k] = want_M ? c.m[k].half_M * erfc_dev<FT>(u - c.m[k].fac) : FT(0);     // M/2 erfc(u − fac)    AA:319
+    }
+    return o;
+}
+
+template <typename FT, int NM, bool SINKS, int VEC>
+__global__ __launch_bounds__(kBlock) void arg_activation_kernel(const ArgConsts<FT> c, const ArgIO<FT> io, const int64_t nvec) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nvec) return;
+    FT T[VEC], p[VEC], w[VEC], qt[VEC], ql[VEC] = {}, qi[VEC] = {}, Nl[VEC] = {}, Ni[VEC] = {};
+    load_col<FT, VEC>(io.T, i, T); load_col<FT, VEC>(io.p, i, p); load_col<FT, VEC>(io.w, i, w); load_col<FT, VEC>(io.q_tot, i, qt);
+    if (io.q_liq) load_col<FT, VEC>(io.q_liq, i, ql);
+    if (io.q_ice) load_col<FT, VEC>(io.q_ice, i, qi);
+    if constexpr (SINKS) {
+        if (io.N_liq) load_col<FT, VEC>(io.N_liq, i, Nl);
+        if (io.N_ice) load_col<FT, VEC>(io.N_ice, i, Ni);
+    }
+    FT sm[VEC], na[NM][VEC], ma[NM][VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+        const ArgOut<FT, NM> o = arg_point<FT, NM, SINKS>(c, T[k], p[k], w[k], qt[k], ql[k], qi[k], Nl[k], Ni[k], io.want_N, io.want_M);
+        sm[k] = o.smax;
+#pragma unroll
+        for (int j = 0; j < NM; ++j) { na[j][k] = o.n[j]; ma[j][k] = o.m[j]; }
+    }
+    if (io.S_max) store_col<FT, VEC>(io.S_max, i, sm);
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+        if (io.want_N && io.N_act[j]) store_col<FT, VEC>(io.N_act[j], i, na[j]);
+        if (io.want_M && io.M_act[j]) store_col<FT, VEC>(io.M_act[j], i, ma[j]);
+    }
+}
+
+template <typename FT, int NM, bool SINKS>
+static void launch_arg(const ArgConsts<FT> &c, const ArgIO<FT> &io0, int64_t n, const void *const *ptrs, int nptrs, hipStream_t s) {
+    constexpr int VEC = Math<FT>::VEC;
+    const uintptr_t mis0 = reinterpret_cast<uintptr_t>(io0.T) & 15u;
+    bool same_mis = (mis0 % sizeof(FT)) == 0;
+    for (int k = 0; k < nptrs; ++k)
+        if (ptrs[k]) same_mis = same_mis && ((reinterpret_cast<uintptr_t>(ptrs[k]) & 15u) == mis0);
+    auto off = [](auto *p, int64_t lo) { return p ? p + lo : p; };
+    auto launch_range = [&](auto vec_tag, int64_t lo, int64_t count) {
+        constexpr int V = decltype(vec_tag)::value;
+        if (count <= 0) return;
+        ArgIO<FT> io = io0;
+        io.T += lo; io.p += lo; io.w += lo; io.q_tot += lo;
+        io.q_liq = off(io.q_liq, lo); io.q_ice = off(io.q_ice, lo); io.N_liq = off(io.N_liq, lo); io.N_ice = off(io.N_ice, lo);
+        io.S_max = off(io.S_max, lo);
+        for (int j = 0; j < CMX_ARG_MAX_MODES; ++j) { io.N_act[j] = off(io.N_act[j], lo); io.M_act[j] = off(io.M_act[j], lo); }
+        const int64_t nv = count / V;
+        hipLaunchKernelGGL((arg_activation_kernel<FT, NM, SINKS, V>), dim3((unsigned)((nv + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, c, io, nv);
+    };
+    if (same_mis) {
+        const int64_t head = std::min<int64_t>(n, mis0 ? (int64_t)((16 - mis0) / sizeof(FT)) : 0);
+        const int64_t body = ((n - head) / VEC) * VEC;
+        launch_range(std::integral_constant<int, 1>{}, 0, head);
+        launch_range(std::integral_constant<int, VEC>{}, head, body);
+        launch_range(std::integral_constant<int, 1>{}, head + body, n - head - body);
+    } else {
+        launch_range(std::integral_constant<int, 1>{}, 0, n);
+    }
+}
+
+template <typename FT, typename AP, typename AD, typename AI, typename TH>
+static int32_t arg_entry(const AP *ap, const AD *ad, const AI *aip, const TH *tps, int64_t n, const FT *T, const FT *p,
+                         const FT *w, const FT *q_tot, const FT *q_liq, const FT *q_ice, const FT *N_liq, const FT *N_ice,
+                         FT *const *N_act, FT *const *M_act, FT *S_max, void *stream) {
+    if (!ap || !ad || !aip || !tps || n < 0 || ad->n_modes < 1 || ad->n_modes > CMX_ARG_MAX_MODES) return CMX_ERR_BAD_ARG;
+    if (n == 0) return CMX_OK;
+    if (!T || !p || !w || !q_tot) return CMX_ERR_BAD_ARG;
+    const ArgConsts<FT> c = make_arg_consts<FT>(*ap, *ad, *aip, *tps);
+    ArgIO<FT> io{};
+    io.T = T; io.p = p; io.w = w; io.q_tot = q_tot; io.q_liq = q_liq; io.q_ice = q_ice; io.N_liq = N_liq; io.N_ice = N_ice;
+    io.S_max = S_max; io.want_N = N_act != nullptr; io.want_M = M_act != nullptr;
+    const void *ptrs[8 + 2 * CMX_ARG_MAX_MODES + 1] = {T, p, w, q_tot, q_liq, q_ice, N_liq, N_ice, S_max};
+    int np = 9;
+    for (int j = 0; j < ad->n_modes; ++j) {
+        io.N_act[j] = N_act ? N_act[j] : nullptr;
+        io.M_act[j] = M_act ? M_act[j] : nullptr;
+        ptrs[np++] = io.N_act[j];
+        ptrs[np++] = io.M_act[j];
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool sinks = N_liq || N_ice;
+#define CMX_ARG_CASE(NM)                                                             \
+    case NM:                                                                         \
+        if (sinks) launch_arg<FT, NM, true>(c, io, n, ptrs, np, s);                  \
+        else launch_arg<FT, NM, false>(c, io, n, ptrs, np, s);                       \
+        break;
+    switch (ad->n_modes) {
+        CMX_ARG_CASE(1) CMX_ARG_CASE(2) CMX_ARG_CASE(3) CMX_ARG_CASE(4)
+        CMX_ARG_CASE(5) CMX_ARG_CASE(6) CMX_ARG_CASE(7) CMX_ARG_CASE(8)
+        default: return CMX_ERR_BAD_ARG;
+    }
+#undef CMX_ARG_CASE
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+
+}  // namespace cmx
+
+extern "C" {
+
+int32_t cmx_arg2000_activation_f32(const cmx_aerosol_activation_params_f32 *ap, const cmx_aerosol_distribution_f32 *ad,
+                                   const cmx_air_properties_f32 *aip, const cmx_thermo_f32 *tps, int64_t n, const float *T,
+                                   const float *p, const float *w, const float *q_tot, const float *q_liq, const float *q_ice,
+                                   const float *N_liq, const float *N_ice, float *const *N_act, float *const *M_act,
+                                   float *S_max, void *stream) {
+    return cmx::arg_entry<float>(ap, ad, aip, tps, n, T, p, w, q_tot, q_liq, q_ice, N_liq, N_ice, N_act, M_act, S_max, stream);
+}
+int32_t cmx_arg2000_activation_f64(const cmx_aerosol_activation_params_f64 *ap, const cmx_aerosol_distribution_f64 *ad,
+                                   const cmx_air_properties_f64 *aip, const cmx_thermo_f64 *tps, int64_t n, const double *T,
+                                   const double *p, const double *w, const double *q_tot, const double *q_liq,
+                                   const double *q_ice, const double *N_liq, const double *N_ice, double *const *N_act,
+                                   double *const *M_act, double *S_max, void *stream) {
+    return cmx::arg_entry<double>(ap, ad, aip, tps, n, T, p, w, q_tot, q_liq, q_ice, N_liq, N_ice, N_act, M_act, S_max, stream);
+}
+
+}  // extern "C"

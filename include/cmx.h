@@ -193,7 +193,24 @@ typedef enum cmx_status {
         cmx_air_properties_##SFX air_properties;                                               \
         cmx_blk1m_vel_rain_##SFX vel_rain;                                                     \
         cmx_blk1m_vel_snow_##SFX vel_snow;                                                     \
-    } cmx_microphysics_1m_##SFX;
+    } cmx_microphysics_1m_##SFX;                                                               \
+    /* AerosolActivationParameters — src/parameters/AerosolActivation.jl:12-37 */              \
+    typedef struct cmx_aerosol_activation_params_##SFX {                                       \
+        FT M_w, R, rho_w, rho_i, sigma, g, f1, f2, g1, g2, p1, p2;                             \
+    } cmx_aerosol_activation_params_##SFX;                                                     \
+    /* One lognormal mode of an AerosolDistribution (src/AerosolModel.jl:26-100), reduced to */ \
+    /* what the activation needs: the component tuples of Mode_B / Mode_κ enter only through */ \
+    /* mean_hygroscopicity_parameter (src/AerosolActivation.jl:55-95) and Σ M_j·w_j (:313),  */ \
+    /* both evaluated on the host.                                                           */ \
+    typedef struct cmx_aerosol_mode_##SFX {                                                    \
+        FT r_dry, stdev, N, hygroscopicity, molar_mass_mix;                                    \
+    } cmx_aerosol_mode_##SFX;                                                                  \
+    typedef struct cmx_aerosol_distribution_##SFX {                                            \
+        int32_t n_modes; int32_t pad_;                                                         \
+        cmx_aerosol_mode_##SFX modes[CMX_ARG_MAX_MODES];                                       \
+    } cmx_aerosol_distribution_##SFX;
+
+#define CMX_ARG_MAX_MODES 8
 
 CMX_DECLARE_PARAM_STRUCTS(float, f32)
 CMX_DECLARE_PARAM_STRUCTS(double, f64)
@@ -408,6 +425,29 @@ int32_t cmx_mp1m_terminal_velocity_f32(const cmx_microphysics_1m_f32 *mp, const 
 int32_t cmx_mp1m_terminal_velocity_f64(const cmx_microphysics_1m_f64 *mp, const cmx_chen2022_rain_vel_f64 *chen,
                                        int64_t n, const double *rho, const double *q_rai, const double *q_sno,
                                        double *vt_rai_blk1m, double *vt_sno_blk1m, double *vt_rai_chen, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * (6) Abdul-Razzak & Ghan (2000) aerosol activation.
+ *
+ * Replaces the broadcasts
+ *   AA.N_activated_per_mode.(Ref(ap), Ref(ad), Ref(aip), Ref(tps), T, p, w, q_tot, q_liq, q_ice[, N_liq, N_ice])
+ *   AA.M_activated_per_mode.(…)      AA.max_supersaturation.(…)
+ * src/AerosolActivation.jl:138-200, 235-259, 294-321 (KA wrapper aerosol_activation_kernel!,
+ * test/gpu_tests.jl:45-79) for an aerosol distribution shared by all states (BASELINE config 3).
+ * Inputs per state: T [K], p [Pa], w [m/s], q_tot [kg/kg]; q_liq, q_ice [kg/kg] and N_liq, N_ice [1/m3] are
+ * optional columns (NULL = 0, the reference's 10-argument methods).  Outputs (all optional): `N_act` / `M_act`
+ * = host arrays of ad->n_modes device column pointers (activated number [1/m3] / mass per mode), `S_max`.
+ * ------------------------------------------------------------------------- */
+int32_t cmx_arg2000_activation_f32(
+    const cmx_aerosol_activation_params_f32 *ap, const cmx_aerosol_distribution_f32 *ad,
+    const cmx_air_properties_f32 *aip, const cmx_thermo_f32 *tps, int64_t n,
+    const float *T, const float *p, const float *w, const float *q_tot, const float *q_liq, const float *q_ice,
+    const float *N_liq, const float *N_ice, float *const *N_act, float *const *M_act, float *S_max, void *stream);
+int32_t cmx_arg2000_activation_f64(
+    const cmx_aerosol_activation_params_f64 *ap, const cmx_aerosol_distribution_f64 *ad,
+    const cmx_air_properties_f64 *aip, const cmx_thermo_f64 *tps, int64_t n,
+    const double *T, const double *p, const double *w, const double *q_tot, const double *q_liq, const double *q_ice,
+    const double *N_liq, const double *N_ice, double *const *N_act, double *const *M_act, double *S_max, void *stream);
 
 /* ---------------------------------------------------------------------------
  * (3) Optional diagnostic sums over one rank's shard: per-column

@@ -36,7 +36,11 @@
 #define M_LGAMMA lgamma
 #define M_LOG1P log1p
 #define M_EXPM1 expm1
+#define M_ERF erf
+#define M_ERFC erfc
 #include "cmx_oracle_impl.h"
+#undef M_ERF
+#undef M_ERFC
 #undef FT
 #undef SFX
 #undef M_POW
@@ -63,4 +67,6 @@
 #define M_LGAMMA lgammaf
 #define M_LOG1P log1pf
 #define M_EXPM1 expm1f
+#define M_ERF erff
+#define M_ERFC erfcf
 #include "cmx_oracle_impl.h"

@@ -700,6 +700,7 @@ void FN(cmxo_chen2022_rain_coeffs)(const TY(cmx_chen2022_rain_vel) * c, FT rho, 
 }
 
 #include "cmx_oracle_1m_impl.h"
+#include "cmx_oracle_arg_impl.h"
 
 #undef CAT_
 #undef CAT

@@ -189,6 +189,27 @@ def logistic_function_integral(fam, x, x_0, k, eps=None):
     return fn(x, x_0, k, eps)
 
 
+def arg2000_activation(fam, ap, ad, aip, tps, T, p, w, q_tot, q_liq=None, q_ice=None, N_liq=None, N_ice=None, *,
+                       float32_gates=None, nthreads=1):
+    """Oracle twin of cmx_arg2000_activation_*: dict(N_act=[…per mode], M_act=[…], S_max=array)."""
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    req = [_col(fam, a) for a in (T, p, w, q_tot)]
+    opt = [(_col(fam, a) if a is not None else (None, None)) for a in (q_liq, q_ice, N_liq, N_ice)]
+    n = req[0][0].size
+    nm = ad.n_modes
+    n_act = [np.empty(n, dtype=NP[fam.sfx]) for _ in range(nm)]
+    m_act = [np.empty(n, dtype=NP[fam.sfx]) for _ in range(nm)]
+    s_max = np.empty(n, dtype=NP[fam.sfx])
+    arr = lambda cols: (C.c_void_p * nm)(*[c.ctypes.data for c in cols])  # noqa: E731
+    fn = getattr(lib(), f"cmxo_arg2000_activation_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(ap), C.byref(ad), C.byref(aip), C.byref(tps), C.byref(th), C.c_int64(n), *[pp for _, pp in req],
+       *[pp for _, pp in opt], arr(n_act), arr(m_act), s_max.ctypes.data_as(C.c_void_p), C.c_int32(nthreads))
+    return dict(N_act=n_act, M_act=m_act, S_max=s_max)
+
+
 def psat_liquid(fam, tps, T):
     return getattr(lib(), f"cmxo_psat_liquid_{fam.sfx}")(C.byref(tps), T)
 

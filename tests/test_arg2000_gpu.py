@@ -1,0 +1,181 @@
+"""GPU parity tests of the fused ARG2000 aerosol-activation kernel through the C ABI: the data the reference's
+tests hold (digitised Fig. 1, κ-vs-B consistency), random-state parity against the oracle for the BASELINE config-3
+distribution (5 modes) and other mode counts, the liquid / ice sink path, ragged / unaligned inputs and the 1e8-state
+size-independent properties."""
+import json
+import math
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import parity
+from cmx import _abi
+from cmx import parameters as P
+from cmx.aerosol import AerosolDistribution, Mode_B, Mode_kappa
+
+pytestmark = pytest.mark.gpu
+DT = {"f32": torch.float32, "f64": torch.float64}
+G = json.loads((Path(__file__).parent / "golden" / "arg2000_kats.json").read_text())
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _params(ft):
+    return P.AerosolActivationParameters(ft), P.AirProperties(ft), P.ThermodynamicsParameters(ft)
+
+
+def _compare(got, ref, adc, ft, what):
+    """N_act / M_act are N·½·erfc(u): compared with the operand scale N_i (resp. M_i); S_max is a plain product."""
+    rtol, kap = parity.RTOL[ft], parity.CTOL[ft] / parity.RTOL[ft]
+    rep = {}
+    e = parity.scaled_err(got.S_max.cpu().numpy(), ref["S_max"], None, parity.FLOOR[ft], parity.CEIL[ft], kap)
+    rep["S_max"] = float(np.nan_to_num(e, nan=np.inf).max())
+    for name, grp, sc in (("N_act", got.N_act, lambda m: m.N), ("M_act", got.M_act, lambda m: m.molar_mass_mix)):
+        if grp is None:
+            continue
+        for k in range(adc.n_modes):
+            x = grp[k].cpu().numpy()
+            e = parity.scaled_err(x, ref[name][k], np.full(x.shape, sc(adc.modes[k])), parity.FLOOR[ft], parity.CEIL[ft], kap)
+            rep[f"{name}[{k}]"] = float(np.nan_to_num(e, nan=np.inf).max())
+    worst = max(rep.values())
+    assert worst <= rtol, (what, rep)
+    return rep
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_reference_test_data_through_the_abi(dev, ft):
+    import cmx
+    ap, aip, tps = _params(ft)
+    t64 = P.ThermodynamicsParameters("f64")
+    T, p, w = G["conditions"]["T"], G["conditions"]["p"], G["conditions"]["w"]
+    dcl = t64.cp_v - t64.cp_l
+    p_vs = t64.press_triple * (T / t64.T_triple) ** (dcl / t64.R_v) * math.exp((t64.LH_v0 - dcl * t64.T_0) / t64.R_v * (1 / t64.T_triple - 1 / T))
+    q_vs = 1 / (1 - (t64.R_v / t64.R_d) * (p_vs - p) / p_vs)
+    col = lambda v: torch.full((8,), v, dtype=DT[ft], device=dev)  # noqa: E731
+    f = G["fig1"]
+    s = P.Sulfate(ft)
+    for chem, rtol in (("B", f["rtol_B"]), ("k", f["rtol_kappa"])):
+        mk = (lambda N: Mode_B(0.05e-6, 2.0, N, (1.0,), (s.eps,), (s.phi,), (s.M,), (s.nu,), (s.rho,))) if chem == "B" else (
+            lambda N: Mode_kappa(0.05e-6, 2.0, N, (1.0,), (1.0,), (s.M,), (s.kappa,)))
+        frac = []
+        for N2 in f["N_2_per_cm3"]:
+            r = cmx.aerosol_activation(ap, AerosolDistribution([mk(100e6), mk(N2 * 1e6)]), aip, tps, col(T), col(p), col(w), col(q_vs))
+            frac.append(r.N_act[0][0].item() / 100e6)
+        obs = np.array(f["N_act_fraction_mode1"])
+        assert np.linalg.norm(np.array(frac) - obs) / max(np.linalg.norm(frac), np.linalg.norm(obs)) <= rtol   # Julia vector isapprox
+    g = G["gpu_consistency"]
+    for m in g["modes"]:
+        B = Mode_B(m["r_dry"], m["stdev"], m["N"], (1.0,), (m["eps"],), (m["phi"],), (m["M"],), (m["nu"],), (m["rho"],))
+        K = Mode_kappa(m["r_dry"], m["stdev"], m["N"], (1.0,), (1.0,), (m["M"],), (m["kappa"],))
+        rB = cmx.aerosol_activation(ap, AerosolDistribution([B]), aip, tps, col(T), col(p), col(w), col(q_vs), want=("N_act", "M_act"))
+        rK = cmx.aerosol_activation(ap, AerosolDistribution([K]), aip, tps, col(T), col(p), col(w), col(q_vs), want=("N_act", "M_act"))
+        tol = g["rtol_act"] if ft == "f64" else 2e-5
+        assert math.isclose(rB.N_act[0][0].item(), rK.N_act[0][0].item(), rel_tol=tol)
+        assert math.isclose(rB.M_act[0][0].item(), rK.M_act[0][0].item(), rel_tol=tol)
+        assert rB.N_act[0][0].item() > 0
+
+
+@pytest.mark.parametrize("ft", ["f32", "f64"])
+@pytest.mark.parametrize("nmodes", [5, 1, 2, 8])
+def test_random_state_parity(dev, oracle, ft, nmodes):
+    import cmx
+    from cmx import synthetic
+    n = 1_000_003 if nmodes == 5 else 100_001
+    st = synthetic.arg_state(n, dtype=DT[ft], seed=1234)
+    base = synthetic.arg_config3_distribution().modes
+    ad = AerosolDistribution([base[k % 5] for k in range(nmodes)])
+    ap, aip, tps = _params(ft)
+    r = cmx.aerosol_activation(ap, ad, aip, tps, *[c.to(dev) for c in st], want=("N_act", "M_act", "S_max"))
+    torch.cuda.synchronize()
+    a64, i64, t64 = _params("f64")
+    adc = ad.c_struct(a64, _abi.F64)
+    ref = oracle.arg2000_activation(_abi.F64, a64, adc, i64, t64, *[c.numpy().astype(np.float64) for c in st], nthreads=8,
+                                    float32_gates=(ft == "f32"))
+    rep = _compare(r, ref, adc, ft, f"{ft} {nmodes} modes")
+    print(f"\n[ARG parity] {ft} {nmodes} modes n={n}: worst {max(rep.values()):.2e} ({max(rep, key=rep.get)})")
+    # activated fractions are fractions
+    for k in range(nmodes):
+        assert bool((r.N_act[k] >= 0).all()) and bool((r.N_act[k] <= ad.modes[k].N * (1 + 1e-6)).all())
+
+
+@pytest.mark.parametrize("ft", ["f32", "f64"])
+def test_liquid_and_ice_sinks(dev, oracle, ft):
+    """12-argument methods (AA:138-200 with N_liq, N_ice): pre-existing droplets / crystals lower S_max."""
+    import cmx
+    from cmx import synthetic
+    n = 200_000
+    st = synthetic.arg_state(n, dtype=DT[ft], seed=7)
+    g = torch.Generator().manual_seed(3)
+    u = lambda: torch.rand(n, dtype=torch.float64, generator=g)  # noqa: E731
+    q_liq = (1e-4 * u()).to(DT[ft])
+    q_ice = (1e-5 * u() * (st.T.double() < 273.15)).to(DT[ft])
+    N_liq = torch.where(u() < 0.2, torch.zeros(n, dtype=torch.float64), torch.exp(math.log(1e6) + u() * math.log(1e3))).to(DT[ft])
+    N_ice = torch.where(u() < 0.5, torch.zeros(n, dtype=torch.float64), torch.exp(math.log(1e2) + u() * math.log(1e3))).to(DT[ft])
+    q_tot = (st.q_tot.double() + q_liq.double() + q_ice.double()).to(DT[ft])
+    cols = (st.T, st.p, st.w, q_tot, q_liq, q_ice, N_liq, N_ice)
+    ad = synthetic.arg_config3_distribution()
+    ap, aip, tps = _params(ft)
+    r = cmx.aerosol_activation(ap, ad, aip, tps, *[c.to(dev) for c in cols], want=("N_act", "S_max"))
+    r0 = cmx.aerosol_activation(ap, ad, aip, tps, *[c.to(dev) for c in cols[:6]], want=("S_max",))
+    torch.cuda.synchronize()
+    a64, i64, t64 = _params("f64")
+    adc = ad.c_struct(a64, _abi.F64)
+    ref = oracle.arg2000_activation(_abi.F64, a64, adc, i64, t64, *[c.numpy().astype(np.float64) for c in cols], nthreads=8,
+                                    float32_gates=(ft == "f32"))
+    _compare(r, ref, adc, ft, f"{ft} sinks")
+    assert bool((r.S_max <= r0.S_max * (1 + 1e-5)).all())
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 5, 257, 1023])
+def test_ragged_and_unaligned(dev, oracle, n):
+    import cmx
+    from cmx import synthetic
+    ad = synthetic.arg_config3_distribution()
+    ap, aip, tps = _params("f32")
+    st = [c.to(dev) for c in synthetic.arg_state(n + 1, seed=n)]
+    a = cmx.aerosol_activation(ap, ad, aip, tps, *[c[1:] for c in st])             # misaligned by 4 bytes
+    b = cmx.aerosol_activation(ap, ad, aip, tps, *[c[1:].clone() for c in st])
+    assert a.N_act[0].shape == (n,) and a.M_act is None and a.S_max is None
+    for x, y in zip(a.N_act, b.N_act):
+        assert torch.equal(x, y)
+    with pytest.raises(TypeError):
+        cmx.aerosol_activation(P.AerosolActivationParameters("f64"), ad, aip, tps, *st)
+
+
+def test_full_size_1e8_f32_properties(dev, oracle):
+    """BASELINE config 3: 5 lognormal modes × 1e8 thermodynamic states, Float32."""
+    import cmx
+    from cmx import sharding, synthetic
+    n = 100_000_000
+    st = synthetic.arg_state(n, dtype=torch.float32, device=dev, seed=1234)
+    ad = synthetic.arg_config3_distribution()
+    ap, aip, tps = _params("f32")
+    full = cmx.aerosol_activation(ap, ad, aip, tps, *st)
+    torch.cuda.synchronize()
+    for k, col in enumerate(full.N_act):
+        assert bool(torch.isfinite(col).all()) and bool((col >= 0).all()) and bool((col <= ad.modes[k].N * (1 + 1e-6)).all())
+    for lo, hi in ((0, 4096), (12_345_677, 12_400_001), (n - 1_000_003, n)):
+        part = cmx.aerosol_activation(ap, ad, aip, tps, *[c[lo:hi] for c in st])
+        for a, b in zip(full.N_act, part.N_act):
+            assert torch.equal(a[lo:hi], b), (lo, hi)
+    tot = cmx.column_sums(list(full.N_act))
+    acc = torch.zeros_like(tot)
+    for r in range(8):
+        lo, hi = sharding.shard_bounds(n, r, 8)
+        acc += cmx.column_sums([c[lo:hi] for c in full.N_act])
+    assert torch.allclose(tot, acc, rtol=1e-9, atol=0)
+    # monotonicity in updraught speed (stronger updraught → more activation), checked on sorted samples of one chunk
+    stride = 101
+    samp = [c[::stride].contiguous().cpu().numpy().astype(np.float64) for c in st]
+    a64, i64, t64 = _params("f64")
+    adc = ad.c_struct(a64, _abi.F64)
+    ref = oracle.arg2000_activation(_abi.F64, a64, adc, i64, t64, *samp, nthreads=8, float32_gates=True)
+    got = cmx.ActivationResult(tuple(c[::stride].contiguous() for c in full.N_act), None, torch.from_numpy(ref["S_max"]))
+    rep = _compare(got, ref, adc, "f32", "1e8 sample")
+    print(f"\n[ARG parity 1e8 f32, {samp[0].size} sampled states] worst {max(rep.values()):.2e}")
