@@ -30,7 +30,7 @@ static inline FT FN(o_max_supersaturation)(const TY(cmx_aerosol_activation_param
                                           const TY(cmx_aerosol_distribution) * ad,
                                           const TY(cmx_air_properties) * aip, const TY(cmx_thermo) * tps,
                                           const TY(cmxo_thresholds) * th, FT T, FT p, FT w, FT q_tot, FT q_liq,
-                                          FT q_ice, FT N_liq, FT N_ice) {
+                                          FT q_ice, FT N_liq, FT N_ice, FT *cond) {
     const FT pi = (FT)M_PI;
     FT R_v = tps->R_v;
     FT R_m = FN(o_gas_constant_air)(tps, q_tot, q_liq, q_ice);
@@ -66,6 +66,9 @@ static inline FT FN(o_max_supersaturation)(const TY(cmx_aerosol_activation_param
     FT K_ice = (FT)(4 * M_PI) * N_ice * r_ice * rho_i_G_i * gamma_i;
     FT S_max = S_max_ARG * (alpha * w - K_ice * (xi - (FT)1)) / (alpha * w + (K_liq + K_ice * xi) * S_max_ARG);
     (void)pi;
+    /* conditioning of the numerator αw − K_ice(ξ−1) (≥ 1; = 1 without ice): how much a relative rounding error of
+     * its operands is amplified in S_max */
+    if (cond) *cond = (M_ABS(alpha * w) + M_ABS(K_ice * (xi - (FT)1))) / M_ABS(alpha * w - K_ice * (xi - (FT)1));
     return FN(o_max)((FT)0, S_max);
 }
 
@@ -74,14 +77,16 @@ void FN(cmxo_arg2000_activation)(const TY(cmx_aerosol_activation_params) * ap, c
                                 const TY(cmx_air_properties) * aip, const TY(cmx_thermo) * tps,
                                 const TY(cmxo_thresholds) * th, int64_t n, const FT *T, const FT *p, const FT *w,
                                 const FT *q_tot, const FT *q_liq, const FT *q_ice, const FT *N_liq, const FT *N_ice,
-                                FT *const *N_act, FT *const *M_act, FT *S_max, int32_t nthreads) {
+                                FT *const *N_act, FT *const *M_act, FT *S_max, FT *S_cond, int32_t nthreads) {
     (void)nthreads;
 #pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
     for (int64_t i = 0; i < n; ++i) {
         FT ql = q_liq ? q_liq[i] : (FT)0, qi = q_ice ? q_ice[i] : (FT)0;
         FT Nl = N_liq ? N_liq[i] : (FT)0, Ni = N_ice ? N_ice[i] : (FT)0;
-        FT smax = FN(o_max_supersaturation)(ap, ad, aip, tps, th, T[i], p[i], w[i], q_tot[i], ql, qi, Nl, Ni);
+        FT cond = 1;
+        FT smax = FN(o_max_supersaturation)(ap, ad, aip, tps, th, T[i], p[i], w[i], q_tot[i], ql, qi, Nl, Ni, &cond);
         if (S_max) S_max[i] = smax;
+        if (S_cond) S_cond[i] = cond;
         for (int k = 0; k < ad->n_modes; ++k) {
             const TY(cmx_aerosol_mode) *m = &ad->modes[k];
             FT sm = FN(o_critical_supersaturation)(ap, m, T[i]);

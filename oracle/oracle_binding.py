@@ -202,12 +202,15 @@ def arg2000_activation(fam, ap, ad, aip, tps, T, p, w, q_tot, q_liq=None, q_ice=
     n_act = [np.empty(n, dtype=NP[fam.sfx]) for _ in range(nm)]
     m_act = [np.empty(n, dtype=NP[fam.sfx]) for _ in range(nm)]
     s_max = np.empty(n, dtype=NP[fam.sfx])
+    s_cond = np.empty(n, dtype=NP[fam.sfx])
     arr = lambda cols: (C.c_void_p * nm)(*[c.ctypes.data for c in cols])  # noqa: E731
     fn = getattr(lib(), f"cmxo_arg2000_activation_{fam.sfx}")
     fn.restype = None
     fn(C.byref(ap), C.byref(ad), C.byref(aip), C.byref(tps), C.byref(th), C.c_int64(n), *[pp for _, pp in req],
-       *[pp for _, pp in opt], arr(n_act), arr(m_act), s_max.ctypes.data_as(C.c_void_p), C.c_int32(nthreads))
-    return dict(N_act=n_act, M_act=m_act, S_max=s_max)
+       *[pp for _, pp in opt], arr(n_act), arr(m_act), s_max.ctypes.data_as(C.c_void_p),
+       s_cond.ctypes.data_as(C.c_void_p), C.c_int32(nthreads))
+    # S_cond ≥ 1: amplification of operand rounding in the ice-sink numerator αw − K_ice(ξ−1) of S_max (AA:197)
+    return dict(N_act=n_act, M_act=m_act, S_max=s_max, S_cond=s_cond)
 
 
 def psat_liquid(fam, tps, T):

@@ -128,7 +128,19 @@ def test_liquid_and_ice_sinks(dev, oracle, ft):
     adc = ad.c_struct(a64, _abi.F64)
     ref = oracle.arg2000_activation(_abi.F64, a64, adc, i64, t64, *[c.numpy().astype(np.float64) for c in cols], nthreads=8,
                                     float32_gates=(ft == "f32"))
-    _compare(r, ref, adc, ft, f"{ft} sinks")
+    # S_max = S_ARG (αw − K_ice(ξ−1)) / (…): where the ice sink nearly cancels the updraught source the numerator is a
+    # small difference of large terms (oracle: S_cond = amplification ≥ 1).  Strict parity on the well-conditioned
+    # states (amplification < 8); on the rest the error must stay within amplification × tolerance.
+    well = ref["S_cond"] < 8.0
+    assert well.mean() > 0.5
+    sel = lambda t: None if t is None else tuple(c[torch.from_numpy(well).to(c.device)] for c in t)  # noqa: E731
+    sub = cmx.ActivationResult(sel(r.N_act), None, r.S_max[torch.from_numpy(well).to(dev)])
+    ref_w = dict(N_act=[a[well] for a in ref["N_act"]], M_act=None, S_max=ref["S_max"][well])
+    _compare(sub, ref_w, adc, ft, f"{ft} sinks (well-conditioned)")
+    got_s = r.S_max.cpu().numpy().astype(np.float64)
+    err = np.abs(got_s - ref["S_max"]) / np.maximum(ref["S_max"], 1e-12)
+    pos = ref["S_max"] > 0
+    assert np.all(err[pos & ~well] <= parity.RTOL[ft] * ref["S_cond"][pos & ~well])
     assert bool((r.S_max <= r0.S_max * (1 + 1e-5)).all())
 
 
