@@ -6,7 +6,7 @@ out) over the rank's resident batch of synthetic grid points (default 1e8 Float3
 configuration BASELINE.json quotes the metric on).  Inputs are generated on the device before the timed
 region; nothing crosses PCIe inside it.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--points P] [--dtype f32|f64] [--workload sb2006|icenuc]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--points P] [--dtype f32|f64] [--workload sb2006|icenuc|mp1m|arg2000|p3]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=100_000_000, help="grid points per GPU")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--workload", choices=["sb2006", "icenuc", "mp1m", "arg2000"], default="sb2006")
+    ap.add_argument("--workload", choices=["sb2006", "icenuc", "mp1m", "arg2000", "p3"], default="sb2006")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the bounded baseline sample")
     ap.add_argument("--diagnostics", action="store_true",
@@ -197,6 +197,35 @@ def setup_arg2000(args, dev, dtype, rank):
     return list(state), step, desc, cpu_run
 
 
+def setup_p3(args, dev, dtype, rank):
+    import cmx
+    from cmx import _abi
+    from cmx import parameters as P
+    from cmx import synthetic
+    state = synthetic.p3_state(args.points, dtype=dtype, device=dev, seed=1234 + rank)
+    p = P.ParametersP3(args.dtype)
+    holder = {}
+
+    def step():
+        holder["out"] = cmx.p3_shape(p, *state)
+
+    def cpu_run(ob, cols, threads):
+        fam = _abi.family(args.dtype)
+        return lambda: ob.p3_shape(fam, p.c, 0, *cols, nthreads=threads)
+
+    step()
+    desc = {
+        "metric": "grid-points/sec P3 shape solve (log-lambda root + D_m)",
+        "bytes_per_point": {"f32": 24, "f64": 48}[args.dtype],      # 4 in + logλ, D_m out
+        "kernel": "p3_shape_kernel",
+        "workload": "P3Scheme state_from_prognostic + get_distribution_logλ (Brent root of the shape equation, "
+                    "incomplete-gamma moments) + D_m per column",
+        "columns_in": 4, "columns_out": 2, "diag_cols": [],
+        "note": "compute-bound (≈1e4 FP64 VALU operations per point: the kernel's HBM fraction is small by nature)",
+    }
+    return list(state), step, desc, cpu_run
+
+
 def cpu_baseline(args, cols_np, desc, cpu_run):
     """The oracle — a C restatement of the reference's scalar arithmetic (kind 'port'; the Julia reference cannot
     run here) — timed on the host cores over repeated passes of a bounded sample of the same synthetic workload."""
@@ -239,7 +268,8 @@ def main():
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     n = args.points                                          # weak scaling: fixed work per GPU
     # rank r owns shard r of the global [0, world·n) index space: disjoint seeds, no exchange
-    setup = {"sb2006": setup_sb2006, "icenuc": setup_icenuc, "mp1m": setup_mp1m, "arg2000": setup_arg2000}[args.workload]
+    setup = {"sb2006": setup_sb2006, "icenuc": setup_icenuc, "mp1m": setup_mp1m, "arg2000": setup_arg2000,
+             "p3": setup_p3}[args.workload]
     state, kernel_step, desc, cpu_run = setup(args, dev, dtype, rank)
 
     def step():
@@ -290,8 +320,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, args.dtype, n),
                          "kernel": desc["kernel"], "kernel_ms": kern_ms, "bytes_per_point": bpp},
         }
+        if "note" in desc:
+            line["roofline"]["note"] = desc["note"]
         if not args.no_cpu_baseline and world == 1:
-            m = min(n, 20_000_000 if args.workload == "sb2006" else 4_000_000)
+            m = min(n, {"sb2006": 20_000_000, "p3": 400_000}.get(args.workload, 4_000_000))
             cols_np = [np.ascontiguousarray(c[:m].cpu().numpy()) for c in state]
             line["cpu_baseline"] = cpu_baseline(args, cols_np, desc, cpu_run)
         print(json.dumps(line), flush=True)

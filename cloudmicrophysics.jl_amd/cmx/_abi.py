@@ -17,6 +17,8 @@ CMX_VEL_SB2006 = 1 << 1
 CMX_VEL_CHEN2022 = 1 << 2
 
 CMX_ARG_MAX_MODES = 8
+CMX_P3_INPUT_IS_STATE = 1 << 0
+CMX_P3_SLOPE_CONSTANT = 1 << 1
 
 CMX_ICENUC_HOM_LINEAR = 1 << 0
 CMX_ICENUC_ERR_SLOTS = 64
@@ -145,6 +147,10 @@ def _family(ft, sfx):
     ns.aerosol_mode = _struct(f"cmx_aerosol_mode_{sfx}", s("r_dry", "stdev", "N", "hygroscopicity", "molar_mass_mix"))
     ns.aerosol_distribution = _struct(f"cmx_aerosol_distribution_{sfx}", [
         ("n_modes", C.c_int32), ("pad_", C.c_int32), ("modes", ns.aerosol_mode * CMX_ARG_MAX_MODES)])
+    # ---- P3
+    ns.p3_params = _struct(f"cmx_p3_params_{sfx}",
+                           s("alpha_va", "beta_va", "gamma", "sigma", "slope_a", "slope_b", "slope_c", "mu_max", "mu_const",
+                             "rho_i", "rho_l", "tau_wet", "T_freeze"))
     return ns
 
 

@@ -155,6 +155,13 @@ DEFAULT_PARAMETERS = {
     "seasalt_aerosol_ion_number": 2.0, "seasalt_aerosol_water_soluble_mass_fraction": 1.0, "seasalt_aerosol_kappa": 1.12,
     "sulfate_aerosol_molar_mass": 0.132, "sulfate_aerosol_density": 1770.0, "sulfate_aerosol_osmotic_coefficient": 1.0,
     "sulfate_aerosol_ion_number": 3.0, "sulfate_aerosol_water_soluble_mass_fraction": 1.0, "sulfate_aerosol_kappa": 0.53,
+    # ---- P3 (src/parameters/MicrophysicsP3.jl name maps :33-36,67,115-120,144,305-308; docs/src/P3Scheme.md:56-59,327)
+    # α_va = BF1995_mass_coeff_alpha · 10^(6β−3) (MicrophysicsP3.jl:37-41)
+    "BF1995_mass_coeff_alpha": 7.38e-11, "BF1995_mass_exponent_beta": 1.9,
+    "M1996_area_coeff_gamma": 0.2285, "M1996_area_exponent_sigma": 1.88,
+    "Heymsfield_mu_coeff1": 0.00191, "Heymsfield_mu_coeff2": 0.8, "Heymsfield_mu_coeff3": 2.0, "Heymsfield_mu_cutoff": 6.0,
+    "P3_constant_slope_parameterization_value": 0.0,   # SlopeConstant default (unpinned; only used with slope_law="constant")
+    "P3_wet_growth_timescale": 100.0,                  # not read by the shape solver
 }
 
 # the reference's calibrated override file src/parameters/toml/ARG2000.toml (PySDM-based calibration)
@@ -525,6 +532,28 @@ class Microphysics1MParams:
     @property
     def flags(self):
         return self.processes.flags
+
+
+class ParametersP3:
+    """CMP.ParametersP3(FT; slope_law = :powerlaw | :constant) — src/parameters/MicrophysicsP3.jl:267-320 (the fields
+    the shape solver reads).  Values: docs/src/P3Scheme.md:56-59,327 (β_va = 1.9, α_va = 7.38e-11·10^(6β−3), γ = 0.2285,
+    σ = 1.88, μ = clamp(0.00191 λ^0.8 − 2, 0, 6)), ρ_i = 916.7; pinned by get_ρ_d = 488.9120789986414
+    (src/P3_particle_properties.jl:185-188) and the D_m KATs (test/p3_tests.jl:440-447)."""
+
+    def __init__(self, FT, slope_law: str = "powerlaw"):
+        td = _td(FT)
+        self.fam = td.fam
+        if slope_law not in ("powerlaw", "constant"):
+            raise ValueError("slope_law must be 'powerlaw' or 'constant'")
+        self.flags = _abi.CMX_P3_SLOPE_CONSTANT if slope_law == "constant" else 0
+        beta = td["BF1995_mass_exponent_beta"]
+        self.c = td.fam.p3_params(
+            alpha_va=td["BF1995_mass_coeff_alpha"] * 10 ** (6 * beta - 3), beta_va=beta,
+            gamma=td["M1996_area_coeff_gamma"], sigma=td["M1996_area_exponent_sigma"],
+            slope_a=td["Heymsfield_mu_coeff1"], slope_b=td["Heymsfield_mu_coeff2"], slope_c=td["Heymsfield_mu_coeff3"],
+            mu_max=td["Heymsfield_mu_cutoff"], mu_const=td["P3_constant_slope_parameterization_value"],
+            rho_i=td["density_ice_water"], rho_l=td["density_liquid_water"], tau_wet=td["P3_wet_growth_timescale"],
+            T_freeze=td["temperature_water_freeze"])
 
 
 def AerosolActivationParameters(FT):

@@ -114,6 +114,32 @@ def arg_config3_distribution():
     return AerosolDistribution([Mode_kappa(r, s, N, (1.0,), (1.0,), (M,), (k,)) for r, s, N, k, M in spec])
 
 
+P3State4 = namedtuple("P3State4", ["rho_q_ice", "rho_n_ice", "rho_q_rim", "rho_b_rim"])
+
+
+def p3_state(n: int, dtype=torch.float64, device="cpu", seed: int = 1234, chunk: int = 1 << 22) -> P3State4:
+    """Prognostic P3 ice columns for BASELINE config 5 (the sweep of test/p3_tests.jl:247-250 randomised):
+    L_ice ~ log-U[1e-6, 1e-3] kg/m³, N_ice ~ log-U[1e2, 1e6] m⁻³, F_rim ∈ {0 (30 %), U[0, 0.95]}, ρ_rim ~ U[200, 800];
+    ρq_rim = F_rim·L_ice, ρb_rim = ρq_rim/ρ_rim; 1 % of the points have no ice at all (logλ = −Inf path)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    cols = [torch.empty(n, dtype=dtype, device=device) for _ in range(4)]
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        u = lambda: torch.rand(m, dtype=torch.float64, device=device, generator=g)  # noqa: E731
+        L = torch.exp(-13.815510557964274 + u() * 6.907755278982137)
+        N = torch.exp(4.605170185988092 + u() * 9.210340371976184)
+        F = torch.where(u() < 0.3, torch.zeros_like(L), 0.95 * u())
+        rho_rim = 200.0 + 600.0 * u()
+        none = u() < 0.01
+        L = torch.where(none, torch.zeros_like(L), L)
+        q_rim = F * L
+        b_rim = q_rim / rho_rim
+        for dst, src in zip(cols, (L, N, q_rim, b_rim)):
+            dst[lo:lo + m] = src.to(dtype)
+    return P3State4(*cols)
+
+
 IceNucState = namedtuple("IceNucState", ["T", "a_w", "r"])
 
 

@@ -208,7 +208,14 @@ typedef enum cmx_status {
     typedef struct cmx_aerosol_distribution_##SFX {                                            \
         int32_t n_modes; int32_t pad_;                                                         \
         cmx_aerosol_mode_##SFX modes[CMX_ARG_MAX_MODES];                                       \
-    } cmx_aerosol_distribution_##SFX;
+    } cmx_aerosol_distribution_##SFX;                                                          \
+    /* ParametersP3 (src/parameters/MicrophysicsP3.jl:267-286), the fields the shape solver  */ \
+    /* reads: MassPowerLaw (α_va, β_va :26-31), AreaPowerLaw (γ, σ :60-65), SlopePowerLaw    */ \
+    /* (a, b, c, μ_max :104-113) or SlopeConstant (μ :139-142), ρ_i, ρ_l                      */ \
+    typedef struct cmx_p3_params_##SFX {                                                       \
+        FT alpha_va, beta_va, gamma, sigma, slope_a, slope_b, slope_c, mu_max, mu_const,       \
+            rho_i, rho_l, tau_wet, T_freeze;                                                   \
+    } cmx_p3_params_##SFX;
 
 #define CMX_ARG_MAX_MODES 8
 
@@ -448,6 +455,31 @@ int32_t cmx_arg2000_activation_f64(
     const cmx_air_properties_f64 *aip, const cmx_thermo_f64 *tps, int64_t n,
     const double *T, const double *p, const double *w, const double *q_tot, const double *q_liq, const double *q_ice,
     const double *N_liq, const double *N_ice, double *const *N_act, double *const *M_act, double *S_max, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * (7) P3 ice scheme: state construction, size-distribution shape solver, mass-weighted mean diameter.
+ *
+ * Replaces, per point,
+ *   state = P3.state_from_prognostic(params, ρq_ice, ρn_ice, ρq_rim, ρb_rim)    src/P3_particle_properties.jl:101-106
+ *           (or P3.P3State(params, ρq_ice, ρn_ice, F_rim, ρ_rim) with CMX_P3_INPUT_IS_STATE, :43-56)
+ *   logλ  = P3.get_distribution_logλ(state)                                      src/P3_size_distribution.jl:284-320
+ *   D_m   = P3.D_m(state, logλ)                                                  src/P3_integral_properties.jl:56-61
+ *   logN₀ = P3.get_logN₀(ρn_ice, μ(logλ), logλ)                                  src/P3_size_distribution.jl:233-237
+ * (KA wrappers test_P3_get_distribution_logλ_kernel!, benchmark_p3_kernel!, test/gpu_tests.jl:436-451,
+ * test/gpu_performance.jl:59-67).  Compute-bound: ≈12 evaluations of the shape residual per point, each 8 incomplete-
+ * gamma evaluations of 20/30 fixed iterations (src/Utilities.jl:93-144).  The root is bracketed on logλ ∈ [2, 17] with
+ * Brent's method like the reference (same end-point fallbacks, :295-297); logλ = −Inf when ρn_ice or ρq_ice < eps(FT).
+ * Output columns may be NULL.
+ * ------------------------------------------------------------------------- */
+#define CMX_P3_INPUT_IS_STATE   (1u << 0)   /* columns 3, 4 are (F_rim, ρ_rim) instead of (ρq_rim, ρb_rim) */
+#define CMX_P3_SLOPE_CONSTANT   (1u << 1)   /* SlopeConstant (μ = mu_const) instead of SlopePowerLaw */
+
+int32_t cmx_p3_shape_f32(const cmx_p3_params_f32 *params, uint32_t flags, int64_t n, const float *rho_q_ice,
+                         const float *rho_n_ice, const float *x3, const float *x4, float *F_rim, float *rho_rim,
+                         float *log_lambda, float *D_m, float *log_N0, void *stream);
+int32_t cmx_p3_shape_f64(const cmx_p3_params_f64 *params, uint32_t flags, int64_t n, const double *rho_q_ice,
+                         const double *rho_n_ice, const double *x3, const double *x4, double *F_rim, double *rho_rim,
+                         double *log_lambda, double *D_m, double *log_N0, void *stream);
 
 /* ---------------------------------------------------------------------------
  * (3) Optional diagnostic sums over one rank's shard: per-column

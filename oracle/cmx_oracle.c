@@ -38,9 +38,17 @@
 #define M_EXPM1 expm1
 #define M_ERF erf
 #define M_ERFC erfc
+#define M_TANH tanh
+#define M_ATANH atanh
+#define M_LOG2 log2
+#define M_EPS DBL_EPSILON
 #include "cmx_oracle_impl.h"
 #undef M_ERF
 #undef M_ERFC
+#undef M_TANH
+#undef M_ATANH
+#undef M_LOG2
+#undef M_EPS
 #undef FT
 #undef SFX
 #undef M_POW
@@ -69,4 +77,8 @@
 #define M_EXPM1 expm1f
 #define M_ERF erff
 #define M_ERFC erfcf
+#define M_TANH tanhf
+#define M_ATANH atanhf
+#define M_LOG2 log2f
+#define M_EPS FLT_EPSILON
 #include "cmx_oracle_impl.h"

@@ -701,6 +701,7 @@ void FN(cmxo_chen2022_rain_coeffs)(const TY(cmx_chen2022_rain_vel) * c, FT rho, 
 
 #include "cmx_oracle_1m_impl.h"
 #include "cmx_oracle_arg_impl.h"
+#include "cmx_oracle_p3_impl.h"
 
 #undef CAT_
 #undef CAT

@@ -1,0 +1,229 @@
+/*
+ * cmx_oracle_p3_impl.h — oracle (TEST INFRASTRUCTURE) for the P3 ice scheme: state construction, regime
+ * thresholds, the size-distribution shape solver and the mass-weighted mean diameter.
+ * Included from cmx_oracle_impl.h (once per float type).  Restates, operation by operation:
+ *   src/Utilities.jl        gamma_inc :93-144, unrolled_logsumexp :399-412, sgs_weight_function /
+ *                           _regularised_ratio / rime_mass_fraction / rime_density :445-509
+ *   src/P3_particle_properties.jl  P3State :43-56, state_from_prognostic :101-106, exprel :159-199,
+ *                           get_ρ_d :191-199(+doc), get_ρ_g, thresholds :222-272, regime_value :320-332,
+ *                           ice_mass_coeffs :346-356
+ *   src/P3_size_distribution.jl    loggamma_inc_moment :97-109, loggamma_moment :151-157, get_μ :171-173,
+ *                           logmass_gamma_moment :193-200, logLdivN :211-216, get_logN₀ :233-237,
+ *                           get_distribution_logλ :284-320
+ *   src/P3_integral_properties.jl  D_m :56-61
+ * of the reference.  SpecialFunctions.loggamma → libm lgamma; LogExpFunctions.xexpy(x, y) = x·eʸ.
+ * RootSolvers.jl (compat "0.3, 0.4, 1"; un-vendored) BrentsMethod is restated from Brent's published algorithm
+ * (inverse quadratic interpolation / secant with bisection safeguards); the reference runs it for a FIXED number
+ * of iterations (8 Float32 / 10 Float64, P3_size_distribution.jl:311) — here `maxiters` is an input, and parity is
+ * asserted on the converged root, not on the iterates.
+ */
+
+typedef struct TY(cmxo_p3_state) {
+    FT rho_q_ice, rho_n_ice, F_rim, rho_rim, rho_g, D_th, D_gr, D_cr;
+} TY(cmxo_p3_state);
+
+/* UT.gamma_inc — src/Utilities.jl:93-144: (P, Q) with a fixed number of series / Lentz iterations */
+static inline void FN(o_gamma_inc)(FT a, FT x, int maxiters, FT *P, FT *Q) {
+    if (x <= 0) { *P = 0; *Q = 1; return; }
+    if (isinf(x)) { *P = 1; *Q = 0; return; }
+    FT factor = M_EXP(a * M_LOG(x) - x - M_LGAMMA(a));
+    if (x < a + 1) {
+        FT term = (FT)1 / a, sum = term;
+        for (int k = 1; k <= maxiters; ++k) { term *= x / (a + k); sum += term; }
+        FT p = FN(o_clamp)(factor * sum, (FT)0, (FT)1);
+        *P = p; *Q = (FT)1 - p;
+    } else {
+        const FT tiny = (FT)1e-30;
+        FT b1 = x + 1 - a, c = b1 + 1 / tiny, d = 1 / b1, h = d;
+        for (int k = 1; k <= maxiters; ++k) {
+            FT ak = -(FT)k * ((FT)k - a), bk = x + 2 * k + 1 - a;
+            FT dt = bk + ak * d;
+            d = M_ABS(dt) < tiny ? tiny : dt;
+            FT ct = bk + ak / c;
+            c = M_ABS(ct) < tiny ? tiny : ct;
+            d = 1 / d;
+            h *= c * d;
+        }
+        FT q = FN(o_clamp)(factor * h, (FT)0, (FT)1);
+        *P = (FT)1 - q; *Q = q;
+    }
+}
+
+/* UT.sgs_weight_function / _regularised_ratio — src/Utilities.jl:445-488 */
+static inline FT FN(o_sgs_weight)(FT a, FT a_half) {
+    if (a < 0) return 0;
+    if (a > FN(o_min)((FT)1, 42 * a_half)) return 1;
+    if (4 * a < M_EPS) return 0;
+    return (1 + M_TANH(2 * M_ATANH(1 - 2 * M_POW(1 - a, -1 / M_LOG2(1 - a_half))))) / 2;
+}
+static inline FT FN(o_regularised_ratio)(FT num, FT den) {
+    FT half = M_EPS, eps2 = M_EPS * M_EPS;
+    FT wgt = FN(o_sgs_weight)(den, half);
+    return den < eps2 ? (FT)0 : wgt * num / den;
+}
+/* exprel — src/P3_particle_properties.jl:159-199 */
+static inline FT FN(o_exprel1)(FT x) { return M_EXPM1(x) / x; }
+static inline FT FN(o_exprel2)(FT x) {
+    if (M_ABS(x) < (FT)(1.0 / 5)) {   /* evalpoly(x, (1/2!, …, 1/9!)) */
+        static const double inv_fac[8] = {1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880};
+        FT r = (FT)inv_fac[7];
+        for (int i = 6; i >= 0; --i) r = r * x + (FT)inv_fac[i];
+        return r;
+    }
+    return (M_EXPM1(x) - x) / (x * x);
+}
+/* get_ρ_d — :191-199 */
+static inline FT FN(o_p3_rho_d)(const TY(cmx_p3_params) * pr, FT F_rim, FT rho_rim) {
+    FT p = 1 / (3 - pr->beta_va);
+    FT logFu = M_LOG1P(-F_rim);
+    FT phi1 = FN(o_exprel1)(logFu);
+    FT phi1mp = FN(o_exprel1)((1 - p) * logFu);
+    FT H = -p * FN(o_exprel2)(-p * logFu) - (1 - p) * FN(o_exprel2)((1 - p) * logFu);
+    FT G = H - phi1mp * phi1;
+    return -(rho_rim * phi1 * phi1mp) / G;
+}
+static inline FT FN(o_p3_threshold)(const TY(cmx_p3_params) * pr, FT rho) {   /* :222-226 */
+    return M_POW(6 * pr->alpha_va / ((FT)M_PI * rho), 1 / (3 - pr->beta_va));
+}
+/* P3State(params, ρq_ice, ρn_ice, F_rim, ρ_rim) — :43-56 */
+static inline TY(cmxo_p3_state) FN(o_p3_state)(const TY(cmx_p3_params) * pr, FT rho_q_ice, FT rho_n_ice, FT F_rim, FT rho_rim) {
+    TY(cmxo_p3_state) s;
+    FT rho_d = FN(o_p3_rho_d)(pr, F_rim, rho_rim);
+    s.rho_q_ice = rho_q_ice; s.rho_n_ice = rho_n_ice; s.F_rim = F_rim; s.rho_rim = rho_rim;
+    s.rho_g = F_rim * rho_rim + (1 - F_rim) * rho_d;                         /* weighted_average :293-295 */
+    s.D_th = FN(o_p3_threshold)(pr, pr->rho_i);
+    s.D_gr = (F_rim == 0) ? (FT)INFINITY : FN(o_p3_threshold)(pr, s.rho_g);
+    s.D_cr = (F_rim == 0) ? (FT)INFINITY : FN(o_p3_threshold)(pr, s.rho_g * (1 - F_rim));
+    return s;
+}
+/* state_from_prognostic — :101-106 */
+static inline TY(cmxo_p3_state) FN(o_p3_state_from_prognostic)(const TY(cmx_p3_params) * pr, FT rho_q_ice, FT rho_n_ice,
+                                                              FT rho_q_rim, FT rho_b_rim) {
+    FT F_rim = FN(o_min)(FN(o_regularised_ratio)(FN(o_min)(rho_q_rim, rho_q_ice), rho_q_ice), (FT)1 - M_EPS);
+    FT rho_rim = FN(o_min)(FN(o_regularised_ratio)(rho_q_rim, rho_b_rim), (FT)0.8 * pr->rho_l);
+    return FN(o_p3_state)(pr, rho_q_ice, rho_n_ice, F_rim, rho_rim);
+}
+/* ice_mass_coeffs at D — :346-356 with regime_value :320-332 */
+static inline void FN(o_p3_mass_coeffs)(const TY(cmx_p3_params) * pr, const TY(cmxo_p3_state) * s, FT D, FT *a, FT *b) {
+    const FT pi = (FT)M_PI;
+    FT Fu = FN(o_max)(1 - s->F_rim, M_EPS);
+    if (D < s->D_th) { *a = pr->rho_i * pi / 6; *b = 3; }
+    else if (s->F_rim == 0) { *a = pr->alpha_va; *b = pr->beta_va; }
+    else if (D < s->D_gr) { *a = pr->alpha_va; *b = pr->beta_va; }
+    else if (D < s->D_cr) { *a = s->rho_g * pi / 6; *b = 3; }
+    else { *a = pr->alpha_va / Fu; *b = pr->beta_va; }
+}
+/* get_μ — :171-173 */
+static inline FT FN(o_p3_mu)(const TY(cmx_p3_params) * pr, uint32_t flags, FT loglam) {
+    if (flags & CMX_P3_SLOPE_CONSTANT) return pr->mu_const;
+    return FN(o_clamp)(pr->slope_a * M_POW(M_EXP(loglam), pr->slope_b) - pr->slope_c, (FT)0, pr->mu_max);
+}
+/* loggamma_inc_moment — :97-109 */
+static inline FT FN(o_loggamma_inc_moment)(FT D1, FT D2, FT mu, FT loglam, FT k, FT scale, int gi_iters) {
+    if (!(D1 < D2)) return -(FT)INFINITY;
+    FT z = k + mu + 1;
+    FT x1 = D1 * M_EXP(loglam), x2 = D2 * M_EXP(loglam);
+    FT p1, q1, p2, q2;
+    FN(o_gamma_inc)(z, x1, gi_iters, &p1, &q1);
+    FN(o_gamma_inc)(z, x2, gi_iters, &p2, &q2);
+    FT dq = x2 < z + 1 ? p2 - p1 : q1 - q2;
+    dq = FN(o_max)(dq, M_EPS);
+    return -z * loglam + M_LGAMMA(z) + M_LOG(dq) + M_LOG(scale);
+}
+/* logmass_gamma_moment — :193-200 (4 segments + unrolled_logsumexp, Utilities.jl:399-412) */
+static inline FT FN(o_logmass_gamma_moment)(const TY(cmx_p3_params) * pr, const TY(cmxo_p3_state) * s, FT mu, FT loglam,
+                                           FT n, int gi_iters) {
+    FT bnd[5] = {0, s->D_th, s->D_gr, s->D_cr, (FT)INFINITY};
+    FT m[4], xmax = -(FT)INFINITY;
+    for (int i = 0; i < 4; ++i) {
+        FT a, b;
+        FN(o_p3_mass_coeffs)(pr, s, (bnd[i] + bnd[i + 1]) / 2, &a, &b);
+        m[i] = FN(o_loggamma_inc_moment)(bnd[i], bnd[i + 1], mu, loglam, b + n, a, gi_iters);
+        if (isnan(m[i])) xmax = m[i];
+        else if (!isnan(xmax) && m[i] > xmax) xmax = m[i];
+    }
+    if (!isfinite(xmax)) return xmax;
+    FT sum = 0;
+    for (int i = 0; i < 4; ++i) sum += M_EXP(m[i] - xmax);
+    return xmax + M_LOG(sum);
+}
+static inline FT FN(o_loggamma_moment)(FT mu, FT loglam, FT k) {   /* :151-157, scale = 1 */
+    FT z = k + mu + 1;
+    return -z * loglam + M_LGAMMA(z);
+}
+/* logLdivN — :211-216 */
+static inline FT FN(o_logLdivN)(const TY(cmx_p3_params) * pr, uint32_t flags, const TY(cmxo_p3_state) * s, FT loglam, int gi_iters) {
+    FT mu = FN(o_p3_mu)(pr, flags, loglam);
+    return FN(o_logmass_gamma_moment)(pr, s, mu, loglam, (FT)0, gi_iters) - FN(o_loggamma_moment)(mu, loglam, (FT)0);
+}
+/* get_distribution_logλ — :284-320 (no warm-start guess), Brent's method on [2, 17] */
+static inline FT FN(o_p3_loglambda)(const TY(cmx_p3_params) * pr, uint32_t flags, const TY(cmxo_p3_state) * s,
+                                   const TY(cmxo_thresholds) * th, int maxiters, int gi_iters) {
+    if (s->rho_n_ice < th->eps_n || s->rho_q_ice < th->eps_m) return -(FT)INFINITY;
+    FT target = M_LOG(s->rho_q_ice) - M_LOG(s->rho_n_ice);
+#define SHAPE(x) (FN(o_logLdivN)(pr, flags, s, (x), gi_iters) - target)
+    FT a = 2, b = 17, fa = SHAPE(a), fb = SHAPE(b);
+    if (!isfinite(fa) || !isfinite(fb) || fa * fb > 0) return M_ABS(fa) <= M_ABS(fb) ? a : b;
+    if (M_ABS(fa) < M_ABS(fb)) { FT t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
+    FT c = a, fc = fa, d = 0;
+    int mflag = 1;
+    for (int it = 0; it < maxiters; ++it) {
+        if (fb == 0 || a == b) break;
+        FT sx;
+        if (fa != fc && fb != fc)
+            sx = a * fb * fc / ((fa - fb) * (fa - fc)) + b * fa * fc / ((fb - fa) * (fb - fc)) + c * fa * fb / ((fc - fa) * (fc - fb));
+        else
+            sx = b - fb * (b - a) / (fb - fa);
+        FT lo3 = (3 * a + b) / 4;
+        int out_of_range = !((sx > FN(o_min)(lo3, b)) && (sx < FN(o_max)(lo3, b)));
+        if (out_of_range || (mflag && M_ABS(sx - b) >= M_ABS(b - c) / 2) || (!mflag && M_ABS(sx - b) >= M_ABS(c - d) / 2)) {
+            sx = (a + b) / 2;
+            mflag = 1;
+        } else {
+            mflag = 0;
+        }
+        FT fs = SHAPE(sx);
+        d = c; c = b; fc = fb;
+        if (fa * fs < 0) { b = sx; fb = fs; } else { a = sx; fa = fs; }
+        if (M_ABS(fa) < M_ABS(fb)) { FT t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
+    }
+#undef SHAPE
+    return b;
+}
+/* D_m — src/P3_integral_properties.jl:56-61 */
+static inline FT FN(o_p3_D_m)(const TY(cmx_p3_params) * pr, uint32_t flags, const TY(cmxo_p3_state) * s, FT loglam, int gi_iters) {
+    FT mu = FN(o_p3_mu)(pr, flags, loglam);
+    FT mwm = FN(o_logmass_gamma_moment)(pr, s, mu, loglam, (FT)1, gi_iters);
+    FT logN0 = M_LOG(s->rho_n_ice) - FN(o_loggamma_moment)(mu, loglam, (FT)0);   /* get_logN₀ :233-237 */
+    return M_EXP(logN0 + mwm) / s->rho_q_ice;
+}
+
+/* oracle twin of cmx_p3_shape_*: columns x3, x4 are (ρq_rim, ρb_rim) or, with CMX_P3_INPUT_IS_STATE, (F_rim, ρ_rim).
+ * maxiters ≤ 0 → the reference's fixed budget (8 Float32 / 10 Float64); gi_iters ≤ 0 → 20 / 30. */
+void FN(cmxo_p3_shape)(const TY(cmx_p3_params) * pr, uint32_t flags, const TY(cmxo_thresholds) * th, int maxiters, int gi_iters,
+                      int64_t n, const FT *rho_q_ice, const FT *rho_n_ice, const FT *x3, const FT *x4, FT *F_rim, FT *rho_rim,
+                      FT *rho_g, FT *D_gr, FT *D_cr, FT *loglam, FT *D_m, FT *logN0, int32_t nthreads) {
+    if (maxiters <= 0) maxiters = sizeof(FT) == 4 ? 8 : 10;
+    if (gi_iters <= 0) gi_iters = sizeof(FT) == 4 ? 20 : 30;
+    (void)nthreads;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads > 0 ? nthreads : 1)
+    for (int64_t i = 0; i < n; ++i) {
+        TY(cmxo_p3_state) s = (flags & CMX_P3_INPUT_IS_STATE) ? FN(o_p3_state)(pr, rho_q_ice[i], rho_n_ice[i], x3[i], x4[i])
+                                                              : FN(o_p3_state_from_prognostic)(pr, rho_q_ice[i], rho_n_ice[i], x3[i], x4[i]);
+        FT ll = FN(o_p3_loglambda)(pr, flags, &s, th, maxiters, gi_iters);
+        if (F_rim) F_rim[i] = s.F_rim;
+        if (rho_rim) rho_rim[i] = s.rho_rim;
+        if (rho_g) rho_g[i] = s.rho_g;
+        if (D_gr) D_gr[i] = s.D_gr;
+        if (D_cr) D_cr[i] = s.D_cr;
+        if (loglam) loglam[i] = ll;
+        if (D_m) D_m[i] = FN(o_p3_D_m)(pr, flags, &s, ll, gi_iters);
+        if (logN0) logN0[i] = M_LOG(s.rho_n_ice) - FN(o_loggamma_moment)(FN(o_p3_mu)(pr, flags, ll), ll, (FT)0);
+    }
+}
+FT FN(cmxo_p3_rho_d)(const TY(cmx_p3_params) * pr, FT F_rim, FT rho_rim) { return FN(o_p3_rho_d)(pr, F_rim, rho_rim); }
+FT FN(cmxo_p3_logLdivN)(const TY(cmx_p3_params) * pr, uint32_t flags, FT F_rim, FT rho_rim, FT loglam) {
+    TY(cmxo_p3_state) s = FN(o_p3_state)(pr, (FT)0, (FT)0, F_rim, rho_rim);
+    return FN(o_logLdivN)(pr, flags, &s, loglam, sizeof(FT) == 4 ? 20 : 30);
+}
+void FN(cmxo_gamma_inc)(FT a, FT x, FT out[2]) { FN(o_gamma_inc)(a, x, sizeof(FT) == 4 ? 20 : 30, &out[0], &out[1]); }

@@ -213,6 +213,46 @@ def arg2000_activation(fam, ap, ad, aip, tps, T, p, w, q_tot, q_liq=None, q_ice=
     return dict(N_act=n_act, M_act=m_act, S_max=s_max, S_cond=s_cond)
 
 
+def p3_shape(fam, params, flags, rho_q_ice, rho_n_ice, x3, x4, *, float32_gates=None, maxiters=0, gi_iters=0, nthreads=1):
+    """Oracle twin of cmx_p3_shape_*: dict of F_rim, rho_rim, rho_g, D_gr, D_cr, log_lambda, D_m, log_N0.
+    maxiters / gi_iters ≤ 0 → the reference's fixed budgets (Brent 8/10, gamma_inc 20/30 for Float32/Float64)."""
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    ins = [_col(fam, a) for a in (rho_q_ice, rho_n_ice, x3, x4)]
+    n = ins[0][0].size
+    names = ["F_rim", "rho_rim", "rho_g", "D_gr", "D_cr", "log_lambda", "D_m", "log_N0"]
+    outs = {k: np.empty(n, dtype=NP[fam.sfx]) for k in names}
+    fn = getattr(lib(), f"cmxo_p3_shape_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(params), C.c_uint32(flags), C.byref(th), C.c_int(maxiters), C.c_int(gi_iters), C.c_int64(n),
+       *[p for _, p in ins], *[outs[k].ctypes.data_as(C.c_void_p) for k in names], C.c_int32(nthreads))
+    return outs
+
+
+def p3_rho_d(fam, params, F_rim, rho_rim):
+    fn = getattr(lib(), f"cmxo_p3_rho_d_{fam.sfx}")
+    fn.restype = fam.ft
+    fn.argtypes = [C.c_void_p, fam.ft, fam.ft]
+    return fn(C.addressof(params), F_rim, rho_rim)
+
+
+def p3_logLdivN(fam, params, flags, F_rim, rho_rim, loglam):
+    fn = getattr(lib(), f"cmxo_p3_logLdivN_{fam.sfx}")
+    fn.restype = fam.ft
+    fn.argtypes = [C.c_void_p, C.c_uint32, fam.ft, fam.ft, fam.ft]
+    return fn(C.addressof(params), flags, F_rim, rho_rim, loglam)
+
+
+def gamma_inc(fam, a, x):
+    out = (fam.ft * 2)()
+    fn = getattr(lib(), f"cmxo_gamma_inc_{fam.sfx}")
+    fn.restype = None
+    fn.argtypes = [fam.ft, fam.ft, C.c_void_p]
+    fn(a, x, out)
+    return out[0], out[1]
+
+
 def psat_liquid(fam, tps, T):
     return getattr(lib(), f"cmxo_psat_liquid_{fam.sfx}")(C.byref(tps), T)
 
