@@ -21,14 +21,15 @@ P3Shape = namedtuple("P3Shape", ["F_rim", "rho_rim", "log_lambda", "D_m", "log_N
 
 
 def p3_shape(params: ParametersP3, rho_q_ice, rho_n_ice, x3, x4, *, from_state=False,
-             want=("log_lambda", "D_m"), stream=None) -> P3Shape:
+             want=("log_lambda", "D_m"), brent_iters=0, stream=None) -> P3Shape:
     """Solve the P3 size distribution for every point.
 
     Inputs: ρq_ice [kg/m³], ρn_ice [1/m³] and either the prognostic rime variables (ρq_rim [kg/m³], ρb_rim [m³/m³];
     `state_from_prognostic`, src/P3_particle_properties.jl:101-106) or, with `from_state=True`, (F_rim, ρ_rim) as in
     `P3State(params, L, N, F_rim, ρ_rim)`.  Outputs (`want`): F_rim, rho_rim (the regularised state), log_lambda
     (`get_distribution_logλ`, src/P3_size_distribution.jl:284-320; −inf for absent ice), D_m (mass-weighted mean
-    diameter, src/P3_integral_properties.jl:56-61) and log_N0 (:233-237)."""
+    diameter, src/P3_integral_properties.jl:56-61) and log_N0 (:233-237).
+    `brent_iters` = 0 keeps the reference's fixed Brent budget (8 Float32 / 10 Float64 iterations, :311)."""
     if not isinstance(params, ParametersP3):
         raise TypeError("params must be ParametersP3")
     cols = (rho_q_ice, rho_n_ice, x3, x4)
@@ -44,7 +45,7 @@ def p3_shape(params: ParametersP3, rho_q_ice, rho_n_ice, x3, x4, *, from_state=F
     s = stream if stream is not None else torch.cuda.current_stream(ref.device)
     fn = getattr(_lib.lib(), f"cmx_p3_shape_{fam.sfx}")
     with torch.cuda.device(ref.device):
-        st = fn(C.byref(params.c), flags, ref.numel(), *[_ptr(t) for t in cols], *[_ptr(outs[k]) for k in P3Shape._fields],
+        st = fn(C.byref(params.c), flags, int(brent_iters), ref.numel(), *[_ptr(t) for t in cols], *[_ptr(outs[k]) for k in P3Shape._fields],
                 C.c_void_p(s.cuda_stream))
     _lib.check(fn.__name__, st)
     return P3Shape(*[outs[k] for k in P3Shape._fields])

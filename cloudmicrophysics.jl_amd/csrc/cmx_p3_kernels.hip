@@ -61,6 +61,7 @@ template <> struct PM<float> {
 
 template <typename FT> struct P3Consts {
     uint32_t flags;
+    int32_t brent_iters;   // fixed Brent iteration budget (P3_size_distribution.jl:311: 8 Float32 / 10 Float64)
     FT alpha_va, beta_va, slope_a, slope_b, slope_c, mu_max, mu_const, rho_i, rho_l_08;
     FT p_inv;            // 1/(3 − β_va)
     FT six_alpha_pi;     // 6 α_va / π
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void p3_shape_kernel(const P3Consts<FT> c, 
             if (P::abs(fa) < P::abs(fb)) { FT t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
             FT cc = a, fc = fa, d = FT(0);
             bool mflag = true;
-            for (int it = 0; it < P::kBrent; ++it) {
+            for (int it = 0; it < c.brent_iters; ++it) {
                 if (fb == FT(0) || a == b) break;
                 FT sx;
                 if (fa != fc && fb != fc)
@@ -274,12 +275,13 @@ __global__ __launch_bounds__(kBlock) void p3_shape_kernel(const P3Consts<FT> c, 
 }
 
 template <typename FT, typename PR>
-static int32_t p3_entry(const PR *params, uint32_t flags, int64_t n, const FT *rho_q, const FT *rho_n, const FT *x3, const FT *x4,
+static int32_t p3_entry(const PR *params, uint32_t flags, int32_t brent_iters, int64_t n, const FT *rho_q, const FT *rho_n, const FT *x3, const FT *x4,
                         FT *F_rim, FT *rho_rim, FT *loglam, FT *D_m, FT *logN0, void *stream) {
     if (!params || n < 0 || (flags & ~(CMX_P3_INPUT_IS_STATE | CMX_P3_SLOPE_CONSTANT))) return CMX_ERR_BAD_ARG;
     if (n == 0) return CMX_OK;
     if (!rho_q || !rho_n || !x3 || !x4) return CMX_ERR_BAD_ARG;
-    const P3Consts<FT> c = make_p3_consts<FT>(*params, flags);
+    P3Consts<FT> c = make_p3_consts<FT>(*params, flags);
+    c.brent_iters = brent_iters > 0 ? brent_iters : PM<FT>::kBrent;
     P3IO<FT> io{rho_q, rho_n, x3, x4, F_rim, rho_rim, loglam, D_m, logN0};
     hipLaunchKernelGGL((p3_shape_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                        reinterpret_cast<hipStream_t>(stream), c, io, n);
@@ -291,15 +293,15 @@ static int32_t p3_entry(const PR *params, uint32_t flags, int64_t n, const FT *r
 
 extern "C" {
 
-int32_t cmx_p3_shape_f32(const cmx_p3_params_f32 *params, uint32_t flags, int64_t n, const float *rho_q_ice, const float *rho_n_ice,
+int32_t cmx_p3_shape_f32(const cmx_p3_params_f32 *params, uint32_t flags, int32_t brent_iters, int64_t n, const float *rho_q_ice, const float *rho_n_ice,
                          const float *x3, const float *x4, float *F_rim, float *rho_rim, float *log_lambda, float *D_m,
                          float *log_N0, void *stream) {
-    return cmx::p3_entry<float>(params, flags, n, rho_q_ice, rho_n_ice, x3, x4, F_rim, rho_rim, log_lambda, D_m, log_N0, stream);
+    return cmx::p3_entry<float>(params, flags, brent_iters, n, rho_q_ice, rho_n_ice, x3, x4, F_rim, rho_rim, log_lambda, D_m, log_N0, stream);
 }
-int32_t cmx_p3_shape_f64(const cmx_p3_params_f64 *params, uint32_t flags, int64_t n, const double *rho_q_ice, const double *rho_n_ice,
+int32_t cmx_p3_shape_f64(const cmx_p3_params_f64 *params, uint32_t flags, int32_t brent_iters, int64_t n, const double *rho_q_ice, const double *rho_n_ice,
                          const double *x3, const double *x4, double *F_rim, double *rho_rim, double *log_lambda, double *D_m,
                          double *log_N0, void *stream) {
-    return cmx::p3_entry<double>(params, flags, n, rho_q_ice, rho_n_ice, x3, x4, F_rim, rho_rim, log_lambda, D_m, log_N0, stream);
+    return cmx::p3_entry<double>(params, flags, brent_iters, n, rho_q_ice, rho_n_ice, x3, x4, F_rim, rho_rim, log_lambda, D_m, log_N0, stream);
 }
 
 }  // extern "C"

@@ -469,15 +469,18 @@ int32_t cmx_arg2000_activation_f64(
  * test/gpu_performance.jl:59-67).  Compute-bound: ≈12 evaluations of the shape residual per point, each 8 incomplete-
  * gamma evaluations of 20/30 fixed iterations (src/Utilities.jl:93-144).  The root is bracketed on logλ ∈ [2, 17] with
  * Brent's method like the reference (same end-point fallbacks, :295-297); logλ = −Inf when ρn_ice or ρq_ice < eps(FT).
+ * brent_iters ≤ 0 selects the reference's fixed budget (8 Float32 / 10 Float64 iterations, :311); a larger value runs
+ * that many (the residual is non-monotonic where μ(λ) ramps, logλ ∈ [8.7, 10.4]: ≈5 % of typical states are not yet
+ * converged at the reference budget, 30 iterations converge all of them to 1e-7).
  * Output columns may be NULL.
  * ------------------------------------------------------------------------- */
 #define CMX_P3_INPUT_IS_STATE   (1u << 0)   /* columns 3, 4 are (F_rim, ρ_rim) instead of (ρq_rim, ρb_rim) */
 #define CMX_P3_SLOPE_CONSTANT   (1u << 1)   /* SlopeConstant (μ = mu_const) instead of SlopePowerLaw */
 
-int32_t cmx_p3_shape_f32(const cmx_p3_params_f32 *params, uint32_t flags, int64_t n, const float *rho_q_ice,
+int32_t cmx_p3_shape_f32(const cmx_p3_params_f32 *params, uint32_t flags, int32_t brent_iters, int64_t n, const float *rho_q_ice,
                          const float *rho_n_ice, const float *x3, const float *x4, float *F_rim, float *rho_rim,
                          float *log_lambda, float *D_m, float *log_N0, void *stream);
-int32_t cmx_p3_shape_f64(const cmx_p3_params_f64 *params, uint32_t flags, int64_t n, const double *rho_q_ice,
+int32_t cmx_p3_shape_f64(const cmx_p3_params_f64 *params, uint32_t flags, int32_t brent_iters, int64_t n, const double *rho_q_ice,
                          const double *rho_n_ice, const double *x3, const double *x4, double *F_rim, double *rho_rim,
                          double *log_lambda, double *D_m, double *log_N0, void *stream);
 

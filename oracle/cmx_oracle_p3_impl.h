@@ -20,6 +20,7 @@
 
 typedef struct TY(cmxo_p3_state) {
     FT rho_q_ice, rho_n_ice, F_rim, rho_rim, rho_g, D_th, D_gr, D_cr;
+    FT eps;   /* eps(FT) of the float type whose gates are being evaluated */
 } TY(cmxo_p3_state);
 
 /* UT.gamma_inc — src/Utilities.jl:93-144: (P, Q) with a fixed number of series / Lentz iterations */
@@ -50,15 +51,15 @@ static inline void FN(o_gamma_inc)(FT a, FT x, int maxiters, FT *P, FT *Q) {
 }
 
 /* UT.sgs_weight_function / _regularised_ratio — src/Utilities.jl:445-488 */
-static inline FT FN(o_sgs_weight)(FT a, FT a_half) {
+static inline FT FN(o_sgs_weight)(FT a, FT a_half, FT eps) {
     if (a < 0) return 0;
     if (a > FN(o_min)((FT)1, 42 * a_half)) return 1;
-    if (4 * a < M_EPS) return 0;
+    if (4 * a < eps) return 0;
     return (1 + M_TANH(2 * M_ATANH(1 - 2 * M_POW(1 - a, -1 / M_LOG2(1 - a_half))))) / 2;
 }
-static inline FT FN(o_regularised_ratio)(FT num, FT den) {
-    FT half = M_EPS, eps2 = M_EPS * M_EPS;
-    FT wgt = FN(o_sgs_weight)(den, half);
+static inline FT FN(o_regularised_ratio)(FT num, FT den, FT eps) {   /* eps = eps(FT) of the gates' float type */
+    FT half = eps, eps2 = eps * eps;
+    FT wgt = FN(o_sgs_weight)(den, half, eps);
     return den < eps2 ? (FT)0 : wgt * num / den;
 }
 /* exprel — src/P3_particle_properties.jl:159-199 */
@@ -86,8 +87,9 @@ static inline FT FN(o_p3_threshold)(const TY(cmx_p3_params) * pr, FT rho) {   /*
     return M_POW(6 * pr->alpha_va / ((FT)M_PI * rho), 1 / (3 - pr->beta_va));
 }
 /* P3State(params, ρq_ice, ρn_ice, F_rim, ρ_rim) — :43-56 */
-static inline TY(cmxo_p3_state) FN(o_p3_state)(const TY(cmx_p3_params) * pr, FT rho_q_ice, FT rho_n_ice, FT F_rim, FT rho_rim) {
+static inline TY(cmxo_p3_state) FN(o_p3_state)(const TY(cmx_p3_params) * pr, FT rho_q_ice, FT rho_n_ice, FT F_rim, FT rho_rim, FT eps) {
     TY(cmxo_p3_state) s;
+    s.eps = eps;
     FT rho_d = FN(o_p3_rho_d)(pr, F_rim, rho_rim);
     s.rho_q_ice = rho_q_ice; s.rho_n_ice = rho_n_ice; s.F_rim = F_rim; s.rho_rim = rho_rim;
     s.rho_g = F_rim * rho_rim + (1 - F_rim) * rho_d;                         /* weighted_average :293-295 */
@@ -98,15 +100,15 @@ static inline TY(cmxo_p3_state) FN(o_p3_state)(const TY(cmx_p3_params) * pr, FT 
 }
 /* state_from_prognostic — :101-106 */
 static inline TY(cmxo_p3_state) FN(o_p3_state_from_prognostic)(const TY(cmx_p3_params) * pr, FT rho_q_ice, FT rho_n_ice,
-                                                              FT rho_q_rim, FT rho_b_rim) {
-    FT F_rim = FN(o_min)(FN(o_regularised_ratio)(FN(o_min)(rho_q_rim, rho_q_ice), rho_q_ice), (FT)1 - M_EPS);
-    FT rho_rim = FN(o_min)(FN(o_regularised_ratio)(rho_q_rim, rho_b_rim), (FT)0.8 * pr->rho_l);
-    return FN(o_p3_state)(pr, rho_q_ice, rho_n_ice, F_rim, rho_rim);
+                                                              FT rho_q_rim, FT rho_b_rim, FT eps) {
+    FT F_rim = FN(o_min)(FN(o_regularised_ratio)(FN(o_min)(rho_q_rim, rho_q_ice), rho_q_ice, eps), (FT)1 - eps);
+    FT rho_rim = FN(o_min)(FN(o_regularised_ratio)(rho_q_rim, rho_b_rim, eps), (FT)0.8 * pr->rho_l);
+    return FN(o_p3_state)(pr, rho_q_ice, rho_n_ice, F_rim, rho_rim, eps);
 }
 /* ice_mass_coeffs at D — :346-356 with regime_value :320-332 */
 static inline void FN(o_p3_mass_coeffs)(const TY(cmx_p3_params) * pr, const TY(cmxo_p3_state) * s, FT D, FT *a, FT *b) {
     const FT pi = (FT)M_PI;
-    FT Fu = FN(o_max)(1 - s->F_rim, M_EPS);
+    FT Fu = FN(o_max)(1 - s->F_rim, s->eps);
     if (D < s->D_th) { *a = pr->rho_i * pi / 6; *b = 3; }
     else if (s->F_rim == 0) { *a = pr->alpha_va; *b = pr->beta_va; }
     else if (D < s->D_gr) { *a = pr->alpha_va; *b = pr->beta_va; }
@@ -119,7 +121,7 @@ static inline FT FN(o_p3_mu)(const TY(cmx_p3_params) * pr, uint32_t flags, FT lo
     return FN(o_clamp)(pr->slope_a * M_POW(M_EXP(loglam), pr->slope_b) - pr->slope_c, (FT)0, pr->mu_max);
 }
 /* loggamma_inc_moment — :97-109 */
-static inline FT FN(o_loggamma_inc_moment)(FT D1, FT D2, FT mu, FT loglam, FT k, FT scale, int gi_iters) {
+static inline FT FN(o_loggamma_inc_moment)(FT D1, FT D2, FT mu, FT loglam, FT k, FT scale, int gi_iters, FT eps) {
     if (!(D1 < D2)) return -(FT)INFINITY;
     FT z = k + mu + 1;
     FT x1 = D1 * M_EXP(loglam), x2 = D2 * M_EXP(loglam);
@@ -127,7 +129,7 @@ static inline FT FN(o_loggamma_inc_moment)(FT D1, FT D2, FT mu, FT loglam, FT k,
     FN(o_gamma_inc)(z, x1, gi_iters, &p1, &q1);
     FN(o_gamma_inc)(z, x2, gi_iters, &p2, &q2);
     FT dq = x2 < z + 1 ? p2 - p1 : q1 - q2;
-    dq = FN(o_max)(dq, M_EPS);
+    dq = FN(o_max)(dq, eps);
     return -z * loglam + M_LGAMMA(z) + M_LOG(dq) + M_LOG(scale);
 }
 /* logmass_gamma_moment — :193-200 (4 segments + unrolled_logsumexp, Utilities.jl:399-412) */
@@ -138,7 +140,7 @@ static inline FT FN(o_logmass_gamma_moment)(const TY(cmx_p3_params) * pr, const 
     for (int i = 0; i < 4; ++i) {
         FT a, b;
         FN(o_p3_mass_coeffs)(pr, s, (bnd[i] + bnd[i + 1]) / 2, &a, &b);
-        m[i] = FN(o_loggamma_inc_moment)(bnd[i], bnd[i + 1], mu, loglam, b + n, a, gi_iters);
+        m[i] = FN(o_loggamma_inc_moment)(bnd[i], bnd[i + 1], mu, loglam, b + n, a, gi_iters, s->eps);
         if (isnan(m[i])) xmax = m[i];
         else if (!isnan(xmax) && m[i] > xmax) xmax = m[i];
     }
@@ -208,8 +210,8 @@ void FN(cmxo_p3_shape)(const TY(cmx_p3_params) * pr, uint32_t flags, const TY(cm
     (void)nthreads;
 #pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads > 0 ? nthreads : 1)
     for (int64_t i = 0; i < n; ++i) {
-        TY(cmxo_p3_state) s = (flags & CMX_P3_INPUT_IS_STATE) ? FN(o_p3_state)(pr, rho_q_ice[i], rho_n_ice[i], x3[i], x4[i])
-                                                              : FN(o_p3_state_from_prognostic)(pr, rho_q_ice[i], rho_n_ice[i], x3[i], x4[i]);
+        TY(cmxo_p3_state) s = (flags & CMX_P3_INPUT_IS_STATE) ? FN(o_p3_state)(pr, rho_q_ice[i], rho_n_ice[i], x3[i], x4[i], th->eps_ft)
+                                                              : FN(o_p3_state_from_prognostic)(pr, rho_q_ice[i], rho_n_ice[i], x3[i], x4[i], th->eps_ft);
         FT ll = FN(o_p3_loglambda)(pr, flags, &s, th, maxiters, gi_iters);
         if (F_rim) F_rim[i] = s.F_rim;
         if (rho_rim) rho_rim[i] = s.rho_rim;
@@ -223,7 +225,7 @@ void FN(cmxo_p3_shape)(const TY(cmx_p3_params) * pr, uint32_t flags, const TY(cm
 }
 FT FN(cmxo_p3_rho_d)(const TY(cmx_p3_params) * pr, FT F_rim, FT rho_rim) { return FN(o_p3_rho_d)(pr, F_rim, rho_rim); }
 FT FN(cmxo_p3_logLdivN)(const TY(cmx_p3_params) * pr, uint32_t flags, FT F_rim, FT rho_rim, FT loglam) {
-    TY(cmxo_p3_state) s = FN(o_p3_state)(pr, (FT)0, (FT)0, F_rim, rho_rim);
+    TY(cmxo_p3_state) s = FN(o_p3_state)(pr, (FT)0, (FT)0, F_rim, rho_rim, M_EPS);
     return FN(o_logLdivN)(pr, flags, &s, loglam, sizeof(FT) == 4 ? 20 : 30);
 }
 void FN(cmxo_gamma_inc)(FT a, FT x, FT out[2]) { FN(o_gamma_inc)(a, x, sizeof(FT) == 4 ? 20 : 30, &out[0], &out[1]); }
