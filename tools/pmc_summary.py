@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 outputs of tools/profile.sh into the two small files that get committed under profiles/:
+  <round>_kernel_stats_<workload>_<dtype>.csv   — the cmx:: rows of the --kernel-trace --stats summary
+  <round>_pmc_traffic[_<workload>]_<dtype>.json — HBM bytes per launch from FETCH_SIZE / WRITE_SIZE (separate passes;
+                                                   gfx950 correction: FETCH_SIZE counts 32-B units → ×2 vs the KiB it
+                                                   claims, MI355X_MICROARCH.md §HBM), next to the algorithmic bytes."""
+import csv
+import glob
+import json
+import sys
+from pathlib import Path
+
+BYTES_PER_POINT = {"sb2006": 13, "icenuc": 5, "mp1m": 11, "arg2000": 9, "p3": 6}   # columns in + out
+
+
+def find(out, sub, suffix):
+    hits = glob.glob(f"{out}/{sub}/**/*{suffix}", recursive=True)
+    return hits[0] if hits else None
+
+
+def main():
+    wl, dt, n, out, rnd = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    dst = Path("gpurun_out/profiles")
+    dst.mkdir(parents=True, exist_ok=True)
+    summary = {"round": rnd, "workload": wl, "dtype": dt, "points": n,
+               "command": f"tools/profile.sh {wl} {dt} {n}  (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE in separate passes, "
+                          f"--kernel-trace --stats in a third; bench.py --steps 5 --warmup 1 --no-cpu-baseline)"}
+    stats = find(out, "kt", "kernel_stats.csv")
+    if stats:
+        rows = list(csv.reader(open(stats)))
+        keep = [rows[0]] + [r for r in rows[1:] if r and "cmx::" in r[0]]
+        with open(dst / f"{rnd}_kernel_stats_{wl}_{dt}.csv", "w", newline="") as f:
+            csv.writer(f, quoting=csv.QUOTE_NONNUMERIC).writerows(keep)
+        main_row = max(keep[1:], key=lambda r: float(r[2]), default=None)
+        if main_row:
+            summary.update(kernel=main_row[0], calls=int(main_row[1]), avg_ns=float(main_row[3]), min_ns=float(main_row[5]))
+    for sub, key in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        path = find(out, sub, "counter_collection.csv")
+        if not path:
+            continue
+        vals = []
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == key and "cmx::" in r["Kernel_Name"] and "column_sums" not in r["Kernel_Name"]:
+                vals.append(float(r["Counter_Value"]))
+                summary.setdefault("vgpr", r["VGPR_Count"]); summary.setdefault("sgpr", r["SGPR_Count"])
+                summary.setdefault("scratch", r["Scratch_Size"])
+        if vals:
+            summary[f"{key}_KiB_per_launch_mean"] = sum(vals) / len(vals)
+            summary[f"{key}_launches"] = len(vals)
+    if "FETCH_SIZE_KiB_per_launch_mean" in summary and "WRITE_SIZE_KiB_per_launch_mean" in summary:
+        fetch = summary["FETCH_SIZE_KiB_per_launch_mean"] * 1024 * 2      # gfx950 correction
+        write = summary["WRITE_SIZE_KiB_per_launch_mean"] * 1024
+        algo = n * BYTES_PER_POINT[wl] * (4 if dt == "f32" else 8)
+        summary.update(fetch_bytes_corrected=fetch, write_bytes=write, hbm_bytes_per_launch=fetch + write,
+                       algorithmic_bytes_per_launch=algo, traffic_over_algorithmic=(fetch + write) / algo)
+    tag = "" if wl == "sb2006" else f"_{wl}"
+    (dst / f"{rnd}_pmc_traffic{tag}_{dt}.json").write_text(json.dumps(summary, indent=1))
+    print(json.dumps(summary))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Profile one bench.py workload on the GPU box: kernel-trace stats + two separate PMC passes (FETCH_SIZE, WRITE_SIZE)
+# as MI355X_MICROARCH.md §HBM prescribes; summaries land in gpurun_out/profiles/ (copy them into profiles/ to commit).
+#   usage: tools/profile.sh <workload> <dtype> <points> [round-tag]
+set -u
+WL=$1; DT=$2; N=$3; R=${4:-r01}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_${WL}_${DT}
+mkdir -p "$OUT" "$ROOT/gpurun_out/profiles"
+export TMPDIR=/tmp
+ARGS="$ROOT/bench.py --workload $WL --dtype $DT --points $N --steps 5 --warmup 1 --no-cpu-baseline"
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 $ARGS > "$OUT/kt.log" 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fetch -- python3 $ARGS > "$OUT/fetch.log" 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- python3 $ARGS > "$OUT/write.log" 2>&1
+cd "$ROOT"
+python3 tools/pmc_summary.py "$WL" "$DT" "$N" "$OUT" "$R"
