@@ -22,6 +22,6 @@ from .microphysics1m import (Instantaneous, Microphysics1Moment, SourceTerms1M, 
 
 from .aerosol import ActivationResult, AerosolDistribution, Mode_B, Mode_kappa, aerosol_activation  # noqa: F401
 
-from .p3 import P3Shape, p3_shape  # noqa: F401
+from .p3 import P3Shape, P3Velocities, p3_shape, p3_terminal_velocities  # noqa: F401
 
 __version__ = "0.1.0"

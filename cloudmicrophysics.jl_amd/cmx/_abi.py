@@ -19,6 +19,8 @@ CMX_VEL_CHEN2022 = 1 << 2
 CMX_ARG_MAX_MODES = 8
 CMX_P3_INPUT_IS_STATE = 1 << 0
 CMX_P3_SLOPE_CONSTANT = 1 << 1
+CMX_P3_NO_ASPECT_RATIO = 1 << 2
+CMX_QUAD_MAX = 128
 
 CMX_ICENUC_HOM_LINEAR = 1 << 0
 CMX_ICENUC_ERR_SLOTS = 64
@@ -151,6 +153,14 @@ def _family(ft, sfx):
     ns.p3_params = _struct(f"cmx_p3_params_{sfx}",
                            s("alpha_va", "beta_va", "gamma", "sigma", "slope_a", "slope_b", "slope_c", "mu_max", "mu_const",
                              "rho_i", "rho_l", "tau_wet", "T_freeze"))
+    ns.chen2022_small_ice_vel = _struct(f"cmx_chen2022_small_ice_vel_{sfx}", [
+        ("A", ft * 3), ("B", ft * 3), ("C", ft * 4), ("E", ft * 3), ("F", ft * 3), ("G", ft * 3), ("cutoff", ft)])
+    ns.chen2022_large_ice_vel = _struct(f"cmx_chen2022_large_ice_vel_{sfx}", [
+        ("A", ft * 3), ("B", ft * 3), ("C", ft * 3), ("E", ft * 3), ("F", ft * 3), ("G", ft * 3), ("H", ft * 3), ("cutoff", ft)])
+    ns.chen2022_ice_vel = _struct(f"cmx_chen2022_ice_vel_{sfx}", [
+        ("small_ice", ns.chen2022_small_ice_vel), ("large_ice", ns.chen2022_large_ice_vel)])
+    ns.quadrature = _struct(f"cmx_quadrature_{sfx}", [
+        ("n", C.c_int32), ("reserved", C.c_int32), ("node", ft * CMX_QUAD_MAX), ("weight", ft * CMX_QUAD_MAX)])
     return ns
 
 

@@ -69,7 +69,11 @@ def _declare(lib):
                       C.POINTER(fam.air_properties), C.POINTER(fam.thermo), i64] + [vp] * 8 + [C.POINTER(vp), C.POINTER(vp), vp, vp]
         f = getattr(lib, f"cmx_p3_shape_{s}")
         f.restype = i32
-        f.argtypes = [C.POINTER(fam.p3_params), u32, i32, i64] + [vp] * 9 + [vp]
+        f.argtypes = [C.POINTER(fam.p3_params), u32, i32, i64] + [vp] * 10 + [vp]
+        f = getattr(lib, f"cmx_p3_terminal_velocities_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.p3_params), C.POINTER(fam.chen2022_ice_vel), C.POINTER(fam.quadrature), u32, fam.ft, i64] \
+            + [vp] * 8 + [vp]
         f = getattr(lib, f"cmx_column_sums_{s}")
         f.restype = i32
         f.argtypes = [i32, C.POINTER(vp), i64, vp, vp]

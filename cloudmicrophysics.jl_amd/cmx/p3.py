@@ -21,7 +21,7 @@ P3Shape = namedtuple("P3Shape", ["F_rim", "rho_rim", "log_lambda", "D_m", "log_N
 
 
 def p3_shape(params: ParametersP3, rho_q_ice, rho_n_ice, x3, x4, *, from_state=False,
-             want=("log_lambda", "D_m"), brent_iters=0, stream=None) -> P3Shape:
+             want=("log_lambda", "D_m"), brent_iters=0, log_lambda_guess=None, stream=None) -> P3Shape:
     """Solve the P3 size distribution for every point.
 
     Inputs: ρq_ice [kg/m³], ρn_ice [1/m³] and either the prognostic rime variables (ρq_rim [kg/m³], ρb_rim [m³/m³];
@@ -29,11 +29,15 @@ def p3_shape(params: ParametersP3, rho_q_ice, rho_n_ice, x3, x4, *, from_state=F
     `P3State(params, L, N, F_rim, ρ_rim)`.  Outputs (`want`): F_rim, rho_rim (the regularised state), log_lambda
     (`get_distribution_logλ`, src/P3_size_distribution.jl:284-320; −inf for absent ice), D_m (mass-weighted mean
     diameter, src/P3_integral_properties.jl:56-61) and log_N0 (:233-237).
-    `brent_iters` = 0 keeps the reference's fixed Brent budget (8 Float32 / 10 Float64 iterations, :311)."""
+    `brent_iters` = 0 keeps the reference's fixed Brent budget (8 Float32 / 10 Float64 iterations, :311);
+    `log_lambda_guess` is the reference's optional warm start (`_narrow_bracket`, :336-353)."""
     if not isinstance(params, ParametersP3):
         raise TypeError("params must be ParametersP3")
     cols = (rho_q_ice, rho_n_ice, x3, x4)
-    ref = _check_cols(cols, ("rho_q_ice", "rho_n_ice", "x3", "x4"))
+    names = ("rho_q_ice", "rho_n_ice", "x3", "x4")
+    if log_lambda_guess is not None:
+        cols, names = cols + (log_lambda_guess,), names + ("log_lambda_guess",)
+    ref = _check_cols(cols, names)
     fam = _fam_of(ref)
     if fam is not params.fam:
         raise TypeError("parameter float type does not match the state columns")
@@ -45,7 +49,45 @@ def p3_shape(params: ParametersP3, rho_q_ice, rho_n_ice, x3, x4, *, from_state=F
     s = stream if stream is not None else torch.cuda.current_stream(ref.device)
     fn = getattr(_lib.lib(), f"cmx_p3_shape_{fam.sfx}")
     with torch.cuda.device(ref.device):
-        st = fn(C.byref(params.c), flags, int(brent_iters), ref.numel(), *[_ptr(t) for t in cols], *[_ptr(outs[k]) for k in P3Shape._fields],
-                C.c_void_p(s.cuda_stream))
+        st = fn(C.byref(params.c), flags, int(brent_iters), ref.numel(), *[_ptr(t) for t in cols[:4]],
+                _ptr(log_lambda_guess) if log_lambda_guess is not None else None,
+                *[_ptr(outs[k]) for k in P3Shape._fields], C.c_void_p(s.cuda_stream))
     _lib.check(fn.__name__, st)
     return P3Shape(*[outs[k] for k in P3Shape._fields])
+
+
+P3Velocities = namedtuple("P3Velocities", ["v_n", "v_m"])
+
+
+def p3_terminal_velocities(params: ParametersP3, velocity_params, rho_air, rho_q_ice, rho_n_ice, x3, x4, log_lambda, *,
+                           from_state=False, aspect_ratio=True, p=1e-6, quad=None, want=("v_n", "v_m"),
+                           stream=None) -> P3Velocities:
+    """Number- and mass-weighted ice fall speeds for every point — `P3.ice_terminal_velocity_number_weighted` /
+    `_mass_weighted(velocity_params, ρₐ, state, logλ; p, quad)` (src/P3_terminal_velocity.jl:72-137) and their
+    `*_from_prognostic` wrappers (:152-178).  `velocity_params` = `parameters.Chen2022VelTypeIce(FT)`; `quad` =
+    `parameters.ChebyshevGauss(FT, n)` (default n = 100, as in the reference) or `parameters.GaussLegendre(FT, n)`;
+    `aspect_ratio=False` ↔ `ParametersP3(FT; aspect_ratio = NoAspectRatio())`."""
+    if not isinstance(params, ParametersP3):
+        raise TypeError("params must be ParametersP3")
+    cols = (rho_q_ice, rho_n_ice, x3, x4, rho_air, log_lambda)
+    ref = _check_cols(cols, ("rho_q_ice", "rho_n_ice", "x3", "x4", "rho_air", "log_lambda"))
+    fam = _fam_of(ref)
+    if fam is not params.fam or not isinstance(velocity_params, fam.chen2022_ice_vel):
+        raise TypeError("parameter float type does not match the state columns")
+    if quad is None:
+        from .parameters import ChebyshevGauss
+        quad = ChebyshevGauss(fam.sfx, 100)
+    if not isinstance(quad, fam.quadrature):
+        raise TypeError("quadrature float type does not match the state columns")
+    unknown = set(want) - set(P3Velocities._fields)
+    if unknown:
+        raise ValueError(f"unknown output(s) {sorted(unknown)}")
+    outs = {k: (torch.empty_like(ref) if k in want else None) for k in P3Velocities._fields}
+    flags = params.flags | (_abi.CMX_P3_INPUT_IS_STATE if from_state else 0) | (0 if aspect_ratio else _abi.CMX_P3_NO_ASPECT_RATIO)
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_p3_terminal_velocities_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(params.c), C.byref(velocity_params), C.byref(quad), flags, p, ref.numel(), *[_ptr(t) for t in cols],
+                _ptr(outs["v_n"]), _ptr(outs["v_m"]), C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return P3Velocities(outs["v_n"], outs["v_m"])

@@ -162,6 +162,17 @@ DEFAULT_PARAMETERS = {
     "Heymsfield_mu_coeff1": 0.00191, "Heymsfield_mu_coeff2": 0.8, "Heymsfield_mu_coeff3": 2.0, "Heymsfield_mu_cutoff": 6.0,
     "P3_constant_slope_parameterization_value": 0.0,   # SlopeConstant default (unpinned; only used with slope_law="constant")
     "P3_wet_growth_timescale": 100.0,                  # not read by the shape solver
+    # Chen et al. (2022) ice tables B3 (small ice) / B5 (large ice) and the small/large cutoff; pinned through the P3
+    # particle-velocity KATs (test/p3_tests.jl:283-307) and, to 14 digits, the bulk fall-speed KATs (:376-379)
+    "Chen2022_table_B3_As": (-0.263503, 0.00174079, 0.0378769), "Chen2022_table_B3_Bs": (0.575231, 0.0909307, 0.515579),
+    "Chen2022_table_B3_Cs": (-0.345387, 0.177362, -0.000427794, 0.00419647),
+    "Chen2022_table_B3_Es": (-0.156593, 0.0189334, 0.1377817), "Chen2022_table_B3_Fs": (-3.35641, 0.0156199, 0.765337),
+    "Chen2022_table_B3_Gs": (-0.0309715, 1.55054, 0.518349),
+    "Chen2022_table_B5_Al": (-0.475897, -0.00231270, 1.12293), "Chen2022_table_B5_Bl": (-2.56289, -0.00513504, 0.608459),
+    "Chen2022_table_B5_Cl": (-0.756064, 0.935922, -1.70952), "Chen2022_table_B5_El": (0.00639847, 0.00906454, -0.108232),
+    "Chen2022_table_B5_Fl": (0.515453, -0.0725042, -1.86810e19), "Chen2022_table_B5_Gl": (2.65236, 0.00158269, 259.935),
+    "Chen2022_table_B5_Hl": (-0.346044, -7.17829e-11, -1.24394e20),
+    "Chen2022_ice_cutoff": 0.000625,
 }
 
 # the reference's calibrated override file src/parameters/toml/ARG2000.toml (PySDM-based calibration)
@@ -554,6 +565,49 @@ class ParametersP3:
             mu_max=td["Heymsfield_mu_cutoff"], mu_const=td["P3_constant_slope_parameterization_value"],
             rho_i=td["density_ice_water"], rho_l=td["density_liquid_water"], tau_wet=td["P3_wet_growth_timescale"],
             T_freeze=td["temperature_water_freeze"])
+
+
+def Chen2022VelTypeIce(FT):
+    """The (small_ice, large_ice) part of CMP.Chen2022VelType(FT) — src/parameters/TerminalVelocity.jl:207-275,325-335."""
+    td = _td(FT)
+    fam = td.fam
+    arr = lambda n, key: (fam.ft * n)(*td[key])  # noqa: E731
+    small = fam.chen2022_small_ice_vel(A=arr(3, "Chen2022_table_B3_As"), B=arr(3, "Chen2022_table_B3_Bs"),
+                                       C=arr(4, "Chen2022_table_B3_Cs"), E=arr(3, "Chen2022_table_B3_Es"),
+                                       F=arr(3, "Chen2022_table_B3_Fs"), G=arr(3, "Chen2022_table_B3_Gs"),
+                                       cutoff=td["Chen2022_ice_cutoff"])
+    large = fam.chen2022_large_ice_vel(A=arr(3, "Chen2022_table_B5_Al"), B=arr(3, "Chen2022_table_B5_Bl"),
+                                       C=arr(3, "Chen2022_table_B5_Cl"), E=arr(3, "Chen2022_table_B5_El"),
+                                       F=arr(3, "Chen2022_table_B5_Fl"), G=arr(3, "Chen2022_table_B5_Gl"),
+                                       H=arr(3, "Chen2022_table_B5_Hl"), cutoff=td["Chen2022_ice_cutoff"])
+    return fam.chen2022_ice_vel(small_ice=small, large_ice=large)
+
+
+def _quadrature(FT, nodes, weights):
+    fam = _abi.family(FT)
+    n = len(nodes)
+    if not 1 <= n <= _abi.CMX_QUAD_MAX:
+        raise ValueError(f"quadrature order must be in 1..{_abi.CMX_QUAD_MAX}")
+    q = fam.quadrature(n=n)
+    for i in range(n):
+        q.node[i], q.weight[i] = float(nodes[i]), float(weights[i])
+    return q
+
+
+def ChebyshevGauss(FT, n: int = 100):
+    """Quadrature.ChebyshevGauss(n) — src/Quadrature.jl:168-175: yᵢ = cospi((2i−1)/(2n)), total weight √(1−yᵢ²)·π/n."""
+    import numpy as np
+    i = np.arange(1, n + 1, dtype=np.float64)
+    y = np.cos(np.pi * (2 * i - 1) / (2 * n))
+    return _quadrature(FT, y, np.sqrt(1 - y * y) * np.pi / n)
+
+
+def GaussLegendre(FT, n: int):
+    """Quadrature.GaussLegendre(FT, n) — src/Quadrature.jl:226-252: Float64 nodes/weights (numpy's leggauss instead of
+    FastGaussQuadrature; both are the exact Gauss–Legendre rule to double rounding) converted to FT."""
+    import numpy as np
+    y, w = np.polynomial.legendre.leggauss(n)
+    return _quadrature(FT, y, w)
 
 
 def AerosolActivationParameters(FT):

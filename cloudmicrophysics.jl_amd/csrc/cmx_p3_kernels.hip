@@ -186,23 +186,20 @@ template <typename FT> __device__ __forceinline__ FT regularised_ratio(FT num, F
     return den < P::eps() * P::eps() ? FT(0) : w * num / den;
 }
 
-template <typename FT> struct P3IO { const FT *rho_q, *rho_n, *x3, *x4; FT *F_rim, *rho_rim, *loglam, *D_m, *logN0; };
+template <typename FT> struct P3IO { const FT *rho_q, *rho_n, *x3, *x4, *guess; FT *F_rim, *rho_rim, *loglam, *D_m, *logN0; };
 
+// state_from_prognostic :101-106 (or P3State from (F_rim, ρ_rim)) → P3State :43-56: ρ_d (exact solution :191-199), ρ_g,
+// thresholds, and the per-segment mass-law coefficients (regime_value at the segment midpoint :320-332)
 template <typename FT>
-__global__ __launch_bounds__(kBlock) void p3_shape_kernel(const P3Consts<FT> c, const P3IO<FT> io, const int64_t n) {
+__device__ __forceinline__ void p3_make_point(const P3Consts<FT> &c, FT rho_q, FT rho_n, FT x3, FT x4, P3Point<FT> &s) {
     using P = PM<FT>;
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    P3Point<FT> s;
-    s.rho_q = io.rho_q[i]; s.rho_n = io.rho_n[i];
+    s.rho_q = rho_q; s.rho_n = rho_n;
     if (c.flags & CMX_P3_INPUT_IS_STATE) {
-        s.F_rim = io.x3[i]; s.rho_rim = io.x4[i];
-    } else {   // state_from_prognostic :101-106
-        const FT q_rim = io.x3[i], b_rim = io.x4[i];
-        s.F_rim = Math<FT>::min(regularised_ratio<FT>(Math<FT>::min(q_rim, s.rho_q), s.rho_q), FT(1) - P::eps());
-        s.rho_rim = Math<FT>::min(regularised_ratio<FT>(q_rim, b_rim), c.rho_l_08);
+        s.F_rim = x3; s.rho_rim = x4;
+    } else {
+        s.F_rim = Math<FT>::min(regularised_ratio<FT>(Math<FT>::min(x3, s.rho_q), s.rho_q), FT(1) - P::eps());
+        s.rho_rim = Math<FT>::min(regularised_ratio<FT>(x3, x4), c.rho_l_08);
     }
-    // P3State :43-56 — ρ_d (exact solution :191-199), ρ_g, thresholds
     {
         const FT p = c.p_inv, logFu = P::log1p(-s.F_rim);
         const FT phi1 = exprel1<FT>(logFu), phi1mp = exprel1<FT>((FT(1) - p) * logFu);
@@ -216,7 +213,7 @@ __global__ __launch_bounds__(kBlock) void p3_shape_kernel(const P3Consts<FT> c, 
     s.bnd[0] = FT(0); s.bnd[1] = c.D_th; s.bnd[2] = D_gr; s.bnd[3] = D_cr; s.bnd[4] = FT(INFINITY);
     const FT Fu = Math<FT>::max(FT(1) - s.F_rim, P::eps());
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {   // regime_value at the segment midpoint :320-332
+    for (int k = 0; k < 4; ++k) {
         const FT D = (s.bnd[k] + s.bnd[k + 1]) / FT(2);
         FT a, b;
         if (D < c.D_th) { a = c.a_sph_i; b = FT(3); }
@@ -226,23 +223,38 @@ __global__ __launch_bounds__(kBlock) void p3_shape_kernel(const P3Consts<FT> c, 
         else { a = c.alpha_va / Fu; b = c.beta_va; }
         s.log_a[k] = P::log(a); s.b[k] = b;
     }
-    // get_distribution_logλ :284-320
+}
+
+template <typename FT>
+__global__ __launch_bounds__(kBlock) void p3_shape_kernel(const P3Consts<FT> c, const P3IO<FT> io, const int64_t n) {
+    using P = PM<FT>;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    P3Point<FT> s;
+    p3_make_point<FT>(c, io.rho_q[i], io.rho_n[i], io.x3[i], io.x4[i], s);
+    // get_distribution_logλ :284-320.  All residual evaluations (the two bracket ends, the optional warm-start guess
+    // of _narrow_bracket :336-353, the Brent iterations) go through ONE inlined call site: steps −3, −2, −1, 0 … —
+    // three separate inlined copies of the residual doubled the VGPR count (255, occupancy 1).
     FT loglam;
     if (s.rho_n < P::eps() || s.rho_q < P::eps()) {
         loglam = -INFINITY;
     } else {
         const FT target = P::log(s.rho_q) - P::log(s.rho_n);
-        FT a = FT(2), b = FT(17);
-        FT fa = p3_logLdivN<FT>(c, s, a) - target, fb = p3_logLdivN<FT>(c, s, b) - target;
-        if (!isfinite(fa) || !isfinite(fb) || fa * fb > FT(0)) {
-            loglam = P::abs(fa) <= P::abs(fb) ? a : b;
-        } else {
-            if (P::abs(fa) < P::abs(fb)) { FT t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
-            FT cc = a, fc = fa, d = FT(0);
-            bool mflag = true;
-            for (int it = 0; it < c.brent_iters; ++it) {
-                if (fb == FT(0) || a == b) break;
-                FT sx;
+        FT a = FT(2), b = FT(17), fa = FT(0), fb = FT(0), cc = FT(0), fc = FT(0), d = FT(0);
+        bool mflag = true, active = true, guess_valid = false;
+        const int first = io.guess ? -3 : -2;          // wave-uniform
+        for (int it = first; it < c.brent_iters; ++it) {
+            // which abscissa this step evaluates
+            FT sx;
+            const int step = it == first ? -3 : (it == first + 1 ? -2 : it);   // −3: lo end, −2: hi end, −1: guess
+            if (step == -3) sx = a;
+            else if (step == -2) sx = b;
+            else if (step == -1) {
+                const FT pg = io.guess[i];
+                guess_valid = isfinite(pg) && (a < pg && pg < b);
+                sx = guess_valid ? pg : a;
+            } else {
+                if (!active || fb == FT(0) || a == b) { active = false; continue; }
                 if (fa != fc && fb != fc)
                     sx = a * fb * fc / ((fa - fb) * (fa - fc)) + b * fa * fc / ((fb - fa) * (fb - fc)) + cc * fa * fb / ((fc - fa) * (fc - fb));
                 else
@@ -255,13 +267,37 @@ __global__ __launch_bounds__(kBlock) void p3_shape_kernel(const P3Consts<FT> c, 
                 } else {
                     mflag = false;
                 }
-                const FT fs = p3_logLdivN<FT>(c, s, sx) - target;
+            }
+            const FT fs = p3_logLdivN<FT>(c, s, sx) - target;
+            // what the step does with the value
+            if (step == -3) {
+                fa = fs;
+            } else if (step == -2) {
+                fb = fs;
+                if (!isfinite(fa) || !isfinite(fb) || fa * fb > FT(0)) {        // no sign change: nearer end (:295-297)
+                    const bool lo_end = P::abs(fa) <= P::abs(fb);
+                    b = lo_end ? a : b; fb = lo_end ? fa : fb;
+                    active = false;
+                }
+            } else if (step == -1) {
+                if (active) {
+                    const bool valid = guess_valid && isfinite(fs);
+                    const bool left = valid && (fa * fs < FT(0)), right = valid && !left;
+                    if (left) { b = sx; fb = fs; }
+                    if (right) { a = sx; fa = fs; }
+                }
+            } else {
                 d = cc; cc = b; fc = fb;
                 if (fa * fs < FT(0)) { b = sx; fb = fs; } else { a = sx; fa = fs; }
                 if (P::abs(fa) < P::abs(fb)) { FT t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
             }
-            loglam = b;
+            // entering the Brent phase: order the bracket so that b is the better end, c = a
+            if (step < 0 && (io.guess ? step == -1 : step == -2) && active) {
+                if (P::abs(fa) < P::abs(fb)) { FT t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
+                cc = a; fc = fa; d = FT(0); mflag = true;
+            }
         }
+        loglam = b;
     }
     if (io.F_rim) io.F_rim[i] = s.F_rim;
     if (io.rho_rim) io.rho_rim[i] = s.rho_rim;
@@ -276,15 +312,185 @@ __global__ __launch_bounds__(kBlock) void p3_shape_kernel(const P3Consts<FT> c, 
 
 template <typename FT, typename PR>
 static int32_t p3_entry(const PR *params, uint32_t flags, int32_t brent_iters, int64_t n, const FT *rho_q, const FT *rho_n, const FT *x3, const FT *x4,
-                        FT *F_rim, FT *rho_rim, FT *loglam, FT *D_m, FT *logN0, void *stream) {
-    if (!params || n < 0 || (flags & ~(CMX_P3_INPUT_IS_STATE | CMX_P3_SLOPE_CONSTANT))) return CMX_ERR_BAD_ARG;
+                        const FT *guess, FT *F_rim, FT *rho_rim, FT *loglam, FT *D_m, FT *logN0, void *stream) {
+    if (!params || n < 0 || (flags & ~(CMX_P3_INPUT_IS_STATE | CMX_P3_SLOPE_CONSTANT | CMX_P3_NO_ASPECT_RATIO))) return CMX_ERR_BAD_ARG;
     if (n == 0) return CMX_OK;
     if (!rho_q || !rho_n || !x3 || !x4) return CMX_ERR_BAD_ARG;
     P3Consts<FT> c = make_p3_consts<FT>(*params, flags);
     c.brent_iters = brent_iters > 0 ? brent_iters : PM<FT>::kBrent;
-    P3IO<FT> io{rho_q, rho_n, x3, x4, F_rim, rho_rim, loglam, D_m, logN0};
+    P3IO<FT> io{rho_q, rho_n, x3, x4, guess, F_rim, rho_rim, loglam, D_m, logN0};
     hipLaunchKernelGGL((p3_shape_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                        reinterpret_cast<hipStream_t>(stream), c, io, n);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Number- and mass-weighted fall speeds — src/P3_terminal_velocity.jl:72-91,118-137.
+//
+// Per quadrature node the reference evaluates n(D)·v(D)[·m(D)] with ≈12 pow/exp/log/cbrt; here every factor is a
+// power law or an exponential of D inside one mass-regime segment, so the whole integrand is assembled in the log
+// domain from ONE log(D):  n·v = Σ_k A_k exp(base + e_k + b_k logD − c_k D),  base = logN₀ + μ logD − λD, where
+//   * (A_k, e_k, b_k, c_k) are the Chen-2022 small- or large-ice terms (selected per node by D ≤ cutoff) with the
+//     parameter-only table reductions at ρᵢ = 916.7 folded on the host and the ρₐ-dependent prefactors once per point;
+//   * the aspect factor cbrt(ϕᵢ) is exactly 1 on the two spherical segments (small ice, graupel), a pure power law
+//     of D on the unrimed / dense-rimed segment (folded into e_k, b_k: no extra transcendental), and needs the mixed
+//     area F·πD²/4 + (1−F)·γD^σ only on the partially-rimed segment (one exp + one log more);
+//   * m(D) = exp(log a_seg + b_seg logD) with the per-segment mass law of the shape solver.
+// → 4 transcendentals per node instead of ≈12; nodes/weights are wave-uniform scalar loads from the kernel arguments.
+template <typename FT> struct P3VelConsts {
+    // small ice (table B3 reduced at ρᵢ): aᵢ = (Es, Fs)·ρₐ^As·1000^b, b = Bs + ρₐ Cs, c = (0, 1000 Gs)
+    FT s_A, s_B, s_C, s_E, s_F, s_c2;
+    // large ice (table B5 reduced): a = (Bl ρₐ^Al 1000^Cl, El ρₐ^Al e^{Hl ρₐ} 1000^Fl), b = (Cl, Fl), c = (0, 1000 Gl)
+    FT l_A, l_a1, l_b1, l_a2, l_H, l_b2, l_c2;
+    FT cutoff, ln1000;
+    FT g0, g1;          // unrimed / dense-rimed aspect factor: cbrt ϕ = exp(g0 + g1 logD)
+    FT h0_num;          // partially rimed: cbrt ϕ = exp((h0_num − log Fu)/3 + β/3 logD − ½ log area)
+    FT pi_4, gamma_area, sigma_area;
+    FT p_lo, p_hi;      // FT(p), FT(1 − p)
+};
+
+template <typename FT, typename PR, typename VR>
+static P3VelConsts<FT> make_p3_vel_consts(const PR &pr, const VR &vel, double p) {
+    P3VelConsts<FT> v{};
+    const double pi = 3.14159265358979323846, rho_i = 916.7;   // src/P3_terminal_velocity.jl:41
+    const double l = std::log(rho_i), sq = std::sqrt(rho_i);
+    const auto &s = vel.small_ice;
+    const auto &g = vel.large_ice;
+    v.s_A = (FT)((double)s.A[1] * l * l - (double)s.A[2] * l + (double)s.A[0]);
+    v.s_B = (FT)(1.0 / ((double)s.B[0] + (double)s.B[1] * l + (double)s.B[2] / sq));
+    v.s_C = (FT)((double)s.C[0] + (double)s.C[1] * std::exp((double)s.C[2] * rho_i) + (double)s.C[3] * sq);
+    v.s_E = (FT)((double)s.E[0] - (double)s.E[1] * l * l + (double)s.E[2] * sq);
+    v.s_F = (FT)(-std::exp((double)s.F[0] - (double)s.F[1] * l * l + (double)s.F[2] * l));
+    v.s_c2 = (FT)(1000.0 / ((double)s.G[0] + (double)s.G[1] / l - (double)s.G[2] * l / rho_i));
+    const double Al = (double)g.A[0] + (double)g.A[1] * l + (double)g.A[2] / (rho_i * sq);
+    const double Bl = std::exp((double)g.B[0] + (double)g.B[1] * l * l + (double)g.B[2] * l);
+    const double Cl = std::exp((double)g.C[0] + (double)g.C[1] / l + (double)g.C[2] / rho_i);
+    const double El = (double)g.E[0] + (double)g.E[1] * l * sq + (double)g.E[2] * sq;
+    const double Fl = (double)g.F[0] + (double)g.F[1] * l - std::exp(std::log(-(double)g.F[2]) - rho_i);
+    const double Gl = 1.0 / ((double)g.G[0] + (double)g.G[1] * l * sq + (double)g.G[2] / sq);
+    const double Hl = (double)g.H[0] + (double)g.H[1] * rho_i * rho_i * sq + std::exp(std::log(-(double)g.H[2]) - rho_i);
+    v.l_A = (FT)Al; v.l_a1 = (FT)(Bl * std::pow(1000.0, Cl)); v.l_b1 = (FT)Cl;
+    v.l_a2 = (FT)(El * std::pow(1000.0, Fl)); v.l_H = (FT)Hl; v.l_b2 = (FT)Fl; v.l_c2 = (FT)(1000.0 * Gl);
+    v.cutoff = (FT)s.cutoff; v.ln1000 = (FT)std::log(1000.0);
+    const double al = (double)pr.alpha_va, be = (double)pr.beta_va, ga = (double)pr.gamma, si = (double)pr.sigma, ri = (double)pr.rho_i;
+    v.g0 = (FT)(std::log(3.0 * std::sqrt(pi) * al / (4.0 * ri * ga * std::sqrt(ga))) / 3.0);
+    v.g1 = (FT)((be - 1.5 * si) / 3.0);
+    v.h0_num = (FT)std::log(3.0 * std::sqrt(pi) * al / (4.0 * ri));
+    v.pi_4 = (FT)(pi / 4.0); v.gamma_area = (FT)ga; v.sigma_area = (FT)si;
+    v.p_lo = (FT)p; v.p_hi = (FT)(1.0 - p);
+    return v;
+}
+
+// UT._gamma_inc_inv — Utilities.jl:205-252 (Halley on P − p or Q − q, ≤ 15 iterations)
+template <typename FT> __device__ FT gamma_inc_inv_dev(FT a, FT p, FT q) {
+    using P = PM<FT>;
+    if (p <= FT(0)) return FT(0);
+    if (q <= FT(0)) return FT(INFINITY);
+    const FT lg = P::lgamma(a);
+    FT x = p < FT(0.5) ? P::exp((P::log(p) + lg + P::log(a)) / a) : a - P::log(q);   // (p Γ(a+1))^{1/a}
+    const bool use_q = p > FT(0.5);
+    for (int it = 0; it < 15; ++it) {
+        const FT g = gamma_inc_dev<FT>(a, x, lg, !use_q);
+        const FT f = use_q ? g - q : g - p;
+        FT fprime = P::exp((a - FT(1)) * P::log(x) - x - lg);
+        if (use_q) fprime = -fprime;
+        if (fprime == FT(0)) break;
+        const FT r = (a - FT(1) - x) / x;
+        FT step = f / (fprime * (FT(1) - FT(0.5) * f * r / fprime));
+        if (x - step <= FT(0)) step = FT(0.5) * x;
+        x = x - step;
+        if (P::abs(step) < P::eps() * x) break;
+    }
+    return x;
+}
+
+template <typename FT, typename QUAD> struct P3VelIO {
+    const FT *rho_q, *rho_n, *x3, *x4, *rho_a, *loglam; FT *v_n, *v_m;
+};
+
+template <typename FT, typename QUAD, bool ASPECT>
+__global__ __launch_bounds__(kBlock) void p3_velocity_kernel(const P3Consts<FT> c, const P3VelConsts<FT> v, const QUAD quad,
+                                                            const P3VelIO<FT, QUAD> io, const int64_t n) {
+    using P = PM<FT>;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    P3Point<FT> s;
+    p3_make_point<FT>(c, io.rho_q[i], io.rho_n[i], io.x3[i], io.x4[i], s);
+    FT vn = FT(0), vm = FT(0);
+    if (!(s.rho_n < P::eps() || s.rho_q < P::eps())) {
+        const FT loglam = io.loglam[i], lam = P::exp(loglam), mu = p3_mu<FT>(c, loglam);
+        const FT logN0 = P::log(s.rho_n) - (-(mu + FT(1)) * loglam + P::lgamma(mu + FT(1)));
+        // Chen-2022 coefficients at this air density — Common.jl:304-350
+        const FT rho_a = Math<FT>::max(io.rho_a[i], FT(0)), lra = P::log(rho_a);
+        const FT sb = v.s_B + rho_a * v.s_C, se = v.s_A * lra + sb * v.ln1000;          // small: both terms share e, b
+        const FT le1 = v.l_A * lra, le2 = le1 + v.l_H * rho_a;                           // large
+        // integral_bounds — P3_integral_properties.jl:34-46
+        const FT D_min = gamma_inc_inv_dev<FT>(mu + FT(1), v.p_lo, FT(1) - v.p_lo) / lam;
+        const FT D_max = gamma_inc_inv_dev<FT>(mu + FT(1), v.p_hi, FT(1) - v.p_hi) / lam;
+        FT bnd[5];
+        bnd[0] = D_min; bnd[4] = D_max;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) bnd[k] = Math<FT>::min(Math<FT>::max(s.bnd[k], D_min), D_max);
+        const FT Fu = Math<FT>::max(FT(1) - s.F_rim, P::eps());
+        const FT h0 = (v.h0_num - P::log(Fu)) / FT(3), h1 = c.beta_va / FT(3);
+        FT sum_n = FT(0), sum_m = FT(0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const FT a = bnd[k], b = bnd[k + 1];
+            if (!(a < b)) continue;
+            const FT scale = (b - a) / FT(2), shift = (a + b) / FT(2);
+            // aspect factor of this segment as exp(q0 + q1 logD [− ½ log area])
+            FT q0 = FT(0), q1 = FT(0);
+            const bool mixed_area = ASPECT && k == 3;
+            if (ASPECT && k == 1) { q0 = v.g0; q1 = v.g1; }
+            if (mixed_area) { q0 = h0; q1 = h1; }
+            const FT lam_ = lam, mb = s.b[k], mla = s.log_a[k];
+            FT rn = FT(0), rm = FT(0);
+            for (int j = 0; j < quad.n; ++j) {
+                const FT x = scale * quad.node[j] + shift, w = quad.weight[j];
+                const FT logD = P::log(x);
+                FT base = logN0 + mu * logD - lam_ * x + q0 + q1 * logD;
+                if (mixed_area) {
+                    const FT area = s.F_rim * v.pi_4 * x * x + (FT(1) - s.F_rim) * v.gamma_area * P::exp(v.sigma_area * logD);
+                    base -= FT(0.5) * P::log(area);
+                }
+                const bool small = x <= v.cutoff;
+                const FT A1 = small ? v.s_E : v.l_a1, A2 = small ? v.s_F : v.l_a2;
+                const FT e1 = small ? se : le1, e2 = small ? se : le2;
+                const FT b1 = small ? sb : v.l_b1, b2 = small ? sb : v.l_b2;
+                const FT c2 = small ? v.s_c2 : v.l_c2;
+                const FT nv = A1 * P::exp(base + e1 + b1 * logD) + A2 * P::exp(base + e2 + b2 * logD - c2 * x);
+                rn += nv * w;
+                rm += nv * P::exp(mla + mb * logD) * w;
+            }
+            sum_n += scale * rn; sum_m += scale * rm;
+        }
+        vn = sum_n / s.rho_n; vm = sum_m / s.rho_q;
+    }
+    if (io.v_n) io.v_n[i] = vn;
+    if (io.v_m) io.v_m[i] = vm;
+}
+
+template <typename FT, typename PR, typename VR, typename QUAD>
+static int32_t p3_velocity_entry(const PR *params, const VR *vel, const QUAD *quad, uint32_t flags, FT p, int64_t n, const FT *rho_q,
+                                 const FT *rho_n, const FT *x3, const FT *x4, const FT *rho_a, const FT *loglam, FT *v_n, FT *v_m,
+                                 void *stream) {
+    if (!params || !vel || !quad || n < 0 || (flags & ~(CMX_P3_INPUT_IS_STATE | CMX_P3_SLOPE_CONSTANT | CMX_P3_NO_ASPECT_RATIO)))
+        return CMX_ERR_BAD_ARG;
+    if (quad->n < 1 || quad->n > CMX_QUAD_MAX || !(p > FT(0) && p < FT(0.5))) return CMX_ERR_BAD_ARG;
+    if (n == 0) return CMX_OK;
+    if (!rho_q || !rho_n || !x3 || !x4 || !rho_a || !loglam) return CMX_ERR_BAD_ARG;
+    P3Consts<FT> c = make_p3_consts<FT>(*params, flags);
+    c.brent_iters = 0;
+    const P3VelConsts<FT> v = make_p3_vel_consts<FT>(*params, *vel, (double)p);
+    P3VelIO<FT, QUAD> io{rho_q, rho_n, x3, x4, rho_a, loglam, v_n, v_m};
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (flags & CMX_P3_NO_ASPECT_RATIO)
+        hipLaunchKernelGGL((p3_velocity_kernel<FT, QUAD, false>), grid, block, 0, st, c, v, *quad, io, n);
+    else
+        hipLaunchKernelGGL((p3_velocity_kernel<FT, QUAD, true>), grid, block, 0, st, c, v, *quad, io, n);
     CMX_HIP_TRY(hipGetLastError());
     return CMX_OK;
 }
@@ -294,14 +500,29 @@ static int32_t p3_entry(const PR *params, uint32_t flags, int32_t brent_iters, i
 extern "C" {
 
 int32_t cmx_p3_shape_f32(const cmx_p3_params_f32 *params, uint32_t flags, int32_t brent_iters, int64_t n, const float *rho_q_ice, const float *rho_n_ice,
-                         const float *x3, const float *x4, float *F_rim, float *rho_rim, float *log_lambda, float *D_m,
-                         float *log_N0, void *stream) {
-    return cmx::p3_entry<float>(params, flags, brent_iters, n, rho_q_ice, rho_n_ice, x3, x4, F_rim, rho_rim, log_lambda, D_m, log_N0, stream);
+                         const float *x3, const float *x4, const float *log_lambda_guess, float *F_rim, float *rho_rim,
+                         float *log_lambda, float *D_m, float *log_N0, void *stream) {
+    return cmx::p3_entry<float>(params, flags, brent_iters, n, rho_q_ice, rho_n_ice, x3, x4, log_lambda_guess, F_rim, rho_rim, log_lambda, D_m,
+                                log_N0, stream);
 }
 int32_t cmx_p3_shape_f64(const cmx_p3_params_f64 *params, uint32_t flags, int32_t brent_iters, int64_t n, const double *rho_q_ice, const double *rho_n_ice,
-                         const double *x3, const double *x4, double *F_rim, double *rho_rim, double *log_lambda, double *D_m,
-                         double *log_N0, void *stream) {
-    return cmx::p3_entry<double>(params, flags, brent_iters, n, rho_q_ice, rho_n_ice, x3, x4, F_rim, rho_rim, log_lambda, D_m, log_N0, stream);
+                         const double *x3, const double *x4, const double *log_lambda_guess, double *F_rim, double *rho_rim,
+                         double *log_lambda, double *D_m, double *log_N0, void *stream) {
+    return cmx::p3_entry<double>(params, flags, brent_iters, n, rho_q_ice, rho_n_ice, x3, x4, log_lambda_guess, F_rim, rho_rim, log_lambda, D_m,
+                                 log_N0, stream);
+}
+
+int32_t cmx_p3_terminal_velocities_f32(const cmx_p3_params_f32 *params, const cmx_chen2022_ice_vel_f32 *vel,
+                                       const cmx_quadrature_f32 *quad, uint32_t flags, float p, int64_t n, const float *rho_q_ice,
+                                       const float *rho_n_ice, const float *x3, const float *x4, const float *rho_air,
+                                       const float *log_lambda, float *v_n, float *v_m, void *stream) {
+    return cmx::p3_velocity_entry<float>(params, vel, quad, flags, p, n, rho_q_ice, rho_n_ice, x3, x4, rho_air, log_lambda, v_n, v_m, stream);
+}
+int32_t cmx_p3_terminal_velocities_f64(const cmx_p3_params_f64 *params, const cmx_chen2022_ice_vel_f64 *vel,
+                                       const cmx_quadrature_f64 *quad, uint32_t flags, double p, int64_t n, const double *rho_q_ice,
+                                       const double *rho_n_ice, const double *x3, const double *x4, const double *rho_air,
+                                       const double *log_lambda, double *v_n, double *v_m, void *stream) {
+    return cmx::p3_velocity_entry<double>(params, vel, quad, flags, p, n, rho_q_ice, rho_n_ice, x3, x4, rho_air, log_lambda, v_n, v_m, stream);
 }
 
 }  // extern "C"

@@ -215,9 +215,29 @@ typedef enum cmx_status {
     typedef struct cmx_p3_params_##SFX {                                                       \
         FT alpha_va, beta_va, gamma, sigma, slope_a, slope_b, slope_c, mu_max, mu_const,       \
             rho_i, rho_l, tau_wet, T_freeze;                                                   \
-    } cmx_p3_params_##SFX;
+    } cmx_p3_params_##SFX;                                                                     \
+    /* CMP.Chen2022VelTypeSmallIce / LargeIce — src/parameters/TerminalVelocity.jl:207-216,    */ \
+    /* 247-257 (Chen et al. 2022 tables B3 / B5 + the small/large cutoff dimension)            */ \
+    typedef struct cmx_chen2022_small_ice_vel_##SFX {                                          \
+        FT A[3], B[3], C[4], E[3], F[3], G[3], cutoff;                                         \
+    } cmx_chen2022_small_ice_vel_##SFX;                                                        \
+    typedef struct cmx_chen2022_large_ice_vel_##SFX {                                          \
+        FT A[3], B[3], C[3], E[3], F[3], G[3], H[3], cutoff;                                   \
+    } cmx_chen2022_large_ice_vel_##SFX;                                                        \
+    typedef struct cmx_chen2022_ice_vel_##SFX {                                                \
+        cmx_chen2022_small_ice_vel_##SFX small_ice;                                            \
+        cmx_chen2022_large_ice_vel_##SFX large_ice;                                            \
+    } cmx_chen2022_ice_vel_##SFX;                                                              \
+    /* Quadrature.ChebyshevGauss(n) / GaussLegendre(FT, n) — src/Quadrature.jl:168-175,226-252: */ \
+    /* n nodes yᵢ on [-1, 1] and TOTAL weights inv_weight_fun(yᵢ)·weight(i) (host-built once,   */ \
+    /* like the reference builds GaussLegendre host-side and ships it as an isbits struct)      */ \
+    typedef struct cmx_quadrature_##SFX {                                                      \
+        int32_t n, reserved;                                                                   \
+        FT node[CMX_QUAD_MAX], weight[CMX_QUAD_MAX];                                           \
+    } cmx_quadrature_##SFX;
 
 #define CMX_ARG_MAX_MODES 8
+#define CMX_QUAD_MAX 128
 
 CMX_DECLARE_PARAM_STRUCTS(float, f32)
 CMX_DECLARE_PARAM_STRUCTS(double, f64)
@@ -472,17 +492,39 @@ int32_t cmx_arg2000_activation_f64(
  * brent_iters ≤ 0 selects the reference's fixed budget (8 Float32 / 10 Float64 iterations, :311); a larger value runs
  * that many (the residual is non-monotonic where μ(λ) ramps, logλ ∈ [8.7, 10.4]: ≈5 % of typical states are not yet
  * converged at the reference budget, 30 iterations converge all of them to 1e-7).
+ * log_lambda_guess (nullable): the reference's optional warm start — the guess, when finite, strictly inside the
+ * bracket and with a finite residual, replaces the bracket end on its side of the root (_narrow_bracket, :336-353).
  * Output columns may be NULL.
  * ------------------------------------------------------------------------- */
 #define CMX_P3_INPUT_IS_STATE   (1u << 0)   /* columns 3, 4 are (F_rim, ρ_rim) instead of (ρq_rim, ρb_rim) */
 #define CMX_P3_SLOPE_CONSTANT   (1u << 1)   /* SlopeConstant (μ = mu_const) instead of SlopePowerLaw */
+#define CMX_P3_NO_ASPECT_RATIO  (1u << 2)   /* CMP.NoAspectRatio() instead of the default CMP.Oblate() (velocities) */
 
 int32_t cmx_p3_shape_f32(const cmx_p3_params_f32 *params, uint32_t flags, int32_t brent_iters, int64_t n, const float *rho_q_ice,
-                         const float *rho_n_ice, const float *x3, const float *x4, float *F_rim, float *rho_rim,
-                         float *log_lambda, float *D_m, float *log_N0, void *stream);
+                         const float *rho_n_ice, const float *x3, const float *x4, const float *log_lambda_guess,
+                         float *F_rim, float *rho_rim, float *log_lambda, float *D_m, float *log_N0, void *stream);
 int32_t cmx_p3_shape_f64(const cmx_p3_params_f64 *params, uint32_t flags, int32_t brent_iters, int64_t n, const double *rho_q_ice,
-                         const double *rho_n_ice, const double *x3, const double *x4, double *F_rim, double *rho_rim,
-                         double *log_lambda, double *D_m, double *log_N0, void *stream);
+                         const double *rho_n_ice, const double *x3, const double *x4, const double *log_lambda_guess,
+                         double *F_rim, double *rho_rim, double *log_lambda, double *D_m, double *log_N0, void *stream);
+
+/* P3 number- and mass-weighted ice fall speeds.  Replaces, per point,
+ *   v_n = P3.ice_terminal_velocity_number_weighted(vel, ρₐ, state, logλ; p, quad)   src/P3_terminal_velocity.jl:72-91
+ *   v_m = P3.ice_terminal_velocity_mass_weighted(vel, ρₐ, state, logλ; p, quad)     src/P3_terminal_velocity.jl:118-137
+ * (and the *_from_prognostic wrappers :152-178 when CMX_P3_INPUT_IS_STATE is not set): the integrals
+ * ∫ n(D) v(D) [m(D)] dD over the four mass-regime segments between the p and 1−p quantiles of the size distribution
+ * (integral_bounds, src/P3_integral_properties.jl:34-46 → UT.gamma_inc_inv, src/Utilities.jl:205-252), with the
+ * piecewise small/large-ice Chen-2022 particle velocity (src/Common.jl:304-350,381-382; ρᵢ = 916.7 as hard-wired at
+ * src/P3_terminal_velocity.jl:41) times the aspect-ratio factor cbrt(ϕᵢ) (src/P3_particle_properties.jl:402-475) unless
+ * CMX_P3_NO_ASPECT_RATIO.  log_lambda is an INPUT here, exactly as in the reference's signatures (use cmx_p3_shape_*
+ * to produce it).  Either output may be NULL.  Points with ρn_ice or ρq_ice < eps(FT) give 0. */
+int32_t cmx_p3_terminal_velocities_f32(const cmx_p3_params_f32 *params, const cmx_chen2022_ice_vel_f32 *vel,
+                                       const cmx_quadrature_f32 *quad, uint32_t flags, float p, int64_t n,
+                                       const float *rho_q_ice, const float *rho_n_ice, const float *x3, const float *x4,
+                                       const float *rho_air, const float *log_lambda, float *v_n, float *v_m, void *stream);
+int32_t cmx_p3_terminal_velocities_f64(const cmx_p3_params_f64 *params, const cmx_chen2022_ice_vel_f64 *vel,
+                                       const cmx_quadrature_f64 *quad, uint32_t flags, double p, int64_t n,
+                                       const double *rho_q_ice, const double *rho_n_ice, const double *x3, const double *x4,
+                                       const double *rho_air, const double *log_lambda, double *v_n, double *v_m, void *stream);
 
 /* ---------------------------------------------------------------------------
  * (3) Optional diagnostic sums over one rank's shard: per-column

@@ -160,12 +160,23 @@ static inline FT FN(o_logLdivN)(const TY(cmx_p3_params) * pr, uint32_t flags, co
 }
 /* get_distribution_logλ — :284-320 (no warm-start guess), Brent's method on [2, 17] */
 static inline FT FN(o_p3_loglambda)(const TY(cmx_p3_params) * pr, uint32_t flags, const TY(cmxo_p3_state) * s,
-                                   const TY(cmxo_thresholds) * th, int maxiters, int gi_iters) {
+                                   const TY(cmxo_thresholds) * th, int maxiters, int gi_iters, const FT *guess) {
     if (s->rho_n_ice < th->eps_n || s->rho_q_ice < th->eps_m) return -(FT)INFINITY;
     FT target = M_LOG(s->rho_q_ice) - M_LOG(s->rho_n_ice);
 #define SHAPE(x) (FN(o_logLdivN)(pr, flags, s, (x), gi_iters) - target)
     FT a = 2, b = 17, fa = SHAPE(a), fb = SHAPE(b);
     if (!isfinite(fa) || !isfinite(fb) || fa * fb > 0) return M_ABS(fa) <= M_ABS(fb) ? a : b;
+    if (guess) {   /* _narrow_bracket — :336-353 (a = lo, b = hi at this point) */
+        FT pg = *guess;
+        int valid = isfinite(pg) && (a < pg && pg < b);
+        FT pc = valid ? pg : a;
+        FT fp = SHAPE(pc);
+        valid = valid && isfinite(fp);
+        int left = valid && (fa * fp < 0);
+        int right = valid && !left;
+        if (left) { b = pc; fb = fp; }
+        if (right) { a = pc; fa = fp; }
+    }
     if (M_ABS(fa) < M_ABS(fb)) { FT t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
     FT c = a, fc = fa, d = 0;
     int mflag = 1;
@@ -203,8 +214,8 @@ static inline FT FN(o_p3_D_m)(const TY(cmx_p3_params) * pr, uint32_t flags, cons
 /* oracle twin of cmx_p3_shape_*: columns x3, x4 are (ρq_rim, ρb_rim) or, with CMX_P3_INPUT_IS_STATE, (F_rim, ρ_rim).
  * maxiters ≤ 0 → the reference's fixed budget (8 Float32 / 10 Float64); gi_iters ≤ 0 → 20 / 30. */
 void FN(cmxo_p3_shape)(const TY(cmx_p3_params) * pr, uint32_t flags, const TY(cmxo_thresholds) * th, int maxiters, int gi_iters,
-                      int64_t n, const FT *rho_q_ice, const FT *rho_n_ice, const FT *x3, const FT *x4, FT *F_rim, FT *rho_rim,
-                      FT *rho_g, FT *D_gr, FT *D_cr, FT *loglam, FT *D_m, FT *logN0, int32_t nthreads) {
+                      int64_t n, const FT *rho_q_ice, const FT *rho_n_ice, const FT *x3, const FT *x4, const FT *guess,
+                      FT *F_rim, FT *rho_rim, FT *rho_g, FT *D_gr, FT *D_cr, FT *loglam, FT *D_m, FT *logN0, int32_t nthreads) {
     if (maxiters <= 0) maxiters = sizeof(FT) == 4 ? 8 : 10;
     if (gi_iters <= 0) gi_iters = sizeof(FT) == 4 ? 20 : 30;
     (void)nthreads;
@@ -212,7 +223,7 @@ void FN(cmxo_p3_shape)(const TY(cmx_p3_params) * pr, uint32_t flags, const TY(cm
     for (int64_t i = 0; i < n; ++i) {
         TY(cmxo_p3_state) s = (flags & CMX_P3_INPUT_IS_STATE) ? FN(o_p3_state)(pr, rho_q_ice[i], rho_n_ice[i], x3[i], x4[i], th->eps_ft)
                                                               : FN(o_p3_state_from_prognostic)(pr, rho_q_ice[i], rho_n_ice[i], x3[i], x4[i], th->eps_ft);
-        FT ll = FN(o_p3_loglambda)(pr, flags, &s, th, maxiters, gi_iters);
+        FT ll = FN(o_p3_loglambda)(pr, flags, &s, th, maxiters, gi_iters, guess ? &guess[i] : NULL);
         if (F_rim) F_rim[i] = s.F_rim;
         if (rho_rim) rho_rim[i] = s.rho_rim;
         if (rho_g) rho_g[i] = s.rho_g;
@@ -223,6 +234,144 @@ void FN(cmxo_p3_shape)(const TY(cmx_p3_params) * pr, uint32_t flags, const TY(cm
         if (logN0) logN0[i] = M_LOG(s.rho_n_ice) - FN(o_loggamma_moment)(FN(o_p3_mu)(pr, flags, ll), ll, (FT)0);
     }
 }
+/* ---- weighted fall speeds: src/P3_terminal_velocity.jl, src/P3_integral_properties.jl:34-46 ------------------- */
+/* UT._gamma_inc_inv — src/Utilities.jl:205-252 (Halley, ≤15 iterations; eps = eps(FT) of the gates) */
+static inline FT FN(o_gamma_inc_inv)(FT a, FT p, FT q, int gi_iters, FT eps) {
+    if (p <= 0) return 0;
+    if (q <= 0) return (FT)INFINITY;
+    FT x = (p < (FT)0.5) ? M_POW(p * M_TGAMMA(a + 1), 1 / a) : a - M_LOG(q);
+    int use_q = p > (FT)0.5;
+    FT lg = M_LGAMMA(a);
+    for (int i = 0; i < 15; ++i) {
+        FT P, Q;
+        FN(o_gamma_inc)(a, x, gi_iters, &P, &Q);
+        FT f = use_q ? Q - q : P - p;
+        FT fprime = M_EXP((a - 1) * M_LOG(x) - x - lg);
+        if (use_q) fprime = -fprime;
+        if (fprime == 0) break;
+        FT r = (a - 1 - x) / x;
+        FT step = f / (fprime * (1 - (FT)0.5 * f * r / fprime));
+        if (x - step <= 0) step = (FT)0.5 * x;
+        x = x - step;
+        if (M_ABS(step) < eps * x) break;
+    }
+    return x;
+}
+/* CO.Chen2022_vel_coeffs (small / large ice) — src/Common.jl:304-350; k = 0, 1 */
+static inline void FN(o_chen_small_ice)(const TY(cmx_chen2022_small_ice_vel) * c, FT rho_a, FT rho_i, FT ai[2], FT bi[2], FT ci[2]) {
+    rho_a = FN(o_max)(rho_a, (FT)0);
+    FT l = M_LOG(rho_i), sq = M_SQRT(rho_i);
+    FT As = c->A[1] * l * l - c->A[2] * l + c->A[0];
+    FT Bs = 1 / (c->B[0] + c->B[1] * l + c->B[2] / sq);
+    FT Cs = c->C[0] + c->C[1] * M_EXP(c->C[2] * rho_i) + c->C[3] * sq;
+    FT Es = c->E[0] - c->E[1] * l * l + c->E[2] * sq;
+    FT Fs = -M_EXP(c->F[0] - c->F[1] * l * l + c->F[2] * l);
+    FT Gs = 1 / (c->G[0] + c->G[1] / l - c->G[2] * l / rho_i);
+    FT ra = M_POW(rho_a, As);
+    bi[0] = bi[1] = Bs + rho_a * Cs;
+    ai[0] = Es * ra * M_POW((FT)1000, bi[0]); ai[1] = Fs * ra * M_POW((FT)1000, bi[1]);
+    ci[0] = 0; ci[1] = Gs * 1000;
+}
+static inline void FN(o_chen_large_ice)(const TY(cmx_chen2022_large_ice_vel) * c, FT rho_a, FT rho_i, FT ai[2], FT bi[2], FT ci[2]) {
+    rho_a = FN(o_max)(rho_a, (FT)0);
+    FT l = M_LOG(rho_i), sq = M_SQRT(rho_i);
+    FT Al = c->A[0] + c->A[1] * l + c->A[2] / (rho_i * sq);
+    FT Bl = M_EXP(c->B[0] + c->B[1] * l * l + c->B[2] * l);
+    FT Cl = M_EXP(c->C[0] + c->C[1] / l + c->C[2] / rho_i);
+    FT El = c->E[0] + c->E[1] * l * sq + c->E[2] * sq;
+    FT Fl = c->F[0] + c->F[1] * l - M_EXP(M_LOG(-c->F[2]) - rho_i);
+    FT Gl = 1 / (c->G[0] + c->G[1] * l * sq + c->G[2] / sq);
+    FT Hl = c->H[0] + c->H[1] * rho_i * rho_i * sq + M_EXP(M_LOG(-c->H[2]) - rho_i);
+    FT ra = M_POW(rho_a, Al);
+    bi[0] = Cl; bi[1] = Fl;
+    ai[0] = Bl * ra * M_POW((FT)1000, bi[0]); ai[1] = El * ra * M_EXP(Hl * rho_a) * M_POW((FT)1000, bi[1]);
+    ci[0] = 0; ci[1] = Gl * 1000;
+}
+/* regime_value — src/P3_particle_properties.jl:320-332 */
+static inline FT FN(o_p3_regime)(const TY(cmxo_p3_state) * s, FT D, FT small, FT unrimed, FT dense, FT graupel, FT partial) {
+    return D < s->D_th ? small : (s->F_rim == 0 ? unrimed : (D < s->D_gr ? dense : (D < s->D_cr ? graupel : partial)));
+}
+static inline FT FN(o_p3_ice_mass)(const TY(cmx_p3_params) * pr, const TY(cmxo_p3_state) * s, FT D) {   /* :366-369 */
+    FT a, b;
+    FN(o_p3_mass_coeffs)(pr, s, D, &a, &b);
+    return a * M_POW(D, b);
+}
+static inline FT FN(o_p3_ice_area)(const TY(cmx_p3_params) * pr, const TY(cmxo_p3_state) * s, FT D) {   /* :412-421 */
+    FT sph = D * D * (FT)M_PI / 4, non = pr->gamma * M_POW(D, pr->sigma);
+    return FN(o_p3_regime)(s, D, sph, non, non, sph, s->F_rim * sph + (1 - s->F_rim) * non);
+}
+static inline FT FN(o_p3_phi)(const TY(cmx_p3_params) * pr, const TY(cmxo_p3_state) * s, FT D) {   /* ϕᵢ :462-475 */
+    FT m = FN(o_p3_ice_mass)(pr, s, D), a = FN(o_p3_ice_area)(pr, s, D);
+    FT rho = FN(o_p3_regime)(s, D, pr->rho_i, pr->rho_i, pr->rho_i, s->rho_g, pr->rho_i);
+    FT phi = 3 * M_SQRT((FT)M_PI) * m / (4 * rho * a * M_SQRT(a));
+    return D == 0 ? (FT)0 : phi;
+}
+typedef struct TY(cmxo_p3_vterm) { FT as[2], bs[2], cs[2], al[2], bl[2], cl[2], cutoff; int aspect; } TY(cmxo_p3_vterm);
+/* P3IceParticleVelocityFunctor — src/P3_terminal_velocity.jl:11-21; Chen2022VelocityCurve src/Common.jl:381-382 */
+static inline FT FN(o_p3_particle_velocity)(const TY(cmx_p3_params) * pr, const TY(cmxo_p3_state) * s, const TY(cmxo_p3_vterm) * v, FT D) {
+    FT vs = v->as[0] * M_POW(D, v->bs[0]) * M_EXP(-v->cs[0] * D) + v->as[1] * M_POW(D, v->bs[1]) * M_EXP(-v->cs[1] * D);
+    FT vl = v->al[0] * M_POW(D, v->bl[0]) * M_EXP(-v->cl[0] * D) + v->al[1] * M_POW(D, v->bl[1]) * M_EXP(-v->cl[1] * D);
+    FT vt = D <= v->cutoff ? vs : vl;
+    return vt * (v->aspect ? M_CBRT(FN(o_p3_phi)(pr, s, D)) : (FT)1);
+}
+/* ice_terminal_velocity_{number,mass}_weighted — src/P3_terminal_velocity.jl:72-91,118-137 with integral_bounds
+ * (src/P3_integral_properties.jl:34-46), segment_boundaries (src/P3_particle_properties.jl:287-292) and
+ * Quadrature.integrate (src/Quadrature.jl:62-125). */
+static inline void FN(o_p3_velocities)(const TY(cmx_p3_params) * pr, const TY(cmx_chen2022_ice_vel) * vel, const TY(cmx_quadrature) * quad,
+                                      uint32_t flags, const TY(cmxo_p3_state) * s, FT rho_a, FT loglam, FT p, int gi_iters, FT *v_n, FT *v_m) {
+    if (s->rho_n_ice < s->eps || s->rho_q_ice < s->eps) { *v_n = 0; *v_m = 0; return; }
+    TY(cmxo_p3_vterm) vt;
+    const FT rho_i = (FT)916.7;
+    FN(o_chen_small_ice)(&vel->small_ice, rho_a, rho_i, vt.as, vt.bs, vt.cs);
+    FN(o_chen_large_ice)(&vel->large_ice, rho_a, rho_i, vt.al, vt.bl, vt.cl);
+    vt.cutoff = vel->small_ice.cutoff;
+    vt.aspect = !(flags & CMX_P3_NO_ASPECT_RATIO);
+    FT mu = FN(o_p3_mu)(pr, flags, loglam), lam = M_EXP(loglam);
+    FT logN0 = M_LOG(s->rho_n_ice) - FN(o_loggamma_moment)(mu, loglam, (FT)0);
+    FT Y1 = p, Y2 = (FT)(1.0 - (double)p);   /* FT(p), FT(1 - p) with p a Float64 keyword in the reference */
+    FT D_min = FN(o_gamma_inc_inv)(mu + 1, Y1, 1 - Y1, gi_iters, s->eps) / lam;
+    FT D_max = FN(o_gamma_inc_inv)(mu + 1, Y2, 1 - Y2, gi_iters, s->eps) / lam;
+    FT bnd[5] = {D_min, FN(o_clamp)(s->D_th, D_min, D_max), FN(o_clamp)(s->D_gr, D_min, D_max), FN(o_clamp)(s->D_cr, D_min, D_max), D_max};
+    FT sum_n = 0, sum_m = 0;
+    for (int k = 0; k < 4; ++k) {
+        FT a = bnd[k], b = bnd[k + 1];
+        if (!(a < b)) continue;
+        FT scale = (b - a) / 2, shift = (a + b) / 2, rn = 0, rm = 0;
+        for (int i = 0; i < quad->n; ++i) {
+            FT x = scale * quad->node[i] + shift, w = quad->weight[i];
+            FT nD = M_EXP(logN0 + mu * M_LOG(x) - lam * x);
+            FT nv = nD * FN(o_p3_particle_velocity)(pr, s, &vt, x);
+            rn += nv * w;
+            rm += nv * FN(o_p3_ice_mass)(pr, s, x) * w;
+        }
+        sum_n += scale * rn; sum_m += scale * rm;
+    }
+    *v_n = sum_n / s->rho_n_ice; *v_m = sum_m / s->rho_q_ice;
+}
+void FN(cmxo_p3_terminal_velocities)(const TY(cmx_p3_params) * pr, const TY(cmx_chen2022_ice_vel) * vel, const TY(cmx_quadrature) * quad,
+                                    uint32_t flags, const TY(cmxo_thresholds) * th, int gi_iters, FT p, int64_t n, const FT *rho_q_ice,
+                                    const FT *rho_n_ice, const FT *x3, const FT *x4, const FT *rho_a, const FT *loglam, FT *v_n, FT *v_m,
+                                    int32_t nthreads) {
+    if (gi_iters <= 0) gi_iters = sizeof(FT) == 4 ? 20 : 30;
+    (void)nthreads;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads > 0 ? nthreads : 1)
+    for (int64_t i = 0; i < n; ++i) {
+        TY(cmxo_p3_state) s = (flags & CMX_P3_INPUT_IS_STATE) ? FN(o_p3_state)(pr, rho_q_ice[i], rho_n_ice[i], x3[i], x4[i], th->eps_ft)
+                                                              : FN(o_p3_state_from_prognostic)(pr, rho_q_ice[i], rho_n_ice[i], x3[i], x4[i], th->eps_ft);
+        FN(o_p3_velocities)(pr, vel, quad, flags, &s, rho_a[i], loglam[i], p, gi_iters, &v_n[i], &v_m[i]);
+    }
+}
+/* probes for the KATs: particle fall speed at diameter D for a state built from (F_rim, ρ_rim); gamma_inc_inv */
+FT FN(cmxo_p3_particle_velocity)(const TY(cmx_p3_params) * pr, const TY(cmx_chen2022_ice_vel) * vel, uint32_t flags, FT F_rim, FT rho_rim,
+                                FT rho_a, FT D) {
+    TY(cmxo_p3_state) s = FN(o_p3_state)(pr, (FT)0, (FT)0, F_rim, rho_rim, M_EPS);
+    TY(cmxo_p3_vterm) vt;
+    FN(o_chen_small_ice)(&vel->small_ice, rho_a, (FT)916.7, vt.as, vt.bs, vt.cs);
+    FN(o_chen_large_ice)(&vel->large_ice, rho_a, (FT)916.7, vt.al, vt.bl, vt.cl);
+    vt.cutoff = vel->small_ice.cutoff; vt.aspect = !(flags & CMX_P3_NO_ASPECT_RATIO);
+    return FN(o_p3_particle_velocity)(pr, &s, &vt, D);
+}
+FT FN(cmxo_gamma_inc_inv)(FT a, FT p, FT q) { return FN(o_gamma_inc_inv)(a, p, q, sizeof(FT) == 4 ? 20 : 30, M_EPS); }
 FT FN(cmxo_p3_rho_d)(const TY(cmx_p3_params) * pr, FT F_rim, FT rho_rim) { return FN(o_p3_rho_d)(pr, F_rim, rho_rim); }
 FT FN(cmxo_p3_logLdivN)(const TY(cmx_p3_params) * pr, uint32_t flags, FT F_rim, FT rho_rim, FT loglam) {
     TY(cmxo_p3_state) s = FN(o_p3_state)(pr, (FT)0, (FT)0, F_rim, rho_rim, M_EPS);

@@ -213,7 +213,8 @@ def arg2000_activation(fam, ap, ad, aip, tps, T, p, w, q_tot, q_liq=None, q_ice=
     return dict(N_act=n_act, M_act=m_act, S_max=s_max, S_cond=s_cond)
 
 
-def p3_shape(fam, params, flags, rho_q_ice, rho_n_ice, x3, x4, *, float32_gates=None, maxiters=0, gi_iters=0, nthreads=1):
+def p3_shape(fam, params, flags, rho_q_ice, rho_n_ice, x3, x4, *, guess=None, float32_gates=None, maxiters=0, gi_iters=0,
+             nthreads=1):
     """Oracle twin of cmx_p3_shape_*: dict of F_rim, rho_rim, rho_g, D_gr, D_cr, log_lambda, D_m, log_N0.
     maxiters / gi_iters ≤ 0 → the reference's fixed budgets (Brent 8/10, gamma_inc 20/30 for Float32/Float64)."""
     if float32_gates is None:
@@ -225,9 +226,40 @@ def p3_shape(fam, params, flags, rho_q_ice, rho_n_ice, x3, x4, *, float32_gates=
     outs = {k: np.empty(n, dtype=NP[fam.sfx]) for k in names}
     fn = getattr(lib(), f"cmxo_p3_shape_{fam.sfx}")
     fn.restype = None
+    g = _col(fam, guess) if guess is not None else (None, None)
     fn(C.byref(params), C.c_uint32(flags), C.byref(th), C.c_int(maxiters), C.c_int(gi_iters), C.c_int64(n),
-       *[p for _, p in ins], *[outs[k].ctypes.data_as(C.c_void_p) for k in names], C.c_int32(nthreads))
+       *[p for _, p in ins], g[1], *[outs[k].ctypes.data_as(C.c_void_p) for k in names], C.c_int32(nthreads))
     return outs
+
+
+def p3_terminal_velocities(fam, params, vel, quad, flags, rho_q_ice, rho_n_ice, x3, x4, rho_a, log_lambda, *, p=1e-6,
+                           float32_gates=None, gi_iters=0, nthreads=1):
+    """Oracle twin of cmx_p3_terminal_velocities_*: (v_n, v_m)."""
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    ins = [_col(fam, a) for a in (rho_q_ice, rho_n_ice, x3, x4, rho_a, log_lambda)]
+    n = ins[0][0].size
+    v_n, v_m = np.empty(n, dtype=NP[fam.sfx]), np.empty(n, dtype=NP[fam.sfx])
+    fn = getattr(lib(), f"cmxo_p3_terminal_velocities_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(params), C.byref(vel), C.byref(quad), C.c_uint32(flags), C.byref(th), C.c_int(gi_iters), fam.ft(p), C.c_int64(n),
+       *[q for _, q in ins], v_n.ctypes.data_as(C.c_void_p), v_m.ctypes.data_as(C.c_void_p), C.c_int32(nthreads))
+    return v_n, v_m
+
+
+def p3_particle_velocity(fam, params, vel, flags, F_rim, rho_rim, rho_a, D):
+    fn = getattr(lib(), f"cmxo_p3_particle_velocity_{fam.sfx}")
+    fn.restype = fam.ft
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, fam.ft, fam.ft, fam.ft, fam.ft]
+    return fn(C.addressof(params), C.addressof(vel), flags, F_rim, rho_rim, rho_a, D)
+
+
+def gamma_inc_inv(fam, a, p, q):
+    fn = getattr(lib(), f"cmxo_gamma_inc_inv_{fam.sfx}")
+    fn.restype = fam.ft
+    fn.argtypes = [fam.ft] * 3
+    return fn(a, p, q)
 
 
 def p3_rho_d(fam, params, F_rim, rho_rim):

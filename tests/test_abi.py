@@ -45,7 +45,7 @@ def test_struct_layout_matches_c(tmp_path):
                      "particle_mass", "particle_area", "ventilation", "acnv_1m", "var_timescale_acnv", "cloud_liquid",
                      "cloud_ice", "rain", "snow", "blk1m_vel_rain", "blk1m_vel_snow", "process_params_1m",
                      "microphysics_1m", "aerosol_activation_params", "aerosol_mode", "aerosol_distribution",
-                     "p3_params"):
+                     "p3_params", "chen2022_small_ice_vel", "chen2022_large_ice_vel", "chen2022_ice_vel", "quadrature"):
             st = getattr(fam, name)
             probes.append((f"cmx_{name}_{fam.sfx}", st))
     src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{REPO}/include/cmx.h"', "int main(void){"]

@@ -198,3 +198,109 @@ def test_full_size_1e7_f64_properties(dev, oracle):
     rho_q, rho_n = [_np64(c[::stride]) for c in (st.rho_q_ice, st.rho_n_ice)]
     rep, _, _ = _solver_parity(oracle, samp, rho_q, rho_n, "f64", 0, 0, "1e7 sample")
     print(f"\n[P3 parity 1e7 f64, {rho_q.size} sampled points] {rep}")
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# number- and mass-weighted fall speeds (cmx_p3_terminal_velocities_*)
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_bulk_fall_speed_kats_through_the_abi(dev, ft):
+    import cmx
+    g = G["bulk_velocity"]
+    p, vel, quad = P.ParametersP3(ft), P.Chen2022VelTypeIce(ft), P.GaussLegendre(ft, g["quad"]["n"])
+    n = len(g["F_rim"])
+    col = lambda v: torch.tensor(v, dtype=DT[ft], device=dev)  # noqa: E731
+    cols = (col([g["L_ice"]] * n), col([g["N_ice"]] * n), col(g["F_rim"]), col([g["rho_rim"]] * n))
+    ll = cmx.p3_shape(p, *cols, from_state=True, want=("log_lambda",)).log_lambda
+    rho_a = col([g["rho_a"]] * n)
+    loose = 1.0 if ft == "f64" else 30.0
+    for ar, sfx, tight in ((True, "oblate", True), (False, "no_aspect_ratio", False)):
+        v = cmx.p3_terminal_velocities(p, vel, rho_a, *cols, ll, from_state=True, aspect_ratio=ar, quad=quad)
+        np.testing.assert_allclose(v.v_n.cpu().numpy(), g[f"v_n_{sfx}"], rtol=(1e-9 if tight else g["rtol_v_n"]) * loose if ft == "f64" else 3e-3)
+        np.testing.assert_allclose(v.v_m.cpu().numpy(), g[f"v_m_{sfx}"], rtol=(1e-9 if tight else g["rtol_v_m"]) * loose if ft == "f64" else 3e-3)
+    # absent ice → exactly zero (test/p3_tests.jl:352-364)
+    v = cmx.p3_terminal_velocities(p, vel, col([1.2, 1.2]), col([0.0, 0.22]), col([1e6, 0.0]), col([0.5, 0.5]), col([800.0, 800.0]),
+                                   col([10.0, 10.0]), from_state=True, quad=quad)
+    assert bool((v.v_n == 0).all()) and bool((v.v_m == 0).all())
+    with pytest.raises(TypeError):
+        cmx.p3_terminal_velocities(p, vel, rho_a, *cols, ll, quad=P.GaussLegendre("f32" if ft == "f64" else "f64", 12))
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+@pytest.mark.parametrize("rule", ["ChebyshevGauss100", "GaussLegendre40"])
+@pytest.mark.parametrize("aspect", [True, False])
+def test_random_state_fall_speed_parity(dev, oracle, ft, rule, aspect):
+    import cmx
+    from cmx import synthetic
+    n = 20_000
+    cols = _columns(n, ft, True, seed=77)
+    rho_a = synthetic.p3_air_density(n, dtype=DT[ft])
+    p, vel = P.ParametersP3(ft), P.Chen2022VelTypeIce(ft)
+    mk = (lambda f: P.ChebyshevGauss(f, 100)) if rule.startswith("Cheb") else (lambda f: P.GaussLegendre(f, 40))
+    dcols = [c.to(dev) for c in cols]
+    ll = cmx.p3_shape(p, *dcols, from_state=True, want=("log_lambda",), brent_iters=40).log_lambda
+    v = cmx.p3_terminal_velocities(p, vel, rho_a.to(dev), *dcols, ll, from_state=True, aspect_ratio=aspect, quad=mk(ft))
+    torch.cuda.synchronize()
+    c64 = [c.numpy().astype(np.float64) for c in cols]
+    flags = STATE | (0 if aspect else _abi.CMX_P3_NO_ASPECT_RATIO)
+    # reference: Float64 arithmetic with ft's gates at the SAME logλ the kernel was given
+    r_n, r_m = oracle.p3_terminal_velocities(_abi.F64, P.ParametersP3("f64").c, P.Chen2022VelTypeIce("f64"), mk("f64"), flags, *c64,
+                                             rho_a.numpy().astype(np.float64), _np64(ll), float32_gates=(ft == "f32"), nthreads=8)
+    rep = {}
+    for name, x, r in (("v_n", _np64(v.v_n), r_n), ("v_m", _np64(v.v_m), r_m)):
+        assert np.array_equal(x == 0, r == 0), name
+        nz = r != 0
+        e = np.abs(x[nz] - r[nz]) / np.abs(r[nz])
+        rep[name] = float(e.max())
+        assert rep[name] <= RTOL[ft], (name, rep)
+    assert (r_n == 0).mean() > 0.005 and np.all(r_n >= 0) and np.all(r_m[r_n > 0] >= r_n[r_n > 0] * 0.5)
+    print(f"\n[P3 fall speeds] {ft} {rule} aspect={aspect}: {rep}")
+
+
+def test_fall_speeds_from_prognostic_and_full_size_properties(dev, oracle):
+    """BASELINE config 5 at full size (1e7 Float64 columns): the five-in / four-out P3 pass (logλ, D_m, v_n, v_m)."""
+    import cmx
+    from cmx import sharding, synthetic
+    n = 10_000_000
+    st = synthetic.p3_state(n, dtype=torch.float64, device=dev, seed=1234)
+    rho_a = synthetic.p3_air_density(n, dtype=torch.float64, device=dev)
+    p, vel, quad = P.ParametersP3("f64"), P.Chen2022VelTypeIce("f64"), P.GaussLegendre("f64", 40)
+    shp = cmx.p3_shape(p, *st)
+    v = cmx.p3_terminal_velocities(p, vel, rho_a, *st, shp.log_lambda, quad=quad)
+    torch.cuda.synchronize()
+    none = st.rho_q_ice == 0
+    assert bool((v.v_n[none] == 0).all()) and bool((v.v_m[none] == 0).all())
+    assert bool(torch.isfinite(v.v_n).all()) and bool(torch.isfinite(v.v_m).all())
+    assert bool((v.v_n[~none] > 0).all()) and bool((v.v_n[~none] < 20).all()) and bool((v.v_m[~none] < 40).all())
+    assert float((v.v_m[~none] >= v.v_n[~none]).double().mean()) > 0.99      # mass weighting favours the large, fast particles
+    for rk in (0, 3, 7):     # chunk invariance over the 8-rank shard layout
+        lo, hi = sharding.shard_bounds(n, rk, 8)
+        part = cmx.p3_terminal_velocities(p, vel, rho_a[lo:hi], *[c[lo:hi] for c in st], shp.log_lambda[lo:hi], quad=quad)
+        assert torch.equal(part.v_n, v.v_n[lo:hi]) and torch.equal(part.v_m, v.v_m[lo:hi])
+    stride = 997
+    samp = [_np64(c[::stride]) for c in (*st, rho_a, shp.log_lambda)]
+    r_n, r_m = oracle.p3_terminal_velocities(_abi.F64, p.c, vel, quad, 0, *samp, nthreads=8)
+    e_n = np.abs(_np64(v.v_n[::stride]) - r_n) / np.maximum(r_n, 1e-300)
+    e_m = np.abs(_np64(v.v_m[::stride]) - r_m) / np.maximum(r_m, 1e-300)
+    ok = r_n > 0
+    print(f"\n[P3 fall speeds 1e7 f64, {ok.sum()} sampled points] v_n {e_n[ok].max():.2e} v_m {e_m[ok].max():.2e}")
+    assert e_n[ok].max() <= 1e-6 and e_m[ok].max() <= 1e-6
+
+
+def test_warm_start_guess_on_device(dev, oracle):
+    import cmx
+    cols = _columns(50_000, "f64", True, seed=5)
+    p = P.ParametersP3("f64", "constant")            # monotonic residual → the guess cannot change which root is found
+    dcols = [c.to(dev) for c in cols]
+    base = cmx.p3_shape(p, *dcols, from_state=True, want=("log_lambda",), brent_iters=40).log_lambda
+    fin = torch.isfinite(base)
+    for guess in (base + 0.3, base - 0.5, torch.full_like(base, float("nan")), torch.full_like(base, 30.0)):
+        ll = cmx.p3_shape(p, *dcols, from_state=True, want=("log_lambda",), brent_iters=40, log_lambda_guess=guess).log_lambda
+        assert float((ll[fin] - base[fin]).abs().max()) < 1e-8 and bool(torch.isneginf(ll[~fin]).all())
+    # iterate-for-iterate against the oracle at the reference budget, with a guess
+    g = (base + 0.2).cpu().numpy()
+    ll = cmx.p3_shape(p, *dcols, from_state=True, want=("log_lambda",), log_lambda_guess=base + 0.2).log_lambda
+    c64 = [c.numpy() for c in cols]
+    ref = oracle.p3_shape(_abi.F64, p.c, STATE | p.flags, *c64, guess=g)["log_lambda"]
+    f = np.isfinite(ref)
+    assert np.abs(_np64(ll)[f] - ref[f]).max() < 1e-9

@@ -101,3 +101,57 @@ def test_state_from_prognostic_regularisation(oracle):
     assert P.ParametersP3("f64", "constant").flags == _abi.CMX_P3_SLOPE_CONSTANT
     with pytest.raises(ValueError):
         P.ParametersP3("f64", "quadratic")
+
+
+def test_particle_and_bulk_fall_speed_kats(oracle):
+    """test/p3_tests.jl:283-307 (Chen-2022 ice particle velocity per regime, with / without the oblate aspect factor)
+    and :336-400 (number- and mass-weighted fall speeds, GaussLegendre(12))."""
+    p, vel = P.ParametersP3("f64").c, P.Chen2022VelTypeIce("f64")
+    NOAR = _abi.CMX_P3_NO_ASPECT_RATIO
+    g = G["particle_velocity"]
+    for flags, key in ((NOAR, "expected_no_aspect_ratio"), (0, "expected_oblate")):
+        v = [oracle.p3_particle_velocity(F64, p, vel, flags, g["F_rim"], g["rho_rim"], g["rho_a"], D) for D in g["D"]]
+        np.testing.assert_allclose(v, g[key], rtol=g["rtol"])
+    g = G["bulk_velocity"]
+    quad = P.GaussLegendre("f64", g["quad"]["n"])
+    n = len(g["F_rim"])
+    cols = ([g["L_ice"]] * n, [g["N_ice"]] * n, g["F_rim"], [g["rho_rim"]] * n)
+    ll = oracle.p3_shape(F64, p, STATE, *cols)["log_lambda"]
+    for flags, sfx, tight in ((NOAR, "no_aspect_ratio", False), (0, "oblate", True)):
+        v_n, v_m = oracle.p3_terminal_velocities(F64, p, vel, quad, STATE | flags, *cols, [g["rho_a"]] * n, ll)
+        np.testing.assert_allclose(v_n, g[f"v_n_{sfx}"], rtol=1e-13 if tight else g["rtol_v_n"])
+        np.testing.assert_allclose(v_m, g[f"v_m_{sfx}"], rtol=1e-13 if tight else g["rtol_v_m"])
+    # absent ice → exactly zero (p3_tests.jl:352-364)
+    v_n, v_m = oracle.p3_terminal_velocities(F64, p, vel, quad, STATE, [0.0, 0.22], [1e6, 0.0], [0.5] * 2, [800.0] * 2, [1.2] * 2, [10.0] * 2)
+    assert np.all(v_n == 0) and np.all(v_m == 0)
+    # the default rule ChebyshevGauss(100) agrees with GaussLegendre(40) on the smooth integrals
+    a = oracle.p3_terminal_velocities(F64, p, vel, P.ChebyshevGauss("f64", 100), STATE, *cols, [g["rho_a"]] * n, ll)
+    b = oracle.p3_terminal_velocities(F64, p, vel, P.GaussLegendre("f64", 40), STATE, *cols, [g["rho_a"]] * n, ll)
+    np.testing.assert_allclose(a[0], b[0], rtol=2e-3)
+    np.testing.assert_allclose(a[1], b[1], rtol=2e-3)
+
+
+def test_gamma_inc_inv_against_scipy(oracle):
+    for a, pp in itertools.product((0.5, 1.0, 2.0, 3.5, 7.0), (1e-6, 1e-3, 0.3, 0.5, 0.7, 1 - 1e-6)):
+        x = oracle.gamma_inc_inv(F64, a, pp, 1 - pp)
+        assert math.isclose(x, sp.gammaincinv(a, pp), rel_tol=1e-9), (a, pp)
+        x32 = oracle.gamma_inc_inv(_abi.F32, a, pp, 1 - np.float32(pp))
+        assert math.isclose(x32, sp.gammaincinv(a, float(np.float32(pp))), rel_tol=5e-3), (a, pp)
+    assert oracle.gamma_inc_inv(F64, 2.0, 0.0, 1.0) == 0 and oracle.gamma_inc_inv(F64, 2.0, 1.0, 0.0) == float("inf")
+
+
+def test_warm_start_guess_keeps_the_root(oracle):
+    """get_distribution_logλ(state, logλ_guess): a guess inside the bracket narrows it on its side of the root
+    (_narrow_bracket, P3_size_distribution.jl:336-353); invalid guesses (NaN, outside [2, 17]) are ignored."""
+    p = P.ParametersP3("f64", "constant")          # monotonic residual: a single root whatever the bracket
+    rng = np.random.default_rng(3)
+    n = 2000
+    L, N = np.exp(rng.uniform(np.log(1e-6), np.log(1e-3), n)), np.exp(rng.uniform(np.log(1e2), np.log(1e6), n))
+    F, rr = rng.uniform(0, 0.9, n), rng.uniform(200, 800, n)
+    base = oracle.p3_shape(F64, p.c, STATE | p.flags, L, N, F, rr, maxiters=60)["log_lambda"]
+    for guess in (base + 0.3, base - 0.5, np.full(n, np.nan), np.full(n, 1.0), np.full(n, 25.0)):
+        ll = oracle.p3_shape(F64, p.c, STATE | p.flags, L, N, F, rr, guess=guess, maxiters=60)["log_lambda"]
+        np.testing.assert_allclose(ll, base, rtol=0, atol=1e-8)
+    # with the reference budget a good guess does not hurt accuracy
+    ll10 = oracle.p3_shape(F64, p.c, STATE | p.flags, L, N, F, rr, guess=base + 0.05)["log_lambda"]
+    assert np.abs(ll10 - base).max() < 1e-6
