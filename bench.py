@@ -202,28 +202,36 @@ def setup_p3(args, dev, dtype, rank):
     from cmx import _abi
     from cmx import parameters as P
     from cmx import synthetic
-    state = synthetic.p3_state(args.points, dtype=dtype, device=dev, seed=1234 + rank)
-    p = P.ParametersP3(args.dtype)
+    st = synthetic.p3_state(args.points, dtype=dtype, device=dev, seed=1234 + rank)
+    rho_a = synthetic.p3_air_density(args.points, dtype=dtype, device=dev, seed=4321 + rank)
+    p, vel = P.ParametersP3(args.dtype), P.Chen2022VelTypeIce(args.dtype)
+    quad = P.ChebyshevGauss(args.dtype, 100)          # the reference's default rule (src/P3_terminal_velocity.jl:74)
     holder = {}
 
-    def step():
-        holder["out"] = cmx.p3_shape(p, *state)
+    def step():   # (ρq_ice, ρn_ice, ρq_rim, ρb_rim, ρₐ) → (logλ, D_m, v_n, v_m)
+        shp = cmx.p3_shape(p, *st)
+        holder["out"] = (shp, cmx.p3_terminal_velocities(p, vel, rho_a, *st, shp.log_lambda, quad=quad))
 
     def cpu_run(ob, cols, threads):
         fam = _abi.family(args.dtype)
-        return lambda: ob.p3_shape(fam, p.c, 0, *cols, nthreads=threads)
+
+        def run():
+            ll = ob.p3_shape(fam, p.c, 0, *cols[:4], nthreads=threads)["log_lambda"]
+            ob.p3_terminal_velocities(fam, p.c, vel, quad, 0, *cols, ll, nthreads=threads)
+        return run
 
     step()
     desc = {
-        "metric": "grid-points/sec P3 shape solve (log-lambda root + D_m)",
-        "bytes_per_point": {"f32": 24, "f64": 48}[args.dtype],      # 4 in + logλ, D_m out
-        "kernel": "p3_shape_kernel",
-        "workload": "P3Scheme state_from_prognostic + get_distribution_logλ (Brent root of the shape equation, "
-                    "incomplete-gamma moments) + D_m per column",
-        "columns_in": 4, "columns_out": 2, "diag_cols": [],
-        "note": "compute-bound (≈1e4 FP64 VALU operations per point: the kernel's HBM fraction is small by nature)",
+        "metric": "grid-points/sec P3 shape solve + integral properties (log-lambda, D_m, v_n, v_m)",
+        "bytes_per_point": {"f32": 40, "f64": 80}[args.dtype],      # 4 + 6 loads (state re-read by the 2nd launch) … see note
+        "kernel": "p3_shape_kernel + p3_velocity_kernel",
+        "workload": "P3Scheme state_from_prognostic + get_distribution_logλ (Brent root, incomplete-gamma moments) + D_m + "
+                    "number/mass-weighted Chen-2022 fall speeds (ChebyshevGauss(100) x 4 segments, gamma_inc_inv bounds)",
+        "columns_in": 5, "columns_out": 4, "diag_cols": [],
+        "note": "compute-bound (shape solve ~3e4, fall-speed quadrature ~1e5 FP operations per point); bytes_per_point "
+                "counts the algorithmic 5 in + 4 out + the log-lambda column handed from the first launch to the second",
     }
-    return list(state), step, desc, cpu_run
+    return list(st) + [rho_a], step, desc, cpu_run
 
 
 def cpu_baseline(args, cols_np, desc, cpu_run):
@@ -323,7 +331,7 @@ def main():
         if "note" in desc:
             line["roofline"]["note"] = desc["note"]
         if not args.no_cpu_baseline and world == 1:
-            m = min(n, {"sb2006": 20_000_000, "p3": 400_000}.get(args.workload, 4_000_000))
+            m = min(n, {"sb2006": 20_000_000, "p3": 100_000}.get(args.workload, 4_000_000))
             cols_np = [np.ascontiguousarray(c[:m].cpu().numpy()) for c in state]
             line["cpu_baseline"] = cpu_baseline(args, cols_np, desc, cpu_run)
         print(json.dumps(line), flush=True)
