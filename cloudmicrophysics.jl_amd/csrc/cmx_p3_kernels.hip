@@ -337,7 +337,7 @@ static int32_t p3_entry(const PR *params, uint32_t flags, int32_t brent_iters, i
 //     of D on the unrimed / dense-rimed segment (folded into e_k, b_k: no extra transcendental), and needs the mixed
 //     area F·πD²/4 + (1−F)·γD^σ only on the partially-rimed segment (one exp + one log more);
 //   * m(D) = exp(log a_seg + b_seg logD) with the per-segment mass law of the shape solver.
-// → 4 transcendentals per node instead of ≈12; nodes/weights are wave-uniform scalar loads from the kernel arguments.
+// → 5 transcendentals per node instead of ≈12; nodes/weights are wave-uniform scalar loads from the kernel arguments.
 template <typename FT> struct P3VelConsts {
     // small ice (table B3 reduced at ρᵢ): aᵢ = (Es, Fs)·ρₐ^As·1000^b, b = Bs + ρₐ Cs, c = (0, 1000 Gs)
     FT s_A, s_B, s_C, s_E, s_F, s_c2;
@@ -455,12 +455,14 @@ __global__ __launch_bounds__(kBlock) void p3_velocity_kernel(const P3Consts<FT> 
                     const FT area = s.F_rim * v.pi_4 * x * x + (FT(1) - s.F_rim) * v.gamma_area * P::exp(v.sigma_area * logD);
                     base -= FT(0.5) * P::log(area);
                 }
+                // Chen-2022 particle speed Σ aₖ D^bₖ e^{−cₖD}: the two terms have opposite signs and cancel to ≈1/200 of
+                // their size for small D, so the shared factor stays OUTSIDE the difference (as D^b does in the reference)
                 const bool small = x <= v.cutoff;
-                const FT A1 = small ? v.s_E : v.l_a1, A2 = small ? v.s_F : v.l_a2;
-                const FT e1 = small ? se : le1, e2 = small ? se : le2;
-                const FT b1 = small ? sb : v.l_b1, b2 = small ? sb : v.l_b2;
-                const FT c2 = small ? v.s_c2 : v.l_c2;
-                const FT nv = A1 * P::exp(base + e1 + b1 * logD) + A2 * P::exp(base + e2 + b2 * logD - c2 * x);
+                const FT E1 = small ? se + sb * logD : le1 + v.l_b1 * logD;
+                const FT E2 = small ? -v.s_c2 * x : le2 + v.l_b2 * logD - v.l_c2 * x;
+                const FT t1 = P::exp(E1), t2 = P::exp(E2);
+                const FT vv = small ? t1 * (v.s_E + v.s_F * t2) : v.l_a1 * t1 + v.l_a2 * t2;
+                const FT nv = P::exp(base) * vv;
                 rn += nv * w;
                 rm += nv * P::exp(mla + mb * logD) * w;
             }

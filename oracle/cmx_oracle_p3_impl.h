@@ -329,8 +329,13 @@ static inline void FN(o_p3_velocities)(const TY(cmx_p3_params) * pr, const TY(cm
     FT mu = FN(o_p3_mu)(pr, flags, loglam), lam = M_EXP(loglam);
     FT logN0 = M_LOG(s->rho_n_ice) - FN(o_loggamma_moment)(mu, loglam, (FT)0);
     FT Y1 = p, Y2 = (FT)(1.0 - (double)p);   /* FT(p), FT(1 - p) with p a Float64 keyword in the reference */
-    FT D_min = FN(o_gamma_inc_inv)(mu + 1, Y1, 1 - Y1, gi_iters, s->eps) / lam;
-    FT D_max = FN(o_gamma_inc_inv)(mu + 1, Y2, 1 - Y2, gi_iters, s->eps) / lam;
+    FT Q1 = 1 - Y1, Q2 = 1 - Y2;
+    if (s->eps > (FT)1e-10) {   /* Float32 gates: the quantile levels are Float32 numbers (1 − Float32(1−1e-6) = 1.0133e-6) */
+        Y1 = (FT)(float)Y1; Y2 = (FT)(float)(1.0 - (double)p);
+        Q1 = (FT)(1.0f - (float)Y1); Q2 = (FT)(1.0f - (float)Y2);
+    }
+    FT D_min = FN(o_gamma_inc_inv)(mu + 1, Y1, Q1, gi_iters, s->eps) / lam;
+    FT D_max = FN(o_gamma_inc_inv)(mu + 1, Y2, Q2, gi_iters, s->eps) / lam;
     FT bnd[5] = {D_min, FN(o_clamp)(s->D_th, D_min, D_max), FN(o_clamp)(s->D_gr, D_min, D_max), FN(o_clamp)(s->D_cr, D_min, D_max), D_max};
     FT sum_n = 0, sum_m = 0;
     for (int k = 0; k < 4; ++k) {
