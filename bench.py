@@ -223,13 +223,13 @@ def setup_p3(args, dev, dtype, rank):
     step()
     desc = {
         "metric": "grid-points/sec P3 shape solve + integral properties (log-lambda, D_m, v_n, v_m)",
-        "bytes_per_point": {"f32": 40, "f64": 80}[args.dtype],      # 4 + 6 loads (state re-read by the 2nd launch) … see note
+        "bytes_per_point": {"f32": 36, "f64": 72}[args.dtype],      # 5 in + 4 out
         "kernel": "p3_shape_kernel + p3_velocity_kernel",
         "workload": "P3Scheme state_from_prognostic + get_distribution_logλ (Brent root, incomplete-gamma moments) + D_m + "
                     "number/mass-weighted Chen-2022 fall speeds (ChebyshevGauss(100) x 4 segments, gamma_inc_inv bounds)",
         "columns_in": 5, "columns_out": 4, "diag_cols": [],
-        "note": "compute-bound (shape solve ~3e4, fall-speed quadrature ~1e5 FP operations per point); bytes_per_point "
-                "counts the algorithmic 5 in + 4 out + the log-lambda column handed from the first launch to the second",
+        "note": "FP64/FP32-vector compute-bound (DESIGN.md §4.5): the HBM fraction is tiny by nature; see "
+                "profiles/r01_pmc_valu_p3_*.json for the VALU-issue utilisation of the two kernels",
     }
     return list(st) + [rho_a], step, desc, cpu_run
 

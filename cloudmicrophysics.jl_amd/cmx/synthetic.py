@@ -141,10 +141,10 @@ def p3_state(n: int, dtype=torch.float64, device="cpu", seed: int = 1234, chunk:
 
 
 def p3_air_density(n: int, dtype=torch.float64, device="cpu", seed: int = 4321):
-    """Air density column for the P3 fall-speed integrals: ρₐ ~ U[0.3, 1.3] kg/m³ (surface to ≈10 km)."""
+    """Air density column for the P3 fall-speed integrals: ρₐ ~ U[0.4, 1.3] kg/m³."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
-    return (0.3 + torch.rand(n, dtype=torch.float64, device=device, generator=g)).to(dtype)
+    return (0.4 + 0.9 * torch.rand(n, dtype=torch.float64, device=device, generator=g)).to(dtype)
 
 
 IceNucState = namedtuple("IceNucState", ["T", "a_w", "r"])

@@ -10,7 +10,7 @@ import json
 import sys
 from pathlib import Path
 
-BYTES_PER_POINT = {"sb2006": 13, "icenuc": 5, "mp1m": 11, "arg2000": 9, "p3": 6}   # columns in + out
+BYTES_PER_POINT = {"sb2006": 13, "icenuc": 5, "mp1m": 11, "arg2000": 9, "p3": 9}   # columns in + out
 
 
 def find(out, sub, suffix):
@@ -18,8 +18,36 @@ def find(out, sub, suffix):
     return hits[0] if hits else None
 
 
+def valu_summary(wl, dt, n, out, rnd):
+    """Per-kernel means of the SQ counters of the 4th pass (compute-bound workloads)."""
+    path = find(out, "sq", "counter_collection.csv")
+    dst = Path("gpurun_out/profiles")
+    acc = {}
+    for r in csv.DictReader(open(path)):
+        if "cmx::" not in r["Kernel_Name"]:
+            continue
+        k = r["Kernel_Name"].split("(")[0]
+        d = acc.setdefault(k, {"vgpr": r["VGPR_Count"], "accum_vgpr": r["Accum_VGPR_Count"], "sgpr": r["SGPR_Count"],
+                               "scratch": r["Scratch_Size"], "counters": {}})
+        d["counters"].setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    res = {"round": rnd, "workload": wl, "dtype": dt, "points": n, "kernels": {}}
+    for k, d in acc.items():
+        c = {name: sum(v) / len(v) for name, v in d["counters"].items()}
+        d["counters"] = c
+        d["launches"] = len(next(iter(acc[k]["counters"].values()), [])) if False else None
+        if "SQ_INSTS_VALU" in c and n:
+            d["valu_wave_instructions_per_point"] = c["SQ_INSTS_VALU"] * 64 / n / 64     # wave-instr ≙ one per lane
+        if c.get("SQ_WAVE_CYCLES"):
+            d["valu_active_over_wave_cycles"] = c.get("SQ_ACTIVE_INST_VALU", 0.0) / c["SQ_WAVE_CYCLES"]
+        res["kernels"][k] = d
+    (dst / f"{rnd}_pmc_valu_{wl}_{dt}.json").write_text(json.dumps(res, indent=1))
+    print(json.dumps(res))
+
+
 def main():
     wl, dt, n, out, rnd = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    if len(sys.argv) > 6 and sys.argv[6] == "valu":
+        return valu_summary(wl, dt, n, out, rnd)
     dst = Path("gpurun_out/profiles")
     dst.mkdir(parents=True, exist_ok=True)
     summary = {"round": rnd, "workload": wl, "dtype": dt, "points": n,

@@ -15,3 +15,10 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fe
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- python3 $ARGS > "$OUT/write.log" 2>&1
 cd "$ROOT"
 python3 tools/pmc_summary.py "$WL" "$DT" "$N" "$OUT" "$R"
+# compute-bound workloads: one more pass with the SQ instruction/cycle counters (VALU issue utilisation)
+if [ "$WL" = "p3" ]; then
+  cd /tmp
+  timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/sq" -o sq -- python3 $ARGS > "$OUT/sq.log" 2>&1
+  cd "$ROOT"
+  python3 tools/pmc_summary.py "$WL" "$DT" "$N" "$OUT" "$R" valu
+fi
