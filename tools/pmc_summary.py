@@ -66,15 +66,15 @@ def main():
         path = find(out, sub, "counter_collection.csv")
         if not path:
             continue
-        vals = []
+        per_kernel = {}
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == key and "cmx::" in r["Kernel_Name"] and "column_sums" not in r["Kernel_Name"]:
-                vals.append(float(r["Counter_Value"]))
+                per_kernel.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
                 summary.setdefault("vgpr", r["VGPR_Count"]); summary.setdefault("sgpr", r["SGPR_Count"])
                 summary.setdefault("scratch", r["Scratch_Size"])
-        if vals:
-            summary[f"{key}_KiB_per_launch_mean"] = sum(vals) / len(vals)
-            summary[f"{key}_launches"] = len(vals)
+        if per_kernel:   # one step = one launch of each kernel of the workload: mean per kernel, summed over kernels
+            summary[f"{key}_KiB_per_launch_mean"] = sum(sum(v) / len(v) for v in per_kernel.values())
+            summary[f"{key}_launches"] = sum(len(v) for v in per_kernel.values())
     if "FETCH_SIZE_KiB_per_launch_mean" in summary and "WRITE_SIZE_KiB_per_launch_mean" in summary:
         fetch = summary["FETCH_SIZE_KiB_per_launch_mean"] * 1024 * 2      # gfx950 correction
         write = summary["WRITE_SIZE_KiB_per_launch_mean"] * 1024
