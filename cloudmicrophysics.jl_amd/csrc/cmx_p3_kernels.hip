@@ -41,7 +41,15 @@ template <> struct PM<double> {
     static __device__ __forceinline__ double atanh(double x) { return ::atanh(x); }
     static __device__ __forceinline__ double log2(double x) { return ::log2(x); }
     static __device__ __forceinline__ double abs(double x) { return __builtin_fabs(x); }
+    // 1/d to ≈1 ulp: v_rcp_f64 (≈2⁻²⁴ relative) + two Newton steps — no div_scale / div_fmas / div_fixup sequence.
+    // Only for finite, normal d (the incomplete-gamma loops: d = a + k, or a rescaled continued-fraction denominator).
+    static __device__ __forceinline__ double rcp(double d) {
+        double r = __builtin_amdgcn_rcp(d);
+        r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+        return __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    }
     static constexpr int kBrent = 10, kGammaIters = 30;      // P3_size_distribution.jl:311, Utilities.jl:104
+    static constexpr int kRescale = 6;                        // continued-fraction rescale period (b ≤ 1e8 → 1e48 growth)
     static constexpr double eps() { return 2.220446049250313e-16; }
 };
 template <> struct PM<float> {
@@ -55,7 +63,12 @@ template <> struct PM<float> {
     static __device__ __forceinline__ float atanh(float x) { return ::atanhf(x); }
     static __device__ __forceinline__ float log2(float x) { return ::log2f(x); }
     static __device__ __forceinline__ float abs(float x) { return __builtin_fabsf(x); }
+    static __device__ __forceinline__ float rcp(float d) {
+        const float r = __builtin_amdgcn_rcpf(d);
+        return __builtin_fmaf(r, __builtin_fmaf(-d, r, 1.0f), r);
+    }
     static constexpr int kBrent = 8, kGammaIters = 20;
+    static constexpr int kRescale = 2;                        // Float32: (1e8)² < 3e38
     static constexpr float eps() { return 1.1920928955078125e-07f; }
 };
 
@@ -84,33 +97,48 @@ template <typename FT, typename PR> static P3Consts<FT> make_p3_consts(const PR 
     return c;
 }
 
-// UT.gamma_inc — Utilities.jl:93-144.  Returns P if want_P else Q (the caller knows which one it will difference).
+// UT.gamma_inc — Utilities.jl:93-144: series for x < a+1, Lentz continued fraction otherwise, both with a FIXED
+// number of terms (20 Float32 / 30 Float64).  The device evaluates the same truncations in cheaper arithmetic:
+//   * series: Σ_k x^k / (a(a+1)…(a+k)) with the reciprocal of (a+k) from rcp() instead of an IEEE division;
+//   * continued fraction: the n-th convergent h_n = A_n/B_n of  1/(b₀+ a₁/(b₁+ a₂/(b₂+…)))  by the forward (Wallis)
+//     recurrence A_n = b_n A_{n−1} + a_n A_{n−2} — the value modified Lentz produces with two divisions per term —
+//     rescaled every kRescale terms; one reciprocal at the end.
+// `gamma_series` / `gamma_cf` return the bracketed sums WITHOUT the prefactor x^a e^{−x}/Γ(a).
+template <typename FT> __device__ __forceinline__ FT gamma_series_sum(FT a, FT x) {
+    using P = PM<FT>;
+    FT term = P::rcp(a), sum = term;
+#pragma unroll 2
+    for (int k = 1; k <= P::kGammaIters; ++k) { term *= x * P::rcp(a + FT(k)); sum += term; }
+    return sum;
+}
+template <typename FT> __device__ __forceinline__ FT gamma_cf_value(FT a, FT x) {
+    using P = PM<FT>;
+    static_assert(P::kGammaIters % P::kRescale == 0, "rescale period must divide the term count");
+    // h₀ = 1/b₀:  A₀ = 1, B₀ = b₀;  A₋₁ = 0, B₋₁ = 1
+    const FT b0 = x + FT(1) - a;
+    FT Am = FT(0), Bm = FT(1), A = FT(1), B = b0;
+#pragma unroll 1
+    for (int k0 = 0; k0 < P::kGammaIters; k0 += P::kRescale) {
+#pragma unroll
+        for (int j = 1; j <= P::kRescale; ++j) {
+            const FT kk = FT(k0 + j);
+            const FT ak = -kk * (kk - a), bk = b0 + FT(2) * kk;
+            const FT An = bk * A + ak * Am, Bn = bk * B + ak * Bm;
+            Am = A; Bm = B; A = An; B = Bn;
+        }
+        const FT r = P::rcp(B);
+        A *= r; Am *= r; Bm *= r; B = FT(1);
+    }
+    return A;
+}
 template <typename FT> __device__ FT gamma_inc_dev(FT a, FT x, FT lgam_a, bool want_P) {
     using P = PM<FT>;
     if (x <= FT(0)) return want_P ? FT(0) : FT(1);
     if (isinf(x)) return want_P ? FT(1) : FT(0);
     const FT factor = P::exp(a * P::log(x) - x - lgam_a);
-    FT pq;   // P on the series branch, Q on the continued-fraction branch
     const bool series = x < a + FT(1);
-    if (series) {
-        FT term = FT(1) / a, sum = term;
-        for (int k = 1; k <= P::kGammaIters; ++k) { term *= x / (a + FT(k)); sum += term; }
-        pq = Math<FT>::min(Math<FT>::max(factor * sum, FT(0)), FT(1));
-    } else {
-        const FT tiny = FT(1e-30);
-        const FT b1 = x + FT(1) - a;
-        FT c = b1 + FT(1) / tiny, d = FT(1) / b1, h = d;
-        for (int k = 1; k <= P::kGammaIters; ++k) {
-            const FT ak = -FT(k) * (FT(k) - a), bk = x + FT(2 * k + 1) - a;
-            const FT dt = bk + ak * d;
-            d = P::abs(dt) < tiny ? tiny : dt;
-            const FT ct = bk + ak / c;
-            c = P::abs(ct) < tiny ? tiny : ct;
-            d = FT(1) / d;
-            h *= c * d;
-        }
-        pq = Math<FT>::min(Math<FT>::max(factor * h, FT(0)), FT(1));
-    }
+    const FT body = series ? gamma_series_sum<FT>(a, x) : gamma_cf_value<FT>(a, x);
+    const FT pq = Math<FT>::min(Math<FT>::max(factor * body, FT(0)), FT(1));   // P on the series branch, Q on the other
     return (series == want_P) ? pq : FT(1) - pq;
 }
 
@@ -333,11 +361,13 @@ static int32_t p3_entry(const PR *params, uint32_t flags, int32_t brent_iters, i
 // domain from ONE log(D):  n·v = Σ_k A_k exp(base + e_k + b_k logD − c_k D),  base = logN₀ + μ logD − λD, where
 //   * (A_k, e_k, b_k, c_k) are the Chen-2022 small- or large-ice terms (selected per node by D ≤ cutoff) with the
 //     parameter-only table reductions at ρᵢ = 916.7 folded on the host and the ρₐ-dependent prefactors once per point;
+//     the two terms have opposite signs and cancel to ≈1/200 of their size for small D, so the sum is formed as
+//     e^{base+E₁}·(A₁ + A₂ e^{E₂−E₁}) — the large shared factor stays OUTSIDE the difference, as D^b does in the reference;
 //   * the aspect factor cbrt(ϕᵢ) is exactly 1 on the two spherical segments (small ice, graupel), a pure power law
 //     of D on the unrimed / dense-rimed segment (folded into e_k, b_k: no extra transcendental), and needs the mixed
 //     area F·πD²/4 + (1−F)·γD^σ only on the partially-rimed segment (one exp + one log more);
 //   * m(D) = exp(log a_seg + b_seg logD) with the per-segment mass law of the shape solver.
-// → 5 transcendentals per node instead of ≈12; nodes/weights are wave-uniform scalar loads from the kernel arguments.
+// → 3–4 transcendentals per node (log D, exp of the shared factor, exp of the term ratio[, D^β]) instead of ≈12; nodes/weights are wave-uniform scalar loads from the kernel arguments.
 template <typename FT> struct P3VelConsts {
     // small ice (table B3 reduced at ρᵢ): aᵢ = (Es, Fs)·ρₐ^As·1000^b, b = Bs + ρₐ Cs, c = (0, 1000 Gs)
     FT s_A, s_B, s_C, s_E, s_F, s_c2;
@@ -446,6 +476,8 @@ __global__ __launch_bounds__(kBlock) void p3_velocity_kernel(const P3Consts<FT> 
             if (ASPECT && k == 1) { q0 = v.g0; q1 = v.g1; }
             if (mixed_area) { q0 = h0; q1 = h1; }
             const FT lam_ = lam, mb = s.b[k], mla = s.log_a[k];
+            const bool sph_mass = mb == FT(3);
+            const FT ma = P::exp(mla);
             FT rn = FT(0), rm = FT(0);
             for (int j = 0; j < quad.n; ++j) {
                 const FT x = scale * quad.node[j] + shift, w = quad.weight[j];
@@ -459,12 +491,13 @@ __global__ __launch_bounds__(kBlock) void p3_velocity_kernel(const P3Consts<FT> 
                 // their size for small D, so the shared factor stays OUTSIDE the difference (as D^b does in the reference)
                 const bool small = x <= v.cutoff;
                 const FT E1 = small ? se + sb * logD : le1 + v.l_b1 * logD;
-                const FT E2 = small ? -v.s_c2 * x : le2 + v.l_b2 * logD - v.l_c2 * x;
-                const FT t1 = P::exp(E1), t2 = P::exp(E2);
-                const FT vv = small ? t1 * (v.s_E + v.s_F * t2) : v.l_a1 * t1 + v.l_a2 * t2;
-                const FT nv = P::exp(base) * vv;
+                const FT dE = small ? -v.s_c2 * x : (le2 - le1) + (v.l_b2 - v.l_b1) * logD - v.l_c2 * x;   // E2 − E1
+                const FT A1 = small ? v.s_E : v.l_a1, A2 = small ? v.s_F : v.l_a2;
+                const FT nv = P::exp(base + E1) * (A1 + A2 * P::exp(dE));
+                // m(D) = a D^b: b = 3 on the spherical segments (no transcendental), β_va otherwise
+                const FT mD = sph_mass ? ma * (x * x * x) : P::exp(mla + mb * logD);
                 rn += nv * w;
-                rm += nv * P::exp(mla + mb * logD) * w;
+                rm += nv * mD * w;
             }
             sum_n += scale * rn; sum_m += scale * rm;
         }
