@@ -4,10 +4,13 @@
 // stays on the hardware quarter-rate units: every pow/cbrt/exp/log of the
 // reference is rewritten in the log2 domain (x^y = exp2(y·log2 x)) so that the
 // Float32 path issues bare v_log_f32 / v_exp_f32 / v_rcp_f32 / v_sqrt_f32 and
-// shares one log2 between all powers of the same base.  Float64 uses the OCML
-// double routines (no hardware transcendental unit for f64).
+// shares one log2 between all powers of the same base.  Float64 has no hardware
+// transcendental unit: it uses the lean routines of cmx_lean_f64.hpp (20–35 VALU
+// instructions, ≤ 4 ulp) instead of OCML's 50–150-instruction ones.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include "cmx_lean_f64.hpp"
 
 namespace cmx {
 
@@ -47,18 +50,18 @@ template <> struct Math<double> {
     static constexpr int VEC = 2;
     static constexpr double eps() { return 2.220446049250313e-16; }            // eps(Float64)
     static constexpr double eps_1m() { return 2.8126442852362996e-103; }      // cbrt(floatmin(Float64))
-    static __device__ __forceinline__ double exp2(double x) { return ::exp2(x); }
-    static __device__ __forceinline__ double log2(double x) { return ::log2(x); }
-    static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
-    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
-    static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
-    static __device__ __forceinline__ double div(double a, double b) { return a / b; }
+    static __device__ __forceinline__ double exp2(double x) { return lean::exp2(x); }
+    static __device__ __forceinline__ double log2(double x) { return lean::log2(x); }
+    static __device__ __forceinline__ double rcp(double x) { return lean::rcp(x); }
+    static __device__ __forceinline__ double sqrt(double x) { return lean::sqrt(x); }
+    static __device__ __forceinline__ double rsqrt(double x) { return lean::rsqrt(x); }
+    static __device__ __forceinline__ double div(double a, double b) { return a * lean::rcp(b); }
     static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
     static __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }
     static __device__ __forceinline__ double min(double a, double b) { return __builtin_fmin(a, b); }
     static __device__ __forceinline__ double tgamma(double z) { return ::tgamma(z); }
-    static __device__ __forceinline__ double log1p(double x) { return ::log1p(x); }
-    static __device__ __forceinline__ double expm1(double x) { return ::expm1(x); }
+    static __device__ __forceinline__ double log1p(double x) { return lean::log1p(x); }
+    static __device__ __forceinline__ double expm1(double x) { return lean::expm1(x); }
 };
 
 template <typename FT> __device__ __forceinline__ FT clampv(FT x, FT lo, FT hi) {

@@ -28,11 +28,12 @@
 
 namespace cmx {
 
-// accurate (OCML) elementary functions for the solver: the residual is a log-sum-exp of incomplete-gamma moments
+// elementary functions for the solver (the residual is a log-sum-exp of incomplete-gamma moments): lean exp/log
+// (cmx_lean_f64.hpp) in Float64, OCML for the rest and for Float32
 template <typename FT> struct PM;
 template <> struct PM<double> {
-    static __device__ __forceinline__ double log(double x) { return ::log(x); }
-    static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
+    static __device__ __forceinline__ double log(double x) { return lean::log(x); }
+    static __device__ __forceinline__ double exp(double x) { return lean::exp(x); }
     static __device__ __forceinline__ double lgamma(double x) { return ::lgamma(x); }
     static __device__ __forceinline__ double expm1(double x) { return ::expm1(x); }
     static __device__ __forceinline__ double log1p(double x) { return ::log1p(x); }
@@ -43,11 +44,7 @@ template <> struct PM<double> {
     static __device__ __forceinline__ double abs(double x) { return __builtin_fabs(x); }
     // 1/d to ≈1 ulp: v_rcp_f64 (≈2⁻²⁴ relative) + two Newton steps — no div_scale / div_fmas / div_fixup sequence.
     // Only for finite, normal d (the incomplete-gamma loops: d = a + k, or a rescaled continued-fraction denominator).
-    static __device__ __forceinline__ double rcp(double d) {
-        double r = __builtin_amdgcn_rcp(d);
-        r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
-        return __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
-    }
+    static __device__ __forceinline__ double rcp(double d) { return lean::rcp_finite(d); }
     static constexpr int kBrent = 10, kGammaIters = 30;      // P3_size_distribution.jl:311, Utilities.jl:104
     static constexpr int kRescale = 6;                        // continued-fraction rescale period (b ≤ 1e8 → 1e48 growth)
     static constexpr double eps() { return 2.220446049250313e-16; }

@@ -1,0 +1,19 @@
+// Host build of csrc/cmx_lean_f64.hpp for tests/test_lean_math.py: evaluates each lean function on an array.
+#include <cstdint>
+#include "../../cloudmicrophysics.jl_amd/csrc/cmx_lean_f64.hpp"
+extern "C" void lean_eval(int which, int64_t n, const double *x, double *y) {
+    namespace L = cmx::lean;
+    for (int64_t i = 0; i < n; ++i) {
+        switch (which) {
+            case 0: y[i] = L::exp2(x[i]); break;
+            case 1: y[i] = L::log2(x[i]); break;
+            case 2: y[i] = L::exp(x[i]); break;
+            case 3: y[i] = L::log(x[i]); break;
+            case 4: y[i] = L::rcp(x[i]); break;
+            case 5: y[i] = L::sqrt(x[i]); break;
+            case 6: y[i] = L::rsqrt(x[i]); break;
+            case 7: y[i] = L::expm1(x[i]); break;
+            case 8: y[i] = L::log1p(x[i]); break;
+        }
+    }
+}

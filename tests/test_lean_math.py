@@ -1,0 +1,70 @@
+"""CPU test of csrc/cmx_lean_f64.hpp (the Float64 elementary functions the f64 kernels use instead of OCML): the
+same header compiled for the host (tests/native/lean_math_host.cpp; the hardware reciprocal / rsqrt seeds are
+replaced by single-precision stand-ins of the same accuracy class) against numpy's libm results."""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def lean(tmp_path_factory):
+    so = tmp_path_factory.mktemp("lean") / "liblean.so"
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-o", str(so),
+                    str(REPO / "tests" / "native" / "lean_math_host.cpp")], check=True)
+    lib = C.CDLL(str(so))
+
+    def ev(which, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        lib.lean_eval(C.c_int(which), C.c_int64(x.size), x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p))
+        return y
+    return ev
+
+
+EXP2, LOG2, EXP, LOG, RCP, SQRT, RSQRT, EXPM1, LOG1P = range(9)
+
+
+def ulps(y, r):
+    with np.errstate(all="ignore"):
+        return np.nanmax(np.abs(y - r) / np.spacing(np.abs(r)))
+
+
+def test_accuracy_in_ulps(lean):
+    rng = np.random.default_rng(0)
+    n = 400_000
+    x = rng.uniform(-1000, 1000, n)
+    assert ulps(lean(EXP2, x), np.exp2(x)) <= 2
+    x = rng.uniform(-700, 700, n)
+    assert ulps(lean(EXP, x), np.exp(x)) <= 2
+    x = np.exp(rng.uniform(-700, 700, n))
+    assert ulps(lean(LOG2, x), np.log2(x)) <= 4 and ulps(lean(LOG, x), np.log(x)) <= 4
+    x = 1 + rng.uniform(-0.3, 0.4, n)            # relative accuracy where the result is small
+    assert np.max(np.abs(lean(LOG2, x) - np.log2(x)) / np.abs(np.log2(x))) < 1e-15
+    x = np.exp(rng.uniform(-80, 80, n))
+    assert ulps(lean(RCP, x), 1 / x) <= 1 and ulps(lean(SQRT, x), np.sqrt(x)) <= 1 and ulps(lean(RSQRT, x), 1 / np.sqrt(x)) <= 3
+    for lo, hi in ((-1e-5, 1e-5), (-0.5, 0.5), (-40, 40), (-3, 700)):
+        x = rng.uniform(lo, hi, n)
+        assert ulps(lean(EXPM1, x), np.expm1(x)) <= 3
+    for lo, hi in ((-1e-5, 1e-5), (-0.9, 0.9), (0, 1e6)):
+        x = rng.uniform(lo, hi, n)
+        assert ulps(lean(LOG1P, x), np.log1p(x)) <= 5
+
+
+def test_special_values(lean):
+    inf, nan = np.inf, np.nan
+    with np.errstate(all="ignore"):
+        np.testing.assert_array_equal(lean(EXP2, [0.0, inf, -inf, nan, 2000.0, -2000.0, -1074.0]), [1.0, inf, 0.0, nan, inf, 0.0, 5e-324])
+        np.testing.assert_array_equal(lean(EXP, [0.0, inf, -inf, nan, 800.0, -800.0]), [1.0, inf, 0.0, nan, inf, 0.0])
+        np.testing.assert_array_equal(lean(LOG2, [0.0, -0.0, inf, nan, -1.0, 1.0, 5e-324, 2.0 ** 1000]), [-inf, -inf, inf, nan, nan, 0.0, -1074.0, 1000.0])
+        np.testing.assert_array_equal(lean(LOG, [0.0, inf, nan, -1.0, 1.0]), [-inf, inf, nan, nan, 0.0])
+        np.testing.assert_array_equal(lean(RCP, [0.0, -0.0, inf, -inf, nan, 4.0]), [inf, -inf, 0.0, -0.0, nan, 0.25])
+        np.testing.assert_array_equal(lean(SQRT, [0.0, inf, nan, 4.0]), [0.0, inf, nan, 2.0])
+        np.testing.assert_array_equal(lean(RSQRT, [0.0, inf, 4.0]), [inf, 0.0, 0.5])
+        np.testing.assert_array_equal(lean(EXPM1, [0.0, inf, -inf, nan, -800.0]), [0.0, inf, -1.0, nan, -1.0])
+        np.testing.assert_array_equal(lean(LOG1P, [0.0, inf, nan, -1.0, -2.0]), [0.0, inf, nan, -inf, nan])
+        assert np.isnan(lean(SQRT, [-1.0])[0])
