@@ -30,6 +30,11 @@ template <typename FT> struct ArgModeConsts {
     FT u_c;          // u_i = u_c · (log2 Sm_i − log2 S_max),  u_c = 2 ln2 /(3√2 ln σ_i)
     FT fac;          // 3 ln σ_i √2 / 2
     FT half_M;       // Σ M_j w_j / 2
+    // mode-only factors of the S_max sum (AA:170-183), so that the per-state loop needs ONE log2 + ONE exp2 per mode:
+    FT inv_N;        // η_i = X / N_i
+    FT fN;           // f_i (ζ/η_i)^p1 = fN · (ζ/X)^p1,           fN = f_i N_i^p1
+    FT gS;           // g_i (Sm_i²/(η_i+3ζ))^p2 = gS · A^(3 p2) · (η_i+3ζ)^(−p2),   gS = g_i (Sm_i² A⁻³)^p2
+    FT inv_sm_c;     // 1/Sm_i = inv_sm_c · A^(−3/2)
 };
 
 template <typename FT> struct ArgConsts {
@@ -79,6 +84,11 @@ static ArgConsts<FT> make_arg_consts(const AP &ap, const AD &ad, const AI &aip, 
         o.u_c = (FT)(2.0 * ln2 / (3.0 * std::sqrt(2.0) * ls));
         o.fac = (FT)(3.0 * ls * std::sqrt(2.0) / 2.0);
         o.half_M = (FT)((double)m.molar_mass_mix / 2.0);
+        const double l2_sm_c = std::log2(2.0 / std::sqrt((double)m.hygroscopicity)) - 1.5 * std::log2(3.0 * (double)m.r_dry);
+        o.inv_N = (FT)(1.0 / (double)m.N);
+        o.fN = (FT)((double)ap.f1 * std::exp((double)ap.f2 * ls * ls) * std::pow((double)m.N, (double)ap.p1));
+        o.gS = (FT)(((double)ap.g1 + (double)ap.g2 * ls) * std::exp2(2.0 * (double)ap.p2 * l2_sm_c));
+        o.inv_sm_c = (FT)std::exp2(-l2_sm_c);
     }
     return c;
 }
@@ -136,16 +146,21 @@ __device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, FT T
     // η_i = sq³ / (2π ρw γ N_i)  →  log2 η_i = l2_X − log2 N_i
     const FT X = sq * sq * sq * M::rcp(c.two_pi_rho_w * gamma);
     const FT l2_X = M::log2(X);
+    // Σ_i (1/Sm_i²)·[f_i (ζ/η_i)^p1 + g_i (Sm_i²/(η_i+3ζ))^p2] — AA:170-183.  Everything that depends only on the mode is
+    // folded on the host (ArgModeConsts); per state three shared powers, per mode one log2 + one exp2.
+    const FT Z1 = M::exp2(c.p1 * (l2_zeta - l2_X));            // (ζ/X)^p1
+    const FT A3p2 = M::exp2(FT(2) * c.p2 * l2_A15);            // A^(3 p2)
+    const FT Am15 = M::exp2(-l2_A15);                          // A^(−3/2)
     FT tmp = FT(0);
     FT l2_sm[NM];
 #pragma unroll
     for (int k = 0; k < NM; ++k) {
         l2_sm[k] = c.m[k].l2_sm_c + l2_A15;
-        const FT l2_eta = l2_X - c.m[k].l2_N;
-        const FT eta = M::exp2(l2_eta);
-        const FT t1 = c.m[k].f * M::exp2(c.p1 * (l2_zeta - l2_eta));                                      // f (ζ/η)^p1
-        const FT t2 = c.m[k].g * M::exp2(c.p2 * (FT(2) * l2_sm[k] - M::log2(M::fma(FT(3), zeta, eta))));  // g (Sm²/(η+3ζ))^p2
-        tmp = M::fma(M::exp2(FT(-2) * l2_sm[k]), t1 + t2, tmp);                                           // AA:181-183
+        const FT eta = X * c.m[k].inv_N;
+        const FT t1 = c.m[k].fN * Z1;
+        const FT t2 = c.m[k].gS * A3p2 * M::exp2(-c.p2 * M::log2(M::fma(FT(3), zeta, eta)));
+        const FT inv_sm = c.m[k].inv_sm_c * Am15;
+        tmp = M::fma(inv_sm * inv_sm, t1 + t2, tmp);
     }
     const FT S_arg = M::rsqrt(tmp);                                                                        // AA:185
     FT smax;

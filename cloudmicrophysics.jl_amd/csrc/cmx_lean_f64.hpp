@@ -34,13 +34,21 @@ CMX_LEAN_FN double rcp_finite(double d) {
     r = fma_(r, fma_(-d, r, 1.0), r);
     return fma_(r, fma_(-d, r, 1.0), r);
 }
-// 1/d with the IEEE results for d = ±0 (±Inf), ±Inf (±0) and NaN; subnormal d (1/d ≥ 4.5e307) saturates to ±Inf
+// 1/d with the IEEE results for d = ±0 (±Inf), ±Inf (±0) and NaN: whenever the seed is 0 or ±Inf the Newton steps
+// would produce NaN, so the seed itself is returned (one class test on the seed; subnormal d saturates to ±Inf)
 CMX_LEAN_FN double rcp(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double r0 = __builtin_amdgcn_rcp(d);
+    double r = fma_(r0, fma_(-d, r0, 1.0), r0);
+    r = fma_(r, fma_(-d, r, 1.0), r);
+    return __builtin_amdgcn_class(r0, 0x204 | 0x060) ? r0 : r;              // ±Inf (0x204), ±0 (0x060)
+#else
     const double inf = std::numeric_limits<double>::infinity();
     const double ad = __builtin_fabs(d);
     const double r = rcp_finite(d);
     const double s = d != d ? d : __builtin_copysign(ad == inf ? 0.0 : inf, d);
     return (ad >= 2.2250738585072014e-308 && ad < inf) ? r : s;
+#endif
 }
 CMX_LEAN_FN double frexp_mant(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -126,9 +134,19 @@ CMX_LEAN_FN MantExp split(double x) {                                        // 
 }
 CMX_LEAN_FN double log_special(double x, double r) {                          // IEEE special values of log-type results
     const double inf = std::numeric_limits<double>::infinity();
+#if defined(__HIP_DEVICE_COMPILE__)
+    // one class test; the fix-ups sit behind a branch that no lane takes for ordinary (positive, finite) arguments
+    if (__builtin_amdgcn_class(x, 0x200 | 0x060 | 0x01C)) {                    // +Inf | ±0 | −Inf, −normal, −subnormal
+        r = x == inf ? inf : r;
+        r = x == 0.0 ? -inf : r;
+        r = x < 0.0 ? std::numeric_limits<double>::quiet_NaN() : r;
+    }
+    return r;
+#else
     r = x == inf ? inf : r;
     r = x == 0.0 ? -inf : r;
     return x < 0.0 ? std::numeric_limits<double>::quiet_NaN() : r;            // NaN input propagates through r
+#endif
 }
 CMX_LEAN_FN double log2(double x) {
     const MantExp s = split(x);
