@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profile one bench.py workload on the GPU box: kernel-trace stats + two separate PMC passes (FETCH_SIZE, WRITE_SIZE)
 # as MI355X_MICROARCH.md §HBM prescribes; summaries land in gpurun_out/profiles/ (copy them into profiles/ to commit).
-#   usage: tools/profile.sh <workload> <dtype> <points> [round-tag]
+#   usage: tools/profile.sh <workload> <dtype> <points> [round-tag] [valu]
 set -u
 WL=$1; DT=$2; N=$3; R=${4:-r01}
 ROOT=$(pwd)
@@ -16,9 +16,9 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o wr
 cd "$ROOT"
 python3 tools/pmc_summary.py "$WL" "$DT" "$N" "$OUT" "$R"
 # compute-bound workloads: one more pass with the SQ instruction/cycle counters (VALU issue utilisation)
-if [ "$WL" = "p3" ]; then
+if [ "$WL" = "p3" ] || [ "${5:-}" = "valu" ]; then
   cd /tmp
-  timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/sq" -o sq -- python3 $ARGS > "$OUT/sq.log" 2>&1
+  timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_INST_ANY SQ_INSTS_VALU_TRANS GRBM_GUI_ACTIVE --output-format csv -d "$OUT/sq" -o sq -- python3 $ARGS > "$OUT/sq.log" 2>&1
   cd "$ROOT"
   python3 tools/pmc_summary.py "$WL" "$DT" "$N" "$OUT" "$R" valu
 fi
