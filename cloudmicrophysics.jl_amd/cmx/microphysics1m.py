@@ -25,8 +25,14 @@ class Microphysics1Moment:
 
 
 class Instantaneous:
-    """BMT.Instantaneous — tendency mode tag: raw point-wise tendencies (BMT:84-90).  `LinearizedAverage` is not on
-    this path yet."""
+    """BMT.Instantaneous — tendency mode tag: raw point-wise tendencies (BMT:84-90)."""
+
+
+class LinearizedAverage:
+    """BMT.LinearizedAverage — tendency mode tag: average tendencies over Δt from `nsub` linearized implicit substeps
+    (BMT:96-115, 572-632).  `bulk_microphysics_tendencies_1m(LinearizedAverage(), scheme, mp, tps, …, dt, nsub)`.
+    `q_min` = TD.Parameters.q_min(tps), the donor floor of the linearization (parameters.DEFAULT_PARAMETERS
+    "specific_humidity_minimum"; not pinned by any reference test)."""
 
 
 Tendencies1M = namedtuple("Tendencies1M", ["dq_lcl_dt", "dq_icl_dt", "dq_rai_dt", "dq_sno_dt"])
@@ -46,11 +52,12 @@ def _prep(mp, tps, cols):
     return ref, fam
 
 
-def bulk_microphysics_tendencies_1m(mode, scheme, mp, tps, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno, *, out=None,
-                                    stream=None) -> Tendencies1M:
-    """1-moment tendencies over columns (Instantaneous mode) — BMT:505-514 → :141-252."""
-    if not isinstance(mode, Instantaneous) or not isinstance(scheme, Microphysics1Moment):
-        raise TypeError("only (Instantaneous(), Microphysics1Moment()) is on this path")
+def bulk_microphysics_tendencies_1m(mode, scheme, mp, tps, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno, dt=None, nsub=1, *,
+                                    q_min=None, out=None, stream=None) -> Tendencies1M:
+    """1-moment tendencies over columns — Instantaneous mode (BMT:505-514 → :141-252) or, with `dt` [, `nsub`],
+    LinearizedAverage mode (BMT:572-632)."""
+    if not isinstance(scheme, Microphysics1Moment) or not isinstance(mode, (Instantaneous, LinearizedAverage)):
+        raise TypeError("mode must be Instantaneous() or LinearizedAverage() and scheme Microphysics1Moment()")
     cols = (rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno)
     ref, fam = _prep(mp, tps, cols)
     if out is None:
@@ -58,10 +65,23 @@ def bulk_microphysics_tendencies_1m(mode, scheme, mp, tps, rho, T, q_tot, q_lcl,
     else:
         _check_cols([ref] + list(out), ["rho"] + ["out"] * 4)
     s = stream if stream is not None else torch.cuda.current_stream(ref.device)
-    fn = getattr(_lib.lib(), f"cmx_mp1m_tendencies_{fam.sfx}")
-    with torch.cuda.device(ref.device):
-        st = fn(C.byref(mp.c), C.byref(tps), mp.flags, ref.numel(), *[_ptr(t) for t in cols], *[_ptr(o) for o in out],
-                C.c_void_p(s.cuda_stream))
+    if isinstance(mode, LinearizedAverage):
+        if dt is None or not dt > 0 or int(nsub) < 1:
+            raise ValueError("LinearizedAverage needs dt > 0 and nsub >= 1")
+        if q_min is None:
+            from .parameters import DEFAULT_PARAMETERS
+            q_min = DEFAULT_PARAMETERS["specific_humidity_minimum"]
+        fn = getattr(_lib.lib(), f"cmx_mp1m_linearized_average_{fam.sfx}")
+        with torch.cuda.device(ref.device):
+            st = fn(C.byref(mp.c), C.byref(tps), mp.flags, q_min, dt, int(nsub), ref.numel(), *[_ptr(t) for t in cols],
+                    *[_ptr(o) for o in out], C.c_void_p(s.cuda_stream))
+    else:
+        if dt is not None:
+            raise TypeError("Instantaneous() takes no dt")
+        fn = getattr(_lib.lib(), f"cmx_mp1m_tendencies_{fam.sfx}")
+        with torch.cuda.device(ref.device):
+            st = fn(C.byref(mp.c), C.byref(tps), mp.flags, ref.numel(), *[_ptr(t) for t in cols], *[_ptr(o) for o in out],
+                    C.c_void_p(s.cuda_stream))
     _lib.check(fn.__name__, st)
     return out
 

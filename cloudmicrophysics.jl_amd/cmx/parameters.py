@@ -162,6 +162,9 @@ DEFAULT_PARAMETERS = {
     "Heymsfield_mu_coeff1": 0.00191, "Heymsfield_mu_coeff2": 0.8, "Heymsfield_mu_coeff3": 2.0, "Heymsfield_mu_cutoff": 6.0,
     "P3_constant_slope_parameterization_value": 0.0,   # SlopeConstant default (unpinned; only used with slope_law="constant")
     "P3_wet_growth_timescale": 100.0,                  # not read by the shape solver
+    # TD.Parameters.q_min(tps): donor floor of the 1M LinearizedAverage linearization (BMT:395); ClimaParams value not
+    # in the tree and not pinned by any reference test (only states with a hydrometeor below it are affected)
+    "specific_humidity_minimum": 1e-10,
     # Chen et al. (2022) ice tables B3 (small ice) / B5 (large ice) and the small/large cutoff; pinned through the P3
     # particle-velocity KATs (test/p3_tests.jl:283-307) and, to 14 digits, the bulk fall-speed KATs (:376-379)
     "Chen2022_table_B3_As": (-0.263503, 0.00174079, 0.0378769), "Chen2022_table_B3_Bs": (0.575231, 0.0909307, 0.515579),

@@ -40,6 +40,8 @@ template <typename FT> struct Mp1mConsts {
     FT vt_c_rai, vt_e_rai, vt_c_sno, vt_e_sno;
     // autoconversion
     FT ka_qthr, ka_k, ka_inv_tau, ka_emk;           // Kessler: threshold, k, 1/τ, e^{-k}
+    FT ka_k_over_x0, ka_x0_over_k, ks_k_over_x0, ks_x0_over_k;   // k/max(x0, ϵ), max(x0, ϵ)/k
+    FT sqrt_v0_sno, inv_eps;
     FT nd_coeff;                                     // PrescribedNd: 1/(τ (Nc/1e8)^α)
     FT ks_qthr, ks_k, ks_inv_tau, ks_emk;           // snow NoSupersaturation
     FT r_is, inv_me_dm_icl;                          // WithSupersaturation
@@ -106,6 +108,13 @@ static Mp1mConsts<FT> make_mp1m_consts(const MP &mp, const TH &tp, uint32_t flag
     c.nd_coeff = (FT)(1.0 / ((double)pp.rain_autoconversion_nd.tau *
                              std::pow((double)pp.rain_autoconversion_nd.Nc / 1e8, (double)pp.rain_autoconversion_nd.alpha)));
     c.ks_qthr = (FT)pp.snow_autoconversion.q_threshold; c.ks_k = (FT)pp.snow_autoconversion.k;
+    {
+        const double e1 = (double)Math<FT>::eps_1m();
+        const double xa = std::fmax((double)pp.rain_autoconversion.q_threshold, e1), xs = std::fmax((double)pp.snow_autoconversion.q_threshold, e1);
+        c.ka_k_over_x0 = (FT)((double)pp.rain_autoconversion.k / xa); c.ka_x0_over_k = (FT)(xa / (double)pp.rain_autoconversion.k);
+        c.ks_k_over_x0 = (FT)((double)pp.snow_autoconversion.k / xs); c.ks_x0_over_k = (FT)(xs / (double)pp.snow_autoconversion.k);
+        c.sqrt_v0_sno = (FT)std::sqrt((double)vs.v0); c.inv_eps = (FT)(1.0 / e1);
+    }
     c.ks_inv_tau = (FT)(1.0 / (double)pp.snow_autoconversion.tau); c.ks_emk = (FT)std::exp(-(double)pp.snow_autoconversion.k);
     c.r_is = (FT)pp.r_ice_snow;
     c.inv_me_dm_icl = (FT)(1.0 / ((double)mp.cloud_ice.mass.me + (double)mp.cloud_ice.mass.delta_m));
@@ -151,19 +160,19 @@ static Mp1mConsts<FT> make_mp1m_consts(const MP &mp, const TH &tp, uint32_t flag
     return c;
 }
 
-template <typename FT> struct Mp1mSrc { FT s[CMX_MP1M_NSRC]; };
+template <typename FT> struct Mp1mSrc { FT s[CMX_MP1M_NSRC]; FT qsat_l, qsat_i; };   // + q_sat over liquid / ice (LinearizedAverage)
 
 // CO.logistic_function_integral (Common.jl:157-173) in a cancellation-free form: with t = −log(1−e^{−k})/k,
 //   (log1pexp(k(x/x0 − 1 + t))/k − t)·x0  =  log1p(e^{−k}·expm1(k x/x0)) · x0/k
-template <typename FT> __device__ __forceinline__ FT logistic_integral(FT x, FT x0, FT k, FT emk, FT eps) {
+template <typename FT> __device__ __forceinline__ FT logistic_integral(FT x, FT x0, FT k, FT emk, FT k_over_x0, FT x0_over_k, FT eps) {
     using M = Math<FT>;
     x = M::max(FT(0), x);
-    const FT xs = M::max(x, eps), x0s = M::max(x0, eps);
+    const FT xs = M::max(x, eps);
     // beyond y = k x/x0 = 60 the same quantity is (y − k) + log1p(e^{k−y} − e^{−y}) = y − k to 1e-25 (and expm1
-    // cannot overflow below it)
-    const FT y = k * xs * M::rcp(x0s);
+    // cannot overflow below it); k/max(x0, ϵ) and its inverse are parameter-only (host-folded)
+    const FT y = xs * k_over_x0;
     const FT lg = M::log1p(emk * M::expm1(M::min(y, FT(60))));
-    const FT r = (y > FT(60) ? y - k : lg) * x0s * M::rcp(k);
+    const FT r = (y > FT(60) ? y - k : lg) * x0_over_k;
     return x < eps ? FT(0) : (x0 < eps ? x : r);
 }
 
@@ -197,6 +206,7 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const Mp1mConsts<FT> &c, FT rh
     const FT inv_RT = c.inv_R_v * inv_T;
     const bool above_freezing = T > c.T_freeze;
     const FT dTf = T - c.T_freeze;
+    o.qsat_l = psat_l * inv_rho_RvT; o.qsat_i = psat_i * inv_rho_RvT;
     if (fl & CMX_1M_CLOUD_LIQUID_FORMATION) {   // NonEq:117-140
         const FT q_sat = psat_l * inv_rho_RvT;
         const FT dq_dT = q_sat * (L_v * inv_RT * inv_T - inv_T);
@@ -212,11 +222,13 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const Mp1mConsts<FT> &c, FT rh
         const FT tend = (ex < FT(0) ? -M::min(-ex, q_icl) : ex) * inv_ts;
         o.s[CMX_1M_S_PHASE_CHANGE_VAP_ICL] = (above_freezing && tend > FT(0)) ? FT(0) : tend;
     }
-    const FT S_l = M::fma(q_vap * rho_RvT, M::rcp(psat_l), FT(-1));              // TDI.supersaturation_over_liquid
-    const FT S_i = M::fma(q_vap * rho_RvT, M::rcp(psat_i), FT(-1));              // …over_ice
+    const FT inv_ps_l = M::rcp(psat_l), inv_ps_i = M::rcp(psat_i);
+    const FT S_l = M::fma(q_vap * rho_RvT, inv_ps_l, FT(-1));                      // TDI.supersaturation_over_liquid
+    const FT S_i = M::fma(q_vap * rho_RvT, inv_ps_i, FT(-1));                      // …over_ice
     const FT LoRT_v = L_v * inv_RT, LoRT_s = L_s * inv_RT;
-    const FT G_l = M::rcp(M::fma(L_v * c.inv_K * inv_T, LoRT_v - FT(1), c.Rv_over_D * T * M::rcp(M::max(psat_l, eps))));   // Common.jl:47-63
-    const FT G_i = M::rcp(M::fma(L_s * c.inv_K * inv_T, LoRT_s - FT(1), c.Rv_over_D * T * M::rcp(M::max(psat_i, eps))));   // :83-102
+    // 1/max(p_sat, ϵ) = min(1/p_sat, 1/ϵ): the reciprocal is shared with the supersaturation
+    const FT G_l = M::rcp(M::fma(L_v * c.inv_K * inv_T, LoRT_v - FT(1), c.Rv_over_D * T * M::min(inv_ps_l, c.inv_eps)));   // Common.jl:47-63
+    const FT G_i = M::rcp(M::fma(L_s * c.inv_K * inv_T, LoRT_s - FT(1), c.Rv_over_D * T * M::min(inv_ps_i, c.inv_eps)));   // :83-102
 
     // ---- size_distr_parameters — CM1:375-388 ------------------------------------------------------------------
     const FT l2_rq_rai = M::log2(rho * q_rai), l2_rq_sno = M::log2(rho * q_sno), l2_rq_icl = M::log2(rho * q_icl);
@@ -233,11 +245,11 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const Mp1mConsts<FT> &c, FT rh
 
     // ---- autoconversion — CM1:354-364, 414-446 ------------------------------------------------------------------
     if (fl & CMX_1M_RAIN_ACNV_KESSLER)
-        o.s[CMX_1M_S_ACNV_LCL_RAI] = logistic_integral<FT>(q_lcl, c.ka_qthr, c.ka_k, c.ka_emk, eps) * c.ka_inv_tau;
+        o.s[CMX_1M_S_ACNV_LCL_RAI] = logistic_integral<FT>(q_lcl, c.ka_qthr, c.ka_k, c.ka_emk, c.ka_k_over_x0, c.ka_x0_over_k, eps) * c.ka_inv_tau;
     else if (fl & CMX_1M_RAIN_ACNV_PRESCRIBED_ND)
         o.s[CMX_1M_S_ACNV_LCL_RAI] = q_lcl * c.nd_coeff;
     if (fl & CMX_1M_SNOW_ACNV_NO_SUPERSAT) {
-        o.s[CMX_1M_S_ACNV_ICL_SNO] = logistic_integral<FT>(q_icl, c.ks_qthr, c.ks_k, c.ks_emk, eps) * c.ks_inv_tau;
+        o.s[CMX_1M_S_ACNV_ICL_SNO] = logistic_integral<FT>(q_icl, c.ks_qthr, c.ks_k, c.ks_emk, c.ks_k_over_x0, c.ks_x0_over_k, eps) * c.ks_inv_tau;
     } else if (fl & CMX_1M_SNOW_ACNV_WITH_SUPERSAT) {
         const FT x = c.r_is * M::rcp(li_icl);
         const FT rate = c.four_pi * S_i * G_i * c.n0_icl * inv_rho * M::exp2(x * FT(-1.4426950408889634)) *
@@ -284,7 +296,7 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const Mp1mConsts<FT> &c, FT rh
 
     // ---- ventilated vapour exchange and melting — CM1:917-1139 ---------------------------------------------------
     const FT F_rai = M::fma(c.vent_b_rai * M::sqrt(v0_rai), M::exp2(c.vent_e_rai * l2_li_rai), c.vent_a_rai);
-    const FT F_sno = M::fma(c.vent_b_sno * M::sqrt(v0_sno), M::exp2(c.vent_e_sno * l2_li_sno), c.vent_a_sno);
+    const FT F_sno = M::fma(c.vent_b_sno * c.sqrt_v0_sno, M::exp2(c.vent_e_sno * l2_li_sno), c.vent_a_sno);
     const FT mp_rai = c.four_pi * c.n0_rai * inv_rho * (li_rai * li_rai) * F_rai;      // 4π n0/ρ λ⁻² F
     const FT mp_sno = c.four_pi * n0_sno * inv_rho * (li_sno * li_sno) * F_sno;
     if (fl & CMX_1M_RAIN_EVAPORATION)
@@ -338,6 +350,77 @@ __global__ __launch_bounds__(kBlock) void mp1m_tendencies_kernel(const Mp1mConst
 }
 
 // _microphysics_source_terms over columns (KAT / diagnostics harness): one point per lane
+// ---------------------------------------------------------------------------------------------------------------------
+// bulk_microphysics_tendencies(LinearizedAverage(), Microphysics1Moment(), …, Δt, nsub) — BMT:572-632: nsub linearized
+// implicit substeps (BMT:381-465) of the donor-based linearization dq/dt ≈ M q + e (BMT:269-379), temperature updated
+// from the latent heating of each substep.  One point per lane (the substep loop carries five state variables); the
+// source terms come from the same mp1m_point as the Instantaneous mode.
+template <typename FT> struct Mp1mLinArgs { FT q_min, dt, dt_sub, inv_dt_sub, inv_dt, Lv_over_cp, Ls_over_cp; int32_t nsub; };
+
+template <typename FT>
+__global__ __launch_bounds__(kBlock) void mp1m_linearized_kernel(const Mp1mConsts<FT> c, const Mp1mLinArgs<FT> a, const Mp1mIn<FT> in,
+                                                                 const Mp1mOut<FT> out, const int64_t n) {
+    using M = Math<FT>;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const FT rho = in.rho[i], q_tot = in.q_tot[i];
+    const FT ql0 = in.q_lcl[i], qi0 = in.q_icl[i], qr0 = in.q_rai[i], qs0 = in.q_sno[i];
+    FT T = in.T[i], ql = ql0, qi = qi0, qr = qr0, qs = qs0;
+    for (int k = 0; k < a.nsub; ++k) {
+        const Mp1mSrc<FT> p = mp1m_point<FT>(c, rho, T, q_tot, ql, qi, qr, qs);
+        const FT *S = p.s;
+        // _linearize — BMT:269-379
+        const FT il = M::rcp(M::max(a.q_min, ql)), ii = M::rcp(M::max(a.q_min, qi)), ir = M::rcp(M::max(a.q_min, qr)),
+                 is = M::rcp(M::max(a.q_min, qs));
+        FT M11 = FT(0), M12, M22 = FT(0), M31, M33, M34, M41, M42, M43, M44 = FT(0), e1 = FT(0), e2 = FT(0), e4 = FT(0);
+        {
+            const FT s1 = S[CMX_1M_S_PHASE_CHANGE_VAP_LCL], s2 = S[CMX_1M_S_PHASE_CHANGE_VAP_ICL], s4 = S[CMX_1M_S_PHASE_CHANGE_VAP_SNO];
+            e1 = s1 >= FT(0) ? s1 : FT(0); M11 = s1 >= FT(0) ? FT(0) : s1 * il;
+            e2 = s2 >= FT(0) ? s2 : FT(0); M22 = s2 >= FT(0) ? FT(0) : s2 * ii;
+            e4 = s4 >= FT(0) ? s4 : FT(0); M44 = s4 >= FT(0) ? FT(0) : s4 * is;
+        }
+        FT D;
+        D = S[CMX_1M_S_MELT_ICL_LCL] * ii;            M22 -= D; M12 = D;
+        D = S[CMX_1M_S_ACNV_LCL_RAI] * il;            M11 -= D; M31 = D;
+        D = S[CMX_1M_S_ACNV_ICL_SNO] * ii;            M22 -= D; M42 = D;
+        D = S[CMX_1M_S_ACCR_LCL_RAI] * il;            M11 -= D; M31 += D;
+        {
+            const FT Dc = S[CMX_1M_S_ACCR_LCL_SNO_COLD] * il, Dw = S[CMX_1M_S_ACCR_LCL_SNO_WARM] * il;
+            M11 -= Dc + Dw; M31 += Dw; M41 = Dc;
+        }
+        D = S[CMX_1M_S_ACCR_MELT_LCL_SNO] * is;       M44 -= D; M34 = D;
+        D = S[CMX_1M_S_ACCR_ICL_RAI] * ii;            M22 -= D; M42 += D;
+        D = S[CMX_1M_S_ACCR_ICL_SNO] * ii;            M22 -= D; M42 += D;
+        D = S[CMX_1M_S_ACCR_FREEZE_ICL_RAI] * ir;     M33 = -D; M43 = D;
+        D = S[CMX_1M_S_ACCR_RAI_SNO_WARM] * is;       M44 -= D; M34 += D;
+        D = S[CMX_1M_S_ACCR_MELT_RAI_SNO] * is;       M44 -= D; M34 += D;
+        D = S[CMX_1M_S_ACCR_RAI_SNO_COLD] * ir;       M33 -= D; M43 += D;
+        D = (-S[CMX_1M_S_PHASE_CHANGE_VAP_RAI]) * ir; M33 -= D;
+        D = S[CMX_1M_S_MELT_SNO_RAI] * is;            M44 -= D; M34 += D;
+        // _linearized_implicit_step — BMT:381-465
+        const FT q_sat_min = M::min(p.qsat_l, p.qsat_i);
+        const FT q_v = (((q_tot - ql) - qi) - qr) - qs;
+        const FT alpha = M::min(FT(1), M::max(FT(0), q_v - q_sat_min) * a.inv_dt_sub * M::rcp(M::max((e1 + e2) + e4, M::eps())));
+        const FT a11 = a.inv_dt_sub - M11, a12 = -M12, a22 = a.inv_dt_sub - M22, a31 = -M31, a33 = a.inv_dt_sub - M33, a34 = -M34;
+        const FT a41 = -M41, a42 = -M42, a43 = -M43, a44 = a.inv_dt_sub - M44;
+        const FT b1 = M::fma(alpha, e1, a.inv_dt_sub * ql), b2 = M::fma(alpha, e2, a.inv_dt_sub * qi), b3 = a.inv_dt_sub * qr,
+                 b4 = M::fma(alpha, e4, a.inv_dt_sub * qs);
+        const FT inv_det12 = M::rcp(a11 * a22);
+        const FT ql_new = (b1 * a22 - a12 * b2) * inv_det12, qi_new = a11 * b2 * inv_det12;
+        const FT r3 = M::fma(-a31, ql_new, b3);
+        const FT r4 = M::fma(-a41, ql_new, M::fma(-a42, qi_new, b4));
+        const FT inv_det = M::rcp(M::fma(-a34, a43, a33 * a44));
+        const FT qr_new = (r3 * a44 - a34 * r4) * inv_det, qs_new = (a33 * r4 - r3 * a43) * inv_det;
+        const FT dl = (ql_new - ql) * a.inv_dt_sub, di = (qi_new - qi) * a.inv_dt_sub, dr = (qr_new - qr) * a.inv_dt_sub,
+                 ds = (qs_new - qs) * a.inv_dt_sub;
+        // BMT:606-617 (the state advances by rate·Δt_sub exactly as the reference writes it)
+        ql += dl * a.dt_sub; qi += di * a.dt_sub; qr += dr * a.dt_sub; qs += ds * a.dt_sub;
+        T += (a.Lv_over_cp * (dl + dr) + a.Ls_over_cp * (di + ds)) * a.dt_sub;
+    }
+    out.dq_lcl[i] = (ql - ql0) * a.inv_dt; out.dq_icl[i] = (qi - qi0) * a.inv_dt;
+    out.dq_rai[i] = (qr - qr0) * a.inv_dt; out.dq_sno[i] = (qs - qs0) * a.inv_dt;
+}
+
 template <typename FT>
 __global__ __launch_bounds__(kBlock) void mp1m_sources_kernel(const Mp1mConsts<FT> c, const Mp1mIn<FT> in,
                                                               const Mp1mSrcOut<FT> out, const int64_t n) {
@@ -444,6 +527,28 @@ static int32_t tendencies_1m_entry(const MP *mp, const TH *tps, uint32_t flags, 
 }
 
 template <typename FT, typename MP, typename TH>
+static int32_t linearized_1m_entry(const MP *mp, const TH *tps, uint32_t flags, FT q_min, FT dt, int32_t nsub, int64_t n, const FT *rho,
+                                   const FT *T, const FT *q_tot, const FT *q_lcl, const FT *q_icl, const FT *q_rai, const FT *q_sno,
+                                   FT *dq_lcl, FT *dq_icl, FT *dq_rai, FT *dq_sno, void *stream) {
+    if (!mp || !tps || n < 0 || nsub < 1 || !(dt > FT(0)) || !(q_min >= FT(0))) return CMX_ERR_BAD_ARG;
+    if (const int32_t st = check_flags_1m(flags)) return st;
+    if (n == 0) return CMX_OK;
+    if (!rho || !T || !q_tot || !q_lcl || !q_icl || !q_rai || !q_sno || !dq_lcl || !dq_icl || !dq_rai || !dq_sno) return CMX_ERR_BAD_ARG;
+    const Mp1mConsts<FT> c = make_mp1m_consts<FT>(*mp, *tps, flags, (double)Math<FT>::eps_1m());
+    Mp1mLinArgs<FT> a{};
+    a.q_min = q_min; a.dt = dt; a.nsub = nsub;
+    a.dt_sub = dt / (FT)nsub;                       // Δt / FT(nsub), BMT:598
+    a.inv_dt_sub = FT(1) / a.dt_sub; a.inv_dt = FT(1) / dt;
+    a.Lv_over_cp = (FT)tps->LH_v0 / (FT)tps->cp_d; a.Ls_over_cp = (FT)tps->LH_s0 / (FT)tps->cp_d;
+    Mp1mIn<FT> in{rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno};
+    Mp1mOut<FT> out{dq_lcl, dq_icl, dq_rai, dq_sno};
+    hipLaunchKernelGGL((mp1m_linearized_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), c, a, in, out, n);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+
+template <typename FT, typename MP, typename TH>
 static int32_t sources_1m_entry(const MP *mp, const TH *tps, uint32_t flags, int64_t n, const FT *rho, const FT *T,
                                 const FT *q_tot, const FT *q_lcl, const FT *q_icl, const FT *q_rai, const FT *q_sno,
                                 FT *const out[CMX_MP1M_NSRC], void *stream) {
@@ -490,6 +595,21 @@ static int32_t velocity_1m_entry(const MP *mp, const CH *chen, int64_t n, const 
 }  // namespace cmx
 
 extern "C" {
+
+int32_t cmx_mp1m_linearized_average_f32(const cmx_microphysics_1m_f32 *mp, const cmx_thermo_f32 *tps, uint32_t flags, float q_min, float dt,
+                                        int32_t nsub, int64_t n, const float *rho, const float *T, const float *q_tot, const float *q_lcl,
+                                        const float *q_icl, const float *q_rai, const float *q_sno, float *dq_lcl_dt, float *dq_icl_dt,
+                                        float *dq_rai_dt, float *dq_sno_dt, void *stream) {
+    return cmx::linearized_1m_entry<float>(mp, tps, flags, q_min, dt, nsub, n, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno, dq_lcl_dt,
+                                           dq_icl_dt, dq_rai_dt, dq_sno_dt, stream);
+}
+int32_t cmx_mp1m_linearized_average_f64(const cmx_microphysics_1m_f64 *mp, const cmx_thermo_f64 *tps, uint32_t flags, double q_min,
+                                        double dt, int32_t nsub, int64_t n, const double *rho, const double *T, const double *q_tot,
+                                        const double *q_lcl, const double *q_icl, const double *q_rai, const double *q_sno,
+                                        double *dq_lcl_dt, double *dq_icl_dt, double *dq_rai_dt, double *dq_sno_dt, void *stream) {
+    return cmx::linearized_1m_entry<double>(mp, tps, flags, q_min, dt, nsub, n, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno, dq_lcl_dt,
+                                            dq_icl_dt, dq_rai_dt, dq_sno_dt, stream);
+}
 
 int32_t cmx_mp1m_tendencies_f32(const cmx_microphysics_1m_f32 *mp, const cmx_thermo_f32 *tps, uint32_t flags, int64_t n,
                                 const float *rho, const float *T, const float *q_tot, const float *q_lcl, const float *q_icl,

@@ -419,6 +419,20 @@ int32_t cmx_mp1m_tendencies_f64(const cmx_microphysics_1m_f64 *mp, const cmx_the
                                 double *dq_lcl_dt, double *dq_icl_dt, double *dq_rai_dt, double *dq_sno_dt,
                                 void *stream);
 
+/* bulk_microphysics_tendencies(LinearizedAverage(), Microphysics1Moment(), mp, tps, ρ, T, q_tot, q_lcl, q_icl, q_rai, q_sno,
+ * Δt, nsub) — src/BulkMicrophysicsTendencies.jl:572-632 (the mode ClimaAtmos runs operationally, :112-115): the average
+ * tendencies over Δt from `nsub` linearized implicit substeps (:381-465) of the donor-based linearization dq/dt ≈ M q + e
+ * (:269-379), with T updated from the latent heating of each substep.  q_min = TD.Parameters.q_min(tps) (the donor floor
+ * of the linearization).  Same flags (Microphysics1MOptions) as cmx_mp1m_tendencies_*. */
+int32_t cmx_mp1m_linearized_average_f32(const cmx_microphysics_1m_f32 *mp, const cmx_thermo_f32 *tps, uint32_t flags, float q_min,
+                                        float dt, int32_t nsub, int64_t n, const float *rho, const float *T, const float *q_tot,
+                                        const float *q_lcl, const float *q_icl, const float *q_rai, const float *q_sno,
+                                        float *dq_lcl_dt, float *dq_icl_dt, float *dq_rai_dt, float *dq_sno_dt, void *stream);
+int32_t cmx_mp1m_linearized_average_f64(const cmx_microphysics_1m_f64 *mp, const cmx_thermo_f64 *tps, uint32_t flags, double q_min,
+                                        double dt, int32_t nsub, int64_t n, const double *rho, const double *T, const double *q_tot,
+                                        const double *q_lcl, const double *q_icl, const double *q_rai, const double *q_sno,
+                                        double *dq_lcl_dt, double *dq_icl_dt, double *dq_rai_dt, double *dq_sno_dt, void *stream);
+
 /* The individual 1M source terms — `_microphysics_source_terms` (BMT:141-217), same inputs (clamped the
  * same way), `out` = host array of CMX_MP1M_NSRC device column pointers (NULL = skip). */
 typedef enum cmx_mp1m_source_column {

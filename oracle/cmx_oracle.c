@@ -27,6 +27,7 @@
 #define FT double
 #define SFX f64
 #define M_POW pow
+#define M_FMA fma
 #define M_EXP exp
 #define M_LOG log
 #define M_CBRT cbrt
@@ -52,6 +53,7 @@
 #undef FT
 #undef SFX
 #undef M_POW
+#undef M_FMA
 #undef M_EXP
 #undef M_LOG
 #undef M_CBRT
@@ -66,6 +68,7 @@
 #define FT float
 #define SFX f32
 #define M_POW powf
+#define M_FMA fmaf
 #define M_EXP expf
 #define M_LOG logf
 #define M_CBRT cbrtf

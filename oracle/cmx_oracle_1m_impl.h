@@ -364,6 +364,90 @@ void FN(cmxo_mp1m)(const TY(cmx_microphysics_1m) * mp, const TY(cmx_thermo) * tp
     }
 }
 
+/* ---- LinearizedAverage mode — src/BulkMicrophysicsTendencies.jl:255-465, 572-632 ------------------------------ */
+typedef struct TY(cmxo_lin_1m) { FT M11, M12, M22, M31, M33, M34, M41, M42, M43, M44, e1, e2, e4; } TY(cmxo_lin_1m);
+/* _linearize — :269-379 (donor-based: D = S / max(q_min, q_donor)) */
+static inline TY(cmxo_lin_1m) FN(o_linearize_1m)(const FT *S, FT q_lcl, FT q_icl, FT q_rai, FT q_sno, FT q_min) {
+    TY(cmxo_lin_1m) L = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const FT dl = FN(o_max)(q_min, q_lcl), di = FN(o_max)(q_min, q_icl), dr = FN(o_max)(q_min, q_rai), ds = FN(o_max)(q_min, q_sno);
+    FT D;
+    D = S[CMX_1M_S_PHASE_CHANGE_VAP_LCL] / dl;
+    if (S[CMX_1M_S_PHASE_CHANGE_VAP_LCL] >= 0) L.e1 += S[CMX_1M_S_PHASE_CHANGE_VAP_LCL]; else L.M11 += D;
+    D = S[CMX_1M_S_PHASE_CHANGE_VAP_ICL] / di;
+    if (S[CMX_1M_S_PHASE_CHANGE_VAP_ICL] >= 0) L.e2 += S[CMX_1M_S_PHASE_CHANGE_VAP_ICL]; else L.M22 += D;
+    D = S[CMX_1M_S_MELT_ICL_LCL] / di;          L.M22 -= D; L.M12 += D;
+    D = S[CMX_1M_S_ACNV_LCL_RAI] / dl;          L.M11 -= D; L.M31 += D;
+    D = S[CMX_1M_S_ACNV_ICL_SNO] / di;          L.M22 -= D; L.M42 += D;
+    D = S[CMX_1M_S_ACCR_LCL_RAI] / dl;          L.M11 -= D; L.M31 += D;
+    {
+        FT Dc = S[CMX_1M_S_ACCR_LCL_SNO_COLD] / dl, Dw = S[CMX_1M_S_ACCR_LCL_SNO_WARM] / dl;
+        L.M11 -= Dc + Dw; L.M31 += Dw; L.M41 += Dc;
+    }
+    D = S[CMX_1M_S_ACCR_MELT_LCL_SNO] / ds;     L.M44 -= D; L.M34 += D;
+    D = S[CMX_1M_S_ACCR_ICL_RAI] / di;          L.M22 -= D; L.M42 += D;
+    D = S[CMX_1M_S_ACCR_ICL_SNO] / di;          L.M22 -= D; L.M42 += D;
+    D = S[CMX_1M_S_ACCR_FREEZE_ICL_RAI] / dr;   L.M33 -= D; L.M43 += D;
+    D = S[CMX_1M_S_ACCR_RAI_SNO_WARM] / ds;     L.M44 -= D; L.M34 += D;
+    D = S[CMX_1M_S_ACCR_MELT_RAI_SNO] / ds;     L.M44 -= D; L.M34 += D;
+    D = S[CMX_1M_S_ACCR_RAI_SNO_COLD] / dr;     L.M33 -= D; L.M43 += D;
+    D = (-S[CMX_1M_S_PHASE_CHANGE_VAP_RAI]) / dr; L.M33 -= D;
+    D = S[CMX_1M_S_PHASE_CHANGE_VAP_SNO] / ds;
+    if (S[CMX_1M_S_PHASE_CHANGE_VAP_SNO] >= 0) L.e4 += S[CMX_1M_S_PHASE_CHANGE_VAP_SNO]; else L.M44 += D;
+    D = S[CMX_1M_S_MELT_SNO_RAI] / ds;          L.M44 -= D; L.M34 += D;
+    return L;
+}
+/* _linearized_implicit_step — :381-465; out = (dq_lcl_dt, dq_icl_dt, dq_rai_dt, dq_sno_dt) */
+static inline void FN(o_linearized_implicit_step_1m)(const TY(cmx_microphysics_1m) * mp, const TY(cmx_thermo) * tps, uint32_t flags,
+                                                    const TY(cmxo_thresholds) * th, FT q_min, FT rho, FT T, FT q_tot, FT q_lcl, FT q_icl,
+                                                    FT q_rai, FT q_sno, FT dt, FT out[4]) {
+    TY(cmxo_src_1m) src = FN(o_source_terms_1m)(mp, tps, flags, th, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno);
+    TY(cmxo_lin_1m) L = FN(o_linearize_1m)(src.s, q_lcl, q_icl, q_rai, q_sno, q_min);
+    const FT inv_dt = 1 / dt;
+    const FT q_sat_min = FN(o_min)(FN(o_psat_liquid)(tps, T) / (rho * tps->R_v * T), FN(o_psat_ice)(tps, T) / (rho * tps->R_v * T));
+    const FT q_v = q_tot - q_lcl - q_icl - q_rai - q_sno;
+    const FT alpha = FN(o_min)((FT)1, FN(o_max)((FT)0, q_v - q_sat_min) * inv_dt / FN(o_max)(L.e1 + L.e2 + L.e4, th->eps_ft));
+    const FT a11 = inv_dt - L.M11, a12 = -L.M12, a22 = inv_dt - L.M22, a31 = -L.M31, a33 = inv_dt - L.M33, a34 = -L.M34;
+    const FT a41 = -L.M41, a42 = -L.M42, a43 = -L.M43, a44 = inv_dt - L.M44;
+    const FT b1 = alpha * L.e1 + inv_dt * q_lcl, b2 = alpha * L.e2 + inv_dt * q_icl, b3 = inv_dt * q_rai, b4 = alpha * L.e4 + inv_dt * q_sno;
+    const FT det12 = a11 * a22;
+    const FT q_lcl_new = (b1 * a22 - a12 * b2) / det12, q_icl_new = a11 * b2 / det12;
+    const FT r3 = M_FMA(-a31, q_lcl_new, b3);
+    const FT r4 = M_FMA(-a41, q_lcl_new, M_FMA(-a42, q_icl_new, b4));
+    const FT det = M_FMA(-a34, a43, a33 * a44);
+    const FT q_rai_new = (r3 * a44 - a34 * r4) / det, q_sno_new = (a33 * r4 - r3 * a43) / det;
+    out[0] = (q_lcl_new - q_lcl) * inv_dt; out[1] = (q_icl_new - q_icl) * inv_dt;
+    out[2] = (q_rai_new - q_rai) * inv_dt; out[3] = (q_sno_new - q_sno) * inv_dt;
+}
+/* bulk_microphysics_tendencies(::LinearizedAverage, …, Δt, nsub) — :572-632; oracle twin of cmx_mp1m_linearized_average_* */
+void FN(cmxo_mp1m_linearized_average)(const TY(cmx_microphysics_1m) * mp, const TY(cmx_thermo) * tps, uint32_t flags,
+                                     const TY(cmxo_thresholds) * th, FT q_min, FT dt, int32_t nsub, int64_t n, const FT *rho,
+                                     const FT *T, const FT *q_tot, const FT *q_lcl, const FT *q_icl, const FT *q_rai,
+                                     const FT *q_sno, FT *const *tend, int32_t nthreads) {
+    (void)nthreads;
+    const FT dt_sub = dt / (FT)nsub;
+    const FT Lv_over_cp = tps->LH_v0 / tps->cp_d, Ls_over_cp = tps->LH_s0 / tps->cp_d;
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+    for (int64_t i = 0; i < n; ++i) {
+        FT Ti = T[i], ql = q_lcl[i], qi = q_icl[i], qr = q_rai[i], qs = q_sno[i];
+        for (int k = 0; k < nsub; ++k) {
+            FT r[4];
+            FN(o_linearized_implicit_step_1m)(mp, tps, flags, th, q_min, rho[i], Ti, q_tot[i], ql, qi, qr, qs, dt_sub, r);
+            ql += r[0] * dt_sub; qi += r[1] * dt_sub; qr += r[2] * dt_sub; qs += r[3] * dt_sub;
+            Ti += (Lv_over_cp * (r[0] + r[2]) + Ls_over_cp * (r[1] + r[3])) * dt_sub;
+        }
+        tend[0][i] = (ql - q_lcl[i]) / dt; tend[1][i] = (qi - q_icl[i]) / dt;
+        tend[2][i] = (qr - q_rai[i]) / dt; tend[3][i] = (qs - q_sno[i]) / dt;
+    }
+}
+/* probe for the reference's "solves the linearized system" test (test/bulk_tendencies_tests.jl:850-882): M and e */
+void FN(cmxo_mp1m_linearize)(const TY(cmx_microphysics_1m) * mp, const TY(cmx_thermo) * tps, uint32_t flags, const TY(cmxo_thresholds) * th,
+                            FT q_min, FT rho, FT T, FT q_tot, FT q_lcl, FT q_icl, FT q_rai, FT q_sno, FT out[13]) {
+    TY(cmxo_src_1m) src = FN(o_source_terms_1m)(mp, tps, flags, th, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno);
+    TY(cmxo_lin_1m) L = FN(o_linearize_1m)(src.s, q_lcl, q_icl, q_rai, q_sno, q_min);
+    const FT v[13] = {L.M11, L.M12, L.M22, L.M31, L.M33, L.M34, L.M41, L.M42, L.M43, L.M44, L.e1, L.e2, L.e4};
+    for (int k = 0; k < 13; ++k) out[k] = v[k];
+}
+
 /* oracle twin of cmx_mp1m_terminal_velocity_* */
 void FN(cmxo_mp1m_terminal_velocity)(const TY(cmx_microphysics_1m) * mp, const TY(cmx_chen2022_rain_vel) * chen,
                                     const TY(cmxo_thresholds) * th, int64_t n, const FT *rho, const FT *q_rai,

@@ -166,6 +166,35 @@ def mp1m(fam, mp, tps, flags, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno, *, floa
     return out
 
 
+def mp1m_linearized_average(fam, mp, tps, flags, q_min, dt, nsub, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno, *, float32_gates=None,
+                            nthreads=1):
+    """Oracle twin of cmx_mp1m_linearized_average_*: dict of the 4 average tendencies."""
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    ins = [_col(fam, a) for a in (rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno)]
+    n = ins[0][0].size
+    tn = ["dq_lcl_dt", "dq_icl_dt", "dq_rai_dt", "dq_sno_dt"]
+    tend = [np.empty(n, dtype=NP[fam.sfx]) for _ in tn]
+    fn = getattr(lib(), f"cmxo_mp1m_linearized_average_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(mp), C.byref(tps), C.c_uint32(flags), C.byref(th), fam.ft(q_min), fam.ft(dt), C.c_int32(nsub), C.c_int64(n),
+       *[p for _, p in ins], (C.c_void_p * 4)(*[c.ctypes.data for c in tend]), C.c_int32(nthreads))
+    return dict(zip(tn, tend))
+
+
+def mp1m_linearize(fam, mp, tps, flags, q_min, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno, float32_gates=None):
+    """(M11, M12, M22, M31, M33, M34, M41, M42, M43, M44, e1, e2, e4) of BMT._linearize at one state."""
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    out = (fam.ft * 13)()
+    fn = getattr(lib(), f"cmxo_mp1m_linearize_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(mp), C.byref(tps), C.c_uint32(flags), C.byref(th), *[fam.ft(v) for v in (q_min, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno)], out)
+    return dict(zip(("M11", "M12", "M22", "M31", "M33", "M34", "M41", "M42", "M43", "M44", "e1", "e2", "e4"), list(out)))
+
+
 def mp1m_terminal_velocity(fam, mp, chen, rho, q_rai, q_sno, float32_gates=None):
     if float32_gates is None:
         float32_gates = fam.sfx == "f32"

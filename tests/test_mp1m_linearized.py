@@ -1,0 +1,167 @@
+"""1-moment LinearizedAverage mode (BMT:255-465, 572-632): the reference's own property tests
+(test/bulk_tendencies_tests.jl:840-1150) re-stated on the oracle (CPU) and, marked gpu, through the C ABI, plus
+random-state parity of the HIP kernel against the oracle."""
+import numpy as np
+import pytest
+
+from cmx import _abi
+from cmx import parameters as P
+
+F64 = _abi.F64
+T_FREEZE = P.DEFAULT_PARAMETERS["temperature_water_freeze"]
+Q_MIN = P.DEFAULT_PARAMETERS["specific_humidity_minimum"]
+NAMES = ("dq_lcl_dt", "dq_icl_dt", "dq_rai_dt", "dq_sno_dt")
+
+
+def _lin(oracle, mp, state, dt, nsub=1, fam=F64):
+    cols = [np.atleast_1d(np.asarray(v, dtype=np.float64)) for v in state]
+    tps = P.ThermodynamicsParameters(fam.sfx)
+    return oracle.mp1m_linearized_average(fam, mp.c, tps, mp.flags, Q_MIN, dt, nsub, *cols)
+
+
+def _inst(oracle, mp, state):
+    cols = [np.atleast_1d(np.asarray(v, dtype=np.float64)) for v in state]
+    return oracle.mp1m(F64, mp.c, P.ThermodynamicsParameters("f64"), mp.flags, *cols, want_sources=False)
+
+
+def _q_sat(oracle, T, rho, ice=False):
+    tps = P.ThermodynamicsParameters("f64")
+    ps = oracle.psat_ice(F64, tps, T) if ice else oracle.psat_liquid(F64, tps, T)
+    return ps / (rho * tps.R_v * T)
+
+
+def test_implicit_step_solves_the_linearized_system(oracle):
+    """(q* − q⁰)/Δt = M q* + e row by row — test/bulk_tendencies_tests.jl:850-882 (α = 1 in this state)."""
+    mp = P.Microphysics1MParams("f64")
+    rho, T, q_tot, q = 1.2, T_FREEZE + 3.0, 0.02, (5e-4, 2e-4, 3e-4, 4e-4)
+    dt = 5.0
+    t = _lin(oracle, mp, (rho, T, q_tot, *q), dt)
+    L = oracle.mp1m_linearize(F64, mp.c, P.ThermodynamicsParameters("f64"), mp.flags, Q_MIN, rho, T, q_tot, *q)
+    new = [q[k] + dt * t[NAMES[k]][0] for k in range(4)]
+    alpha = min(1.0, max(0.0, q_tot - sum(q) - min(_q_sat(oracle, T, rho), _q_sat(oracle, T, rho, True))) / dt
+                / max(L["e1"] + L["e2"] + L["e4"], np.finfo(float).eps))
+    tol = 100 * np.finfo(float).eps
+    assert abs(t["dq_lcl_dt"][0] - (L["M11"] * new[0] + L["M12"] * new[1] + alpha * L["e1"])) <= tol
+    assert abs(t["dq_icl_dt"][0] - (L["M22"] * new[1] + alpha * L["e2"])) <= tol
+    assert abs(t["dq_rai_dt"][0] - (L["M31"] * new[0] + L["M33"] * new[2] + L["M34"] * new[3])) <= tol
+    assert abs(t["dq_sno_dt"][0] - (L["M41"] * new[0] + L["M42"] * new[1] + L["M43"] * new[2] + L["M44"] * new[3] + alpha * L["e4"])) <= tol
+
+
+@pytest.mark.parametrize("dT,q", [(5.0, (5e-4, 2e-4, 3e-4, 3e-4)), (-10.0, (3e-4, 5e-4, 2e-4, 4e-4))])
+def test_small_dt_agrees_with_instantaneous(oracle, dT, q):
+    """test/bulk_tendencies_tests.jl:919-977 (all species, warm and cold)."""
+    mp = P.Microphysics1MParams("f64")
+    state = (1.2, T_FREEZE + dT, 0.012, *q)
+    inst, lin = _inst(oracle, mp, state), _lin(oracle, mp, state, 1e-2)
+    for k in NAMES:
+        assert lin[k][0] == pytest.approx(inst[k][0], rel=5e-2), k
+
+
+def test_reference_property_tests(oracle):
+    mp = P.Microphysics1MParams("f64")
+    # finiteness (:979-999), all-zero inputs (:1020-1040)
+    t = _lin(oracle, mp, (1.2, T_FREEZE - 5, 0.015, 5e-4, 5e-4, 5e-4, 5e-4), 10.0)
+    assert all(np.isfinite(t[k][0]) for k in NAMES)
+    t = _lin(oracle, mp, (1.2, T_FREEZE + 5, 0.0, 0.0, 0.0, 0.0, 0.0), 10.0)
+    assert all(t[k][0] == 0 for k in NAMES)
+    # warm pure snow melt keeps the expected signs (:1070-1091)
+    rho, T = 1.0, T_FREEZE + 5
+    t = _lin(oracle, mp, (rho, T, _q_sat(oracle, T, rho, True) + 1e-3, 0.0, 0.0, 0.0, 1e-3), 10.0)
+    assert t["dq_sno_dt"][0] < 0 < t["dq_rai_dt"][0]
+    # more substeps do not change a simple rain-only case much (:1093-1124); small Δt → instantaneous (:884-917)
+    rho, T = 1.2, T_FREEZE + 15
+    qs = _q_sat(oracle, T, rho)
+    state = (rho, T, 0.5 * qs + 1e-3, 0.0, 0.0, 1e-3, 0.0)
+    t1, t10 = _lin(oracle, mp, state, 1.0, 1), _lin(oracle, mp, state, 1.0, 10)
+    for k in ("dq_lcl_dt", "dq_icl_dt", "dq_sno_dt"):
+        assert abs(t10[k][0] - t1[k][0]) <= 1e-10
+    assert t10["dq_rai_dt"][0] == pytest.approx(t1["dq_rai_dt"][0], rel=1e-2)
+    inst, avg = _inst(oracle, mp, state), _lin(oracle, mp, state, 1e-2)
+    assert avg["dq_rai_dt"][0] == pytest.approx(inst["dq_rai_dt"][0], rel=1e-3)
+    # substepping remains finite near freezing (:1126-1147)
+    t = _lin(oracle, mp, (1.2, T_FREEZE + 0.01, 0.015, 1e-3, 0.0, 0.0, 5e-4), 20.0, 20)
+    assert all(np.isfinite(t[k][0]) for k in NAMES)
+
+
+def _random_state(n, seed=11):
+    rng = np.random.default_rng(seed)
+    rho, T = rng.uniform(0.3, 1.3, n), rng.uniform(235, 300, n)
+    q = lambda: np.where(rng.random(n) < 0.25, 0.0, 10 ** rng.uniform(-7, -2.7, n))  # noqa: E731
+    q_lcl, q_icl, q_rai, q_sno = q(), q(), q(), q()
+    q_tot = q_lcl + q_icl + q_rai + q_sno + 10 ** rng.uniform(-5, -1.8, n)
+    return rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno
+
+
+def test_mass_budget_and_nonnegativity_on_random_states(oracle):
+    """Properties of the implicit solve: hydrometeors stay non-negative after the step (A is an M-matrix with
+    non-negative right-hand side), and the condensate gained never exceeds the vapour above saturation (α cap)."""
+    mp = P.Microphysics1MParams("f64")
+    st = _random_state(20000)
+    dt = 30.0
+    t = _lin(oracle, mp, st, dt, 3)
+    for k, q0 in zip(NAMES, st[3:]):
+        assert np.all(np.isfinite(t[k]))
+        assert np.all(q0 + dt * t[k] >= -1e-18), k
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+@pytest.mark.parametrize("dt,nsub", [(1e-2, 1), (20.0, 1), (60.0, 4)])
+def test_gpu_parity_with_the_oracle(oracle, ft, dt, nsub):
+    import torch
+
+    import cmx
+    dev = torch.device("cuda:0")
+    dtype = {"f32": torch.float32, "f64": torch.float64}[ft]
+    n = 200_003
+    st = [torch.from_numpy(c).to(dtype) for c in _random_state(n, seed=21)]
+    mp, tps = P.Microphysics1MParams(ft), P.ThermodynamicsParameters(ft)
+    got = cmx.bulk_microphysics_tendencies_1m(cmx.LinearizedAverage(), cmx.Microphysics1Moment(), mp, tps, *[c.to(dev) for c in st], dt, nsub)
+    torch.cuda.synchronize()
+    c64 = [c.numpy().astype(np.float64) for c in st]
+    mp64 = P.Microphysics1MParams("f64")
+    ref = oracle.mp1m_linearized_average(F64, mp64.c, P.ThermodynamicsParameters("f64"), mp64.flags, Q_MIN, dt, nsub, *c64,
+                                         float32_gates=(ft == "f32"), nthreads=8)
+    # the result is (q_new − q_old)/Δt: its natural scale is max(|tendency|, q_old/Δt) (for small Δt the difference of two
+    # nearly equal specific contents carries eps·q/Δt of rounding — the reference's own remark, bulk_tendencies_tests.jl:924-926);
+    # states within 1e-4 K of T_freeze may route warm/cold differently in another precision (genuine discontinuity)
+    near = np.abs(c64[1] - T_FREEZE) < (1e-3 if ft == "f32" else 1e-9)
+    rtol, eps = {"f64": (1e-6, 2.2e-16), "f32": (1e-3, 1.2e-7)}[ft]
+    worst = {}
+    for k, q0 in zip(NAMES, c64[3:]):
+        x, r = got._asdict()[k].cpu().numpy().astype(np.float64), ref[k]
+        assert np.all(np.isfinite(x)), k
+        scale = np.maximum(np.abs(r), 64 * eps * (q0 + np.abs(r) * dt) / dt)
+        e = (np.abs(x - r) / np.maximum(scale, 1e-300))[~near]
+        worst[k] = float(e.max())
+        assert worst[k] <= rtol * (10 if ft == "f32" else 1), (k, worst)
+    print(f"\n[1M LinearizedAverage parity] {ft} dt={dt} nsub={nsub}: {worst} (excluded near T_freeze: {int(near.sum())})")
+
+
+@pytest.mark.gpu
+def test_gpu_reference_properties_and_errors():
+    import torch
+
+    import cmx
+    dev = torch.device("cuda:0")
+    mp, tps = P.Microphysics1MParams("f64"), P.ThermodynamicsParameters("f64")
+    mode, scheme = cmx.LinearizedAverage(), cmx.Microphysics1Moment()
+    col = lambda *v: [torch.tensor([x], dtype=torch.float64, device=dev) for x in v]  # noqa: E731
+    t = cmx.bulk_microphysics_tendencies_1m(mode, scheme, mp, tps, *col(1.2, T_FREEZE + 5, 0.0, 0.0, 0.0, 0.0, 0.0), 10.0)
+    assert all(float(c) == 0.0 for c in t)
+    state = col(1.2, T_FREEZE + 5.0, 0.012, 5e-4, 2e-4, 3e-4, 3e-4)
+    inst = cmx.bulk_microphysics_tendencies_1m(cmx.Instantaneous(), scheme, mp, tps, *state)
+    lin = cmx.bulk_microphysics_tendencies_1m(mode, scheme, mp, tps, *state, 1e-2)
+    for a, b in zip(lin, inst):
+        assert float(a) == pytest.approx(float(b), rel=5e-2)
+    t = cmx.bulk_microphysics_tendencies_1m(mode, scheme, mp, tps, *col(1.2, T_FREEZE + 0.01, 0.015, 1e-3, 0.0, 0.0, 5e-4), 20.0, 20)
+    assert all(np.isfinite(float(c)) for c in t)
+    with pytest.raises(ValueError):
+        cmx.bulk_microphysics_tendencies_1m(mode, scheme, mp, tps, *state)            # dt missing
+    with pytest.raises(TypeError):
+        cmx.bulk_microphysics_tendencies_1m(cmx.Instantaneous(), scheme, mp, tps, *state, 1.0)
+    lib = cmx._lib.lib()
+    import ctypes as C
+    assert lib.cmx_mp1m_linearized_average_f64(C.byref(mp.c), C.byref(tps), mp.flags, 1e-10, -1.0, 1, 1, *[None] * 11, None) == _abi.CMX_ERR_BAD_ARG
+    assert lib.cmx_mp1m_linearized_average_f64(C.byref(mp.c), C.byref(tps), mp.flags, 1e-10, 1.0, 0, 1, *[None] * 11, None) == _abi.CMX_ERR_BAD_ARG
