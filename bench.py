@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=100_000_000, help="grid points per GPU")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--workload", choices=["sb2006", "icenuc", "mp1m", "arg2000", "p3"], default="sb2006")
+    ap.add_argument("--workload", choices=["sb2006", "icenuc", "mp1m", "mp1m_lin", "arg2000", "p3"], default="sb2006")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the bounded baseline sample")
     ap.add_argument("--diagnostics", action="store_true",
@@ -167,6 +167,38 @@ def setup_mp1m(args, dev, dtype, rank):
     return list(state), step, desc, cpu_run
 
 
+def setup_mp1m_lin(args, dev, dtype, rank):
+    """1-moment LinearizedAverage mode (the mode ClimaAtmos runs operationally, BMT:112-115): Δt = 30 s, nsub = 2."""
+    import torch
+
+    import cmx
+    from cmx import _abi
+    from cmx import parameters as P
+    from cmx import synthetic
+    state = synthetic.mp1m_state(args.points, dtype=dtype, device=dev, seed=1234 + rank)
+    mp, tps = P.Microphysics1MParams(args.dtype), P.ThermodynamicsParameters(args.dtype)
+    out = cmx.Tendencies1M(*[torch.empty_like(state.rho) for _ in range(4)])
+    mode, scheme = cmx.LinearizedAverage(), cmx.Microphysics1Moment()
+    dt, nsub, q_min = 30.0, 2, P.DEFAULT_PARAMETERS["specific_humidity_minimum"]
+
+    def step():
+        cmx.bulk_microphysics_tendencies_1m(mode, scheme, mp, tps, *state, dt, nsub, out=out)
+
+    def cpu_run(ob, cols, threads):
+        fam = _abi.family(args.dtype)
+        return lambda: ob.mp1m_linearized_average(fam, mp.c, tps, mp.flags, q_min, dt, nsub, *cols, nthreads=threads)
+
+    desc = {
+        "metric": "grid-points/sec 1-moment LinearizedAverage tendency sweep (dt = 30 s, nsub = 2)",
+        "bytes_per_point": {"f32": 44, "f64": 88}[args.dtype],      # 7 in + 4 out
+        "kernel": "mp1m_linearized_kernel",
+        "workload": "Microphysics1M LinearizedAverage bulk tendencies: 2 linearized implicit substeps (13 processes, 4x4 sparse solve, "
+                    "T update) per point",
+        "columns_in": 7, "columns_out": 4, "diag_cols": list(out),
+    }
+    return list(state), step, desc, cpu_run
+
+
 def setup_arg2000(args, dev, dtype, rank):
     import torch
 
@@ -276,7 +308,7 @@ def main():
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     n = args.points                                          # weak scaling: fixed work per GPU
     # rank r owns shard r of the global [0, world·n) index space: disjoint seeds, no exchange
-    setup = {"sb2006": setup_sb2006, "icenuc": setup_icenuc, "mp1m": setup_mp1m, "arg2000": setup_arg2000,
+    setup = {"sb2006": setup_sb2006, "icenuc": setup_icenuc, "mp1m": setup_mp1m, "mp1m_lin": setup_mp1m_lin, "arg2000": setup_arg2000,
              "p3": setup_p3}[args.workload]
     state, kernel_step, desc, cpu_run = setup(args, dev, dtype, rank)
 
