@@ -90,6 +90,7 @@ def _family(ft, sfx):
     ns.rain_pdf_sb2006 = _struct(f"cmx_rain_pdf_sb2006_{sfx}",
                                  s("nu_r", "mu_r", "xr_min", "xr_max", "N0_min", "N0_max",
                                    "lambda_min", "lambda_max", "rho_w", "rho_0"))
+    ns.stokes_vel = _struct(f"cmx_stokes_vel_{sfx}", s("rho_w", "nu_air", "grav"))
     ns.acnv_sb2006 = _struct(f"cmx_acnv_sb2006_{sfx}", s("kcc", "x_star", "rho_0", "A", "a", "b"))
     ns.accr_sb2006 = _struct(f"cmx_accr_sb2006_{sfx}", s("kcr", "tau_0", "rho_0", "c"))
     ns.selfcol_sb2006 = _struct(f"cmx_selfcol_sb2006_{sfx}", s("krr", "kappa_rr", "d"))

@@ -160,3 +160,25 @@ def column_sums(cols, stream=None) -> torch.Tensor:
         st = fn(len(cols), arr, ref.numel(), _ptr(sums), C.c_void_p(s.cuda_stream))
     _lib.check(fn.__name__, st)
     return sums
+
+
+CloudTerminalVelocity = namedtuple("CloudTerminalVelocity", ["vt_n", "vt_m"])
+
+
+def cloud_terminal_velocity(pdf_c, vel, q_liq, rho, N_liq, *, stream=None) -> CloudTerminalVelocity:
+    """`CM2.cloud_terminal_velocity.(Ref(pdf_c), Ref(vel), q_liq, ρₐ, N_liq)` (src/Microphysics2M.jl:647-664): number- and
+    mass-weighted mean fall speeds of the cloud droplets; `pdf_c` = SB2006(FT).pdf_c, `vel` = StokesRegimeVelType(FT);
+    N_liq per m³."""
+    cols = (q_liq, rho, N_liq)
+    ref = _check_cols(cols, ("q_liq", "rho", "N_liq"))
+    fam = _fam_of(ref)
+    if not isinstance(pdf_c, fam.cloud_pdf_sb2006) or not isinstance(vel, fam.stokes_vel):
+        raise TypeError("parameter float type does not match the state columns")
+    out = CloudTerminalVelocity(torch.empty_like(ref), torch.empty_like(ref))
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_sb2006_cloud_terminal_velocity_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(pdf_c), C.byref(vel), ref.numel(), *[_ptr(t) for t in cols], _ptr(out.vt_n), _ptr(out.vt_m),
+                C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return out

@@ -238,6 +238,13 @@ def ThermodynamicsParameters(FT):
         cv_l=td["isochoric_specific_heat_liquid"])
 
 
+def StokesRegimeVelType(FT):
+    """CMP.StokesRegimeVelType(FT) — src/parameters/TerminalVelocity.jl:150-164."""
+    td = _td(FT)
+    return td.fam.stokes_vel(rho_w=td["density_liquid_water"], nu_air=td["kinematic_viscosity_of_air"],
+                             grav=td["gravitational_acceleration"])
+
+
 def AirProperties(FT):
     """CMP.AirProperties — src/parameters/AirProperties.jl:11-30."""
     td = _td(FT)

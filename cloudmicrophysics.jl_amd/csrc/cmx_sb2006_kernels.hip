@@ -17,7 +17,10 @@ static int decode_vel(uint32_t flags, bool want) {
     return sb ? VEL_SB : VEL_CHEN;
 }
 
-constexpr int kTendBS = 256;
+#ifndef CMX_TEND_BS
+#define CMX_TEND_BS 256
+#endif
+constexpr int kTendBS = CMX_TEND_BS;   // lanes per workgroup of the fused tendency kernel (tuning: -DCMX_TEND_BS=128|512)
 
 template <typename FT, int VEC>
 static void launch_tendencies(bool limited, int vel, const SbConsts<FT> &c, const SbIn<FT> &in, const SbOut<FT> &out,
@@ -119,9 +122,60 @@ static int32_t process_entry(const WR *wr, const TH *tps, const VL *vel, uint32_
     return CMX_OK;
 }
 
+// CM2.cloud_terminal_velocity — Microphysics2M.jl:647-664.  With B = (x̄ Γ(z₁)/Γ(z₂))^(−μ) (log_pdf_cloud_parameters_mass
+// :174-192) the two moments collapse to one power of the mean droplet mass x̄ = ρq/N:
+//   vt_n = pref·K₂₃·x̄^(2/3),  vt_m = pref·K₅₃·x̄^(5/3)·N/(ρq) = pref·K₅₃·x̄^(2/3),
+// K_n = (Γ(z₁)/Γ(z₂))^n · Γ(z₁ + n/μ)/Γ(z₁) parameter-only (host, double).  20 B/point (f32), one point per lane.
+template <typename FT> struct CloudVelConsts { FT pre_c, rho_w, K23, K53; };
+template <typename FT>
+__global__ __launch_bounds__(kBlock) void sb2006_cloud_velocity_kernel(const CloudVelConsts<FT> c, const FT *__restrict__ q_liq,
+                                                                       const FT *__restrict__ rho, const FT *__restrict__ N_liq,
+                                                                       FT *__restrict__ vt_n, FT *__restrict__ vt_m, const int64_t n) {
+    using M = Math<FT>;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const FT q = q_liq[i], r = rho[i], N = N_liq[i];
+    const FT sq = M::max(q, M::eps()), sN = M::max(N, M::eps());
+    const FT x23 = M::exp2(FT(2.0 / 3.0) * M::log2(r * sq * M::rcp(sN)));
+    const FT pref = c.pre_c * (c.rho_w * M::rcp(r) - FT(1));
+    const bool none = N < M::eps() || q < M::eps();
+    if (vt_n) vt_n[i] = none ? FT(0) : pref * c.K23 * x23;
+    if (vt_m) vt_m[i] = none ? FT(0) : pref * c.K53 * x23;
+}
+
+template <typename FT, typename PDF, typename VEL>
+static int32_t cloud_velocity_entry(const PDF *pdf, const VEL *vel, int64_t n, const FT *q_liq, const FT *rho, const FT *N_liq, FT *vt_n,
+                                    FT *vt_m, void *stream) {
+    if (!pdf || !vel || n < 0) return CMX_ERR_BAD_ARG;
+    if (n == 0) return CMX_OK;
+    if (!q_liq || !rho || !N_liq) return CMX_ERR_BAD_ARG;
+    const double pi = 3.14159265358979323846, nu = pdf->nu_c, mu = pdf->mu_c, z1 = (nu + 1.0) / mu;
+    const double dlg = (double)pdf->loggamma_z1 - (double)pdf->loggamma_z2;   // log Γ(z₁)/Γ(z₂)
+    CloudVelConsts<FT> c;
+    c.rho_w = (FT)vel->rho_w;
+    c.pre_c = (FT)(1.0 / 18.0 * std::cbrt(std::pow(6.0 / (double)vel->rho_w / pi, 2.0)) * (double)vel->grav / (double)vel->nu_air);
+    c.K23 = (FT)std::exp(2.0 / 3.0 * dlg + std::lgamma(z1 + 2.0 / 3.0 / mu) - std::lgamma(z1));
+    c.K53 = (FT)std::exp(5.0 / 3.0 * dlg + std::lgamma(z1 + 5.0 / 3.0 / mu) - std::lgamma(z1));
+    hipLaunchKernelGGL((sb2006_cloud_velocity_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), c, q_liq, rho, N_liq, vt_n, vt_m, n);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+
 }  // namespace cmx
 
 extern "C" {
+
+int32_t cmx_sb2006_cloud_terminal_velocity_f32(const cmx_cloud_pdf_sb2006_f32 *pdf_c, const cmx_stokes_vel_f32 *vel, int64_t n,
+                                               const float *q_liq, const float *rho, const float *N_liq, float *vt_n, float *vt_m,
+                                               void *stream) {
+    return cmx::cloud_velocity_entry<float>(pdf_c, vel, n, q_liq, rho, N_liq, vt_n, vt_m, stream);
+}
+int32_t cmx_sb2006_cloud_terminal_velocity_f64(const cmx_cloud_pdf_sb2006_f64 *pdf_c, const cmx_stokes_vel_f64 *vel, int64_t n,
+                                               const double *q_liq, const double *rho, const double *N_liq, double *vt_n, double *vt_m,
+                                               void *stream) {
+    return cmx::cloud_velocity_entry<double>(pdf_c, vel, n, q_liq, rho, N_liq, vt_n, vt_m, stream);
+}
 
 int32_t cmx_sb2006_warm_rain_tendencies_f32(const cmx_warm_rain_2m_f32 *warm_rain, const cmx_thermo_f32 *tps,
                                             const cmx_rain_vel_f32 *vel, uint32_t flags, int64_t n, const float *rho,

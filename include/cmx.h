@@ -117,6 +117,8 @@ typedef enum cmx_status {
         FT R_v, R_d, cp_d, cp_v, cp_l, cp_i, LH_v0, LH_s0, T_0, T_triple, press_triple,        \
             T_freeze, cv_l;                                                                    \
     } cmx_thermo_##SFX;                                                                        \
+    /* StokesRegimeVelType — src/parameters/TerminalVelocity.jl:150-154 */                     \
+    typedef struct cmx_stokes_vel_##SFX { FT rho_w, nu_air, grav; } cmx_stokes_vel_##SFX;      \
     /* SB2006VelType — src/parameters/TerminalVelocity.jl:174-182 */                           \
     typedef struct cmx_sb2006_vel_##SFX { FT rho_0, aR, bR, cR, rho_w, nu_air, grav; }         \
         cmx_sb2006_vel_##SFX;                                                                  \
@@ -328,6 +330,16 @@ int32_t cmx_sb2006_process_rates_f64(
     const double *q_tot, const double *q_lcl, const double *q_rai, const double *N_lcl,
     const double *N_rai, const double *rho, const double *T,
     double *const out[CMX_SB2006_NPROC], void *stream);
+
+/* CM2.cloud_terminal_velocity(pdf_c, vel::StokesRegimeVelType, q_liq, ρₐ, N_liq) — src/Microphysics2M.jl:647-664:
+ * number- and mass-weighted mean fall speeds of the cloud droplets (Stokes regime, generalized-gamma PSD moments
+ * M^{2/3}, M^{5/3}; DistributionTools.jl:109-112).  N_liq is per m³ as in the reference.  Either output may be NULL. */
+int32_t cmx_sb2006_cloud_terminal_velocity_f32(const cmx_cloud_pdf_sb2006_f32 *pdf_c, const cmx_stokes_vel_f32 *vel, int64_t n,
+                                               const float *q_liq, const float *rho, const float *N_liq, float *vt_n, float *vt_m,
+                                               void *stream);
+int32_t cmx_sb2006_cloud_terminal_velocity_f64(const cmx_cloud_pdf_sb2006_f64 *pdf_c, const cmx_stokes_vel_f64 *vel, int64_t n,
+                                               const double *q_liq, const double *rho, const double *N_liq, double *vt_n, double *vt_m,
+                                               void *stream);
 
 /* ---------------------------------------------------------------------------
  * (4) Ice nucleation rates — ABIFM immersion freezing + Koop-2000 homogeneous freezing.

@@ -699,6 +699,13 @@ void FN(cmxo_chen2022_rain_coeffs)(const TY(cmx_chen2022_rain_vel) * c, FT rho, 
     FN(o_chen2022_rain_coeffs)(c, rho, out, out + 3, out + 6);
 }
 
+/* oracle twin of cmx_sb2006_cloud_terminal_velocity_* (CM2.cloud_terminal_velocity, src/Microphysics2M.jl:647-664) */
+void FN(cmxo_sb2006_cloud_terminal_velocity)(const TY(cmx_cloud_pdf_sb2006) * pdf, const TY(cmx_stokes_vel) * v, const TY(cmxo_thresholds) * th,
+                                            int64_t n, const FT *q_liq, const FT *rho, const FT *N_liq, FT *vt0, FT *vt1) {
+    for (int64_t i = 0; i < n; ++i)
+        FN(o_cloud_terminal_velocity)(pdf, v->rho_w, v->grav, v->nu_air, q_liq[i], rho[i], N_liq[i], th, &vt0[i], &vt1[i]);
+}
+
 #include "cmx_oracle_1m_impl.h"
 #include "cmx_oracle_arg_impl.h"
 #include "cmx_oracle_p3_impl.h"

@@ -349,6 +349,21 @@ def cloud_terminal_velocity(fam, pdf_c, rho_w, grav, nu_air, q_liq, rho, N_liq, 
     return out[0], out[1]
 
 
+def sb2006_cloud_terminal_velocity(fam, pdf_c, vel, q_liq, rho, N_liq, float32_gates=None):
+    """Oracle twin of cmx_sb2006_cloud_terminal_velocity_*: (vt_n, vt_m) columns."""
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    ins = [_col(fam, a) for a in (q_liq, rho, N_liq)]
+    n = ins[0][0].size
+    v0, v1 = np.empty(n, dtype=NP[fam.sfx]), np.empty(n, dtype=NP[fam.sfx])
+    fn = getattr(lib(), f"cmxo_sb2006_cloud_terminal_velocity_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(pdf_c), C.byref(vel), C.byref(th), C.c_int64(n), *[p for _, p in ins], v0.ctypes.data_as(C.c_void_p),
+       v1.ctypes.data_as(C.c_void_p))
+    return v0, v1
+
+
 def chen2022_rain_coeffs(fam, chen, rho):
     out = (fam.ft * 9)()
     fn = getattr(lib(), f"cmxo_chen2022_rain_coeffs_{fam.sfx}")

@@ -326,3 +326,40 @@ def test_full_size_1e8_f32_properties(dev, oracle):
     got = {k: v[::stride].contiguous().cpu().numpy() for k, v in full._asdict().items()}
     rep = parity.assert_parity(got, ref, parity.RTOL["f32"], what="1e8 f32 strided sample")
     print(f"\n[parity 1e8 f32, {samp[0].size} sampled points] max scaled err {rep}")
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_cloud_terminal_velocity(dev, oracle, ft):
+    """CM2.cloud_terminal_velocity over columns (Microphysics2M.jl:647-664): the reference's formula test
+    (test/microphysics2M_tests.jl:380-416) through the C ABI + random-state parity + zero gates."""
+    import math
+
+    import cmx
+    dt = {"f32": torch.float32, "f64": torch.float64}[ft]
+    pdf_c, vel = P.SB2006(ft).pdf_c, P.StokesRegimeVelType(ft)
+    col = lambda v: torch.tensor(v, dtype=dt, device=dev)  # noqa: E731
+    rho, q, N = 1.1, 1e-3, 1e7
+    got = cmx.cloud_terminal_velocity(pdf_c, vel, col([q, q, 0.0, 0.0]), col([rho] * 4), col([N, 0.0, N, 0.0]))
+    nu, mu = pdf_c.nu_c, pdf_c.mu_c
+    z1, z2 = (nu + 1) / mu, (nu + 2) / mu
+    Bc = (rho * q / N * math.gamma(z1) / math.gamma(z2)) ** (-mu)
+    pref = 2 / 9 * (3 / 4 / math.pi / vel.rho_w) ** (2 / 3) * (vel.rho_w / rho - 1) * vel.grav / vel.nu_air
+    Mn = lambda n: N * Bc ** (-n / mu) * math.gamma((nu + 1 + n) / mu) / math.gamma(z1)  # noqa: E731
+    rt = 1e-6 if ft == "f64" else 1e-5
+    assert float(got.vt_n[0]) == pytest.approx(pref * Mn(2 / 3) / N, rel=rt)
+    assert float(got.vt_m[0]) == pytest.approx(pref * Mn(5 / 3) / rho / q, rel=rt)
+    assert bool((got.vt_n[1:] == 0).all()) and bool((got.vt_m[1:] == 0).all())
+    g = torch.Generator().manual_seed(3)
+    n = 100_001
+    ql = torch.where(torch.rand(n, generator=g, dtype=torch.float64) < 0.1, torch.zeros(n, dtype=torch.float64),
+                     10 ** (-8 + 5.5 * torch.rand(n, generator=g, dtype=torch.float64))).to(dt)
+    rh = (0.3 + torch.rand(n, generator=g, dtype=torch.float64)).to(dt)
+    Nl = (10 ** (5 + 4 * torch.rand(n, generator=g, dtype=torch.float64))).to(dt)
+    got = cmx.cloud_terminal_velocity(pdf_c, vel, ql.to(dev), rh.to(dev), Nl.to(dev))
+    r0, r1 = oracle.sb2006_cloud_terminal_velocity(_abi.F64, P.SB2006("f64").pdf_c, P.StokesRegimeVelType("f64"),
+                                                   ql.numpy().astype(np.float64), rh.numpy().astype(np.float64),
+                                                   Nl.numpy().astype(np.float64), float32_gates=(ft == "f32"))
+    for x, r in ((got.vt_n, r0), (got.vt_m, r1)):
+        x = x.cpu().numpy().astype(np.float64)
+        assert np.array_equal(x == 0, r == 0)
+        assert np.max(np.abs(x - r) / np.maximum(np.abs(r), 1e-300)) <= (1e-6 if ft == "f64" else 1e-3)
