@@ -20,7 +20,8 @@ from .microphysics1m import (Instantaneous, LinearizedAverage, Microphysics1Mome
                              TerminalVelocities1M, bulk_microphysics_tendencies_1m,
                              microphysics_source_terms_1m, terminal_velocity_1m)
 
-from .aerosol import ActivationResult, AerosolDistribution, Mode_B, Mode_kappa, aerosol_activation  # noqa: F401
+from .aerosol import (ActivationResult, AerosolDistribution, ModeColumns, Mode_B, Mode_kappa, aerosol_activation,  # noqa: F401
+                      aerosol_activation_columns)
 
 from .p3 import P3Shape, P3Velocities, p3_shape, p3_terminal_velocities  # noqa: F401
 

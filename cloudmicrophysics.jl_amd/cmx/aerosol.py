@@ -29,7 +29,7 @@ class Mode_B:
     """AM.Mode_B — src/AerosolModel.jl:26-45 (Abdul-Razzak & Ghan 2000 chemistry: per-component tuples)."""
 
     def __init__(self, r_dry, stdev, N, mass_mix_ratio, soluble_mass_frac, osmotic_coeff, molar_mass, dissoc, aerosol_density):
-        self.r_dry, self.stdev, self.N = float(r_dry), float(stdev), float(N)
+        self.r_dry, self.stdev, self.N = r_dry, stdev, N
         self.mass_mix_ratio, self.soluble_mass_frac = _tup(mass_mix_ratio), _tup(soluble_mass_frac)
         self.osmotic_coeff, self.molar_mass = _tup(osmotic_coeff), _tup(molar_mass)
         self.dissoc, self.aerosol_density = _tup(dissoc), _tup(aerosol_density)
@@ -46,7 +46,7 @@ class Mode_kappa:
     """AM.Mode_κ — src/AerosolModel.jl:60-76 (Petters & Kreidenweis 2007 chemistry)."""
 
     def __init__(self, r_dry, stdev, N, vol_mix_ratio, mass_mix_ratio, molar_mass, kappa):
-        self.r_dry, self.stdev, self.N = float(r_dry), float(stdev), float(N)
+        self.r_dry, self.stdev, self.N = r_dry, stdev, N
         self.vol_mix_ratio, self.mass_mix_ratio = _tup(vol_mix_ratio), _tup(mass_mix_ratio)
         self.molar_mass, self.kappa = _tup(molar_mass), _tup(kappa)
 
@@ -110,6 +110,54 @@ def aerosol_activation(ap, ad: AerosolDistribution, aip, tps, T, p, w, q_tot, q_
     with torch.cuda.device(ref.device):
         st = fn(C.byref(ap), C.byref(adc), C.byref(aip), C.byref(tps), ref.numel(), _ptr(T), _ptr(p), _ptr(w), _ptr(q_tot),
                 _ptr(q_liq), _ptr(q_ice), _ptr(N_liq), _ptr(N_ice), arr(n_act), arr(m_act), _ptr(s_max),
+                C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return ActivationResult(n_act, m_act, s_max)
+
+
+ModeColumns = namedtuple("ModeColumns", ["r_dry", "stdev", "N", "hygroscopicity", "molar_mass_mix"], defaults=(None,))
+ModeColumns.__doc__ = """One aerosol mode whose descriptors vary in space: device columns r_dry [m], stdev, N [1/m³], the mode's mean
+hygroscopicity (B̄ of Mode_B or κ̄ of Mode_κ: `Mode_B.hygroscopicity` / `Mode_kappa.hygroscopicity` work elementwise on
+tensors too) and, if M_act is wanted, molar_mass_mix = Σ w_j M_j."""
+
+
+def aerosol_activation_columns(ap, modes: Sequence[ModeColumns], aip, tps, T, p, w, q_tot, q_liq=None, q_ice=None, N_liq=None,
+                               N_ice=None, *, want=("N_act",), stream=None) -> ActivationResult:
+    """ARG2000 activation when the aerosol itself varies in space — the reference's own KA kernel builds one
+    `AerosolDistribution` per element from columns (aerosol_activation_kernel!, test/gpu_tests.jl:45-79).  Same
+    outputs as `aerosol_activation`."""
+    modes = tuple(modes)
+    nm = len(modes)
+    if not 1 <= nm <= _abi.CMX_ARG_MAX_MODES:
+        raise ValueError(f"1 … {_abi.CMX_ARG_MAX_MODES} modes supported")
+    cols = [c for c in (T, p, w, q_tot, q_liq, q_ice, N_liq, N_ice) if c is not None]
+    names = ["T", "p", "w", "q_tot", "q_liq", "q_ice", "N_liq", "N_ice"][:len(cols)]
+    for k, m in enumerate(modes):
+        for f in ("r_dry", "stdev", "N", "hygroscopicity"):
+            cols.append(getattr(m, f)); names.append(f"modes[{k}].{f}")
+        if m.molar_mass_mix is not None:
+            cols.append(m.molar_mass_mix); names.append(f"modes[{k}].molar_mass_mix")
+    ref = _check_cols(cols, names)
+    fam = _fam_of(ref)
+    if not (isinstance(ap, fam.aerosol_activation_params) and isinstance(aip, fam.air_properties) and isinstance(tps, fam.thermo)):
+        raise TypeError("parameter float type does not match the state columns")
+    unknown = set(want) - {"N_act", "M_act", "S_max"}
+    if unknown:
+        raise ValueError(f"unknown output(s) {sorted(unknown)}")
+    have_mm = all(m.molar_mass_mix is not None for m in modes)
+    if "M_act" in want and not have_mm:
+        raise ValueError("M_act needs molar_mass_mix for every mode")
+    n_act = tuple(torch.empty_like(ref) for _ in range(nm)) if "N_act" in want else None
+    m_act = tuple(torch.empty_like(ref) for _ in range(nm)) if "M_act" in want else None
+    s_max = torch.empty_like(ref) if "S_max" in want else None
+    arr = lambda cols_: (C.c_void_p * nm)(*[c.data_ptr() for c in cols_]) if cols_ is not None else None  # noqa: E731
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_arg2000_activation_columns_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(ap), C.byref(aip), C.byref(tps), nm, ref.numel(), _ptr(T), _ptr(p), _ptr(w), _ptr(q_tot), _ptr(q_liq),
+                _ptr(q_ice), _ptr(N_liq), _ptr(N_ice), arr([m.r_dry for m in modes]), arr([m.stdev for m in modes]),
+                arr([m.N for m in modes]), arr([m.hygroscopicity for m in modes]),
+                arr([m.molar_mass_mix for m in modes]) if have_mm else None, arr(n_act), arr(m_act), _ptr(s_max),
                 C.c_void_p(s.cuda_stream))
     _lib.check(fn.__name__, st)
     return ActivationResult(n_act, m_act, s_max)

@@ -115,8 +115,8 @@ template <typename FT, int NM> struct ArgOut { FT smax; FT n[NM]; FT m[NM]; };
 
 // one thermodynamic state.  NM = compile-time mode count (1…8)
 template <typename FT, int NM, bool SINKS>
-__device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, FT T, FT p, FT w, FT q_tot, FT q_liq, FT q_ice,
-                                                    FT N_liq, FT N_ice, bool want_N, bool want_M) {
+__device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, const ArgModeConsts<FT> *__restrict__ cm, FT T, FT p, FT w,
+                                                    FT q_tot, FT q_liq, FT q_ice, FT N_liq, FT N_ice, bool want_N, bool want_M) {
     using M = Math<FT>;
     ArgOut<FT, NM> o;
     const FT inv_T = M::rcp(T);
@@ -155,11 +155,11 @@ __device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, FT T
     FT l2_sm[NM];
 #pragma unroll
     for (int k = 0; k < NM; ++k) {
-        l2_sm[k] = c.m[k].l2_sm_c + l2_A15;
-        const FT eta = X * c.m[k].inv_N;
-        const FT t1 = c.m[k].fN * Z1;
-        const FT t2 = c.m[k].gS * A3p2 * M::exp2(-c.p2 * M::log2(M::fma(FT(3), zeta, eta)));
-        const FT inv_sm = c.m[k].inv_sm_c * Am15;
+        l2_sm[k] = cm[k].l2_sm_c + l2_A15;
+        const FT eta = X * cm[k].inv_N;
+        const FT t1 = cm[k].fN * Z1;
+        const FT t2 = cm[k].gS * A3p2 * M::exp2(-c.p2 * M::log2(M::fma(FT(3), zeta, eta)));
+        const FT inv_sm = cm[k].inv_sm_c * Am15;
         tmp = M::fma(inv_sm * inv_sm, t1 + t2, tmp);
     }
     const FT S_arg = M::rsqrt(tmp);                                                                        // AA:185
@@ -186,9 +186,9 @@ __device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, FT T
 #pragma unroll
     for (int k = 0; k < NM; ++k) {
         const FT dl = l2_sm[k] - l2_smax;                       // log2(Sm_i / S_max)
-        const FT u = c.m[k].u_c * dl;                           // AA:255   (= ln(sm/smax)/fac, AA:316)
-        o.n[k] = want_N ? c.m[k].half_N * erfc_dev<FT>(u) : FT(0);                  // N ½ (1 − erf u)      AA:257
-        o.m[k] = want_M ? c.m[k].half_M * erfc_dev<FT>(u - c.m[k].fac) : FT(0);     // M/2 erfc(u − fac)    AA:319
+        const FT u = cm[k].u_c * dl;                           // AA:255   (= ln(sm/smax)/fac, AA:316)
+        o.n[k] = want_N ? cm[k].half_N * erfc_dev<FT>(u) : FT(0);                  // N ½ (1 − erf u)      AA:257
+        o.m[k] = want_M ? cm[k].half_M * erfc_dev<FT>(u - cm[k].fac) : FT(0);     // M/2 erfc(u − fac)    AA:319
     }
     return o;
 }
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void arg_activation_kernel(const ArgConsts<
     FT sm[VEC], na[NM][VEC], ma[NM][VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
-        const ArgOut<FT, NM> o = arg_point<FT, NM, SINKS>(c, T[k], p[k], w[k], qt[k], ql[k], qi[k], Nl[k], Ni[k], io.want_N, io.want_M);
+        const ArgOut<FT, NM> o = arg_point<FT, NM, SINKS>(c, c.m, T[k], p[k], w[k], qt[k], ql[k], qi[k], Nl[k], Ni[k], io.want_N, io.want_M);
         sm[k] = o.smax;
 #pragma unroll
         for (int j = 0; j < NM; ++j) { na[j][k] = o.n[j]; ma[j][k] = o.m[j]; }
@@ -287,6 +287,98 @@ static int32_t arg_entry(const AP *ap, const AD *ad, const AI *aip, const TH *tp
     return CMX_OK;
 }
 
+// ---- aerosol that varies in space: mode descriptors are columns (test/gpu_tests.jl:45-79) --------------------------------
+template <typename FT> struct ArgColIO {
+    const FT *r_dry[CMX_ARG_MAX_MODES], *stdev[CMX_ARG_MAX_MODES], *N[CMX_ARG_MAX_MODES], *hyg[CMX_ARG_MAX_MODES], *mmix[CMX_ARG_MAX_MODES];
+};
+// device twin of the per-mode part of make_arg_consts (same definitions, evaluated per state)
+template <typename FT>
+__device__ __forceinline__ ArgModeConsts<FT> arg_mode_consts_dev(const ArgConsts<FT> &c, FT f1, FT f2, FT g1, FT g2, FT r_dry, FT stdev,
+                                                                 FT N, FT hyg, FT mmix) {
+    using M = Math<FT>;
+    const FT ln2 = FT(0.6931471805599453), l2e = FT(1.4426950408889634);
+    ArgModeConsts<FT> o;
+    const FT l2s = M::log2(stdev), ls = l2s * ln2;
+    const FT l2_sm_c = FT(1) - FT(0.5) * M::log2(hyg) - FT(1.5) * M::log2(FT(3) * r_dry);   // log2(2/√B) − 1.5 log2(3 r)
+    const FT l2_N = M::log2(N);
+    o.l2_sm_c = l2_sm_c;
+    o.f = f1 * M::exp2(f2 * ls * ls * l2e);
+    o.g = M::fma(g2, ls, g1);
+    o.l2_N = l2_N; o.N = N; o.half_N = FT(0.5) * N;
+    o.u_c = FT(2) * ln2 * M::rcp(FT(4.242640687119285) * ls);   // 2 ln2 / (3√2 ln σ)
+    o.fac = FT(2.1213203435596424) * ls;                          // 3 ln σ √2 / 2
+    o.half_M = FT(0.5) * mmix;
+    o.inv_N = M::rcp(N);
+    o.fN = o.f * M::exp2(c.p1 * l2_N);
+    o.gS = o.g * M::exp2(FT(2) * c.p2 * l2_sm_c);
+    o.inv_sm_c = M::exp2(-l2_sm_c);
+    return o;
+}
+
+template <typename FT, int NM, bool SINKS>
+__global__ __launch_bounds__(kBlock) void arg_activation_columns_kernel(const ArgConsts<FT> c, const FT f1, const FT f2, const FT g1,
+                                                                        const FT g2, const ArgIO<FT> io, const ArgColIO<FT> mc,
+                                                                        const int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    ArgModeConsts<FT> cm[NM];
+#pragma unroll
+    for (int k = 0; k < NM; ++k)
+        cm[k] = arg_mode_consts_dev<FT>(c, f1, f2, g1, g2, mc.r_dry[k][i], mc.stdev[k][i], mc.N[k][i], mc.hyg[k][i],
+                                        mc.mmix[k] ? mc.mmix[k][i] : FT(0));
+    const FT ql = io.q_liq ? io.q_liq[i] : FT(0), qi = io.q_ice ? io.q_ice[i] : FT(0);
+    FT Nl = FT(0), Ni = FT(0);
+    if constexpr (SINKS) { Nl = io.N_liq ? io.N_liq[i] : FT(0); Ni = io.N_ice ? io.N_ice[i] : FT(0); }
+    const ArgOut<FT, NM> o = arg_point<FT, NM, SINKS>(c, cm, io.T[i], io.p[i], io.w[i], io.q_tot[i], ql, qi, Nl, Ni, io.want_N, io.want_M);
+    if (io.S_max) io.S_max[i] = o.smax;
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+        if (io.want_N && io.N_act[j]) io.N_act[j][i] = o.n[j];
+        if (io.want_M && io.M_act[j]) io.M_act[j][i] = o.m[j];
+    }
+}
+
+template <typename FT, typename AP, typename AI, typename TH>
+static int32_t arg_columns_entry(const AP *ap, const AI *aip, const TH *tps, int32_t n_modes, int64_t n, const FT *T, const FT *p,
+                                 const FT *w, const FT *q_tot, const FT *q_liq, const FT *q_ice, const FT *N_liq, const FT *N_ice,
+                                 const FT *const *r_dry, const FT *const *stdev, const FT *const *N_mode, const FT *const *hyg,
+                                 const FT *const *mmix, FT *const *N_act, FT *const *M_act, FT *S_max, void *stream) {
+    if (!ap || !aip || !tps || n < 0 || n_modes < 1 || n_modes > CMX_ARG_MAX_MODES) return CMX_ERR_BAD_ARG;
+    if (n == 0) return CMX_OK;
+    if (!T || !p || !w || !q_tot || !r_dry || !stdev || !N_mode || !hyg) return CMX_ERR_BAD_ARG;
+    if (M_act && !mmix) return CMX_ERR_BAD_ARG;
+    // thermodynamic / parameter constants from the shared builder with an empty distribution
+    struct EmptyDist { int32_t n_modes = 0; struct Mode { FT r_dry, stdev, N, hygroscopicity, molar_mass_mix; } modes[1]; } none;
+    const ArgConsts<FT> c = make_arg_consts<FT>(*ap, none, *aip, *tps);
+    ArgIO<FT> io{};
+    io.T = T; io.p = p; io.w = w; io.q_tot = q_tot; io.q_liq = q_liq; io.q_ice = q_ice; io.N_liq = N_liq; io.N_ice = N_ice;
+    io.S_max = S_max; io.want_N = N_act != nullptr; io.want_M = M_act != nullptr;
+    ArgColIO<FT> mc{};
+    for (int j = 0; j < n_modes; ++j) {
+        if (!r_dry[j] || !stdev[j] || !N_mode[j] || !hyg[j]) return CMX_ERR_BAD_ARG;
+        mc.r_dry[j] = r_dry[j]; mc.stdev[j] = stdev[j]; mc.N[j] = N_mode[j]; mc.hyg[j] = hyg[j]; mc.mmix[j] = mmix ? mmix[j] : nullptr;
+        io.N_act[j] = N_act ? N_act[j] : nullptr;
+        io.M_act[j] = M_act ? M_act[j] : nullptr;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool sinks = N_liq || N_ice;
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+    const FT f1 = (FT)ap->f1, f2 = (FT)ap->f2, g1 = (FT)ap->g1, g2 = (FT)ap->g2;
+#define CMX_ARGC_CASE(NM)                                                                                                       \
+    case NM:                                                                                                                    \
+        if (sinks) hipLaunchKernelGGL((arg_activation_columns_kernel<FT, NM, true>), grid, block, 0, s, c, f1, f2, g1, g2, io, mc, n);  \
+        else hipLaunchKernelGGL((arg_activation_columns_kernel<FT, NM, false>), grid, block, 0, s, c, f1, f2, g1, g2, io, mc, n);       \
+        break;
+    switch (n_modes) {
+        CMX_ARGC_CASE(1) CMX_ARGC_CASE(2) CMX_ARGC_CASE(3) CMX_ARGC_CASE(4)
+        CMX_ARGC_CASE(5) CMX_ARGC_CASE(6) CMX_ARGC_CASE(7) CMX_ARGC_CASE(8)
+        default: return CMX_ERR_BAD_ARG;
+    }
+#undef CMX_ARGC_CASE
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+
 }  // namespace cmx
 
 extern "C" {
@@ -304,6 +396,26 @@ int32_t cmx_arg2000_activation_f64(const cmx_aerosol_activation_params_f64 *ap, 
                                    const double *q_ice, const double *N_liq, const double *N_ice, double *const *N_act,
                                    double *const *M_act, double *S_max, void *stream) {
     return cmx::arg_entry<double>(ap, ad, aip, tps, n, T, p, w, q_tot, q_liq, q_ice, N_liq, N_ice, N_act, M_act, S_max, stream);
+}
+
+int32_t cmx_arg2000_activation_columns_f32(const cmx_aerosol_activation_params_f32 *ap, const cmx_air_properties_f32 *aip,
+                                           const cmx_thermo_f32 *tps, int32_t n_modes, int64_t n, const float *T, const float *p,
+                                           const float *w, const float *q_tot, const float *q_liq, const float *q_ice, const float *N_liq,
+                                           const float *N_ice, const float *const *r_dry, const float *const *stdev,
+                                           const float *const *N_mode, const float *const *hygroscopicity, const float *const *molar_mass,
+                                           float *const *N_act, float *const *M_act, float *S_max, void *stream) {
+    return cmx::arg_columns_entry<float>(ap, aip, tps, n_modes, n, T, p, w, q_tot, q_liq, q_ice, N_liq, N_ice, r_dry, stdev, N_mode,
+                                         hygroscopicity, molar_mass, N_act, M_act, S_max, stream);
+}
+int32_t cmx_arg2000_activation_columns_f64(const cmx_aerosol_activation_params_f64 *ap, const cmx_air_properties_f64 *aip,
+                                           const cmx_thermo_f64 *tps, int32_t n_modes, int64_t n, const double *T, const double *p,
+                                           const double *w, const double *q_tot, const double *q_liq, const double *q_ice,
+                                           const double *N_liq, const double *N_ice, const double *const *r_dry,
+                                           const double *const *stdev, const double *const *N_mode, const double *const *hygroscopicity,
+                                           const double *const *molar_mass, double *const *N_act, double *const *M_act, double *S_max,
+                                           void *stream) {
+    return cmx::arg_columns_entry<double>(ap, aip, tps, n_modes, n, T, p, w, q_tot, q_liq, q_ice, N_liq, N_ice, r_dry, stdev, N_mode,
+                                          hygroscopicity, molar_mass, N_act, M_act, S_max, stream);
 }
 
 }  // extern "C"

@@ -502,6 +502,24 @@ int32_t cmx_arg2000_activation_f64(
     const double *T, const double *p, const double *w, const double *q_tot, const double *q_liq, const double *q_ice,
     const double *N_liq, const double *N_ice, double *const *N_act, double *const *M_act, double *S_max, void *stream);
 
+/* Same activation for aerosol that varies in space: every mode's (r_dry, stdev, N, hygroscopicity, molar_mass_mix) is a
+ * device column (arrays of n_modes column pointers), as the reference's own KA kernel passes them per element
+ * (aerosol_activation_kernel!, test/gpu_tests.jl:45-79).  hygroscopicity = the mode's mean B̄ or κ̄
+ * (AA.mean_hygroscopicity_parameter, src/AerosolActivation.jl:61-97); molar_mass (nullable) = Σ w_j M_j, only needed
+ * for M_act.  The mode-only factors the shared-distribution entry folds on the host are formed per state here. */
+int32_t cmx_arg2000_activation_columns_f32(
+    const cmx_aerosol_activation_params_f32 *ap, const cmx_air_properties_f32 *aip, const cmx_thermo_f32 *tps, int32_t n_modes,
+    int64_t n, const float *T, const float *p, const float *w, const float *q_tot, const float *q_liq, const float *q_ice,
+    const float *N_liq, const float *N_ice, const float *const *r_dry, const float *const *stdev, const float *const *N_mode,
+    const float *const *hygroscopicity, const float *const *molar_mass, float *const *N_act, float *const *M_act, float *S_max,
+    void *stream);
+int32_t cmx_arg2000_activation_columns_f64(
+    const cmx_aerosol_activation_params_f64 *ap, const cmx_air_properties_f64 *aip, const cmx_thermo_f64 *tps, int32_t n_modes,
+    int64_t n, const double *T, const double *p, const double *w, const double *q_tot, const double *q_liq, const double *q_ice,
+    const double *N_liq, const double *N_ice, const double *const *r_dry, const double *const *stdev, const double *const *N_mode,
+    const double *const *hygroscopicity, const double *const *molar_mass, double *const *N_act, double *const *M_act, double *S_max,
+    void *stream);
+
 /* ---------------------------------------------------------------------------
  * (7) P3 ice scheme: state construction, size-distribution shape solver, mass-weighted mean diameter.
  *

@@ -102,3 +102,28 @@ void FN(cmxo_arg2000_activation)(const TY(cmx_aerosol_activation_params) * ap, c
         }
     }
 }
+
+/* oracle twin of cmx_arg2000_activation_columns_*: the aerosol modes vary in space — (r_dry, stdev, N, hygroscopicity,
+ * molar_mass_mix) are columns per mode, as the reference's own GPU test passes them (test/gpu_tests.jl:45-79) */
+void FN(cmxo_arg2000_activation_columns)(const TY(cmx_aerosol_activation_params) * ap, const TY(cmx_air_properties) * aip,
+                                        const TY(cmx_thermo) * tps, const TY(cmxo_thresholds) * th, int32_t n_modes, int64_t n,
+                                        const FT *T, const FT *p, const FT *w, const FT *q_tot, const FT *q_liq, const FT *q_ice,
+                                        const FT *N_liq, const FT *N_ice, const FT *const *r_dry, const FT *const *stdev,
+                                        const FT *const *N_mode, const FT *const *hyg, const FT *const *mmix, FT *const *N_act,
+                                        FT *const *M_act, FT *S_max, int32_t nthreads) {
+    (void)nthreads;
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+    for (int64_t i = 0; i < n; ++i) {
+        TY(cmx_aerosol_distribution) ad;
+        ad.n_modes = n_modes;
+        for (int k = 0; k < n_modes; ++k) {
+            ad.modes[k].r_dry = r_dry[k][i]; ad.modes[k].stdev = stdev[k][i]; ad.modes[k].N = N_mode[k][i];
+            ad.modes[k].hygroscopicity = hyg[k][i]; ad.modes[k].molar_mass_mix = mmix ? mmix[k][i] : (FT)0;
+        }
+        FT *na[CMX_ARG_MAX_MODES], *ma[CMX_ARG_MAX_MODES];
+        for (int k = 0; k < n_modes; ++k) { na[k] = N_act ? N_act[k] + i : NULL; ma[k] = M_act ? M_act[k] + i : NULL; }
+        FN(cmxo_arg2000_activation)(ap, &ad, aip, tps, th, 1, T + i, p + i, w + i, q_tot + i, q_liq ? q_liq + i : NULL,
+                                    q_ice ? q_ice + i : NULL, N_liq ? N_liq + i : NULL, N_ice ? N_ice + i : NULL,
+                                    N_act ? na : NULL, M_act ? ma : NULL, S_max ? S_max + i : NULL, NULL, 1);
+    }
+}

@@ -242,6 +242,28 @@ def arg2000_activation(fam, ap, ad, aip, tps, T, p, w, q_tot, q_liq=None, q_ice=
     return dict(N_act=n_act, M_act=m_act, S_max=s_max, S_cond=s_cond)
 
 
+def arg2000_activation_columns(fam, ap, aip, tps, T, p, w, q_tot, modes, *, want_M=False, float32_gates=None, nthreads=1):
+    """Oracle twin of cmx_arg2000_activation_columns_*; `modes` = sequence of (r_dry, stdev, N, hygroscopicity, molar_mass_mix)
+    numpy columns.  Returns dict(N_act=[…], M_act=[…] or None, S_max)."""
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    req = [_col(fam, a) for a in (T, p, w, q_tot)]
+    n, nm = req[0][0].size, len(modes)
+    mc = [[_col(fam, m[j]) for m in modes] for j in range(5)]
+    arr = lambda cols: (C.c_void_p * nm)(*[c[0].ctypes.data for c in cols])  # noqa: E731
+    n_act = [np.empty(n, dtype=NP[fam.sfx]) for _ in range(nm)]
+    m_act = [np.empty(n, dtype=NP[fam.sfx]) for _ in range(nm)] if want_M else None
+    s_max = np.empty(n, dtype=NP[fam.sfx])
+    out = lambda cols: (C.c_void_p * nm)(*[c.ctypes.data for c in cols]) if cols is not None else None  # noqa: E731
+    fn = getattr(lib(), f"cmxo_arg2000_activation_columns_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(ap), C.byref(aip), C.byref(tps), C.byref(th), C.c_int32(nm), C.c_int64(n), *[q for _, q in req], None, None, None, None,
+       arr(mc[0]), arr(mc[1]), arr(mc[2]), arr(mc[3]), arr(mc[4]), out(n_act), out(m_act), s_max.ctypes.data_as(C.c_void_p),
+       C.c_int32(nthreads))
+    return dict(N_act=n_act, M_act=m_act, S_max=s_max)
+
+
 def p3_shape(fam, params, flags, rho_q_ice, rho_n_ice, x3, x4, *, guess=None, float32_gates=None, maxiters=0, gi_iters=0,
              nthreads=1):
     """Oracle twin of cmx_p3_shape_*: dict of F_rim, rho_rim, rho_g, D_gr, D_cr, log_lambda, D_m, log_N0.

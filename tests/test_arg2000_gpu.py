@@ -13,6 +13,7 @@ import torch
 import parity
 from cmx import _abi
 from cmx import parameters as P
+from cmx import synthetic
 from cmx.aerosol import AerosolDistribution, Mode_B, Mode_kappa
 
 pytestmark = pytest.mark.gpu
@@ -191,3 +192,61 @@ def test_full_size_1e8_f32_properties(dev, oracle):
     got = cmx.ActivationResult(tuple(c[::stride].contiguous() for c in full.N_act), None, torch.from_numpy(ref["S_max"]))
     rep = _compare(got, ref, adc, "f32", "1e8 sample")
     print(f"\n[ARG parity 1e8 f32, {samp[0].size} sampled states] worst {max(rep.values()):.2e}")
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_spatially_varying_aerosol_columns(dev, oracle, ft):
+    """Mode descriptors as per-state columns (the reference's aerosol_activation_kernel!, test/gpu_tests.jl:45-79,549-587):
+    the reference's own κ-vs-B consistency check on its two test elements, equality with the shared-distribution entry
+    when the columns are constant, and random-column parity with the oracle."""
+    import cmx
+    dt = {"f32": torch.float32, "f64": torch.float64}[ft]
+    ap, aip, tps = P.AerosolActivationParameters(ft), P.AirProperties(ft), P.ThermodynamicsParameters(ft)
+    col = lambda v: torch.tensor(v, dtype=dt, device=dev)  # noqa: E731
+    # the two elements of the reference test: sulfate-like and seasalt-like single-mode aerosol
+    r, sd, N = [0.243e-6, 1.5e-6], [1.4, 2.1], [100e6, 1e6]
+    eps_, phi, Mm, nu, rho_a, kappa = [1.0, 1.0], [1.0, 0.9], [0.132, 0.058443], [3.0, 2.0], [1770.0, 2170.0], [0.53, 1.12]
+    T = col([294.0, 294.0]); p = col([1e5, 1e5]); w = col([0.5, 0.5])
+    p_vs = np.array([oracle.psat_liquid(_abi.F64, P.ThermodynamicsParameters("f64"), 294.0)] * 2)
+    q_vs = 1 / (1 - 1 / (tps.R_d / tps.R_v) * (p_vs - 1e5) / p_vs)
+    q_tot = col(q_vs.tolist())
+    mB = cmx.Mode_B(col(r), col(sd), col(N), (1.0,), (col(eps_),), (col(phi),), (col(Mm),), (col(nu),), (col(rho_a),))
+    mK = cmx.Mode_kappa(col(r), col(sd), col(N), (1.0,), (1.0,), (col(Mm),), (col(kappa),))
+    res = {}
+    for name, m in (("B", mB), ("kappa", mK)):
+        mc = cmx.ModeColumns(m.r_dry, m.stdev, m.N, m.hygroscopicity(ap), m.molar_mass[0] * 1.0)
+        res[name] = cmx.aerosol_activation_columns(ap, [mc], aip, tps, T, p, w, q_tot, want=("N_act", "M_act"))
+    for k in range(2):   # gpu_tests.jl:580-587
+        assert float(res["B"].N_act[0][k]) == pytest.approx(float(res["kappa"].N_act[0][k]), rel=0.3)
+        assert float(res["B"].N_act[0][k]) > 0 and float(res["B"].M_act[0][k]) > 0
+    # constant columns == the shared-distribution entry
+    n = 50_001
+    st = synthetic.arg_state(n, dtype=dt, device=dev, seed=9)
+    ad = synthetic.arg_config3_distribution()
+    shared = cmx.aerosol_activation(ap, ad, aip, tps, *st, want=("N_act", "S_max"))
+    adc = ad.c_struct(ap, _abi.family(ft))
+    full = lambda v: torch.full((n,), float(v), dtype=dt, device=dev)  # noqa: E731
+    modes = [cmx.ModeColumns(full(adc.modes[k].r_dry), full(adc.modes[k].stdev), full(adc.modes[k].N), full(adc.modes[k].hygroscopicity))
+             for k in range(adc.n_modes)]
+    varying = cmx.aerosol_activation_columns(ap, modes, aip, tps, *st, want=("N_act", "S_max"))
+    rt = 1e-9 if ft == "f64" else 2e-4
+    assert torch.allclose(varying.S_max, shared.S_max, rtol=rt, atol=0)
+    for a, b, m in zip(varying.N_act, shared.N_act, modes):
+        assert float(((a - b).abs() / m.N).max()) <= rt
+    # random columns vs the oracle
+    g = torch.Generator(device="cpu").manual_seed(4)
+    u = lambda lo, hi: (lo + (hi - lo) * torch.rand(n, generator=g, dtype=torch.float64)).to(dt)  # noqa: E731
+    rm = [(10 ** u(-8.0, -6.0), u(1.3, 2.2), 10 ** u(6.0, 9.5), u(0.1, 1.3), u(0.05, 0.15)) for _ in range(3)]
+    got = cmx.aerosol_activation_columns(ap, [cmx.ModeColumns(*[c.to(dev) for c in m]) for m in rm], aip, tps, *st, want=("N_act", "M_act", "S_max"))
+    ref = oracle.arg2000_activation_columns(_abi.F64, P.AerosolActivationParameters("f64"), P.AirProperties("f64"),
+                                            P.ThermodynamicsParameters("f64"), *[c.cpu().numpy().astype(np.float64) for c in st],
+                                            [[c.numpy().astype(np.float64) for c in m] for m in rm], want_M=True,
+                                            float32_gates=(ft == "f32"), nthreads=8)
+    tol = 1e-6 if ft == "f64" else 1e-3
+    sm = got.S_max.cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(sm - ref["S_max"]) / ref["S_max"]) <= tol
+    for k in range(3):
+        Nk = rm[k][2].numpy().astype(np.float64)
+        assert np.max(np.abs(got.N_act[k].cpu().numpy() - ref["N_act"][k]) / Nk) <= tol
+        Mk = rm[k][4].numpy().astype(np.float64)
+        assert np.max(np.abs(got.M_act[k].cpu().numpy() - ref["M_act"][k]) / Mk) <= tol
