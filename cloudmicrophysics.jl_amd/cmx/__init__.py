@@ -16,9 +16,9 @@ from .bulk_tendencies import (Chen2022VelTypeRain, Microphysics2Moment, SB2006Pr
 from .ice_nucleation import (IceNucleationRates, a_w_eT, a_w_ice, domain_error_count,  # noqa: F401
                              ice_nucleation_rates)
 
-from .microphysics1m import (Instantaneous, LinearizedAverage, Microphysics1Moment, SourceTerms1M, Tendencies1M,  # noqa: F401
+from .microphysics1m import (Instantaneous, LinearizedAverage, Microphysics1Moment, SedimentationVelocities, SourceTerms1M, Tendencies1M,  # noqa: F401
                              TerminalVelocities1M, bulk_microphysics_tendencies_1m,
-                             microphysics_source_terms_1m, terminal_velocity_1m)
+                             microphysics_source_terms_1m, sedimentation_velocities, terminal_velocity_1m)
 
 from .aerosol import (ActivationResult, AerosolDistribution, ModeColumns, Mode_B, Mode_kappa, aerosol_activation,  # noqa: F401
                       aerosol_activation_columns)

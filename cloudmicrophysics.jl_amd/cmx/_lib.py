@@ -57,6 +57,10 @@ def _declare(lib):
         f = getattr(lib, f"cmx_mp1m_tendencies_{s}")
         f.restype = i32
         f.argtypes = [C.POINTER(fam.microphysics_1m), C.POINTER(fam.thermo), u32, i64] + [vp] * 11 + [vp]
+        f = getattr(lib, f"cmx_sedimentation_velocities_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.microphysics_1m), C.POINTER(fam.stokes_vel), C.POINTER(fam.chen2022_rain_vel),
+                      C.POINTER(fam.chen2022_ice_vel), i64] + [vp] * 9 + [vp]
         f = getattr(lib, f"cmx_arg2000_activation_columns_{s}")
         f.restype = i32
         f.argtypes = [C.POINTER(fam.aerosol_activation_params), C.POINTER(fam.air_properties), C.POINTER(fam.thermo), i32, i64] \

@@ -122,3 +122,31 @@ def terminal_velocity_1m(mp, rho, q_rai=None, q_sno=None, *, chen=False, stream=
                 *[_ptr(o) for o in out], C.c_void_p(s.cuda_stream))
     _lib.check(fn.__name__, st)
     return out
+
+
+SedimentationVelocities = namedtuple("SedimentationVelocities", ["w_lcl", "w_icl", "w_rai", "w_sno"])
+
+
+def sedimentation_velocities(mp, stokes, chen_rain, chen_ice, rho, q_lcl=None, q_icl=None, q_rai=None, q_sno=None, *,
+                             stream=None) -> SedimentationVelocities:
+    """The bulk fall speeds a host model precomputes for sedimentation (ClimaAtmos `set_sedimentation_precomputed_quantities`,
+    test/gpu_clima_core_test.jl:36-45): cloud liquid (Stokes), cloud ice (Chen-2022 small ice), rain (Chen-2022 rain) and
+    snow (Chen-2022 large ice) — `CMNonEq.terminal_velocity` (NonEq:250-281) and `CM1.terminal_velocity` (CM1:251-297).
+    Species whose q column is None are skipped (None in the result)."""
+    if not isinstance(mp, Microphysics1MParams):
+        raise TypeError("mp must be Microphysics1MParams")
+    qs = (q_lcl, q_icl, q_rai, q_sno)
+    cols = [rho] + [q for q in qs if q is not None]
+    ref = _check_cols(cols, ["rho"] + ["q"] * (len(cols) - 1))
+    fam = _fam_of(ref)
+    if fam is not mp.fam:
+        raise TypeError("parameter float type does not match the state columns")
+    outs = [torch.empty_like(ref) if q is not None else None for q in qs]
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    ref_or_null = lambda x: C.byref(x) if x is not None else None  # noqa: E731
+    fn = getattr(_lib.lib(), f"cmx_sedimentation_velocities_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(mp.c), ref_or_null(stokes), ref_or_null(chen_rain), ref_or_null(chen_ice), ref.numel(), _ptr(rho),
+                *[_ptr(q) for q in qs], *[_ptr(o) for o in outs], C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return SedimentationVelocities(*outs)

@@ -126,14 +126,14 @@ DEFAULT_PARAMETERS = {
     "snow_terminal_velocity_size_relation_coefficient_chiv": 1.0,
     "snow_flake_size_distribution_coefficient_mu": 4.36e9, "snow_flake_size_distribution_coefficient_nu": 0.63,
     "snow_ventilation_coefficient_a": 0.65, "snow_ventilation_coefficient_b": 0.44,
-    "snow_apparent_density": 100.0,            # only enters the Chen-2022 snow velocity (not on this path); unpinned
-    "snow_aspect_ratio": 0.15, "snow_aspect_ratio_coefficient": 1.0 / 3.0,   # idem (unpinned)
+    "snow_apparent_density": 100.0,            # Chen-2022 snow velocity; pinned with the two below by gpu_tests.jl:627
+    "snow_aspect_ratio": 0.15, "snow_aspect_ratio_coefficient": 1.0 / 3.0,   # ϕ^κ = 0.15^(1/3)
     "cloud_ice_crystals_length_scale": 1e-5, "cloud_ice_mass_size_relation_coefficient_me": 3.0,
     "cloud_ice_mass_size_relation_coefficient_delm": 0.0, "cloud_ice_mass_size_relation_coefficient_chim": 1.0,
     "cloud_ice_size_distribution_coefficient_n0": 2e7,
     "cloud_ice_apparent_density": 500.0,       # back-solved from the ice accretion KATs
     "liquid_cloud_effective_radius": 14e-6, "ice_cloud_effective_radius": 25e-6,            # not used by the rates
-    "cloud_liquid_sedimentation_number_concentration": 5e8, "cloud_ice_sedimentation_number_concentration": 5e5,  # idem
+    "cloud_liquid_sedimentation_number_concentration": 5e8, "cloud_ice_sedimentation_number_concentration": 5e8,  # pinned: gpu_tests.jl:624-625
     "rain_autoconversion_timescale": 1e3, "snow_autoconversion_timescale": 1e2,
     "cloud_liquid_water_specific_humidity_autoconversion_threshold": 5e-4,
     "cloud_ice_specific_humidity_autoconversion_threshold": 1e-6,

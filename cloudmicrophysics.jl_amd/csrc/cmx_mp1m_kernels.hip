@@ -437,8 +437,18 @@ template <typename FT> struct Vel1mConsts {
     FT eps_1m, l2_eps, lam_c_rai, lam_e_rai, lam_floor_rai, lam_c_sno, lam_e_sno, lam_floor_sno, sno_l2_mu, sno_nu;
     FT v0c_rai, rho_w, v0_sno, vt_c_rai, vt_e_rai, vt_c_sno, vt_e_sno;
     FT ch_rho0_l2e, ch_a[3], ch_a3_pow, ch_b[3], ch_b_rho, ch_c1000[3], l2_1000;
+    // cloud liquid, Stokes (NonEq:250-265): v = st_pref (ρw/ρ − 1) D², D³ = st_D3 ρ q
+    FT st_pref, st_rho_w, st_D3;
+    // cloud ice, Chen-2022 small ice reduced at ρᵢ(cloud ice) (NonEq:267-281, Common.jl:304-325): D³ = ci_D3 ρ q
+    FT ci_D3, ci_A, ci_B, ci_C, ci_E, ci_F, ci_c2;
+    // snow, Chen-2022 large ice reduced at ρᵢ(snow), mass-weighted over the Marshall–Palmer PSD (CM1:272-297):
+    // ϕ^κ Γ(b+4)/3! folded into the amplitudes
+    FT sn_A, sn_a1, sn_b1, sn_a2, sn_H, sn_b2, sn_c2;
 };
-template <typename FT> struct Vel1mIO { const FT *rho, *q_rai, *q_sno; FT *vt_rai, *vt_sno, *vt_chen; };
+template <typename FT> struct Vel1mIO {
+    const FT *rho, *q_rai, *q_sno; FT *vt_rai, *vt_sno, *vt_chen;
+    const FT *q_lcl, *q_icl; FT *w_lcl, *w_icl, *w_sno_chen;
+};
 
 template <typename FT>
 __global__ __launch_bounds__(kBlock) void mp1m_velocity_kernel(const Vel1mConsts<FT> c, const Vel1mIO<FT> io, const int64_t n) {
@@ -477,6 +487,33 @@ __global__ __launch_bounds__(kBlock) void mp1m_velocity_kernel(const Vel1mConsts
         const FT l2_n0 = has ? M::fma(c.sno_nu, l2_rq, c.sno_l2_mu) : c.l2_eps;
         const FT l2_li = M::max(c.lam_floor_sno, (l2_rq + c.lam_c_sno - M::max(l2_n0, c.l2_eps)) * c.lam_e_sno);
         io.vt_sno[i] = has ? c.vt_c_sno * c.v0_sno * M::exp2(c.vt_e_sno * l2_li) : FT(0);
+    }
+    if (io.w_lcl) {   // CMNonEq.terminal_velocity(::CloudLiquid, ::StokesRegimeVelType, ρ, q): Stokes at the mean-volume diameter
+        const FT q = io.q_lcl[i];
+        const FT D2 = M::exp2(FT(2.0 / 3.0) * M::log2(c.st_D3 * rho * M::max(FT(0), q)));
+        io.w_lcl[i] = q > eps ? c.st_pref * (c.st_rho_w * M::rcp(rho) - FT(1)) * D2 : FT(0);
+    }
+    if (io.w_icl) {   // CMNonEq.terminal_velocity(::CloudIce, ::Chen2022VelTypeSmallIce, ρ, q): Σ aₖ D^bₖ e^{−cₖD} at that diameter
+        const FT q = io.q_icl[i];
+        const FT l2_D = FT(1.0 / 3.0) * M::log2(c.ci_D3 * rho * M::max(FT(0), q));
+        const FT D = M::exp2(l2_D);
+        const FT b = M::fma(rp, c.ci_C, c.ci_B);
+        const FT common = M::exp2(c.ci_A * M::log2(rp) + b * (c.l2_1000 + l2_D));           // ρₐ^As · (1000 D)^b
+        const FT w = common * M::fma(c.ci_F, M::exp2(-c.ci_c2 * D * FT(1.4426950408889634)), c.ci_E);
+        io.w_icl[i] = q > eps ? M::max(FT(0), w) : FT(0);
+    }
+    if (io.w_sno_chen) {   // CM1.terminal_velocity(::Snow, ::Chen2022VelTypeLargeIce, ρ, q): mass-weighted (k = 3), λ_D⁻¹ = 2 λ⁻¹
+        const FT q = io.q_sno[i];
+        const bool has = q > eps;
+        const FT l2_rq = M::log2(rp * M::max(FT(0), q));
+        const FT l2_n0 = has ? M::fma(c.sno_nu, l2_rq, c.sno_l2_mu) : c.l2_eps;
+        const FT l2_li = M::max(c.lam_floor_sno, (l2_rq + c.lam_c_sno - M::max(l2_n0, c.l2_eps)) * c.lam_e_sno);
+        const FT l2_ld = l2_li + FT(1), lam = M::exp2(-l2_ld);
+        const FT l2_ra = c.sn_A * M::log2(rp);
+        // aₖ e^{−4 ln λ_D⁻¹ − (bₖ+4) ln(λ_D + cₖ)}: term 1 has c = 0 → λ_D^{−b₁}·… collapses to one power
+        const FT t1 = c.sn_a1 * M::exp2(l2_ra + c.sn_b1 * l2_ld);
+        const FT t2 = c.sn_a2 * M::exp2(l2_ra + c.sn_H * rp * FT(1.4426950408889634) - FT(4) * l2_ld - (c.sn_b2 + FT(4)) * M::log2(lam + c.sn_c2));
+        io.w_sno_chen[i] = has ? M::max(FT(0), t1 + t2) : FT(0);
     }
 }
 
@@ -567,11 +604,8 @@ static int32_t sources_1m_entry(const MP *mp, const TH *tps, uint32_t flags, int
 }
 
 template <typename FT, typename MP, typename CH>
-static int32_t velocity_1m_entry(const MP *mp, const CH *chen, int64_t n, const FT *rho, const FT *q_rai, const FT *q_sno,
-                                 FT *vt_rai, FT *vt_sno, FT *vt_chen, void *stream) {
-    if (!mp || n < 0) return CMX_ERR_BAD_ARG;
-    if (n == 0) return CMX_OK;
-    if (!rho || ((vt_rai || vt_chen) && !q_rai) || (vt_sno && !q_sno) || (vt_chen && !chen)) return CMX_ERR_BAD_ARG;
+static Vel1mConsts<FT> make_vel1m_consts(const MP &mpr, const CH *chen) {
+    const MP *mp = &mpr;
     // reuse the folding of the tendencies kernel (thermo part unused): a neutral thermo struct keeps it well-defined
     cmx_thermo_f64 tp{461.5, 287.0, 1004.5, 1859.0, 4181.0, 2070.0, 2.5008e6, 2.8344e6, 273.16, 273.16, 611.657, 273.15, 4181.0};
     const Mp1mConsts<FT> m = make_mp1m_consts<FT>(*mp, tp, 0u, (double)Math<FT>::eps_1m());
@@ -585,7 +619,71 @@ static int32_t velocity_1m_entry(const MP *mp, const CH *chen, int64_t n, const 
         for (int k = 0; k < 3; ++k) { c.ch_a[k] = (FT)chen->a[k]; c.ch_b[k] = (FT)chen->b[k]; c.ch_c1000[k] = (FT)((double)chen->c[k] * 1000.0); }
         c.ch_a3_pow = (FT)chen->a3_pow; c.ch_b_rho = (FT)chen->b_rho; c.l2_1000 = (FT)std::log2(1000.0);
     }
-    Vel1mIO<FT> io{rho, q_rai, q_sno, vt_rai, vt_sno, vt_chen};
+    return c;
+}
+
+template <typename FT, typename MP, typename CH>
+static int32_t velocity_1m_entry(const MP *mp, const CH *chen, int64_t n, const FT *rho, const FT *q_rai, const FT *q_sno,
+                                 FT *vt_rai, FT *vt_sno, FT *vt_chen, void *stream) {
+    if (!mp || n < 0) return CMX_ERR_BAD_ARG;
+    if (n == 0) return CMX_OK;
+    if (!rho || ((vt_rai || vt_chen) && !q_rai) || (vt_sno && !q_sno) || (vt_chen && !chen)) return CMX_ERR_BAD_ARG;
+    const Vel1mConsts<FT> c = make_vel1m_consts<FT>(*mp, chen);
+    Vel1mIO<FT> io{rho, q_rai, q_sno, vt_rai, vt_sno, vt_chen, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL((mp1m_velocity_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), c, io, n);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+
+// The four bulk sedimentation velocities a host model precomputes (ClimaAtmos set_sedimentation_precomputed_quantities;
+// test/gpu_clima_core_test.jl:36-45, KA kernel test/gpu_tests.jl:608-630)
+template <typename FT, typename MP, typename ST, typename CH, typename CI>
+static int32_t sedimentation_entry(const MP *mp, const ST *stokes, const CH *chen_rain, const CI *chen_ice, int64_t n, const FT *rho,
+                                   const FT *q_lcl, const FT *q_icl, const FT *q_rai, const FT *q_sno, FT *w_lcl, FT *w_icl, FT *w_rai,
+                                   FT *w_sno, void *stream) {
+    if (!mp || n < 0) return CMX_ERR_BAD_ARG;
+    if (n == 0) return CMX_OK;
+    if (!rho || (w_lcl && (!q_lcl || !stokes)) || (w_icl && (!q_icl || !chen_ice)) || (w_rai && (!q_rai || !chen_rain)) ||
+        (w_sno && (!q_sno || !chen_ice)))
+        return CMX_ERR_BAD_ARG;
+    Vel1mConsts<FT> c = make_vel1m_consts<FT>(*mp, chen_rain);
+    const double pi = 3.14159265358979323846;
+    c.l2_1000 = (FT)std::log2(1000.0);
+    if (stokes) {
+        c.st_pref = (FT)((double)stokes->grav / (18.0 * (double)stokes->nu_air));
+        c.st_rho_w = (FT)stokes->rho_w;
+        c.st_D3 = (FT)(6.0 / pi / ((double)mp->cloud_liquid.N_0 * (double)mp->cloud_liquid.rho_w));
+    }
+    if (chen_ice) {
+        {   // small ice reduced at the cloud-ice apparent density — Common.jl:304-325
+            const auto &t = chen_ice->small_ice;
+            const double ri = (double)mp->cloud_ice.rho_i, l = std::log(ri), sq = std::sqrt(ri);
+            c.ci_D3 = (FT)(6.0 / pi / ((double)mp->cloud_ice.N_0 * ri));
+            c.ci_A = (FT)((double)t.A[1] * l * l - (double)t.A[2] * l + (double)t.A[0]);
+            c.ci_B = (FT)(1.0 / ((double)t.B[0] + (double)t.B[1] * l + (double)t.B[2] / sq));
+            c.ci_C = (FT)((double)t.C[0] + (double)t.C[1] * std::exp((double)t.C[2] * ri) + (double)t.C[3] * sq);
+            c.ci_E = (FT)((double)t.E[0] - (double)t.E[1] * l * l + (double)t.E[2] * sq);
+            c.ci_F = (FT)(-std::exp((double)t.F[0] - (double)t.F[1] * l * l + (double)t.F[2] * l));
+            c.ci_c2 = (FT)(1000.0 / ((double)t.G[0] + (double)t.G[1] / l - (double)t.G[2] * l / ri));
+        }
+        {   // large ice reduced at the snow apparent density — Common.jl:327-350; ϕ^κ Γ(b+4)/3! folded in (CM1:287-295)
+            const auto &t = chen_ice->large_ice;
+            const double ri = (double)mp->snow.rho_i, l = std::log(ri), sq = std::sqrt(ri);
+            const double Al = (double)t.A[0] + (double)t.A[1] * l + (double)t.A[2] / (ri * sq);
+            const double Bl = std::exp((double)t.B[0] + (double)t.B[1] * l * l + (double)t.B[2] * l);
+            const double Cl = std::exp((double)t.C[0] + (double)t.C[1] / l + (double)t.C[2] / ri);
+            const double El = (double)t.E[0] + (double)t.E[1] * l * sq + (double)t.E[2] * sq;
+            const double Fl = (double)t.F[0] + (double)t.F[1] * l - std::exp(std::log(-(double)t.F[2]) - ri);
+            const double Gl = 1.0 / ((double)t.G[0] + (double)t.G[1] * l * sq + (double)t.G[2] / sq);
+            const double Hl = (double)t.H[0] + (double)t.H[1] * ri * ri * sq + std::exp(std::log(-(double)t.H[2]) - ri);
+            const double pk = std::pow((double)mp->snow.phi, (double)mp->snow.kappa);
+            c.sn_A = (FT)Al; c.sn_b1 = (FT)Cl; c.sn_b2 = (FT)Fl; c.sn_H = (FT)Hl; c.sn_c2 = (FT)(1000.0 * Gl);
+            c.sn_a1 = (FT)(pk * Bl * std::pow(1000.0, Cl) * std::tgamma(Cl + 4.0) / 6.0);
+            c.sn_a2 = (FT)(pk * El * std::pow(1000.0, Fl) * std::tgamma(Fl + 4.0) / 6.0);
+        }
+    }
+    Vel1mIO<FT> io{rho, q_rai, q_sno, nullptr, nullptr, w_rai, q_lcl, q_icl, w_lcl, w_icl, w_sno};
     hipLaunchKernelGGL((mp1m_velocity_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                        reinterpret_cast<hipStream_t>(stream), c, io, n);
     CMX_HIP_TRY(hipGetLastError());
@@ -595,6 +693,21 @@ static int32_t velocity_1m_entry(const MP *mp, const CH *chen, int64_t n, const 
 }  // namespace cmx
 
 extern "C" {
+
+int32_t cmx_sedimentation_velocities_f32(const cmx_microphysics_1m_f32 *mp, const cmx_stokes_vel_f32 *stokes,
+                                         const cmx_chen2022_rain_vel_f32 *chen_rain, const cmx_chen2022_ice_vel_f32 *chen_ice, int64_t n,
+                                         const float *rho, const float *q_lcl, const float *q_icl, const float *q_rai, const float *q_sno,
+                                         float *w_lcl, float *w_icl, float *w_rai, float *w_sno, void *stream) {
+    return cmx::sedimentation_entry<float>(mp, stokes, chen_rain, chen_ice, n, rho, q_lcl, q_icl, q_rai, q_sno, w_lcl, w_icl, w_rai, w_sno,
+                                           stream);
+}
+int32_t cmx_sedimentation_velocities_f64(const cmx_microphysics_1m_f64 *mp, const cmx_stokes_vel_f64 *stokes,
+                                         const cmx_chen2022_rain_vel_f64 *chen_rain, const cmx_chen2022_ice_vel_f64 *chen_ice, int64_t n,
+                                         const double *rho, const double *q_lcl, const double *q_icl, const double *q_rai,
+                                         const double *q_sno, double *w_lcl, double *w_icl, double *w_rai, double *w_sno, void *stream) {
+    return cmx::sedimentation_entry<double>(mp, stokes, chen_rain, chen_ice, n, rho, q_lcl, q_icl, q_rai, q_sno, w_lcl, w_icl, w_rai, w_sno,
+                                            stream);
+}
 
 int32_t cmx_mp1m_linearized_average_f32(const cmx_microphysics_1m_f32 *mp, const cmx_thermo_f32 *tps, uint32_t flags, float q_min, float dt,
                                         int32_t nsub, int64_t n, const float *rho, const float *T, const float *q_tot, const float *q_lcl,

@@ -479,6 +479,22 @@ int32_t cmx_mp1m_terminal_velocity_f64(const cmx_microphysics_1m_f64 *mp, const 
                                        int64_t n, const double *rho, const double *q_rai, const double *q_sno,
                                        double *vt_rai_blk1m, double *vt_sno_blk1m, double *vt_rai_chen, void *stream);
 
+/* The bulk sedimentation velocities a host model precomputes per cell (ClimaAtmos set_sedimentation_precomputed_quantities;
+ * test/gpu_clima_core_test.jl:36-45; KA kernel test_chen2022_terminal_velocity_kernel!, test/gpu_tests.jl:608-630):
+ *   w_lcl = CMNonEq.terminal_velocity(liquid, ::StokesRegimeVelType, ρ, q_lcl)          src/MicrophysicsNonEq.jl:250-265
+ *   w_icl = CMNonEq.terminal_velocity(ice, ::Chen2022VelTypeSmallIce, ρ, q_icl)         src/MicrophysicsNonEq.jl:267-281
+ *   w_rai = CM1.terminal_velocity(rain, ::Chen2022VelTypeRain, ρ, q_rai)                src/Microphysics1M.jl:251-270
+ *   w_sno = CM1.terminal_velocity(snow, ::Chen2022VelTypeLargeIce, ρ, q_sno)            src/Microphysics1M.jl:272-297
+ * Any (q, w) pair may be NULL together with the parameter struct only it needs. */
+int32_t cmx_sedimentation_velocities_f32(const cmx_microphysics_1m_f32 *mp, const cmx_stokes_vel_f32 *stokes,
+                                         const cmx_chen2022_rain_vel_f32 *chen_rain, const cmx_chen2022_ice_vel_f32 *chen_ice, int64_t n,
+                                         const float *rho, const float *q_lcl, const float *q_icl, const float *q_rai, const float *q_sno,
+                                         float *w_lcl, float *w_icl, float *w_rai, float *w_sno, void *stream);
+int32_t cmx_sedimentation_velocities_f64(const cmx_microphysics_1m_f64 *mp, const cmx_stokes_vel_f64 *stokes,
+                                         const cmx_chen2022_rain_vel_f64 *chen_rain, const cmx_chen2022_ice_vel_f64 *chen_ice, int64_t n,
+                                         const double *rho, const double *q_lcl, const double *q_icl, const double *q_rai,
+                                         const double *q_sno, double *w_lcl, double *w_icl, double *w_rai, double *w_sno, void *stream);
+
 /* ---------------------------------------------------------------------------
  * (6) Abdul-Razzak & Ghan (2000) aerosol activation.
  *

@@ -709,6 +709,7 @@ void FN(cmxo_sb2006_cloud_terminal_velocity)(const TY(cmx_cloud_pdf_sb2006) * pd
 #include "cmx_oracle_1m_impl.h"
 #include "cmx_oracle_arg_impl.h"
 #include "cmx_oracle_p3_impl.h"
+#include "cmx_oracle_sed_impl.h"
 
 #undef CAT_
 #undef CAT

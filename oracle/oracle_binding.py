@@ -195,6 +195,22 @@ def mp1m_linearize(fam, mp, tps, flags, q_min, rho, T, q_tot, q_lcl, q_icl, q_ra
     return dict(zip(("M11", "M12", "M22", "M31", "M33", "M34", "M41", "M42", "M43", "M44", "e1", "e2", "e4"), list(out)))
 
 
+def sedimentation_velocities(fam, mp, stokes, chen_rain, chen_ice, rho, q_lcl, q_icl, q_rai, q_sno, float32_gates=None):
+    """Oracle twin of cmx_sedimentation_velocities_*: dict(w_lcl, w_icl, w_rai, w_sno)."""
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    ins = [_col(fam, a) for a in (rho, q_lcl, q_icl, q_rai, q_sno)]
+    n = ins[0][0].size
+    names = ("w_lcl", "w_icl", "w_rai", "w_sno")
+    outs = [np.empty(n, dtype=NP[fam.sfx]) for _ in names]
+    fn = getattr(lib(), f"cmxo_sedimentation_velocities_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(mp), C.byref(stokes), C.byref(chen_rain), C.byref(chen_ice), C.byref(th), C.c_int64(n), *[p for _, p in ins],
+       *[o.ctypes.data_as(C.c_void_p) for o in outs])
+    return dict(zip(names, outs))
+
+
 def mp1m_terminal_velocity(fam, mp, chen, rho, q_rai, q_sno, float32_gates=None):
     if float32_gates is None:
         float32_gates = fam.sfx == "f32"

@@ -191,3 +191,35 @@ def test_full_size_1e8_f32_properties(dev, oracle):
     got = {k: getattr(full, k)[::stride].contiguous().cpu().numpy() for k in TN}
     rep = parity.assert_parity(got, ref, parity.RTOL["f32"], names=TN, what="1M 1e8 f32 sample")
     print(f"\n[1M parity 1e8 f32, {samp[0].size} sampled points] {rep}")
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_sedimentation_velocities(dev, oracle, ft):
+    """cmx_sedimentation_velocities_*: the reference's KATs (test/gpu_tests.jl:608-630) through the C ABI + random parity."""
+    import cmx
+    dt = DT[ft]
+    g = G["chen2022_sedimentation_velocities"]
+    mp = P.Microphysics1MParams(ft)
+    par = (P.StokesRegimeVelType(ft), P.Chen2022VelTypeRain(ft), P.Chen2022VelTypeIce(ft))
+    col = lambda v: torch.tensor(v, dtype=dt, device=dev)  # noqa: E731
+    r = cmx.sedimentation_velocities(mp, *par, col([g["rho"]]), col([g["q_lcl"]]), col([g["q_icl"]]), col([g["q_rai"]]), col([g["q_sno"]]))
+    for k in ("w_lcl", "w_icl", "w_rai", "w_sno"):
+        assert float(getattr(r, k)[0]) == pytest.approx(g[k], rel=1e-10 if ft == "f64" else 2e-5), k
+    only = cmx.sedimentation_velocities(mp, par[0], None, None, col([0.95]), q_lcl=col([0.004]))
+    assert only.w_icl is None and float(only.w_lcl[0]) == pytest.approx(g["w_lcl"], rel=1e-5)
+    n = 100_003
+    gen = torch.Generator().manual_seed(8)
+    rho = (0.3 + torch.rand(n, generator=gen, dtype=torch.float64)).to(dt)
+    qq = lambda: torch.where(torch.rand(n, generator=gen, dtype=torch.float64) < 0.15, torch.zeros(n, dtype=torch.float64),  # noqa: E731
+                             10 ** (-9 + 6.5 * torch.rand(n, generator=gen, dtype=torch.float64))).to(dt)
+    qs = [qq() for _ in range(4)]
+    got = cmx.sedimentation_velocities(mp, *par, rho.to(dev), *[q.to(dev) for q in qs])
+    mp64 = P.Microphysics1MParams("f64")
+    ref = oracle.sedimentation_velocities(_abi.F64, mp64.c, P.StokesRegimeVelType("f64"), P.Chen2022VelTypeRain("f64"),
+                                          P.Chen2022VelTypeIce("f64"), rho.numpy().astype(np.float64),
+                                          *[q.numpy().astype(np.float64) for q in qs], float32_gates=(ft == "f32"))
+    for k in ("w_lcl", "w_icl", "w_rai", "w_sno"):
+        x, rr = getattr(got, k).cpu().numpy().astype(np.float64), ref[k]
+        assert np.array_equal(x == 0, rr == 0), k
+        nz = rr != 0
+        assert np.max(np.abs(x[nz] - rr[nz]) / rr[nz]) <= (1e-6 if ft == "f64" else 1e-3), k

@@ -193,3 +193,16 @@ def test_float32_arithmetic_oracle_tracks_float64_1m(oracle):
     near = np.abs(cols[1].astype(np.float64) - 273.15) < 1e-4
     r64["near_branch"] = near
     parity.assert_parity(r32, r64, 1e-3, names=["dq_lcl_dt", "dq_icl_dt", "dq_rai_dt", "dq_sno_dt"], what="1M f32 oracle")
+
+
+def test_chen2022_sedimentation_velocity_kats(oracle):
+    """test/gpu_tests.jl:608-630: the four bulk fall speeds (cloud liquid Stokes, cloud ice / rain / snow Chen-2022)."""
+    g = G["chen2022_sedimentation_velocities"]
+    mp = P.Microphysics1MParams("f64")
+    r = oracle.sedimentation_velocities(F64, mp.c, P.StokesRegimeVelType("f64"), P.Chen2022VelTypeRain("f64"), P.Chen2022VelTypeIce("f64"),
+                                        [g["rho"]], [g["q_lcl"]], [g["q_icl"]], [g["q_rai"]], [g["q_sno"]])
+    for k in ("w_lcl", "w_icl", "w_rai", "w_sno"):
+        assert math.isclose(r[k][0], g[k], rel_tol=g["rtol"]), k
+    z = oracle.sedimentation_velocities(F64, mp.c, P.StokesRegimeVelType("f64"), P.Chen2022VelTypeRain("f64"), P.Chen2022VelTypeIce("f64"),
+                                        [1.0, 1.0], [0.0, -1e-9], [0.0, -1e-9], [0.0, -1e-9], [0.0, -1e-9])
+    assert all(np.all(v == 0) for v in z.values())
