@@ -17,6 +17,8 @@ CMX_VEL_SB2006 = 1 << 1
 CMX_VEL_CHEN2022 = 1 << 2
 
 CMX_ARG_MAX_MODES = 8
+CMX_2M_KK2000, CMX_2M_B1994, CMX_2M_TC1980, CMX_2M_LD2004 = 0, 1, 2, 3
+CMX_2M_SMOOTH_TRANSITION = 1 << 8
 CMX_P3_INPUT_IS_STATE = 1 << 0
 CMX_P3_SLOPE_CONSTANT = 1 << 1
 CMX_P3_NO_ASPECT_RATIO = 1 << 2
@@ -90,6 +92,12 @@ def _family(ft, sfx):
     ns.rain_pdf_sb2006 = _struct(f"cmx_rain_pdf_sb2006_{sfx}",
                                  s("nu_r", "mu_r", "xr_min", "xr_max", "N0_min", "N0_max",
                                    "lambda_min", "lambda_max", "rho_w", "rho_0"))
+    ns.kk2000 = _struct(f"cmx_kk2000_{sfx}", s("acnv_A", "acnv_a", "acnv_b", "acnv_c", "accr_A", "accr_a", "accr_b"))
+    ns.b1994 = _struct(f"cmx_b1994_{sfx}", s("acnv_C", "acnv_a", "acnv_b", "acnv_c", "acnv_N_0", "acnv_d_low", "acnv_d_high", "acnv_k", "accr_A"))
+    ns.tc1980 = _struct(f"cmx_tc1980_{sfx}", s("acnv_a", "acnv_b", "acnv_D", "acnv_r_0", "acnv_me_liq", "acnv_m0_liq_coeff", "acnv_k", "accr_A"))
+    ns.ld2004 = _struct(f"cmx_ld2004_{sfx}", s("R_6C_0", "E_0", "rho_w", "k"))
+    ns.bulk_2m_schemes = _struct(f"cmx_bulk_2m_schemes_{sfx}", [("kk2000", ns.kk2000), ("b1994", ns.b1994), ("tc1980", ns.tc1980),
+                                                                  ("ld2004", ns.ld2004)])
     ns.stokes_vel = _struct(f"cmx_stokes_vel_{sfx}", s("rho_w", "nu_air", "grav"))
     ns.acnv_sb2006 = _struct(f"cmx_acnv_sb2006_{sfx}", s("kcc", "x_star", "rho_0", "A", "a", "b"))
     ns.accr_sb2006 = _struct(f"cmx_accr_sb2006_{sfx}", s("kcr", "tau_0", "rho_0", "c"))

@@ -57,6 +57,9 @@ def _declare(lib):
         f = getattr(lib, f"cmx_mp1m_tendencies_{s}")
         f.restype = i32
         f.argtypes = [C.POINTER(fam.microphysics_1m), C.POINTER(fam.thermo), u32, i64] + [vp] * 11 + [vp]
+        f = getattr(lib, f"cmx_bulk_2m_cloud_to_rain_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.bulk_2m_schemes), u32, i64] + [vp] * 6 + [vp]
         f = getattr(lib, f"cmx_sedimentation_velocities_{s}")
         f.restype = i32
         f.argtypes = [C.POINTER(fam.microphysics_1m), C.POINTER(fam.stokes_vel), C.POINTER(fam.chen2022_rain_vel),

@@ -182,3 +182,35 @@ def cloud_terminal_velocity(pdf_c, vel, q_liq, rho, N_liq, *, stream=None) -> Cl
                 C.c_void_p(s.cuda_stream))
     _lib.check(fn.__name__, st)
     return out
+
+
+_SCHEMES_2M = {"KK2000": _abi.CMX_2M_KK2000, "B1994": _abi.CMX_2M_B1994, "TC1980": _abi.CMX_2M_TC1980, "LD2004": _abi.CMX_2M_LD2004}
+CloudToRain2M = namedtuple("CloudToRain2M", ["acnv", "accr"])
+
+
+def bulk_2m_cloud_to_rain(schemes, scheme: str, q_lcl, rho, N_d=None, q_rai=None, *, smooth_transition=False,
+                          stream=None) -> CloudToRain2M:
+    """`CM2.conv_q_lcl_to_q_rai.(Ref(scheme), q_lcl, ρ, N_d[, smooth_transition])` (→ `acnv`, needs N_d [1/m³]) and
+    `CM2.accretion.(Ref(scheme), q_lcl, q_rai, ρ)` (→ `accr`, needs q_rai) for scheme ∈ KK2000 | B1994 | TC1980 | LD2004
+    (src/Microphysics2M.jl:920-1003); `schemes` = parameters.Bulk2MSchemes(FT)."""
+    if scheme not in _SCHEMES_2M:
+        raise ValueError(f"scheme must be one of {sorted(_SCHEMES_2M)}")
+    if scheme == "LD2004" and q_rai is not None:
+        raise ValueError("LD2004 has no accretion parameterization")
+    cols = [c for c in (q_lcl, rho, N_d, q_rai) if c is not None]
+    ref = _check_cols(cols, ["q_lcl", "rho", "N_d", "q_rai"][:len(cols)])
+    fam = _fam_of(ref)
+    if not isinstance(schemes, fam.bulk_2m_schemes):
+        raise TypeError("parameter float type does not match the state columns")
+    if N_d is None and q_rai is None:
+        raise ValueError("pass N_d (autoconversion) and / or q_rai (accretion)")
+    acnv = torch.empty_like(ref) if N_d is not None else None
+    accr = torch.empty_like(ref) if q_rai is not None else None
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_bulk_2m_cloud_to_rain_{fam.sfx}")
+    flags = _SCHEMES_2M[scheme] | (_abi.CMX_2M_SMOOTH_TRANSITION if smooth_transition else 0)
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(schemes), flags, ref.numel(), _ptr(q_lcl), _ptr(q_rai), _ptr(rho), _ptr(N_d), _ptr(acnv), _ptr(accr),
+                C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return CloudToRain2M(acnv, accr)

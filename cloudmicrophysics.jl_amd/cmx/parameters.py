@@ -161,6 +161,16 @@ DEFAULT_PARAMETERS = {
     "M1996_area_coeff_gamma": 0.2285, "M1996_area_exponent_sigma": 1.88,
     "Heymsfield_mu_coeff1": 0.00191, "Heymsfield_mu_coeff2": 0.8, "Heymsfield_mu_coeff3": 2.0, "Heymsfield_mu_cutoff": 6.0,
     "P3_constant_slope_parameterization_value": 0.0,   # SlopeConstant default (unpinned; only used with slope_law="constant")
+    # bulk 2M autoconversion / accretion variants — docs/src/Microphysics2M.md:690-880; pinned by test/gpu_tests.jl:782-818
+    "KK2000_autoconversion_coeff_A": 7.42e13, "KK2000_autoconversion_coeff_a": 2.47, "KK2000_autoconversion_coeff_b": -1.79,
+    "KK2000_autoconversion_coeff_c": -1.47, "KK2000_accretion_coeff_A": 67.0, "KK2000_accretion_coeff_a": 1.15,
+    "KK2000_accretion_coeff_b": -1.3,
+    "B1994_autoconversion_coeff_C": 3e34, "B1994_autoconversion_coeff_a": -1.7, "B1994_autoconversion_coeff_b": 4.7,
+    "B1994_autoconversion_coeff_c": -3.3, "B1994_autoconversion_coeff_N_0": 2e8, "B1994_autoconversion_coeff_d_low": 3.9,
+    "B1994_autoconversion_coeff_d_high": 9.9, "B1994_accretion_coeff_A": 6.0,
+    "TC1980_autoconversion_coeff_a": 7.0 / 3.0, "TC1980_autoconversion_coeff_b": -1.0 / 3.0, "TC1980_autoconversion_coeff_D": 3268.0,
+    "TC1980_autoconversion_coeff_r_0": 7e-6, "TC1980_autoconversion_coeff_me_liq": 3.0, "TC1980_accretion_coeff_A": 4.7,
+    "LD2004_R_6C_coeff": 7.5, "LD2004_E_0_coeff": 1.08e10,
     "P3_wet_growth_timescale": 100.0,                  # not read by the shape solver
     # TD.Parameters.q_min(tps): donor floor of the 1M LinearizedAverage linearization (BMT:395); ClimaParams value not
     # in the tree and not pinned by any reference test (only states with a hydrometeor below it are affected)
@@ -236,6 +246,27 @@ def ThermodynamicsParameters(FT):
         T_0=td["thermodynamics_temperature_reference"], T_triple=td["temperature_triple_point"],
         press_triple=td["pressure_triple_point"], T_freeze=td["temperature_water_freeze"],
         cv_l=td["isochoric_specific_heat_liquid"])
+
+
+def Bulk2MSchemes(FT):
+    """CMP.KK2000(FT), CMP.B1994(FT), CMP.TC1980(FT), CMP.LD2004(FT) bundled (include/cmx.h: cmx_bulk_2m_schemes) —
+    src/parameters/Microphysics2M.jl:11-279."""
+    td = _td(FT)
+    f = td.fam
+    k = td["threshold_smooth_transition_steepness"]
+    return f.bulk_2m_schemes(
+        kk2000=f.kk2000(acnv_A=td["KK2000_autoconversion_coeff_A"], acnv_a=td["KK2000_autoconversion_coeff_a"],
+                        acnv_b=td["KK2000_autoconversion_coeff_b"], acnv_c=td["KK2000_autoconversion_coeff_c"],
+                        accr_A=td["KK2000_accretion_coeff_A"], accr_a=td["KK2000_accretion_coeff_a"], accr_b=td["KK2000_accretion_coeff_b"]),
+        b1994=f.b1994(acnv_C=td["B1994_autoconversion_coeff_C"], acnv_a=td["B1994_autoconversion_coeff_a"],
+                      acnv_b=td["B1994_autoconversion_coeff_b"], acnv_c=td["B1994_autoconversion_coeff_c"],
+                      acnv_N_0=td["B1994_autoconversion_coeff_N_0"], acnv_d_low=td["B1994_autoconversion_coeff_d_low"],
+                      acnv_d_high=td["B1994_autoconversion_coeff_d_high"], acnv_k=k, accr_A=td["B1994_accretion_coeff_A"]),
+        tc1980=f.tc1980(acnv_a=td["TC1980_autoconversion_coeff_a"], acnv_b=td["TC1980_autoconversion_coeff_b"],
+                        acnv_D=td["TC1980_autoconversion_coeff_D"], acnv_r_0=td["TC1980_autoconversion_coeff_r_0"],
+                        acnv_me_liq=td["TC1980_autoconversion_coeff_me_liq"],
+                        acnv_m0_liq_coeff=td["density_liquid_water"] * 4 / 3 * math.pi, acnv_k=k, accr_A=td["TC1980_accretion_coeff_A"]),
+        ld2004=f.ld2004(R_6C_0=td["LD2004_R_6C_coeff"], E_0=td["LD2004_E_0_coeff"], rho_w=td["density_liquid_water"], k=k))
 
 
 def StokesRegimeVelType(FT):

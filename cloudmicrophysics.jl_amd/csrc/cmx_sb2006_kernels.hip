@@ -162,9 +162,117 @@ static int32_t cloud_velocity_entry(const PDF *pdf, const VEL *vel, int64_t n, c
     return CMX_OK;
 }
 
+// ---- bulk 2M cloud → rain conversion of KK2000 / B1994 / TC1980 / LD2004 — Microphysics2M.jl:920-1003 -------------------
+// Four 1-line power laws; every power in the log2 domain on the hardware units; one point per lane (16–24 B/point).
+template <typename FT> struct Bulk2mConsts {
+    uint32_t scheme; FT eps_1m, eps_m;
+    FT kk_l2A, kk_a, kk_b, kk_c, kk_accr_A, kk_accr_a, kk_accr_b;
+    FT b_l2C, b_a, b_b, b_c, b_N_0, b_d_low, b_d_high, b_k, b_accr_A;
+    FT t_a, t_b, t_D, t_thr_c, t_k, t_accr_A;                    // threshold = t_thr_c · N_d / ρ
+    FT l_rvol_c, l_E_0, l_R_6C_0, l_k;                           // r_vol³ = l_rvol_c · q ρ / N_d  [µm³]
+};
+template <typename FT> __device__ __forceinline__ FT logistic_dev(FT x, FT x_0, FT k, FT eps) {   // Common.jl:125-139
+    using M = Math<FT>;
+    x = M::max(FT(0), x);
+    const FT xs = M::max(x, eps), x0s = M::max(x_0, eps);
+    const FT z = k * (xs * M::rcp(x0s) - x0s * M::rcp(xs));
+    // σ(z) = 1/(1 + e^{−z}); e^{−z} may overflow to +Inf → σ = 0, the correct limit
+    const FT r = M::rcp(FT(1) + M::exp2(-z * FT(1.4426950408889634)));
+    return x < eps ? FT(0) : (x_0 < eps ? FT(1) : r);
+}
+template <typename FT>
+__global__ __launch_bounds__(kBlock) void bulk_2m_cloud_to_rain_kernel(const Bulk2mConsts<FT> c, const FT *__restrict__ q_lcl,
+                                                                       const FT *__restrict__ q_rai, const FT *__restrict__ rho,
+                                                                       const FT *__restrict__ N_d, FT *__restrict__ acnv,
+                                                                       FT *__restrict__ accr, const int64_t n) {
+    using M = Math<FT>;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t sch = c.scheme & 0xffu;
+    const bool smooth = c.scheme & CMX_2M_SMOOTH_TRANSITION;
+    const FT ql_raw = q_lcl[i], r = rho[i];
+    const FT ql = M::max(FT(0), ql_raw);
+    if (acnv) {
+        const FT Nd = N_d[i];
+        const FT l2q = M::log2(ql), l2N = M::log2(Nd), l2r = M::log2(r);
+        FT v;
+        if (sch == CMX_2M_KK2000) {
+            v = M::exp2(c.kk_l2A + c.kk_a * l2q + c.kk_b * l2N + c.kk_c * l2r);
+        } else if (sch == CMX_2M_B1994) {
+            FT d;
+            if (smooth) {
+                const FT f = logistic_dev<FT>(Nd, c.b_N_0, c.b_k, c.eps_1m);
+                d = f * c.b_d_low + (FT(1) - f) * c.b_d_high;
+            } else {
+                d = Nd >= c.b_N_0 ? c.b_d_low : c.b_d_high;
+            }
+            v = M::exp2(c.b_l2C + c.b_a * M::log2(d) + c.b_b * (l2q + l2r) + c.b_c * l2N - l2r);
+        } else if (sch == CMX_2M_TC1980) {
+            const FT thr = c.t_thr_c * Nd * M::rcp(r);
+            const FT out = smooth ? logistic_dev<FT>(ql, thr, c.t_k, c.eps_1m) : (ql - thr > FT(0) ? FT(1) : FT(0));
+            v = c.t_D * M::exp2(c.t_a * l2q + c.t_b * l2N) * out;
+        } else {   // LD2004 (:948-972): everything from r_vol [µm]
+            const FT l2_rv3 = M::log2(c.l_rvol_c * ql_raw * r * M::rcp(Nd));
+            const FT r_vol = M::exp2(l2_rv3 * FT(1.0 / 3.0));
+            const FT l2_b6 = FT(1.0 / 3.0) * M::log2((r_vol + FT(3)) * M::rcp(r_vol));
+            const FT R_6 = M::exp2(l2_b6) * r_vol;
+            const FT l2_qr = M::log2(ql_raw * r);
+            const FT R_6C = c.l_R_6C_0 * M::exp2(FT(-1.0 / 6.0) * l2_qr) * M::rsqrt(R_6);
+            const FT out = smooth ? logistic_dev<FT>(R_6, R_6C, c.l_k, c.eps_1m) : (R_6 - R_6C > FT(0) ? FT(1) : FT(0));
+            const FT val = c.l_E_0 * M::exp2(FT(6) * l2_b6 + FT(3) * l2_qr - l2N - l2r) * out;
+            v = ql_raw <= c.eps_m ? FT(0) : val;
+        }
+        acnv[i] = v;
+    }
+    if (accr) {
+        const FT qr = M::max(FT(0), q_rai[i]);
+        FT v;
+        if (sch == CMX_2M_KK2000) v = c.kk_accr_A * M::exp2(c.kk_accr_a * M::log2(ql * qr) + c.kk_accr_b * M::log2(r));
+        else if (sch == CMX_2M_B1994) v = c.b_accr_A * ql * r * qr;
+        else v = c.t_accr_A * ql * qr;
+        accr[i] = v;
+    }
+}
+
+template <typename FT, typename SC>
+static int32_t bulk_2m_entry(const SC *p, uint32_t scheme, int64_t n, const FT *q_lcl, const FT *q_rai, const FT *rho, const FT *N_d,
+                             FT *acnv, FT *accr, void *stream) {
+    const uint32_t sch = scheme & 0xffu;
+    if (!p || n < 0 || sch > CMX_2M_LD2004 || (scheme & ~(0xffu | CMX_2M_SMOOTH_TRANSITION))) return CMX_ERR_BAD_ARG;
+    if (sch == CMX_2M_LD2004 && accr) return CMX_ERR_BAD_ARG;
+    if (n == 0) return CMX_OK;
+    if (!q_lcl || !rho || (acnv && !N_d) || (accr && !q_rai) || (!acnv && !accr)) return CMX_ERR_BAD_ARG;
+    const double pi = 3.14159265358979323846;
+    Bulk2mConsts<FT> c{};
+    c.scheme = scheme; c.eps_1m = Math<FT>::eps_1m(); c.eps_m = Math<FT>::eps();
+    c.kk_l2A = (FT)std::log2((double)p->kk2000.acnv_A); c.kk_a = p->kk2000.acnv_a; c.kk_b = p->kk2000.acnv_b; c.kk_c = p->kk2000.acnv_c;
+    c.kk_accr_A = p->kk2000.accr_A; c.kk_accr_a = p->kk2000.accr_a; c.kk_accr_b = p->kk2000.accr_b;
+    c.b_l2C = (FT)std::log2((double)p->b1994.acnv_C); c.b_a = p->b1994.acnv_a; c.b_b = p->b1994.acnv_b; c.b_c = p->b1994.acnv_c;
+    c.b_N_0 = p->b1994.acnv_N_0; c.b_d_low = p->b1994.acnv_d_low; c.b_d_high = p->b1994.acnv_d_high; c.b_k = p->b1994.acnv_k;
+    c.b_accr_A = p->b1994.accr_A;
+    c.t_a = p->tc1980.acnv_a; c.t_b = p->tc1980.acnv_b; c.t_D = p->tc1980.acnv_D; c.t_k = p->tc1980.acnv_k; c.t_accr_A = p->tc1980.accr_A;
+    c.t_thr_c = (FT)((double)p->tc1980.acnv_m0_liq_coeff * std::pow((double)p->tc1980.acnv_r_0, (double)p->tc1980.acnv_me_liq));
+    c.l_rvol_c = (FT)(3.0 / 4.0 / pi / (double)p->ld2004.rho_w * 1e18);
+    c.l_E_0 = p->ld2004.E_0; c.l_R_6C_0 = p->ld2004.R_6C_0; c.l_k = p->ld2004.k;
+    hipLaunchKernelGGL((bulk_2m_cloud_to_rain_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), c, q_lcl, q_rai, rho, N_d, acnv, accr, n);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+
 }  // namespace cmx
 
 extern "C" {
+
+int32_t cmx_bulk_2m_cloud_to_rain_f32(const cmx_bulk_2m_schemes_f32 *schemes, uint32_t scheme, int64_t n, const float *q_lcl,
+                                      const float *q_rai, const float *rho, const float *N_d, float *acnv, float *accr, void *stream) {
+    return cmx::bulk_2m_entry<float>(schemes, scheme, n, q_lcl, q_rai, rho, N_d, acnv, accr, stream);
+}
+int32_t cmx_bulk_2m_cloud_to_rain_f64(const cmx_bulk_2m_schemes_f64 *schemes, uint32_t scheme, int64_t n, const double *q_lcl,
+                                      const double *q_rai, const double *rho, const double *N_d, double *acnv, double *accr,
+                                      void *stream) {
+    return cmx::bulk_2m_entry<double>(schemes, scheme, n, q_lcl, q_rai, rho, N_d, acnv, accr, stream);
+}
 
 int32_t cmx_sb2006_cloud_terminal_velocity_f32(const cmx_cloud_pdf_sb2006_f32 *pdf_c, const cmx_stokes_vel_f32 *vel, int64_t n,
                                                const float *q_liq, const float *rho, const float *N_liq, float *vt_n, float *vt_m,

@@ -117,6 +117,20 @@ typedef enum cmx_status {
         FT R_v, R_d, cp_d, cp_v, cp_l, cp_i, LH_v0, LH_s0, T_0, T_triple, press_triple,        \
             T_freeze, cv_l;                                                                    \
     } cmx_thermo_##SFX;                                                                        \
+    /* KK2000 / B1994 / TC1980 / LD2004 bulk two-moment autoconversion and accretion parameter */ \
+    /* sets — src/parameters/Microphysics2M.jl:11-75, 89-160, 172-240, 258-279                 */ \
+    typedef struct cmx_kk2000_##SFX { FT acnv_A, acnv_a, acnv_b, acnv_c, accr_A, accr_a, accr_b; } cmx_kk2000_##SFX; \
+    typedef struct cmx_b1994_##SFX {                                                           \
+        FT acnv_C, acnv_a, acnv_b, acnv_c, acnv_N_0, acnv_d_low, acnv_d_high, acnv_k, accr_A;  \
+    } cmx_b1994_##SFX;                                                                         \
+    typedef struct cmx_tc1980_##SFX {                                                          \
+        FT acnv_a, acnv_b, acnv_D, acnv_r_0, acnv_me_liq, acnv_m0_liq_coeff, acnv_k, accr_A;   \
+    } cmx_tc1980_##SFX;                                                                        \
+    typedef struct cmx_ld2004_##SFX { FT R_6C_0, E_0, rho_w, k; } cmx_ld2004_##SFX;            \
+    typedef struct cmx_bulk_2m_schemes_##SFX {                                                 \
+        cmx_kk2000_##SFX kk2000; cmx_b1994_##SFX b1994; cmx_tc1980_##SFX tc1980;               \
+        cmx_ld2004_##SFX ld2004;                                                               \
+    } cmx_bulk_2m_schemes_##SFX;                                                               \
     /* StokesRegimeVelType — src/parameters/TerminalVelocity.jl:150-154 */                     \
     typedef struct cmx_stokes_vel_##SFX { FT rho_w, nu_air, grav; } cmx_stokes_vel_##SFX;      \
     /* SB2006VelType — src/parameters/TerminalVelocity.jl:174-182 */                           \
@@ -340,6 +354,23 @@ int32_t cmx_sb2006_cloud_terminal_velocity_f32(const cmx_cloud_pdf_sb2006_f32 *p
 int32_t cmx_sb2006_cloud_terminal_velocity_f64(const cmx_cloud_pdf_sb2006_f64 *pdf_c, const cmx_stokes_vel_f64 *vel, int64_t n,
                                                const double *q_liq, const double *rho, const double *N_liq, double *vt_n, double *vt_m,
                                                void *stream);
+
+/* Bulk cloud → rain conversion of the other two-moment schemes — src/Microphysics2M.jl:920-1003:
+ *   acnv = CM2.conv_q_lcl_to_q_rai(scheme, q_lcl, ρ, N_d[, smooth_transition])     KK2000 | B1994 | TC1980 | LD2004
+ *   accr = CM2.accretion(scheme, q_lcl, q_rai, ρ)                                   KK2000 | B1994 | TC1980
+ * (KA kernels test_2_moment_acnv_kernel! / test_2_moment_accr_kernel!, test/gpu_tests.jl:782-818).  `scheme` is one of
+ * CMX_2M_KK2000 … CMX_2M_LD2004; CMX_2M_SMOOTH_TRANSITION selects the logistic threshold (src/Common.jl:125-139) instead
+ * of the step.  N_d per m³.  accr (and q_rai) may be NULL; LD2004 has no accretion (accr must be NULL). */
+#define CMX_2M_KK2000 0u
+#define CMX_2M_B1994 1u
+#define CMX_2M_TC1980 2u
+#define CMX_2M_LD2004 3u
+#define CMX_2M_SMOOTH_TRANSITION (1u << 8)
+int32_t cmx_bulk_2m_cloud_to_rain_f32(const cmx_bulk_2m_schemes_f32 *schemes, uint32_t scheme, int64_t n, const float *q_lcl,
+                                      const float *q_rai, const float *rho, const float *N_d, float *acnv, float *accr, void *stream);
+int32_t cmx_bulk_2m_cloud_to_rain_f64(const cmx_bulk_2m_schemes_f64 *schemes, uint32_t scheme, int64_t n, const double *q_lcl,
+                                      const double *q_rai, const double *rho, const double *N_d, double *acnv, double *accr,
+                                      void *stream);
 
 /* ---------------------------------------------------------------------------
  * (4) Ice nucleation rates — ABIFM immersion freezing + Koop-2000 homogeneous freezing.

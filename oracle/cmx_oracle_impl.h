@@ -706,6 +706,72 @@ void FN(cmxo_sb2006_cloud_terminal_velocity)(const TY(cmx_cloud_pdf_sb2006) * pd
         FN(o_cloud_terminal_velocity)(pdf, v->rho_w, v->grav, v->nu_air, q_liq[i], rho[i], N_liq[i], th, &vt0[i], &vt1[i]);
 }
 
+/* ---- bulk 2M cloud → rain conversion of KK2000 / B1994 / TC1980 / LD2004 — src/Microphysics2M.jl:920-1003 -------- */
+/* CO.logistic_function — src/Common.jl:125-139 (log1pexp: LogExpFunctions, stable form) */
+static inline FT FN(o_logistic_function)(FT x, FT x_0, FT k, FT eps) {
+    x = FN(o_max)((FT)0, x);
+    FT xs = FN(o_max)(x, eps), x0s = FN(o_max)(x_0, eps);
+    FT z = k * (xs / x0s - x0s / xs);
+    FT mz = -z;
+    FT l1pe = mz > 0 ? mz + M_LOG1P(M_EXP(-mz)) : M_LOG1P(M_EXP(mz));
+    FT r = M_EXP(-l1pe);
+    return x < eps ? (FT)0 : (x_0 < eps ? (FT)1 : r);
+}
+static inline FT FN(o_acnv_2m)(const TY(cmx_bulk_2m_schemes) * p, uint32_t scheme, const TY(cmxo_thresholds) * th, FT q_lcl, FT rho, FT N_d) {
+    const int smooth = (scheme & CMX_2M_SMOOTH_TRANSITION) != 0;
+    const FT eps = th->eps_1m;
+    switch (scheme & 0xffu) {
+    case CMX_2M_KK2000: {
+        FT q = FN(o_max)((FT)0, q_lcl);
+        return p->kk2000.acnv_A * M_POW(q, p->kk2000.acnv_a) * M_POW(N_d, p->kk2000.acnv_b) * M_POW(rho, p->kk2000.acnv_c);
+    }
+    case CMX_2M_B1994: {
+        const TY(cmx_b1994) *b = &p->b1994;
+        FT q = FN(o_max)((FT)0, q_lcl), d;
+        if (smooth) {
+            FT f_low = FN(o_logistic_function)(N_d, b->acnv_N_0, b->acnv_k, eps);
+            d = f_low * b->acnv_d_low + (1 - f_low) * b->acnv_d_high;
+        } else {
+            d = N_d >= b->acnv_N_0 ? b->acnv_d_low : b->acnv_d_high;
+        }
+        return b->acnv_C * M_POW(d, b->acnv_a) * M_POW(q * rho, b->acnv_b) * M_POW(N_d, b->acnv_c) / rho;
+    }
+    case CMX_2M_TC1980: {
+        const TY(cmx_tc1980) *t = &p->tc1980;
+        FT q = FN(o_max)((FT)0, q_lcl);
+        FT thr = t->acnv_m0_liq_coeff * N_d / rho * M_POW(t->acnv_r_0, t->acnv_me_liq);
+        FT out = smooth ? FN(o_logistic_function)(q, thr, t->acnv_k, eps) : (FT)(q - thr > 0);
+        return t->acnv_D * M_POW(q, t->acnv_a) * M_POW(N_d, t->acnv_b) * out;
+    }
+    default: {   /* LD2004 */
+        const TY(cmx_ld2004) *l = &p->ld2004;
+        if (q_lcl <= th->eps_m) return 0;
+        FT r_vol = M_CBRT(3 * q_lcl * rho / 4 / (FT)M_PI / l->rho_w / N_d) * 1000000;
+        FT beta_6 = M_CBRT((r_vol + 3) / r_vol);
+        FT E = l->E_0 * M_POW(beta_6, (FT)6);
+        FT R_6 = beta_6 * r_vol;
+        FT R_6C = l->R_6C_0 / M_CBRT(M_SQRT(q_lcl * rho)) / M_SQRT(R_6);
+        FT out = smooth ? FN(o_logistic_function)(R_6, R_6C, l->k, eps) : (FT)(R_6 - R_6C > 0);
+        return E * M_POW(q_lcl * rho, (FT)3) / N_d / rho * out;
+    }
+    }
+}
+static inline FT FN(o_accr_2m)(const TY(cmx_bulk_2m_schemes) * p, uint32_t scheme, FT q_lcl, FT q_rai, FT rho) {
+    FT ql = FN(o_max)((FT)0, q_lcl), qr = FN(o_max)((FT)0, q_rai);
+    switch (scheme & 0xffu) {
+    case CMX_2M_KK2000: return p->kk2000.accr_A * M_POW(ql * qr, p->kk2000.accr_a) * M_POW(rho, p->kk2000.accr_b);
+    case CMX_2M_B1994: return p->b1994.accr_A * ql * rho * qr;
+    default: return p->tc1980.accr_A * ql * qr;
+    }
+}
+void FN(cmxo_bulk_2m_cloud_to_rain)(const TY(cmx_bulk_2m_schemes) * p, uint32_t scheme, const TY(cmxo_thresholds) * th, int64_t n,
+                                   const FT *q_lcl, const FT *q_rai, const FT *rho, const FT *N_d, FT *acnv, FT *accr) {
+    for (int64_t i = 0; i < n; ++i) {
+        if (acnv) acnv[i] = FN(o_acnv_2m)(p, scheme, th, q_lcl[i], rho[i], N_d[i]);
+        if (accr) accr[i] = FN(o_accr_2m)(p, scheme, q_lcl[i], q_rai[i], rho[i]);
+    }
+}
+
 #include "cmx_oracle_1m_impl.h"
 #include "cmx_oracle_arg_impl.h"
 #include "cmx_oracle_p3_impl.h"

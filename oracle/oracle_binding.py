@@ -387,6 +387,23 @@ def cloud_terminal_velocity(fam, pdf_c, rho_w, grav, nu_air, q_liq, rho, N_liq, 
     return out[0], out[1]
 
 
+def bulk_2m_cloud_to_rain(fam, schemes, scheme, q_lcl, q_rai, rho, N_d, float32_gates=None):
+    """Oracle twin of cmx_bulk_2m_cloud_to_rain_*: (acnv, accr) columns (accr None for LD2004 / q_rai None)."""
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    want_accr = q_rai is not None and (scheme & 0xff) != _abi.CMX_2M_LD2004
+    ins = [_col(fam, a) if a is not None else (None, None) for a in (q_lcl, q_rai, rho, N_d)]
+    n = ins[0][0].size
+    acnv = np.empty(n, dtype=NP[fam.sfx])
+    accr = np.empty(n, dtype=NP[fam.sfx]) if want_accr else None
+    fn = getattr(lib(), f"cmxo_bulk_2m_cloud_to_rain_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(schemes), C.c_uint32(scheme), C.byref(th), C.c_int64(n), *[p for _, p in ins], acnv.ctypes.data_as(C.c_void_p),
+       accr.ctypes.data_as(C.c_void_p) if want_accr else None)
+    return acnv, accr
+
+
 def sb2006_cloud_terminal_velocity(fam, pdf_c, vel, q_liq, rho, N_liq, float32_gates=None):
     """Oracle twin of cmx_sb2006_cloud_terminal_velocity_*: (vt_n, vt_m) columns."""
     if float32_gates is None:

@@ -41,7 +41,7 @@ def test_struct_layout_matches_c(tmp_path):
     for fam in (_abi.F32, _abi.F64):
         for name in ("cloud_pdf_sb2006", "rain_pdf_sb2006", "acnv_sb2006", "accr_sb2006", "selfcol_sb2006",
                      "breakup_sb2006", "evap_sb2006", "numadj_horn2012", "sb2006", "air_properties", "warm_rain_2m",
-                     "thermo", "stokes_vel", "sb2006_vel", "chen2022_rain_vel", "rain_vel", "koop2000", "abifm_dust",
+                     "thermo", "kk2000", "b1994", "tc1980", "ld2004", "bulk_2m_schemes", "stokes_vel", "sb2006_vel", "chen2022_rain_vel", "rain_vel", "koop2000", "abifm_dust",
                      "particle_mass", "particle_area", "ventilation", "acnv_1m", "var_timescale_acnv", "cloud_liquid",
                      "cloud_ice", "rain", "snow", "blk1m_vel_rain", "blk1m_vel_snow", "process_params_1m",
                      "microphysics_1m", "aerosol_activation_params", "aerosol_mode", "aerosol_distribution",

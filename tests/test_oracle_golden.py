@@ -280,3 +280,33 @@ def test_float32_arithmetic_oracle_tracks_float64(oracle):
         r32 = oracle.sb2006_warm_rain_tendencies(_abi.F32, P.WarmRainParams2M("f32", limited).c, P.ThermodynamicsParameters("f32"),
                                                  P.rain_vel_params("f32"), fl, *cols, nthreads=4)
         parity.assert_parity(r32, r64, 1e-3, what=f"f32-oracle limited={limited}")
+
+
+def test_bulk_2m_autoconversion_and_accretion_variants(oracle, golden):
+    """KK2000 / B1994 / TC1980 / LD2004 (src/Microphysics2M.jl:920-1003) against test/gpu_tests.jl:782-818, plus the limits
+    the reference's CPU tests assert (test/microphysics2M_tests.jl:20-85): zero cloud water → zero rate, thresholds."""
+    from cmx import _abi
+    from cmx import parameters as P
+    g = golden["bulk_2m_variants"]
+    sc = P.Bulk2MSchemes("f64")
+    ids = {"KK2000": _abi.CMX_2M_KK2000, "B1994": _abi.CMX_2M_B1994, "TC1980": _abi.CMX_2M_TC1980, "LD2004": _abi.CMX_2M_LD2004}
+    for name, exp in g["acnv"].items():
+        a, _ = oracle.bulk_2m_cloud_to_rain(_abi.F64, sc, ids[name], [g["q_lcl"]], None, [g["rho"]], [g["N_d"]])
+        assert math.isclose(a[0], exp, rel_tol=g["rtol_acnv"]), name
+    for name, exp in g["accr"].items():
+        _, b = oracle.bulk_2m_cloud_to_rain(_abi.F64, sc, ids[name], [g["q_lcl"]], [g["q_rai"]], [g["rho"]], [g["N_d"]])
+        assert math.isclose(b[0], exp, rel_tol=g["rtol_accr"]), name
+    for name, sid in ids.items():
+        a, _ = oracle.bulk_2m_cloud_to_rain(_abi.F64, sc, sid, [0.0, -1e-6], None, [1.2, 1.2], [1e8, 1e8])
+        assert np.all(a == 0), name
+    # TC1980 threshold: q below 4/3 π ρw N_d r₀³ / ρ gives zero with the step, a small positive value with the logistic
+    thr = 4 / 3 * math.pi * 1000.0 * 1e8 * 7e-6 ** 3 / 1.2
+    a, _ = oracle.bulk_2m_cloud_to_rain(_abi.F64, sc, _abi.CMX_2M_TC1980, [0.9 * thr, 1.1 * thr], None, [1.2] * 2, [1e8] * 2)
+    assert a[0] == 0 and a[1] > 0
+    s, _ = oracle.bulk_2m_cloud_to_rain(_abi.F64, sc, _abi.CMX_2M_TC1980 | _abi.CMX_2M_SMOOTH_TRANSITION, [0.9 * thr, 1.1 * thr], None,
+                                        [1.2] * 2, [1e8] * 2)
+    assert 0 < s[0] < s[1] < a[1]
+    # B1994: d switches at N_0 = 2e8; the smooth version interpolates
+    a, _ = oracle.bulk_2m_cloud_to_rain(_abi.F64, sc, _abi.CMX_2M_B1994, [2e-3] * 2, None, [1.2] * 2, [1.9e8, 2.1e8])
+    s, _ = oracle.bulk_2m_cloud_to_rain(_abi.F64, sc, _abi.CMX_2M_B1994 | _abi.CMX_2M_SMOOTH_TRANSITION, [2e-3] * 2, None, [1.2] * 2, [1.9e8, 2.1e8])
+    assert a[0] < s[0] and s[1] < a[1] * 10 and np.all(np.isfinite(s))

@@ -363,3 +363,48 @@ def test_cloud_terminal_velocity(dev, oracle, ft):
         x = x.cpu().numpy().astype(np.float64)
         assert np.array_equal(x == 0, r == 0)
         assert np.max(np.abs(x - r) / np.maximum(np.abs(r), 1e-300)) <= (1e-6 if ft == "f64" else 1e-3)
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+@pytest.mark.parametrize("smooth", [False, True])
+def test_bulk_2m_cloud_to_rain_variants(dev, oracle, golden, ft, smooth):
+    """cmx_bulk_2m_cloud_to_rain_*: KATs of test/gpu_tests.jl:782-818 through the C ABI + random-state parity."""
+    import cmx
+    dt = {"f32": torch.float32, "f64": torch.float64}[ft]
+    sc = P.Bulk2MSchemes(ft)
+    g = golden["bulk_2m_variants"]
+    col = lambda v: torch.tensor([v], dtype=dt, device=dev)  # noqa: E731
+    if not smooth:
+        for name, exp in g["acnv"].items():
+            r = cmx.bulk_2m_cloud_to_rain(sc, name, col(g["q_lcl"]), col(g["rho"]), N_d=col(g["N_d"]))
+            assert float(r.acnv[0]) == pytest.approx(exp, rel=1e-10 if ft == "f64" else 3e-5), name
+        for name, exp in g["accr"].items():
+            r = cmx.bulk_2m_cloud_to_rain(sc, name, col(g["q_lcl"]), col(g["rho"]), q_rai=col(g["q_rai"]))
+            assert float(r.accr[0]) == pytest.approx(exp, rel=1e-6 if ft == "f64" else 3e-5), name
+        with pytest.raises(ValueError):
+            cmx.bulk_2m_cloud_to_rain(sc, "LD2004", col(1e-3), col(1.2), q_rai=col(1e-4))
+    gen = torch.Generator().manual_seed(12)
+    n = 100_001
+    u = lambda: torch.rand(n, generator=gen, dtype=torch.float64)  # noqa: E731
+    ql = torch.where(u() < 0.1, torch.zeros(n, dtype=torch.float64), 10 ** (-7 + 4.7 * u())).to(dt)
+    qr = (10 ** (-8 + 5.5 * u())).to(dt)
+    rho = (0.3 + u()).to(dt)
+    Nd = (10 ** (6.5 + 2.5 * u())).to(dt)
+    ids = {"KK2000": _abi.CMX_2M_KK2000, "B1994": _abi.CMX_2M_B1994, "TC1980": _abi.CMX_2M_TC1980, "LD2004": _abi.CMX_2M_LD2004}
+    sc64 = P.Bulk2MSchemes("f64")
+    c64 = [c.numpy().astype(np.float64) for c in (ql, qr, rho, Nd)]
+    for name, sid in ids.items():
+        has_accr = name != "LD2004"
+        got = cmx.bulk_2m_cloud_to_rain(sc, name, ql.to(dev), rho.to(dev), N_d=Nd.to(dev), q_rai=qr.to(dev) if has_accr else None,
+                                        smooth_transition=smooth)
+        flags = sid | (_abi.CMX_2M_SMOOTH_TRANSITION if smooth else 0)
+        ra, rb = oracle.bulk_2m_cloud_to_rain(_abi.F64, sc64, flags, c64[0], c64[1] if has_accr else None, c64[2], c64[3],
+                                              float32_gates=(ft == "f32"))
+        x = got.acnv.cpu().numpy().astype(np.float64)
+        # the step thresholds (B1994 N_0, TC1980 q threshold, LD2004 R_6 vs R_6C) are genuine discontinuities: a point within
+        # rounding of one may fall on the other side in another precision — tolerate a handful, exact elsewhere
+        bad = np.abs(x - ra) > (1e-6 if ft == "f64" else 1e-3) * np.abs(ra) + 1e-300
+        assert bad.mean() <= (0.0 if smooth else 2e-4), (name, float(bad.mean()))
+        if has_accr:
+            y = got.accr.cpu().numpy().astype(np.float64)
+            assert np.max(np.abs(y - rb) / np.maximum(np.abs(rb), 1e-300)) <= (1e-6 if ft == "f64" else 1e-3), name
