@@ -91,3 +91,34 @@ def p3_terminal_velocities(params: ParametersP3, velocity_params, rho_air, rho_q
                 _ptr(outs["v_n"]), _ptr(outs["v_m"]), C.c_void_p(s.cuda_stream))
     _lib.check(fn.__name__, st)
     return P3Velocities(outs["v_n"], outs["v_m"])
+
+
+P3Melt = namedtuple("P3Melt", ["dNdt", "dLdt"])
+
+
+def p3_ice_melt(params: ParametersP3, velocity_params, aps, tps, vent, T, rho_air, rho_q_ice, rho_n_ice, x3, x4, log_lambda, *,
+                from_state=False, aspect_ratio=True, p=1e-6, quad=None, stream=None) -> P3Melt:
+    """`P3.ice_melt(vel, aps, tps, T, ρₐ, state, logλ; quad)` for every point (src/P3_processes.jl:64-94): melting rates
+    (dNdt [1/m³/s], dLdt [kg/m³/s]); zero at and below T_freeze.  `vent` = parameters.VentilationFactorP3(FT)."""
+    if not isinstance(params, ParametersP3):
+        raise TypeError("params must be ParametersP3")
+    cols = (rho_q_ice, rho_n_ice, x3, x4, rho_air, T, log_lambda)
+    ref = _check_cols(cols, ("rho_q_ice", "rho_n_ice", "x3", "x4", "rho_air", "T", "log_lambda"))
+    fam = _fam_of(ref)
+    if fam is not params.fam or not (isinstance(velocity_params, fam.chen2022_ice_vel) and isinstance(aps, fam.air_properties)
+                                     and isinstance(tps, fam.thermo) and isinstance(vent, fam.ventilation)):
+        raise TypeError("parameter float type does not match the state columns")
+    if quad is None:
+        from .parameters import ChebyshevGauss
+        quad = ChebyshevGauss(fam.sfx, 100)
+    if not isinstance(quad, fam.quadrature):
+        raise TypeError("quadrature float type does not match the state columns")
+    out = P3Melt(torch.empty_like(ref), torch.empty_like(ref))
+    flags = params.flags | (_abi.CMX_P3_INPUT_IS_STATE if from_state else 0) | (0 if aspect_ratio else _abi.CMX_P3_NO_ASPECT_RATIO)
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_p3_ice_melt_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(params.c), C.byref(velocity_params), C.byref(aps), C.byref(tps), C.byref(vent), C.byref(quad), flags, p,
+                ref.numel(), *[_ptr(t) for t in cols], _ptr(out.dNdt), _ptr(out.dLdt), C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return out

@@ -608,6 +608,13 @@ class ParametersP3:
             T_freeze=td["temperature_water_freeze"])
 
 
+def VentilationFactorP3(FT):
+    """CMP.VentilationFactor(FT) of ParametersP3 (src/parameters/MicrophysicsP3.jl:165-180): the SB2006 coefficients
+    (a_v, b_v); pinned by the P3 melting KATs (test/p3_tests.jl:650-668)."""
+    td = _td(FT)
+    return td.fam.ventilation(a=td["SB2006_ventilation_factor_coeff_av"], b=td["SB2006_ventilation_factor_coeff_bv"])
+
+
 def Chen2022VelTypeIce(FT):
     """The (small_ice, large_ice) part of CMP.Chen2022VelType(FT) — src/parameters/TerminalVelocity.jl:207-275,325-335."""
     td = _td(FT)

@@ -375,6 +375,8 @@ template <typename FT> struct P3VelConsts {
     FT h0_num;          // partially rimed: cbrt ϕ = exp((h0_num − log Fu)/3 + β/3 logD − ½ log area)
     FT pi_4, gamma_area, sigma_area;
     FT p_lo, p_hi;      // FT(p), FT(1 − p)
+    // ice_melt (P3_processes.jl:64-94): F_v = vent_a + vent_bc √(D v), vent_bc = b_v ∛(ν/D_v)/√ν; L_f(T) = LH_f0 + dcp_f (T − T_0)
+    FT vent_a, vent_bc, K4, LH_f0, dcp_f, T_0, T_freeze;
 };
 
 template <typename FT, typename PR, typename VR>
@@ -434,9 +436,10 @@ template <typename FT> __device__ FT gamma_inc_inv_dev(FT a, FT p, FT q) {
 
 template <typename FT, typename QUAD> struct P3VelIO {
     const FT *rho_q, *rho_n, *x3, *x4, *rho_a, *loglam; FT *v_n, *v_m;
+    const FT *T; FT *dNdt, *dLdt;     // MELT mode
 };
 
-template <typename FT, typename QUAD, bool ASPECT>
+template <typename FT, typename QUAD, bool ASPECT, bool MELT = false>
 __global__ __launch_bounds__(kBlock) void p3_velocity_kernel(const P3Consts<FT> c, const P3VelConsts<FT> v, const QUAD quad,
                                                             const P3VelIO<FT, QUAD> io, const int64_t n) {
     using P = PM<FT>;
@@ -479,10 +482,11 @@ __global__ __launch_bounds__(kBlock) void p3_velocity_kernel(const P3Consts<FT> 
             for (int j = 0; j < quad.n; ++j) {
                 const FT x = scale * quad.node[j] + shift, w = quad.weight[j];
                 const FT logD = P::log(x);
-                FT base = logN0 + mu * logD - lam_ * x + q0 + q1 * logD;
+                const FT eN = logN0 + mu * logD - lam_ * x;                 // log n(D)
+                FT eA = q0 + q1 * logD;                                      // log of the aspect factor
                 if (mixed_area) {
                     const FT area = s.F_rim * v.pi_4 * x * x + (FT(1) - s.F_rim) * v.gamma_area * P::exp(v.sigma_area * logD);
-                    base -= FT(0.5) * P::log(area);
+                    eA -= FT(0.5) * P::log(area);
                 }
                 // Chen-2022 particle speed Σ aₖ D^bₖ e^{−cₖD}: the two terms have opposite signs and cancel to ≈1/200 of
                 // their size for small D, so the shared factor stays OUTSIDE the difference (as D^b does in the reference)
@@ -490,18 +494,39 @@ __global__ __launch_bounds__(kBlock) void p3_velocity_kernel(const P3Consts<FT> 
                 const FT E1 = small ? se + sb * logD : le1 + v.l_b1 * logD;
                 const FT dE = small ? -v.s_c2 * x : (le2 - le1) + (v.l_b2 - v.l_b1) * logD - v.l_c2 * x;   // E2 − E1
                 const FT A1 = small ? v.s_E : v.l_a1, A2 = small ? v.s_F : v.l_a2;
-                const FT nv = P::exp(base + E1) * (A1 + A2 * P::exp(dE));
-                // m(D) = a D^b: b = 3 on the spherical segments (no transcendental), β_va otherwise
-                const FT mD = sph_mass ? ma * (x * x * x) : P::exp(mla + mb * logD);
-                rn += nv * w;
-                rm += nv * mD * w;
+                const FT S = A1 + A2 * P::exp(dE);
+                if constexpr (!MELT) {
+                    const FT nv = P::exp(eN + eA + E1) * S;
+                    // m(D) = a D^b: b = 3 on the spherical segments (no transcendental), β_va otherwise
+                    const FT mD = sph_mass ? ma * (x * x * x) : P::exp(mla + mb * logD);
+                    rn += nv * w;
+                    rm += nv * mD * w;
+                } else {
+                    // ∂m/∂D · F_v(D) · N′(D) / D,  ∂m/∂D = a b D^(b−1)
+                    const FT vD = P::exp(eA + E1) * S;                                     // fall speed incl. aspect factor
+                    const FT Fv = v.vent_a + v.vent_bc * Math<FT>::sqrt(Math<FT>::max(x * vD, FT(0)));
+                    const FT dm_over_D = sph_mass ? ma * mb * x : ma * mb * P::exp((mb - FT(2)) * logD);
+                    rn += dm_over_D * Fv * P::exp(eN) * w;
+                }
             }
             sum_n += scale * rn; sum_m += scale * rm;
         }
-        vn = sum_n / s.rho_n; vm = sum_m / s.rho_q;
+        if constexpr (!MELT) {
+            vn = sum_n / s.rho_n; vm = sum_m / s.rho_q;
+        } else {
+            const FT T = io.T[i];
+            const FT L_f = v.LH_f0 + v.dcp_f * (T - v.T_0);
+            vm = Math<FT>::max(FT(0), v.K4 / L_f * (T - v.T_freeze) * sum_n);                 // dL/dt
+            vn = s.rho_n / s.rho_q * vm;                                                        // dN/dt
+        }
     }
-    if (io.v_n) io.v_n[i] = vn;
-    if (io.v_m) io.v_m[i] = vm;
+    if constexpr (!MELT) {
+        if (io.v_n) io.v_n[i] = vn;
+        if (io.v_m) io.v_m[i] = vm;
+    } else {
+        if (io.dNdt) io.dNdt[i] = vn;
+        if (io.dLdt) io.dLdt[i] = vm;
+    }
 }
 
 template <typename FT, typename PR, typename VR, typename QUAD>
@@ -516,13 +541,42 @@ static int32_t p3_velocity_entry(const PR *params, const VR *vel, const QUAD *qu
     P3Consts<FT> c = make_p3_consts<FT>(*params, flags);
     c.brent_iters = 0;
     const P3VelConsts<FT> v = make_p3_vel_consts<FT>(*params, *vel, (double)p);
-    P3VelIO<FT, QUAD> io{rho_q, rho_n, x3, x4, rho_a, loglam, v_n, v_m};
+    P3VelIO<FT, QUAD> io{rho_q, rho_n, x3, x4, rho_a, loglam, v_n, v_m, nullptr, nullptr, nullptr};
     const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (flags & CMX_P3_NO_ASPECT_RATIO)
         hipLaunchKernelGGL((p3_velocity_kernel<FT, QUAD, false>), grid, block, 0, st, c, v, *quad, io, n);
     else
         hipLaunchKernelGGL((p3_velocity_kernel<FT, QUAD, true>), grid, block, 0, st, c, v, *quad, io, n);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+
+template <typename FT, typename PR, typename VR, typename AP, typename TH, typename VT, typename QUAD>
+static int32_t p3_melt_entry(const PR *params, const VR *vel, const AP *aps, const TH *tps, const VT *vent, const QUAD *quad, uint32_t flags,
+                             FT p, int64_t n, const FT *rho_q, const FT *rho_n, const FT *x3, const FT *x4, const FT *rho_a, const FT *T,
+                             const FT *loglam, FT *dNdt, FT *dLdt, void *stream) {
+    if (!params || !vel || !aps || !tps || !vent || !quad || n < 0 ||
+        (flags & ~(CMX_P3_INPUT_IS_STATE | CMX_P3_SLOPE_CONSTANT | CMX_P3_NO_ASPECT_RATIO)))
+        return CMX_ERR_BAD_ARG;
+    if (quad->n < 1 || quad->n > CMX_QUAD_MAX || !(p > FT(0) && p < FT(0.5))) return CMX_ERR_BAD_ARG;
+    if (n == 0) return CMX_OK;
+    if (!rho_q || !rho_n || !x3 || !x4 || !rho_a || !T || !loglam) return CMX_ERR_BAD_ARG;
+    P3Consts<FT> c = make_p3_consts<FT>(*params, flags);
+    c.brent_iters = 0;
+    P3VelConsts<FT> v = make_p3_vel_consts<FT>(*params, *vel, (double)p);
+    v.vent_a = (FT)vent->a;
+    v.vent_bc = (FT)((double)vent->b * std::cbrt((double)aps->nu_air / (double)aps->D_vapor) / std::sqrt((double)aps->nu_air));
+    v.K4 = (FT)(4.0 * (double)aps->K_therm);
+    v.LH_f0 = (FT)((double)tps->LH_s0 - (double)tps->LH_v0); v.dcp_f = (FT)((double)tps->cp_l - (double)tps->cp_i);
+    v.T_0 = (FT)tps->T_0; v.T_freeze = (FT)params->T_freeze;
+    P3VelIO<FT, QUAD> io{rho_q, rho_n, x3, x4, rho_a, loglam, nullptr, nullptr, T, dNdt, dLdt};
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (flags & CMX_P3_NO_ASPECT_RATIO)
+        hipLaunchKernelGGL((p3_velocity_kernel<FT, QUAD, false, true>), grid, block, 0, st, c, v, *quad, io, n);
+    else
+        hipLaunchKernelGGL((p3_velocity_kernel<FT, QUAD, true, true>), grid, block, 0, st, c, v, *quad, io, n);
     CMX_HIP_TRY(hipGetLastError());
     return CMX_OK;
 }
@@ -555,6 +609,21 @@ int32_t cmx_p3_terminal_velocities_f64(const cmx_p3_params_f64 *params, const cm
                                        const double *rho_n_ice, const double *x3, const double *x4, const double *rho_air,
                                        const double *log_lambda, double *v_n, double *v_m, void *stream) {
     return cmx::p3_velocity_entry<double>(params, vel, quad, flags, p, n, rho_q_ice, rho_n_ice, x3, x4, rho_air, log_lambda, v_n, v_m, stream);
+}
+
+int32_t cmx_p3_ice_melt_f32(const cmx_p3_params_f32 *params, const cmx_chen2022_ice_vel_f32 *vel, const cmx_air_properties_f32 *aps,
+                            const cmx_thermo_f32 *tps, const cmx_ventilation_f32 *vent, const cmx_quadrature_f32 *quad, uint32_t flags,
+                            float p, int64_t n, const float *rho_q_ice, const float *rho_n_ice, const float *x3, const float *x4,
+                            const float *rho_air, const float *T, const float *log_lambda, float *dNdt, float *dLdt, void *stream) {
+    return cmx::p3_melt_entry<float>(params, vel, aps, tps, vent, quad, flags, p, n, rho_q_ice, rho_n_ice, x3, x4, rho_air, T, log_lambda,
+                                     dNdt, dLdt, stream);
+}
+int32_t cmx_p3_ice_melt_f64(const cmx_p3_params_f64 *params, const cmx_chen2022_ice_vel_f64 *vel, const cmx_air_properties_f64 *aps,
+                            const cmx_thermo_f64 *tps, const cmx_ventilation_f64 *vent, const cmx_quadrature_f64 *quad, uint32_t flags,
+                            double p, int64_t n, const double *rho_q_ice, const double *rho_n_ice, const double *x3, const double *x4,
+                            const double *rho_air, const double *T, const double *log_lambda, double *dNdt, double *dLdt, void *stream) {
+    return cmx::p3_melt_entry<double>(params, vel, aps, tps, vent, quad, flags, p, n, rho_q_ice, rho_n_ice, x3, x4, rho_air, T, log_lambda,
+                                      dNdt, dLdt, stream);
 }
 
 }  // extern "C"

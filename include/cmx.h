@@ -617,6 +617,21 @@ int32_t cmx_p3_terminal_velocities_f64(const cmx_p3_params_f64 *params, const cm
                                        const double *rho_q_ice, const double *rho_n_ice, const double *x3, const double *x4,
                                        const double *rho_air, const double *log_lambda, double *v_n, double *v_m, void *stream);
 
+/* P3 melting rate (QIMLT of Morrison & Milbrandt 2015): replaces, per point,
+ *   (; dNdt, dLdt) = P3.ice_melt(vel, aps, tps, T, ρₐ, state, logλ; quad)                  src/P3_processes.jl:64-94
+ * dL/dt = max(0, 4 K_therm / L_f(T) · (T − T_freeze) ∫ ∂m/∂D · F_v(D) · N′(D)/D dD) over the same bounds / segments as the fall
+ * speeds, F_v = a_v + b_v ∛(ν/D_v) √(D v(D)/ν) (CO.ventilation_factor, src/Common.jl:506-514; vent = params.vent, the SB2006
+ * ventilation coefficients); dN/dt = N/L · dL/dt.  Points with ρn_ice or ρq_ice < eps(FT) give 0 (the reference calls
+ * ice_melt only where ice is present, BMT:966). */
+int32_t cmx_p3_ice_melt_f32(const cmx_p3_params_f32 *params, const cmx_chen2022_ice_vel_f32 *vel, const cmx_air_properties_f32 *aps,
+                            const cmx_thermo_f32 *tps, const cmx_ventilation_f32 *vent, const cmx_quadrature_f32 *quad, uint32_t flags,
+                            float p, int64_t n, const float *rho_q_ice, const float *rho_n_ice, const float *x3, const float *x4,
+                            const float *rho_air, const float *T, const float *log_lambda, float *dNdt, float *dLdt, void *stream);
+int32_t cmx_p3_ice_melt_f64(const cmx_p3_params_f64 *params, const cmx_chen2022_ice_vel_f64 *vel, const cmx_air_properties_f64 *aps,
+                            const cmx_thermo_f64 *tps, const cmx_ventilation_f64 *vent, const cmx_quadrature_f64 *quad, uint32_t flags,
+                            double p, int64_t n, const double *rho_q_ice, const double *rho_n_ice, const double *x3, const double *x4,
+                            const double *rho_air, const double *T, const double *log_lambda, double *dNdt, double *dLdt, void *stream);
+
 /* ---------------------------------------------------------------------------
  * (3) Optional diagnostic sums over one rank's shard: per-column
  * Σx (double accumulation) of `ncols` device columns of length n into

@@ -366,6 +366,64 @@ void FN(cmxo_p3_terminal_velocities)(const TY(cmx_p3_params) * pr, const TY(cmx_
         FN(o_p3_velocities)(pr, vel, quad, flags, &s, rho_a[i], loglam[i], p, gi_iters, &v_n[i], &v_m[i]);
     }
 }
+/* ice_melt — src/P3_processes.jl:64-94 (QIMLT of Morrison & Milbrandt 2015): dL/dt = 4 K/L_f (T − T_freeze) ∫ ∂m/∂D F_v(D) N′(D)/D dD
+ * with the ventilation factor CO.ventilation_factor (src/Common.jl:506-514); dN/dt = N/L · dL/dt. */
+static inline void FN(o_p3_ice_melt)(const TY(cmx_p3_params) * pr, const TY(cmx_chen2022_ice_vel) * vel, const TY(cmx_air_properties) * aps,
+                                    const TY(cmx_thermo) * tps, const TY(cmx_ventilation) * vent, const TY(cmx_quadrature) * quad,
+                                    uint32_t flags, const TY(cmxo_p3_state) * s, FT rho_a, FT T, FT loglam, FT p, int gi_iters,
+                                    FT *dNdt, FT *dLdt) {
+    if (s->rho_n_ice < s->eps || s->rho_q_ice < s->eps) { *dNdt = 0; *dLdt = 0; return; }   /* N/L undefined: no ice, no melt */
+    TY(cmxo_p3_vterm) vt;
+    const FT rho_i = (FT)916.7;
+    FN(o_chen_small_ice)(&vel->small_ice, rho_a, rho_i, vt.as, vt.bs, vt.cs);
+    FN(o_chen_large_ice)(&vel->large_ice, rho_a, rho_i, vt.al, vt.bl, vt.cl);
+    vt.cutoff = vel->small_ice.cutoff;
+    vt.aspect = !(flags & CMX_P3_NO_ASPECT_RATIO);
+    FT mu = FN(o_p3_mu)(pr, flags, loglam), lam = M_EXP(loglam);
+    FT logN0 = M_LOG(s->rho_n_ice) - FN(o_loggamma_moment)(mu, loglam, (FT)0);
+    FT Y1 = p, Y2 = (FT)(1.0 - (double)p), Q1 = 1 - Y1, Q2 = 1 - Y2;
+    if (s->eps > (FT)1e-10) {
+        Y1 = (FT)(float)Y1; Y2 = (FT)(float)(1.0 - (double)p);
+        Q1 = (FT)(1.0f - (float)Y1); Q2 = (FT)(1.0f - (float)Y2);
+    }
+    FT D_min = FN(o_gamma_inc_inv)(mu + 1, Y1, Q1, gi_iters, s->eps) / lam;
+    FT D_max = FN(o_gamma_inc_inv)(mu + 1, Y2, Q2, gi_iters, s->eps) / lam;
+    FT bnd[5] = {D_min, FN(o_clamp)(s->D_th, D_min, D_max), FN(o_clamp)(s->D_gr, D_min, D_max), FN(o_clamp)(s->D_cr, D_min, D_max), D_max};
+    FT cbrt_Nsc = M_CBRT(aps->nu_air / aps->D_vapor);
+    FT total = 0;
+    for (int k = 0; k < 4; ++k) {
+        FT a = bnd[k], b = bnd[k + 1];
+        if (!(a < b)) continue;
+        FT scale = (b - a) / 2, shift = (a + b) / 2, r = 0;
+        for (int i = 0; i < quad->n; ++i) {
+            FT x = scale * quad->node[i] + shift, w = quad->weight[i];
+            FT nD = M_EXP(logN0 + mu * M_LOG(x) - lam * x);
+            FT ma, mb;
+            FN(o_p3_mass_coeffs)(pr, s, x, &ma, &mb);
+            FT dm = ma * mb * M_POW(x, mb - 1);                                       /* ∂ice_mass_∂D :394-397 */
+            FT Fv = vent->a + vent->b * cbrt_Nsc * M_SQRT(x * FN(o_p3_particle_velocity)(pr, s, &vt, x) / aps->nu_air);
+            r += dm * Fv * nD / x * w;
+        }
+        total += scale * r;
+    }
+    FT L_f = FN(o_latent_heat_fusion)(tps, T);
+    FT dL = FN(o_max)((FT)0, 4 * aps->K_therm / L_f * (T - pr->T_freeze) * total);
+    *dLdt = dL;
+    *dNdt = s->rho_n_ice / s->rho_q_ice * dL;
+}
+void FN(cmxo_p3_ice_melt)(const TY(cmx_p3_params) * pr, const TY(cmx_chen2022_ice_vel) * vel, const TY(cmx_air_properties) * aps,
+                         const TY(cmx_thermo) * tps, const TY(cmx_ventilation) * vent, const TY(cmx_quadrature) * quad, uint32_t flags,
+                         const TY(cmxo_thresholds) * th, FT p, int64_t n, const FT *rho_q_ice, const FT *rho_n_ice, const FT *x3,
+                         const FT *x4, const FT *rho_a, const FT *T, const FT *loglam, FT *dNdt, FT *dLdt, int32_t nthreads) {
+    const int gi_iters = sizeof(FT) == 4 ? 20 : 30;
+    (void)nthreads;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads > 0 ? nthreads : 1)
+    for (int64_t i = 0; i < n; ++i) {
+        TY(cmxo_p3_state) s = (flags & CMX_P3_INPUT_IS_STATE) ? FN(o_p3_state)(pr, rho_q_ice[i], rho_n_ice[i], x3[i], x4[i], th->eps_ft)
+                                                              : FN(o_p3_state_from_prognostic)(pr, rho_q_ice[i], rho_n_ice[i], x3[i], x4[i], th->eps_ft);
+        FN(o_p3_ice_melt)(pr, vel, aps, tps, vent, quad, flags, &s, rho_a[i], T[i], loglam[i], p, gi_iters, &dNdt[i], &dLdt[i]);
+    }
+}
 /* probes for the KATs: particle fall speed at diameter D for a state built from (F_rim, ρ_rim); gamma_inc_inv */
 FT FN(cmxo_p3_particle_velocity)(const TY(cmx_p3_params) * pr, const TY(cmx_chen2022_ice_vel) * vel, uint32_t flags, FT F_rim, FT rho_rim,
                                 FT rho_a, FT D) {

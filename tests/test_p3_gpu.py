@@ -304,3 +304,48 @@ def test_warm_start_guess_on_device(dev, oracle):
     ref = oracle.p3_shape(_abi.F64, p.c, STATE | p.flags, *c64, guess=g)["log_lambda"]
     f = np.isfinite(ref)
     assert np.abs(_np64(ll)[f] - ref[f]).max() < 1e-9
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_ice_melt(dev, oracle, ft):
+    """cmx_p3_ice_melt_*: the reference's melting KATs (test/p3_tests.jl:617-668) through the C ABI + random-state parity."""
+    import cmx
+    from cmx import synthetic
+    g = G["ice_melt"]
+    p, vel = P.ParametersP3(ft), P.Chen2022VelTypeIce(ft)
+    aps, tps, vent = P.AirProperties(ft), P.ThermodynamicsParameters(ft), P.VentilationFactorP3(ft)
+    col = lambda v: torch.tensor(v, dtype=DT[ft], device=dev)  # noqa: E731
+    n = len(g["T"])
+    cols = (col([g["L_ice"]] * n), col([g["N_ice"]] * n), col([g["F_rim"]] * n), col([g["rho_rim"]] * n))
+    ll = cmx.p3_shape(p, *cols, from_state=True, want=("log_lambda",)).log_lambda
+    r = cmx.p3_ice_melt(p, vel, aps, tps, vent, col(g["T"]), col([g["rho_a"]] * n), *cols, ll, from_state=True,
+                        quad=P.GaussLegendre(ft, 12))
+    assert float(r.dNdt[0]) == 0 and float(r.dLdt[0]) == 0
+    if ft == "f64":
+        np.testing.assert_allclose(r.dNdt.cpu().numpy()[1:], g["dNdt"][1:], rtol=1e-9)
+        np.testing.assert_allclose(r.dLdt.cpu().numpy()[1:], g["dLdt"][1:], rtol=1e-9)
+    else:   # the reference's own Float32 values differ from its Float64 ones by 1e-3 (T − T_freeze = 0.01 K in Float32)
+        np.testing.assert_allclose(r.dLdt.cpu().numpy()[1:], g["dLdt"][1:], rtol=3e-3)
+    m = 20_000
+    st = _columns(m, ft, True, seed=31)
+    rho_a = synthetic.p3_air_density(m, dtype=DT[ft])
+    gen = torch.Generator().manual_seed(2)
+    T = (268.0 + 12.0 * torch.rand(m, generator=gen, dtype=torch.float64)).to(DT[ft])
+    dcols = [c.to(dev) for c in st]
+    ll = cmx.p3_shape(p, *dcols, from_state=True, want=("log_lambda",), brent_iters=40).log_lambda
+    got = cmx.p3_ice_melt(p, vel, aps, tps, vent, T.to(dev), rho_a.to(dev), *dcols, ll, from_state=True, quad=P.GaussLegendre(ft, 40))
+    c64 = [c.numpy().astype(np.float64) for c in st]
+    dN, dL = oracle.p3_ice_melt(_abi.F64, P.ParametersP3("f64").c, P.Chen2022VelTypeIce("f64"), P.AirProperties("f64"),
+                                P.ThermodynamicsParameters("f64"), P.VentilationFactorP3("f64"), P.GaussLegendre("f64", 40), STATE, *c64,
+                                rho_a.numpy().astype(np.float64), T.numpy().astype(np.float64), _np64(ll), float32_gates=(ft == "f32"),
+                                nthreads=8)
+    # T − T_freeze carries the Float32 rounding of T (≈3e-5 K): conditioning scale |T| eps / |T − T_freeze|
+    dT = np.abs(T.numpy().astype(np.float64) - 273.15)
+    amp = 1.0 + (280.0 * 1.2e-7 / np.maximum(dT, 1e-30) / RTOL[ft] if ft == "f32" else 0.0)
+    for x, r_ in ((got.dNdt, dN), (got.dLdt, dL)):
+        x = _np64(x)
+        assert np.array_equal(x == 0, r_ == 0) or ft == "f32"
+        nz = r_ != 0
+        e = np.abs(x[nz] - r_[nz]) / np.abs(r_[nz]) / (amp[nz] if ft == "f32" else 1.0)
+        assert e.max() <= RTOL[ft], float(e.max())
+    assert (dL > 0).mean() > 0.3 and (dL == 0).mean() > 0.3

@@ -155,3 +155,20 @@ def test_warm_start_guess_keeps_the_root(oracle):
     # with the reference budget a good guess does not hurt accuracy
     ll10 = oracle.p3_shape(F64, p.c, STATE | p.flags, L, N, F, rr, guess=base + 0.05)["log_lambda"]
     assert np.abs(ll10 - base).max() < 1e-6
+
+
+def test_ice_melt_kats(oracle):
+    """test/p3_tests.jl:617-668: zero at and below freezing, the two reference rates above (GaussLegendre(12))."""
+    g = G["ice_melt"]
+    p, vel = P.ParametersP3("f64").c, P.Chen2022VelTypeIce("f64")
+    aps, tps, vent = P.AirProperties("f64"), P.ThermodynamicsParameters("f64"), P.VentilationFactorP3("f64")
+    quad = P.GaussLegendre("f64", 12)
+    n = len(g["T"])
+    cols = ([g["L_ice"]] * n, [g["N_ice"]] * n, [g["F_rim"]] * n, [g["rho_rim"]] * n)
+    ll = oracle.p3_shape(F64, p, STATE, *cols)["log_lambda"]
+    dN, dL = oracle.p3_ice_melt(F64, p, vel, aps, tps, vent, quad, STATE, *cols, [g["rho_a"]] * n, g["T"], ll)
+    assert dN[0] == 0 and dL[0] == 0
+    np.testing.assert_allclose(dN[1:], g["dNdt"][1:], rtol=g["rtol"])
+    np.testing.assert_allclose(dL[1:], g["dLdt"][1:], rtol=g["rtol"])
+    # dN/dt = N/L · dL/dt exactly
+    np.testing.assert_allclose(dN[1:] / dL[1:], g["N_ice"] / g["L_ice"], rtol=1e-14)
