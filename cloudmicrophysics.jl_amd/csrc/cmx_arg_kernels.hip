@@ -35,6 +35,8 @@ template <typename FT> struct ArgModeConsts {
     FT fN;           // f_i (ζ/η_i)^p1 = fN · (ζ/X)^p1,           fN = f_i N_i^p1
     FT gS;           // g_i (Sm_i²/(η_i+3ζ))^p2 = gS · A^(3 p2) · (η_i+3ζ)^(−p2),   gS = g_i (Sm_i² A⁻³)^p2
     FT inv_sm_c;     // 1/Sm_i = inv_sm_c · A^(−3/2)
+    FT c1, c2;       // Σ_i (1/Sm_i²)[…] = A⁻³ · ( (ζ/X)^p1 Σ c1_i + A^(3 p2) Σ c2_i (η_i+3ζ)^(−p2) ),  c1 = fN/Sm_c², c2 = gS/Sm_c²
+    FT uc_sm;        // u_i = u_c (log2 Sm_i − log2 S_max) = uc_sm + u_c (1.5 log2 A − log2 S_max),  uc_sm = u_c · l2_sm_c
 };
 
 template <typename FT> struct ArgConsts {
@@ -42,7 +44,7 @@ template <typename FT> struct ArgConsts {
     // thermodynamics
     FT R_v, R_d, Rv_over_Rd, inv_R_v, T_0, LH_v0, LH_s0, dcp_l, dcp_i, ps_c0, psl_a, psl_b, psi_a, psi_b, inv_T_tr;
     FT cp_d, cpm_qt, cpm_ql, cpm_qi;
-    FT inv_K, Rv_over_D, eps_1m, eps_ft;
+    FT inv_K, Rv_over_D, eps_1m, inv_eps_1m, eps_ft;
     FT g, rho_w, inv_rho_w, rho_i, A_c, p1, p2, two_pi_rho_w, four_pi, inv_43pi_rho_w, inv_43pi_rho_i;
     ArgModeConsts<FT> m[CMX_ARG_MAX_MODES];
 };
@@ -65,7 +67,7 @@ static ArgConsts<FT> make_arg_consts(const AP &ap, const AD &ad, const AI &aip, 
     c.cpm_ql = (FT)((double)tp.cp_l - (double)tp.cp_v); c.cpm_qi = (FT)((double)tp.cp_i - (double)tp.cp_v);
     c.inv_K = (FT)(1.0 / std::fmax((double)aip.K_therm, eps));
     c.Rv_over_D = (FT)(Rv / std::fmax((double)aip.D_vapor, eps));
-    c.eps_1m = (FT)eps; c.eps_ft = Math<FT>::eps();
+    c.eps_1m = (FT)eps; c.inv_eps_1m = (FT)(1.0 / eps); c.eps_ft = Math<FT>::eps();
     c.g = (FT)ap.g; c.rho_w = (FT)ap.rho_w; c.inv_rho_w = (FT)(1.0 / (double)ap.rho_w); c.rho_i = (FT)ap.rho_i;
     c.A_c = (FT)(2.0 * (double)ap.sigma * (double)ap.M_w / (double)ap.rho_w / (double)ap.R);   // A = A_c / T
     c.p1 = (FT)ap.p1; c.p2 = (FT)ap.p2;
@@ -89,6 +91,10 @@ static ArgConsts<FT> make_arg_consts(const AP &ap, const AD &ad, const AI &aip, 
         o.fN = (FT)((double)ap.f1 * std::exp((double)ap.f2 * ls * ls) * std::pow((double)m.N, (double)ap.p1));
         o.gS = (FT)(((double)ap.g1 + (double)ap.g2 * ls) * std::exp2(2.0 * (double)ap.p2 * l2_sm_c));
         o.inv_sm_c = (FT)std::exp2(-l2_sm_c);
+        const double inv_sm2 = std::exp2(-2.0 * l2_sm_c);
+        o.c1 = (FT)(inv_sm2 * (double)ap.f1 * std::exp((double)ap.f2 * ls * ls) * std::pow((double)m.N, (double)ap.p1));
+        o.c2 = (FT)(inv_sm2 * ((double)ap.g1 + (double)ap.g2 * ls) * std::exp2(2.0 * (double)ap.p2 * l2_sm_c));
+        o.uc_sm = (FT)(2.0 * ln2 / (3.0 * std::sqrt(2.0) * ls) * l2_sm_c);
     }
     return c;
 }
@@ -129,15 +135,16 @@ __device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, cons
     const FT p_v = (q_tot - q_liq - q_ice) * rho_air * c.R_v * T;
     const FT l2_TT = M::log2(T * c.inv_T_tr), dinvT = c.inv_T_tr - inv_T;
     const FT l2_pvs = M::fma(c.psl_a, l2_TT, M::fma(c.psl_b, dinvT, c.ps_c0));
-    const FT p_vs = M::exp2(l2_pvs), inv_pvs = M::exp2(-l2_pvs);
+    const FT inv_pvs = M::exp2(-l2_pvs);
     const FT LoRT = L_v * c.inv_R_v * inv_T;
-    const FT G_liq = M::rcp(M::fma(L_v * c.inv_K * inv_T, LoRT - FT(1), c.Rv_over_D * T * M::rcp(M::max(p_vs, c.eps_1m))));
-    const FT G = G_liq * c.inv_rho_w;
+    // 1/G_liq = L/(K T)(L/(R_v T) − 1) + R_v T/(D max(p_vs, ϵ))  (Common.jl:47-63); 1/max(p_vs, ϵ) = min(1/p_vs, 1/ϵ).  Only the
+    // reciprocal of G = G_liq/ρ_w enters S_max (αw/G), so G itself is formed only for the sink terms.
+    const FT inv_G_liq = M::fma(L_v * c.inv_K * inv_T, LoRT - FT(1), c.Rv_over_D * T * M::min(inv_pvs, c.inv_eps_1m));
     const FT ratio = p_v * inv_pvs;
     const FT alpha = ratio * (LoRT * c.g * inv_cp * inv_T - c.g * inv_Rm * inv_T);                       // AA:164
     const FT gamma = M::fma(ratio * R_m * L_v, LoRT * inv_cp * M::rcp(p), c.R_v * T * inv_pvs);          // AA:165
     const FT aw = alpha * w;
-    const FT aw_over_G = aw * M::rcp(G);
+    const FT aw_over_G = aw * c.rho_w * inv_G_liq;
     const FT sq = M::sqrt(aw_over_G);
     const FT A = c.A_c * inv_T;                                                                          // AA:35-40
     const FT zeta = FT(2.0 / 3.0) * A * sq;                                                               // AA:168
@@ -151,23 +158,23 @@ __device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, cons
     const FT Z1 = M::exp2(c.p1 * (l2_zeta - l2_X));            // (ζ/X)^p1
     const FT A3p2 = M::exp2(FT(2) * c.p2 * l2_A15);            // A^(3 p2)
     const FT Am15 = M::exp2(-l2_A15);                          // A^(−3/2)
-    FT tmp = FT(0);
-    FT l2_sm[NM];
+    // with the mode-only factors c1_i, c2_i the sum is  A⁻³·(Z1 Σ c1_i + A^(3p2) Σ c2_i (η_i + 3ζ)^(−p2)): per mode one
+    // multiply, one FMA, one log2, one exp2 and one accumulating FMA
+    FT sum1 = FT(0), sum2 = FT(0);
 #pragma unroll
     for (int k = 0; k < NM; ++k) {
-        l2_sm[k] = cm[k].l2_sm_c + l2_A15;
+        sum1 += cm[k].c1;
         const FT eta = X * cm[k].inv_N;
-        const FT t1 = cm[k].fN * Z1;
-        const FT t2 = cm[k].gS * A3p2 * M::exp2(-c.p2 * M::log2(M::fma(FT(3), zeta, eta)));
-        const FT inv_sm = cm[k].inv_sm_c * Am15;
-        tmp = M::fma(inv_sm * inv_sm, t1 + t2, tmp);
+        sum2 = M::fma(cm[k].c2, M::exp2(-c.p2 * M::log2(M::fma(FT(3), zeta, eta))), sum2);
     }
+    const FT tmp = (Am15 * Am15) * M::fma(A3p2, sum2, Z1 * sum1);
     const FT S_arg = M::rsqrt(tmp);                                                                        // AA:185
     FT smax;
     if constexpr (SINKS) {   // liquid / ice sink correction — AA:187-197
         const FT L_s = M::fma(c.dcp_i, T - c.T_0, c.LH_s0);
         const FT l2_pvi = M::fma(c.psi_a, l2_TT, M::fma(c.psi_b, dinvT, c.ps_c0));
-        const FT p_vi = M::exp2(l2_pvi);
+        const FT p_vi = M::exp2(l2_pvi), p_vs = M::exp2(l2_pvs);
+        const FT G = M::rcp(inv_G_liq) * c.inv_rho_w;
         const FT r_liq = N_liq < c.eps_ft ? FT(0) : M::exp2(M::log2(rho_air * q_liq * M::rcp(N_liq) * c.inv_43pi_rho_w) * FT(1.0 / 3.0));
         const FT K_liq = c.four_pi * c.rho_w * N_liq * r_liq * G * gamma;
         const FT gamma_i = M::fma(ratio * R_m * L_v, L_s * c.inv_R_v * inv_cp * inv_T * M::rcp(p), c.R_v * T * inv_pvs);
@@ -182,11 +189,10 @@ __device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, cons
     }
     smax = M::max(FT(0), smax);                                                                            // AA:199
     o.smax = smax;
-    const FT l2_smax = M::log2(smax);
+    const FT dl0 = l2_A15 - M::log2(smax);                       // log2(Sm_i / S_max) = l2_sm_c + dl0
 #pragma unroll
     for (int k = 0; k < NM; ++k) {
-        const FT dl = l2_sm[k] - l2_smax;                       // log2(Sm_i / S_max)
-        const FT u = cm[k].u_c * dl;                           // AA:255   (= ln(sm/smax)/fac, AA:316)
+        const FT u = M::fma(cm[k].u_c, dl0, cm[k].uc_sm);       // AA:255   (= ln(sm/smax)/fac, AA:316)
         o.n[k] = want_N ? cm[k].half_N * erfc_dev<FT>(u) : FT(0);                  // N ½ (1 − erf u)      AA:257
         o.m[k] = want_M ? cm[k].half_M * erfc_dev<FT>(u - cm[k].fac) : FT(0);     // M/2 erfc(u − fac)    AA:319
     }
@@ -312,6 +318,9 @@ __device__ __forceinline__ ArgModeConsts<FT> arg_mode_consts_dev(const ArgConsts
     o.fN = o.f * M::exp2(c.p1 * l2_N);
     o.gS = o.g * M::exp2(FT(2) * c.p2 * l2_sm_c);
     o.inv_sm_c = M::exp2(-l2_sm_c);
+    const FT inv_sm2 = o.inv_sm_c * o.inv_sm_c;
+    o.c1 = inv_sm2 * o.fN; o.c2 = inv_sm2 * o.gS;
+    o.uc_sm = o.u_c * l2_sm_c;
     return o;
 }
 
