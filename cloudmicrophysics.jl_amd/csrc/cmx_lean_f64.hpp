@@ -12,10 +12,10 @@
 #include <cmath>
 #include <limits>
 
-#if defined(__HIP_DEVICE_COMPILE__)
-#define CMX_LEAN_FN __device__ __forceinline__
+#if defined(__HIPCC__)
+#define CMX_LEAN_FN __host__ __device__ __forceinline__   // hipcc: both passes see the same overload set
 #else
-#define CMX_LEAN_FN inline
+#define CMX_LEAN_FN inline                                // plain host build (tests/native/lean_math_host.cpp)
 #endif
 
 namespace cmx {
@@ -188,6 +188,63 @@ CMX_LEAN_FN double log1p(double x) {
     const double inf = std::numeric_limits<double>::infinity();
     return d == 0.0 ? x : (x == inf ? inf : r);                                // x = −1 → −Inf, x < −1 → NaN via log
 }
+// ---- register-pinned constants -----------------------------------------------------------------------------------------
+// A Float64 constant that is not one of the few inline values occupies an SGPR pair.  A loop that calls exp and log a few
+// times needs ≈35 such constants on top of the kernel's parameters: beyond the SGPR file the compiler parks them in VGPR
+// lanes and re-reads each with v_readlane_b32 — VALU instructions (measured: 96 of 264 per quadrature node in the P3
+// fall-speed kernel).  `PinnedCoefs` keeps the polynomial / reduction constants in VGPRs instead (an empty asm makes each
+// value opaque, so it cannot be rematerialised as a scalar constant): 62 VGPRs, no spill traffic.
+struct PinnedCoefs {
+    double e[13];           // 1/13!, 1/12!, …, 1/2!, 1/1! of exp_poly
+    double log2e, ln2_hi, ln2_lo, exp_lo, exp_hi;
+    double l[10];           // 1/21, 1/19, …, 1/3 of log_mant
+    double sqrt_half;
+};
+CMX_LEAN_FN void pin(double &x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#else
+    (void)x;
+#endif
+}
+CMX_LEAN_FN PinnedCoefs pinned_coefs() {
+    PinnedCoefs k;
+    const double f[13] = {1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0,
+                          1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0};
+    for (int i = 0; i < 13; ++i) { k.e[i] = f[i]; pin(k.e[i]); }
+    k.log2e = 1.4426950408889634; k.ln2_hi = 0.6931471803691238; k.ln2_lo = 1.9082149292705877e-10; k.exp_lo = -760.0; k.exp_hi = 760.0;
+    pin(k.log2e); pin(k.ln2_hi); pin(k.ln2_lo); pin(k.exp_lo); pin(k.exp_hi);
+    for (int i = 0; i < 10; ++i) { k.l[i] = 1.0 / (21.0 - 2.0 * i); pin(k.l[i]); }
+    k.sqrt_half = 0.7071067811865476; pin(k.sqrt_half);
+    return k;
+}
+// eˣ and ln x with the constants taken from `k` (same arithmetic as exp / log above)
+CMX_LEAN_FN double exp(double x, const PinnedCoefs &k) {
+    const double xc = __builtin_fmin(__builtin_fmax(x, k.exp_lo), k.exp_hi);
+    const double n = __builtin_rint(xc * k.log2e);
+    double t = fma_(-n, k.ln2_hi, xc);
+    t = fma_(-n, k.ln2_lo, t);
+    double p = k.e[0];
+    for (int i = 1; i < 13; ++i) p = fma_(p, t, k.e[i]);
+    p = fma_(p, t, 1.0);
+    const double r = ldexp_(p, (int)n);
+    return x != x ? x : r;
+}
+CMX_LEAN_FN double log(double x, const PinnedCoefs &k) {
+    double m = frexp_mant(x);
+    int e = frexp_exp(x);
+    const bool lo = m < k.sqrt_half;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double s = (m - 1.0) * rcp_finite(m + 1.0);
+    const double z = s * s;
+    double p = k.l[0];
+    for (int i = 1; i < 10; ++i) p = fma_(p, z, k.l[i]);
+    const double lm = fma_(2.0 * s * z, p, 2.0 * s);
+    const double ed = (double)e;
+    return log_special(x, fma_(ed, k.ln2_hi, fma_(ed, k.ln2_lo, lm)));
+}
+
 // √x and 1/√x: hardware rsq seed + two coupled Newton (Goldschmidt) steps; x = 0 / Inf / < 0 follow IEEE
 CMX_LEAN_FN double rsqrt_core(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
