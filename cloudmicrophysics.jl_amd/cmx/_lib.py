@@ -95,6 +95,9 @@ def _declare(lib):
         f.restype = i32
         f.argtypes = [C.POINTER(fam.p3_params), C.POINTER(fam.chen2022_ice_vel), C.POINTER(fam.air_properties), C.POINTER(fam.thermo),
                       C.POINTER(fam.ventilation), C.POINTER(fam.quadrature), u32, fam.ft, i64] + [vp] * 9 + [vp]
+        f = getattr(lib, f"cmx_p3_ice_self_collection_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.p3_params), C.POINTER(fam.chen2022_ice_vel), C.POINTER(fam.quadrature), u32, i64] + [vp] * 7 + [vp]
         f = getattr(lib, f"cmx_column_sums_{s}")
         f.restype = i32
         f.argtypes = [i32, C.POINTER(vp), i64, vp, vp]

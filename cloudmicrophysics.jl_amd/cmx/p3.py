@@ -122,3 +122,31 @@ def p3_ice_melt(params: ParametersP3, velocity_params, aps, tps, vent, T, rho_ai
                 ref.numel(), *[_ptr(t) for t in cols], _ptr(out.dNdt), _ptr(out.dLdt), C.c_void_p(s.cuda_stream))
     _lib.check(fn.__name__, st)
     return out
+
+
+def p3_ice_self_collection(params: ParametersP3, velocity_params, rho_air, rho_q_ice, rho_n_ice, x3, x4, log_lambda, *, from_state=False,
+                           aspect_ratio=True, quad=None, stream=None):
+    """`P3.ice_self_collection(state, logλ, vel, ρₐ; quad).dNdt` for every point (src/P3_processes.jl:676-712): the ice number
+    loss rate by aggregation [1/m³/s].  8·n² integrand evaluations per point for an n-point rule (default ChebyshevGauss(100),
+    as in the reference; GaussLegendre(40) is 6× cheaper for the same accuracy)."""
+    if not isinstance(params, ParametersP3):
+        raise TypeError("params must be ParametersP3")
+    cols = (rho_q_ice, rho_n_ice, x3, x4, rho_air, log_lambda)
+    ref = _check_cols(cols, ("rho_q_ice", "rho_n_ice", "x3", "x4", "rho_air", "log_lambda"))
+    fam = _fam_of(ref)
+    if fam is not params.fam or not isinstance(velocity_params, fam.chen2022_ice_vel):
+        raise TypeError("parameter float type does not match the state columns")
+    if quad is None:
+        from .parameters import ChebyshevGauss
+        quad = ChebyshevGauss(fam.sfx, 100)
+    if not isinstance(quad, fam.quadrature):
+        raise TypeError("quadrature float type does not match the state columns")
+    out = torch.empty_like(ref)
+    flags = params.flags | (_abi.CMX_P3_INPUT_IS_STATE if from_state else 0) | (0 if aspect_ratio else _abi.CMX_P3_NO_ASPECT_RATIO)
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_p3_ice_self_collection_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(params.c), C.byref(velocity_params), C.byref(quad), flags, ref.numel(), *[_ptr(t) for t in cols], _ptr(out),
+                C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return out

@@ -601,6 +601,114 @@ static int32_t p3_melt_entry(const PR *params, const VR *vel, const AP *aps, con
     return CMX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// ice_self_collection — P3_processes.jl:676-712: dN/dt = ½ ∫∫ π (r₁+r₂)² |v₁ − v₂| n(D₁) n(D₂) dD₂ dD₁ (E = 1, r = √(area/π)).
+// Outer integral over the four regime segments between the eps(FT) and 1 − eps(FT) quantiles, inner integral over
+// (D_lo, D₁) and (D₁, D_hi) — split at the |v₁ − v₂| cusp, not at the regime thresholds, so the regime of every inner
+// node is found by comparison.  8 n² integrand evaluations per point (n = quadrature order): the heaviest P3 process.
+template <typename FT, typename QUAD> struct P3SelfIO { const FT *rho_q, *rho_n, *x3, *x4, *rho_a, *loglam; FT *dNdt; };
+
+template <typename FT, typename QUAD, bool ASPECT>
+__global__ __launch_bounds__(kBlock) void p3_self_collection_kernel(const P3Consts<FT> c, const P3VelConsts<FT> v, const QUAD quad,
+                                                                   const P3SelfIO<FT, QUAD> io, const int64_t n) {
+    using P = PM<FT>;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    P3Point<FT> s;
+    p3_make_point<FT>(c, io.rho_q[i], io.rho_n[i], io.x3[i], io.x4[i], s);
+    FT out = FT(0);
+    if (!(s.rho_n < P::eps() || s.rho_q < P::eps())) {
+        const FT loglam = io.loglam[i], lam = P::exp(loglam), mu = p3_mu<FT>(c, loglam);
+        const FT logN0 = P::log(s.rho_n) - (-(mu + FT(1)) * loglam + P::lgamma(mu + FT(1)));
+        const FT rho_a = Math<FT>::max(io.rho_a[i], FT(0)), lra = P::log(rho_a);
+        const FT sb = v.s_B + rho_a * v.s_C, se = v.s_A * lra + sb * v.ln1000;
+        const FT le1 = v.l_A * lra, le2 = le1 + v.l_H * rho_a;
+        const FT D_lo = gamma_inc_inv_dev<FT>(mu + FT(1), P::eps(), FT(1) - P::eps()) / lam;      // p = eps(one(ρₐ))
+        const FT D_hi = gamma_inc_inv_dev<FT>(mu + FT(1), FT(1) - P::eps(), FT(1) - (FT(1) - P::eps())) / lam;
+        FT bnd[5];
+        bnd[0] = D_lo; bnd[4] = D_hi;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) bnd[k] = Math<FT>::min(Math<FT>::max(s.bnd[k], D_lo), D_hi);
+        const FT Fu = Math<FT>::max(FT(1) - s.F_rim, P::eps());
+        const FT h0 = (v.h0_num - P::log(Fu)) / FT(3), h1 = c.beta_va / FT(3);
+        const bool unrimed = s.F_rim == FT(0);
+        const FT inv_pi = FT(0.3183098861837907);
+        const typename P::Coefs kc = P::coefs();
+        // fall speed (incl. aspect factor), collision radius and number density at diameter x
+        auto eval = [&](FT x, FT &vv, FT &rr, FT &nn) {
+            const FT logD = P::log(x, kc);
+            const int reg = x < s.bnd[1] ? 0 : (unrimed ? 1 : (x < s.bnd[2] ? 1 : (x < s.bnd[3] ? 2 : 3)));
+            const FT sph = v.pi_4 * x * x;
+            FT area = sph, eA = FT(0);
+            if (reg == 1 || reg == 3) {
+                const FT non = v.gamma_area * P::exp(v.sigma_area * logD, kc);
+                area = reg == 1 ? non : s.F_rim * sph + (FT(1) - s.F_rim) * non;
+                if (ASPECT) eA = reg == 1 ? v.g0 + v.g1 * logD : h0 + h1 * logD - FT(0.5) * P::log(area, kc);
+            }
+            const bool small = x <= v.cutoff;
+            const FT E1 = small ? se + sb * logD : le1 + v.l_b1 * logD;
+            const FT dE = small ? -v.s_c2 * x : (le2 - le1) + (v.l_b2 - v.l_b1) * logD - v.l_c2 * x;
+            const FT A1 = small ? v.s_E : v.l_a1, A2 = small ? v.s_F : v.l_a2;
+            vv = P::exp(eA + E1, kc) * (A1 + A2 * P::exp(dE, kc));
+            rr = Math<FT>::sqrt(area * inv_pi);
+            nn = P::exp(logN0 + mu * logD - lam * x, kc);
+        };
+        FT total = FT(0);
+        for (int k = 0; k < 4; ++k) {
+            const FT a = bnd[k], b = bnd[k + 1];
+            if (!(a < b)) continue;
+            const FT scale = (b - a) / FT(2), shift = (a + b) / FT(2);
+            FT r_out = FT(0);
+            for (int j1 = 0; j1 < quad.n; ++j1) {
+                const FT D1 = scale * quad.node[j1] + shift;
+                FT v1, r1, n1;
+                eval(D1, v1, r1, n1);
+                FT inner = FT(0);
+                for (int h = 0; h < 2; ++h) {
+                    const FT ia = h == 0 ? D_lo : D1, ib = h == 0 ? D1 : D_hi;
+                    if (!(ia < ib)) continue;
+                    const FT sc2 = (ib - ia) / FT(2), sh2 = (ia + ib) / FT(2);
+                    FT r_in = FT(0);
+                    for (int j2 = 0; j2 < quad.n; ++j2) {
+                        FT v2, r2, n2;
+                        eval(sc2 * quad.node[j2] + sh2, v2, r2, n2);
+                        const FT rs = r1 + r2;
+                        r_in += rs * rs * P::abs(v1 - v2) * n2 * quad.weight[j2];
+                    }
+                    inner += sc2 * r_in;
+                }
+                r_out += inner * n1 * quad.weight[j1];
+            }
+            total += scale * r_out;
+        }
+        out = FT(0.5) * FT(3.14159265358979323846) * total;       // the π of K = π (r₁+r₂)² taken out of the sums
+    }
+    io.dNdt[i] = out;
+}
+
+template <typename FT, typename PR, typename VR, typename QUAD>
+static int32_t p3_self_collection_entry(const PR *params, const VR *vel, const QUAD *quad, uint32_t flags, int64_t n, const FT *rho_q,
+                                        const FT *rho_n, const FT *x3, const FT *x4, const FT *rho_a, const FT *loglam, FT *dNdt,
+                                        void *stream) {
+    if (!params || !vel || !quad || n < 0 || (flags & ~(CMX_P3_INPUT_IS_STATE | CMX_P3_SLOPE_CONSTANT | CMX_P3_NO_ASPECT_RATIO)))
+        return CMX_ERR_BAD_ARG;
+    if (quad->n < 1 || quad->n > CMX_QUAD_MAX) return CMX_ERR_BAD_ARG;
+    if (n == 0) return CMX_OK;
+    if (!rho_q || !rho_n || !x3 || !x4 || !rho_a || !loglam || !dNdt) return CMX_ERR_BAD_ARG;
+    P3Consts<FT> c = make_p3_consts<FT>(*params, flags);
+    c.brent_iters = 0;
+    const P3VelConsts<FT> v = make_p3_vel_consts<FT>(*params, *vel, 1e-6);
+    P3SelfIO<FT, QUAD> io{rho_q, rho_n, x3, x4, rho_a, loglam, dNdt};
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (flags & CMX_P3_NO_ASPECT_RATIO)
+        hipLaunchKernelGGL((p3_self_collection_kernel<FT, QUAD, false>), grid, block, 0, st, c, v, *quad, io, n);
+    else
+        hipLaunchKernelGGL((p3_self_collection_kernel<FT, QUAD, true>), grid, block, 0, st, c, v, *quad, io, n);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+
 }  // namespace cmx
 
 extern "C" {
@@ -644,6 +752,17 @@ int32_t cmx_p3_ice_melt_f64(const cmx_p3_params_f64 *params, const cmx_chen2022_
                             const double *rho_air, const double *T, const double *log_lambda, double *dNdt, double *dLdt, void *stream) {
     return cmx::p3_melt_entry<double>(params, vel, aps, tps, vent, quad, flags, p, n, rho_q_ice, rho_n_ice, x3, x4, rho_air, T, log_lambda,
                                       dNdt, dLdt, stream);
+}
+
+int32_t cmx_p3_ice_self_collection_f32(const cmx_p3_params_f32 *params, const cmx_chen2022_ice_vel_f32 *vel, const cmx_quadrature_f32 *quad,
+                                       uint32_t flags, int64_t n, const float *rho_q_ice, const float *rho_n_ice, const float *x3,
+                                       const float *x4, const float *rho_air, const float *log_lambda, float *dNdt, void *stream) {
+    return cmx::p3_self_collection_entry<float>(params, vel, quad, flags, n, rho_q_ice, rho_n_ice, x3, x4, rho_air, log_lambda, dNdt, stream);
+}
+int32_t cmx_p3_ice_self_collection_f64(const cmx_p3_params_f64 *params, const cmx_chen2022_ice_vel_f64 *vel, const cmx_quadrature_f64 *quad,
+                                       uint32_t flags, int64_t n, const double *rho_q_ice, const double *rho_n_ice, const double *x3,
+                                       const double *x4, const double *rho_air, const double *log_lambda, double *dNdt, void *stream) {
+    return cmx::p3_self_collection_entry<double>(params, vel, quad, flags, n, rho_q_ice, rho_n_ice, x3, x4, rho_air, log_lambda, dNdt, stream);
 }
 
 }  // extern "C"

@@ -632,6 +632,18 @@ int32_t cmx_p3_ice_melt_f64(const cmx_p3_params_f64 *params, const cmx_chen2022_
                             double p, int64_t n, const double *rho_q_ice, const double *rho_n_ice, const double *x3, const double *x4,
                             const double *rho_air, const double *T, const double *log_lambda, double *dNdt, double *dLdt, void *stream);
 
+/* P3 ice self-collection (aggregation): replaces, per point,
+ *   (; dNdt) = P3.ice_self_collection(state, logλ, vel, ρₐ; quad)                          src/P3_processes.jl:676-712
+ * (KA kernels test_P3_ice_self_collection_kernel!, test/gpu_tests.jl:444-451, and the reference's own P3 benchmark kernel
+ * benchmark_p3_kernel!, test/gpu_performance.jl:59-67).  dN/dt ≥ 0 is the loss rate of ice number [1/m³/s].  8·quad.n²
+ * integrand evaluations per point. */
+int32_t cmx_p3_ice_self_collection_f32(const cmx_p3_params_f32 *params, const cmx_chen2022_ice_vel_f32 *vel, const cmx_quadrature_f32 *quad,
+                                       uint32_t flags, int64_t n, const float *rho_q_ice, const float *rho_n_ice, const float *x3,
+                                       const float *x4, const float *rho_air, const float *log_lambda, float *dNdt, void *stream);
+int32_t cmx_p3_ice_self_collection_f64(const cmx_p3_params_f64 *params, const cmx_chen2022_ice_vel_f64 *vel, const cmx_quadrature_f64 *quad,
+                                       uint32_t flags, int64_t n, const double *rho_q_ice, const double *rho_n_ice, const double *x3,
+                                       const double *x4, const double *rho_air, const double *log_lambda, double *dNdt, void *stream);
+
 /* ---------------------------------------------------------------------------
  * (3) Optional diagnostic sums over one rank's shard: per-column
  * Σx (double accumulation) of `ncols` device columns of length n into

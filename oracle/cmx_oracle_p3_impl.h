@@ -424,6 +424,64 @@ void FN(cmxo_p3_ice_melt)(const TY(cmx_p3_params) * pr, const TY(cmx_chen2022_ic
         FN(o_p3_ice_melt)(pr, vel, aps, tps, vent, quad, flags, &s, rho_a[i], T[i], loglam[i], p, gi_iters, &dNdt[i], &dLdt[i]);
     }
 }
+/* ice_self_collection — src/P3_processes.jl:676-712: dN/dt = ½ ∫∫ π (r₁+r₂)² |v₁−v₂| n(D₁) n(D₂) dD₂ dD₁, r = √(ice_area/π), E = 1;
+ * outer integral over the regime segments between the eps(FT) and 1−eps(FT) quantiles, inner integral split at the cusp D₂ = D₁ */
+static inline FT FN(o_p3_ice_self_collection)(const TY(cmx_p3_params) * pr, const TY(cmx_chen2022_ice_vel) * vel, const TY(cmx_quadrature) * quad,
+                                             uint32_t flags, const TY(cmxo_p3_state) * s, FT rho_a, FT loglam, int gi_iters) {
+    if (s->rho_n_ice < s->eps || s->rho_q_ice < s->eps) return 0;
+    TY(cmxo_p3_vterm) vt;
+    const FT rho_i = (FT)916.7, pi = (FT)M_PI;
+    FN(o_chen_small_ice)(&vel->small_ice, rho_a, rho_i, vt.as, vt.bs, vt.cs);
+    FN(o_chen_large_ice)(&vel->large_ice, rho_a, rho_i, vt.al, vt.bl, vt.cl);
+    vt.cutoff = vel->small_ice.cutoff;
+    vt.aspect = !(flags & CMX_P3_NO_ASPECT_RATIO);
+    FT mu = FN(o_p3_mu)(pr, flags, loglam), lam = M_EXP(loglam);
+    FT logN0 = M_LOG(s->rho_n_ice) - FN(o_loggamma_moment)(mu, loglam, (FT)0);
+    FT Y1 = s->eps, Y2 = 1 - s->eps;            /* p = eps(one(ρₐ)) */
+    FT D_lo = FN(o_gamma_inc_inv)(mu + 1, Y1, 1 - Y1, gi_iters, s->eps) / lam;
+    FT D_hi = FN(o_gamma_inc_inv)(mu + 1, Y2, 1 - Y2, gi_iters, s->eps) / lam;
+    FT bnd[5] = {D_lo, FN(o_clamp)(s->D_th, D_lo, D_hi), FN(o_clamp)(s->D_gr, D_lo, D_hi), FN(o_clamp)(s->D_cr, D_lo, D_hi), D_hi};
+    FT total = 0;
+    for (int k = 0; k < 4; ++k) {
+        FT a = bnd[k], b = bnd[k + 1];
+        if (!(a < b)) continue;
+        FT scale = (b - a) / 2, shift = (a + b) / 2, r_out = 0;
+        for (int i = 0; i < quad->n; ++i) {
+            FT D1 = scale * quad->node[i] + shift;
+            FT v1 = FN(o_p3_particle_velocity)(pr, s, &vt, D1);
+            FT r1 = M_SQRT(FN(o_p3_ice_area)(pr, s, D1) / pi);
+            FT inner = 0;
+            for (int h = 0; h < 2; ++h) {
+                FT ia = h == 0 ? D_lo : D1, ib = h == 0 ? D1 : D_hi;
+                if (!(ia < ib)) continue;
+                FT sc2 = (ib - ia) / 2, sh2 = (ia + ib) / 2, r_in = 0;
+                for (int j = 0; j < quad->n; ++j) {
+                    FT D2 = sc2 * quad->node[j] + sh2;
+                    FT v2 = FN(o_p3_particle_velocity)(pr, s, &vt, D2);
+                    FT r2 = M_SQRT(FN(o_p3_ice_area)(pr, s, D2) / pi);
+                    FT K = pi * (r1 + r2) * (r1 + r2);
+                    r_in += K * M_ABS(v1 - v2) * M_EXP(logN0 + mu * M_LOG(D2) - lam * D2) * quad->weight[j];
+                }
+                inner += sc2 * r_in;
+            }
+            r_out += inner * M_EXP(logN0 + mu * M_LOG(D1) - lam * D1) * quad->weight[i];
+        }
+        total += scale * r_out;
+    }
+    return (FT)0.5 * total;
+}
+void FN(cmxo_p3_ice_self_collection)(const TY(cmx_p3_params) * pr, const TY(cmx_chen2022_ice_vel) * vel, const TY(cmx_quadrature) * quad,
+                                    uint32_t flags, const TY(cmxo_thresholds) * th, int64_t n, const FT *rho_q_ice, const FT *rho_n_ice,
+                                    const FT *x3, const FT *x4, const FT *rho_a, const FT *loglam, FT *dNdt, int32_t nthreads) {
+    const int gi_iters = sizeof(FT) == 4 ? 20 : 30;
+    (void)nthreads;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads > 0 ? nthreads : 1)
+    for (int64_t i = 0; i < n; ++i) {
+        TY(cmxo_p3_state) s = (flags & CMX_P3_INPUT_IS_STATE) ? FN(o_p3_state)(pr, rho_q_ice[i], rho_n_ice[i], x3[i], x4[i], th->eps_ft)
+                                                              : FN(o_p3_state_from_prognostic)(pr, rho_q_ice[i], rho_n_ice[i], x3[i], x4[i], th->eps_ft);
+        dNdt[i] = FN(o_p3_ice_self_collection)(pr, vel, quad, flags, &s, rho_a[i], loglam[i], gi_iters);
+    }
+}
 /* probes for the KATs: particle fall speed at diameter D for a state built from (F_rim, ρ_rim); gamma_inc_inv */
 FT FN(cmxo_p3_particle_velocity)(const TY(cmx_p3_params) * pr, const TY(cmx_chen2022_ice_vel) * vel, uint32_t flags, FT F_rim, FT rho_rim,
                                 FT rho_a, FT D) {

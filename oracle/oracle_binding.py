@@ -331,6 +331,22 @@ def p3_ice_melt(fam, params, vel, aps, tps, vent, quad, flags, rho_q_ice, rho_n_
     return dN, dL
 
 
+def p3_ice_self_collection(fam, params, vel, quad, flags, rho_q_ice, rho_n_ice, x3, x4, rho_a, log_lambda, *, float32_gates=None,
+                           nthreads=1):
+    """Oracle twin of cmx_p3_ice_self_collection_*: dNdt column."""
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    ins = [_col(fam, a) for a in (rho_q_ice, rho_n_ice, x3, x4, rho_a, log_lambda)]
+    n = ins[0][0].size
+    out = np.empty(n, dtype=NP[fam.sfx])
+    fn = getattr(lib(), f"cmxo_p3_ice_self_collection_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(params), C.byref(vel), C.byref(quad), C.c_uint32(flags), C.byref(th), C.c_int64(n), *[q for _, q in ins],
+       out.ctypes.data_as(C.c_void_p), C.c_int32(nthreads))
+    return out
+
+
 def p3_particle_velocity(fam, params, vel, flags, F_rim, rho_rim, rho_a, D):
     fn = getattr(lib(), f"cmxo_p3_particle_velocity_{fam.sfx}")
     fn.restype = fam.ft

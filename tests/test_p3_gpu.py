@@ -349,3 +349,35 @@ def test_ice_melt(dev, oracle, ft):
         e = np.abs(x[nz] - r_[nz]) / np.abs(r_[nz]) / (amp[nz] if ft == "f32" else 1.0)
         assert e.max() <= RTOL[ft], float(e.max())
     assert (dL > 0).mean() > 0.3 and (dL == 0).mean() > 0.3
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_ice_self_collection(dev, oracle, ft):
+    """cmx_p3_ice_self_collection_*: the reference's tests (test/p3_tests.jl:885-917; KA kernel test/gpu_tests.jl:1285-1300:
+    positive loss rate, zero without ice) + random-state parity with the oracle (GaussLegendre(12) — 1152 nodes per point)."""
+    import cmx
+    from cmx import synthetic
+    p, vel = P.ParametersP3(ft), P.Chen2022VelTypeIce(ft)
+    col = lambda v: torch.tensor(v, dtype=DT[ft], device=dev)  # noqa: E731
+    cols = (col([1.2e-4, 0.0]), col([2.4e5, 0.0]), col([0.8, 0.8]), col([800.0, 800.0]))
+    ll = cmx.p3_shape(p, *cols, from_state=True, want=("log_lambda",)).log_lambda
+    r = cmx.p3_ice_self_collection(p, vel, col([1.2, 1.2]), *cols, ll, from_state=True, quad=P.GaussLegendre(ft, 12))
+    assert float(r[0]) > 0 and float(r[1]) == 0
+    m = 4_000
+    st = _columns(m, ft, True, seed=41)
+    rho_a = synthetic.p3_air_density(m, dtype=DT[ft])
+    dcols = [c.to(dev) for c in st]
+    ll = cmx.p3_shape(p, *dcols, from_state=True, want=("log_lambda",), brent_iters=40).log_lambda
+    for aspect in (True, False):
+        got = cmx.p3_ice_self_collection(p, vel, rho_a.to(dev), *dcols, ll, from_state=True, aspect_ratio=aspect,
+                                         quad=P.GaussLegendre(ft, 12))
+        c64 = [c.numpy().astype(np.float64) for c in st]
+        ref = oracle.p3_ice_self_collection(_abi.F64, P.ParametersP3("f64").c, P.Chen2022VelTypeIce("f64"), P.GaussLegendre("f64", 12),
+                                            STATE | (0 if aspect else _abi.CMX_P3_NO_ASPECT_RATIO), *c64,
+                                            rho_a.numpy().astype(np.float64), _np64(ll), float32_gates=(ft == "f32"), nthreads=8)
+        x = _np64(got)
+        assert np.array_equal(x == 0, ref == 0)
+        nz = ref != 0
+        e = np.abs(x[nz] - ref[nz]) / ref[nz]
+        print(f"\n[P3 self-collection] {ft} aspect={aspect}: max rel err {e.max():.2e}")
+        assert e.max() <= RTOL[ft] and np.all(x >= 0)

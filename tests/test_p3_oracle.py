@@ -172,3 +172,19 @@ def test_ice_melt_kats(oracle):
     np.testing.assert_allclose(dL[1:], g["dLdt"][1:], rtol=g["rtol"])
     # dN/dt = N/L · dL/dt exactly
     np.testing.assert_allclose(dN[1:] / dL[1:], g["N_ice"] / g["L_ice"], rtol=1e-14)
+
+
+def test_ice_self_collection_properties(oracle):
+    """test/p3_tests.jl:885-917 (positive loss rate, zero without ice) + quadrature convergence + N² scaling of the
+    double integral (doubling N at fixed λ doubles n(D) everywhere → 4× the rate)."""
+    p, vel = P.ParametersP3("f64").c, P.Chen2022VelTypeIce("f64")
+    cols = ([1.2e-4], [2.4e5], [0.8], [800.0])
+    ll = oracle.p3_shape(F64, p, STATE, *cols)["log_lambda"]
+    r12 = oracle.p3_ice_self_collection(F64, p, vel, P.GaussLegendre("f64", 12), STATE, *cols, [1.2], ll)[0]
+    r40 = oracle.p3_ice_self_collection(F64, p, vel, P.GaussLegendre("f64", 40), STATE, *cols, [1.2], ll)[0]
+    rc = oracle.p3_ice_self_collection(F64, p, vel, P.ChebyshevGauss("f64", 100), STATE, *cols, [1.2], ll)[0]
+    assert r12 > 0 and abs(r12 / r40 - 1) < 2e-3 and abs(rc / r40 - 1) < 1e-4
+    assert oracle.p3_ice_self_collection(F64, p, vel, P.GaussLegendre("f64", 12), STATE, [0.0], [0.0], [0.8], [800.0], [1.2], [-np.inf])[0] == 0
+    # same λ (same L/N), twice the number: n(D) doubles → rate × 4
+    r2 = oracle.p3_ice_self_collection(F64, p, vel, P.GaussLegendre("f64", 40), STATE, [2.4e-4], [4.8e5], [0.8], [800.0], [1.2], ll)[0]
+    assert abs(r2 / r40 - 4) < 1e-9
