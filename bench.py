@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=100_000_000, help="grid points per GPU")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--workload", choices=["sb2006", "icenuc", "mp1m", "mp1m_lin", "arg2000", "p3"], default="sb2006")
+    ap.add_argument("--workload", choices=["sb2006", "icenuc", "mp1m", "mp1m_lin", "arg2000", "p3", "p3_selfcol"], default="sb2006")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the bounded baseline sample")
     ap.add_argument("--diagnostics", action="store_true",
@@ -266,6 +266,50 @@ def setup_p3(args, dev, dtype, rank):
     return list(st) + [rho_a], step, desc, cpu_run
 
 
+def setup_p3_selfcol(args, dev, dtype, rank):
+    """The reference's own P3 GPU benchmark kernel (benchmark_p3_kernel!, test/gpu_performance.jl:59-67): P3State from
+    (L_ice, N_ice, F_rim, ρ_rim), get_distribution_logλ and ice_self_collection per state."""
+    import torch
+
+    import cmx
+    from cmx import _abi
+    from cmx import parameters as P
+    from cmx import synthetic
+    st = synthetic.p3_state(args.points, dtype=torch.float64, device=dev, seed=1234 + rank)
+    F = torch.where(st.rho_q_ice > 0, st.rho_q_rim / st.rho_q_ice.clamp(min=1e-300), torch.zeros_like(st.rho_q_ice))
+    rr = torch.where(st.rho_b_rim > 0, st.rho_q_rim / st.rho_b_rim.clamp(min=1e-300), torch.full_like(F, 400.0))
+    cols = [c.to(dtype) for c in (st.rho_q_ice, st.rho_n_ice, F, rr)]
+    rho_a = synthetic.p3_air_density(args.points, dtype=dtype, device=dev, seed=4321 + rank)
+    p, vel = P.ParametersP3(args.dtype), P.Chen2022VelTypeIce(args.dtype)
+    quad = P.GaussLegendre(args.dtype, 40)            # ClimaAtmos production quadrature order (src/Quadrature.jl:216)
+    holder = {}
+
+    def step():
+        shp = cmx.p3_shape(p, *cols, from_state=True, want=("log_lambda",))
+        holder["out"] = (shp.log_lambda, cmx.p3_ice_self_collection(p, vel, rho_a, *cols, shp.log_lambda, from_state=True, quad=quad))
+
+    def cpu_run(ob, c, threads):
+        fam = _abi.family(args.dtype)
+        S = _abi.CMX_P3_INPUT_IS_STATE
+
+        def run():
+            ll = ob.p3_shape(fam, p.c, S, *c[:4], nthreads=threads)["log_lambda"]
+            ob.p3_ice_self_collection(fam, p.c, vel, quad, S, *c, ll, nthreads=threads)
+        return run
+
+    step()
+    desc = {
+        "metric": "states/sec P3 benchmark kernel (log-lambda + ice self-collection, GaussLegendre(40))",
+        "bytes_per_point": {"f32": 28, "f64": 56}[args.dtype],      # 5 in + 2 out
+        "kernel": "p3_shape_kernel + p3_self_collection_kernel",
+        "workload": "P3State + get_distribution_logλ + ice_self_collection (double quadrature, 8 n² = 12800 integrand evaluations per "
+                    "state) — the reference's benchmark_p3_kernel!",
+        "columns_in": 5, "columns_out": 2, "diag_cols": [],
+        "note": "FP64/FP32-vector compute-bound (≈3e6 VALU instructions per state); the HBM fraction is tiny by nature",
+    }
+    return cols + [rho_a], step, desc, cpu_run
+
+
 def cpu_baseline(args, cols_np, desc, cpu_run):
     """The oracle — a C restatement of the reference's scalar arithmetic (kind 'port'; the Julia reference cannot
     run here) — timed on the host cores over repeated passes of a bounded sample of the same synthetic workload."""
@@ -309,7 +353,7 @@ def main():
     n = args.points                                          # weak scaling: fixed work per GPU
     # rank r owns shard r of the global [0, world·n) index space: disjoint seeds, no exchange
     setup = {"sb2006": setup_sb2006, "icenuc": setup_icenuc, "mp1m": setup_mp1m, "mp1m_lin": setup_mp1m_lin, "arg2000": setup_arg2000,
-             "p3": setup_p3}[args.workload]
+             "p3": setup_p3, "p3_selfcol": setup_p3_selfcol}[args.workload]
     state, kernel_step, desc, cpu_run = setup(args, dev, dtype, rank)
 
     def step():
@@ -363,7 +407,7 @@ def main():
         if "note" in desc:
             line["roofline"]["note"] = desc["note"]
         if not args.no_cpu_baseline and world == 1:
-            m = min(n, {"sb2006": 20_000_000, "p3": 100_000}.get(args.workload, 4_000_000))
+            m = min(n, {"sb2006": 20_000_000, "p3": 100_000, "p3_selfcol": 2_000}.get(args.workload, 4_000_000))
             cols_np = [np.ascontiguousarray(c[:m].cpu().numpy()) for c in state]
             line["cpu_baseline"] = cpu_baseline(args, cols_np, desc, cpu_run)
         print(json.dumps(line), flush=True)
