@@ -10,6 +10,8 @@ for wl in sb2006 icenuc mp1m arg2000; do
 done
 for dt in f32 f64; do
   timeout 600 python bench.py --workload p3 --dtype $dt --points 10000000 --steps 5 --warmup 1 > gpurun_out/bench/p3_${dt}.json 2> gpurun_out/bench/p3_${dt}.err
+  timeout 600 python bench.py --workload p3_selfcol --dtype $dt --points 1000000 --steps 3 --warmup 1 > gpurun_out/bench/p3_selfcol_${dt}.json 2> gpurun_out/bench/p3_selfcol_${dt}.err
+  timeout 600 python bench.py --workload mp1m_lin --dtype $dt --steps 10 --warmup 2 > gpurun_out/bench/mp1m_lin_${dt}.json 2> gpurun_out/bench/mp1m_lin_${dt}.err
 done
 tools/profile.sh sb2006 f32 100000000 > /dev/null
 tools/profile.sh sb2006 f64 100000000 > /dev/null
