@@ -38,6 +38,8 @@ template <typename FT> struct SbConsts {
     FT xr_min, xr_max, N0_min, N0_max, lam_min, lam_max, pi_rho_w;
     // evaporation (CM2:780-828)
     FT l2_6xstar, l2_Drc;               // log2(6 x*), log2(6/(π ρw))
+    // log2 of the PSD limiters (the rain PSD parameters are formed in the log2 domain)
+    FT l2_pi_rho_w, l2_xr_min, l2_xr_max, l2_N0_min, l2_N0_max, l2_lam_min, l2_lam_max, inv_eps_1m;
     FT ga_c1, ga_e1, ga_c2, ga_e2;      // Γ_incl(−1, t)   (CM2:746-753)
     FT gb_c1, gb_e1, gb_c2, gb_e2;      // Γ_incl(β_vent_0, t)
     FT a_vent_0_coeff, bSc_vent_0, a_vent_1, bSc_vent_1;   // b·∛Sc folded
@@ -98,6 +100,11 @@ inline SbConsts<FT> make_sb_consts(const WR &wr, const TH &tp, const VL *vel, do
     const double x_star_ev = (double)pr.xr_min;  // CM2:795
     c.l2_6xstar = (FT)std::log2(6.0 * x_star_ev);
     c.l2_Drc = (FT)std::log2(6.0 / (pi * (double)pr.rho_w));
+    c.l2_pi_rho_w = (FT)std::log2(pi * (double)pr.rho_w);
+    c.l2_xr_min = (FT)std::log2((double)pr.xr_min); c.l2_xr_max = (FT)std::log2((double)pr.xr_max);
+    c.l2_N0_min = (FT)std::log2(std::fmax((double)pr.N0_min, 1e-300)); c.l2_N0_max = (FT)std::log2(std::fmax((double)pr.N0_max, 1e-300));
+    c.l2_lam_min = (FT)std::log2(std::fmax((double)pr.lambda_min, 1e-300)); c.l2_lam_max = (FT)std::log2(std::fmax((double)pr.lambda_max, 1e-300));
+    c.inv_eps_1m = (FT)(1.0 / eps_1m);
     auto gincl = [](double a, FT &c1, FT &e1, FT &c2, FT &e2) {
         c1 = (FT)(0.33 - 0.7 * a);
         e1 = (FT)(0.08 - 0.93 * a);
@@ -225,7 +232,7 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
     }
     const FT S = M::fma(q_vap * rho_RvT, inv_p_sat, FT(-1));                 // TDI.supersaturation_over_liquid
     // G_func_liquid  Common.jl:47-63
-    const FT inv_p_safe = (p_sat > c.eps_1m) ? inv_p_sat : M::rcp(c.eps_1m);
+    const FT inv_p_safe = M::min(inv_p_sat, c.inv_eps_1m);                  // 1/max(p_sat, ϵ)
     const FT G = M::rcp(M::fma(L_v * c.inv_K * inv_T, LoRT - FT(1), c.Rv_over_D * T * inv_p_safe));
 
     // ---- cloud side: autoconversion, cloud self-collection, accretion --------------------------
@@ -269,24 +276,25 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
         const bool gate = no_q_lcl || no_q_rai || no_N_lcl;
         r.ac_dq_rai = gate ? FT(0) : dL_rai * inv_rho;
         r.ac_dq_lcl = -r.ac_dq_rai;
-        r.ac_dN_lcl = gate ? FT(0) : -dL_rai * M::rcp(x_lcl_raw);
+        // −dL_rai / x̄_c with x̄_c = L_lcl / N_lcl: the L_lcl of dL_rai cancels
+        r.ac_dN_lcl = gate ? FT(0) : -(c.kcr_s * rs_rho * L_rai * phi_ac) * sN_lcl;
     }
 
     // ---- rain PSD parameters, once (CM2:67-110), from the safe values ----------
-    FT xr_mean, lam, Dr_mean;
+    // All four limiters (Eq. 94-97) are clamps of monotone power laws of L_rai and N_rai, so they are applied to the
+    // log2 values: two log2 in, then every derived quantity is one exp2 (11 → 5-6 transcendentals).
+    const FT l2_L = M::log2(L_rai), l2_N = M::log2(sN_rai);
+    FT l2_xr, l2_lam;
     if constexpr (LIMITED) {
-        const FT xt = clampv(L_rai * M::rcp(sN_rai), c.xr_min, c.xr_max);                      // Eq. 94
-        const FT cb = M::exp2(M::log2(c.pi_rho_w * M::rcp(xt)) * FT(1.0 / 3.0));
-        const FT N0 = clampv(sN_rai * cb, c.N0_min, c.N0_max);                                // Eq. 95
-        lam = clampv(M::sqrt(M::sqrt(c.pi_rho_w * N0 * M::rcp(L_rai))), c.lam_min, c.lam_max); // Eq. 96
-        xr_mean = clampv(L_rai * lam * M::rcp(N0), c.xr_min, c.xr_max);                       // Eq. 97
-        Dr_mean = M::rcp(lam);
+        const FT l2_xt = clampv(l2_L - l2_N, c.l2_xr_min, c.l2_xr_max);                               // Eq. 94
+        const FT l2_N0 = clampv(l2_N + (c.l2_pi_rho_w - l2_xt) * FT(1.0 / 3.0), c.l2_N0_min, c.l2_N0_max);   // Eq. 95
+        l2_lam = clampv((c.l2_pi_rho_w + l2_N0 - l2_L) * FT(0.25), c.l2_lam_min, c.l2_lam_max);       // Eq. 96
+        l2_xr = clampv(l2_L + l2_lam - l2_N0, c.l2_xr_min, c.l2_xr_max);                              // Eq. 97
     } else {
-        xr_mean = L_rai * M::rcp(sN_rai);
-        lam = M::exp2(M::log2(c.pi_rho_w * M::rcp(xr_mean)) * FT(1.0 / 3.0));
-        Dr_mean = M::rcp(lam);
+        l2_xr = l2_L - l2_N;
+        l2_lam = (c.l2_pi_rho_w - l2_xr) * FT(1.0 / 3.0);
     }
-    const FT l2_xr = M::log2(xr_mean);
+    const FT xr_mean = M::exp2(l2_xr), lam = M::exp2(l2_lam), Dr_mean = M::exp2(-l2_lam);
     const FT l2_Dr = (l2_xr + c.l2_Drc) * FT(1.0 / 3.0);
     const FT Dr = M::exp2(l2_Dr);                       // ∛(6 x̄_r/(π ρw)): CM2:588 and :809
     const bool no_N_rai = N_rai < eps;
@@ -313,7 +321,7 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
         const FT Fv0 = M::fma(c.bSc_vent_0 * g_b, sqrt_N_Re, c.a_vent_0_coeff * g_a);
         const FT Fv1 = M::fma(c.bSc_vent_1, sqrt_N_Re, c.a_vent_1);
         const FT common = c.two_pi * G * S * N_rai * Dr;
-        const FT inv_xr = M::rcp(xr_mean);
+        const FT inv_xr = M::exp2(-l2_xr);
         const FT dN = M::min(FT(0), common * Fv0 * inv_xr);
         const FT dq = M::min(FT(0), common * Fv1 * inv_rho);
         const bool gate_q = no_q_rai || (N_rai <= eps) || (S >= FT(0));
@@ -350,7 +358,7 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
         const FT rho_c = M::max(rho, FT(0));
         const FT l2_q = c.ch_rho0_l2e * rho_c;                  // log2 exp(ρ0 ρ)
         const FT l2_rho = M::log2(rho_c);
-        const FT l2_lam_inv = -M::log2(lam);                    // log2 Dr_mean
+        const FT l2_lam_inv = -l2_lam;                          // log2 Dr_mean
         FT vt0 = FT(0), vt3 = FT(0);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
