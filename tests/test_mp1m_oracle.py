@@ -203,6 +203,11 @@ def test_chen2022_sedimentation_velocity_kats(oracle):
                                         [g["rho"]], [g["q_lcl"]], [g["q_icl"]], [g["q_rai"]], [g["q_sno"]])
     for k in ("w_lcl", "w_icl", "w_rai", "w_sno"):
         assert math.isclose(r[k][0], g[k], rel_tol=g["rtol"]), k
+    e = g["extra"]      # test/microphysics1M_tests.jl:56-78
+    x = oracle.sedimentation_velocities(F64, mp.c, P.StokesRegimeVelType("f64"), P.Chen2022VelTypeRain("f64"), P.Chen2022VelTypeIce("f64"),
+                                        [e["snow"]["rho"], e["rain"]["rho"]], [0.0, 0.0], [0.0, 0.0], [0.0, e["rain"]["q_rai"]],
+                                        [e["snow"]["q_sno"], 0.0])
+    assert math.isclose(x["w_sno"][0], e["snow"]["w_sno"], rel_tol=1e-14) and math.isclose(x["w_rai"][1], e["rain"]["w_rai"], rel_tol=1e-14)
     z = oracle.sedimentation_velocities(F64, mp.c, P.StokesRegimeVelType("f64"), P.Chen2022VelTypeRain("f64"), P.Chen2022VelTypeIce("f64"),
                                         [1.0, 1.0], [0.0, -1e-9], [0.0, -1e-9], [0.0, -1e-9], [0.0, -1e-9])
     assert all(np.all(v == 0) for v in z.values())
