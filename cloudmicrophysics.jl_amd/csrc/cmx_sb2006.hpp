@@ -187,6 +187,7 @@ template <typename FT> struct SbRates {
     FT cond;                                            // NonEq:117-140 [kg/kg/s]
     FT au_dq_lcl, au_dN_lcl, au_dq_rai, au_dN_rai;      // CM2:396-427
     FT lsc;                                             // CM2:488-501 [1/m3/s]
+    FT lsc_plus_au;                                     // lsc + au_dN_lcl = −k_sc/ρ·L² (the autoconversion part cancels), gated like lsc
     FT ac_dq_lcl, ac_dN_lcl, ac_dq_rai;                 // CM2:445-470
     FT rsc, rbr;                                        // CM2:545-601 [1/m3/s]
     FT evN, evq;                                        // CM2:780-828
@@ -269,6 +270,8 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
         const FT Lr = rho * q_lcl;
         const FT sc = -c.ksc * inv_rho * (Lr * Lr) - r.au_dN_lcl;
         r.lsc = no_q_lcl ? FT(0) : sc;
+        // with q_lcl present but N_lcl absent autoconversion is gated to 0 and lsc = −k_sc/ρ·L² as well: one expression serves both
+        r.lsc_plus_au = no_q_lcl ? FT(0) : -c.ksc * inv_rho * (Lr * Lr);
     }
     {   // accretion CM2:445-470
         const FT phi_ac = M::exp2(c.accr_c * (l2_tau - M::log2(tau + c.tau_0)));

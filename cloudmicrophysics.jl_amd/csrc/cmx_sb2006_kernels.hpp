@@ -61,11 +61,13 @@ __global__ __launch_bounds__(BS) void sb2006_tendencies_kernel(const SbConsts<FT
             const FT nr = M::max(FT(0), n_rai[t][k]);
             // N = ρ n — BMT:718-719
             const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL>(c, r_, T[t][k], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
-            // accumulation order of warm_rain_tendencies_2m — BMT:738-779
+            // sums of warm_rain_tendencies_2m — BMT:738-779.  The per-m³ number rates are added first and divided by ρ once (the
+            // reference divides each term: same value to rounding, five multiplies fewer); autoconversion's −2·dN_rai cancels
+            // against the same term inside cloud self-collection (CM2:499), so their sum is formed directly.
             dq_lcl[k] = (p.cond + p.au_dq_lcl) + p.ac_dq_lcl;
-            dn_lcl[k] = ((p.au_dN_lcl * p.inv_rho + p.lsc * p.inv_rho) + p.ac_dN_lcl * p.inv_rho) + p.na_lcl;
+            dn_lcl[k] = M::fma(p.lsc_plus_au + p.ac_dN_lcl, p.inv_rho, p.na_lcl);
             dq_rai[k] = (p.evq + p.au_dq_rai) + p.ac_dq_rai;
-            dn_rai[k] = (((p.evN * p.inv_rho + p.au_dN_rai * p.inv_rho) + p.rsc * p.inv_rho) + p.rbr * p.inv_rho) + p.na_rai;
+            dn_rai[k] = M::fma(((p.evN + p.au_dN_rai) + p.rsc) + p.rbr, p.inv_rho, p.na_rai);
             vt_n[k] = p.vt_n;
             vt_m[k] = p.vt_m;
         }
