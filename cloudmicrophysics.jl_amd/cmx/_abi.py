@@ -22,6 +22,7 @@ CMX_2M_SMOOTH_TRANSITION = 1 << 8
 CMX_P3_INPUT_IS_STATE = 1 << 0
 CMX_P3_SLOPE_CONSTANT = 1 << 1
 CMX_P3_NO_ASPECT_RATIO = 1 << 2
+CMX_P3_RAIN_PDF_LIMITED = 1 << 3
 CMX_QUAD_MAX = 128
 
 CMX_ICENUC_HOM_LINEAR = 1 << 0
@@ -170,6 +171,16 @@ def _family(ft, sfx):
         ("small_ice", ns.chen2022_small_ice_vel), ("large_ice", ns.chen2022_large_ice_vel)])
     ns.quadrature = _struct(f"cmx_quadrature_{sfx}", [
         ("n", C.c_int32), ("reserved", C.c_int32), ("node", ft * CMX_QUAD_MAX), ("weight", ft * CMX_QUAD_MAX)])
+    # ---- P3 liquid–ice collisions, immersion / deposition nucleation, P3IceParams
+    ns.local_rime_density = _struct(f"cmx_local_rime_density_{sfx}", s("a", "b", "c", "rho_ice"))
+    ns.rain_freezing = _struct(f"cmx_rain_freezing_{sfx}", s("het_a", "het_B"))
+    ns.frostenberg2023 = _struct(f"cmx_frostenberg2023_{sfx}", s("sigma", "a", "b", "T_freeze", "log_a"))
+    ns.morrison_milbrandt2014 = _struct(f"cmx_morrison_milbrandt2014_{sfx}", s("T_dep_thres", "c1", "c2", "T0", "het_a", "het_B"))
+    ns.p3_ice_params = _struct(f"cmx_p3_ice_params_{sfx}", [
+        ("scheme", ns.p3_params), ("vent", ns.ventilation), ("rho_rim_local", ns.local_rime_density),
+        ("vel_rain", ns.chen2022_rain_vel), ("vel_ice", ns.chen2022_ice_vel), ("cloud_pdf", ns.cloud_pdf_sb2006),
+        ("rain_pdf", ns.rain_pdf_sb2006), ("ice_nucleation", ns.frostenberg2023), ("rain_freezing", ns.rain_freezing),
+        ("tau_act", ft), ("quad", ns.quadrature)])
     return ns
 
 

@@ -186,6 +186,19 @@ DEFAULT_PARAMETERS = {
     "Chen2022_table_B5_Fl": (0.515453, -0.0725042, -1.86810e19), "Chen2022_table_B5_Gl": (2.65236, 0.00158269, 259.935),
     "Chen2022_table_B5_Hl": (-0.346044, -7.17829e-11, -1.24394e20),
     "Chen2022_ice_cutoff": 0.000625,
+    # Cober & List (1993) local rime density, Eq. 17 in kg/m³ — pinned by test/p3_tests.jl:719-726 (a + b + c = 159.5,
+    # ρ′(8) = 51 + 114·8 − 5.5·64, ρ′(12) = ρ_ice)
+    "CL1993_local_rime_density_constant_coeff": 51.0, "CL1993_local_rime_density_linear_coeff": 114.0,
+    "CL1993_local_rime_density_quadratic_coeff": -5.5,
+    # Bigg (1953) / Barklie & Gokhale (1959) immersion freezing: B·exp(a·33.15) pinned by the P3_het_N_i KAT
+    # (test/gpu_tests.jl:1014-1037: 0.0002736160475969029 at T = 240, N = 2000, V = 3e-18, Δt = 0.1) with a = 0.65
+    "BarklieGokhale1959_a_parameter": 0.65, "BarklieGokhale1959_B_parameter": 200.0,
+    # Thompson et al. (2004) / Cooper deposition number: pinned by P3_deposition_N_i(240 K) = 119018.93920746
+    # (test/gpu_tests.jl:1001-1012); T_dep_thres ∈ (232, 234] by test/heterogeneous_ice_nucleation_tests.jl:155-168
+    "Thompson2004_c1_Cooper": 0.005, "Thompson2004_c2_Cooper": 0.304, "temperature_homogenous_nucleation": 233.0,
+    # Frostenberg et al. (2023) INPC(T) climatology: a = b = 1 pinned by INP_concentration_mean = 9 log 2
+    # (test/heterogeneous_ice_nucleation_tests.jl:250-253); σ = 1.37 from docs/src/IceNucleation.md:299
+    "Frostenberg2023_standard_deviation": 1.37, "Frostenberg2023_a_coefficient": 1.0, "Frostenberg2023_b_coefficient": 1.0,
 }
 
 # the reference's calibrated override file src/parameters/toml/ARG2000.toml (PySDM-based calibration)
@@ -397,11 +410,9 @@ class Microphysics2MParams:
     src/parameters/Microphysics2MParams.jl:134-162.  Only the warm-rain (`ice == nothing`) form is
     on this path."""
 
-    def __init__(self, FT, with_ice: bool = False, is_limited: bool = True):
-        if with_ice:
-            raise NotImplementedError("2M + P3 ice entry (BMT:898-1083) is outside the current hot path (DESIGN.md §7)")
+    def __init__(self, FT, with_ice: bool = False, is_limited: bool = True, quadrature_order: int = 16, tau_act: float = 300.0):
         self.warm_rain = WarmRainParams2M(FT, is_limited)
-        self.ice = None
+        self.ice = P3IceParams(FT, is_limited=is_limited, quadrature_order=quadrature_order, tau_act=tau_act) if with_ice else None
         self.fam = self.warm_rain.fam
 
 
@@ -632,7 +643,7 @@ def Chen2022VelTypeIce(FT):
 
 
 def _quadrature(FT, nodes, weights):
-    fam = _abi.family(FT)
+    fam = FT.fam if isinstance(FT, ParamDict) else _abi.family(FT)
     n = len(nodes)
     if not 1 <= n <= _abi.CMX_QUAD_MAX:
         raise ValueError(f"quadrature order must be in 1..{_abi.CMX_QUAD_MAX}")
@@ -656,6 +667,68 @@ def GaussLegendre(FT, n: int):
     import numpy as np
     y, w = np.polynomial.legendre.leggauss(n)
     return _quadrature(FT, y, w)
+
+
+def build_quadrature(FT, quadrature_order: int):
+    """Quadrature.build_quadrature(FT, order) — src/Quadrature.jl:272-278: Gauss–Legendre for 16/32/40/64, else Chebyshev–Gauss."""
+    return GaussLegendre(FT, quadrature_order) if quadrature_order in (16, 32, 40, 64) else ChebyshevGauss(FT, quadrature_order)
+
+
+def LocalRimeDensity(FT):
+    """CMP.LocalRimeDensity — src/parameters/MicrophysicsP3.jl:202-221."""
+    td = _td(FT)
+    return td.fam.local_rime_density(a=td["CL1993_local_rime_density_constant_coeff"], b=td["CL1993_local_rime_density_linear_coeff"],
+                                     c=td["CL1993_local_rime_density_quadratic_coeff"], rho_ice=td["density_ice_water"])
+
+
+def RainFreezing(FT):
+    """CMP.RainFreezing — src/parameters/IceNucleation.jl:129-146."""
+    td = _td(FT)
+    return td.fam.rain_freezing(het_a=td["BarklieGokhale1959_a_parameter"], het_B=td["BarklieGokhale1959_B_parameter"])
+
+
+def Frostenberg2023(FT, a=None, b=None):
+    """CMP.Frostenberg2023 — src/parameters/IceNucleation.jl:171-193 (log_a = log(a))."""
+    import math
+    td = _td(FT)
+    a = td["Frostenberg2023_a_coefficient"] if a is None else a
+    b = td["Frostenberg2023_b_coefficient"] if b is None else b
+    return td.fam.frostenberg2023(sigma=td["Frostenberg2023_standard_deviation"], a=a, b=b,
+                                  T_freeze=td["temperature_water_freeze"], log_a=math.log(a))
+
+
+def MorrisonMilbrandt2014(FT):
+    """CMP.MorrisonMilbrandt2014 — src/parameters/IceNucleation.jl:80-107."""
+    td = _td(FT)
+    return td.fam.morrison_milbrandt2014(
+        T_dep_thres=td["temperature_homogenous_nucleation"], c1=td["Thompson2004_c1_Cooper"], c2=td["Thompson2004_c2_Cooper"],
+        T0=td["temperature_water_freeze"], het_a=td["BarklieGokhale1959_a_parameter"], het_B=td["BarklieGokhale1959_B_parameter"])
+
+
+class P3IceParams:
+    """CMP.P3IceParams(toml_dict; is_limited = true, quadrature_order = 16, inp_depletion_model = NIceProxyDepletion(τ_act = 300))
+    — src/parameters/Microphysics2MParams.jl:58-106, flattened into the C layout `cmx_p3_ice_params`."""
+
+    def __init__(self, FT, is_limited: bool = True, quadrature_order: int = 16, tau_act: float = 300.0, slope_law: str = "powerlaw",
+                 quad=None):
+        td = _td(FT)
+        self.fam = td.fam
+        self.is_limited = bool(is_limited)
+        scheme = ParametersP3(td, slope_law)
+        self.flags = scheme.flags | (_abi.CMX_P3_RAIN_PDF_LIMITED if is_limited else 0)
+        self.c = td.fam.p3_ice_params()
+        self.c.scheme = scheme.c
+        self.c.vent = VentilationFactorP3(td)
+        self.c.rho_rim_local = LocalRimeDensity(td)
+        self.c.vel_rain = Chen2022VelTypeRain(td)
+        self.c.vel_ice = Chen2022VelTypeIce(td)
+        sb = SB2006(td, is_limited)
+        self.c.cloud_pdf = sb.pdf_c
+        self.c.rain_pdf = sb.pdf_r
+        self.c.ice_nucleation = Frostenberg2023(td)
+        self.c.rain_freezing = RainFreezing(td)
+        self.c.tau_act = tau_act
+        self.c.quad = quad if quad is not None else build_quadrature(td, quadrature_order)
 
 
 def AerosolActivationParameters(FT):

@@ -250,7 +250,33 @@ typedef enum cmx_status {
     typedef struct cmx_quadrature_##SFX {                                                      \
         int32_t n, reserved;                                                                   \
         FT node[CMX_QUAD_MAX], weight[CMX_QUAD_MAX];                                           \
-    } cmx_quadrature_##SFX;
+    } cmx_quadrature_##SFX;                                                                    \
+    /* LocalRimeDensity — src/parameters/MicrophysicsP3.jl:202-239 (Cober & List 1993 Eq. 16-17) */ \
+    typedef struct cmx_local_rime_density_##SFX { FT a, b, c, rho_ice; } cmx_local_rime_density_##SFX; \
+    /* RainFreezing (Bigg 1953 / Barklie–Gokhale 1959) — src/parameters/IceNucleation.jl:129-146 */ \
+    typedef struct cmx_rain_freezing_##SFX { FT het_a, het_B; } cmx_rain_freezing_##SFX;       \
+    /* Frostenberg2023 — src/parameters/IceNucleation.jl:171-193 (log_a = log(a), host-derived) */ \
+    typedef struct cmx_frostenberg2023_##SFX { FT sigma, a, b, T_freeze, log_a; } cmx_frostenberg2023_##SFX; \
+    /* MorrisonMilbrandt2014 — src/parameters/IceNucleation.jl:80-107 */                       \
+    typedef struct cmx_morrison_milbrandt2014_##SFX { FT T_dep_thres, c1, c2, T0, het_a, het_B; } \
+        cmx_morrison_milbrandt2014_##SFX;                                                      \
+    /* P3IceParams — src/parameters/Microphysics2MParams.jl:58-86: scheme (+ its vent and      */ \
+    /* ρ_rim_local members, src/parameters/MicrophysicsP3.jl:267-288), terminal_velocity       */ \
+    /* (Chen2022VelType: rain, small_ice, large_ice), cloud_pdf, rain_pdf, ice_nucleation,     */ \
+    /* rain_freezing, inp_depletion_model.τ_act, quad                                          */ \
+    typedef struct cmx_p3_ice_params_##SFX {                                                   \
+        cmx_p3_params_##SFX scheme;                                                            \
+        cmx_ventilation_##SFX vent;                                                            \
+        cmx_local_rime_density_##SFX rho_rim_local;                                            \
+        cmx_chen2022_rain_vel_##SFX vel_rain;                                                  \
+        cmx_chen2022_ice_vel_##SFX vel_ice;                                                    \
+        cmx_cloud_pdf_sb2006_##SFX cloud_pdf;                                                  \
+        cmx_rain_pdf_sb2006_##SFX rain_pdf;                                                    \
+        cmx_frostenberg2023_##SFX ice_nucleation;                                              \
+        cmx_rain_freezing_##SFX rain_freezing;                                                 \
+        FT tau_act;                                                                            \
+        cmx_quadrature_##SFX quad;                                                             \
+    } cmx_p3_ice_params_##SFX;
 
 #define CMX_ARG_MAX_MODES 8
 #define CMX_QUAD_MAX 128
@@ -590,6 +616,7 @@ int32_t cmx_arg2000_activation_columns_f64(
 #define CMX_P3_INPUT_IS_STATE   (1u << 0)   /* columns 3, 4 are (F_rim, ρ_rim) instead of (ρq_rim, ρb_rim) */
 #define CMX_P3_SLOPE_CONSTANT   (1u << 1)   /* SlopeConstant (μ = mu_const) instead of SlopePowerLaw */
 #define CMX_P3_NO_ASPECT_RATIO  (1u << 2)   /* CMP.NoAspectRatio() instead of the default CMP.Oblate() (velocities) */
+#define CMX_P3_RAIN_PDF_LIMITED (1u << 3)   /* rain_pdf is RainParticlePDF_SB2006_limited (collisions, rain freezing, 2M+P3 entry) */
 
 int32_t cmx_p3_shape_f32(const cmx_p3_params_f32 *params, uint32_t flags, int32_t brent_iters, int64_t n, const float *rho_q_ice,
                          const float *rho_n_ice, const float *x3, const float *x4, const float *log_lambda_guess,

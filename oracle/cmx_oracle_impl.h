@@ -426,7 +426,7 @@ typedef struct TY(cmxo_warm_rain_out) {
 static inline TY(cmxo_warm_rain_out) FN(o_bulk_tendencies_2m_warm)(
     const TY(cmx_warm_rain_2m) * wr, const TY(cmx_thermo) * tps, const TY(cmx_rain_vel) * vel,
     uint32_t flags, const TY(cmxo_thresholds) * th, FT branch_margin, FT rho, FT T, FT q_tot,
-    FT q_lcl, FT n_lcl, FT q_rai, FT n_rai) {
+    FT q_lcl, FT n_lcl, FT q_rai, FT n_rai, FT q_ice) {   /* q_ice = 0 for the warm-only entry, the P3 ice content for BMT:942 */
     TY(cmxo_warm_rain_out) o;
     const TY(cmx_sb2006) *sb = &wr->seifert_beheng;
     const TY(cmx_air_properties) *aps = &wr->air_properties;
@@ -438,7 +438,7 @@ static inline TY(cmxo_warm_rain_out) FN(o_bulk_tendencies_2m_warm)(
     q_rai = FN(o_max)((FT)0, q_rai);
     n_lcl = FN(o_max)((FT)0, n_lcl);
     n_rai = FN(o_max)((FT)0, n_rai);
-    const FT q_ice = 0;
+    q_ice = FN(o_max)((FT)0, q_ice);
     FT N_lcl = rho * n_lcl;                                                       /* BMT:718-719 */
     FT N_rai = rho * n_rai;
     FT dq_lcl = 0, dq_rai = 0, dn_lcl = 0, dn_rai = 0;
@@ -553,7 +553,7 @@ void FN(cmxo_sb2006_warm_rain_tendencies)(
     for (int64_t i = 0; i < n; ++i) {
         TY(cmxo_warm_rain_out) o = FN(o_bulk_tendencies_2m_warm)(
             wr, tps, vel, flags, th, branch_margin, rho[i], T[i], q_tot[i], q_lcl[i], n_lcl[i], q_rai[i],
-            n_rai[i]);
+            n_rai[i], (FT)0);
         dq_lcl_dt[i] = o.dq_lcl_dt;
         dn_lcl_dt[i] = o.dn_lcl_dt;
         dq_rai_dt[i] = o.dq_rai_dt;
@@ -776,6 +776,7 @@ void FN(cmxo_bulk_2m_cloud_to_rain)(const TY(cmx_bulk_2m_schemes) * p, uint32_t 
 #include "cmx_oracle_arg_impl.h"
 #include "cmx_oracle_p3_impl.h"
 #include "cmx_oracle_sed_impl.h"
+#include "cmx_oracle_p3col_impl.h"
 
 #undef CAT_
 #undef CAT

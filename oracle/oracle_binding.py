@@ -457,3 +457,113 @@ def chen2022_rain_coeffs(fam, chen, rho):
     fn.restype = None
     fn(C.byref(chen), fam.ft(rho), out)
     return list(out[0:3]), list(out[3:6]), list(out[6:9])
+
+
+def p3_liquid_ice_collisions(fam, ice_params, aps, tps, quad, flags, rho_q_ice, rho_n_ice, x3, x4, L_c, N_c, L_r, N_r, rho_a, T,
+                             log_lambda, *, float32_gates=None, nthreads=1):
+    """Oracle twin of cmx_p3_liquid_ice_collisions_*: (sources[7, n], rates[10, n]) — bulk_liquid_ice_collision_sources and the ten
+    ∫liquid_ice_collisions integrals."""
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    ins = [_col(fam, a) for a in (rho_q_ice, rho_n_ice, x3, x4, L_c, N_c, L_r, N_r, rho_a, T, log_lambda)]
+    n = ins[0][0].size
+    src = np.empty((7, n), dtype=NP[fam.sfx])
+    rates = np.empty((10, n), dtype=NP[fam.sfx])
+    fn = getattr(lib(), f"cmxo_p3_liquid_ice_collisions_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(ice_params), C.byref(aps), C.byref(tps), C.byref(quad), C.c_uint32(flags), C.byref(th), C.c_int64(n),
+       *[q for _, q in ins], src.ctypes.data_as(C.c_void_p), rates.ctypes.data_as(C.c_void_p), C.c_int32(nthreads))
+    return src, rates
+
+
+def p3_collision_probes(fam, ice_params, aps, tps, flags, L, N, F_rim, rho_rim, rho_a, T, log_lambda, D_ice, D_liq):
+    """(compute_max_freeze_rate(…)(D_ice), compute_local_rime_density(…)(D_ice, D_liq)) for a P3State(L, N, F_rim, ρ_rim)."""
+    fn = getattr(lib(), f"cmxo_p3_collision_probes_{fam.sfx}")
+    fn.restype = None
+    out = (fam.ft * 2)()
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32] + [fam.ft] * 9 + [C.c_void_p]
+    fn(C.addressof(ice_params), C.addressof(aps), C.addressof(tps), flags, L, N, F_rim, rho_rim, rho_a, T, log_lambda, D_ice, D_liq,
+       C.addressof(out))
+    return out[0], out[1]
+
+
+def microphysics_2m_p3_tendencies(fam, warm_rain, ice_params, tps, flags, rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice, n_ice, q_rim,
+                                  b_rim, log_lambda, inpc_log_shift=None, *, float32_gates=None, nthreads=1):
+    """Oracle twin of cmx_microphysics_2m_p3_tendencies_* (BMT:898-1083): (out[8, n], scale[8, n]) with rows
+    (dq_lcl, dn_lcl, dq_rai, dn_rai, dq_ice, dn_ice, dq_rim, db_rim)."""
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    ins = [_col(fam, a) for a in (rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice, n_ice, q_rim, b_rim, log_lambda)]
+    n = ins[0][0].size
+    sh = _col(fam, inpc_log_shift) if inpc_log_shift is not None else (None, None)
+    out = np.empty((8, n), dtype=NP[fam.sfx])
+    scale = np.empty((8, n), dtype=NP[fam.sfx])
+    fn = getattr(lib(), f"cmxo_microphysics_2m_p3_tendencies_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(warm_rain), C.byref(ice_params), C.byref(tps), C.c_uint32(flags), C.byref(th), C.c_int64(n), *[q for _, q in ins], sh[1],
+       out.ctypes.data_as(C.c_void_p), scale.ctypes.data_as(C.c_void_p), C.c_int32(nthreads))
+    return out, scale
+
+
+def liquid_freezing_rate(fam, rf, pdf, tps, q, rho, N, T, *, cloud, limited=True, float32_gates=None):
+    """CMI_het.liquid_freezing_rate (Bigg) for the cloud (generalized gamma) or rain (exponential) PSD: (∂ₜn_frz, ∂ₜq_frz)."""
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    ins = [_col(fam, a) for a in (q, rho, N, T)]
+    n = ins[0][0].size
+    dn, dq = np.empty(n, dtype=NP[fam.sfx]), np.empty(n, dtype=NP[fam.sfx])
+    fn = getattr(lib(), f"cmxo_liquid_freezing_rate_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(rf), C.byref(pdf) if cloud else None, None if cloud else C.byref(pdf), C.c_int32(int(limited)), C.byref(tps), C.byref(th),
+       C.c_int64(n), *[p for _, p in ins], dn.ctypes.data_as(C.c_void_p), dq.ctypes.data_as(C.c_void_p))
+    return dn, dq
+
+
+def f23_deposition_rate(fam, ip, tps, m_nuc, tau_act, T, rho, q_tot, q_liq, q_ice, n_ice, shift=None):
+    ins = [_col(fam, a) for a in (T, rho, q_tot, q_liq, q_ice, n_ice)]
+    n = ins[0][0].size
+    sh = _col(fam, shift) if shift is not None else (None, None)
+    dn, dq = np.empty(n, dtype=NP[fam.sfx]), np.empty(n, dtype=NP[fam.sfx])
+    fn = getattr(lib(), f"cmxo_f23_deposition_rate_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(ip), C.byref(tps), fam.ft(m_nuc), fam.ft(tau_act), C.c_int64(n), *[p for _, p in ins], sh[1],
+       dn.ctypes.data_as(C.c_void_p), dq.ctypes.data_as(C.c_void_p))
+    return dn, dq
+
+
+def f23_immersion_limit_rate(fam, ip, tau, T, rho, n_active=None, shift=None):
+    ins = [_col(fam, a) for a in (T, rho)]
+    n = ins[0][0].size
+    na = _col(fam, n_active) if n_active is not None else (None, None)
+    sh = _col(fam, shift) if shift is not None else (None, None)
+    dn = np.empty(n, dtype=NP[fam.sfx])
+    fn = getattr(lib(), f"cmxo_f23_immersion_limit_rate_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(ip), fam.ft(tau), C.c_int64(n), *[p for _, p in ins], na[1], sh[1], dn.ctypes.data_as(C.c_void_p))
+    return dn
+
+
+def _scalar(fam, name, argtypes, *args):
+    fn = getattr(lib(), f"{name}_{fam.sfx}")
+    fn.restype = fam.ft
+    fn.argtypes = argtypes
+    return fn(*args)
+
+
+def INP_concentration_mean(fam, ip, T):
+    return _scalar(fam, "cmxo_INP_concentration_mean", [C.c_void_p, fam.ft], C.addressof(ip), T)
+
+
+def INP_concentration_frequency(fam, ip, INPC, T):
+    return _scalar(fam, "cmxo_INP_concentration_frequency", [C.c_void_p, fam.ft, fam.ft], C.addressof(ip), INPC, T)
+
+
+def P3_deposition_N_i(fam, ip, T):
+    return _scalar(fam, "cmxo_P3_deposition_N_i", [C.c_void_p, fam.ft], C.addressof(ip), T)
+
+
+def P3_het_N_i(fam, ip, T, N_l, V_l, dt):
+    return _scalar(fam, "cmxo_P3_het_N_i", [C.c_void_p] + [fam.ft] * 4, C.addressof(ip), T, N_l, V_l, dt)
