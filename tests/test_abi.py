@@ -45,7 +45,8 @@ def test_struct_layout_matches_c(tmp_path):
                      "particle_mass", "particle_area", "ventilation", "acnv_1m", "var_timescale_acnv", "cloud_liquid",
                      "cloud_ice", "rain", "snow", "blk1m_vel_rain", "blk1m_vel_snow", "process_params_1m",
                      "microphysics_1m", "aerosol_activation_params", "aerosol_mode", "aerosol_distribution",
-                     "p3_params", "chen2022_small_ice_vel", "chen2022_large_ice_vel", "chen2022_ice_vel", "quadrature"):
+                     "p3_params", "chen2022_small_ice_vel", "chen2022_large_ice_vel", "chen2022_ice_vel", "quadrature",
+                     "local_rime_density", "rain_freezing", "frostenberg2023", "morrison_milbrandt2014", "p3_ice_params"):
             st = getattr(fam, name)
             probes.append((f"cmx_{name}_{fam.sfx}", st))
     src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{REPO}/include/cmx.h"', "int main(void){"]
@@ -106,5 +107,6 @@ def test_parameter_defaults_and_overrides():
     assert sb2.acnv.x_star == sb2.pdf_r.xr_min == sb2.pdf_c.xc_max == 6.54e-11 and sb2.pdf_r.N0_max == 2e11
     with pytest.raises(KeyError):
         P.create_toml_dict("f64", {"not_a_parameter": 1.0})
-    with pytest.raises(NotImplementedError):
-        P.Microphysics2MParams("f32", with_ice=True)
+    mp = P.Microphysics2MParams("f32", with_ice=True)            # P3IceParams defaults — Microphysics2MParams.jl:88-106
+    assert mp.ice.c.quad.n == 16 and mp.ice.c.tau_act == 300.0 and mp.ice.is_limited
+    assert P.build_quadrature("f64", 20).n == 20 and P.Microphysics2MParams("f64").ice is None
