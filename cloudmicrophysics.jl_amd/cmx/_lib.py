@@ -98,6 +98,10 @@ def _declare(lib):
         f = getattr(lib, f"cmx_p3_ice_self_collection_{s}")
         f.restype = i32
         f.argtypes = [C.POINTER(fam.p3_params), C.POINTER(fam.chen2022_ice_vel), C.POINTER(fam.quadrature), u32, i64] + [vp] * 7 + [vp]
+        f = getattr(lib, f"cmx_p3_liquid_ice_collisions_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.p3_ice_params), C.POINTER(fam.air_properties), C.POINTER(fam.thermo), C.POINTER(fam.quadrature),
+                      u32, i64] + [vp] * 11 + [C.POINTER(vp), C.POINTER(vp), vp]
         f = getattr(lib, f"cmx_column_sums_{s}")
         f.restype = i32
         f.argtypes = [i32, C.POINTER(vp), i64, vp, vp]

@@ -150,3 +150,38 @@ def p3_ice_self_collection(params: ParametersP3, velocity_params, rho_air, rho_q
                 C.c_void_p(s.cuda_stream))
     _lib.check(fn.__name__, st)
     return out
+
+
+COLLISION_SOURCES = ("dq_c", "dq_r", "dN_c", "dN_r", "dL_rim", "dL_ice", "dB_rim")
+COLLISION_RATES = ("QCFRZ", "QCSHD", "NCCOL", "QRFRZ", "QRSHD", "NRCOL", "int_M_col", "BCCOL", "BRCOL", "int_wet_M_col")
+
+
+def p3_liquid_ice_collisions(ice_params, aps, tps, rho_air, T, rho_q_ice, rho_n_ice, x3, x4, log_lambda, L_c, N_c, L_r, N_r, *,
+                             from_state=False, aspect_ratio=True, quad=None, want_rates=False, stream=None):
+    """`P3.bulk_liquid_ice_collision_sources(state, logλ, psd_c, psd_r, L_c, N_c, L_r, N_r, aps, tps, vel, ρₐ, T; quad)` for every
+    point (src/P3_processes.jl:600-655): dict of the seven bulk tendencies (∂ₜq_c, ∂ₜq_r [kg/kg/s], ∂ₜN_c, ∂ₜN_r [1/m³/s], ∂ₜL_rim,
+    ∂ₜL_ice [kg/m³/s], ∂ₜB_rim [1/s]); with `want_rates` also the ten ∫liquid_ice_collisions integrals (:527-562).  `ice_params` is a
+    `P3IceParams` (scheme, fall-speed tables, cloud and rain PSDs); `quad` defaults to its quadrature rule."""
+    from .parameters import P3IceParams
+    if not isinstance(ice_params, P3IceParams):
+        raise TypeError("ice_params must be P3IceParams")
+    cols = (rho_q_ice, rho_n_ice, x3, x4, L_c, N_c, L_r, N_r, rho_air, T, log_lambda)
+    ref = _check_cols(cols, ("rho_q_ice", "rho_n_ice", "x3", "x4", "L_c", "N_c", "L_r", "N_r", "rho_air", "T", "log_lambda"))
+    fam = _fam_of(ref)
+    if fam is not ice_params.fam or not isinstance(aps, fam.air_properties) or not isinstance(tps, fam.thermo):
+        raise TypeError("parameter float type does not match the state columns")
+    quad = ice_params.c.quad if quad is None else quad
+    if not isinstance(quad, fam.quadrature):
+        raise TypeError("quadrature float type does not match the state columns")
+    src = {k: torch.empty_like(ref) for k in COLLISION_SOURCES}
+    rates = {k: torch.empty_like(ref) for k in COLLISION_RATES} if want_rates else None
+    src_p = (C.c_void_p * 7)(*[t.data_ptr() for t in src.values()])
+    rates_p = (C.c_void_p * 10)(*[t.data_ptr() for t in rates.values()]) if want_rates else None
+    flags = ice_params.flags | (_abi.CMX_P3_INPUT_IS_STATE if from_state else 0) | (0 if aspect_ratio else _abi.CMX_P3_NO_ASPECT_RATIO)
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_p3_liquid_ice_collisions_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(ice_params.c), C.byref(aps), C.byref(tps), C.byref(quad), flags, ref.numel(), *[_ptr(t) for t in cols], src_p, rates_p,
+                C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return (src, rates) if want_rates else src

@@ -1,0 +1,510 @@
+// cmx_p3_collisions.hip — P3 liquid–ice collisions for gfx950: bulk_liquid_ice_collision_sources and the ten
+// ∫liquid_ice_collisions integrals (src/P3_processes.jl:96-655); C-ABI entry points of include/cmx.h §(8).
+//
+// Work decomposition — one grid POINT per 16-lane group (4 points per wave64, 16 per 256-lane workgroup), one OUTER
+// quadrature node (ice diameter Dᵢ) per lane:
+//   * the reference evaluates, per outer node, two inner integrals over the liquid diameters (cloud: 3 sums by
+//     quadrature; rain: N and M in closed form, the rime-volume sum by quadrature).  The inner nodes and everything
+//     at them that does not depend on Dᵢ — D, v_l(D), w·n(D)[·m(D)] — are the same for every outer node of a point:
+//     the group computes them once (lane j ↔ inner node j) into LDS and every outer node then re-reads them as LDS
+//     broadcasts: 1 log + 5 exp per (outer, inner) pair become ≈20 plain VALU operations;
+//   * the closed-form rain integral needs ∫ D^{z−1} e^{−αD} dD on [D_lo, D*] and [D*, D_hi] for 4 (α, z₀) families ×
+//     6 consecutive z (cross-section monomials i = 0..2 × moments p = 0, 3).  One unregularised lower incomplete gamma
+//     function per (family, x) plus the three-term recurrence in z (downward from the series at the top z, upward from
+//     the continued fraction at the bottom z — both stable) replaces the reference's 96 regularised gamma_inc calls
+//     per outer node by 4; the end-point values (x = α D_lo, α D_hi) do not depend on the outer node either and are
+//     evaluated once per point by 8 lanes of the group;
+//   * the ten outer sums are reduced over the group with 4 xor-shuffle steps.
+// The per-point set-up (P3 state, the two Halley solves for the integration bounds, PSD parameters) is evaluated
+// redundantly by the 16 lanes of a group — that is what bounds the group width from above; DESIGN.md §4.8 has the
+// instruction budget that led to 16.
+//
+// COMPUTE-bound (FP64 / FP32 vector rate); HBM traffic is 11 input + ≤17 output columns per point.
+#include <hip/hip_runtime.h>
+
+#include "cmx_p3.hpp"
+
+namespace cmx {
+
+constexpr int kGroup = 16;                       // lanes per grid point
+constexpr int kPointsPerBlock = kBlock / kGroup;
+
+template <typename FT> struct P3ColConsts {
+    // rain Chen-2022 curve (table B1; Common.jl:290-302): v_l(D) = Σ_j a_j exp(e_j + b_j logD − c_j D)
+    FT r_a[3], r_b[3], r_c[3], r_rho0, r_brho, r_a3pow;
+    // cloud PSD (CM2:172-236)
+    FT nu_c, mu_c, lg_z1, lg_z2, log_mu_c, z1, logN0_shift, log_km_mu, nu_cD, mu_cD, inv_mu_cD, log_zq_lo, log_zq_hi;
+    // rain PSD (CM2:67-110) and its quantile bounds D = D̄·(−log1p(−Y)) (DistributionTools.jl:158-165)
+    FT xr_min, xr_max, N0_min, N0_max, lam_min, lam_max, pi_rho_w, k_lo, k_hi;
+    int limited;
+    // local rime density (MicrophysicsP3.jl:222-239)
+    FT rime_a, rime_b, rime_c, rime_rho8, rime_rho_ice;
+    // compute_max_freeze_rate (P3_processes.jl:167-201): latent heats, ice saturation pressure, ventilation
+    FT K_therm, D_vapor, cp_l, LH_v0, dcp_v, LH_f0, dcp_f, T_0, T_freeze_tps, qsi_frz /* p_sat,ice(T_frz)/(R_v T_frz) */,
+        ps_pow, ps_b, inv_T_tr, press_tr, R_v, vent_a, vent_bc;
+    FT T_freeze_p3;                 // params.T_freeze of compute_local_rime_density :281
+    FT m_fac;                       // ρ_w π/6
+    FT tau_wet, rho_i, inv_m_shd;   // bulk sources :612-650
+    int brent_iters;
+};
+
+// host: regularised incomplete gamma P(a, x) to convergence and its inverse (for parameter-only quantiles)
+static double host_gamma_P(double a, double x) {
+    if (x <= 0) return 0;
+    const double lg = std::lgamma(a), pf = std::exp(a * std::log(x) - x - lg);
+    if (x < a + 1) {
+        double term = 1 / a, sum = term;
+        for (int k = 1; k < 2000; ++k) { term *= x / (a + k); sum += term; if (term < sum * 1e-17) break; }
+        return pf * sum;
+    }
+    double b = x + 1 - a, c = 1e300, d = 1 / b, h = d;
+    for (int k = 1; k < 2000; ++k) {
+        const double an = -k * (k - a);
+        b += 2; d = an * d + b; if (std::fabs(d) < 1e-300) d = 1e-300;
+        c = b + an / c; if (std::fabs(c) < 1e-300) c = 1e-300;
+        d = 1 / d; const double del = d * c; h *= del;
+        if (std::fabs(del - 1) < 1e-16) break;
+    }
+    return 1 - pf * h;
+}
+static double host_gamma_inc_inv(double a, double p) {   // bisection on log x: parameter-only, called twice per entry
+    double lo = -700, hi = 50;
+    for (int it = 0; it < 200; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        (host_gamma_P(a, std::exp(mid)) < p ? lo : hi) = mid;
+    }
+    return std::exp(0.5 * (lo + hi));
+}
+
+template <typename FT, typename IP, typename AP, typename TH>
+static P3ColConsts<FT> make_p3col_consts(const IP &ip, const AP &aps, const TH &tps, uint32_t flags) {
+    P3ColConsts<FT> k{};
+    const double pi = 3.14159265358979323846;
+    for (int j = 0; j < 3; ++j) { k.r_a[j] = ip.vel_rain.a[j]; k.r_b[j] = ip.vel_rain.b[j]; k.r_c[j] = (FT)(1000.0 * (double)ip.vel_rain.c[j]); }
+    k.r_rho0 = ip.vel_rain.rho_0; k.r_brho = ip.vel_rain.b_rho; k.r_a3pow = ip.vel_rain.a3_pow;
+    const auto &pc = ip.cloud_pdf;
+    const double nu = pc.nu_c, mu = pc.mu_c, km = (double)pc.rho_w * pi / 6.0;
+    k.nu_c = pc.nu_c; k.mu_c = pc.mu_c; k.lg_z1 = pc.loggamma_z1; k.lg_z2 = pc.loggamma_z2; k.log_mu_c = (FT)std::log(mu);
+    k.z1 = (FT)((nu + 1) / mu);
+    k.logN0_shift = (FT)(std::log(3.0) + (nu + 1) * std::log(km));
+    k.log_km_mu = (FT)(mu * std::log(km));
+    k.nu_cD = (FT)(3 * nu + 2); k.mu_cD = (FT)(3 * mu); k.inv_mu_cD = (FT)(1.0 / (3 * mu));
+    // p = FT(0.00001) (P3_processes.jl:546): the quantile levels are FT numbers
+    const FT p_lo = FT(0.00001), p_hi = FT(1) - p_lo;
+    const double zq = (3 * nu + 3) / (3 * mu);
+    k.log_zq_lo = (FT)std::log(host_gamma_inc_inv(zq, (double)p_lo));
+    k.log_zq_hi = (FT)std::log(host_gamma_inc_inv(zq, (double)p_hi));
+    const auto &pr = ip.rain_pdf;
+    k.xr_min = pr.xr_min; k.xr_max = pr.xr_max; k.N0_min = pr.N0_min; k.N0_max = pr.N0_max; k.lam_min = pr.lambda_min; k.lam_max = pr.lambda_max;
+    k.pi_rho_w = (FT)(pi * (double)pr.rho_w);
+    k.k_lo = (FT)(-std::log1p(-(double)p_lo)); k.k_hi = (FT)(-std::log1p(-(double)p_hi));
+    k.limited = (flags & CMX_P3_RAIN_PDF_LIMITED) != 0;
+    const auto &rl = ip.rho_rim_local;
+    k.rime_a = rl.a; k.rime_b = rl.b; k.rime_c = rl.c; k.rime_rho_ice = rl.rho_ice;
+    k.rime_rho8 = (FT)((double)rl.a + 8.0 * (double)rl.b + 64.0 * (double)rl.c);
+    k.K_therm = aps.K_therm; k.D_vapor = aps.D_vapor; k.cp_l = tps.cp_l;
+    k.LH_v0 = tps.LH_v0; k.dcp_v = (FT)((double)tps.cp_v - (double)tps.cp_l);
+    k.LH_f0 = (FT)((double)tps.LH_s0 - (double)tps.LH_v0); k.dcp_f = (FT)((double)tps.cp_l - (double)tps.cp_i);
+    k.T_0 = tps.T_0; k.T_freeze_tps = tps.T_freeze;
+    const double dcp_i = (double)tps.cp_v - (double)tps.cp_i, Rv = tps.R_v, Ttr = tps.T_triple;
+    k.ps_pow = (FT)(dcp_i / Rv); k.ps_b = (FT)(((double)tps.LH_s0 - dcp_i * (double)tps.T_0) / Rv); k.inv_T_tr = (FT)(1.0 / Ttr);
+    k.press_tr = tps.press_triple; k.R_v = tps.R_v;
+    const double Tf = tps.T_freeze;
+    const double ps_frz = (double)tps.press_triple * std::pow(Tf / Ttr, dcp_i / Rv) * std::exp(((double)tps.LH_s0 - dcp_i * (double)tps.T_0) / Rv * (1 / Ttr - 1 / Tf));
+    k.qsi_frz = (FT)(ps_frz / (Rv * Tf));
+    k.vent_a = ip.vent.a;
+    k.vent_bc = (FT)((double)ip.vent.b * std::cbrt((double)aps.nu_air / (double)aps.D_vapor) / std::sqrt((double)aps.nu_air));
+    k.T_freeze_p3 = ip.scheme.T_freeze;
+    k.m_fac = (FT)((double)pc.rho_w * pi / 6.0);
+    k.tau_wet = ip.scheme.tau_wet; k.rho_i = ip.scheme.rho_i;
+    k.inv_m_shd = (FT)(1.0 / ((double)pc.rho_w * 1e-9 * pi / 6.0));      // 1/m_liq(D_shd = 1 mm)
+    k.brent_iters = sizeof(FT) == 4 ? 8 : 10;
+    return k;
+}
+
+// unregularised lower incomplete gamma γ(z₀+m, x), m = 0..5, from ONE series or continued-fraction evaluation:
+//   x < z₀ + 3.5: series at z₅ = z₀+5 (x < z₅ − 1.5: fast), then γ(z,x) = (γ(z+1,x) + x^z e^{−x})/z downwards (all terms > 0);
+//   otherwise   : continued fraction for Γ(z₀,x), Γ(z+1,x) = z Γ(z,x) + x^z e^{−x} upwards (all terms > 0), γ = Γ(z) − Γ(z,x)
+//                 with P(z₅,x) ≳ 0.2 there — no cancellation in either branch.
+template <typename FT> __device__ __forceinline__ void lower_gamma6(FT z0, FT x, FT G0 /* Γ(z₀) */, FT (&g)[6]) {
+    using P = PM<FT>;
+    const FT lx = P::log(x);
+    if (x < z0 + FT(3.5)) {
+        const FT z5 = z0 + FT(5);
+        FT t = P::exp(z5 * lx - x);
+        g[5] = t * gamma_series_sum<FT>(z5, x);
+        const FT inv_x = P::rcp(x);
+#pragma unroll
+        for (int m = 4; m >= 0; --m) { t *= inv_x; g[m] = (g[m + 1] + t) * P::rcp(z0 + FT(m)); }
+    } else {
+        FT t = P::exp(z0 * lx - x);
+        FT U = t * gamma_cf_value<FT>(z0, x), Gz = G0;
+        g[0] = Gz - U;
+#pragma unroll
+        for (int m = 0; m < 5; ++m) { const FT z = z0 + FT(m); U = z * U + t; t *= x; Gz *= z; g[m + 1] = Gz - U; }
+    }
+}
+
+template <typename FT> struct P3ColIO {
+    const FT *rho_q, *rho_n, *x3, *x4, *L_c, *N_c, *L_r, *N_r, *rho_a, *T, *loglam;
+    FT *src[7];      // ∂ₜq_c, ∂ₜq_r, ∂ₜN_c, ∂ₜN_r, ∂ₜL_rim, ∂ₜL_ice, ∂ₜB_rim   (nullable)
+    FT *rates[10];   // QCFRZ, QCSHD, NCCOL, QRFRZ, QRSHD, NRCOL, ∫M_col, BCCOL, BRCOL, ∫𝟙_wet M_col   (nullable)
+};
+
+// LDS per group, in FT units: quadrature copy is per block
+template <typename FT> struct ColLds {
+    static __device__ __forceinline__ int per_group(int n) { return 6 * n + 72; }
+};
+
+template <typename FT, typename QUAD, bool ASPECT>
+__global__ __launch_bounds__(kBlock) void p3_collision_kernel(const P3Consts<FT> c, const P3VelConsts<FT> v, const P3ColConsts<FT> k,
+                                                             const QUAD quad, const P3ColIO<FT> io, const int64_t n) {
+    using P = PM<FT>;
+    using M = Math<FT>;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    FT *lds = reinterpret_cast<FT *>(lds_raw);
+    const int nq = quad.n;
+    // block-wide copy of the quadrature rule: per-lane node indices need a memory the lanes can index
+    FT *q_node = lds, *q_wt = lds + nq;
+    if (threadIdx.x == 0)
+        for (int j = 0; j < nq; ++j) { q_node[j] = quad.node[j]; q_wt[j] = quad.weight[j]; }
+    const int grp = threadIdx.x / kGroup, g = threadIdx.x % kGroup;
+    FT *G = lds + 2 * nq + grp * ColLds<FT>::per_group(nq);
+    FT *cD = G, *cV = G + nq, *cW = G + 2 * nq, *rD = G + 3 * nq, *rV = G + 4 * nq, *rW = G + 5 * nq, *E = G + 6 * nq, *Fm = G + 6 * nq + 48;
+    const int64_t pt_raw = (int64_t)blockIdx.x * kPointsPerBlock + grp;
+    const bool valid = pt_raw < n;
+    const int64_t i = valid ? pt_raw : n - 1;
+    __syncthreads();
+
+    // ---- per-point set-up (uniform over the group) ---------------------------------------------------------------
+    P3Point<FT> s;
+    p3_make_point<FT>(c, io.rho_q[i], io.rho_n[i], io.x3[i], io.x4[i], s);
+    const bool present = !(s.rho_n < P::eps() || s.rho_q < P::eps());
+    const FT rho_a = M::max(io.rho_a[i], FT(0)), T = io.T[i];
+    const FT loglam = present ? io.loglam[i] : FT(10), lam = P::exp(loglam), mu = p3_mu<FT>(c, loglam);
+    const FT logN0 = P::log(present ? s.rho_n : FT(1)) - (-(mu + FT(1)) * loglam + P::lgamma(mu + FT(1)));
+    const FT lra = P::log(rho_a);
+    const FT sb = v.s_B + rho_a * v.s_C, se = v.s_A * lra + sb * v.ln1000;
+    const FT le1 = v.l_A * lra, le2 = le1 + v.l_H * rho_a;
+    const FT D_min = gamma_inc_inv_dev<FT>(mu + FT(1), v.p_lo, FT(1) - v.p_lo) / lam;
+    const FT D_max = gamma_inc_inv_dev<FT>(mu + FT(1), v.p_hi, FT(1) - v.p_hi) / lam;
+    FT bnd[5];
+    bnd[0] = D_min; bnd[4] = D_max;
+#pragma unroll
+    for (int q = 1; q < 4; ++q) bnd[q] = M::min(M::max(s.bnd[q], D_min), D_max);
+    const FT Fu = M::max(FT(1) - s.F_rim, P::eps());
+    const FT h0 = (v.h0_num - P::log(Fu)) / FT(3), h1 = c.beta_va / FT(3);
+    const bool unrimed = s.F_rim == FT(0);
+    const FT pi = FT(3.14159265358979323846), inv_pi = FT(0.3183098861837907);
+    // ice fall speed (incl. aspect factor), collision radius and number density at diameter x — as in p3_self_collection_kernel
+    auto eval_ice = [&](FT x, FT &vv, FT &rr, FT &nn) {
+        const FT logD = P::log(x);
+        const int reg = x < s.bnd[1] ? 0 : (unrimed ? 1 : (x < s.bnd[2] ? 1 : (x < s.bnd[3] ? 2 : 3)));
+        const FT sph = v.pi_4 * x * x;
+        FT area = sph, eA = FT(0);
+        if (reg == 1 || reg == 3) {
+            const FT non = v.gamma_area * P::exp(v.sigma_area * logD);
+            area = reg == 1 ? non : s.F_rim * sph + (FT(1) - s.F_rim) * non;
+            if (ASPECT) eA = reg == 1 ? v.g0 + v.g1 * logD : h0 + h1 * logD - FT(0.5) * P::log(area);
+        }
+        const bool small = x <= v.cutoff;
+        const FT E1 = small ? se + sb * logD : le1 + v.l_b1 * logD;
+        const FT dE = small ? -v.s_c2 * x : (le2 - le1) + (v.l_b2 - v.l_b1) * logD - v.l_c2 * x;
+        const FT A1 = small ? v.s_E : v.l_a1, A2 = small ? v.s_F : v.l_a2;
+        vv = P::exp(eA + E1) * (A1 + A2 * P::exp(dE));
+        rr = M::sqrt(area * inv_pi);
+        nn = P::exp(logN0 + mu * logD - lam * x);
+    };
+    // rain Chen-2022 curve at ρₐ
+    FT re[3], rb[3];
+    {
+        const FT q0 = k.r_rho0 * rho_a;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { rb[j] = k.r_b[j] - k.r_brho * rho_a; re[j] = q0 + rb[j] * v.ln1000; }
+        re[2] += k.r_a3pow * lra;
+    }
+    auto v_liq = [&](FT D, FT logD) {
+        return k.r_a[0] * P::exp(re[0] + rb[0] * logD - k.r_c[0] * D) + k.r_a[1] * P::exp(re[1] + rb[1] * logD - k.r_c[1] * D) +
+               k.r_a[2] * P::exp(re[2] + rb[2] * logD - k.r_c[2] * D);
+    };
+    // cloud PSD in diameter — log_pdf_cloud_parameters_mass CM2:172-188, pdf_cloud_parameters :227-236
+    const FT L_c = io.L_c[i], N_c = io.N_c[i], L_r = io.L_r[i], N_r = io.N_r[i];
+    const FT inv_rho = FT(1) / rho_a;
+    const FT q_c = L_c * inv_rho, q_r = L_r * inv_rho;
+    const bool no_cloud = N_c < P::eps() || q_c < P::eps();
+    FT logN0c, lam_c, c_lo = FT(0), c_hi = FT(0);
+    {
+        const FT sq = M::max(q_c, P::eps()), sN = M::max(N_c, P::eps());
+        const FT logx = P::log(rho_a * sq / sN);
+        const FT logB = -k.mu_c * (logx + k.lg_z1 - k.lg_z2);
+        const FT logA = k.log_mu_c + P::log(sN) + k.z1 * logB - k.lg_z1;
+        logN0c = logA + k.logN0_shift;
+        const FT log_lam_c = logB + k.log_km_mu;
+        lam_c = P::exp(log_lam_c);
+        if (!no_cloud) { c_lo = P::exp((k.log_zq_lo - log_lam_c) * k.inv_mu_cD); c_hi = P::exp((k.log_zq_hi - log_lam_c) * k.inv_mu_cD); }
+    }
+    // rain PSD — pdf_rain_parameters CM2:67-110
+    FT N0r, lam_r;
+    {
+        const FT sq = M::max(q_r, P::eps()), sN = M::max(N_r, P::eps());
+        const FT L = rho_a * sq;
+        bool gate;
+        if (!k.limited) {
+            lam_r = P::exp(P::log(k.pi_rho_w / (L / sN)) / FT(3)); N0r = lam_r * sN;
+            gate = N_r < P::eps() || q_r < P::eps();
+        } else {
+            const FT xt = M::min(M::max(L / sN, k.xr_min), k.xr_max);
+            N0r = M::min(M::max(sN * P::exp(P::log(k.pi_rho_w / xt) / FT(3)), k.N0_min), k.N0_max);
+            lam_r = M::min(M::max(M::sqrt(M::sqrt(k.pi_rho_w * N0r / L)), k.lam_min), k.lam_max);
+            gate = N_r < P::eps() && q_r < P::eps();
+        }
+        if (gate) { N0r = FT(0); lam_r = FT(0); }
+    }
+    const FT Dr_mean = lam_r > FT(0) ? FT(1) / lam_r : FT(0);
+    const FT r_lo = Dr_mean * k.k_lo, r_hi = Dr_mean * k.k_hi;
+    const bool has_cloud = present && c_lo < c_hi, has_rain = present && N0r != FT(0) && r_hi > r_lo;
+    // compute_max_freeze_rate — :167-201
+    const FT T_C = T - k.T_freeze_p3, inv_2TC = FT(1000000) / (FT(2) * T_C);
+    const bool above_freezing = T >= k.T_freeze_tps;
+    FT mfr_fac;
+    bool freeze_all;                 // Musil denominator ≤ 0 (T ≲ 220 K): floatmax in the reference, i.e. f_frz = 1
+    {
+        const FT L_v = k.LH_v0 + k.dcp_v * (T - k.T_0), L_f = k.LH_f0 + k.dcp_f * (T - k.T_0);
+        const FT dT = k.T_freeze_tps - T;
+        const FT ps = k.press_tr * P::exp(k.ps_pow * P::log(T * k.inv_T_tr) + k.ps_b * (k.inv_T_tr - FT(1) / T));
+        const FT drho_v = k.qsi_frz - ps / (k.R_v * T);
+        const FT denom = L_f - k.cp_l * dT;
+        freeze_all = !(denom > FT(0));
+        mfr_fac = FT(2) * pi * (k.K_therm * dT + L_v * k.D_vapor * drho_v) / denom;
+    }
+
+    // ---- inner-node caches: lane j ↔ inner node j -------------------------------------------------------------------
+    if (has_cloud) {
+        const FT sc = (c_hi - c_lo) / FT(2), sh = (c_lo + c_hi) / FT(2);
+        for (int j = g; j < nq; j += kGroup) {
+            const FT D = sc * q_node[j] + sh, logD = P::log(D);
+            const FT nD = P::exp(logN0c + k.nu_cD * logD - lam_c * P::exp(k.mu_cD * logD));
+            cD[j] = D; cV[j] = v_liq(D, logD); cW[j] = q_wt[j] * sc * nD;
+        }
+    }
+    if (has_rain) {
+        const FT sc = (r_hi - r_lo) / FT(2), sh = (r_lo + r_hi) / FT(2);
+        for (int j = g; j < nq; j += kGroup) {
+            const FT D = sc * q_node[j] + sh, logD = P::log(D);
+            rD[j] = D; rV[j] = v_liq(D, logD);
+            rW[j] = q_wt[j] * sc * (N0r * P::exp(-D * lam_r)) * (k.m_fac * (D * D * D));
+        }
+        if (g < 8) {
+            // families of the closed form (closed_rain_inner_NM :343-369): (α, z₀) = (λ, 1) for the v_i term and (λ + c_j, 1 + b_j)
+            // for the three terms of the rain curve.  lane ↔ (family f, end-point): the end-point incomplete gammas → E, and
+            // the family record F[f] = (α, z₀, Γ(z₀), w, λ/α, (λ/α)^z₀) with w = −a_j e^{e_j} λ^{−b_j} (the j-th term of v_l at the
+            // mean diameter): all powers of α are taken relative to λ so that nothing leaves the Float32 range
+            const int f = g >> 1;
+            const FT bj = f == 0 ? FT(0) : (f == 1 ? rb[0] : (f == 2 ? rb[1] : rb[2]));
+            const FT cj = f == 0 ? FT(0) : (f == 1 ? k.r_c[0] : (f == 2 ? k.r_c[1] : k.r_c[2]));
+            const FT aj = f == 0 ? FT(0) : (f == 1 ? k.r_a[0] : (f == 2 ? k.r_a[1] : k.r_a[2]));
+            const FT ej = f == 0 ? FT(0) : (f == 1 ? re[0] : (f == 2 ? re[1] : re[2]));
+            const FT al = lam_r + cj, z0 = FT(1) + bj;
+            const FT G0 = f == 0 ? FT(1) : P::exp(P::lgamma(z0));
+            FT gg[6];
+            lower_gamma6<FT>(z0, al * ((g & 1) ? r_hi : r_lo), G0, gg);
+#pragma unroll
+            for (int m = 0; m < 6; ++m) E[g * 6 + m] = gg[m];
+            if (!(g & 1)) {
+                const FT rr = lam_r / al;
+                Fm[f * 6 + 0] = al; Fm[f * 6 + 1] = z0; Fm[f * 6 + 2] = G0; Fm[f * 6 + 3] = -aj * P::exp(ej - bj * P::log(lam_r));
+                Fm[f * 6 + 4] = rr; Fm[f * 6 + 5] = P::exp(z0 * P::log(rr));
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- outer nodes: lane ↔ node of the current ice segment ---------------------------------------------------------
+    FT acc[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) acc[q] = FT(0);
+    if (present) {
+        for (int sg = 0; sg < 4; ++sg) {
+            const FT a = bnd[sg], b = bnd[sg + 1];
+            if (!(a < b)) continue;
+            const FT scale = (b - a) / FT(2), shift = (a + b) / FT(2);
+            for (int o = g; o < nq; o += kGroup) {
+                const FT Di = scale * q_node[o] + shift, w = q_wt[o] * scale;
+                FT v_i, r_i, n_i;
+                eval_ice(Di, v_i, r_i, n_i);
+                const FT K0 = pi * (r_i * r_i), K1 = pi * r_i, K2 = FT(0.7853981633974483);
+                FT Nc = FT(0), Mc = FT(0), Bc = FT(0), Nr = FT(0), Mr = FT(0), Br = FT(0);
+                if (has_cloud) {
+                    for (int j = 0; j < nq; ++j) {
+                        const FT D = cD[j], dv = P::abs(v_i - cV[j]);
+                        const FT t1 = M::fma(D, M::fma(D, K2, K1), K0) * dv * cW[j];
+                        const FT t2 = t1 * (k.m_fac * (D * D * D));
+                        const FT Ri = M::min(M::max(D * dv * inv_2TC, FT(1)), FT(12));
+                        const FT rho_p = Ri <= FT(8) ? k.rime_a + k.rime_b * Ri + k.rime_c * (Ri * Ri)
+                                                     : k.rime_rho8 + (Ri - FT(8)) * FT(0.25) * (k.rime_rho_ice - k.rime_rho8);
+                        Nc += t1; Mc += t2; Bc += t2 * P::rcp(rho_p);
+                    }
+                }
+                if (has_rain) {
+                    // crossover_diameter — :325-334: Brent on v_l(D) − v_i over [r_lo, r_hi], fixed iteration budget
+                    FT Dstar;
+                    {
+                        FT xa = r_lo, xb = r_hi;
+                        FT fa = v_liq(xa, P::log(xa)) - v_i, fb = v_liq(xb, P::log(xb)) - v_i;
+                        if (!(fa * fb <= FT(0))) Dstar = P::abs(fa) <= P::abs(fb) ? xa : xb;
+                        else {
+                            if (P::abs(fa) < P::abs(fb)) { FT t = xa; xa = xb; xb = t; t = fa; fa = fb; fb = t; }
+                            FT xc = xa, fc = fa, xd = FT(0);
+                            bool mflag = true;
+                            for (int it = 0; it < k.brent_iters; ++it) {
+                                if (fb == FT(0) || xa == xb) break;
+                                FT sx;
+                                if (fa != fc && fb != fc)
+                                    sx = xa * fb * fc / ((fa - fb) * (fa - fc)) + xb * fa * fc / ((fb - fa) * (fb - fc)) + xc * fa * fb / ((fc - fa) * (fc - fb));
+                                else
+                                    sx = xb - fb * (xb - xa) / (fb - fa);
+                                const FT lo3 = (FT(3) * xa + xb) / FT(4);
+                                const bool out_of_range = !((sx > M::min(lo3, xb)) && (sx < M::max(lo3, xb)));
+                                if (out_of_range || (mflag && P::abs(sx - xb) >= P::abs(xb - xc) / FT(2)) ||
+                                    (!mflag && P::abs(sx - xb) >= P::abs(xc - xd) / FT(2))) {
+                                    sx = (xa + xb) / FT(2); mflag = true;
+                                } else mflag = false;
+                                const FT fs = v_liq(sx, P::log(sx)) - v_i;
+                                xd = xc; xc = xb; fc = fb;
+                                if (fa * fs < FT(0)) { xb = sx; fb = fs; } else { xa = sx; fa = fs; }
+                                if (P::abs(fa) < P::abs(fb)) { FT t = xa; xa = xb; xb = t; t = fa; fa = fb; fb = t; }
+                            }
+                            Dstar = xb;
+                        }
+                    }
+                    // crossing(p) = Σ_f coef_f Σ_i K_i α_f^{−z} [2γ(z, α_f D*) − γ(z, α_f D_lo) − γ(z, α_f D_hi)],  z = z₀_f + p + i,
+                    // with every α^{−z} written as λ^{−z} (λ/α)^z: N = N₀r/λ · S₀, M = N₀r/λ · ρ_w π/6 · D̄³ · S₃
+                    FT S0 = FT(0), S3 = FT(0);
+                    const FT Kt1 = K1 * Dr_mean, Kt2 = K2 * (Dr_mean * Dr_mean);
+#pragma unroll 1
+                    for (int f = 0; f < 4; ++f) {
+                        const FT al = Fm[f * 6 + 0], z0 = Fm[f * 6 + 1], G0 = Fm[f * 6 + 2], rr = Fm[f * 6 + 4];
+                        const FT wq = f == 0 ? v_i : Fm[f * 6 + 3];
+                        FT pw = Fm[f * 6 + 5];
+                        FT gs[6], I[6];
+                        lower_gamma6<FT>(z0, al * Dstar, G0, gs);
+#pragma unroll
+                        for (int m = 0; m < 6; ++m) {
+                            I[m] = pw * (FT(2) * gs[m] - E[(2 * f) * 6 + m] - E[(2 * f + 1) * 6 + m]);
+                            pw *= rr;
+                        }
+                        S0 += wq * (K0 * I[0] + Kt1 * I[1] + Kt2 * I[2]);
+                        S3 += wq * (K0 * I[3] + Kt1 * I[4] + Kt2 * I[5]);
+                    }
+                    const FT N0_lam = N0r * Dr_mean;
+                    Nr = N0_lam * S0; Mr = N0_lam * (k.m_fac * (Dr_mean * Dr_mean * Dr_mean)) * S3;
+                    if (!(isfinite(Nr) && isfinite(Mr))) { Nr = FT(0); Mr = FT(0); }
+                    else {
+                        for (int j = 0; j < nq; ++j) {
+                            const FT D = rD[j], dv = P::abs(v_i - rV[j]);
+                            const FT t2 = M::fma(D, M::fma(D, K2, K1), K0) * dv * rW[j];
+                            const FT Ri = M::min(M::max(D * dv * inv_2TC, FT(1)), FT(12));
+                            const FT rho_p = Ri <= FT(8) ? k.rime_a + k.rime_b * Ri + k.rime_c * (Ri * Ri)
+                                                         : k.rime_rho8 + (Ri - FT(8)) * FT(0.25) * (k.rime_rho_ice - k.rime_rho8);
+                            Br += t2 * P::rcp(rho_p);
+                        }
+                    }
+                }
+                // outer integrand — :451-486
+                const FT M_col = Mc + Mr;
+                FT M_max;
+                if (above_freezing) M_max = FT(0);
+                else if (freeze_all) M_max = M_col;                                        // min(M_col, floatmax)
+                else M_max = mfr_fac * Di * (k.vent_a + k.vent_bc * M::sqrt(M::max(Di * v_i, FT(0))));
+                const FT M_frz = M::min(M_col, M_max);
+                const FT f_frz = M_col == FT(0) ? FT(0) : M_frz / M_col;
+                const FT nw = n_i * w;
+                acc[0] += nw * Mc * f_frz; acc[1] += nw * Mc * (FT(1) - f_frz); acc[2] += nw * Nc;
+                acc[3] += nw * Mr * f_frz; acc[4] += nw * Mr * (FT(1) - f_frz); acc[5] += nw * Nr;
+                acc[6] += nw * M_col;      acc[7] += nw * Bc * f_frz;           acc[8] += nw * Br * f_frz;
+                acc[9] += M_col > M_frz ? nw * M_col : FT(0);
+            }
+        }
+    }
+    // ---- group reduction + bulk sources (:600-655) -----------------------------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+        FT x = acc[q];
+#pragma unroll
+        for (int d = kGroup / 2; d >= 1; d >>= 1) x += __shfl_xor(x, d, kGroup);
+        acc[q] = x;
+    }
+    if (g == 0 && valid) {
+#pragma unroll
+        for (int q = 0; q < 10; ++q)
+            if (io.rates[q]) io.rates[q][i] = acc[q];
+        const FT f_wet = acc[6] == FT(0) ? FT(0) : acc[9] / acc[6];
+        const FT NRSHD = acc[4] * k.inv_m_shd;
+        const FT B_rim = s.rho_rim == FT(0) ? FT(0) : (s.rho_q * s.F_rim) / s.rho_rim;
+        const FT QIWET = present ? f_wet * s.rho_q * (FT(1) - s.F_rim) / k.tau_wet : FT(0);
+        const FT BIWET = present ? f_wet * (s.rho_q / k.rho_i - B_rim) / k.tau_wet : FT(0);
+        const FT o[7] = {(-acc[0] - acc[1]) * inv_rho, (-acc[3] + acc[1]) * inv_rho, -acc[2], -acc[5] + NRSHD,
+                         acc[0] + acc[3] + QIWET, acc[0] + acc[3], acc[7] + acc[8] + BIWET};
+#pragma unroll
+        for (int q = 0; q < 7; ++q)
+            if (io.src[q]) io.src[q][i] = o[q];
+    }
+}
+
+template <typename FT, typename IP, typename AP, typename TH, typename QUAD>
+static int32_t p3_collision_entry(const IP *ip, const AP *aps, const TH *tps, const QUAD *quad, uint32_t flags, int64_t n, const FT *rho_q,
+                                  const FT *rho_n, const FT *x3, const FT *x4, const FT *L_c, const FT *N_c, const FT *L_r, const FT *N_r,
+                                  const FT *rho_a, const FT *T, const FT *loglam, FT *const *sources, FT *const *rates, void *stream) {
+    if (!ip || !aps || !tps || !quad || n < 0 ||
+        (flags & ~(CMX_P3_INPUT_IS_STATE | CMX_P3_SLOPE_CONSTANT | CMX_P3_NO_ASPECT_RATIO | CMX_P3_RAIN_PDF_LIMITED)))
+        return CMX_ERR_BAD_ARG;
+    if (quad->n < 1 || quad->n > CMX_QUAD_MAX) return CMX_ERR_BAD_ARG;
+    if (n == 0) return CMX_OK;
+    if (!rho_q || !rho_n || !x3 || !x4 || !L_c || !N_c || !L_r || !N_r || !rho_a || !T || !loglam || (!sources && !rates)) return CMX_ERR_BAD_ARG;
+    P3Consts<FT> c = make_p3_consts<FT>(ip->scheme, flags);
+    c.brent_iters = 0;
+    P3VelConsts<FT> v = make_p3_vel_consts<FT>(ip->scheme, ip->vel_ice, 1e-5);
+    v.p_lo = FT(0.00001); v.p_hi = FT(1) - v.p_lo;
+    const P3ColConsts<FT> k = make_p3col_consts<FT>(*ip, *aps, *tps, flags);
+    P3ColIO<FT> io{rho_q, rho_n, x3, x4, L_c, N_c, L_r, N_r, rho_a, T, loglam, {}, {}};
+    for (int q = 0; q < 7; ++q) io.src[q] = sources ? sources[q] : nullptr;
+    for (int q = 0; q < 10; ++q) io.rates[q] = rates ? rates[q] : nullptr;
+    const dim3 grid((unsigned)((n + kPointsPerBlock - 1) / kPointsPerBlock)), block(kBlock);
+    const size_t lds = sizeof(FT) * (size_t)(2 * quad->n + kPointsPerBlock * (6 * quad->n + 72));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (lds > 48 * 1024) {   // large quadrature orders need more than the default dynamic-LDS limit
+        CMX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&p3_collision_kernel<FT, QUAD, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CMX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&p3_collision_kernel<FT, QUAD, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (flags & CMX_P3_NO_ASPECT_RATIO)
+        hipLaunchKernelGGL((p3_collision_kernel<FT, QUAD, false>), grid, block, lds, st, c, v, k, *quad, io, n);
+    else
+        hipLaunchKernelGGL((p3_collision_kernel<FT, QUAD, true>), grid, block, lds, st, c, v, k, *quad, io, n);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+
+}  // namespace cmx
+
+extern "C" {
+
+int32_t cmx_p3_liquid_ice_collisions_f32(const cmx_p3_ice_params_f32 *ice, const cmx_air_properties_f32 *aps, const cmx_thermo_f32 *tps,
+                                         const cmx_quadrature_f32 *quad, uint32_t flags, int64_t n, const float *rho_q_ice,
+                                         const float *rho_n_ice, const float *x3, const float *x4, const float *L_c, const float *N_c,
+                                         const float *L_r, const float *N_r, const float *rho_air, const float *T, const float *log_lambda,
+                                         float *const *sources, float *const *rates, void *stream) {
+    return cmx::p3_collision_entry<float>(ice, aps, tps, quad, flags, n, rho_q_ice, rho_n_ice, x3, x4, L_c, N_c, L_r, N_r, rho_air, T, log_lambda,
+                                          sources, rates, stream);
+}
+int32_t cmx_p3_liquid_ice_collisions_f64(const cmx_p3_ice_params_f64 *ice, const cmx_air_properties_f64 *aps, const cmx_thermo_f64 *tps,
+                                         const cmx_quadrature_f64 *quad, uint32_t flags, int64_t n, const double *rho_q_ice,
+                                         const double *rho_n_ice, const double *x3, const double *x4, const double *L_c, const double *N_c,
+                                         const double *L_r, const double *N_r, const double *rho_air, const double *T, const double *log_lambda,
+                                         double *const *sources, double *const *rates, void *stream) {
+    return cmx::p3_collision_entry<double>(ice, aps, tps, quad, flags, n, rho_q_ice, rho_n_ice, x3, x4, L_c, N_c, L_r, N_r, rho_air, T, log_lambda,
+                                           sources, rates, stream);
+}
+
+}  // extern "C"

@@ -671,6 +671,30 @@ int32_t cmx_p3_ice_self_collection_f64(const cmx_p3_params_f64 *params, const cm
                                        uint32_t flags, int64_t n, const double *rho_q_ice, const double *rho_n_ice, const double *x3,
                                        const double *x4, const double *rho_air, const double *log_lambda, double *dNdt, void *stream);
 
+/* (8) P3 liquid–ice collisions: replaces, per point,
+ *   rates   = P3.∫liquid_ice_collisions(state, logλ, psd_c, psd_r, L_c, N_c, L_r, N_r, aps, tps, vel, ρₐ, T, m_liq; quad)
+ *                                                                                         src/P3_processes.jl:527-562
+ *   sources = P3.bulk_liquid_ice_collision_sources(state, logλ, psd_c, psd_r, L_c, N_c, L_r, N_r, aps, tps, vel, ρₐ, T; quad)
+ *                                                                                         src/P3_processes.jl:600-655
+ * (called from the 2M+P3 fused entry, BMT:962-972).  `ice` carries scheme (+ vent, ρ_rim_local), the Chen-2022 rain and
+ * ice fall-speed tables, cloud_pdf and rain_pdf (flags & CMX_P3_RAIN_PDF_LIMITED selects the limited rain PSD); the
+ * quadrature rule is the explicit `quad` (ice->quad is what the fused entry passes).  The rain inner integral uses the
+ * reference's closed form (closed_rain_inner_NM :343-369: crossover diameter by a fixed-budget Brent solve, incomplete-gamma
+ * moments), the cloud inner integral and both rime-volume integrals the quadrature rule.
+ * sources[7] = device columns (∂ₜq_c, ∂ₜq_r, ∂ₜN_c, ∂ₜN_r, ∂ₜL_rim, ∂ₜL_ice, ∂ₜB_rim), rates[10] = device columns (QCFRZ, QCSHD,
+ * NCCOL, QRFRZ, QRSHD, NRCOL, ∫M_col, BCCOL, BRCOL, ∫𝟙_wet M_col); either array (host array of device pointers) or any
+ * entry may be NULL.  Points with ρn_ice or ρq_ice < eps(FT) give 0. */
+int32_t cmx_p3_liquid_ice_collisions_f32(const cmx_p3_ice_params_f32 *ice, const cmx_air_properties_f32 *aps, const cmx_thermo_f32 *tps,
+                                         const cmx_quadrature_f32 *quad, uint32_t flags, int64_t n, const float *rho_q_ice,
+                                         const float *rho_n_ice, const float *x3, const float *x4, const float *L_c, const float *N_c,
+                                         const float *L_r, const float *N_r, const float *rho_air, const float *T, const float *log_lambda,
+                                         float *const *sources, float *const *rates, void *stream);
+int32_t cmx_p3_liquid_ice_collisions_f64(const cmx_p3_ice_params_f64 *ice, const cmx_air_properties_f64 *aps, const cmx_thermo_f64 *tps,
+                                         const cmx_quadrature_f64 *quad, uint32_t flags, int64_t n, const double *rho_q_ice,
+                                         const double *rho_n_ice, const double *x3, const double *x4, const double *L_c, const double *N_c,
+                                         const double *L_r, const double *N_r, const double *rho_air, const double *T, const double *log_lambda,
+                                         double *const *sources, double *const *rates, void *stream);
+
 /* ---------------------------------------------------------------------------
  * (3) Optional diagnostic sums over one rank's shard: per-column
  * Σx (double accumulation) of `ncols` device columns of length n into
