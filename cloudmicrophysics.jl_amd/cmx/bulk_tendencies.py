@@ -46,6 +46,11 @@ WarmRainTendencies2M = namedtuple(
 
 SB2006ProcessRates = namedtuple("SB2006ProcessRates", _abi.SB2006_PROCESS_COLUMNS)
 
+# return of the 2M + P3 method (BMT:1079-1082)
+Tendencies2MP3 = namedtuple(
+    "Tendencies2MP3",
+    ["dq_lcl_dt", "dn_lcl_dt", "dq_rai_dt", "dn_rai_dt", "dq_ice_dt", "dn_ice_dt", "dq_rim_dt", "db_rim_dt", "dn_lcl_activation_dt"])
+
 
 def _fam_of(t: torch.Tensor):
     if t.dtype == torch.float32:
@@ -88,9 +93,40 @@ def _vel_flag(vel):
     return flag
 
 
-def bulk_microphysics_tendencies(scheme, mp, tps, rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, *,
-                                 vel=None, out: Optional[WarmRainTendencies2M] = None, stream=None):
-    """2-moment warm-rain tendencies over columns — BMT:820-854 → warm_rain_tendencies_2m BMT:707-782.
+def _bulk_tendencies_2m_p3(mp, tps, rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice, n_ice, q_rim, b_rim, log_lambda, inpc_log_shift,
+                           aspect_ratio, stream):
+    """bulk_microphysics_tendencies(::Microphysics2Moment, mp{WR, P3IceParams}, …) — BMT:898-1083 behind
+    cmx_microphysics_2m_p3_tendencies_*."""
+    cols = (rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice, n_ice, q_rim, b_rim, log_lambda)
+    ref = _check_cols(cols, ("rho", "T", "q_tot", "q_lcl", "n_lcl", "q_rai", "n_rai", "q_ice", "n_ice", "q_rim", "b_rim", "log_lambda"))
+    fam = _fam_of(ref)
+    if fam is not mp.fam or fam is not mp.ice.fam or not isinstance(tps, fam.thermo):
+        raise TypeError("parameter float type does not match the state columns")
+    if mp.ice.is_limited != mp.warm_rain.is_limited:
+        raise ValueError("warm_rain and ice must use the same rain PSD variant (is_limited)")
+    if inpc_log_shift is not None:
+        _check_cols([ref, inpc_log_shift], ["rho", "inpc_log_shift"])
+    outs = [torch.empty_like(ref) for _ in range(8)]
+    out_p = (C.c_void_p * 8)(*[t.data_ptr() for t in outs])
+    flags = mp.ice.flags | (0 if aspect_ratio else _abi.CMX_P3_NO_ASPECT_RATIO)
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_microphysics_2m_p3_tendencies_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(mp.warm_rain.c), C.byref(mp.ice.c), C.byref(tps), flags, ref.numel(), *[_ptr(t) for t in cols], _ptr(inpc_log_shift),
+                out_p, C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return Tendencies2MP3(*outs, torch.zeros((), dtype=ref.dtype, device=ref.device).expand_as(ref))
+
+
+def bulk_microphysics_tendencies(scheme, mp, tps, rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice=None, n_ice=None, q_rim=None,
+                                 b_rim=None, log_lambda=None, inpc_log_shift=None, *, vel=None, aspect_ratio=True,
+                                 out: Optional[WarmRainTendencies2M] = None, stream=None):
+    """2-moment tendencies over columns.
+
+    With `mp = Microphysics2MParams(FT; with_ice = true)` and the P3 ice columns (q_ice, n_ice, q_rim, b_rim, logλ[, inpc_log_shift])
+    this is the warm rain + P3 ice method, BMT:898-1083 (returns `Tendencies2MP3`).  Otherwise:
+
+    2-moment warm-rain tendencies over columns — BMT:820-854 → warm_rain_tendencies_2m BMT:707-782.
 
     `vel` (None | SB2006VelType | Chen2022VelTypeRain) additionally fuses
     CM2.rain_terminal_velocity (CM2:685-719) into the same pass (two more output columns).
@@ -98,6 +134,15 @@ def bulk_microphysics_tendencies(scheme, mp, tps, rho, T, q_tot, q_lcl, n_lcl, q
     Asynchronous on `stream` (default: torch's current stream)."""
     if not isinstance(scheme, Microphysics2Moment):
         raise TypeError("only Microphysics2Moment() is on this path")
+    if isinstance(mp, Microphysics2MParams) and mp.ice is not None:
+        if any(x is None for x in (q_ice, n_ice, q_rim, b_rim, log_lambda)):
+            raise TypeError("the 2M + P3 method needs q_ice, n_ice, q_rim, b_rim and log_lambda columns")
+        if vel is not None or out is not None:
+            raise TypeError("vel / out are options of the warm-rain method")
+        return _bulk_tendencies_2m_p3(mp, tps, rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice, n_ice, q_rim, b_rim, log_lambda,
+                                      inpc_log_shift, aspect_ratio, stream)
+    if q_ice is not None:
+        raise TypeError("ice columns given but mp has no ice parameters (Microphysics2MParams(FT, with_ice=True))")
     wr = _warm_rain(mp)
     cols = (rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai)
     ref = _check_cols(cols, ("rho", "T", "q_tot", "q_lcl", "n_lcl", "q_rai", "n_rai"))

@@ -22,7 +22,10 @@
 // COMPUTE-bound (FP64 / FP32 vector rate); HBM traffic is 11 input + ≤17 output columns per point.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "cmx_p3.hpp"
+#include "cmx_sb2006.hpp"
 
 namespace cmx {
 
@@ -45,6 +48,7 @@ template <typename FT> struct P3ColConsts {
     FT T_freeze_p3;                 // params.T_freeze of compute_local_rime_density :281
     FT m_fac;                       // ρ_w π/6
     FT tau_wet, rho_i, inv_m_shd;   // bulk sources :612-650
+    FT p_lo_m, p_hi_m, K4;          // ice_melt :64-94 inside the fused entry: FT(1e-6), FT(1 − 1e-6), 4 K_therm
     int brent_iters;
 };
 
@@ -119,6 +123,7 @@ static P3ColConsts<FT> make_p3col_consts(const IP &ip, const AP &aps, const TH &
     k.tau_wet = ip.scheme.tau_wet; k.rho_i = ip.scheme.rho_i;
     k.inv_m_shd = (FT)(1.0 / ((double)pc.rho_w * 1e-9 * pi / 6.0));      // 1/m_liq(D_shd = 1 mm)
     k.brent_iters = sizeof(FT) == 4 ? 8 : 10;
+    k.p_lo_m = (FT)1e-6; k.p_hi_m = (FT)(1.0 - 1e-6); k.K4 = (FT)(4.0 * (double)aps.K_therm);
     return k;
 }
 
@@ -149,6 +154,10 @@ template <typename FT> struct P3ColIO {
     const FT *rho_q, *rho_n, *x3, *x4, *L_c, *N_c, *L_r, *N_r, *rho_a, *T, *loglam;
     FT *src[7];      // ∂ₜq_c, ∂ₜq_r, ∂ₜN_c, ∂ₜN_r, ∂ₜL_rim, ∂ₜL_ice, ∂ₜB_rim   (nullable)
     FT *rates[10];   // QCFRZ, QCSHD, NCCOL, QRFRZ, QRSHD, NRCOL, ∫M_col, BCCOL, BRCOL, ∫𝟙_wet M_col   (nullable)
+    // FUSED (2M+P3 entry, BMT:898-1083): per-kg prognostic columns in (ρ = rho_a, T, loglam as above), the eight tendency columns
+    // (dq_lcl, dn_lcl, dq_rai, dn_rai, dq_ice, dn_ice, dq_rim, db_rim) are read-modify-written
+    const FT *q_lcl, *n_lcl, *q_rai, *n_rai, *q_ice, *n_ice, *q_rim, *b_rim;
+    FT *out[8];
 };
 
 // LDS per group, in FT units: quadrature copy is per block
@@ -156,7 +165,7 @@ template <typename FT> struct ColLds {
     static __device__ __forceinline__ int per_group(int n) { return 6 * n + 72; }
 };
 
-template <typename FT, typename QUAD, bool ASPECT>
+template <typename FT, typename QUAD, bool ASPECT, bool FUSED>
 __global__ __launch_bounds__(kBlock) void p3_collision_kernel(const P3Consts<FT> c, const P3VelConsts<FT> v, const P3ColConsts<FT> k,
                                                              const QUAD quad, const P3ColIO<FT> io, const int64_t n) {
     using P = PM<FT>;
@@ -178,16 +187,44 @@ __global__ __launch_bounds__(kBlock) void p3_collision_kernel(const P3Consts<FT>
 
     // ---- per-point set-up (uniform over the group) ---------------------------------------------------------------
     P3Point<FT> s;
-    p3_make_point<FT>(c, io.rho_q[i], io.rho_n[i], io.x3[i], io.x4[i], s);
-    const bool present = !(s.rho_n < P::eps() || s.rho_q < P::eps());
+    FT L_c, N_c, L_r, N_r;
+    bool present;
     const FT rho_a = M::max(io.rho_a[i], FT(0)), T = io.T[i];
+    if constexpr (FUSED) {
+        // clamp_to_nonneg and the volumetric quantities of BMT:912-932; ice processes only where q_ice > ϵₘ && n_ice > ϵₙ (:959)
+        const FT q_ice = M::max(io.q_ice[i], FT(0)), n_ice = M::max(io.n_ice[i], FT(0));
+        L_c = M::max(io.q_lcl[i], FT(0)) * rho_a; N_c = M::max(io.n_lcl[i], FT(0)) * rho_a;
+        L_r = M::max(io.q_rai[i], FT(0)) * rho_a; N_r = M::max(io.n_rai[i], FT(0)) * rho_a;
+        p3_make_point<FT>(c, q_ice * rho_a, n_ice * rho_a, M::max(io.q_rim[i], FT(0)) * rho_a, M::max(io.b_rim[i], FT(0)) * rho_a, s);
+        present = q_ice > P::eps() && n_ice > P::eps() && !(s.rho_n < P::eps() || s.rho_q < P::eps());
+    } else {
+        L_c = io.L_c[i]; N_c = io.N_c[i]; L_r = io.L_r[i]; N_r = io.N_r[i];
+        p3_make_point<FT>(c, io.rho_q[i], io.rho_n[i], io.x3[i], io.x4[i], s);
+        present = !(s.rho_n < P::eps() || s.rho_q < P::eps());
+    }
     const FT loglam = present ? io.loglam[i] : FT(10), lam = P::exp(loglam), mu = p3_mu<FT>(c, loglam);
     const FT logN0 = P::log(present ? s.rho_n : FT(1)) - (-(mu + FT(1)) * loglam + P::lgamma(mu + FT(1)));
     const FT lra = P::log(rho_a);
     const FT sb = v.s_B + rho_a * v.s_C, se = v.s_A * lra + sb * v.ln1000;
     const FT le1 = v.l_A * lra, le2 = le1 + v.l_H * rho_a;
-    const FT D_min = gamma_inc_inv_dev<FT>(mu + FT(1), v.p_lo, FT(1) - v.p_lo) / lam;
-    const FT D_max = gamma_inc_inv_dev<FT>(mu + FT(1), v.p_hi, FT(1) - v.p_hi) / lam;
+    // quantiles of the ice PSD (integral_bounds, P3_integral_properties.jl:34-46): one Halley solve per LANE — lanes 0/1 the
+    // collision bounds (p = 1e-5), 2/3 the self-collection bounds (p = eps), 4/5 the melting bounds (p = 1e-6) — shared by shuffles
+    FT D_min, D_max, D_lo_sc = FT(0), D_hi_sc = FT(0), D_lo_m = FT(0), D_hi_m = FT(0);
+    {
+        FT plev = (g & 1) ? v.p_hi : v.p_lo;
+        if constexpr (FUSED) {
+            if (g == 2) plev = P::eps();
+            if (g == 3) plev = FT(1) - P::eps();
+            if (g == 4) plev = k.p_lo_m;
+            if (g == 5) plev = k.p_hi_m;
+        }
+        const FT xq = gamma_inc_inv_dev<FT>(mu + FT(1), plev, FT(1) - plev) / lam;
+        D_min = __shfl(xq, 0, kGroup); D_max = __shfl(xq, 1, kGroup);
+        if constexpr (FUSED) {
+            D_lo_sc = __shfl(xq, 2, kGroup); D_hi_sc = __shfl(xq, 3, kGroup);
+            D_lo_m = __shfl(xq, 4, kGroup); D_hi_m = __shfl(xq, 5, kGroup);
+        }
+    }
     FT bnd[5];
     bnd[0] = D_min; bnd[4] = D_max;
 #pragma unroll
@@ -228,7 +265,6 @@ __global__ __launch_bounds__(kBlock) void p3_collision_kernel(const P3Consts<FT>
                k.r_a[2] * P::exp(re[2] + rb[2] * logD - k.r_c[2] * D);
     };
     // cloud PSD in diameter — log_pdf_cloud_parameters_mass CM2:172-188, pdf_cloud_parameters :227-236
-    const FT L_c = io.L_c[i], N_c = io.N_c[i], L_r = io.L_r[i], N_r = io.N_r[i];
     const FT inv_rho = FT(1) / rho_a;
     const FT q_c = L_c * inv_rho, q_r = L_r * inv_rho;
     const bool no_cloud = N_c < P::eps() || q_c < P::eps();
@@ -426,6 +462,62 @@ __global__ __launch_bounds__(kBlock) void p3_collision_kernel(const P3Consts<FT>
             }
         }
     }
+    // ---- 2M+P3 entry only: aggregation (ice_self_collection :676-712) and melting (ice_melt :64-94), outer node per lane ------
+    FT acc_sc = FT(0), acc_m = FT(0);
+    if constexpr (FUSED) {
+        if (present) {
+            FT bs[5];
+            bs[0] = D_lo_sc; bs[4] = D_hi_sc;
+#pragma unroll
+            for (int q = 1; q < 4; ++q) bs[q] = M::min(M::max(s.bnd[q], D_lo_sc), D_hi_sc);
+            for (int sg = 0; sg < 4; ++sg) {
+                const FT a = bs[sg], b = bs[sg + 1];
+                if (!(a < b)) continue;
+                const FT scale = (b - a) / FT(2), shift = (a + b) / FT(2);
+                for (int o = g; o < nq; o += kGroup) {
+                    const FT D1 = scale * q_node[o] + shift;
+                    FT v1, r1, n1;
+                    eval_ice(D1, v1, r1, n1);
+                    FT inner = FT(0);
+                    for (int h = 0; h < 2; ++h) {   // inner integral split at the |v₁ − v₂| cusp D₂ = D₁
+                        const FT ia = h == 0 ? D_lo_sc : D1, ib = h == 0 ? D1 : D_hi_sc;
+                        if (!(ia < ib)) continue;
+                        const FT sc2 = (ib - ia) / FT(2), sh2 = (ia + ib) / FT(2);
+                        FT r_in = FT(0);
+                        for (int j = 0; j < nq; ++j) {
+                            FT v2, r2, n2;
+                            eval_ice(sc2 * q_node[j] + sh2, v2, r2, n2);
+                            const FT rs = r1 + r2;
+                            r_in += rs * rs * P::abs(v1 - v2) * n2 * q_wt[j];
+                        }
+                        inner += sc2 * r_in;
+                    }
+                    acc_sc += inner * n1 * (q_wt[o] * scale);
+                }
+            }
+            if (T > k.T_freeze_tps) {   // BMT:980
+                FT bm[5];
+                bm[0] = D_lo_m; bm[4] = D_hi_m;
+#pragma unroll
+                for (int q = 1; q < 4; ++q) bm[q] = M::min(M::max(s.bnd[q], D_lo_m), D_hi_m);
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg) {
+                    const FT a = bm[sg], b = bm[sg + 1];
+                    if (!(a < b)) continue;
+                    const FT scale = (b - a) / FT(2), shift = (a + b) / FT(2);
+                    const FT mb = s.b[sg], ma = P::exp(s.log_a[sg]);
+                    for (int o = g; o < nq; o += kGroup) {
+                        const FT x = scale * q_node[o] + shift;
+                        FT vD, rD_, nD;
+                        eval_ice(x, vD, rD_, nD);
+                        const FT Fv = k.vent_a + k.vent_bc * M::sqrt(M::max(x * vD, FT(0)));
+                        const FT dm_over_D = mb == FT(3) ? ma * mb * x : ma * mb * P::exp((mb - FT(2)) * P::log(x));   // ∂m/∂D / D
+                        acc_m += dm_over_D * Fv * nD * (q_wt[o] * scale);
+                    }
+                }
+            }
+        }
+    }
     // ---- group reduction + bulk sources (:600-655) -----------------------------------------------------------------------
 #pragma unroll
     for (int q = 0; q < 10; ++q) {
@@ -434,10 +526,11 @@ __global__ __launch_bounds__(kBlock) void p3_collision_kernel(const P3Consts<FT>
         for (int d = kGroup / 2; d >= 1; d >>= 1) x += __shfl_xor(x, d, kGroup);
         acc[q] = x;
     }
-    if (g == 0 && valid) {
+    if constexpr (FUSED) {
 #pragma unroll
-        for (int q = 0; q < 10; ++q)
-            if (io.rates[q]) io.rates[q][i] = acc[q];
+        for (int d = kGroup / 2; d >= 1; d >>= 1) { acc_sc += __shfl_xor(acc_sc, d, kGroup); acc_m += __shfl_xor(acc_m, d, kGroup); }
+    }
+    if (g == 0 && valid) {
         const FT f_wet = acc[6] == FT(0) ? FT(0) : acc[9] / acc[6];
         const FT NRSHD = acc[4] * k.inv_m_shd;
         const FT B_rim = s.rho_rim == FT(0) ? FT(0) : (s.rho_q * s.F_rim) / s.rho_rim;
@@ -445,9 +538,24 @@ __global__ __launch_bounds__(kBlock) void p3_collision_kernel(const P3Consts<FT>
         const FT BIWET = present ? f_wet * (s.rho_q / k.rho_i - B_rim) / k.tau_wet : FT(0);
         const FT o[7] = {(-acc[0] - acc[1]) * inv_rho, (-acc[3] + acc[1]) * inv_rho, -acc[2], -acc[5] + NRSHD,
                          acc[0] + acc[3] + QIWET, acc[0] + acc[3], acc[7] + acc[8] + BIWET};
+        if constexpr (!FUSED) {
 #pragma unroll
-        for (int q = 0; q < 7; ++q)
-            if (io.src[q]) io.src[q][i] = o[q];
+            for (int q = 0; q < 10; ++q)
+                if (io.rates[q]) io.rates[q][i] = acc[q];
+#pragma unroll
+            for (int q = 0; q < 7; ++q)
+                if (io.src[q]) io.src[q][i] = o[q];
+        } else if (present) {
+            // BMT:966-994: collisions, aggregation (½π factored out of the sums), melting (ice → rain; rime drains in proportion)
+            const FT agg = FT(0.5) * pi * acc_sc;
+            const FT L_f = k.LH_f0 + k.dcp_f * (T - k.T_0);
+            const FT mL = T > k.T_freeze_tps ? M::max(FT(0), k.K4 / L_f * (T - k.T_freeze_p3) * acc_m) : FT(0);
+            const FT mq = mL * inv_rho, mn = (s.rho_n / s.rho_q * mL) * inv_rho;
+            const FT d[8] = {o[0], o[2] * inv_rho, o[1] + mq, o[3] * inv_rho + mn, o[5] * inv_rho - mq, -agg * inv_rho - mn,
+                             o[4] * inv_rho - mq * s.F_rim, o[6] * inv_rho - (s.rho_rim > FT(0) ? mq * s.F_rim / s.rho_rim : FT(0))};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) io.out[q][i] += d[q];
+        }
     }
 }
 
@@ -466,22 +574,216 @@ static int32_t p3_collision_entry(const IP *ip, const AP *aps, const TH *tps, co
     P3VelConsts<FT> v = make_p3_vel_consts<FT>(ip->scheme, ip->vel_ice, 1e-5);
     v.p_lo = FT(0.00001); v.p_hi = FT(1) - v.p_lo;
     const P3ColConsts<FT> k = make_p3col_consts<FT>(*ip, *aps, *tps, flags);
-    P3ColIO<FT> io{rho_q, rho_n, x3, x4, L_c, N_c, L_r, N_r, rho_a, T, loglam, {}, {}};
+    P3ColIO<FT> io{};
+    io.rho_q = rho_q; io.rho_n = rho_n; io.x3 = x3; io.x4 = x4; io.L_c = L_c; io.N_c = N_c; io.L_r = L_r; io.N_r = N_r;
+    io.rho_a = rho_a; io.T = T; io.loglam = loglam;
     for (int q = 0; q < 7; ++q) io.src[q] = sources ? sources[q] : nullptr;
     for (int q = 0; q < 10; ++q) io.rates[q] = rates ? rates[q] : nullptr;
     const dim3 grid((unsigned)((n + kPointsPerBlock - 1) / kPointsPerBlock)), block(kBlock);
     const size_t lds = sizeof(FT) * (size_t)(2 * quad->n + kPointsPerBlock * (6 * quad->n + 72));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (lds > 48 * 1024) {   // large quadrature orders need more than the default dynamic-LDS limit
-        CMX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&p3_collision_kernel<FT, QUAD, false>),
+        CMX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&p3_collision_kernel<FT, QUAD, false, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CMX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&p3_collision_kernel<FT, QUAD, true>),
+        CMX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&p3_collision_kernel<FT, QUAD, true, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     if (flags & CMX_P3_NO_ASPECT_RATIO)
-        hipLaunchKernelGGL((p3_collision_kernel<FT, QUAD, false>), grid, block, lds, st, c, v, k, *quad, io, n);
+        hipLaunchKernelGGL((p3_collision_kernel<FT, QUAD, false, false>), grid, block, lds, st, c, v, k, *quad, io, n);
     else
-        hipLaunchKernelGGL((p3_collision_kernel<FT, QUAD, true>), grid, block, lds, st, c, v, k, *quad, io, n);
+        hipLaunchKernelGGL((p3_collision_kernel<FT, QUAD, true, false>), grid, block, lds, st, c, v, k, *quad, io, n);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+
+// =====================================================================================================================
+// 2M + P3 fused entry — bulk_microphysics_tendencies(::Microphysics2Moment, mp{WR, P3IceParams}, …), BMT:898-1083.
+// Two launches on the caller's stream:
+//   1. mp2m_p3_pointwise_kernel (lane per point, HBM-bound): clamps, warm rain with the ice content in the vapour budget
+//      (sb2006_point<ICE>), F23 deposition nucleation, F23-capped Bigg freezing of cloud drops, ice sublimation/deposition,
+//      ice number adjustment, Bigg freezing of rain — writes the eight tendency columns;
+//   2. p3_collision_kernel<FUSED> (16 lanes per point, compute-bound): liquid–ice collisions, aggregation and melting where
+//      q_ice > ϵ and n_ice > ϵ — read-modify-writes the same columns.
+template <typename FT> struct PointwiseConsts {
+    FT f23_b10, f23_log_a, f23_T_freeze, inv_tau_act, m_nuc, T_dep, S_thresh;           // Frostenberg 2023 (IceNucleation.jl:250-511)
+    FT rf_a, rf_B, T_bigg;                                                             // RainFreezing, T_freeze − 4
+    FT ps_pow, ps_b, inv_T_tr, press_tr, R_v, LH_s0, dcp_s, T_0, cp_d, cpm_qt, cpm_ql, cpm_qi, T_freeze_tps;
+    FT tau_subdep;
+    FT mu_c, lg_z1, lg_z2, log_km_mu, G3, G6, k3, k6, V1, rho_w_V1sq;                   // cloud PSD moments (generalized gamma)
+    FT xr_min, xr_max, N0_min, N0_max, lam_min, lam_max, pi_rho_w;                      // rain PSD
+    FT inv_rho_i;
+};
+template <typename FT, typename WR, typename IP, typename TH>
+static PointwiseConsts<FT> make_pointwise_consts(const WR &wr, const IP &ip, const TH &tps) {
+    PointwiseConsts<FT> k{};
+    const double pi = 3.14159265358979323846;
+    const auto &fr = ip.ice_nucleation;
+    k.f23_b10 = (FT)(-(double)fr.b / 10.0); k.f23_log_a = fr.log_a; k.f23_T_freeze = fr.T_freeze;
+    k.inv_tau_act = (FT)(1.0 / (double)ip.tau_act);
+    k.m_nuc = (FT)((double)ip.scheme.rho_i * (1e-15 * pi / 6.0));                       // ρ_i · volume_sphere_D(10 µm) — BMT:999-1000
+    k.T_dep = (FT)((double)fr.T_freeze - 15.0); k.S_thresh = (FT)0.05;
+    k.rf_a = ip.rain_freezing.het_a; k.rf_B = ip.rain_freezing.het_B; k.T_bigg = (FT)((double)tps.T_freeze - 4.0);
+    const double dcp_i = (double)tps.cp_v - (double)tps.cp_i, Rv = tps.R_v;
+    k.ps_pow = (FT)(dcp_i / Rv); k.ps_b = (FT)(((double)tps.LH_s0 - dcp_i * (double)tps.T_0) / Rv); k.inv_T_tr = (FT)(1.0 / (double)tps.T_triple);
+    k.press_tr = tps.press_triple; k.R_v = tps.R_v; k.LH_s0 = tps.LH_s0; k.dcp_s = (FT)dcp_i; k.T_0 = tps.T_0;
+    k.cp_d = tps.cp_d; k.cpm_qt = (FT)((double)tps.cp_v - (double)tps.cp_d); k.cpm_ql = (FT)((double)tps.cp_l - (double)tps.cp_v);
+    k.cpm_qi = (FT)((double)tps.cp_i - (double)tps.cp_v); k.T_freeze_tps = tps.T_freeze;
+    k.tau_subdep = wr.subdep_tau_relax;
+    const auto &pc = ip.cloud_pdf;
+    const double nu = pc.nu_c, mu = pc.mu_c, km = (double)pc.rho_w * pi / 6.0, nuD = 3 * nu + 2, muD = 3 * mu;
+    k.mu_c = pc.mu_c; k.lg_z1 = pc.loggamma_z1; k.lg_z2 = pc.loggamma_z2; k.log_km_mu = (FT)(mu * std::log(km));
+    k.G3 = (FT)(std::tgamma((nuD + 4) / muD) / std::tgamma((nuD + 1) / muD));
+    k.G6 = (FT)(std::tgamma((nuD + 7) / muD) / std::tgamma((nuD + 1) / muD));
+    k.k3 = (FT)(-3.0 / muD); k.k6 = (FT)(-6.0 / muD);
+    k.V1 = (FT)(pi / 6.0); k.rho_w_V1sq = (FT)((double)pc.rho_w * (pi / 6.0) * (pi / 6.0));
+    const auto &pr = ip.rain_pdf;
+    k.xr_min = pr.xr_min; k.xr_max = pr.xr_max; k.N0_min = pr.N0_min; k.N0_max = pr.N0_max; k.lam_min = pr.lambda_min; k.lam_max = pr.lambda_max;
+    k.pi_rho_w = (FT)(pi * (double)pr.rho_w);
+    k.inv_rho_i = (FT)(1.0 / (double)ip.scheme.rho_i);
+    return k;
+}
+template <typename FT> struct FusedIO {
+    const FT *rho, *T, *q_tot, *q_lcl, *n_lcl, *q_rai, *n_rai, *q_ice, *n_ice, *q_rim, *b_rim, *shift;
+    FT *out[8];
+};
+
+template <typename FT, bool LIMITED>
+__global__ __launch_bounds__(kBlock) void mp2m_p3_pointwise_kernel(const SbConsts<FT> sc, const P3Consts<FT> c, const PointwiseConsts<FT> k,
+                                                                  const FusedIO<FT> io, const int64_t n) {
+    using P = PM<FT>;
+    using M = Math<FT>;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const FT eps = P::eps();
+    // clamp_to_nonneg — BMT:912-921 (T is not clamped)
+    const FT rho = M::max(io.rho[i], FT(0)), T = io.T[i], q_tot = M::max(io.q_tot[i], FT(0));
+    const FT q_lcl = M::max(io.q_lcl[i], FT(0)), n_lcl = M::max(io.n_lcl[i], FT(0)), q_rai = M::max(io.q_rai[i], FT(0)), n_rai = M::max(io.n_rai[i], FT(0));
+    const FT q_ice = M::max(io.q_ice[i], FT(0)), n_ice = M::max(io.n_ice[i], FT(0)), q_rim = M::max(io.q_rim[i], FT(0)), b_rim = M::max(io.b_rim[i], FT(0));
+    const FT shift = io.shift ? io.shift[i] : FT(0);
+    const FT N_lcl = rho * n_lcl, N_rai = rho * n_rai, inv_rho = FT(1) / rho;
+    // warm rain — BMT:942 → warm_rain_tendencies_2m :707-782
+    const SbRates<FT> w = sb2006_point<FT, LIMITED, VEL_NONE, true>(sc, rho, T, q_tot, q_lcl, q_rai, N_lcl, N_rai, n_lcl, n_rai, q_ice);
+    FT dq_lcl = (w.cond + w.au_dq_lcl) + w.ac_dq_lcl;
+    FT dn_lcl = M::fma(w.lsc_plus_au + w.ac_dN_lcl, w.inv_rho, w.na_lcl);
+    FT dq_rai = (w.evq + w.au_dq_rai) + w.ac_dq_rai;
+    FT dn_rai = M::fma(((w.evN + w.au_dN_rai) + w.rsc) + w.rbr, w.inv_rho, w.na_rai);
+    FT dq_ice = FT(0), dn_ice = FT(0), dq_rim = FT(0), db_rim = FT(0);
+    // P3 state (F_rim, ρ_rim) — state_from_prognostic, P3_particle_properties.jl:101-106
+    P3Point<FT> s;
+    p3_make_point<FT>(c, q_ice * rho, n_ice * rho, q_rim * rho, b_rim * rho, s);
+    // ice saturation
+    const FT inv_T = FT(1) / T;
+    const FT ps_i = k.press_tr * P::exp(k.ps_pow * P::log(T * k.inv_T_tr) + k.ps_b * (k.inv_T_tr - inv_T));
+    const FT qsi = ps_i / (rho * k.R_v * T);
+    const FT q_vap = M::max(FT(0), (q_tot - (q_lcl + q_rai)) - q_ice);
+    // Frostenberg INPC per kg — INP_concentration_mean :250-253
+    const FT T_c = M::min(T - k.f23_T_freeze, FT(0));
+    const FT inpc_kg = P::exp(FT(9) * P::log(k.f23_b10 * T_c) - k.f23_log_a + shift) * inv_rho;
+    const FT n_active = n_ice;                                                    // NIceProxyDepletion :527
+    {   // deposition_rate :491-511
+        const bool cond = (T < k.T_dep) && (q_vap / qsi - FT(1) > k.S_thresh);
+        const FT rn = cond ? M::max(FT(0), inpc_kg - n_active) * k.inv_tau_act : FT(0);
+        const FT rq = M::min(k.m_nuc * rn, M::max(FT(0), q_vap - qsi) * (FT(0.5) * k.inv_tau_act));
+        dn_ice += rn; dq_ice += rq;
+    }
+    const FT J_bigg = k.rf_B * P::exp(k.rf_a * (k.T_freeze_tps - T));                // RainFreezing functor, parameters/IceNucleation.jl:146
+    {   // Bigg freezing of cloud drops (:355-389) capped by the F23 budget (immersion_limit_rate :425-435) — BMT:1013-1034
+        FT bn = FT(0), bq = FT(0);
+        if (n_lcl > eps && q_lcl > eps && T < k.T_bigg && !(N_lcl < eps)) {
+            const FT log_lam_c = -k.mu_c * (P::log(rho * q_lcl / N_lcl) + k.lg_z1 - k.lg_z2) + k.log_km_mu;
+            bn = J_bigg * k.V1 * (n_lcl * P::exp(k.k3 * log_lam_c) * k.G3);
+            bq = J_bigg * k.rho_w_V1sq * (n_lcl * P::exp(k.k6 * log_lam_c) * k.G6);
+        }
+        const FT cap = T >= k.f23_T_freeze ? FT(0) : M::max(FT(0), inpc_kg - n_active) * k.inv_tau_act;
+        const FT imm_n = M::min(bn, cap);
+        const FT imm_q = bn > FT(0) ? bq * imm_n / bn : FT(0);
+        dq_lcl -= imm_q; dn_lcl -= imm_n; dq_ice += imm_q; dn_ice += imm_n; dq_rim += imm_q; db_rim += imm_q * k.inv_rho_i;
+    }
+    {   // sublimation / deposition — BMT:1037-1054, _conv_q_vap_to_q_icl_const NonEq:168-193
+        const FT L_s = k.LH_s0 + k.dcp_s * (T - k.T_0);
+        const FT cp_air = k.cp_d + k.cpm_qt * q_tot + k.cpm_ql * (q_lcl + q_rai) + k.cpm_qi * q_ice;
+        const FT dqsi_dT = qsi * (L_s / (k.R_v * (T * T)) - inv_T);
+        const FT ts = k.tau_subdep * (FT(1) + (L_s / cp_air) * dqsi_dT);
+        const FT excess = q_vap - qsi;
+        FT sd = excess < FT(0) ? -M::min(-excess, q_ice) / ts : excess / ts;
+        if (T > k.T_freeze_tps && sd > FT(0)) sd = FT(0);                         // INP limiter :56-58 and BMT:1045
+        const FT n_per_q = q_ice > eps ? n_ice / q_ice : FT(0);
+        dq_ice += sd;
+        dn_ice += sd < FT(0) ? n_per_q * sd : FT(0);
+        const FT sub = M::min(sd, FT(0));
+        dq_rim += sub * s.F_rim;
+        db_rim += s.rho_rim > FT(0) ? sub * s.F_rim / s.rho_rim : FT(0);
+    }
+    {   // ice number adjustment — BMT:1057-1064 (τ = 100 s, x ∈ [1e-12, 1e-5] kg), number_tendency_from_mass_limits CM2:882-891
+        const FT target = q_ice < eps ? FT(0) : clampv(n_ice, q_ice * FT(1e5), q_ice * FT(1e12));
+        dn_ice += (target - n_ice) * FT(0.01);
+    }
+    {   // Bigg freezing of rain — liquid_freezing_rate :274-311, BMT:1067-1075
+        FT rn = FT(0), rq = FT(0);
+        if (n_rai > eps && q_rai > eps && T < k.T_bigg) {
+            const FT sq = q_rai, sN = M::max(N_rai, eps), L = rho * sq;
+            FT lam_r;
+            if constexpr (!LIMITED) lam_r = P::exp(P::log(k.pi_rho_w / (L / sN)) / FT(3));
+            else {
+                const FT xt = M::min(M::max(L / sN, k.xr_min), k.xr_max);
+                const FT N0 = M::min(M::max(sN * P::exp(P::log(k.pi_rho_w / xt) / FT(3)), k.N0_min), k.N0_max);
+                lam_r = M::min(M::max(M::sqrt(M::sqrt(k.pi_rho_w * N0 / L)), k.lam_min), k.lam_max);
+            }
+            FT Dr = FT(1) / lam_r;
+            if constexpr (!LIMITED) { if (N_rai < eps) Dr = FT(0); }                // gate of the not-limited PSD (CM2:83)
+            const FT D3 = Dr * Dr * Dr;
+            rn = J_bigg * k.V1 * (n_rai * FT(6) * D3);
+            rq = J_bigg * k.rho_w_V1sq * (n_rai * FT(720) * (D3 * D3));
+        }
+        dq_rai -= rq; dn_rai -= rn; dq_ice += rq; dn_ice += rn; dq_rim += rq; db_rim += rq * k.inv_rho_i;
+    }
+    io.out[0][i] = dq_lcl; io.out[1][i] = dn_lcl; io.out[2][i] = dq_rai; io.out[3][i] = dn_rai;
+    io.out[4][i] = dq_ice; io.out[5][i] = dn_ice; io.out[6][i] = dq_rim; io.out[7][i] = db_rim;
+}
+
+template <typename FT, typename WR, typename IP, typename TH>
+static int32_t mp2m_p3_entry(const WR *wr, const IP *ip, const TH *tps, uint32_t flags, int64_t n, const FT *rho, const FT *T, const FT *q_tot,
+                             const FT *q_lcl, const FT *n_lcl, const FT *q_rai, const FT *n_rai, const FT *q_ice, const FT *n_ice, const FT *q_rim,
+                             const FT *b_rim, const FT *loglam, const FT *shift, FT *const *out, void *stream) {
+    if (!wr || !ip || !tps || n < 0 || (flags & ~(CMX_P3_SLOPE_CONSTANT | CMX_P3_NO_ASPECT_RATIO | CMX_P3_RAIN_PDF_LIMITED))) return CMX_ERR_BAD_ARG;
+    if (ip->quad.n < 1 || ip->quad.n > CMX_QUAD_MAX) return CMX_ERR_BAD_ARG;
+    if (n == 0) return CMX_OK;
+    if (!rho || !T || !q_tot || !q_lcl || !n_lcl || !q_rai || !n_rai || !q_ice || !n_ice || !q_rim || !b_rim || !loglam || !out) return CMX_ERR_BAD_ARG;
+    for (int q = 0; q < 8; ++q) if (!out[q]) return CMX_ERR_BAD_ARG;
+    const bool limited = (flags & CMX_P3_RAIN_PDF_LIMITED) != 0;
+    using RV = std::conditional_t<std::is_same_v<FT, float>, cmx_rain_vel_f32, cmx_rain_vel_f64>;
+    const SbConsts<FT> sc = make_sb_consts<FT>(*wr, *tps, (const RV *)nullptr, (double)Math<FT>::eps_1m());
+    P3Consts<FT> c = make_p3_consts<FT>(ip->scheme, flags & CMX_P3_SLOPE_CONSTANT);
+    c.brent_iters = 0;
+    const PointwiseConsts<FT> pk = make_pointwise_consts<FT>(*wr, *ip, *tps);
+    FusedIO<FT> fio{rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice, n_ice, q_rim, b_rim, shift, {}};
+    for (int q = 0; q < 8; ++q) fio.out[q] = out[q];
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 block(kBlock), grid1((unsigned)((n + kBlock - 1) / kBlock));
+    if (limited) hipLaunchKernelGGL((mp2m_p3_pointwise_kernel<FT, true>), grid1, block, 0, st, sc, c, pk, fio, n);
+    else hipLaunchKernelGGL((mp2m_p3_pointwise_kernel<FT, false>), grid1, block, 0, st, sc, c, pk, fio, n);
+    CMX_HIP_TRY(hipGetLastError());
+    // ice processes
+    P3VelConsts<FT> v = make_p3_vel_consts<FT>(ip->scheme, ip->vel_ice, 1e-5);
+    v.p_lo = FT(0.00001); v.p_hi = FT(1) - v.p_lo;
+    const P3ColConsts<FT> k = make_p3col_consts<FT>(*ip, wr->air_properties, *tps, flags);
+    P3ColIO<FT> io{};
+    io.rho_a = rho; io.T = T; io.loglam = loglam;
+    io.q_lcl = q_lcl; io.n_lcl = n_lcl; io.q_rai = q_rai; io.n_rai = n_rai; io.q_ice = q_ice; io.n_ice = n_ice; io.q_rim = q_rim; io.b_rim = b_rim;
+    for (int q = 0; q < 8; ++q) io.out[q] = out[q];
+    using QUAD = std::remove_cv_t<std::remove_reference_t<decltype(ip->quad)>>;
+    const dim3 grid2((unsigned)((n + kPointsPerBlock - 1) / kPointsPerBlock));
+    const size_t lds = sizeof(FT) * (size_t)(2 * ip->quad.n + kPointsPerBlock * (6 * ip->quad.n + 72));
+    if (lds > 48 * 1024) {
+        CMX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&p3_collision_kernel<FT, QUAD, false, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CMX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&p3_collision_kernel<FT, QUAD, true, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (flags & CMX_P3_NO_ASPECT_RATIO)
+        hipLaunchKernelGGL((p3_collision_kernel<FT, QUAD, false, true>), grid2, block, lds, st, c, v, k, ip->quad, io, n);
+    else
+        hipLaunchKernelGGL((p3_collision_kernel<FT, QUAD, true, true>), grid2, block, lds, st, c, v, k, ip->quad, io, n);
     CMX_HIP_TRY(hipGetLastError());
     return CMX_OK;
 }
@@ -505,6 +807,23 @@ int32_t cmx_p3_liquid_ice_collisions_f64(const cmx_p3_ice_params_f64 *ice, const
                                          double *const *sources, double *const *rates, void *stream) {
     return cmx::p3_collision_entry<double>(ice, aps, tps, quad, flags, n, rho_q_ice, rho_n_ice, x3, x4, L_c, N_c, L_r, N_r, rho_air, T, log_lambda,
                                            sources, rates, stream);
+}
+
+int32_t cmx_microphysics_2m_p3_tendencies_f32(const cmx_warm_rain_2m_f32 *warm_rain, const cmx_p3_ice_params_f32 *ice, const cmx_thermo_f32 *tps,
+                                              uint32_t flags, int64_t n, const float *rho, const float *T, const float *q_tot, const float *q_lcl,
+                                              const float *n_lcl, const float *q_rai, const float *n_rai, const float *q_ice, const float *n_ice,
+                                              const float *q_rim, const float *b_rim, const float *log_lambda, const float *inpc_log_shift,
+                                              float *const *tendencies, void *stream) {
+    return cmx::mp2m_p3_entry<float>(warm_rain, ice, tps, flags, n, rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice, n_ice, q_rim, b_rim, log_lambda,
+                                     inpc_log_shift, tendencies, stream);
+}
+int32_t cmx_microphysics_2m_p3_tendencies_f64(const cmx_warm_rain_2m_f64 *warm_rain, const cmx_p3_ice_params_f64 *ice, const cmx_thermo_f64 *tps,
+                                              uint32_t flags, int64_t n, const double *rho, const double *T, const double *q_tot, const double *q_lcl,
+                                              const double *n_lcl, const double *q_rai, const double *n_rai, const double *q_ice, const double *n_ice,
+                                              const double *q_rim, const double *b_rim, const double *log_lambda, const double *inpc_log_shift,
+                                              double *const *tendencies, void *stream) {
+    return cmx::mp2m_p3_entry<double>(warm_rain, ice, tps, flags, n, rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice, n_ice, q_rim, b_rim, log_lambda,
+                                      inpc_log_shift, tendencies, stream);
 }
 
 }  // extern "C"

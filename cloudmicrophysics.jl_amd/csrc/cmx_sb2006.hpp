@@ -31,7 +31,7 @@ template <typename FT> struct SbConsts {
     // thermodynamics (Thermodynamics.jl restatement, see oracle/cmx_oracle_impl.h)
     FT T_0, LH_v0, dcp, R_v, inv_R_v;
     FT ps_c0, ps_a, ps_b, inv_T_tr;     // log2 p_sat = c0 + a·log2(T/T_tr) + b·(1/T_tr − 1/T)
-    FT cp_d, cpm_qt, cpm_ql;            // cp_m = cp_d + cpm_qt·q_tot + cpm_ql·q_liq
+    FT cp_d, cpm_qt, cpm_ql, cpm_qi;    // cp_m = cp_d + cpm_qt·q_tot + cpm_ql·q_liq [+ cpm_qi·q_ice]
     FT tau_ce;                          // CondEvap2M.τ_relax
     FT inv_K, Rv_over_D, eps_1m;        // G_func_liquid (Common.jl:47-63)
     // rain PSD (CM2:67-110)
@@ -80,6 +80,7 @@ inline SbConsts<FT> make_sb_consts(const WR &wr, const TH &tp, const VL *vel, do
     c.cp_d = (FT)tp.cp_d;
     c.cpm_qt = (FT)((double)tp.cp_v - (double)tp.cp_d);
     c.cpm_ql = (FT)((double)tp.cp_l - (double)tp.cp_v);
+    c.cpm_qi = (FT)((double)tp.cp_i - (double)tp.cp_v);
     c.tau_ce = (FT)wr.condevap_tau_relax;
     const double K_safe = std::fmax((double)wr.air_properties.K_therm, eps_1m);
     const double D_safe = std::fmax((double)wr.air_properties.D_vapor, eps_1m);
@@ -199,10 +200,11 @@ template <typename FT> struct SbRates {
 // `n_lcl`, `n_rai` are per-kg numbers (BMT), `N_*` = ρ n_* per m³ (CM2).  No input clamping here:
 // the fused entry clamps first (BMT:828-837), the per-process entry passes raw values like the
 // reference's KA wrapper does.
-template <typename FT, bool LIMITED, int VEL>
+// ICE: the 2M+P3 entry passes the ice content into the vapour budget and cp_m (BMT:942 → :731-744); the warm-only entry has q_ice ≡ 0.
+template <typename FT, bool LIMITED, int VEL, bool ICE = false>
 __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rho, FT T, FT q_tot,
                                                     FT q_lcl, FT q_rai, FT N_lcl, FT N_rai,
-                                                    FT n_lcl, FT n_rai) {
+                                                    FT n_lcl, FT n_rai, FT q_ice = FT(0)) {
     using M = Math<FT>;
     const FT eps = M::eps();  // ϵ_numerics_2M_M = ϵ_numerics_2M_N = eps(FT)  (Utilities.jl:325,332)
     SbRates<FT> r;
@@ -217,13 +219,15 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
     const FT l2_ps = M::fma(c.ps_a, M::log2(T * c.inv_T_tr), M::fma(c.ps_b, c.inv_T_tr - inv_T, c.ps_c0));
     const FT p_sat = M::exp2(l2_ps);                                         // TD.saturation_vapor_pressure
     const FT q_liq = q_lcl + q_rai;
-    const FT q_vap = M::max(FT(0), q_tot - q_liq);                           // TDI.q_vap (q_ice = q_sno = 0)
+    FT q_vap = M::max(FT(0), q_tot - q_liq);                                 // TDI.q_vap (q_ice = q_sno = 0)
+    if constexpr (ICE) q_vap = M::max(FT(0), (q_tot - q_liq) - q_ice);
     const FT rho_RvT = rho * (c.R_v * T);
     const FT inv_p_sat = M::rcp(p_sat);
     const FT q_sat = p_sat * M::rcp(rho_RvT);                                // TD.q_vap_saturation
     const FT LoRT = L_v * c.inv_R_v * inv_T;                                 // L/(R_v T)
     {   // _conv_q_vap_to_q_lcl_const  NonEq:117-140
-        const FT cp_air = M::fma(c.cpm_ql, q_liq, M::fma(c.cpm_qt, q_tot, c.cp_d));   // TD.cp_m
+        FT cp_air = M::fma(c.cpm_ql, q_liq, M::fma(c.cpm_qt, q_tot, c.cp_d));         // TD.cp_m
+        if constexpr (ICE) cp_air = M::fma(c.cpm_qi, q_ice, cp_air);
         const FT dqsl_dT = q_sat * (LoRT * inv_T - inv_T);                   // dqcld_dT NonEq:74-76
         const FT Gamma_l = M::fma(L_v * M::rcp(cp_air), dqsl_dT, FT(1));     // gamma_helper NonEq:88-90
         const FT excess = q_vap - q_sat;

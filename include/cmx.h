@@ -695,6 +695,30 @@ int32_t cmx_p3_liquid_ice_collisions_f64(const cmx_p3_ice_params_f64 *ice, const
                                          const double *L_r, const double *N_r, const double *rho_air, const double *T, const double *log_lambda,
                                          double *const *sources, double *const *rates, void *stream);
 
+/* (9) 2M + P3 fused entry: replaces, per point,
+ *   bulk_microphysics_tendencies(Microphysics2Moment(), mp::Microphysics2MParams{WR, P3IceParams}, tps, ρ, T, q_tot, q_lcl, n_lcl,
+ *                                q_rai, n_rai, q_ice, n_ice, q_rim, b_rim, logλ, inpc_log_shift)          BMT:898-1083
+ * i.e. warm rain with the ice content in the vapour budget (:942), liquid–ice collisions, aggregation and melting where
+ * q_ice > ϵ and n_ice > ϵ (:959-995), Frostenberg-2023 deposition nucleation (:1004-1010), F23-capped Bigg immersion freezing
+ * of cloud drops (:1013-1034), ice sublimation / deposition (:1037-1054), ice number adjustment (:1057-1064) and Bigg freezing
+ * of rain (:1067-1075).  log_lambda is an INPUT (the host model caches it, cmx_p3_shape_* produces it); inpc_log_shift may be
+ * NULL (= 0); the optional w, p arguments of the reference are unused by it (aerosol activation is not wired in, :729).
+ * tendencies[8] = device columns (dq_lcl_dt, dn_lcl_dt, dq_rai_dt, dn_rai_dt, dq_ice_dt, dn_ice_dt, dq_rim_dt, db_rim_dt), all
+ * required; the ninth field of the reference's NamedTuple, dn_lcl_activation_dt, is identically 0.
+ * flags: CMX_P3_RAIN_PDF_LIMITED (is_limited of both the SB2006 set and P3IceParams.rain_pdf), CMX_P3_SLOPE_CONSTANT,
+ * CMX_P3_NO_ASPECT_RATIO.  Two launches on `stream`: a pointwise kernel that writes the columns, then the 16-lanes-per-point
+ * quadrature kernel that adds the ice-process terms to them. */
+int32_t cmx_microphysics_2m_p3_tendencies_f32(const cmx_warm_rain_2m_f32 *warm_rain, const cmx_p3_ice_params_f32 *ice, const cmx_thermo_f32 *tps,
+                                              uint32_t flags, int64_t n, const float *rho, const float *T, const float *q_tot, const float *q_lcl,
+                                              const float *n_lcl, const float *q_rai, const float *n_rai, const float *q_ice, const float *n_ice,
+                                              const float *q_rim, const float *b_rim, const float *log_lambda, const float *inpc_log_shift,
+                                              float *const *tendencies, void *stream);
+int32_t cmx_microphysics_2m_p3_tendencies_f64(const cmx_warm_rain_2m_f64 *warm_rain, const cmx_p3_ice_params_f64 *ice, const cmx_thermo_f64 *tps,
+                                              uint32_t flags, int64_t n, const double *rho, const double *T, const double *q_tot, const double *q_lcl,
+                                              const double *n_lcl, const double *q_rai, const double *n_rai, const double *q_ice, const double *n_ice,
+                                              const double *q_rim, const double *b_rim, const double *log_lambda, const double *inpc_log_shift,
+                                              double *const *tendencies, void *stream);
+
 /* ---------------------------------------------------------------------------
  * (3) Optional diagnostic sums over one rank's shard: per-column
  * Σx (double accumulation) of `ncols` device columns of length n into

@@ -393,7 +393,9 @@ static inline void FN(o_bulk_tendencies_2m_p3)(const TY(cmx_warm_rain_2m) * wr, 
     FT sc[8] = {w.scale[0], w.scale[1], w.scale[2], w.scale[3], 0, 0, 0, 0};
     uint32_t p3flags = flags & (CMX_P3_SLOPE_CONSTANT | CMX_P3_NO_ASPECT_RATIO | CMX_P3_RAIN_PDF_LIMITED);
     const int gi_iters = sizeof(FT) == 4 ? 20 : 30;
-    if (q_ice > th->eps_m && n_ice > th->eps_n) {                                             /* BMT:959 */
+    /* BMT:959; the P3 integrals additionally need ρq, ρn ≥ eps (the gate of every cmx_p3_* entry: below it the size distribution
+     * is not defined and get_distribution_logλ returns −Inf) */
+    if (q_ice > th->eps_m && n_ice > th->eps_n && !(s.rho_n_ice < s.eps || s.rho_q_ice < s.eps)) {
         TY(cmxo_p3col) k;
         FT r[10], src[7];
         FN(o_p3col_setup)(&k, ip, aps, tps, p3flags, th, &s, L_lcl, N_lcl, L_rai, N_rai, rho, T, loglam);

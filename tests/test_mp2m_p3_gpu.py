@@ -1,0 +1,140 @@
+"""GPU parity tests of the 2M + P3 fused entry (cmx_microphysics_2m_p3_tendencies_*, BMT:898-1083) through the C ABI against the
+oracle: every one of the eight tendency columns over random mixed-phase states, Float64 and Float32; reduction to the warm-rain
+entry when no ice is present; the qualitative checks of the reference's own tests (test/bulk_tendencies_tests.jl:1280-1420).
+
+Tolerance: each tendency is a sum of process terms of both signs, so the comparison is |x − ref| ≤ RTOL·|ref| + CTOL·Σ|terms| with
+the oracle's Σ|terms| (the parity metric of tests/parity.py)."""
+import numpy as np
+import pytest
+import torch
+
+import parity
+from cmx import _abi
+from cmx import parameters as P
+
+pytestmark = pytest.mark.gpu
+DT = {"f32": torch.float32, "f64": torch.float64}
+NAMES = ("dq_lcl_dt", "dn_lcl_dt", "dq_rai_dt", "dn_rai_dt", "dq_ice_dt", "dn_ice_dt", "dq_rim_dt", "db_rim_dt")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _np64(t):
+    return t.cpu().numpy().astype(np.float64)
+
+
+def _states(n, seed=11, f32_safe=False):
+    """Mixed-phase states.  `f32_safe`: keep L_ice and B_rim out of the blending band of the reference's regularised ratios
+    (F_rim = L_rim/L_ice, ρ_rim = L_rim/B_rim are blended to 0 for denominators in (eps/4, 42 eps), Utilities.jl:445-488).  In
+    Float32 that band is 3e-8…5e-6 — where every realistic rime volume lies — and the blending weight (1 − a)^(…) with a ≈ 1e-7 is
+    not computable in Float32 arithmetic, the reference's included; Float32 parity is therefore checked on unrimed states and on
+    states with B_rim above the band."""
+    rng = np.random.default_rng(seed)
+    rho = rng.uniform(0.4, 1.3, n)
+    T = rng.uniform(215.0, 295.0, n)
+    q_lcl = np.where(rng.random(n) < 0.7, 10 ** rng.uniform(-6, -3, n), 0.0)
+    q_rai = np.where(rng.random(n) < 0.6, 10 ** rng.uniform(-7, -3, n), 0.0)
+    n_lcl = 10 ** rng.uniform(6, 9, n)
+    n_rai = 10 ** rng.uniform(1, 6, n)
+    q_ice = np.where(rng.random(n) < 0.8, 10 ** rng.uniform(-7, -3, n), 0.0)
+    n_ice = 10 ** rng.uniform(2, 6, n)
+    F = np.where(rng.random(n) < 0.3, 0.0, rng.uniform(0.05, 0.9, n))
+    q_rim = F * q_ice
+    b_rim = q_rim / rng.uniform(200, 800, n)
+    if f32_safe:
+        q_ice = np.where(rng.random(n) < 0.8, 10 ** rng.uniform(-4.5, -2.5, n), 0.0)
+        heavy = (rng.random(n) < 0.4) & (q_ice > 0)
+        q_ice = np.where(heavy, rng.uniform(1.5e-2, 3e-2, n), q_ice)
+        q_rim = np.where(heavy, rng.uniform(0.5, 0.9, n) * q_ice, 0.0)
+        b_rim = np.where(heavy, q_rim / rng.uniform(200, 400, n), 0.0)
+    q_tot = q_lcl + q_rai + q_ice + 10 ** rng.uniform(-5, -2, n)
+    neg = rng.random(n) < 0.01                       # a few slightly negative inputs: the clamps of BMT:912-921
+    q_rai = np.where(neg, -1e-9, q_rai)
+    return dict(rho=rho, T=T, q_tot=q_tot, q_lcl=q_lcl, n_lcl=n_lcl, q_rai=q_rai, n_rai=n_rai, q_ice=q_ice, n_ice=n_ice, q_rim=q_rim, b_rim=b_rim)
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+@pytest.mark.parametrize("limited", [True, False])
+def test_fused_entry_parity(dev, oracle, ft, limited):
+    import cmx
+    n = 3000
+    s = _states(n, f32_safe=(ft == "f32"))
+    cols = {k: torch.from_numpy(v).to(DT[ft]) for k, v in s.items()}
+    d = {k: v.to(dev) for k, v in cols.items()}
+    mp = P.Microphysics2MParams(ft, with_ice=True, is_limited=limited)
+    tps = P.ThermodynamicsParameters(ft)
+    ll = cmx.p3_shape(P.ParametersP3(ft), d["q_ice"] * d["rho"], d["n_ice"] * d["rho"], d["q_rim"] * d["rho"], d["b_rim"] * d["rho"],
+                      want=("log_lambda",), brent_iters=40).log_lambda
+    ll = torch.where(torch.isfinite(ll), ll, torch.zeros_like(ll))
+    shift = torch.from_numpy(np.random.default_rng(3).uniform(-1, 1, n)).to(DT[ft]).to(dev)
+    got = cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), mp, tps, *[d[k] for k in s], ll, shift)
+    torch.cuda.synchronize()
+    assert float(got.dn_lcl_activation_dt.abs().max()) == 0.0
+    mp64 = P.Microphysics2MParams("f64", with_ice=True, is_limited=limited)
+    c64 = [cols[k].numpy().astype(np.float64) for k in s]
+    ref, scale = oracle.microphysics_2m_p3_tendencies(_abi.F64, mp64.warm_rain.c, mp64.ice.c, P.ThermodynamicsParameters("f64"), mp64.ice.flags,
+                                                      *c64, _np64(ll), _np64(shift), float32_gates=(ft == "f32"), nthreads=8)
+    ok = np.ones(n, bool)
+    worst = {}
+    for q, k in enumerate(NAMES):
+        x = _np64(getattr(got, k))
+        assert np.all(np.isfinite(x)), k
+        tol = parity.RTOL[ft] * np.abs(ref[q]) + parity.CTOL[ft] * scale[q]
+        err = np.abs(x - ref[q]) / np.maximum(tol, 1e-300)
+        err[(x == 0) & (ref[q] == 0)] = 0
+        worst[k] = err[ok].max()
+        j = int(np.argmax(np.where(ok, err, 0)))
+        assert worst[k] <= 1.0, (k, j, x[j], ref[q][j], scale[q][j], {kk: s[kk][j] for kk in s})
+    print(f"\n[2M+P3 fused] {ft} limited={limited}: worst err/tol " + " ".join(f"{k}={v:.2f}" for k, v in worst.items()) + f" (compared {ok.mean():.1%})")
+    # every process family is exercised
+    ice = (s["q_ice"] > 0)
+    assert (ref[5][ice] != 0).all() and (ref[4][~ice & (s["T"] < 250)] >= 0).all()
+
+
+def test_reduces_to_warm_rain_without_ice_and_validates(dev):
+    import cmx
+    ft = "f64"
+    s = _states(2000, seed=2)
+    z = np.zeros_like(s["rho"])
+    s.update(q_ice=z, n_ice=z, q_rim=z, b_rim=z)
+    s["T"] = np.maximum(s["T"], 274.0)                      # above freezing: no Bigg freezing, no nucleation, no vapour deposition
+    d = {k: torch.from_numpy(v).to(dev) for k, v in s.items()}
+    mp = P.Microphysics2MParams(ft, with_ice=True)
+    tps = P.ThermodynamicsParameters(ft)
+    ll = torch.zeros_like(d["rho"])
+    got = cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), mp, tps, *[d[k] for k in s], ll)
+    warm = cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), P.Microphysics2MParams(ft), tps, *[d[k] for k in list(s)[:7]])
+    for k in NAMES[:4]:
+        assert torch.equal(getattr(got, k), getattr(warm, k)), k
+    for k in NAMES[4:]:
+        assert float(getattr(got, k).abs().max()) == 0.0, k
+    with pytest.raises(TypeError):
+        cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), mp, tps, *[d[k] for k in list(s)[:7]])
+    with pytest.raises(TypeError):
+        cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), P.Microphysics2MParams(ft), tps, *[d[k] for k in s], ll)
+
+
+def test_process_signs(dev):
+    """test/bulk_tendencies_tests.jl:1283-1420: melting above freezing moves ice to rain; collisions below freezing move liquid to
+    (rimed) ice; cold supersaturated air without ice nucleates ice."""
+    import cmx
+    ft = "f64"
+    mp = P.Microphysics2MParams(ft, with_ice=True)
+    tps = P.ThermodynamicsParameters(ft)
+    col = lambda v: torch.tensor(v, dtype=DT[ft], device=dev)  # noqa: E731
+    Tf = tps.T_freeze
+    rho = col([1.0, 1.0, 0.6]); T = col([Tf + 5, Tf - 10, Tf - 35])
+    q_lcl = col([0.0, 1e-3, 0.0]); n_lcl = col([0.0, 1e8, 0.0]); q_rai = col([0.0, 1e-4, 0.0]); n_rai = col([0.0, 1e4, 0.0])
+    q_ice = col([1e-3, 5e-4, 0.0]); n_ice = col([1e5, 1e5, 0.0]); q_rim = col([2e-4, 1e-4, 0.0]); b_rim = col([4e-7, 2e-7, 0.0])
+    q_tot = col([5e-3 + 1e-3, 2e-3 + 1.6e-3, 6e-4])
+    ll = cmx.p3_shape(P.ParametersP3(ft), q_ice * rho, n_ice * rho, q_rim * rho, b_rim * rho, want=("log_lambda",), brent_iters=40).log_lambda
+    ll = torch.where(torch.isfinite(ll), ll, torch.zeros_like(ll))
+    r = cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), mp, tps, rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice, n_ice, q_rim, b_rim, ll)
+    g = {k: _np64(getattr(r, k)) for k in NAMES}
+    assert g["dq_ice_dt"][0] < 0 and g["dq_rai_dt"][0] > 0 and g["dn_rai_dt"][0] > 0 and g["dq_rim_dt"][0] < 0        # melting
+    assert g["dq_lcl_dt"][1] < 0 and g["dq_rim_dt"][1] > 0 and g["dn_ice_dt"][1] != 0                                      # riming
+    assert g["dq_ice_dt"][2] > 0 and g["dn_ice_dt"][2] > 0 and g["dq_rim_dt"][2] == 0                                      # deposition nucleation
