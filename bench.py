@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=100_000_000, help="grid points per GPU")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--workload", choices=["sb2006", "icenuc", "mp1m", "mp1m_lin", "arg2000", "p3", "p3_selfcol"], default="sb2006")
+    ap.add_argument("--workload", choices=["sb2006", "icenuc", "mp1m", "mp1m_lin", "arg2000", "p3", "p3_selfcol", "mp2m_p3"], default="sb2006")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the bounded baseline sample")
     ap.add_argument("--diagnostics", action="store_true",
@@ -310,6 +310,52 @@ def setup_p3_selfcol(args, dev, dtype, rank):
     return cols + [rho_a], step, desc, cpu_run
 
 
+def setup_mp2m_p3(args, dev, dtype, rank):
+    """The 2M + P3 fused entry, bulk_microphysics_tendencies(::Microphysics2Moment, mp{WR, P3IceParams}, …) (BMT:898-1083), at the
+    default quadrature order 16 (P3IceParams, src/parameters/Microphysics2MParams.jl:73-80): mixed-phase states, log λ cached by
+    the host model (an input, as in the reference's signature)."""
+    import numpy as np
+    import torch
+
+    import cmx
+    from cmx import _abi
+    from cmx import parameters as P
+    n = args.points
+    rng = np.random.default_rng(1234 + rank)
+    rho = rng.uniform(0.4, 1.3, n); T = rng.uniform(215.0, 295.0, n)
+    q_lcl = np.where(rng.random(n) < 0.7, 10 ** rng.uniform(-6, -3, n), 0.0); n_lcl = 10 ** rng.uniform(6, 9, n)
+    q_rai = np.where(rng.random(n) < 0.6, 10 ** rng.uniform(-7, -3, n), 0.0); n_rai = 10 ** rng.uniform(1, 6, n)
+    q_ice = np.where(rng.random(n) < 0.8, 10 ** rng.uniform(-6, -3, n), 0.0); n_ice = 10 ** rng.uniform(2, 6, n)
+    q_rim = np.where(rng.random(n) < 0.3, 0.0, rng.uniform(0.05, 0.9, n)) * q_ice
+    b_rim = q_rim / rng.uniform(200, 800, n)
+    q_tot = q_lcl + q_rai + q_ice + 10 ** rng.uniform(-5, -2, n)
+    cols = [torch.from_numpy(c).to(dtype).to(dev) for c in (rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice, n_ice, q_rim, b_rim)]
+    mp, tps = P.Microphysics2MParams(args.dtype, with_ice=True), P.ThermodynamicsParameters(args.dtype)
+    ll = cmx.p3_shape(P.ParametersP3(args.dtype), cols[7] * cols[0], cols[8] * cols[0], cols[9] * cols[0], cols[10] * cols[0],
+                      want=("log_lambda",)).log_lambda
+    ll = torch.where(torch.isfinite(ll), ll, torch.zeros_like(ll))
+    holder = {}
+
+    def step():
+        holder["out"] = cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), mp, tps, *cols, ll)
+
+    def cpu_run(ob, c, threads):
+        fam = _abi.family(args.dtype)
+        return lambda: ob.microphysics_2m_p3_tendencies(fam, mp.warm_rain.c, mp.ice.c, tps, mp.ice.flags, *c, nthreads=threads)
+
+    step()
+    desc = {
+        "metric": "grid-points/sec 2M + P3 fused tendencies (warm rain + collisions + aggregation + melting + nucleation, GaussLegendre(16))",
+        "bytes_per_point": {"f32": 112, "f64": 224}[args.dtype],      # 12 in + 8 out (the second launch re-reads and re-writes the 8)
+        "kernel": "mp2m_p3_pointwise_kernel + p3_collision_kernel<FUSED>",
+        "workload": "bulk_microphysics_tendencies(Microphysics2Moment(), mp{WarmRain, P3IceParams}, …) — BMT:898-1083, quadrature_order 16",
+        "columns_in": 12, "columns_out": 8, "diag_cols": [],
+        "note": "FP64/FP32-vector compute-bound (liquid–ice collisions: 64 outer × (16 + 16 inner nodes + closed-form rain integral) "
+                "per state with ice); the HBM fraction is tiny by nature",
+    }
+    return cols + [ll], step, desc, cpu_run
+
+
 def cpu_baseline(args, cols_np, desc, cpu_run):
     """The oracle — a C restatement of the reference's scalar arithmetic (kind 'port'; the Julia reference cannot
     run here) — timed on the host cores over repeated passes of a bounded sample of the same synthetic workload."""
@@ -353,7 +399,7 @@ def main():
     n = args.points                                          # weak scaling: fixed work per GPU
     # rank r owns shard r of the global [0, world·n) index space: disjoint seeds, no exchange
     setup = {"sb2006": setup_sb2006, "icenuc": setup_icenuc, "mp1m": setup_mp1m, "mp1m_lin": setup_mp1m_lin, "arg2000": setup_arg2000,
-             "p3": setup_p3, "p3_selfcol": setup_p3_selfcol}[args.workload]
+             "p3": setup_p3, "p3_selfcol": setup_p3_selfcol, "mp2m_p3": setup_mp2m_p3}[args.workload]
     state, kernel_step, desc, cpu_run = setup(args, dev, dtype, rank)
 
     def step():
@@ -407,7 +453,7 @@ def main():
         if "note" in desc:
             line["roofline"]["note"] = desc["note"]
         if not args.no_cpu_baseline and world == 1:
-            m = min(n, {"sb2006": 20_000_000, "p3": 100_000, "p3_selfcol": 2_000}.get(args.workload, 4_000_000))
+            m = min(n, {"sb2006": 20_000_000, "p3": 100_000, "p3_selfcol": 2_000, "mp2m_p3": 20_000}.get(args.workload, 4_000_000))
             cols_np = [np.ascontiguousarray(c[:m].cpu().numpy()) for c in state]
             line["cpu_baseline"] = cpu_baseline(args, cols_np, desc, cpu_run)
         print(json.dumps(line), flush=True)

@@ -166,7 +166,7 @@ template <typename FT> struct ColLds {
 };
 
 template <typename FT, typename QUAD, bool ASPECT, bool FUSED>
-__global__ __launch_bounds__(kBlock) void p3_collision_kernel(const P3Consts<FT> c, const P3VelConsts<FT> v, const P3ColConsts<FT> k,
+__global__ __launch_bounds__(kBlock, 2) void p3_collision_kernel(const P3Consts<FT> c, const P3VelConsts<FT> v, const P3ColConsts<FT> k,
                                                              const QUAD quad, const P3ColIO<FT> io, const int64_t n) {
     using P = PM<FT>;
     using M = Math<FT>;
@@ -234,23 +234,24 @@ __global__ __launch_bounds__(kBlock) void p3_collision_kernel(const P3Consts<FT>
     const bool unrimed = s.F_rim == FT(0);
     const FT pi = FT(3.14159265358979323846), inv_pi = FT(0.3183098861837907);
     // ice fall speed (incl. aspect factor), collision radius and number density at diameter x — as in p3_self_collection_kernel
+    const typename P::Coefs kc = P::coefs();          // exp / log constants pinned in VGPRs for the node loops
     auto eval_ice = [&](FT x, FT &vv, FT &rr, FT &nn) {
-        const FT logD = P::log(x);
+        const FT logD = P::log(x, kc);
         const int reg = x < s.bnd[1] ? 0 : (unrimed ? 1 : (x < s.bnd[2] ? 1 : (x < s.bnd[3] ? 2 : 3)));
         const FT sph = v.pi_4 * x * x;
         FT area = sph, eA = FT(0);
         if (reg == 1 || reg == 3) {
-            const FT non = v.gamma_area * P::exp(v.sigma_area * logD);
+            const FT non = v.gamma_area * P::exp(v.sigma_area * logD, kc);
             area = reg == 1 ? non : s.F_rim * sph + (FT(1) - s.F_rim) * non;
-            if (ASPECT) eA = reg == 1 ? v.g0 + v.g1 * logD : h0 + h1 * logD - FT(0.5) * P::log(area);
+            if (ASPECT) eA = reg == 1 ? v.g0 + v.g1 * logD : h0 + h1 * logD - FT(0.5) * P::log(area, kc);
         }
         const bool small = x <= v.cutoff;
         const FT E1 = small ? se + sb * logD : le1 + v.l_b1 * logD;
         const FT dE = small ? -v.s_c2 * x : (le2 - le1) + (v.l_b2 - v.l_b1) * logD - v.l_c2 * x;
         const FT A1 = small ? v.s_E : v.l_a1, A2 = small ? v.s_F : v.l_a2;
-        vv = P::exp(eA + E1) * (A1 + A2 * P::exp(dE));
+        vv = P::exp(eA + E1, kc) * (A1 + A2 * P::exp(dE, kc));
         rr = M::sqrt(area * inv_pi);
-        nn = P::exp(logN0 + mu * logD - lam * x);
+        nn = P::exp(logN0 + mu * logD - lam * x, kc);
     };
     // rain Chen-2022 curve at ρₐ
     FT re[3], rb[3];
@@ -261,8 +262,8 @@ __global__ __launch_bounds__(kBlock) void p3_collision_kernel(const P3Consts<FT>
         re[2] += k.r_a3pow * lra;
     }
     auto v_liq = [&](FT D, FT logD) {
-        return k.r_a[0] * P::exp(re[0] + rb[0] * logD - k.r_c[0] * D) + k.r_a[1] * P::exp(re[1] + rb[1] * logD - k.r_c[1] * D) +
-               k.r_a[2] * P::exp(re[2] + rb[2] * logD - k.r_c[2] * D);
+        return k.r_a[0] * P::exp(re[0] + rb[0] * logD - k.r_c[0] * D, kc) + k.r_a[1] * P::exp(re[1] + rb[1] * logD - k.r_c[1] * D, kc) +
+               k.r_a[2] * P::exp(re[2] + rb[2] * logD - k.r_c[2] * D, kc);
     };
     // cloud PSD in diameter — log_pdf_cloud_parameters_mass CM2:172-188, pdf_cloud_parameters :227-236
     const FT inv_rho = FT(1) / rho_a;
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(kBlock) void p3_collision_kernel(const P3Consts<FT>
                     FT Dstar;
                     {
                         FT xa = r_lo, xb = r_hi;
-                        FT fa = v_liq(xa, P::log(xa)) - v_i, fb = v_liq(xb, P::log(xb)) - v_i;
+                        FT fa = v_liq(xa, P::log(xa, kc)) - v_i, fb = v_liq(xb, P::log(xb, kc)) - v_i;
                         if (!(fa * fb <= FT(0))) Dstar = P::abs(fa) <= P::abs(fb) ? xa : xb;
                         else {
                             if (P::abs(fa) < P::abs(fb)) { FT t = xa; xa = xb; xb = t; t = fa; fa = fb; fb = t; }
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(kBlock) void p3_collision_kernel(const P3Consts<FT>
                                     (!mflag && P::abs(sx - xb) >= P::abs(xc - xd) / FT(2))) {
                                     sx = (xa + xb) / FT(2); mflag = true;
                                 } else mflag = false;
-                                const FT fs = v_liq(sx, P::log(sx)) - v_i;
+                                const FT fs = v_liq(sx, P::log(sx, kc)) - v_i;
                                 xd = xc; xc = xb; fc = fb;
                                 if (fa * fs < FT(0)) { xb = sx; fb = fs; } else { xa = sx; fa = fs; }
                                 if (P::abs(fa) < P::abs(fb)) { FT t = xa; xa = xb; xb = t; t = fa; fa = fb; fb = t; }
