@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--points", type=int, default=100_000_000, help="grid points per GPU")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--workload", choices=["sb2006", "icenuc", "mp1m", "mp1m_lin", "arg2000", "p3", "p3_selfcol", "mp2m_p3"], default="sb2006")
+    ap.add_argument("--workload", choices=["sb2006", "icenuc", "mp1m", "mp1m_lin", "arg2000", "p3", "p3_selfcol", "mp2m_p3", "sb2006_aos", "sb2006_fields"], default="sb2006")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the bounded baseline sample")
     ap.add_argument("--diagnostics", action="store_true",
@@ -106,6 +106,58 @@ def setup_sb2006(args, dev, dtype, rank):
         "columns_in": 7, "columns_out": 6, "diag_cols": list(out[:4]),
     }
     return list(state), step, desc, cpu_run
+
+
+def setup_sb2006_layout(args, dev, dtype, rank):
+    """The north-star tendencies behind the host model's layouts: `sb2006_aos` writes the reference's own result type —
+    an array of 8-field NamedTuples, 4 fields identically zero (test/gpu_performance.jl:212-216); `sb2006_fields` reads and writes
+    components of ClimaCore VIJFH fields in place (state field with 9 components, tendency field with 5; runs of Nv·Ni·Nj = 74·16)."""
+    import torch
+
+    import cmx
+    from cmx import _abi
+    from cmx import parameters as P
+    from cmx import synthetic
+    mp, tps = P.Microphysics2MParams(args.dtype), P.ThermodynamicsParameters(args.dtype)
+    scheme = cmx.Microphysics2Moment()
+    aos = args.workload == "sb2006_aos"
+    S = 74 * 16
+    n = args.points if aos else (args.points // S) * S
+    state = synthetic.sb2006_state(n, dtype=dtype, device=dev, seed=1234 + rank)
+    holder = {}
+    if aos:
+        cols = list(state)
+
+        def step():
+            holder["out"] = cmx.bulk_microphysics_tendencies_fields(scheme, mp, tps, *cols, aos=True)
+    else:
+        Nh = n // S
+        Y = torch.empty((Nh, 9, S), dtype=dtype, device=dev)
+        for f, c in enumerate(state):
+            Y[:, f + 1, :] = c.reshape(Nh, S)
+        Yt = torch.empty((Nh, 5, S), dtype=dtype, device=dev)
+        cols = [Y[:, f + 1, :] for f in range(7)]
+        outs = [Yt[:, k, :] for k in range(4)]
+
+        def step():
+            cmx.bulk_microphysics_tendencies_fields(scheme, mp, tps, *cols, out=outs)
+
+    def cpu_run(ob, c, threads):
+        fam = _abi.family(args.dtype)
+        wr, t = P.WarmRainParams2M(args.dtype).c, P.ThermodynamicsParameters(args.dtype)
+        return lambda: ob.sb2006_warm_rain_tendencies(fam, wr, t, None, _abi.CMX_SB2006_LIMITED, *c, nthreads=threads, want_scale=False)
+
+    args.points = n
+    desc = {
+        "metric": "grid-points/sec SB2006 2M tendency sweep, " + ("array-of-NamedTuples output" if aos else "ClimaCore VIJFH fields in place"),
+        "bytes_per_point": ({"f32": 60, "f64": 120} if aos else {"f32": 44, "f64": 88})[args.dtype],     # 7 in + 8 (AoS) / 4 out
+        "kernel": "sb2006_tendencies_layout_kernel",
+        "workload": "Microphysics2M SB2006 fused warm-rain tendencies, limited rain PSD, " +
+                    ("result written as Vector{NamedTuple} (8 fields, 4 zero) through an LDS transpose" if aos else
+                     "7 components of a 9-component VIJFH state field → 4 components of a 5-component tendency field"),
+        "columns_in": 7, "columns_out": 8 if aos else 4, "diag_cols": [],
+    }
+    return [c.contiguous() for c in state], step, desc, cpu_run
 
 
 def setup_icenuc(args, dev, dtype, rank):
@@ -399,8 +451,9 @@ def main():
     n = args.points                                          # weak scaling: fixed work per GPU
     # rank r owns shard r of the global [0, world·n) index space: disjoint seeds, no exchange
     setup = {"sb2006": setup_sb2006, "icenuc": setup_icenuc, "mp1m": setup_mp1m, "mp1m_lin": setup_mp1m_lin, "arg2000": setup_arg2000,
-             "p3": setup_p3, "p3_selfcol": setup_p3_selfcol, "mp2m_p3": setup_mp2m_p3}[args.workload]
+             "p3": setup_p3, "p3_selfcol": setup_p3_selfcol, "mp2m_p3": setup_mp2m_p3, "sb2006_aos": setup_sb2006_layout, "sb2006_fields": setup_sb2006_layout}[args.workload]
     state, kernel_step, desc, cpu_run = setup(args, dev, dtype, rank)
+    n = args.points                                          # a layout workload may round the size to whole field runs
 
     def step():
         kernel_step()
@@ -453,7 +506,7 @@ def main():
         if "note" in desc:
             line["roofline"]["note"] = desc["note"]
         if not args.no_cpu_baseline and world == 1:
-            m = min(n, {"sb2006": 20_000_000, "p3": 100_000, "p3_selfcol": 2_000, "mp2m_p3": 20_000}.get(args.workload, 4_000_000))
+            m = min(n, {"sb2006": 20_000_000, "sb2006_aos": 20_000_000, "sb2006_fields": 20_000_000, "p3": 100_000, "p3_selfcol": 2_000, "mp2m_p3": 20_000}.get(args.workload, 4_000_000))
             cols_np = [np.ascontiguousarray(c[:m].cpu().numpy()) for c in state]
             line["cpu_baseline"] = cpu_baseline(args, cols_np, desc, cpu_run)
         print(json.dumps(line), flush=True)

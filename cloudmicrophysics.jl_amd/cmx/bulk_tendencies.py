@@ -166,6 +166,78 @@ def bulk_microphysics_tendencies(scheme, mp, tps, rho, T, q_tot, q_lcl, n_lcl, q
     return out
 
 
+AOS_FIELDS = ("dq_lcl_dt", "dn_lcl_dt", "dq_rai_dt", "dn_rai_dt", "dq_ice_dt", "dq_rim_dt", "db_rim_dt", "dn_lcl_activation_dt")
+
+
+def _segments(t: torch.Tensor, name: str):
+    """(n_seg, seg_len, stride) of a column given as a 1-D contiguous tensor or a 2-D (n_seg, seg_len) view whose rows are
+    contiguous — e.g. `parent(field)[h, f, :]` of a ClimaCore VIJFH array seen from C order as (Nh, Nf, Nv·Ni·Nj)."""
+    if t.dim() == 1 and t.stride(0) == 1:
+        return 1, t.numel(), 0
+    if t.dim() == 2 and (t.stride(1) == 1 or t.shape[1] == 1) and t.stride(0) >= t.shape[1]:
+        return t.shape[0], t.shape[1], t.stride(0)
+    raise TypeError(f"{name}: expected a contiguous 1-D column or a (n_seg, seg_len) view with contiguous rows")
+
+
+def bulk_microphysics_tendencies_fields(scheme, mp, tps, rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, *, out=None, aos=False, stream=None):
+    """The 2-moment warm-rain tendencies (BMT:820-854) on the host model's own storage — zero-copy layout adapters of
+    `cmx_sb2006_warm_rain_tendencies_fields_*`:
+
+    * inputs: each column is a contiguous 1-D tensor or a 2-D strided view (n_seg, seg_len) with contiguous rows — a component of a
+      ClimaCore `VIJFH` field in place (every column may have its own row stride, all share the shape);
+    * `aos=False`: the four tendencies go into `out` (4 tensors of the same shape, e.g. components of the tendency field; allocated
+      contiguous if None) → `WarmRainTendencies2M` without velocities;
+    * `aos=True`: returns the reference's result layout, an (n, 8) tensor whose rows are the NamedTuple
+      (dq_lcl_dt, dn_lcl_dt, dq_rai_dt, dn_rai_dt, dq_ice_dt, dq_rim_dt, db_rim_dt, dn_lcl_activation_dt) — `AOS_FIELDS`.
+
+    The values are bit-identical to `bulk_microphysics_tendencies` on the same points."""
+    if not isinstance(scheme, Microphysics2Moment):
+        raise TypeError("only Microphysics2Moment() is on this path")
+    wr = _warm_rain(mp)
+    cols = (rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai)
+    names = ("rho", "T", "q_tot", "q_lcl", "n_lcl", "q_rai", "n_rai")
+    ref = cols[0]
+    fam = _fam_of(ref)
+    if fam is not wr.fam or not isinstance(tps, fam.thermo):
+        raise TypeError("parameter float type does not match the state columns")
+    n_seg, seg_len, _ = _segments(ref, "rho")
+    strides = []
+    for c, nm in zip(cols, names):
+        if not c.is_cuda or c.device != ref.device or c.dtype != ref.dtype:
+            raise TypeError(f"{nm}: all columns must live on the same GPU with the same dtype")
+        ns, sl, st = _segments(c, nm)
+        if (ns, sl) != (n_seg, seg_len):
+            raise ValueError(f"{nm}: shape differs from rho")
+        strides.append(st)
+    n = n_seg * seg_len
+    in_p = (C.c_void_p * 7)(*[c.data_ptr() for c in cols])
+    in_s = (C.c_int64 * 7)(*strides)
+    out_p = out_s = aos_t = None
+    if aos:
+        if out is not None:
+            raise TypeError("out is the SoA form; aos=True allocates the (n, 8) result")
+        aos_t = torch.empty((n, 8), dtype=ref.dtype, device=ref.device)
+    else:
+        if out is None:
+            out = [torch.empty(ref.shape, dtype=ref.dtype, device=ref.device) for _ in range(4)]
+        ostr = []
+        for o in out:
+            ns, sl, st = _segments(o, "out")
+            if (ns, sl) != (n_seg, seg_len) or o.dtype != ref.dtype or o.device != ref.device:
+                raise ValueError("out: shape / dtype / device differs from rho")
+            ostr.append(st)
+        out_p = (C.c_void_p * 4)(*[o.data_ptr() for o in out])
+        out_s = (C.c_int64 * 4)(*ostr)
+    flags = _abi.CMX_SB2006_LIMITED if wr.is_limited else 0
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_sb2006_warm_rain_tendencies_fields_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(wr.c), C.byref(tps), flags, n_seg, seg_len, in_p, in_s, out_p, out_s, C.c_void_p(aos_t.data_ptr()) if aos else None,
+                C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return aos_t if aos else WarmRainTendencies2M(*out, None, None)
+
+
 def sb2006_process_rates(mp, tps, q_tot, q_lcl, q_rai, N_lcl, N_rai, rho, T, *, vel=SB2006VelType, stream=None):
     """The individual SB2006 process rates over columns — the reference's SB2006_2M_kernel
     (test/gpu_tests.jl:220-235) + cond/evap (NonEq:117-140).  N_* are per m³ (CM2 convention)."""

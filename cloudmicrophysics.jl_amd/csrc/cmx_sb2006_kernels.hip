@@ -89,6 +89,58 @@ static int32_t tendencies_entry(const WR *wr, const TH *tps, const VL *vel, uint
     return CMX_OK;
 }
 
+// cmx_sb2006_warm_rain_tendencies_fields_*: segmented (ClimaCore field) columns in, segmented columns or the reference's
+// array-of-NamedTuples out — see sb2006_tendencies_layout_kernel
+template <typename FT, typename WR, typename TH>
+static int32_t fields_entry(const WR *wr, const TH *tps, uint32_t flags, int64_t n_seg, int64_t seg_len, const FT *const *in,
+                            const int64_t *in_stride, FT *const *out, const int64_t *out_stride, FT *aos, void *stream) {
+    if (!wr || !tps || n_seg < 0 || seg_len < 0 || !in || (flags & ~(uint32_t)CMX_SB2006_LIMITED)) return CMX_ERR_BAD_ARG;
+    if ((out != nullptr) == (aos != nullptr)) return CMX_ERR_BAD_ARG;                // exactly one output form
+    const int64_t n = n_seg * seg_len;
+    if (n == 0) return CMX_OK;
+    if (n_seg > 1 && (!in_stride || (out && !out_stride))) return CMX_ERR_BAD_ARG;
+    constexpr int VEC = Math<FT>::VEC;
+    bool vec_ok = seg_len % VEC == 0;
+    SbLayoutIO<FT> io{};
+    for (int k = 0; k < 7; ++k) {
+        if (!in[k]) return CMX_ERR_BAD_ARG;
+        io.in[k] = in[k]; io.in_stride[k] = n_seg > 1 ? in_stride[k] : 0;
+        if (n_seg > 1 && io.in_stride[k] < seg_len) return CMX_ERR_BAD_ARG;
+        vec_ok = vec_ok && aligned16(in[k]) && io.in_stride[k] % VEC == 0;
+    }
+    for (int k = 0; k < 4 && out; ++k) {
+        if (!out[k]) return CMX_ERR_BAD_ARG;
+        io.out[k] = out[k]; io.out_stride[k] = n_seg > 1 ? out_stride[k] : 0;
+        if (n_seg > 1 && io.out_stride[k] < seg_len) return CMX_ERR_BAD_ARG;
+        vec_ok = vec_ok && aligned16(out[k]) && io.out_stride[k] % VEC == 0;
+    }
+    if (aos && !aligned16(aos)) return CMX_ERR_BAD_ARG;                               // rows are 8 FT = 32 / 64 B
+    io.aos = aos; io.seg_len = seg_len; io.inv_seg_len = 1.0 / (double)seg_len;
+    const bool limited = flags & CMX_SB2006_LIMITED, seg = n_seg > 1;
+    const SbConsts<FT> c = make_sb_consts<FT>(*wr, *tps, (const std::conditional_t<std::is_same_v<FT, float>, cmx_rain_vel_f32, cmx_rain_vel_f64> *)nullptr,
+                                              (double)Math<FT>::eps_1m());
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    auto launch = [&](auto vec_tag) {
+        constexpr int V = decltype(vec_tag)::value;
+        const int64_t nvec = n / V;
+        const dim3 grid((unsigned)((nvec + kBlock - 1) / kBlock)), block(kBlock);
+        const size_t lds = aos ? sizeof(FT) * (size_t)kBlock * (V * 8 + 16 / sizeof(FT)) : 0;
+#define CMX_LAUNCH(L, S, A) hipLaunchKernelGGL((sb2006_tendencies_layout_kernel<FT, L, V, S, A>), grid, block, lds, s, c, io, nvec)
+        if (limited) {
+            if (seg) { if (aos) CMX_LAUNCH(true, true, true); else CMX_LAUNCH(true, true, false); }
+            else     { if (aos) CMX_LAUNCH(true, false, true); else CMX_LAUNCH(true, false, false); }
+        } else {
+            if (seg) { if (aos) CMX_LAUNCH(false, true, true); else CMX_LAUNCH(false, true, false); }
+            else     { if (aos) CMX_LAUNCH(false, false, true); else CMX_LAUNCH(false, false, false); }
+        }
+#undef CMX_LAUNCH
+    };
+    if (vec_ok) launch(std::integral_constant<int, VEC>{});
+    else launch(std::integral_constant<int, 1>{});
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+
 template <typename FT, typename WR, typename TH, typename VL>
 static int32_t process_entry(const WR *wr, const TH *tps, const VL *vel, uint32_t flags, int64_t n, const FT *q_tot,
                              const FT *q_lcl, const FT *q_rai, const FT *N_lcl, const FT *N_rai, const FT *rho,
@@ -321,6 +373,17 @@ int32_t cmx_sb2006_process_rates_f64(const cmx_warm_rain_2m_f64 *warm_rain, cons
                                      double *const out[CMX_SB2006_NPROC], void *stream) {
     return cmx::process_entry<double>(warm_rain, tps, vel, flags, n, q_tot, q_lcl, q_rai, N_lcl, N_rai, rho, T, out,
                                       stream);
+}
+
+int32_t cmx_sb2006_warm_rain_tendencies_fields_f32(const cmx_warm_rain_2m_f32 *warm_rain, const cmx_thermo_f32 *tps, uint32_t flags, int64_t n_seg,
+                                                   int64_t seg_len, const float *const *in, const int64_t *in_seg_stride, float *const *out,
+                                                   const int64_t *out_seg_stride, float *out_aos, void *stream) {
+    return cmx::fields_entry<float>(warm_rain, tps, flags, n_seg, seg_len, in, in_seg_stride, out, out_seg_stride, out_aos, stream);
+}
+int32_t cmx_sb2006_warm_rain_tendencies_fields_f64(const cmx_warm_rain_2m_f64 *warm_rain, const cmx_thermo_f64 *tps, uint32_t flags, int64_t n_seg,
+                                                   int64_t seg_len, const double *const *in, const int64_t *in_seg_stride, double *const *out,
+                                                   const int64_t *out_seg_stride, double *out_aos, void *stream) {
+    return cmx::fields_entry<double>(warm_rain, tps, flags, n_seg, seg_len, in, in_seg_stride, out, out_seg_stride, out_aos, stream);
 }
 
 }  // extern "C"

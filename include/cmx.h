@@ -326,6 +326,25 @@ int32_t cmx_sb2006_warm_rain_tendencies_f64(
     double *dq_lcl_dt, double *dn_lcl_dt, double *dq_rai_dt, double *dn_rai_dt,
     double *vt_rai_n, double *vt_rai_m, void *stream);
 
+/* (1b) The same tendencies behind the host model's own data layouts.
+ * Input: 7 SEGMENTED columns in[k] (k = rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai): n_seg runs of seg_len contiguous
+ * elements, run s of column k starting at in[k] + s·in_seg_stride[k] (elements).  That is a ClimaCore field in place: a
+ * DataLayouts.VIJFH array (Nv, Ni, Nj, Nf, Nh) stores component f of element h as one run of Nv·Ni·Nj elements, i.e.
+ * in[k] = pointer(parent(field)) + f·Nv·Ni·Nj, seg_len = Nv·Ni·Nj, stride = Nv·Ni·Nj·Nf, n_seg = Nh
+ * (test/gpu_clima_core_test.jl:16-30,100-114); VF columns and VIJHF fields are the single-run case n_seg = 1 (strides may be NULL).
+ * Output, exactly one of:
+ *   out[4] + out_seg_stride[4]: dq_lcl_dt, dn_lcl_dt, dq_rai_dt, dn_rai_dt as segmented columns (each with its own stride);
+ *   out_aos: n_seg·seg_len rows of 8 FT — the reference's result type, Vector{@NamedTuple{dq_lcl_dt, dn_lcl_dt, dq_rai_dt,
+ *            dn_rai_dt, dq_ice_dt, dq_rim_dt, db_rim_dt, dn_lcl_activation_dt}} (BMT:852-853, test/gpu_performance.jl:212-216;
+ *            the last four are 0), 16-byte aligned.
+ * Values are bit-identical to cmx_sb2006_warm_rain_tendencies_* on the same points.  flags: CMX_SB2006_LIMITED. */
+int32_t cmx_sb2006_warm_rain_tendencies_fields_f32(const cmx_warm_rain_2m_f32 *warm_rain, const cmx_thermo_f32 *tps, uint32_t flags, int64_t n_seg,
+                                                   int64_t seg_len, const float *const *in, const int64_t *in_seg_stride, float *const *out,
+                                                   const int64_t *out_seg_stride, float *out_aos, void *stream);
+int32_t cmx_sb2006_warm_rain_tendencies_fields_f64(const cmx_warm_rain_2m_f64 *warm_rain, const cmx_thermo_f64 *tps, uint32_t flags, int64_t n_seg,
+                                                   int64_t seg_len, const double *const *in, const int64_t *in_seg_stride, double *const *out,
+                                                   const int64_t *out_seg_stride, double *out_aos, void *stream);
+
 /* ---------------------------------------------------------------------------
  * (2) SB2006 per-process rates ("verbose" variant of the same kernel).
  *

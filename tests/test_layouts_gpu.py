@@ -1,0 +1,90 @@
+"""GPU tests of the layout adapters (cmx_sb2006_warm_rain_tendencies_fields_*): ClimaCore field storage in, ClimaCore
+field storage or the reference's array of NamedTuples out.  The adapters run the same per-point instruction sequence as the SoA
+entry, so every comparison is BIT-exact against `bulk_microphysics_tendencies` on the gathered points."""
+import numpy as np
+import pytest
+import torch
+
+from cmx import parameters as P
+
+pytestmark = pytest.mark.gpu
+DT = {"f32": torch.float32, "f64": torch.float64}
+NAMES = ("rho", "T", "q_tot", "q_lcl", "n_lcl", "q_rai", "n_rai")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _state_field(Nh, Nf, S, ft, dev, seed=5):
+    """A ClimaCore VIJFH array (Nv, Ni, Nj, Nf, Nh) seen from C order: (Nh, Nf, S = Nv·Ni·Nj).  Components 0..6 hold the state."""
+    from cmx import synthetic
+    st = synthetic.sb2006_state(Nh * S, dtype=DT[ft], seed=seed)
+    Y = torch.full((Nh, Nf, S), float("nan"), dtype=DT[ft])
+    for f, k in enumerate(NAMES):
+        Y[:, f, :] = getattr(st, k).reshape(Nh, S)
+    return Y.to(dev)
+
+
+@pytest.mark.parametrize("ft", ["f32", "f64"])
+@pytest.mark.parametrize("shape", [(24, 9, 74 * 16), (7, 8, 63 * 9 + 1), (1, 7, 4096), (5, 7, 1)])   # RCEMIP box, odd run length, single run
+def test_vijfh_fields_in_and_out(dev, ft, shape):
+    import cmx
+    Nh, Nf, S = shape
+    Y = _state_field(Nh, Nf, S, ft, dev)
+    mp, tps = P.Microphysics2MParams(ft), P.ThermodynamicsParameters(ft)
+    cols = [Y[:, f, :] for f in range(7)]                                    # strided views, no copy
+    assert Nf == 7 and Nh == 1 or not cols[0].is_contiguous() or Nh == 1
+    ref = cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), mp, tps, *[c.contiguous().reshape(-1) for c in cols])
+    # tendency field with its own number of components (Nf_out = 5, tendencies in components 1..4)
+    Yt = torch.full((Nh, 5, S), float("nan"), dtype=DT[ft], device=dev)
+    got = cmx.bulk_microphysics_tendencies_fields(cmx.Microphysics2Moment(), mp, tps, *cols, out=[Yt[:, k, :] for k in (1, 2, 3, 4)])
+    torch.cuda.synchronize()
+    for k, name in enumerate(("dq_lcl_dt", "dn_lcl_dt", "dq_rai_dt", "dn_rai_dt")):
+        assert torch.equal(Yt[:, k + 1, :].reshape(-1), getattr(ref, name)), name
+        assert getattr(got, name).data_ptr() == Yt[:, k + 1, :].data_ptr()
+    assert torch.isnan(Yt[:, 0, :]).all()                                     # nothing written outside the four components
+    # array-of-NamedTuples result from the same strided inputs
+    aos = cmx.bulk_microphysics_tendencies_fields(cmx.Microphysics2Moment(), mp, tps, *cols, aos=True)
+    assert aos.shape == (Nh * S, 8)
+    for k, name in enumerate(("dq_lcl_dt", "dn_lcl_dt", "dq_rai_dt", "dn_rai_dt")):
+        assert torch.equal(aos[:, k], getattr(ref, name)), name
+    assert float(aos[:, 4:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("ft", ["f32", "f64"])
+@pytest.mark.parametrize("limited", [True, False])
+def test_aos_from_contiguous_columns_ragged_sizes(dev, ft, limited):
+    import cmx
+    from cmx import synthetic
+    mp, tps = P.Microphysics2MParams(ft, is_limited=limited), P.ThermodynamicsParameters(ft)
+    for n in (1, 3, 255, 1024, 1027, 50_001):
+        st = synthetic.sb2006_state(n, dtype=DT[ft], device=dev, seed=n)
+        ref = cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), mp, tps, *st)
+        aos = cmx.bulk_microphysics_tendencies_fields(cmx.Microphysics2Moment(), mp, tps, *st, aos=True)
+        for k, name in enumerate(("dq_lcl_dt", "dn_lcl_dt", "dq_rai_dt", "dn_rai_dt")):
+            assert torch.equal(aos[:, k], getattr(ref, name)), (n, name)
+        assert float(aos[:, 4:].abs().max()) == 0.0
+        # misaligned columns (an odd slice) take the one-point-per-lane variant: same bits
+        if n > 3:
+            sl = [c[1:] for c in st]
+            a2 = cmx.bulk_microphysics_tendencies_fields(cmx.Microphysics2Moment(), mp, tps, *sl, aos=True)
+            assert torch.equal(a2, aos[1:])
+
+
+def test_large_aos_and_validation(dev):
+    import cmx
+    from cmx import synthetic
+    ft = "f32"
+    mp, tps = P.Microphysics2MParams(ft), P.ThermodynamicsParameters(ft)
+    n = 20_000_000
+    st = synthetic.sb2006_state(n, dtype=DT[ft], device=dev, seed=9)
+    ref = cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), mp, tps, *st)
+    aos = cmx.bulk_microphysics_tendencies_fields(cmx.Microphysics2Moment(), mp, tps, *st, aos=True)
+    assert torch.equal(aos[:, 0], ref.dq_lcl_dt) and torch.equal(aos[:, 3], ref.dn_rai_dt) and float(aos[:, 4:].abs().max()) == 0.0
+    with pytest.raises(TypeError):
+        cmx.bulk_microphysics_tendencies_fields(cmx.Microphysics2Moment(), mp, tps, *[c[::2] for c in st], aos=True)       # element stride 2
+    with pytest.raises(ValueError):
+        cmx.bulk_microphysics_tendencies_fields(cmx.Microphysics2Moment(), mp, tps, st[0][:10], *st[1:], aos=True)
