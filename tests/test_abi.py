@@ -79,6 +79,18 @@ def test_argument_validation_without_gpu():
     assert f(C.byref(wr.c), C.byref(tps), None, 1, -1, *null, None) == _abi.CMX_ERR_BAD_ARG
     assert f(C.byref(wr.c), C.byref(tps), None, 1, 10, *null, None) == _abi.CMX_ERR_BAD_ARG   # null columns
     assert f(C.byref(wr.c), C.byref(tps), None, 1, 0, *null, None) == _abi.CMX_OK            # empty input
+    # layout adapters: exactly one output form, strides required for more than one run, runs must not overlap
+    h = lib.cmx_sb2006_warm_rain_tendencies_fields_f32
+    ins = (C.c_void_p * 7)(*[16 * (k + 1) for k in range(7)])
+    outs = (C.c_void_p * 4)(*[1600 + 16 * k for k in range(4)])
+    st7, st4 = (C.c_int64 * 7)(*[8] * 7), (C.c_int64 * 4)(*[8] * 4)
+    assert h(C.byref(wr.c), C.byref(tps), 1, 0, 8, ins, st7, outs, st4, None, None) == _abi.CMX_OK                  # no runs
+    assert h(C.byref(wr.c), C.byref(tps), 1, 2, 8, ins, st7, None, None, None, None) == _abi.CMX_ERR_BAD_ARG       # no output
+    assert h(C.byref(wr.c), C.byref(tps), 1, 2, 8, ins, st7, outs, st4, C.c_void_p(4096), None) == _abi.CMX_ERR_BAD_ARG   # both outputs
+    assert h(C.byref(wr.c), C.byref(tps), 1, 2, 8, ins, None, outs, st4, None, None) == _abi.CMX_ERR_BAD_ARG       # strides missing
+    assert h(C.byref(wr.c), C.byref(tps), 1, 2, 16, ins, st7, outs, st4, None, None) == _abi.CMX_ERR_BAD_ARG      # stride < run length
+    assert h(C.byref(wr.c), C.byref(tps), 1, 1, 8, ins, None, None, None, C.c_void_p(4100), None) == _abi.CMX_ERR_BAD_ARG   # AoS misaligned
+    assert h(C.byref(wr.c), C.byref(tps), 4, 1, 8, ins, None, outs, None, None, None) == _abi.CMX_ERR_BAD_ARG      # unknown flag
     g = lib.cmx_column_sums_f64
     assert g(-1, None, 0, None, None) == _abi.CMX_ERR_BAD_ARG
     assert g(0, None, 0, None, None) == _abi.CMX_OK
