@@ -663,7 +663,7 @@ __global__ __launch_bounds__(kBlock) void mp2m_p3_pointwise_kernel(const SbConst
     const FT shift = io.shift ? io.shift[i] : FT(0);
     const FT N_lcl = rho * n_lcl, N_rai = rho * n_rai, inv_rho = FT(1) / rho;
     // warm rain — BMT:942 → warm_rain_tendencies_2m :707-782
-    const SbRates<FT> w = sb2006_point<FT, LIMITED, VEL_NONE, true>(sc, rho, T, q_tot, q_lcl, q_rai, N_lcl, N_rai, n_lcl, n_rai, q_ice);
+    const SbRates<FT> w = sb2006_point<FT, LIMITED, VEL_NONE, true>(sc, rho, T, q_tot, q_lcl, q_rai, N_lcl, N_rai, n_lcl, n_rai, q_ice, k.cpm_qi);
     FT dq_lcl = (w.cond + w.au_dq_lcl) + w.ac_dq_lcl;
     FT dn_lcl = M::fma(w.lsc_plus_au + w.ac_dN_lcl, w.inv_rho, w.na_lcl);
     FT dq_rai = (w.evq + w.au_dq_rai) + w.ac_dq_rai;

@@ -31,7 +31,7 @@ template <typename FT> struct SbConsts {
     // thermodynamics (Thermodynamics.jl restatement, see oracle/cmx_oracle_impl.h)
     FT T_0, LH_v0, dcp, R_v, inv_R_v;
     FT ps_c0, ps_a, ps_b, inv_T_tr;     // log2 p_sat = c0 + a·log2(T/T_tr) + b·(1/T_tr − 1/T)
-    FT cp_d, cpm_qt, cpm_ql, cpm_qi;    // cp_m = cp_d + cpm_qt·q_tot + cpm_ql·q_liq [+ cpm_qi·q_ice]
+    FT cp_d, cpm_qt, cpm_ql;            // cp_m = cp_d + cpm_qt·q_tot + cpm_ql·q_liq
     FT tau_ce;                          // CondEvap2M.τ_relax
     FT inv_K, Rv_over_D, eps_1m;        // G_func_liquid (Common.jl:47-63)
     // rain PSD (CM2:67-110)
@@ -44,13 +44,13 @@ template <typename FT> struct SbConsts {
     FT gb_c1, gb_e1, gb_c2, gb_e2;      // Γ_incl(β_vent_0, t)
     FT a_vent_0_coeff, bSc_vent_0, a_vent_1, bSc_vent_1;   // b·∛Sc folded
     FT sqrt_alpha_nu, beta, ev_rho0_q;  // √(α/ν_air), β, ρ0^(1/4)
-    FT two_pi, inv_xstar_ev;
+    FT two_pi, l2_gate_N;               // log2(eps(FT)·x*) of the evaporation number gate
     // autoconversion / cloud self-collection (CM2:396-427, 488-501)
     FT sqrt_kfac, x_star, inv_x_star, acnv_A, acnv_a, acnv_b, acnv_rho0, ksc;
     // accretion (CM2:445-470)
     FT kcr_s, tau_0, accr_c;            // kcr·√ρ0
     // rain self-collection / breakup (CM2:545-601)
-    FT krr_s, kappa_rr, self_d, l2_6;   // krr·√ρ0(pdf_r)
+    FT krr_s, kappa_rr_K, self_d;       // krr·√ρ0(pdf_r), κ_rr·∛(π ρw/36)
     FT Deq, Dr_th, kbr, kappa_br_l2e;
     // number adjustment (CM2:882-891)
     FT inv_tau_na, inv_xc_min, inv_xc_max, inv_xr_min, inv_xr_max;
@@ -80,7 +80,6 @@ inline SbConsts<FT> make_sb_consts(const WR &wr, const TH &tp, const VL *vel, do
     c.cp_d = (FT)tp.cp_d;
     c.cpm_qt = (FT)((double)tp.cp_v - (double)tp.cp_d);
     c.cpm_ql = (FT)((double)tp.cp_l - (double)tp.cp_v);
-    c.cpm_qi = (FT)((double)tp.cp_i - (double)tp.cp_v);
     c.tau_ce = (FT)wr.condevap_tau_relax;
     const double K_safe = std::fmax((double)wr.air_properties.K_therm, eps_1m);
     const double D_safe = std::fmax((double)wr.air_properties.D_vapor, eps_1m);
@@ -123,7 +122,7 @@ inline SbConsts<FT> make_sb_consts(const WR &wr, const TH &tp, const VL *vel, do
     c.beta = (FT)ev.beta;
     c.ev_rho0_q = (FT)std::sqrt(std::sqrt((double)ev.rho_0));
     c.two_pi = (FT)(2.0 * pi);
-    c.inv_xstar_ev = (FT)(1.0 / x_star_ev);
+    c.l2_gate_N = (FT)std::log2((double)Math<FT>::eps() * x_star_ev);
     // autoconversion
     const auto &ac = sb.acnv;
     const double nu_c = (double)sb.pdf_c.nu_c;
@@ -143,9 +142,8 @@ inline SbConsts<FT> make_sb_consts(const WR &wr, const TH &tp, const VL *vel, do
     c.accr_c = (FT)sb.accr.c;
     // rain self-collection / breakup
     c.krr_s = (FT)((double)sb.self.krr * std::sqrt((double)pr.rho_0));
-    c.kappa_rr = (FT)sb.self.kappa_rr;
+    c.kappa_rr_K = (FT)((double)sb.self.kappa_rr * std::cbrt(pi * (double)pr.rho_w / 36.0));
     c.self_d = (FT)sb.self.d;
-    c.l2_6 = (FT)std::log2(6.0);
     c.Deq = (FT)sb.brek.Deq;
     c.Dr_th = (FT)sb.brek.Dr_th;
     c.kbr = (FT)sb.brek.kbr;
@@ -204,13 +202,13 @@ template <typename FT> struct SbRates {
 template <typename FT, bool LIMITED, int VEL, bool ICE = false>
 __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rho, FT T, FT q_tot,
                                                     FT q_lcl, FT q_rai, FT N_lcl, FT N_rai,
-                                                    FT n_lcl, FT n_rai, FT q_ice = FT(0)) {
+                                                    FT n_lcl, FT n_rai, FT q_ice = FT(0), FT cpm_qi = FT(0)) {
     using M = Math<FT>;
     const FT eps = M::eps();  // ϵ_numerics_2M_M = ϵ_numerics_2M_N = eps(FT)  (Utilities.jl:325,332)
     SbRates<FT> r;
 
-    const FT inv_rho = M::rcp(rho);
     const FT rs_rho = M::rsqrt(rho);  // ρ^(-1/2); each √(ρ0/ρ) is (host √ρ0)·rs_rho
+    const FT inv_rho = rs_rho * rs_rho;   // one hardware transcendental for both
     r.inv_rho = inv_rho;
 
     // ---- thermodynamics: one p_sat(T) shared by cond/evap, S and G -----------------------------
@@ -223,15 +221,16 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
     if constexpr (ICE) q_vap = M::max(FT(0), (q_tot - q_liq) - q_ice);
     const FT rho_RvT = rho * (c.R_v * T);
     const FT inv_p_sat = M::rcp(p_sat);
-    const FT q_sat = p_sat * M::rcp(rho_RvT);                                // TD.q_vap_saturation
-    const FT LoRT = L_v * c.inv_R_v * inv_T;                                 // L/(R_v T)
+    const FT inv_RvT = c.inv_R_v * inv_T;
+    const FT q_sat = p_sat * (inv_rho * inv_RvT);                            // TD.q_vap_saturation
+    const FT LoRT = L_v * inv_RvT;                                           // L/(R_v T)
     {   // _conv_q_vap_to_q_lcl_const  NonEq:117-140
         FT cp_air = M::fma(c.cpm_ql, q_liq, M::fma(c.cpm_qt, q_tot, c.cp_d));         // TD.cp_m
-        if constexpr (ICE) cp_air = M::fma(c.cpm_qi, q_ice, cp_air);
+        if constexpr (ICE) cp_air = M::fma(cpm_qi, q_ice, cp_air);      // cpm_qi = cp_i − cp_v, passed by the 2M+P3 caller
         const FT dqsl_dT = q_sat * (LoRT * inv_T - inv_T);                   // dqcld_dT NonEq:74-76
-        const FT Gamma_l = M::fma(L_v * M::rcp(cp_air), dqsl_dT, FT(1));     // gamma_helper NonEq:88-90
+        // gamma_helper NonEq:88-90: Γ = 1 + (L/cp)·dq/dT = (cp + L·dq/dT)/cp, so 1/(τΓ) needs one reciprocal, not two
         const FT excess = q_vap - q_sat;
-        const FT inv_ts = M::rcp(c.tau_ce * Gamma_l);
+        const FT inv_ts = cp_air * M::rcp(c.tau_ce * M::fma(L_v, dqsl_dT, cp_air));
         const FT evap_lim = -M::min(-excess, M::max(FT(0), q_lcl));
         r.cond = (excess < FT(0) ? evap_lim : excess) * inv_ts;
     }
@@ -301,13 +300,13 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
         l2_xr = l2_L - l2_N;
         l2_lam = (c.l2_pi_rho_w - l2_xr) * FT(1.0 / 3.0);
     }
-    const FT xr_mean = M::exp2(l2_xr), lam = M::exp2(l2_lam), Dr_mean = M::exp2(-l2_lam);
+    const FT lam = M::exp2(l2_lam), Dr_mean = M::exp2(-l2_lam);
     const FT l2_Dr = (l2_xr + c.l2_Drc) * FT(1.0 / 3.0);
     const FT Dr = M::exp2(l2_Dr);                       // ∛(6 x̄_r/(π ρw)): CM2:588 and :809
     const bool no_N_rai = N_rai < eps;
     {   // rain_self_collection CM2:545-560 + rain_breakup CM2:579-601
-        const FT inv_Br = M::exp2((l2_xr - c.l2_6) * FT(1.0 / 3.0));      // 1/∛(6/x̄_r)
-        const FT pw = M::exp2(c.self_d * M::log2(M::fma(c.kappa_rr, inv_Br, FT(1))));
+        // 1/Br = ∛(x̄_r/6) = Dr·∛(π ρw/36): κ_rr/Br = kappa_rr_K·Dr
+        const FT pw = M::exp2(c.self_d * M::log2(M::fma(c.kappa_rr_K, Dr, FT(1))));
         const FT sc = -c.krr_s * rs_rho * N_rai * L_rai * pw;
         const bool gate = no_q_rai || no_N_rai;
         r.rsc = gate ? FT(0) : sc;
@@ -332,7 +331,7 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
         const FT dN = M::min(FT(0), common * Fv0 * inv_xr);
         const FT dq = M::min(FT(0), common * Fv1 * inv_rho);
         const bool gate_q = no_q_rai || (N_rai <= eps) || (S >= FT(0));
-        const bool gate_N = gate_q || (xr_mean * c.inv_xstar_ev < eps);
+        const bool gate_N = gate_q || (l2_xr < c.l2_gate_N);             // x̄_r/x* < eps(FT) — CM2:824-825
         r.evN = gate_N ? FT(0) : dN;
         r.evq = gate_q ? FT(0) : dq;
     }

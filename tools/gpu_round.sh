@@ -12,6 +12,9 @@ for dt in f32 f64; do
   timeout 600 python bench.py --workload p3 --dtype $dt --points 10000000 --steps 5 --warmup 1 > gpurun_out/bench/p3_${dt}.json 2> gpurun_out/bench/p3_${dt}.err
   timeout 600 python bench.py --workload p3_selfcol --dtype $dt --points 1000000 --steps 3 --warmup 1 > gpurun_out/bench/p3_selfcol_${dt}.json 2> gpurun_out/bench/p3_selfcol_${dt}.err
   timeout 600 python bench.py --workload mp1m_lin --dtype $dt --steps 10 --warmup 2 > gpurun_out/bench/mp1m_lin_${dt}.json 2> gpurun_out/bench/mp1m_lin_${dt}.err
+  timeout 600 python bench.py --workload mp2m_p3 --dtype $dt --points 1000000 --steps 3 --warmup 1 > gpurun_out/bench/mp2m_p3_${dt}.json 2> gpurun_out/bench/mp2m_p3_${dt}.err
+  timeout 600 python bench.py --workload sb2006_aos --dtype $dt --steps 20 --warmup 3 > gpurun_out/bench/sb2006_aos_${dt}.json 2> gpurun_out/bench/sb2006_aos_${dt}.err
+  timeout 600 python bench.py --workload sb2006_fields --dtype $dt --steps 20 --warmup 3 > gpurun_out/bench/sb2006_fields_${dt}.json 2> gpurun_out/bench/sb2006_fields_${dt}.err
 done
 tools/profile.sh sb2006 f32 100000000 > /dev/null
 tools/profile.sh sb2006 f64 100000000 > /dev/null
@@ -19,4 +22,6 @@ tools/profile.sh icenuc f32 100000000 > /dev/null
 tools/profile.sh mp1m f32 100000000 > /dev/null
 tools/profile.sh arg2000 f32 100000000 > /dev/null
 tools/profile.sh p3 f64 10000000 > /dev/null
+tools/profile.sh mp2m_p3 f64 1000000 r01 valu > /dev/null
+tools/profile.sh sb2006_aos f32 100000000 > /dev/null
 ls gpurun_out/profiles
