@@ -52,7 +52,7 @@ def main():
     dst.mkdir(parents=True, exist_ok=True)
     summary = {"round": rnd, "workload": wl, "dtype": dt, "points": n,
                "command": f"tools/profile.sh {wl} {dt} {n}  (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE in separate passes, "
-                          f"--kernel-trace --stats in a third; bench.py --steps 5 --warmup 1 --no-cpu-baseline)"}
+                          f"--kernel-trace --stats in a third; PMC passes: bench.py --steps 5 --warmup 1; kernel-trace pass: --steps 40 --warmup 5)"}
     stats = find(out, "kt", "kernel_stats.csv")
     if stats:
         rows = list(csv.reader(open(stats)))

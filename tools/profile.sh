@@ -9,8 +9,10 @@ OUT=$ROOT/gpurun_out/prof_${WL}_${DT}
 mkdir -p "$OUT" "$ROOT/gpurun_out/profiles"
 export TMPDIR=/tmp
 ARGS="$ROOT/bench.py --workload $WL --dtype $DT --points $N --steps 5 --warmup 1 --no-cpu-baseline"
+# the kernel-trace pass runs enough launches for its average to be the steady-state duration bench.py reports
+KTARGS="$ROOT/bench.py --workload $WL --dtype $DT --points $N --steps ${KT_STEPS:-40} --warmup 5 --no-cpu-baseline"
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 $ARGS > "$OUT/kt.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 $KTARGS > "$OUT/kt.log" 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fetch -- python3 $ARGS > "$OUT/fetch.log" 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- python3 $ARGS > "$OUT/write.log" 2>&1
 cd "$ROOT"
