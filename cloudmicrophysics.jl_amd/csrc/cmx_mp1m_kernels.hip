@@ -176,14 +176,17 @@ template <typename FT> __device__ __forceinline__ FT logistic_integral(FT x, FT 
     return x < eps ? FT(0) : (x0 < eps ? x : r);
 }
 
-template <typename FT>
+// FLAGS: the Microphysics1MOptions bits as a compile-time constant (the default option set gets its own instantiation:
+// one straight-line basic block, the unselected variants removed), or kRuntimeFlags to read them from the constants.
+constexpr uint32_t kRuntimeFlags = 0xffffffffu;
+template <typename FT, uint32_t FLAGS = kRuntimeFlags>
 __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const Mp1mConsts<FT> &c, FT rho, FT T, FT q_tot, FT q_lcl, FT q_icl,
                                                   FT q_rai, FT q_sno) {
     using M = Math<FT>;
     Mp1mSrc<FT> o;
 #pragma unroll
     for (int k = 0; k < CMX_MP1M_NSRC; ++k) o.s[k] = FT(0);
-    const uint32_t fl = c.flags;
+    const uint32_t fl = FLAGS == kRuntimeFlags ? c.flags : FLAGS;
     const FT eps = c.eps_1m;   // ϵ_numerics(FT) = cbrt(floatmin(FT))  Utilities.jl:318
     // clamp_to_nonneg — BMT:147-152 (T is not clamped)
     rho = M::max(FT(0), rho); q_tot = M::max(FT(0), q_tot); q_lcl = M::max(FT(0), q_lcl);
@@ -317,7 +320,7 @@ template <typename FT> struct Mp1mOut { FT *dq_lcl, *dq_icl, *dq_rai, *dq_sno; }
 template <typename FT> struct Mp1mSrcOut { FT *col[CMX_MP1M_NSRC]; };
 
 // bulk_microphysics_tendencies(Instantaneous(), Microphysics1Moment(), …) over columns — BMT:505-514
-template <typename FT, int VEC>
+template <typename FT, int VEC, uint32_t FLAGS = kRuntimeFlags>
 __global__ __launch_bounds__(kBlock) void mp1m_tendencies_kernel(const Mp1mConsts<FT> c, const Mp1mIn<FT> in,
                                                                  const Mp1mOut<FT> out, const int64_t nvec) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(kBlock) void mp1m_tendencies_kernel(const Mp1mConst
     FT dl[VEC], di[VEC], dr[VEC], ds[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
-        const Mp1mSrc<FT> p = mp1m_point<FT>(c, rho[k], T[k], q_tot[k], q_lcl[k], q_icl[k], q_rai[k], q_sno[k]);
+        const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(c, rho[k], T[k], q_tot[k], q_lcl[k], q_icl[k], q_rai[k], q_sno[k]);
         const FT *s = p.s;
         // _aggregate_tendencies — BMT:227-252 (same order of additions)
         dl[k] = ((((s[CMX_1M_S_PHASE_CHANGE_VAP_LCL] - s[CMX_1M_S_ACNV_LCL_RAI]) - s[CMX_1M_S_ACCR_LCL_RAI]) -
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(kBlock) void mp1m_tendencies_kernel(const Mp1mConst
 // source terms come from the same mp1m_point as the Instantaneous mode.
 template <typename FT> struct Mp1mLinArgs { FT q_min, dt, dt_sub, inv_dt_sub, inv_dt, Lv_over_cp, Ls_over_cp; int32_t nsub; };
 
-template <typename FT>
+template <typename FT, uint32_t FLAGS = kRuntimeFlags>
 __global__ __launch_bounds__(kBlock) void mp1m_linearized_kernel(const Mp1mConsts<FT> c, const Mp1mLinArgs<FT> a, const Mp1mIn<FT> in,
                                                                  const Mp1mOut<FT> out, const int64_t n) {
     using M = Math<FT>;
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(kBlock) void mp1m_linearized_kernel(const Mp1mConst
     const FT ql0 = in.q_lcl[i], qi0 = in.q_icl[i], qr0 = in.q_rai[i], qs0 = in.q_sno[i];
     FT T = in.T[i], ql = ql0, qi = qi0, qr = qr0, qs = qs0;
     for (int k = 0; k < a.nsub; ++k) {
-        const Mp1mSrc<FT> p = mp1m_point<FT>(c, rho, T, q_tot, ql, qi, qr, qs);
+        const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(c, rho, T, q_tot, ql, qi, qr, qs);
         const FT *S = p.s;
         // _linearize — BMT:269-379
         const FT il = M::rcp(M::max(a.q_min, ql)), ii = M::rcp(M::max(a.q_min, qi)), ir = M::rcp(M::max(a.q_min, qr)),
@@ -548,7 +551,11 @@ static int32_t tendencies_1m_entry(const MP *mp, const TH *tps, uint32_t flags, 
         Mp1mIn<FT> in{rho + lo, T + lo, q_tot + lo, q_lcl + lo, q_icl + lo, q_rai + lo, q_sno + lo};
         Mp1mOut<FT> out{dq_lcl + lo, dq_icl + lo, dq_rai + lo, dq_sno + lo};
         const int64_t nv = count / V;
-        hipLaunchKernelGGL((mp1m_tendencies_kernel<FT, V>), dim3((unsigned)((nv + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, c, in, out, nv);
+        const dim3 grid((unsigned)((nv + kBlock - 1) / kBlock));
+        if (flags == CMX_1M_DEFAULT_OPTIONS)
+            hipLaunchKernelGGL((mp1m_tendencies_kernel<FT, V, CMX_1M_DEFAULT_OPTIONS>), grid, dim3(kBlock), 0, s, c, in, out, nv);
+        else
+            hipLaunchKernelGGL((mp1m_tendencies_kernel<FT, V>), grid, dim3(kBlock), 0, s, c, in, out, nv);
     };
     if (same_mis) {
         const int64_t head = std::min<int64_t>(n, mis0 ? (int64_t)((16 - mis0) / sizeof(FT)) : 0);
@@ -579,8 +586,12 @@ static int32_t linearized_1m_entry(const MP *mp, const TH *tps, uint32_t flags, 
     a.Lv_over_cp = (FT)tps->LH_v0 / (FT)tps->cp_d; a.Ls_over_cp = (FT)tps->LH_s0 / (FT)tps->cp_d;
     Mp1mIn<FT> in{rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno};
     Mp1mOut<FT> out{dq_lcl, dq_icl, dq_rai, dq_sno};
-    hipLaunchKernelGGL((mp1m_linearized_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                       reinterpret_cast<hipStream_t>(stream), c, a, in, out, n);
+    if (flags == CMX_1M_DEFAULT_OPTIONS)
+        hipLaunchKernelGGL((mp1m_linearized_kernel<FT, CMX_1M_DEFAULT_OPTIONS>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                           reinterpret_cast<hipStream_t>(stream), c, a, in, out, n);
+    else
+        hipLaunchKernelGGL((mp1m_linearized_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                           reinterpret_cast<hipStream_t>(stream), c, a, in, out, n);
     CMX_HIP_TRY(hipGetLastError());
     return CMX_OK;
 }
