@@ -199,7 +199,9 @@ __device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, cons
     return o;
 }
 
-template <typename FT, int NM, bool SINKS, int VEC>
+// N_ONLY: the number-activation-only request (N_act columns, no M_act — the BASELINE configuration) as a compile-time fact; with
+// the two wants as run-time flags the compiler keeps both erfc chains and their selects alive (1212 → 729 VALU per 4 points).
+template <typename FT, int NM, bool SINKS, int VEC, bool N_ONLY = false>
 __global__ __launch_bounds__(kBlock) void arg_activation_kernel(const ArgConsts<FT> c, const ArgIO<FT> io, const int64_t nvec) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= nvec) return;
@@ -214,7 +216,8 @@ __global__ __launch_bounds__(kBlock) void arg_activation_kernel(const ArgConsts<
     FT sm[VEC], na[NM][VEC], ma[NM][VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
-        const ArgOut<FT, NM> o = arg_point<FT, NM, SINKS>(c, c.m, T[k], p[k], w[k], qt[k], ql[k], qi[k], Nl[k], Ni[k], io.want_N, io.want_M);
+        const ArgOut<FT, NM> o = arg_point<FT, NM, SINKS>(c, c.m, T[k], p[k], w[k], qt[k], ql[k], qi[k], Nl[k], Ni[k], N_ONLY ? true : io.want_N,
+                                                         N_ONLY ? false : io.want_M);
         sm[k] = o.smax;
 #pragma unroll
         for (int j = 0; j < NM; ++j) { na[j][k] = o.n[j]; ma[j][k] = o.m[j]; }
@@ -222,8 +225,10 @@ __global__ __launch_bounds__(kBlock) void arg_activation_kernel(const ArgConsts<
     if (io.S_max) store_col<FT, VEC>(io.S_max, i, sm);
 #pragma unroll
     for (int j = 0; j < NM; ++j) {
-        if (io.want_N && io.N_act[j]) store_col<FT, VEC>(io.N_act[j], i, na[j]);
-        if (io.want_M && io.M_act[j]) store_col<FT, VEC>(io.M_act[j], i, ma[j]);
+        if ((N_ONLY || io.want_N) && io.N_act[j]) store_col<FT, VEC>(io.N_act[j], i, na[j]);
+        if constexpr (!N_ONLY) {
+            if (io.want_M && io.M_act[j]) store_col<FT, VEC>(io.M_act[j], i, ma[j]);
+        }
     }
 }
 
@@ -244,7 +249,9 @@ static void launch_arg(const ArgConsts<FT> &c, const ArgIO<FT> &io0, int64_t n, 
         io.S_max = off(io.S_max, lo);
         for (int j = 0; j < CMX_ARG_MAX_MODES; ++j) { io.N_act[j] = off(io.N_act[j], lo); io.M_act[j] = off(io.M_act[j], lo); }
         const int64_t nv = count / V;
-        hipLaunchKernelGGL((arg_activation_kernel<FT, NM, SINKS, V>), dim3((unsigned)((nv + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, c, io, nv);
+        const dim3 grid((unsigned)((nv + kBlock - 1) / kBlock));
+        if (io.want_N && !io.want_M) hipLaunchKernelGGL((arg_activation_kernel<FT, NM, SINKS, V, true>), grid, dim3(kBlock), 0, s, c, io, nv);
+        else hipLaunchKernelGGL((arg_activation_kernel<FT, NM, SINKS, V, false>), grid, dim3(kBlock), 0, s, c, io, nv);
     };
     if (same_mis) {
         const int64_t head = std::min<int64_t>(n, mis0 ? (int64_t)((16 - mis0) / sizeof(FT)) : 0);
