@@ -57,7 +57,9 @@ static int32_t tendencies_entry(const WR *wr, const TH *tps, const VL *vel, uint
     const bool limited = flags & CMX_SB2006_LIMITED;
     const SbConsts<FT> c = make_sb_consts<FT>(*wr, *tps, vel, (double)Math<FT>::eps_1m());
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    constexpr int VEC = Math<FT>::VEC;
+    // Float64: one point per lane (8-byte loads).  The kernel is VALU-bound there and the two-points-per-lane variant spends 14 % of
+    // its instructions on SGPR spill traffic (60 Float64 constants = 120 SGPRs): 1307 vs 1048 VALU instructions per point.
+    constexpr int VEC = sizeof(FT) == 8 ? 1 : Math<FT>::VEC;
     // Alignment dispatch.  The 16-byte body needs every column at the same offset modulo 16 B (true for
     // any common slice [lo:hi] of aligned columns): `head` points are peeled so the body starts aligned,
     // the body runs VEC points per lane, the ragged tail one point per lane.  Columns with mixed
