@@ -1,7 +1,7 @@
 // cmx_p3_collisions.hip — P3 liquid–ice collisions for gfx950: bulk_liquid_ice_collision_sources and the ten
 // ∫liquid_ice_collisions integrals (src/P3_processes.jl:96-655); C-ABI entry points of include/cmx.h §(8).
 //
-// Work decomposition — one grid POINT per 16-lane group (4 points per wave64, 16 per 256-lane workgroup), one OUTER
+// Work decomposition — one grid POINT per 8-lane group (8 points per wave64, 32 per 256-lane workgroup), one OUTER
 // quadrature node (ice diameter Dᵢ) per lane:
 //   * the reference evaluates, per outer node, two inner integrals over the liquid diameters (cloud: 3 sums by
 //     quadrature; rain: N and M in closed form, the rime-volume sum by quadrature).  The inner nodes and everything
@@ -14,10 +14,11 @@
 //     the continued fraction at the bottom z — both stable) replaces the reference's 96 regularised gamma_inc calls
 //     per outer node by 4; the end-point values (x = α D_lo, α D_hi) do not depend on the outer node either and are
 //     evaluated once per point by 8 lanes of the group;
-//   * the ten outer sums are reduced over the group with 4 xor-shuffle steps.
+//   * the ten outer sums are reduced over the group with log2(group) xor-shuffle steps.
 // The per-point set-up (P3 state, the two Halley solves for the integration bounds, PSD parameters) is evaluated
-// redundantly by the 16 lanes of a group — that is what bounds the group width from above; DESIGN.md §4.8 has the
-// instruction budget that led to 16.
+// redundantly by the 8 lanes of a group — that is what bounds the group width from above; DESIGN.md §4.8 has the
+// instruction budget and the measurement that led to 8 (the end-point incomplete gammas and the six
+// quantile solves each use up to 8 lanes of the group: 8 is also the smallest width that keeps them one pass).
 //
 // COMPUTE-bound (FP64 / FP32 vector rate); HBM traffic is 11 input + ≤17 output columns per point.
 #include <hip/hip_runtime.h>
@@ -29,8 +30,8 @@
 
 namespace cmx {
 
-constexpr int kGroup = 16;                       // lanes per grid point
-constexpr int kPointsPerBlock = kBlock / kGroup;
+constexpr int kGroup = 8;                        // lanes per grid point (measured: 8 → 32.3 ms, 16 → 36.2 ms, 32 → 69.4 ms per 1e6 f64 states at GaussLegendre(16))
+static_assert(kGroup >= 8 && (kGroup & (kGroup - 1)) == 0 && kGroup <= 64, "lanes 0..7 of a group hold the end-point gammas and the quantile solves");
 
 template <typename FT> struct P3ColConsts {
     // rain Chen-2022 curve (table B1; Common.jl:290-302): v_l(D) = Σ_j a_j exp(e_j + b_j logD − c_j D)
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(kBlock, 2) void p3_collision_kernel(const P3Consts<
     const int grp = threadIdx.x / kGroup, g = threadIdx.x % kGroup;
     FT *G = lds + 2 * nq + grp * ColLds<FT>::per_group(nq);
     FT *cD = G, *cV = G + nq, *cW = G + 2 * nq, *rD = G + 3 * nq, *rV = G + 4 * nq, *rW = G + 5 * nq, *E = G + 6 * nq, *Fm = G + 6 * nq + 48;
-    const int64_t pt_raw = (int64_t)blockIdx.x * kPointsPerBlock + grp;
+    const int64_t pt_raw = (int64_t)blockIdx.x * (blockDim.x / kGroup) + grp;
     const bool valid = pt_raw < n;
     const int64_t i = valid ? pt_raw : n - 1;
     __syncthreads();
@@ -560,6 +561,15 @@ __global__ __launch_bounds__(kBlock, 2) void p3_collision_kernel(const P3Consts<
     }
 }
 
+// launch geometry: 256 lanes (32 states) per workgroup unless the per-state LDS caches (6n + 72 values) would not fit — then 128
+template <typename FT> static void collision_geometry(int nq, int64_t n, dim3 &grid, dim3 &block, size_t &lds) {
+    int threads = kBlock;
+    auto bytes = [&](int t) { return sizeof(FT) * (size_t)(2 * nq + (t / kGroup) * (6 * nq + 72)); };
+    while (threads > 64 && bytes(threads) > 150 * 1024) threads /= 2;
+    const int ppb = threads / kGroup;
+    grid = dim3((unsigned)((n + ppb - 1) / ppb)); block = dim3(threads); lds = bytes(threads);
+}
+
 template <typename FT, typename IP, typename AP, typename TH, typename QUAD>
 static int32_t p3_collision_entry(const IP *ip, const AP *aps, const TH *tps, const QUAD *quad, uint32_t flags, int64_t n, const FT *rho_q,
                                   const FT *rho_n, const FT *x3, const FT *x4, const FT *L_c, const FT *N_c, const FT *L_r, const FT *N_r,
@@ -580,8 +590,9 @@ static int32_t p3_collision_entry(const IP *ip, const AP *aps, const TH *tps, co
     io.rho_a = rho_a; io.T = T; io.loglam = loglam;
     for (int q = 0; q < 7; ++q) io.src[q] = sources ? sources[q] : nullptr;
     for (int q = 0; q < 10; ++q) io.rates[q] = rates ? rates[q] : nullptr;
-    const dim3 grid((unsigned)((n + kPointsPerBlock - 1) / kPointsPerBlock)), block(kBlock);
-    const size_t lds = sizeof(FT) * (size_t)(2 * quad->n + kPointsPerBlock * (6 * quad->n + 72));
+    dim3 grid, block;
+    size_t lds;
+    collision_geometry<FT>(quad->n, n, grid, block, lds);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (lds > 48 * 1024) {   // large quadrature orders need more than the default dynamic-LDS limit
         CMX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&p3_collision_kernel<FT, QUAD, false, false>),
@@ -603,7 +614,7 @@ static int32_t p3_collision_entry(const IP *ip, const AP *aps, const TH *tps, co
 //   1. mp2m_p3_pointwise_kernel (lane per point, HBM-bound): clamps, warm rain with the ice content in the vapour budget
 //      (sb2006_point<ICE>), F23 deposition nucleation, F23-capped Bigg freezing of cloud drops, ice sublimation/deposition,
 //      ice number adjustment, Bigg freezing of rain — writes the eight tendency columns;
-//   2. p3_collision_kernel<FUSED> (16 lanes per point, compute-bound): liquid–ice collisions, aggregation and melting where
+//   2. p3_collision_kernel<FUSED> (8 lanes per point, compute-bound): liquid–ice collisions, aggregation and melting where
 //      q_ice > ϵ and n_ice > ϵ — read-modify-writes the same columns.
 template <typename FT> struct PointwiseConsts {
     FT f23_b10, f23_log_a, f23_T_freeze, inv_tau_act, m_nuc, T_dep, S_thresh;           // Frostenberg 2023 (IceNucleation.jl:250-511)
@@ -773,8 +784,9 @@ static int32_t mp2m_p3_entry(const WR *wr, const IP *ip, const TH *tps, uint32_t
     io.q_lcl = q_lcl; io.n_lcl = n_lcl; io.q_rai = q_rai; io.n_rai = n_rai; io.q_ice = q_ice; io.n_ice = n_ice; io.q_rim = q_rim; io.b_rim = b_rim;
     for (int q = 0; q < 8; ++q) io.out[q] = out[q];
     using QUAD = std::remove_cv_t<std::remove_reference_t<decltype(ip->quad)>>;
-    const dim3 grid2((unsigned)((n + kPointsPerBlock - 1) / kPointsPerBlock));
-    const size_t lds = sizeof(FT) * (size_t)(2 * ip->quad.n + kPointsPerBlock * (6 * ip->quad.n + 72));
+    dim3 grid2, block2;
+    size_t lds;
+    collision_geometry<FT>(ip->quad.n, n, grid2, block2, lds);
     if (lds > 48 * 1024) {
         CMX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&p3_collision_kernel<FT, QUAD, false, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -782,9 +794,9 @@ static int32_t mp2m_p3_entry(const WR *wr, const IP *ip, const TH *tps, uint32_t
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     if (flags & CMX_P3_NO_ASPECT_RATIO)
-        hipLaunchKernelGGL((p3_collision_kernel<FT, QUAD, false, true>), grid2, block, lds, st, c, v, k, ip->quad, io, n);
+        hipLaunchKernelGGL((p3_collision_kernel<FT, QUAD, false, true>), grid2, block2, lds, st, c, v, k, ip->quad, io, n);
     else
-        hipLaunchKernelGGL((p3_collision_kernel<FT, QUAD, true, true>), grid2, block, lds, st, c, v, k, ip->quad, io, n);
+        hipLaunchKernelGGL((p3_collision_kernel<FT, QUAD, true, true>), grid2, block2, lds, st, c, v, k, ip->quad, io, n);
     CMX_HIP_TRY(hipGetLastError());
     return CMX_OK;
 }

@@ -725,7 +725,7 @@ int32_t cmx_p3_liquid_ice_collisions_f64(const cmx_p3_ice_params_f64 *ice, const
  * tendencies[8] = device columns (dq_lcl_dt, dn_lcl_dt, dq_rai_dt, dn_rai_dt, dq_ice_dt, dn_ice_dt, dq_rim_dt, db_rim_dt), all
  * required; the ninth field of the reference's NamedTuple, dn_lcl_activation_dt, is identically 0.
  * flags: CMX_P3_RAIN_PDF_LIMITED (is_limited of both the SB2006 set and P3IceParams.rain_pdf), CMX_P3_SLOPE_CONSTANT,
- * CMX_P3_NO_ASPECT_RATIO.  Two launches on `stream`: a pointwise kernel that writes the columns, then the 16-lanes-per-point
+ * CMX_P3_NO_ASPECT_RATIO.  Two launches on `stream`: a pointwise kernel that writes the columns, then the 8-lanes-per-point
  * quadrature kernel that adds the ice-process terms to them. */
 int32_t cmx_microphysics_2m_p3_tendencies_f32(const cmx_warm_rain_2m_f32 *warm_rain, const cmx_p3_ice_params_f32 *ice, const cmx_thermo_f32 *tps,
                                               uint32_t flags, int64_t n, const float *rho, const float *T, const float *q_tot, const float *q_lcl,

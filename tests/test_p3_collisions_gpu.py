@@ -154,3 +154,30 @@ def test_edge_cases_and_validation(dev):
                                            llr[i:i + 1].clone(), *[c[i:i + 1].clone() for c in cols[4:8]], from_state=True)
         for k in full:
             assert float(full[k][i]) == float(one[k][0]), (k, i)
+
+
+@pytest.mark.parametrize("quad", ["cheb100", "gl128", "gl40"])
+def test_large_quadrature_orders(dev, oracle, quad):
+    """The reference's default rule ChebyshevGauss(100), the production order 40 and the largest supported order 128: the per-state LDS
+    caches grow with the order and the launch falls back to smaller workgroups (Float64, 128 nodes: 107 KB for 16 states)."""
+    import cmx
+    ft = "f64"
+    mk = {"cheb100": lambda f: P.ChebyshevGauss(f, 100), "gl128": lambda f: P.GaussLegendre(f, 128), "gl40": lambda f: P.GaussLegendre(f, 40)}[quad]
+    n = 70
+    cols = _random_states(n, ft, seed=19)
+    ip = P.P3IceParams(ft, quad=mk(ft))
+    aps, tps = P.AirProperties(ft), P.ThermodynamicsParameters(ft)
+    d = [c.to(dev) for c in cols]
+    ll = cmx.p3_shape(P.ParametersP3(ft), *d[:4], from_state=True, want=("log_lambda",), brent_iters=40).log_lambda
+    ll = torch.where(torch.isfinite(ll), ll, torch.zeros_like(ll))
+    src, rates = cmx.p3_liquid_ice_collisions(ip, aps, tps, d[8], d[9], *d[:4], ll, *d[4:8], from_state=True, want_rates=True)
+    torch.cuda.synchronize()
+    c64 = [c.numpy().astype(np.float64) for c in cols]
+    _, orates = oracle.p3_liquid_ice_collisions(_abi.F64, ip.c, aps, tps, ip.c.quad, ip.flags | STATE, *c64[:4], *c64[4:8], c64[8], c64[9], _np64(ll),
+                                                nthreads=8)
+    for q, k in enumerate(rates.keys()):
+        x, r = _np64(rates[k]), orates[q]
+        scale = np.maximum(np.abs(r), orates[6] if k in ("QCSHD", "QRSHD", "int_wet_M_col") else 0)
+        err = np.abs(x - r) / np.maximum(scale, 1e-300)
+        err[(r == 0) & (x == 0)] = 0
+        assert err.max() <= RTOL[ft], (quad, k, float(err.max()))
