@@ -185,3 +185,23 @@ def p3_liquid_ice_collisions(ice_params, aps, tps, rho_air, T, rho_q_ice, rho_n_
                 C.c_void_p(s.cuda_stream))
     _lib.check(fn.__name__, st)
     return (src, rates) if want_rates else src
+
+
+P3HetNucleation = namedtuple("P3HetNucleation", ["dNdt", "dLdt"])
+
+
+def p3_het_ice_nucleation(aerosol, tps, q_lcl, N_lcl, RH, T, rho_air, *, stream=None):
+    """`P3.het_ice_nucleation(aerosol, tps, q_lcl, N_lcl, RH, T, ρₐ)` for every point (src/P3_processes.jl:20-46): ABIFM immersion
+    freezing rates (dNdt [1/m³/s], dLdt [kg/m³/s]) for a dust type with ABIFM coefficients (`parameters.Illite / Kaolinite / …`)."""
+    cols = (q_lcl, N_lcl, RH, T, rho_air)
+    ref = _check_cols(cols, ("q_lcl", "N_lcl", "RH", "T", "rho_air"))
+    fam = _fam_of(ref)
+    if not isinstance(aerosol, fam.abifm_dust) or not isinstance(tps, fam.thermo):
+        raise TypeError("parameter float type does not match the state columns")
+    out = P3HetNucleation(torch.empty_like(ref), torch.empty_like(ref))
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_p3_het_ice_nucleation_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(aerosol), C.byref(tps), ref.numel(), *[_ptr(t) for t in cols], _ptr(out.dNdt), _ptr(out.dLdt), C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return out

@@ -211,6 +211,37 @@ static int32_t water_activity_entry(const TH *tps, int64_t n, const FT *T, const
     return CMX_OK;
 }
 
+// P3.het_ice_nucleation(aerosol, tps, q_lcl, N_lcl, RH, T, ρₐ) — src/P3_processes.jl:20-46: ABIFM immersion freezing on an assumed
+// aerosol surface A_aer = 1e-10 m² per droplet; a non-finite J counts as no nucleation.  32 B/point (f32), one point per lane.
+template <typename FT>
+__global__ __launch_bounds__(kBlock) void p3_het_nucleation_kernel(const IceNucConsts<FT> c, const FT *__restrict__ q_lcl,
+                                                                  const FT *__restrict__ N_lcl, const FT *__restrict__ RH,
+                                                                  const FT *__restrict__ T, const FT *__restrict__ rho, FT *__restrict__ dNdt,
+                                                                  FT *__restrict__ dLdt, const int64_t n) {
+    using M = Math<FT>;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const FT Ti = T[i];
+    const FT d = RH[i] - a_w_ice_dev<FT>(c, Ti, M::rcp(Ti));
+    const FT J = M::exp2(M::fma(c.abifm_m_l2, d, c.abifm_c_l2));              // ABIFM_J  IceNucleation.jl:124-134 [1/m²/s]
+    const FT JA = (J - J == FT(0)) ? J * FT(1e-10) : FT(0);                    // isfinite(J) ? J·A_aer : 0
+    if (dNdt) dNdt[i] = M::max(FT(0), JA * N_lcl[i]);
+    if (dLdt) dLdt[i] = M::max(FT(0), JA * q_lcl[i] * rho[i]);
+}
+template <typename FT, typename TH, typename DU>
+static int32_t p3_het_nucleation_entry(const DU *dust, const TH *tps, int64_t n, const FT *q_lcl, const FT *N_lcl, const FT *RH, const FT *T,
+                                       const FT *rho, FT *dNdt, FT *dLdt, void *stream) {
+    if (!dust || !tps || n < 0) return CMX_ERR_BAD_ARG;
+    if (n == 0) return CMX_OK;
+    if (!q_lcl || !N_lcl || !RH || !T || !rho || (!dNdt && !dLdt)) return CMX_ERR_BAD_ARG;
+    using KO = std::conditional_t<std::is_same_v<FT, float>, cmx_koop2000_f32, cmx_koop2000_f64>;
+    const IceNucConsts<FT> c = make_icenuc_consts<FT>(*tps, dust, (const KO *)nullptr);
+    hipLaunchKernelGGL((p3_het_nucleation_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       reinterpret_cast<hipStream_t>(stream), c, q_lcl, N_lcl, RH, T, rho, dNdt, dLdt, n);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+
 }  // namespace cmx
 
 extern "C" {
@@ -236,6 +267,17 @@ int32_t cmx_water_activity_f32(const cmx_thermo_f32 *tps, int64_t n, const float
 int32_t cmx_water_activity_f64(const cmx_thermo_f64 *tps, int64_t n, const double *T, const double *e, double *a_w_ice,
                                double *a_w_eT, void *stream) {
     return cmx::water_activity_entry<double>(tps, n, T, e, a_w_ice, a_w_eT, stream);
+}
+
+int32_t cmx_p3_het_ice_nucleation_f32(const cmx_abifm_dust_f32 *dust, const cmx_thermo_f32 *tps, int64_t n, const float *q_lcl,
+                                      const float *N_lcl, const float *RH, const float *T, const float *rho_air, float *dNdt, float *dLdt,
+                                      void *stream) {
+    return cmx::p3_het_nucleation_entry<float>(dust, tps, n, q_lcl, N_lcl, RH, T, rho_air, dNdt, dLdt, stream);
+}
+int32_t cmx_p3_het_ice_nucleation_f64(const cmx_abifm_dust_f64 *dust, const cmx_thermo_f64 *tps, int64_t n, const double *q_lcl,
+                                      const double *N_lcl, const double *RH, const double *T, const double *rho_air, double *dNdt,
+                                      double *dLdt, void *stream) {
+    return cmx::p3_het_nucleation_entry<double>(dust, tps, n, q_lcl, N_lcl, RH, T, rho_air, dNdt, dLdt, stream);
 }
 
 }  // extern "C"

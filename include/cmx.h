@@ -690,6 +690,17 @@ int32_t cmx_p3_ice_self_collection_f64(const cmx_p3_params_f64 *params, const cm
                                        uint32_t flags, int64_t n, const double *rho_q_ice, const double *rho_n_ice, const double *x3,
                                        const double *x4, const double *rho_air, const double *log_lambda, double *dNdt, void *stream);
 
+/* P3 heterogeneous (immersion) freezing: replaces, per point,
+ *   (; dNdt, dLdt) = P3.het_ice_nucleation(aerosol, tps, q_lcl, N_lcl, RH, T, ρₐ)              src/P3_processes.jl:20-46
+ * J = CM_HetIce.ABIFM_J(aerosol, RH − a_w_ice(T)) on an assumed aerosol surface of 1e-10 m² per droplet; dNdt = max(0, J A N_lcl)
+ * [1/m³/s], dLdt = max(0, J A q_lcl ρₐ) [kg/m³/s]; a non-finite J gives 0.  Either output may be NULL. */
+int32_t cmx_p3_het_ice_nucleation_f32(const cmx_abifm_dust_f32 *dust, const cmx_thermo_f32 *tps, int64_t n, const float *q_lcl,
+                                      const float *N_lcl, const float *RH, const float *T, const float *rho_air, float *dNdt, float *dLdt,
+                                      void *stream);
+int32_t cmx_p3_het_ice_nucleation_f64(const cmx_abifm_dust_f64 *dust, const cmx_thermo_f64 *tps, int64_t n, const double *q_lcl,
+                                      const double *N_lcl, const double *RH, const double *T, const double *rho_air, double *dNdt,
+                                      double *dLdt, void *stream);
+
 /* (8) P3 liquid–ice collisions: replaces, per point,
  *   rates   = P3.∫liquid_ice_collisions(state, logλ, psd_c, psd_r, L_c, N_c, L_r, N_r, aps, tps, vel, ρₐ, T, m_liq; quad)
  *                                                                                         src/P3_processes.jl:527-562

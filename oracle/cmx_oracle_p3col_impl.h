@@ -494,3 +494,14 @@ FT FN(cmxo_INP_concentration_mean)(const TY(cmx_frostenberg2023) * ip, FT T) { r
 FT FN(cmxo_INP_concentration_frequency)(const TY(cmx_frostenberg2023) * ip, FT INPC, FT T) { return FN(o_INP_concentration_frequency)(ip, INPC, T); }
 FT FN(cmxo_P3_deposition_N_i)(const TY(cmx_morrison_milbrandt2014) * ip, FT T) { return FN(o_P3_deposition_N_i)(ip, T); }
 FT FN(cmxo_P3_het_N_i)(const TY(cmx_morrison_milbrandt2014) * ip, FT T, FT N_l, FT V_l, FT dt) { return FN(o_P3_het_N_i)(ip, T, N_l, V_l, dt); }
+/* P3.het_ice_nucleation — src/P3_processes.jl:20-46 (ABIFM_J: src/IceNucleation.jl:124-134) */
+void FN(cmxo_p3_het_ice_nucleation)(const TY(cmx_abifm_dust) * dust, const TY(cmx_thermo) * tps, int64_t n, const FT *q_lcl, const FT *N_lcl,
+                                   const FT *RH, const FT *T, const FT *rho, FT *dNdt, FT *dLdt) {
+    for (int64_t i = 0; i < n; ++i) {
+        FT J = FN(o_ABIFM_J)(dust, RH[i] - FN(o_a_w_ice)(tps, T[i]));
+        FT A_aer = (FT)1e-10;
+        FT JA = isfinite(J) ? J * A_aer : (FT)0;
+        dNdt[i] = FN(o_max)((FT)0, JA * N_lcl[i]);
+        dLdt[i] = FN(o_max)((FT)0, JA * q_lcl[i] * rho[i]);
+    }
+}

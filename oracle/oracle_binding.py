@@ -567,3 +567,14 @@ def P3_deposition_N_i(fam, ip, T):
 
 def P3_het_N_i(fam, ip, T, N_l, V_l, dt):
     return _scalar(fam, "cmxo_P3_het_N_i", [C.c_void_p] + [fam.ft] * 4, C.addressof(ip), T, N_l, V_l, dt)
+
+
+def p3_het_ice_nucleation(fam, dust, tps, q_lcl, N_lcl, RH, T, rho):
+    """Oracle twin of cmx_p3_het_ice_nucleation_*: (dNdt, dLdt)."""
+    ins = [_col(fam, a) for a in (q_lcl, N_lcl, RH, T, rho)]
+    n = ins[0][0].size
+    dN, dL = np.empty(n, dtype=NP[fam.sfx]), np.empty(n, dtype=NP[fam.sfx])
+    fn = getattr(lib(), f"cmxo_p3_het_ice_nucleation_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(dust), C.byref(tps), C.c_int64(n), *[p for _, p in ins], dN.ctypes.data_as(C.c_void_p), dL.ctypes.data_as(C.c_void_p))
+    return dN, dL

@@ -181,3 +181,30 @@ def test_large_quadrature_orders(dev, oracle, quad):
         err = np.abs(x - r) / np.maximum(scale, 1e-300)
         err[(r == 0) & (x == 0)] = 0
         assert err.max() <= RTOL[ft], (quad, k, float(err.max()))
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_p3_het_ice_nucleation(dev, oracle, ft):
+    """cmx_p3_het_ice_nucleation_*: the reference's six known answers (test/p3_tests.jl:590-612) and random-state parity."""
+    import cmx
+    from test_p3_collisions_oracle import _het_freezing_inputs
+    g, tps64, ql, Nl, RH, T, rho = _het_freezing_inputs()
+    tps, dust = P.ThermodynamicsParameters(ft), P.Illite(ft)
+    col = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DT[ft]).to(dev)  # noqa: E731
+    r = cmx.p3_het_ice_nucleation(dust, tps, col(ql), col(Nl), col(RH), col(T), col(rho))
+    tol = 1e-9 if ft == "f64" else g["rtol_reference"]       # exp2(m·Δa_w·log2 10) with m ≈ 54: Float32 carries ≈1e-4 of J
+    np.testing.assert_allclose(_np64(r.dNdt), g["dNdt"], rtol=tol)
+    np.testing.assert_allclose(_np64(r.dLdt), g["dLdt"], rtol=tol)
+    rng = np.random.default_rng(4)
+    n = 100_000
+    T = rng.uniform(200, 272, n); RHr = rng.uniform(0.5, 1.15, n); rho = rng.uniform(0.3, 1.3, n)
+    ql = 10 ** rng.uniform(-7, -3, n); Nl = 10 ** rng.uniform(6, 9, n)
+    cols32 = [col(a) for a in (ql, Nl, RHr, T, rho)]
+    got = cmx.p3_het_ice_nucleation(dust, tps, *cols32)
+    c64 = [_np64(c) for c in cols32]
+    dN, dL = oracle.p3_het_ice_nucleation(_abi.F64, P.Illite("f64"), tps64, *c64)
+    ok = np.isfinite(dN) & (dN < (1e30 if ft == "f32" else 1e300)) & (dL < (1e30 if ft == "f32" else 1e300))
+    rt = 1e-9 if ft == "f64" else 2e-3
+    for x, r_ in ((_np64(got.dNdt), dN), (_np64(got.dLdt), dL)):
+        live = ok & (r_ > (1e-30 if ft == "f32" else 1e-290))
+        assert np.all(np.abs(x[live] - r_[live]) <= rt * r_[live]) and np.all(x >= 0)

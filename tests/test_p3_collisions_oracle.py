@@ -192,3 +192,27 @@ def test_fused_2m_p3_entry_properties(oracle):
     # rime mass never grows faster than ice mass through collisions + freezing alone when nothing sublimates or melts
     cold = ice & (s["T"] < tps.T_freeze - 1)
     assert cold.any()
+
+
+def _het_freezing_inputs():
+    g = G["het_freezing"]
+    tps = P.ThermodynamicsParameters("f64")
+    T, p = g["T"], g["p"]
+    qv = np.array(g["q_vap"])
+    eps = tps.R_d / tps.R_v
+    dcp = tps.cp_v - tps.cp_l
+    ps = tps.press_triple * (T / tps.T_triple) ** (dcp / tps.R_v) * math.exp((tps.LH_v0 - dcp * tps.T_0) / tps.R_v * (1 / tps.T_triple - 1 / T))
+    RH = p * qv / (eps + qv * (1 - eps)) / ps
+    rho = p / ((tps.R_d * (1 - (qv + g["q_lcl"])) + tps.R_v * qv) * T)
+    n = qv.size
+    return g, tps, np.full(n, g["q_lcl"]), np.full(n, g["N_lcl"]), RH, np.full(n, T), rho
+
+
+def test_p3_het_ice_nucleation_kats(oracle):
+    g, tps, ql, Nl, RH, T, rho = _het_freezing_inputs()
+    dN, dL = oracle.p3_het_ice_nucleation(F64, P.Illite("f64"), tps, ql, Nl, RH, T, rho)
+    np.testing.assert_allclose(dN, g["dNdt"], rtol=g["rtol_reproduced"])
+    np.testing.assert_allclose(dL, g["dLdt"], rtol=g["rtol_reproduced"])
+    # a non-finite J (huge RH in Float32) counts as no nucleation (src/P3_processes.jl:37-41)
+    dN32, dL32 = oracle.p3_het_ice_nucleation(F32, P.Illite("f32"), P.ThermodynamicsParameters("f32"), [2e-4], [1e8], [3.0], [244.0], [0.7])
+    assert dN32[0] == 0 and dL32[0] == 0
