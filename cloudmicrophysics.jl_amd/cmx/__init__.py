@@ -15,7 +15,7 @@ from .bulk_tendencies import (Chen2022VelTypeRain, Microphysics2Moment, SB2006Pr
                               bulk_2m_cloud_to_rain, cloud_terminal_velocity, column_sums, sb2006_process_rates)
 
 from .ice_nucleation import (IceNucleationRates, a_w_eT, a_w_ice, domain_error_count,  # noqa: F401
-                             ice_nucleation_rates)
+                             ice_nucleation_rates, liquid_freezing_rate)
 
 from .microphysics1m import (Instantaneous, LinearizedAverage, Microphysics1Moment, SedimentationVelocities, SourceTerms1M, Tendencies1M,  # noqa: F401
                              TerminalVelocities1M, bulk_microphysics_tendencies_1m,

@@ -23,6 +23,7 @@ CMX_P3_INPUT_IS_STATE = 1 << 0
 CMX_P3_SLOPE_CONSTANT = 1 << 1
 CMX_P3_NO_ASPECT_RATIO = 1 << 2
 CMX_P3_RAIN_PDF_LIMITED = 1 << 3
+CMX_FREEZE_CLOUD_PSD = 1 << 4
 CMX_QUAD_MAX = 128
 
 CMX_ICENUC_HOM_LINEAR = 1 << 0

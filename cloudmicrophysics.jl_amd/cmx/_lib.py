@@ -98,6 +98,9 @@ def _declare(lib):
         f = getattr(lib, f"cmx_p3_ice_self_collection_{s}")
         f.restype = i32
         f.argtypes = [C.POINTER(fam.p3_params), C.POINTER(fam.chen2022_ice_vel), C.POINTER(fam.quadrature), u32, i64] + [vp] * 7 + [vp]
+        f = getattr(lib, f"cmx_liquid_freezing_rate_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.p3_ice_params), C.POINTER(fam.thermo), u32, i64] + [vp] * 6 + [vp]
         f = getattr(lib, f"cmx_p3_het_ice_nucleation_{s}")
         f.restype = i32
         f.argtypes = [C.POINTER(fam.abifm_dust), C.POINTER(fam.thermo), i64] + [vp] * 7 + [vp]

@@ -90,3 +90,31 @@ def _water_activity(tps, T, e, stream):
         st = fn(C.byref(tps), ref.numel(), _ptr(T), _ptr(e), _ptr(ice), _ptr(eT), C.c_void_p(s.cuda_stream))
     _lib.check(fn.__name__, st)
     return ice, eT
+
+
+LiquidFreezingRate = namedtuple("LiquidFreezingRate", ["dn_frz", "dq_frz"])
+
+
+def liquid_freezing_rate(ice_params, tps, q, rho, N, T, *, cloud: bool = False, stream=None):
+    """`CMI_het.liquid_freezing_rate(rf, pdf, tps, q, ρ, N, T)` for every point — Bigg (1953) immersion freezing integrated over the
+    SB2006 rain PSD (src/IceNucleation.jl:274-311) or, with `cloud=True`, the generalized-gamma cloud PSD (:355-389).  `ice_params`
+    is a `P3IceParams` (its rain_freezing, rain_pdf / cloud_pdf members are used).  Returns (∂ₜn_frz [1/kg/s], ∂ₜq_frz [kg/kg/s])."""
+    from .parameters import P3IceParams
+    if not isinstance(ice_params, P3IceParams):
+        raise TypeError("ice_params must be P3IceParams")
+    cols = (q, rho, N, T)
+    for c in cols:
+        if not (c.is_cuda and c.is_contiguous() and c.dim() == 1 and c.dtype == q.dtype and c.numel() == q.numel()):
+            raise TypeError("columns must be contiguous 1-D GPU tensors of one dtype and length")
+    fam = _abi.family(q.dtype)
+    if fam is not ice_params.fam or not isinstance(tps, fam.thermo):
+        raise TypeError("parameter float type does not match the state columns")
+    out = LiquidFreezingRate(torch.empty_like(q), torch.empty_like(q))
+    flags = (_abi.CMX_FREEZE_CLOUD_PSD if cloud else 0) | (_abi.CMX_P3_RAIN_PDF_LIMITED if ice_params.is_limited else 0)
+    s = stream if stream is not None else torch.cuda.current_stream(q.device)
+    fn = getattr(_lib.lib(), f"cmx_liquid_freezing_rate_{fam.sfx}")
+    with torch.cuda.device(q.device):
+        st = fn(C.byref(ice_params.c), C.byref(tps), flags, q.numel(), *[C.c_void_p(t.data_ptr()) for t in cols],
+                C.c_void_p(out.dn_frz.data_ptr()), C.c_void_p(out.dq_frz.data_ptr()), C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return out

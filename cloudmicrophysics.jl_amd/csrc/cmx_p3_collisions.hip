@@ -654,6 +654,43 @@ static PointwiseConsts<FT> make_pointwise_consts(const WR &wr, const IP &ip, con
     k.inv_rho_i = (FT)(1.0 / (double)ip.scheme.rho_i);
     return k;
 }
+// liquid_freezing_rate(::RainFreezing, ::CloudParticlePDF_SB2006, …) — IceNucleation.jl:355-389: Bigg kinetics over the generalized-gamma
+// cloud PSD, M_D^k = n λc^(−k/μ) Γ((ν+1+k)/μ)/Γ((ν+1)/μ) with the Γ ratios folded on the host
+template <typename FT>
+__device__ __forceinline__ void bigg_cloud(const PointwiseConsts<FT> &k, FT J_bigg, FT rho, FT q_lcl, FT n_lcl, FT N_lcl, FT T, FT &bn, FT &bq) {
+    using P = PM<FT>;
+    const FT eps = P::eps();
+    bn = FT(0); bq = FT(0);
+    if (n_lcl > eps && q_lcl > eps && T < k.T_bigg && !(N_lcl < eps)) {
+        const FT log_lam_c = -k.mu_c * (P::log(rho * q_lcl / N_lcl) + k.lg_z1 - k.lg_z2) + k.log_km_mu;
+        bn = J_bigg * k.V1 * (n_lcl * P::exp(k.k3 * log_lam_c) * k.G3);
+        bq = J_bigg * k.rho_w_V1sq * (n_lcl * P::exp(k.k6 * log_lam_c) * k.G6);
+    }
+}
+// liquid_freezing_rate(::RainFreezing, pdf_r, …) — IceNucleation.jl:274-311: exponential rain PSD, M_D³ = 6 n D̄³, M_D⁶ = 720 n D̄⁶
+template <typename FT, bool LIMITED>
+__device__ __forceinline__ void bigg_rain(const PointwiseConsts<FT> &k, FT J_bigg, FT rho, FT q_rai, FT n_rai, FT N_rai, FT T, FT &rn, FT &rq) {
+    using P = PM<FT>;
+    using M = Math<FT>;
+    const FT eps = P::eps();
+    rn = FT(0); rq = FT(0);
+    if (n_rai > eps && q_rai > eps && T < k.T_bigg) {
+        const FT sq = q_rai, sN = M::max(N_rai, eps), L = rho * sq;
+        FT lam_r;
+        if constexpr (!LIMITED) lam_r = P::exp(P::log(k.pi_rho_w / (L / sN)) / FT(3));
+        else {
+            const FT xt = M::min(M::max(L / sN, k.xr_min), k.xr_max);
+            const FT N0 = M::min(M::max(sN * P::exp(P::log(k.pi_rho_w / xt) / FT(3)), k.N0_min), k.N0_max);
+            lam_r = M::min(M::max(M::sqrt(M::sqrt(k.pi_rho_w * N0 / L)), k.lam_min), k.lam_max);
+        }
+        FT Dr = FT(1) / lam_r;
+        if constexpr (!LIMITED) { if (N_rai < eps) Dr = FT(0); }                // gate of the not-limited PSD (CM2:83)
+        const FT D3 = Dr * Dr * Dr;
+        rn = J_bigg * k.V1 * (n_rai * FT(6) * D3);
+        rq = J_bigg * k.rho_w_V1sq * (n_rai * FT(720) * (D3 * D3));
+    }
+}
+
 template <typename FT> struct FusedIO {
     const FT *rho, *T, *q_tot, *q_lcl, *n_lcl, *q_rai, *n_rai, *q_ice, *n_ice, *q_rim, *b_rim, *shift;
     FT *out[8];
@@ -700,12 +737,8 @@ __global__ __launch_bounds__(kBlock) void mp2m_p3_pointwise_kernel(const SbConst
     }
     const FT J_bigg = k.rf_B * P::exp(k.rf_a * (k.T_freeze_tps - T));                // RainFreezing functor, parameters/IceNucleation.jl:146
     {   // Bigg freezing of cloud drops (:355-389) capped by the F23 budget (immersion_limit_rate :425-435) — BMT:1013-1034
-        FT bn = FT(0), bq = FT(0);
-        if (n_lcl > eps && q_lcl > eps && T < k.T_bigg && !(N_lcl < eps)) {
-            const FT log_lam_c = -k.mu_c * (P::log(rho * q_lcl / N_lcl) + k.lg_z1 - k.lg_z2) + k.log_km_mu;
-            bn = J_bigg * k.V1 * (n_lcl * P::exp(k.k3 * log_lam_c) * k.G3);
-            bq = J_bigg * k.rho_w_V1sq * (n_lcl * P::exp(k.k6 * log_lam_c) * k.G6);
-        }
+        FT bn, bq;
+        bigg_cloud<FT>(k, J_bigg, rho, q_lcl, n_lcl, N_lcl, T, bn, bq);
         const FT cap = T >= k.f23_T_freeze ? FT(0) : M::max(FT(0), inpc_kg - n_active) * k.inv_tau_act;
         const FT imm_n = M::min(bn, cap);
         const FT imm_q = bn > FT(0) ? bq * imm_n / bn : FT(0);
@@ -731,26 +764,46 @@ __global__ __launch_bounds__(kBlock) void mp2m_p3_pointwise_kernel(const SbConst
         dn_ice += (target - n_ice) * FT(0.01);
     }
     {   // Bigg freezing of rain — liquid_freezing_rate :274-311, BMT:1067-1075
-        FT rn = FT(0), rq = FT(0);
-        if (n_rai > eps && q_rai > eps && T < k.T_bigg) {
-            const FT sq = q_rai, sN = M::max(N_rai, eps), L = rho * sq;
-            FT lam_r;
-            if constexpr (!LIMITED) lam_r = P::exp(P::log(k.pi_rho_w / (L / sN)) / FT(3));
-            else {
-                const FT xt = M::min(M::max(L / sN, k.xr_min), k.xr_max);
-                const FT N0 = M::min(M::max(sN * P::exp(P::log(k.pi_rho_w / xt) / FT(3)), k.N0_min), k.N0_max);
-                lam_r = M::min(M::max(M::sqrt(M::sqrt(k.pi_rho_w * N0 / L)), k.lam_min), k.lam_max);
-            }
-            FT Dr = FT(1) / lam_r;
-            if constexpr (!LIMITED) { if (N_rai < eps) Dr = FT(0); }                // gate of the not-limited PSD (CM2:83)
-            const FT D3 = Dr * Dr * Dr;
-            rn = J_bigg * k.V1 * (n_rai * FT(6) * D3);
-            rq = J_bigg * k.rho_w_V1sq * (n_rai * FT(720) * (D3 * D3));
-        }
+        FT rn, rq;
+        bigg_rain<FT, LIMITED>(k, J_bigg, rho, q_rai, n_rai, N_rai, T, rn, rq);
         dq_rai -= rq; dn_rai -= rn; dq_ice += rq; dn_ice += rn; dq_rim += rq; db_rim += rq * k.inv_rho_i;
     }
     io.out[0][i] = dq_lcl; io.out[1][i] = dn_lcl; io.out[2][i] = dq_rai; io.out[3][i] = dn_rai;
     io.out[4][i] = dq_ice; io.out[5][i] = dn_ice; io.out[6][i] = dq_rim; io.out[7][i] = db_rim;
+}
+
+// stand-alone Bigg freezing rates (the KA kernel test_rain_freezing_kernel!, test/gpu_tests.jl:463-468): cloud = generalized-gamma PSD
+template <typename FT, bool CLOUD, bool LIMITED>
+__global__ __launch_bounds__(kBlock) void liquid_freezing_kernel(const PointwiseConsts<FT> k, const FT *__restrict__ q, const FT *__restrict__ rho,
+                                                                const FT *__restrict__ N, const FT *__restrict__ T, FT *__restrict__ dn,
+                                                                FT *__restrict__ dq, const int64_t n) {
+    using P = PM<FT>;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const FT r = rho[i], Ni = N[i], Ti = T[i], qi = q[i];
+    const FT J = k.rf_B * P::exp(k.rf_a * (k.T_freeze_tps - Ti));
+    FT a, b;
+    if constexpr (CLOUD) bigg_cloud<FT>(k, J, r, qi, Ni / r, Ni, Ti, a, b);
+    else bigg_rain<FT, LIMITED>(k, J, r, qi, Ni / r, Ni, Ti, a, b);
+    if (dn) dn[i] = a;
+    if (dq) dq[i] = b;
+}
+template <typename FT, typename IP, typename TH>
+static int32_t liquid_freezing_entry(const IP *ip, const TH *tps, uint32_t flags, int64_t n, const FT *q, const FT *rho, const FT *N, const FT *T,
+                                     FT *dn, FT *dq, void *stream) {
+    if (!ip || !tps || n < 0 || (flags & ~(uint32_t)(CMX_FREEZE_CLOUD_PSD | CMX_P3_RAIN_PDF_LIMITED))) return CMX_ERR_BAD_ARG;
+    if (n == 0) return CMX_OK;
+    if (!q || !rho || !N || !T || (!dn && !dq)) return CMX_ERR_BAD_ARG;
+    using WR = std::conditional_t<std::is_same_v<FT, float>, cmx_warm_rain_2m_f32, cmx_warm_rain_2m_f64>;
+    WR wr{};
+    const PointwiseConsts<FT> k = make_pointwise_consts<FT>(wr, *ip, *tps);
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (flags & CMX_FREEZE_CLOUD_PSD) hipLaunchKernelGGL((liquid_freezing_kernel<FT, true, true>), grid, block, 0, st, k, q, rho, N, T, dn, dq, n);
+    else if (flags & CMX_P3_RAIN_PDF_LIMITED) hipLaunchKernelGGL((liquid_freezing_kernel<FT, false, true>), grid, block, 0, st, k, q, rho, N, T, dn, dq, n);
+    else hipLaunchKernelGGL((liquid_freezing_kernel<FT, false, false>), grid, block, 0, st, k, q, rho, N, T, dn, dq, n);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
 }
 
 template <typename FT, typename WR, typename IP, typename TH>
@@ -837,6 +890,15 @@ int32_t cmx_microphysics_2m_p3_tendencies_f64(const cmx_warm_rain_2m_f64 *warm_r
                                               double *const *tendencies, void *stream) {
     return cmx::mp2m_p3_entry<double>(warm_rain, ice, tps, flags, n, rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice, n_ice, q_rim, b_rim, log_lambda,
                                       inpc_log_shift, tendencies, stream);
+}
+
+int32_t cmx_liquid_freezing_rate_f32(const cmx_p3_ice_params_f32 *ice, const cmx_thermo_f32 *tps, uint32_t flags, int64_t n, const float *q,
+                                     const float *rho, const float *N, const float *T, float *dn_frz, float *dq_frz, void *stream) {
+    return cmx::liquid_freezing_entry<float>(ice, tps, flags, n, q, rho, N, T, dn_frz, dq_frz, stream);
+}
+int32_t cmx_liquid_freezing_rate_f64(const cmx_p3_ice_params_f64 *ice, const cmx_thermo_f64 *tps, uint32_t flags, int64_t n, const double *q,
+                                     const double *rho, const double *N, const double *T, double *dn_frz, double *dq_frz, void *stream) {
+    return cmx::liquid_freezing_entry<double>(ice, tps, flags, n, q, rho, N, T, dn_frz, dq_frz, stream);
 }
 
 }  // extern "C"

@@ -635,6 +635,7 @@ int32_t cmx_arg2000_activation_columns_f64(
 #define CMX_P3_INPUT_IS_STATE   (1u << 0)   /* columns 3, 4 are (F_rim, ρ_rim) instead of (ρq_rim, ρb_rim) */
 #define CMX_P3_SLOPE_CONSTANT   (1u << 1)   /* SlopeConstant (μ = mu_const) instead of SlopePowerLaw */
 #define CMX_P3_NO_ASPECT_RATIO  (1u << 2)   /* CMP.NoAspectRatio() instead of the default CMP.Oblate() (velocities) */
+#define CMX_FREEZE_CLOUD_PSD     (1u << 4)   /* cmx_liquid_freezing_rate_*: cloud (generalized gamma) PSD instead of the rain PSD */
 #define CMX_P3_RAIN_PDF_LIMITED (1u << 3)   /* rain_pdf is RainParticlePDF_SB2006_limited (collisions, rain freezing, 2M+P3 entry) */
 
 int32_t cmx_p3_shape_f32(const cmx_p3_params_f32 *params, uint32_t flags, int32_t brent_iters, int64_t n, const float *rho_q_ice,
@@ -700,6 +701,17 @@ int32_t cmx_p3_het_ice_nucleation_f32(const cmx_abifm_dust_f32 *dust, const cmx_
 int32_t cmx_p3_het_ice_nucleation_f64(const cmx_abifm_dust_f64 *dust, const cmx_thermo_f64 *tps, int64_t n, const double *q_lcl,
                                       const double *N_lcl, const double *RH, const double *T, const double *rho_air, double *dNdt,
                                       double *dLdt, void *stream);
+
+/* Bigg (1953) immersion freezing of liquid drops: replaces, per point,
+ *   (; ∂ₜn_frz, ∂ₜq_frz) = CMI_het.liquid_freezing_rate(rf, pdf, tps, q, ρ, N, T)          src/IceNucleation.jl:274-311 (rain PSD),
+ *                                                                                            :355-389 (cloud PSD)
+ * (KA kernel test_rain_freezing_kernel!, test/gpu_tests.jl:463-468).  ice->rain_freezing, ice->rain_pdf / ice->cloud_pdf are read;
+ * flags: CMX_FREEZE_CLOUD_PSD selects the cloud method, CMX_P3_RAIN_PDF_LIMITED the limited rain PSD.  N is per m³; the rates are per
+ * kg of air.  Either output may be NULL. */
+int32_t cmx_liquid_freezing_rate_f32(const cmx_p3_ice_params_f32 *ice, const cmx_thermo_f32 *tps, uint32_t flags, int64_t n, const float *q,
+                                     const float *rho, const float *N, const float *T, float *dn_frz, float *dq_frz, void *stream);
+int32_t cmx_liquid_freezing_rate_f64(const cmx_p3_ice_params_f64 *ice, const cmx_thermo_f64 *tps, uint32_t flags, int64_t n, const double *q,
+                                     const double *rho, const double *N, const double *T, double *dn_frz, double *dq_frz, void *stream);
 
 /* (8) P3 liquid–ice collisions: replaces, per point,
  *   rates   = P3.∫liquid_ice_collisions(state, logλ, psd_c, psd_r, L_c, N_c, L_r, N_r, aps, tps, vel, ρₐ, T, m_liq; quad)

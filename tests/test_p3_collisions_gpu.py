@@ -208,3 +208,31 @@ def test_p3_het_ice_nucleation(dev, oracle, ft):
     for x, r_ in ((_np64(got.dNdt), dN), (_np64(got.dLdt), dL)):
         live = ok & (r_ > (1e-30 if ft == "f32" else 1e-290))
         assert np.all(np.abs(x[live] - r_[live]) <= rt * r_[live]) and np.all(x >= 0)
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+@pytest.mark.parametrize("psd", ["cloud", "rain_limited", "rain_notlimited"])
+def test_liquid_freezing_rate(dev, oracle, ft, psd):
+    """cmx_liquid_freezing_rate_*: Bigg freezing over the cloud / rain PSD against the oracle (test/gpu_tests.jl:1072-1091 and
+    test/heterogeneous_ice_nucleation_tests.jl:430-480: colder ⇒ larger, −4 °C gate, zero N or q ⇒ zero)."""
+    import cmx
+    limited = psd != "rain_notlimited"
+    cloud = psd == "cloud"
+    ip, tps = P.P3IceParams(ft, is_limited=limited), P.ThermodynamicsParameters(ft)
+    rng = np.random.default_rng(8)
+    n = 50_000
+    T = rng.uniform(235, 275, n); rho = rng.uniform(0.3, 1.3, n)
+    q = np.where(rng.random(n) < 0.9, 10 ** rng.uniform(-7, -3, n), 0.0)
+    N = np.where(rng.random(n) < 0.95, 10 ** (rng.uniform(6, 9, n) if cloud else rng.uniform(1, 6, n)), 0.0)
+    cols = [torch.from_numpy(a).to(DT[ft]).to(dev) for a in (q, rho, N, T)]
+    got = cmx.liquid_freezing_rate(ip, tps, *cols, cloud=cloud)
+    c64 = [_np64(c) for c in cols]
+    ip64 = P.P3IceParams("f64", is_limited=limited)
+    dn, dq = oracle.liquid_freezing_rate(_abi.F64, ip64.c.rain_freezing, ip64.c.cloud_pdf if cloud else ip64.c.rain_pdf,
+                                         P.ThermodynamicsParameters("f64"), *c64, cloud=cloud, limited=limited, float32_gates=(ft == "f32"))
+    for x, r in ((_np64(got.dn_frz), dn), (_np64(got.dq_frz), dq)):
+        assert np.array_equal(x == 0, r == 0)
+        live = (r > (1e-30 if ft == "f32" else 1e-290)) & (r < (1e30 if ft == "f32" else 1e290))
+        assert np.all(np.abs(x[live] - r[live]) <= RTOL[ft] * r[live]) and live.mean() > 0.3
+    warm = c64[3] >= tps.T_freeze - 4
+    assert warm.any() and np.all(_np64(got.dn_frz)[warm] == 0)
