@@ -18,7 +18,7 @@ from .ice_nucleation import (IceNucleationRates, a_w_eT, a_w_ice, domain_error_c
                              ice_nucleation_rates, liquid_freezing_rate)
 
 from .microphysics1m import (Instantaneous, LinearizedAverage, Microphysics1Moment, SedimentationVelocities, SourceTerms1M, Tendencies1M,  # noqa: F401
-                             TerminalVelocities1M, bulk_microphysics_tendencies_1m,
+                             TerminalVelocities1M, bulk_microphysics_tendencies_1m, bulk_microphysics_tendencies_1m_fields,
                              microphysics_source_terms_1m, sedimentation_velocities, terminal_velocity_1m)
 
 from .aerosol import (ActivationResult, AerosolDistribution, ModeColumns, Mode_B, Mode_kappa, aerosol_activation,  # noqa: F401

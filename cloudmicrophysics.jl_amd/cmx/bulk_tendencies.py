@@ -179,6 +179,47 @@ def _segments(t: torch.Tensor, name: str):
     raise TypeError(f"{name}: expected a contiguous 1-D column or a (n_seg, seg_len) view with contiguous rows")
 
 
+def _fields_call(fn_name, params_c, tps, flags, cols, names, n_out, n_aos, out, aos, stream):
+    """Shared driver of the `_fields` entry points (segmented columns in; segmented columns or an (n, n_aos) array of rows out)."""
+    ref = cols[0]
+    fam = _fam_of(ref)
+    n_seg, seg_len, _ = _segments(ref, names[0])
+    strides = []
+    for c, nm in zip(cols, names):
+        if not c.is_cuda or c.device != ref.device or c.dtype != ref.dtype:
+            raise TypeError(f"{nm}: all columns must live on the same GPU with the same dtype")
+        ns, sl, st = _segments(c, nm)
+        if (ns, sl) != (n_seg, seg_len):
+            raise ValueError(f"{nm}: shape differs from {names[0]}")
+        strides.append(st)
+    n = n_seg * seg_len
+    in_p = (C.c_void_p * len(cols))(*[c.data_ptr() for c in cols])
+    in_s = (C.c_int64 * len(cols))(*strides)
+    out_p = out_s = aos_t = None
+    if aos:
+        if out is not None:
+            raise TypeError("out is the SoA form; aos=True allocates the array-of-rows result")
+        aos_t = torch.empty((n, n_aos), dtype=ref.dtype, device=ref.device)
+    else:
+        if out is None:
+            out = [torch.empty(ref.shape, dtype=ref.dtype, device=ref.device) for _ in range(n_out)]
+        ostr = []
+        for o in out:
+            ns, sl, st = _segments(o, "out")
+            if (ns, sl) != (n_seg, seg_len) or o.dtype != ref.dtype or o.device != ref.device:
+                raise ValueError("out: shape / dtype / device differs from the inputs")
+            ostr.append(st)
+        out_p = (C.c_void_p * n_out)(*[o.data_ptr() for o in out])
+        out_s = (C.c_int64 * n_out)(*ostr)
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"{fn_name}_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(params_c), C.byref(tps), flags, n_seg, seg_len, in_p, in_s, out_p, out_s, C.c_void_p(aos_t.data_ptr()) if aos else None,
+                C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return aos_t if aos else out
+
+
 def bulk_microphysics_tendencies_fields(scheme, mp, tps, rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, *, out=None, aos=False, stream=None):
     """The 2-moment warm-rain tendencies (BMT:820-854) on the host model's own storage — zero-copy layout adapters of
     `cmx_sb2006_warm_rain_tendencies_fields_*`:
@@ -195,47 +236,13 @@ def bulk_microphysics_tendencies_fields(scheme, mp, tps, rho, T, q_tot, q_lcl, n
         raise TypeError("only Microphysics2Moment() is on this path")
     wr = _warm_rain(mp)
     cols = (rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai)
-    names = ("rho", "T", "q_tot", "q_lcl", "n_lcl", "q_rai", "n_rai")
-    ref = cols[0]
-    fam = _fam_of(ref)
+    fam = _fam_of(rho)
     if fam is not wr.fam or not isinstance(tps, fam.thermo):
         raise TypeError("parameter float type does not match the state columns")
-    n_seg, seg_len, _ = _segments(ref, "rho")
-    strides = []
-    for c, nm in zip(cols, names):
-        if not c.is_cuda or c.device != ref.device or c.dtype != ref.dtype:
-            raise TypeError(f"{nm}: all columns must live on the same GPU with the same dtype")
-        ns, sl, st = _segments(c, nm)
-        if (ns, sl) != (n_seg, seg_len):
-            raise ValueError(f"{nm}: shape differs from rho")
-        strides.append(st)
-    n = n_seg * seg_len
-    in_p = (C.c_void_p * 7)(*[c.data_ptr() for c in cols])
-    in_s = (C.c_int64 * 7)(*strides)
-    out_p = out_s = aos_t = None
-    if aos:
-        if out is not None:
-            raise TypeError("out is the SoA form; aos=True allocates the (n, 8) result")
-        aos_t = torch.empty((n, 8), dtype=ref.dtype, device=ref.device)
-    else:
-        if out is None:
-            out = [torch.empty(ref.shape, dtype=ref.dtype, device=ref.device) for _ in range(4)]
-        ostr = []
-        for o in out:
-            ns, sl, st = _segments(o, "out")
-            if (ns, sl) != (n_seg, seg_len) or o.dtype != ref.dtype or o.device != ref.device:
-                raise ValueError("out: shape / dtype / device differs from rho")
-            ostr.append(st)
-        out_p = (C.c_void_p * 4)(*[o.data_ptr() for o in out])
-        out_s = (C.c_int64 * 4)(*ostr)
     flags = _abi.CMX_SB2006_LIMITED if wr.is_limited else 0
-    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
-    fn = getattr(_lib.lib(), f"cmx_sb2006_warm_rain_tendencies_fields_{fam.sfx}")
-    with torch.cuda.device(ref.device):
-        st = fn(C.byref(wr.c), C.byref(tps), flags, n_seg, seg_len, in_p, in_s, out_p, out_s, C.c_void_p(aos_t.data_ptr()) if aos else None,
-                C.c_void_p(s.cuda_stream))
-    _lib.check(fn.__name__, st)
-    return aos_t if aos else WarmRainTendencies2M(*out, None, None)
+    r = _fields_call("cmx_sb2006_warm_rain_tendencies_fields", wr.c, tps, flags, cols, ("rho", "T", "q_tot", "q_lcl", "n_lcl", "q_rai", "n_rai"),
+                     4, 8, out, aos, stream)
+    return r if aos else WarmRainTendencies2M(*r, None, None)
 
 
 def sb2006_process_rates(mp, tps, q_tot, q_lcl, q_rai, N_lcl, N_rai, rho, T, *, vel=SB2006VelType, stream=None):

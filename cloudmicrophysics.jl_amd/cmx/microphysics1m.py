@@ -16,7 +16,7 @@ from collections import namedtuple
 import torch
 
 from . import _abi, _lib
-from .bulk_tendencies import _check_cols, _fam_of, _ptr
+from .bulk_tendencies import _check_cols, _fam_of, _fields_call, _ptr
 from .parameters import Chen2022VelTypeRain, Microphysics1MParams
 
 
@@ -84,6 +84,23 @@ def bulk_microphysics_tendencies_1m(mode, scheme, mp, tps, rho, T, q_tot, q_lcl,
                     C.c_void_p(s.cuda_stream))
     _lib.check(fn.__name__, st)
     return out
+
+
+def bulk_microphysics_tendencies_1m_fields(mode, scheme, mp, tps, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno, *, out=None, aos=False, stream=None):
+    """The Instantaneous 1-moment tendencies on the host model's own storage (`cmx_mp1m_tendencies_fields_*`): every column
+    a contiguous 1-D tensor or a (n_seg, seg_len) view with contiguous rows (a ClimaCore `VIJFH` field component in place); the result
+    goes into `out` (4 tensors of the same shape → `Tendencies1M`) or, with `aos=True`, into the reference's own result layout — an
+    (n, 4) tensor of NamedTuple rows (dq_lcl_dt, dq_icl_dt, dq_rai_dt, dq_sno_dt).  Bit-identical to `bulk_microphysics_tendencies_1m`."""
+    if not isinstance(scheme, Microphysics1Moment) or not isinstance(mode, Instantaneous):
+        raise TypeError("mode must be Instantaneous() and scheme Microphysics1Moment()")
+    if not isinstance(mp, Microphysics1MParams):
+        raise TypeError("mp must be Microphysics1MParams")
+    fam = _fam_of(rho)
+    if fam is not mp.fam or not isinstance(tps, fam.thermo):
+        raise TypeError("parameter float type does not match the state columns")
+    r = _fields_call("cmx_mp1m_tendencies_fields", mp.c, tps, mp.flags, (rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno),
+                     ("rho", "T", "q_tot", "q_lcl", "q_icl", "q_rai", "q_sno"), 4, 4, out, aos, stream)
+    return r if aos else Tendencies1M(*r)
 
 
 def microphysics_source_terms_1m(mp, tps, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno, *, stream=None) -> SourceTerms1M:

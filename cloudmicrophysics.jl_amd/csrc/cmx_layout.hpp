@@ -1,0 +1,147 @@
+// cmx_layout.hpp — host-model layout adapters shared by the bulk-tendency kernels.
+//
+// The per-point arithmetic of a fused tendency kernel behind two layouts:
+//   * SEGMENTED columns: column k is n_seg runs of seg_len contiguous elements, run s starting at base_k + s·stride_k.
+//     That is a ClimaCore field in its storage: a DataLayouts.VIJFH array (Nv, Ni, Nj, Nf, Nh) holds component f of
+//     element h as the contiguous run [v + Nv (i + Ni j)] of length Nv·Ni·Nj at offset Nv·Ni·Nj·(f + Nf h); VF columns
+//     and VIJHF are the single-run case.  Every column has its own stride (state and tendency fields differ in Nf).
+//   * AoS output: the reference's result type, an array of NamedTuples (2M warm rain: 8 fields, the last four identically
+//     zero — BMT:852-853, test/gpu_performance.jl:212-216; 1M: the 4 tendencies — BMT:246-251, test/gpu_performance.jl:178-182).
+//     A lane owns VEC consecutive points = VEC·NAOS contiguous values of the output; written directly that is a handful of
+//     16-byte stores at a large lane stride (partial cache lines).  The workgroup's tile goes through LDS instead (rows
+//     padded by 16 B) and leaves as fully coalesced 1-KiB-per-wave non-temporal stores.
+// POLICY supplies: NIN, NOUT, NAOS, Consts<FT>, and  static void point(const Consts&, const FT (&x)[NIN], FT (&y)[NOUT])
+// (clamps included); AoS rows are (y[0..NOUT), 0 …).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "cmx_launch.hpp"
+#include "cmx_math.hpp"
+
+namespace cmx {
+
+template <typename FT, int NIN, int NOUT> struct LayoutIO {
+    const FT *in[NIN];
+    int64_t in_stride[NIN];
+    FT *out[NOUT];            // SoA mode
+    int64_t out_stride[NOUT];
+    FT *aos;                  // n × NAOS (AoS mode)
+    int64_t seg_len;
+    double inv_seg_len;
+};
+
+template <typename FT, typename POLICY, int VEC, bool SEG, bool AOS, int BS = kBlock>
+__global__ __launch_bounds__(BS) void tendencies_layout_kernel(const typename POLICY::Consts c,
+                                                               const LayoutIO<FT, POLICY::NIN, POLICY::NOUT> io, const int64_t nvec) {
+    constexpr int NIN = POLICY::NIN, NOUT = POLICY::NOUT, NAOS = POLICY::NAOS;
+    constexpr int CH = 16 / (int)sizeof(FT);                  // elements per 16-byte chunk
+    constexpr int ROW = VEC * NAOS + CH;                      // LDS row of one lane (+1 chunk of padding against bank conflicts)
+    static_assert((VEC * NAOS) % CH == 0, "a lane's AoS rows must be whole 16-byte chunks");
+    const int64_t tile0 = (int64_t)blockIdx.x * BS;
+    const int64_t i = tile0 + threadIdx.x;
+    const bool active = i < nvec;
+    FT y[VEC][NOUT];
+    int64_t seg = 0, off = i * VEC;                           // element index → (run, offset in run)
+    if constexpr (SEG) {
+        const int64_t e = i * VEC;
+        seg = (int64_t)((double)e * io.inv_seg_len);
+        off = e - seg * io.seg_len;
+        if (off < 0) { --seg; off += io.seg_len; }
+        if (off >= io.seg_len) { ++seg; off -= io.seg_len; }
+    }
+    if (active) {
+        FT x[NIN][VEC];
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) load_col<FT, VEC, true>(io.in[k] + (SEG ? seg * io.in_stride[k] : 0), off / VEC, x[k]);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            FT xi[NIN];
+#pragma unroll
+            for (int q = 0; q < NIN; ++q) xi[q] = x[q][k];
+            POLICY::point(c, xi, y[k]);
+        }
+    }
+    if constexpr (!AOS) {
+        if (!active) return;
+#pragma unroll
+        for (int q = 0; q < NOUT; ++q) {
+            FT col[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) col[k] = y[k][q];
+            store_col<FT, VEC, true>(io.out[q] + (SEG ? seg * io.out_stride[q] : 0), off / VEC, col);
+        }
+    } else {
+        extern __shared__ __align__(16) unsigned char lds_raw[];
+        FT *lds = reinterpret_cast<FT *>(lds_raw);
+        using V16 = typename VecT<FT, CH>::type;
+        if (active) {
+            FT *row = lds + threadIdx.x * ROW;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+#pragma unroll
+                for (int q = 0; q < NAOS; ++q) row[k * NAOS + q] = q < NOUT ? y[k][q < NOUT ? q : 0] : FT(0);
+            }
+        }
+        __syncthreads();
+        constexpr int CPL = VEC * NAOS / CH;                  // 16-byte chunks per lane
+        const int64_t nvalid = nvec - tile0 < BS ? nvec - tile0 : BS;
+        V16 *dst = reinterpret_cast<V16 *>(io.aos) + tile0 * CPL;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int t = j * BS + threadIdx.x;                // chunk of the tile, in output order
+            const int src = t / CPL, sub = t % CPL;
+            if (src < nvalid) __builtin_nontemporal_store(*reinterpret_cast<const V16 *>(lds + src * ROW + sub * CH), dst + t);
+        }
+    }
+}
+
+// host side: validation + launch shared by the `_fields` entry points
+template <typename FT, typename POLICY>
+static int32_t launch_layout(const typename POLICY::Consts &c, int64_t n_seg, int64_t seg_len, const FT *const *in, const int64_t *in_stride,
+                             FT *const *out, const int64_t *out_stride, FT *aos, hipStream_t s) {
+    constexpr int NIN = POLICY::NIN, NOUT = POLICY::NOUT, NAOS = POLICY::NAOS;
+    if (n_seg < 0 || seg_len < 0 || !in) return CMX_ERR_BAD_ARG;
+    if ((out != nullptr) == (aos != nullptr)) return CMX_ERR_BAD_ARG;                // exactly one output form
+    const int64_t n = n_seg * seg_len;
+    if (n == 0) return CMX_OK;
+    if (n_seg > 1 && (!in_stride || (out && !out_stride))) return CMX_ERR_BAD_ARG;
+    constexpr int VEC = Math<FT>::VEC;
+    bool vec_ok = seg_len % VEC == 0;
+    LayoutIO<FT, NIN, NOUT> io{};
+    for (int k = 0; k < NIN; ++k) {
+        if (!in[k]) return CMX_ERR_BAD_ARG;
+        io.in[k] = in[k]; io.in_stride[k] = n_seg > 1 ? in_stride[k] : 0;
+        if (n_seg > 1 && io.in_stride[k] < seg_len) return CMX_ERR_BAD_ARG;
+        vec_ok = vec_ok && aligned16(in[k]) && io.in_stride[k] % VEC == 0;
+    }
+    for (int k = 0; k < NOUT && out; ++k) {
+        if (!out[k]) return CMX_ERR_BAD_ARG;
+        io.out[k] = out[k]; io.out_stride[k] = n_seg > 1 ? out_stride[k] : 0;
+        if (n_seg > 1 && io.out_stride[k] < seg_len) return CMX_ERR_BAD_ARG;
+        vec_ok = vec_ok && aligned16(out[k]) && io.out_stride[k] % VEC == 0;
+    }
+    if (aos && !aligned16(aos)) return CMX_ERR_BAD_ARG;
+    io.aos = aos; io.seg_len = seg_len; io.inv_seg_len = 1.0 / (double)seg_len;
+    const bool seg = n_seg > 1;
+    auto launch = [&](auto vec_tag) {
+        constexpr int V = decltype(vec_tag)::value;
+        const int64_t nvec = n / V;
+        const dim3 grid((unsigned)((nvec + kBlock - 1) / kBlock)), block(kBlock);
+        const size_t lds = aos ? sizeof(FT) * (size_t)kBlock * (V * NAOS + 16 / sizeof(FT)) : 0;
+        if (seg) {
+            if (aos) hipLaunchKernelGGL((tendencies_layout_kernel<FT, POLICY, V, true, true>), grid, block, lds, s, c, io, nvec);
+            else hipLaunchKernelGGL((tendencies_layout_kernel<FT, POLICY, V, true, false>), grid, block, lds, s, c, io, nvec);
+        } else {
+            if (aos) hipLaunchKernelGGL((tendencies_layout_kernel<FT, POLICY, V, false, true>), grid, block, lds, s, c, io, nvec);
+            else hipLaunchKernelGGL((tendencies_layout_kernel<FT, POLICY, V, false, false>), grid, block, lds, s, c, io, nvec);
+        }
+    };
+    if (vec_ok) launch(std::integral_constant<int, VEC>{});
+    else launch(std::integral_constant<int, 1>{});
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+
+}  // namespace cmx

@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "cmx_launch.hpp"
+#include "cmx_layout.hpp"
 #include "cmx_math.hpp"
 
 namespace cmx {
@@ -319,6 +320,22 @@ template <typename FT> struct Mp1mIn { const FT *rho, *T, *q_tot, *q_lcl, *q_icl
 template <typename FT> struct Mp1mOut { FT *dq_lcl, *dq_icl, *dq_rai, *dq_sno; };
 template <typename FT> struct Mp1mSrcOut { FT *col[CMX_MP1M_NSRC]; };
 
+// _aggregate_tendencies — BMT:227-252 (same order of additions)
+template <typename FT> __device__ __forceinline__ void mp1m_aggregate(const FT *s, FT &dl, FT &di, FT &dr, FT &ds) {
+    dl = ((((s[CMX_1M_S_PHASE_CHANGE_VAP_LCL] - s[CMX_1M_S_ACNV_LCL_RAI]) - s[CMX_1M_S_ACCR_LCL_RAI]) -
+              s[CMX_1M_S_ACCR_LCL_SNO_COLD]) - s[CMX_1M_S_ACCR_LCL_SNO_WARM]) + s[CMX_1M_S_MELT_ICL_LCL];
+    di = (((s[CMX_1M_S_PHASE_CHANGE_VAP_ICL] - s[CMX_1M_S_ACNV_ICL_SNO]) - s[CMX_1M_S_ACCR_ICL_RAI]) -
+             s[CMX_1M_S_ACCR_ICL_SNO]) - s[CMX_1M_S_MELT_ICL_LCL];
+    dr = ((((((((s[CMX_1M_S_ACNV_LCL_RAI] + s[CMX_1M_S_ACCR_LCL_RAI]) + s[CMX_1M_S_ACCR_LCL_SNO_WARM]) +
+                  s[CMX_1M_S_ACCR_MELT_LCL_SNO]) - s[CMX_1M_S_ACCR_FREEZE_ICL_RAI]) - s[CMX_1M_S_ACCR_RAI_SNO_COLD]) +
+               s[CMX_1M_S_ACCR_RAI_SNO_WARM]) + s[CMX_1M_S_ACCR_MELT_RAI_SNO]) + s[CMX_1M_S_PHASE_CHANGE_VAP_RAI]) +
+            s[CMX_1M_S_MELT_SNO_RAI];
+    ds = (((((((((s[CMX_1M_S_ACNV_ICL_SNO] + s[CMX_1M_S_ACCR_LCL_SNO_COLD]) - s[CMX_1M_S_ACCR_MELT_LCL_SNO]) +
+                   s[CMX_1M_S_ACCR_ICL_RAI]) + s[CMX_1M_S_ACCR_FREEZE_ICL_RAI]) + s[CMX_1M_S_ACCR_ICL_SNO]) +
+                s[CMX_1M_S_ACCR_RAI_SNO_COLD]) - s[CMX_1M_S_ACCR_RAI_SNO_WARM]) - s[CMX_1M_S_ACCR_MELT_RAI_SNO]) +
+             s[CMX_1M_S_PHASE_CHANGE_VAP_SNO]) - s[CMX_1M_S_MELT_SNO_RAI];
+}
+
 // bulk_microphysics_tendencies(Instantaneous(), Microphysics1Moment(), …) over columns — BMT:505-514
 template <typename FT, int VEC, uint32_t FLAGS = kRuntimeFlags>
 __global__ __launch_bounds__(kBlock) void mp1m_tendencies_kernel(const Mp1mConsts<FT> c, const Mp1mIn<FT> in,
@@ -333,20 +350,7 @@ __global__ __launch_bounds__(kBlock) void mp1m_tendencies_kernel(const Mp1mConst
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
         const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(c, rho[k], T[k], q_tot[k], q_lcl[k], q_icl[k], q_rai[k], q_sno[k]);
-        const FT *s = p.s;
-        // _aggregate_tendencies — BMT:227-252 (same order of additions)
-        dl[k] = ((((s[CMX_1M_S_PHASE_CHANGE_VAP_LCL] - s[CMX_1M_S_ACNV_LCL_RAI]) - s[CMX_1M_S_ACCR_LCL_RAI]) -
-                  s[CMX_1M_S_ACCR_LCL_SNO_COLD]) - s[CMX_1M_S_ACCR_LCL_SNO_WARM]) + s[CMX_1M_S_MELT_ICL_LCL];
-        di[k] = (((s[CMX_1M_S_PHASE_CHANGE_VAP_ICL] - s[CMX_1M_S_ACNV_ICL_SNO]) - s[CMX_1M_S_ACCR_ICL_RAI]) -
-                 s[CMX_1M_S_ACCR_ICL_SNO]) - s[CMX_1M_S_MELT_ICL_LCL];
-        dr[k] = ((((((((s[CMX_1M_S_ACNV_LCL_RAI] + s[CMX_1M_S_ACCR_LCL_RAI]) + s[CMX_1M_S_ACCR_LCL_SNO_WARM]) +
-                      s[CMX_1M_S_ACCR_MELT_LCL_SNO]) - s[CMX_1M_S_ACCR_FREEZE_ICL_RAI]) - s[CMX_1M_S_ACCR_RAI_SNO_COLD]) +
-                   s[CMX_1M_S_ACCR_RAI_SNO_WARM]) + s[CMX_1M_S_ACCR_MELT_RAI_SNO]) + s[CMX_1M_S_PHASE_CHANGE_VAP_RAI]) +
-                s[CMX_1M_S_MELT_SNO_RAI];
-        ds[k] = (((((((((s[CMX_1M_S_ACNV_ICL_SNO] + s[CMX_1M_S_ACCR_LCL_SNO_COLD]) - s[CMX_1M_S_ACCR_MELT_LCL_SNO]) +
-                       s[CMX_1M_S_ACCR_ICL_RAI]) + s[CMX_1M_S_ACCR_FREEZE_ICL_RAI]) + s[CMX_1M_S_ACCR_ICL_SNO]) +
-                    s[CMX_1M_S_ACCR_RAI_SNO_COLD]) - s[CMX_1M_S_ACCR_RAI_SNO_WARM]) - s[CMX_1M_S_ACCR_MELT_RAI_SNO]) +
-                 s[CMX_1M_S_PHASE_CHANGE_VAP_SNO]) - s[CMX_1M_S_MELT_SNO_RAI];
+        mp1m_aggregate<FT>(p.s, dl[k], di[k], dr[k], ds[k]);
     }
     store_col<FT, VEC>(out.dq_lcl, i, dl); store_col<FT, VEC>(out.dq_icl, i, di);
     store_col<FT, VEC>(out.dq_rai, i, dr); store_col<FT, VEC>(out.dq_sno, i, ds);
@@ -570,6 +574,27 @@ static int32_t tendencies_1m_entry(const MP *mp, const TH *tps, uint32_t flags, 
     return CMX_OK;
 }
 
+// host-model layouts: the Instantaneous tendencies as a policy of the generic adapter kernel (cmx_layout.hpp)
+template <typename FT, uint32_t FLAGS> struct Mp1mLayoutPolicy {
+    static constexpr int NIN = 7, NOUT = 4, NAOS = 4;   // rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno → (dq_lcl_dt, dq_icl_dt, dq_rai_dt, dq_sno_dt)
+    using Consts = Mp1mConsts<FT>;
+    static __device__ __forceinline__ void point(const Consts &c, const FT (&x)[NIN], FT (&y)[NOUT]) {
+        const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(c, x[0], x[1], x[2], x[3], x[4], x[5], x[6]);
+        mp1m_aggregate<FT>(p.s, y[0], y[1], y[2], y[3]);
+    }
+};
+template <typename FT, typename MP, typename TH>
+static int32_t fields_1m_entry(const MP *mp, const TH *tps, uint32_t flags, int64_t n_seg, int64_t seg_len, const FT *const *in,
+                               const int64_t *in_stride, FT *const *out, const int64_t *out_stride, FT *aos, void *stream) {
+    if (!mp || !tps) return CMX_ERR_BAD_ARG;
+    if (const int32_t st = check_flags_1m(flags)) return st;
+    const Mp1mConsts<FT> c = make_mp1m_consts<FT>(*mp, *tps, flags, (double)Math<FT>::eps_1m());
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (flags == CMX_1M_DEFAULT_OPTIONS)
+        return launch_layout<FT, Mp1mLayoutPolicy<FT, CMX_1M_DEFAULT_OPTIONS>>(c, n_seg, seg_len, in, in_stride, out, out_stride, aos, s);
+    return launch_layout<FT, Mp1mLayoutPolicy<FT, kRuntimeFlags>>(c, n_seg, seg_len, in, in_stride, out, out_stride, aos, s);
+}
+
 template <typename FT, typename MP, typename TH>
 static int32_t linearized_1m_entry(const MP *mp, const TH *tps, uint32_t flags, FT q_min, FT dt, int32_t nsub, int64_t n, const FT *rho,
                                    const FT *T, const FT *q_tot, const FT *q_lcl, const FT *q_icl, const FT *q_rai, const FT *q_sno,
@@ -748,6 +773,16 @@ int32_t cmx_mp1m_tendencies_f64(const cmx_microphysics_1m_f64 *mp, const cmx_the
                                 double *dq_icl_dt, double *dq_rai_dt, double *dq_sno_dt, void *stream) {
     return cmx::tendencies_1m_entry<double>(mp, tps, flags, n, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno, dq_lcl_dt, dq_icl_dt,
                                             dq_rai_dt, dq_sno_dt, stream);
+}
+int32_t cmx_mp1m_tendencies_fields_f32(const cmx_microphysics_1m_f32 *mp, const cmx_thermo_f32 *tps, uint32_t flags, int64_t n_seg, int64_t seg_len,
+                                       const float *const *in, const int64_t *in_seg_stride, float *const *out, const int64_t *out_seg_stride,
+                                       float *out_aos, void *stream) {
+    return cmx::fields_1m_entry<float>(mp, tps, flags, n_seg, seg_len, in, in_seg_stride, out, out_seg_stride, out_aos, stream);
+}
+int32_t cmx_mp1m_tendencies_fields_f64(const cmx_microphysics_1m_f64 *mp, const cmx_thermo_f64 *tps, uint32_t flags, int64_t n_seg, int64_t seg_len,
+                                       const double *const *in, const int64_t *in_seg_stride, double *const *out, const int64_t *out_seg_stride,
+                                       double *out_aos, void *stream) {
+    return cmx::fields_1m_entry<double>(mp, tps, flags, n_seg, seg_len, in, in_seg_stride, out, out_seg_stride, out_aos, stream);
 }
 int32_t cmx_mp1m_source_terms_f32(const cmx_microphysics_1m_f32 *mp, const cmx_thermo_f32 *tps, uint32_t flags, int64_t n,
                                   const float *rho, const float *T, const float *q_tot, const float *q_lcl, const float *q_icl,

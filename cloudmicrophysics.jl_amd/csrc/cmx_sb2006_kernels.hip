@@ -92,55 +92,16 @@ static int32_t tendencies_entry(const WR *wr, const TH *tps, const VL *vel, uint
 }
 
 // cmx_sb2006_warm_rain_tendencies_fields_*: segmented (ClimaCore field) columns in, segmented columns or the reference's
-// array-of-NamedTuples out — see sb2006_tendencies_layout_kernel
+// array-of-NamedTuples out — cmx_layout.hpp with Sb2006LayoutPolicy
 template <typename FT, typename WR, typename TH>
 static int32_t fields_entry(const WR *wr, const TH *tps, uint32_t flags, int64_t n_seg, int64_t seg_len, const FT *const *in,
                             const int64_t *in_stride, FT *const *out, const int64_t *out_stride, FT *aos, void *stream) {
-    if (!wr || !tps || n_seg < 0 || seg_len < 0 || !in || (flags & ~(uint32_t)CMX_SB2006_LIMITED)) return CMX_ERR_BAD_ARG;
-    if ((out != nullptr) == (aos != nullptr)) return CMX_ERR_BAD_ARG;                // exactly one output form
-    const int64_t n = n_seg * seg_len;
-    if (n == 0) return CMX_OK;
-    if (n_seg > 1 && (!in_stride || (out && !out_stride))) return CMX_ERR_BAD_ARG;
-    constexpr int VEC = Math<FT>::VEC;
-    bool vec_ok = seg_len % VEC == 0;
-    SbLayoutIO<FT> io{};
-    for (int k = 0; k < 7; ++k) {
-        if (!in[k]) return CMX_ERR_BAD_ARG;
-        io.in[k] = in[k]; io.in_stride[k] = n_seg > 1 ? in_stride[k] : 0;
-        if (n_seg > 1 && io.in_stride[k] < seg_len) return CMX_ERR_BAD_ARG;
-        vec_ok = vec_ok && aligned16(in[k]) && io.in_stride[k] % VEC == 0;
-    }
-    for (int k = 0; k < 4 && out; ++k) {
-        if (!out[k]) return CMX_ERR_BAD_ARG;
-        io.out[k] = out[k]; io.out_stride[k] = n_seg > 1 ? out_stride[k] : 0;
-        if (n_seg > 1 && io.out_stride[k] < seg_len) return CMX_ERR_BAD_ARG;
-        vec_ok = vec_ok && aligned16(out[k]) && io.out_stride[k] % VEC == 0;
-    }
-    if (aos && !aligned16(aos)) return CMX_ERR_BAD_ARG;                               // rows are 8 FT = 32 / 64 B
-    io.aos = aos; io.seg_len = seg_len; io.inv_seg_len = 1.0 / (double)seg_len;
-    const bool limited = flags & CMX_SB2006_LIMITED, seg = n_seg > 1;
+    if (!wr || !tps || (flags & ~(uint32_t)CMX_SB2006_LIMITED)) return CMX_ERR_BAD_ARG;
     const SbConsts<FT> c = make_sb_consts<FT>(*wr, *tps, (const std::conditional_t<std::is_same_v<FT, float>, cmx_rain_vel_f32, cmx_rain_vel_f64> *)nullptr,
                                               (double)Math<FT>::eps_1m());
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    auto launch = [&](auto vec_tag) {
-        constexpr int V = decltype(vec_tag)::value;
-        const int64_t nvec = n / V;
-        const dim3 grid((unsigned)((nvec + kBlock - 1) / kBlock)), block(kBlock);
-        const size_t lds = aos ? sizeof(FT) * (size_t)kBlock * (V * 8 + 16 / sizeof(FT)) : 0;
-#define CMX_LAUNCH(L, S, A) hipLaunchKernelGGL((sb2006_tendencies_layout_kernel<FT, L, V, S, A>), grid, block, lds, s, c, io, nvec)
-        if (limited) {
-            if (seg) { if (aos) CMX_LAUNCH(true, true, true); else CMX_LAUNCH(true, true, false); }
-            else     { if (aos) CMX_LAUNCH(true, false, true); else CMX_LAUNCH(true, false, false); }
-        } else {
-            if (seg) { if (aos) CMX_LAUNCH(false, true, true); else CMX_LAUNCH(false, true, false); }
-            else     { if (aos) CMX_LAUNCH(false, false, true); else CMX_LAUNCH(false, false, false); }
-        }
-#undef CMX_LAUNCH
-    };
-    if (vec_ok) launch(std::integral_constant<int, VEC>{});
-    else launch(std::integral_constant<int, 1>{});
-    CMX_HIP_TRY(hipGetLastError());
-    return CMX_OK;
+    if (flags & CMX_SB2006_LIMITED) return launch_layout<FT, Sb2006LayoutPolicy<FT, true>>(c, n_seg, seg_len, in, in_stride, out, out_stride, aos, s);
+    return launch_layout<FT, Sb2006LayoutPolicy<FT, false>>(c, n_seg, seg_len, in, in_stride, out, out_stride, aos, s);
 }
 
 template <typename FT, typename WR, typename TH, typename VL>

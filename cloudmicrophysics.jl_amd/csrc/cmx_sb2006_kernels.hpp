@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include "cmx_launch.hpp"
+#include "cmx_layout.hpp"
 #include "cmx_sb2006.hpp"
 
 namespace cmx {
@@ -82,88 +83,21 @@ __global__ __launch_bounds__(BS) void sb2006_tendencies_kernel(const SbConsts<FT
     }
 }
 
-// ---- host-model layouts -------------------------------------------------------------------------------
-// The same per-point arithmetic as sb2006_tendencies_kernel (VEL_NONE) behind two layout adapters:
-//   * SEGMENTED columns: column k is n_seg runs of seg_len contiguous elements, run s starting at base_k + s·stride_k.
-//     That is a ClimaCore field in its storage: a DataLayouts.VIJFH array (Nv, Ni, Nj, Nf, Nh) holds component f of
-//     element h as the contiguous run [v + Nv (i + Ni j)] of length Nv·Ni·Nj at offset Nv·Ni·Nj·(f + Nf h); VF columns
-//     and VIJHF are the single-run case.  Every column has its own stride (state and tendency fields differ in Nf).
-//   * AoS output: the reference's result type, an array of 8-field NamedTuples (dq_lcl_dt, dn_lcl_dt, dq_rai_dt, dn_rai_dt,
-//     dq_ice_dt, dq_rim_dt, db_rim_dt, dn_lcl_activation_dt — BMT:852-853; test/gpu_performance.jl:212-216), the last
-//     four identically zero.  A lane owns VEC consecutive points = 128 B of the output; written directly that is 8
-//     store instructions of 16 B at a 128-B lane stride (64 partial cache lines each).  The tile goes through LDS
-//     instead and leaves as 8 fully coalesced 1-KiB-per-wave stores.
-template <typename FT> struct SbLayoutIO {
-    const FT *in[7];          // rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai
-    int64_t in_stride[7];
-    FT *out[4];               // dq_lcl, dn_lcl, dq_rai, dn_rai (SoA mode)
-    int64_t out_stride[4];
-    FT *aos;                  // n × 8 (AoS mode)
-    int64_t seg_len;
-    double inv_seg_len;
+// ---- host-model layouts: the VEL_NONE tendencies as a policy of the generic adapter kernel (cmx_layout.hpp) ---
+template <typename FT, bool LIMITED> struct Sb2006LayoutPolicy {
+    static constexpr int NIN = 7, NOUT = 4, NAOS = 8;       // rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai → dq_lcl, dn_lcl, dq_rai, dn_rai (+4 zero fields)
+    using Consts = SbConsts<FT>;
+    static __device__ __forceinline__ void point(const Consts &c, const FT (&x)[NIN], FT (&y)[NOUT]) {
+        using M = Math<FT>;
+        const FT r_ = M::max(FT(0), x[0]), qt = M::max(FT(0), x[2]), ql = M::max(FT(0), x[3]);
+        const FT nl = M::max(FT(0), x[4]), qr = M::max(FT(0), x[5]), nr = M::max(FT(0), x[6]);
+        const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL_NONE>(c, r_, x[1], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
+        y[0] = (p.cond + p.au_dq_lcl) + p.ac_dq_lcl;
+        y[1] = M::fma(p.lsc_plus_au + p.ac_dN_lcl, p.inv_rho, p.na_lcl);
+        y[2] = (p.evq + p.au_dq_rai) + p.ac_dq_rai;
+        y[3] = M::fma(((p.evN + p.au_dN_rai) + p.rsc) + p.rbr, p.inv_rho, p.na_rai);
+    }
 };
-template <typename FT, bool LIMITED, int VEC, bool SEG, bool AOS, int BS = kBlock>
-__global__ __launch_bounds__(BS) void sb2006_tendencies_layout_kernel(const SbConsts<FT> c, const SbLayoutIO<FT> io, const int64_t nvec) {
-    using M = Math<FT>;
-    constexpr int CH = 16 / (int)sizeof(FT);                  // elements per 16-byte chunk
-    constexpr int ROW = VEC * 8 + CH;                         // LDS row of one lane (+1 chunk of padding against bank conflicts)
-    const int64_t tile0 = (int64_t)blockIdx.x * BS;
-    const int64_t i = tile0 + threadIdx.x;
-    const bool active = i < nvec;
-    FT dq_lcl[VEC], dn_lcl[VEC], dq_rai[VEC], dn_rai[VEC];
-    int64_t seg = 0, off = i * VEC;                           // element index → (run, offset in run)
-    if constexpr (SEG) {
-        const int64_t e = i * VEC;
-        seg = (int64_t)((double)e * io.inv_seg_len);
-        off = e - seg * io.seg_len;
-        if (off < 0) { --seg; off += io.seg_len; }
-        if (off >= io.seg_len) { ++seg; off -= io.seg_len; }
-    }
-    if (active) {
-        FT x[7][VEC];
-#pragma unroll
-        for (int k = 0; k < 7; ++k) load_col<FT, VEC, true>(io.in[k] + (SEG ? seg * io.in_stride[k] : 0), off / VEC, x[k]);
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            const FT r_ = M::max(FT(0), x[0][k]), qt = M::max(FT(0), x[2][k]), ql = M::max(FT(0), x[3][k]);
-            const FT nl = M::max(FT(0), x[4][k]), qr = M::max(FT(0), x[5][k]), nr = M::max(FT(0), x[6][k]);
-            const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL_NONE>(c, r_, x[1][k], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
-            dq_lcl[k] = (p.cond + p.au_dq_lcl) + p.ac_dq_lcl;
-            dn_lcl[k] = M::fma(p.lsc_plus_au + p.ac_dN_lcl, p.inv_rho, p.na_lcl);
-            dq_rai[k] = (p.evq + p.au_dq_rai) + p.ac_dq_rai;
-            dn_rai[k] = M::fma(((p.evN + p.au_dN_rai) + p.rsc) + p.rbr, p.inv_rho, p.na_rai);
-        }
-    }
-    if constexpr (!AOS) {
-        if (!active) return;
-        store_col<FT, VEC, true>(io.out[0] + (SEG ? seg * io.out_stride[0] : 0), off / VEC, dq_lcl);
-        store_col<FT, VEC, true>(io.out[1] + (SEG ? seg * io.out_stride[1] : 0), off / VEC, dn_lcl);
-        store_col<FT, VEC, true>(io.out[2] + (SEG ? seg * io.out_stride[2] : 0), off / VEC, dq_rai);
-        store_col<FT, VEC, true>(io.out[3] + (SEG ? seg * io.out_stride[3] : 0), off / VEC, dn_rai);
-    } else {
-        extern __shared__ __align__(16) unsigned char lds_raw[];
-        FT *lds = reinterpret_cast<FT *>(lds_raw);
-        using V16 = typename VecT<FT, CH>::type;
-        if (active) {
-            FT *row = lds + threadIdx.x * ROW;
-#pragma unroll
-            for (int k = 0; k < VEC; ++k) {
-                row[k * 8 + 0] = dq_lcl[k]; row[k * 8 + 1] = dn_lcl[k]; row[k * 8 + 2] = dq_rai[k]; row[k * 8 + 3] = dn_rai[k];
-                row[k * 8 + 4] = FT(0); row[k * 8 + 5] = FT(0); row[k * 8 + 6] = FT(0); row[k * 8 + 7] = FT(0);
-            }
-        }
-        __syncthreads();
-        constexpr int CPL = VEC * 8 / CH;                     // 16-byte chunks per lane
-        const int64_t nvalid = nvec - tile0 < BS ? nvec - tile0 : BS;
-        V16 *dst = reinterpret_cast<V16 *>(io.aos) + tile0 * CPL;
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-            const int t = j * BS + threadIdx.x;                // chunk of the tile, in output order
-            const int src = t / CPL, sub = t % CPL;
-            if (src < nvalid) __builtin_nontemporal_store(*reinterpret_cast<const V16 *>(lds + src * ROW + sub * CH), dst + t);
-        }
-    }
-}
 
 // SB2006_2M_kernel (test/gpu_tests.jl:220-235): the individual process rates, N per m³, no clamping
 template <typename FT, bool LIMITED, int VEL>

@@ -507,6 +507,18 @@ int32_t cmx_mp1m_tendencies_f64(const cmx_microphysics_1m_f64 *mp, const cmx_the
                                 double *dq_lcl_dt, double *dq_icl_dt, double *dq_rai_dt, double *dq_sno_dt,
                                 void *stream);
 
+/* The 1-moment Instantaneous tendencies behind the host model's layouts — same conventions as
+ * cmx_sb2006_warm_rain_tendencies_fields_*: in[7] = (rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno) as segmented columns (n_seg runs of
+ * seg_len elements, per-column run strides; a ClimaCore VIJFH field component in place), output either out[4] segmented columns or
+ * out_aos = n rows of the reference's NamedTuple (dq_lcl_dt, dq_icl_dt, dq_rai_dt, dq_sno_dt) (BMT:246-251; the output type of
+ * benchmark_1m_bulk_tendencies_kernel!, test/gpu_performance.jl:138-182).  Bit-identical to cmx_mp1m_tendencies_*. */
+int32_t cmx_mp1m_tendencies_fields_f32(const cmx_microphysics_1m_f32 *mp, const cmx_thermo_f32 *tps, uint32_t flags, int64_t n_seg, int64_t seg_len,
+                                       const float *const *in, const int64_t *in_seg_stride, float *const *out, const int64_t *out_seg_stride,
+                                       float *out_aos, void *stream);
+int32_t cmx_mp1m_tendencies_fields_f64(const cmx_microphysics_1m_f64 *mp, const cmx_thermo_f64 *tps, uint32_t flags, int64_t n_seg, int64_t seg_len,
+                                       const double *const *in, const int64_t *in_seg_stride, double *const *out, const int64_t *out_seg_stride,
+                                       double *out_aos, void *stream);
+
 /* bulk_microphysics_tendencies(LinearizedAverage(), Microphysics1Moment(), mp, tps, ρ, T, q_tot, q_lcl, q_icl, q_rai, q_sno,
  * Δt, nsub) — src/BulkMicrophysicsTendencies.jl:572-632 (the mode ClimaAtmos runs operationally, :112-115): the average
  * tendencies over Δt from `nsub` linearized implicit substeps (:381-465) of the donor-based linearization dq/dt ≈ M q + e

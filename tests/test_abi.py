@@ -91,6 +91,10 @@ def test_argument_validation_without_gpu():
     assert h(C.byref(wr.c), C.byref(tps), 1, 2, 16, ins, st7, outs, st4, None, None) == _abi.CMX_ERR_BAD_ARG      # stride < run length
     assert h(C.byref(wr.c), C.byref(tps), 1, 1, 8, ins, None, None, None, C.c_void_p(4100), None) == _abi.CMX_ERR_BAD_ARG   # AoS misaligned
     assert h(C.byref(wr.c), C.byref(tps), 4, 1, 8, ins, None, outs, None, None, None) == _abi.CMX_ERR_BAD_ARG      # unknown flag
+    h1 = lib.cmx_mp1m_tendencies_fields_f32
+    mp1 = P.Microphysics1MParams("f32")
+    assert h1(C.byref(mp1.c), C.byref(tps), mp1.flags, 2, 8, ins, st7, None, None, None, None) == _abi.CMX_ERR_BAD_ARG       # no output
+    assert h1(C.byref(mp1.c), C.byref(tps), mp1.flags, 0, 8, ins, st7, outs, st4, None, None) == _abi.CMX_OK
     g = lib.cmx_column_sums_f64
     assert g(-1, None, 0, None, None) == _abi.CMX_ERR_BAD_ARG
     assert g(0, None, 0, None, None) == _abi.CMX_OK

@@ -88,3 +88,38 @@ def test_large_aos_and_validation(dev):
         cmx.bulk_microphysics_tendencies_fields(cmx.Microphysics2Moment(), mp, tps, *[c[::2] for c in st], aos=True)       # element stride 2
     with pytest.raises(ValueError):
         cmx.bulk_microphysics_tendencies_fields(cmx.Microphysics2Moment(), mp, tps, st[0][:10], *st[1:], aos=True)
+
+
+@pytest.mark.parametrize("ft", ["f32", "f64"])
+def test_mp1m_fields_and_aos(dev, ft):
+    """cmx_mp1m_tendencies_fields_*: VIJFH components in place and the reference's 4-field NamedTuple rows, bit-exact vs the SoA entry;
+    default and non-default option sets (compile-time and run-time flag instantiations)."""
+    import cmx
+    from cmx import synthetic
+    tps = P.ThermodynamicsParameters(ft)
+    Nh, Nf, S = 11, 9, 74 * 16
+    st = synthetic.mp1m_state(Nh * S, dtype=DT[ft], seed=21)
+    Y = torch.full((Nh, Nf, S), float("nan"), dtype=DT[ft])
+    for f, c in enumerate(st):
+        Y[:, f + 1, :] = c.reshape(Nh, S)
+    Y = Y.to(dev)
+    cols = [Y[:, f + 1, :] for f in range(7)]
+    flat = [c.contiguous().reshape(-1) for c in cols]
+    for mp in (P.Microphysics1MParams(ft), P.Microphysics1MParams(ft, snow_autoconversion=P.WithSupersaturation, snow_deposition_sublimation=P.SublimationOnly)):
+        ref = cmx.bulk_microphysics_tendencies_1m(cmx.Instantaneous(), cmx.Microphysics1Moment(), mp, tps, *flat)
+        Yt = torch.full((Nh, 6, S), float("nan"), dtype=DT[ft], device=dev)
+        got = cmx.bulk_microphysics_tendencies_1m_fields(cmx.Instantaneous(), cmx.Microphysics1Moment(), mp, tps, *cols,
+                                                         out=[Yt[:, k, :] for k in (0, 2, 3, 5)])
+        aos = cmx.bulk_microphysics_tendencies_1m_fields(cmx.Instantaneous(), cmx.Microphysics1Moment(), mp, tps, *cols, aos=True)
+        assert aos.shape == (Nh * S, 4)
+        for k, (name, comp) in enumerate(zip(("dq_lcl_dt", "dq_icl_dt", "dq_rai_dt", "dq_sno_dt"), (0, 2, 3, 5))):
+            assert torch.equal(Yt[:, comp, :].reshape(-1), getattr(ref, name)), name
+            assert torch.equal(aos[:, k], getattr(ref, name)), name
+            assert getattr(got, name).data_ptr() == Yt[:, comp, :].data_ptr()
+        assert torch.isnan(Yt[:, 1, :]).all() and torch.isnan(Yt[:, 4, :]).all()
+    for n in (1, 5, 1023, 4099):      # ragged contiguous sizes through the AoS path
+        s1 = synthetic.mp1m_state(n, dtype=DT[ft], device=dev, seed=n)
+        mp = P.Microphysics1MParams(ft)
+        ref = cmx.bulk_microphysics_tendencies_1m(cmx.Instantaneous(), cmx.Microphysics1Moment(), mp, tps, *s1)
+        aos = cmx.bulk_microphysics_tendencies_1m_fields(cmx.Instantaneous(), cmx.Microphysics1Moment(), mp, tps, *s1, aos=True)
+        assert torch.equal(aos[:, 0], ref.dq_lcl_dt) and torch.equal(aos[:, 3], ref.dq_sno_dt)
