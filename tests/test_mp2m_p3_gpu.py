@@ -138,3 +138,31 @@ def test_process_signs(dev):
     assert g["dq_ice_dt"][0] < 0 and g["dq_rai_dt"][0] > 0 and g["dn_rai_dt"][0] > 0 and g["dq_rim_dt"][0] < 0        # melting
     assert g["dq_lcl_dt"][1] < 0 and g["dq_rim_dt"][1] > 0 and g["dn_ice_dt"][1] != 0                                      # riming
     assert g["dq_ice_dt"][2] > 0 and g["dn_ice_dt"][2] > 0 and g["dq_rim_dt"][2] == 0                                      # deposition nucleation
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_million_states_water_budget(dev, ft):
+    """1e6 mixed-phase states through the fused entry: finite everywhere; where there is no ice and T is above freezing the ice
+    tendencies vanish and the liquid tendencies equal the warm-rain entry bit for bit; where the state holds no liquid at all the
+    liquid number tendencies come from melting / shedding only (≥ 0 for rain)."""
+    import cmx
+    n = 1_000_000
+    s = _states(n, seed=77, f32_safe=(ft == "f32"))
+    d = {k: torch.from_numpy(v).to(DT[ft]).to(dev) for k, v in s.items()}
+    mp, tps = P.Microphysics2MParams(ft, with_ice=True), P.ThermodynamicsParameters(ft)
+    ll = cmx.p3_shape(P.ParametersP3(ft), d["q_ice"] * d["rho"], d["n_ice"] * d["rho"], d["q_rim"] * d["rho"], d["b_rim"] * d["rho"],
+                      want=("log_lambda",)).log_lambda
+    ll = torch.where(torch.isfinite(ll), ll, torch.zeros_like(ll))
+    got = cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), mp, tps, *[d[k] for k in s], ll)
+    torch.cuda.synchronize()
+    for k in NAMES:
+        assert bool(torch.isfinite(getattr(got, k)).all()), k
+    warm = cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), P.Microphysics2MParams(ft), tps, *[d[k] for k in list(s)[:7]])
+    m = (d["q_ice"] == 0) & (d["T"] > tps.T_freeze + 0.5)
+    assert int(m.sum()) > 1000
+    for k in NAMES[:4]:
+        assert torch.equal(getattr(got, k)[m], getattr(warm, k)[m]), k
+    for k in ("dq_ice_dt", "dq_rim_dt", "db_rim_dt"):
+        assert float(getattr(got, k)[m].abs().max()) == 0.0, k
+    # ice number without ice mass is relaxed away by the number adjustment (BMT:1057-1064): dn_ice = (0 − n_ice)/τ, τ = 100 s
+    assert torch.allclose(got.dn_ice_dt[m], -d["n_ice"][m] * 0.01, rtol=1e-6 if ft == "f64" else 1e-5, atol=0)

@@ -236,3 +236,31 @@ def test_liquid_freezing_rate(dev, oracle, ft, psd):
         assert np.all(np.abs(x[live] - r[live]) <= RTOL[ft] * r[live]) and live.mean() > 0.3
     warm = c64[3] >= tps.T_freeze - 4
     assert warm.any() and np.all(_np64(got.dn_frz)[warm] == 0)
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_million_states_identities(dev, ft):
+    """Size-independent properties at 1e6 random mixed-phase states (no oracle at this size): the integrand identities of
+    ∫liquid_ice_collisions (src/P3_processes.jl:466-486) — freeze + shed = collected mass for cloud and rain together, wet ≤ total,
+    all ten integrals ≥ 0 and finite — and the bulk-source bookkeeping (:640-650)."""
+    import cmx
+    n = 1_000_000
+    cols = [c.to(dev) for c in _random_states(n, ft, seed=101)]
+    ip = P.P3IceParams(ft)
+    aps, tps = P.AirProperties(ft), P.ThermodynamicsParameters(ft)
+    ll = cmx.p3_shape(P.ParametersP3(ft), *cols[:4], from_state=True, want=("log_lambda",)).log_lambda
+    ll = torch.where(torch.isfinite(ll), ll, torch.zeros_like(ll))
+    src, r = cmx.p3_liquid_ice_collisions(ip, aps, tps, cols[8], cols[9], *cols[:4], ll, *cols[4:8], from_state=True, want_rates=True)
+    torch.cuda.synchronize()
+    for k, v in r.items():
+        assert bool(torch.isfinite(v).all()) and float(v.min()) >= 0.0, k
+    tot = r["int_M_col"]
+    parts = r["QCFRZ"] + r["QCSHD"] + r["QRFRZ"] + r["QRSHD"]
+    tol = 1e-12 if ft == "f64" else 2e-5
+    tiny = 1e-300 if ft == "f64" else 1e-35
+    assert float(((parts - tot).abs() / tot.clamp(min=tiny)).max()) <= tol
+    assert bool((r["int_wet_M_col"] <= tot * (1 + tol)).all())
+    rho = cols[8]
+    assert float(((src["dq_c"] + (r["QCFRZ"] + r["QCSHD"]) / rho).abs() / ((r["QCFRZ"] + r["QCSHD"]) / rho).clamp(min=tiny)).max()) <= tol
+    assert float(((src["dL_ice"] - (r["QCFRZ"] + r["QRFRZ"])).abs() / (r["QCFRZ"] + r["QRFRZ"]).clamp(min=tiny)).max()) <= tol
+    assert bool((src["dL_rim"] >= src["dL_ice"] * (1 - tol)).all()) and float((tot > 0).float().mean()) > 0.5
