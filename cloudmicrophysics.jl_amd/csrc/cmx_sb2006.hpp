@@ -42,7 +42,7 @@ template <typename FT> struct SbConsts {
     FT l2_pi_rho_w, l2_xr_min, l2_xr_max, l2_N0_min, l2_N0_max, l2_lam_min, l2_lam_max, inv_eps_1m;
     FT ga_c1, ga_e1, ga_c2, ga_e2;      // Γ_incl(−1, t)   (CM2:746-753)
     FT gb_c1, gb_e1, gb_c2, gb_e2;      // Γ_incl(β_vent_0, t)
-    FT a_vent_0_coeff, bSc_vent_0, a_vent_1, bSc_vent_1;   // b·∛Sc folded
+    FT a_vent_1, bSc_vent_1;            // b·∛Sc folded (the order-0 pair lives in ga_c*, gb_c*)
     FT sqrt_alpha_nu, beta, ev_rho0_q;  // √(α/ν_air), β, ρ0^(1/4)
     FT two_pi, l2_gate_N;               // log2(eps(FT)·x*) of the evaporation number gate
     // autoconversion / cloud self-collection (CM2:396-427, 488-501)
@@ -114,8 +114,13 @@ inline SbConsts<FT> make_sb_consts(const WR &wr, const TH &tp, const VL *vel, do
     gincl(-1.0, c.ga_c1, c.ga_e1, c.ga_c2, c.ga_e2);
     gincl((double)ev.beta_vent_0, c.gb_c1, c.gb_e1, c.gb_c2, c.gb_e2);
     const double cbrt_Sc = std::cbrt((double)wr.air_properties.nu_air / D_safe);
-    c.a_vent_0_coeff = (FT)ev.a_vent_0_coeff;
-    c.bSc_vent_0 = (FT)((double)ev.b_vent_0_coeff * cbrt_Sc);
+    // 1/(c1 t^e1 + c2 t^e2) scaled by a_vent_0 resp. b_vent_0·∛Sc: fold the scale into c1, c2
+    {
+        const double sa = (double)ev.a_vent_0_coeff, sb = (double)ev.b_vent_0_coeff * cbrt_Sc;
+        c.ga_c1 = (FT)((0.33 + 0.7) / sa); c.ga_c2 = (FT)((1.34 + 0.1) / sa);
+        const double ab = (double)ev.beta_vent_0;
+        c.gb_c1 = (FT)((0.33 - 0.7 * ab) / sb); c.gb_c2 = (FT)((1.34 - 0.1 * ab) / sb);
+    }
     c.a_vent_1 = (FT)ev.a_vent_1;
     c.bSc_vent_1 = (FT)((double)ev.b_vent_1 * cbrt_Sc);
     c.sqrt_alpha_nu = (FT)std::sqrt((double)ev.alpha / (double)wr.air_properties.nu_air);
@@ -318,17 +323,18 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
     {   // rain_evaporation CM2:780-828
         const FT l2_t = (c.l2_6xstar - l2_xr) * FT(1.0 / 3.0);            // t* = ∛(6 x*/x̄_r)
         const FT t_star = M::exp2(l2_t);
-        const FT e_t = M::exp2(t_star * FT(-1.4426950408889634));
-        const FT g_a = e_t * M::rcp(M::fma(c.ga_c1, M::exp2(c.ga_e1 * l2_t), c.ga_c2 * M::exp2(c.ga_e2 * l2_t)));
-        const FT g_b = e_t * M::rcp(M::fma(c.gb_c1, M::exp2(c.gb_e1 * l2_t), c.gb_c2 * M::exp2(c.gb_e2 * l2_t)));
+        // e^{−t*}/x̄_r in one exponential: both factors enter the number tendency only (Γ_incl does not appear in the mass one);
+        // the ventilation coefficients a_vent_0, b_vent_0·∛Sc are folded into the Γ_incl denominators on the host
+        const FT e_tx = M::exp2(M::fma(t_star, FT(-1.4426950408889634), -l2_xr));
+        const FT g_a = M::rcp(M::fma(c.ga_c1, M::exp2(c.ga_e1 * l2_t), c.ga_c2 * M::exp2(c.ga_e2 * l2_t)));   // a_vent_0·Γ_incl(−1, t*)·e^{t*}
+        const FT g_b = M::rcp(M::fma(c.gb_c1, M::exp2(c.gb_e1 * l2_t), c.gb_c2 * M::exp2(c.gb_e2 * l2_t)));   // b_vent_0 ∛Sc·Γ_incl(β, t*)·e^{t*}
         // √N_Re = √(α/ν)·(ρ0/ρ)^¼·√(x̄^β·Dr)
         const FT sqrt_N_Re = c.sqrt_alpha_nu * c.ev_rho0_q * M::sqrt(rs_rho) *
                              M::exp2(FT(0.5) * M::fma(c.beta, l2_xr, l2_Dr));
-        const FT Fv0 = M::fma(c.bSc_vent_0 * g_b, sqrt_N_Re, c.a_vent_0_coeff * g_a);
+        const FT Fv0 = M::fma(g_b, sqrt_N_Re, g_a);
         const FT Fv1 = M::fma(c.bSc_vent_1, sqrt_N_Re, c.a_vent_1);
         const FT common = c.two_pi * G * S * N_rai * Dr;
-        const FT inv_xr = M::exp2(-l2_xr);
-        const FT dN = M::min(FT(0), common * Fv0 * inv_xr);
+        const FT dN = M::min(FT(0), common * Fv0 * e_tx);
         const FT dq = M::min(FT(0), common * Fv1 * inv_rho);
         const bool gate_q = no_q_rai || (N_rai <= eps) || (S >= FT(0));
         const bool gate_N = gate_q || (l2_xr < c.l2_gate_N);             // x̄_r/x* < eps(FT) — CM2:824-825
