@@ -18,9 +18,11 @@ static int decode_vel(uint32_t flags, bool want) {
 }
 
 #ifndef CMX_TEND_BS
-#define CMX_TEND_BS 256
+#define CMX_TEND_BS 128
 #endif
-constexpr int kTendBS = CMX_TEND_BS;   // lanes per workgroup of the fused tendency kernel (tuning: -DCMX_TEND_BS=128|512)
+constexpr int kTendBS = CMX_TEND_BS;   // lanes per workgroup of the fused tendency kernel (tuning: -DCMX_TEND_BS=64|256|512).  Measured with the
+                                       // 263-instruction point function, 1e8 f32 points, three runs on one box: 128 → 0.883–0.885 ms, 64 → 0.887–0.902,
+                                       // 512 → 0.894–0.923, 256 → 0.915–0.962 (256 was the optimum of the 350-instruction version)
 
 template <typename FT, int VEC>
 static void launch_tendencies(bool limited, int vel, const SbConsts<FT> &c, const SbIn<FT> &in, const SbOut<FT> &out,
