@@ -32,7 +32,9 @@ template <typename FT, int NIN, int NOUT> struct LayoutIO {
     double inv_seg_len;
 };
 
-template <typename FT, typename POLICY, int VEC, bool SEG, bool AOS, int BS = kBlock>
+constexpr int kLayoutBS = 128;   // lanes per workgroup of the adapter kernel
+
+template <typename FT, typename POLICY, int VEC, bool SEG, bool AOS, int BS = kLayoutBS>
 __global__ __launch_bounds__(BS) void tendencies_layout_kernel(const typename POLICY::Consts c,
                                                                const LayoutIO<FT, POLICY::NIN, POLICY::NOUT> io, const int64_t nvec) {
     constexpr int NIN = POLICY::NIN, NOUT = POLICY::NOUT, NAOS = POLICY::NAOS;
@@ -128,8 +130,8 @@ static int32_t launch_layout(const typename POLICY::Consts &c, int64_t n_seg, in
     auto launch = [&](auto vec_tag) {
         constexpr int V = decltype(vec_tag)::value;
         const int64_t nvec = n / V;
-        const dim3 grid((unsigned)((nvec + kBlock - 1) / kBlock)), block(kBlock);
-        const size_t lds = aos ? sizeof(FT) * (size_t)kBlock * (V * NAOS + 16 / sizeof(FT)) : 0;
+        const dim3 grid((unsigned)((nvec + kLayoutBS - 1) / kLayoutBS)), block(kLayoutBS);
+        const size_t lds = aos ? sizeof(FT) * (size_t)kLayoutBS * (V * NAOS + 16 / sizeof(FT)) : 0;
         if (seg) {
             if (aos) hipLaunchKernelGGL((tendencies_layout_kernel<FT, POLICY, V, true, true>), grid, block, lds, s, c, io, nvec);
             else hipLaunchKernelGGL((tendencies_layout_kernel<FT, POLICY, V, true, false>), grid, block, lds, s, c, io, nvec);
