@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--points", type=int, default=100_000_000, help="grid points per GPU")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--workload", choices=["sb2006", "icenuc", "mp1m", "mp1m_lin", "arg2000", "p3", "p3_selfcol", "mp2m_p3", "sb2006_aos", "sb2006_fields"], default="sb2006")
