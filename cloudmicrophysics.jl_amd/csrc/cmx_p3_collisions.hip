@@ -30,8 +30,10 @@
 
 namespace cmx {
 
-constexpr int kGroup = 8;                        // lanes per grid point (measured: 8 → 32.3 ms, 16 → 36.2 ms, 32 → 69.4 ms per 1e6 f64 states at GaussLegendre(16))
-static_assert(kGroup >= 8 && (kGroup & (kGroup - 1)) == 0 && kGroup <= 64, "lanes 0..7 of a group hold the end-point gammas and the quantile solves");
+// lanes per grid point (template parameter GROUP of the kernel): 8 up to quadrature order 47, 16 above.  Measured, 1e6 f64 states:
+// GaussLegendre(16): 8 → 32.3 ms, 16 → 36.2, 32 → 69.4;  (40): 8 → 134, 16 → 160;  (64): 8 → 441, 16 → 307 (the per-wave LDS caches of 8
+// states no longer leave room for two waves per SIMD).  Lanes 0..7 of a group hold the end-point gammas and the quantile solves.
+static inline int collision_group(int nq) { return nq >= 48 ? 16 : 8; }
 
 template <typename FT> struct P3ColConsts {
     // rain Chen-2022 curve (table B1; Common.jl:290-302): v_l(D) = Σ_j a_j exp(e_j + b_j logD − c_j D)
@@ -166,7 +168,7 @@ template <typename FT> struct ColLds {
     static __device__ __forceinline__ int per_group(int n) { return 6 * n + 72; }
 };
 
-template <typename FT, typename QUAD, bool ASPECT, bool FUSED>
+template <typename FT, typename QUAD, bool ASPECT, bool FUSED, int GROUP>
 __global__ __launch_bounds__(kBlock, 2) void p3_collision_kernel(const P3Consts<FT> c, const P3VelConsts<FT> v, const P3ColConsts<FT> k,
                                                              const QUAD quad, const P3ColIO<FT> io, const int64_t n) {
     using P = PM<FT>;
@@ -178,10 +180,10 @@ __global__ __launch_bounds__(kBlock, 2) void p3_collision_kernel(const P3Consts<
     FT *q_node = lds, *q_wt = lds + nq;
     if (threadIdx.x == 0)
         for (int j = 0; j < nq; ++j) { q_node[j] = quad.node[j]; q_wt[j] = quad.weight[j]; }
-    const int grp = threadIdx.x / kGroup, g = threadIdx.x % kGroup;
+    const int grp = threadIdx.x / GROUP, g = threadIdx.x % GROUP;
     FT *G = lds + 2 * nq + grp * ColLds<FT>::per_group(nq);
     FT *cD = G, *cV = G + nq, *cW = G + 2 * nq, *rD = G + 3 * nq, *rV = G + 4 * nq, *rW = G + 5 * nq, *E = G + 6 * nq, *Fm = G + 6 * nq + 48;
-    const int64_t pt_raw = (int64_t)blockIdx.x * (blockDim.x / kGroup) + grp;
+    const int64_t pt_raw = (int64_t)blockIdx.x * (blockDim.x / GROUP) + grp;
     const bool valid = pt_raw < n;
     const int64_t i = valid ? pt_raw : n - 1;
     __syncthreads();
@@ -220,10 +222,10 @@ __global__ __launch_bounds__(kBlock, 2) void p3_collision_kernel(const P3Consts<
             if (g == 5) plev = k.p_hi_m;
         }
         const FT xq = gamma_inc_inv_dev<FT>(mu + FT(1), plev, FT(1) - plev) / lam;
-        D_min = __shfl(xq, 0, kGroup); D_max = __shfl(xq, 1, kGroup);
+        D_min = __shfl(xq, 0, GROUP); D_max = __shfl(xq, 1, GROUP);
         if constexpr (FUSED) {
-            D_lo_sc = __shfl(xq, 2, kGroup); D_hi_sc = __shfl(xq, 3, kGroup);
-            D_lo_m = __shfl(xq, 4, kGroup); D_hi_m = __shfl(xq, 5, kGroup);
+            D_lo_sc = __shfl(xq, 2, GROUP); D_hi_sc = __shfl(xq, 3, GROUP);
+            D_lo_m = __shfl(xq, 4, GROUP); D_hi_m = __shfl(xq, 5, GROUP);
         }
     }
     FT bnd[5];
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(kBlock, 2) void p3_collision_kernel(const P3Consts<
     // ---- inner-node caches: lane j ↔ inner node j -------------------------------------------------------------------
     if (has_cloud) {
         const FT sc = (c_hi - c_lo) / FT(2), sh = (c_lo + c_hi) / FT(2);
-        for (int j = g; j < nq; j += kGroup) {
+        for (int j = g; j < nq; j += GROUP) {
             const FT D = sc * q_node[j] + sh, logD = P::log(D);
             const FT nD = P::exp(logN0c + k.nu_cD * logD - lam_c * P::exp(k.mu_cD * logD));
             cD[j] = D; cV[j] = v_liq(D, logD); cW[j] = q_wt[j] * sc * nD;
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(kBlock, 2) void p3_collision_kernel(const P3Consts<
     }
     if (has_rain) {
         const FT sc = (r_hi - r_lo) / FT(2), sh = (r_lo + r_hi) / FT(2);
-        for (int j = g; j < nq; j += kGroup) {
+        for (int j = g; j < nq; j += GROUP) {
             const FT D = sc * q_node[j] + sh, logD = P::log(D);
             rD[j] = D; rV[j] = v_liq(D, logD);
             rW[j] = q_wt[j] * sc * (N0r * P::exp(-D * lam_r)) * (k.m_fac * (D * D * D));
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(kBlock, 2) void p3_collision_kernel(const P3Consts<
             const FT a = bnd[sg], b = bnd[sg + 1];
             if (!(a < b)) continue;
             const FT scale = (b - a) / FT(2), shift = (a + b) / FT(2);
-            for (int o = g; o < nq; o += kGroup) {
+            for (int o = g; o < nq; o += GROUP) {
                 const FT Di = scale * q_node[o] + shift, w = q_wt[o] * scale;
                 FT v_i, r_i, n_i;
                 eval_ice(Di, v_i, r_i, n_i);
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(kBlock, 2) void p3_collision_kernel(const P3Consts<
                 const FT a = bs[sg], b = bs[sg + 1];
                 if (!(a < b)) continue;
                 const FT scale = (b - a) / FT(2), shift = (a + b) / FT(2);
-                for (int o = g; o < nq; o += kGroup) {
+                for (int o = g; o < nq; o += GROUP) {
                     const FT D1 = scale * q_node[o] + shift;
                     FT v1, r1, n1;
                     eval_ice(D1, v1, r1, n1);
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(kBlock, 2) void p3_collision_kernel(const P3Consts<
                     if (!(a < b)) continue;
                     const FT scale = (b - a) / FT(2), shift = (a + b) / FT(2);
                     const FT mb = s.b[sg], ma = P::exp(s.log_a[sg]);
-                    for (int o = g; o < nq; o += kGroup) {
+                    for (int o = g; o < nq; o += GROUP) {
                         const FT x = scale * q_node[o] + shift;
                         FT vD, rD_, nD;
                         eval_ice(x, vD, rD_, nD);
@@ -525,12 +527,12 @@ __global__ __launch_bounds__(kBlock, 2) void p3_collision_kernel(const P3Consts<
     for (int q = 0; q < 10; ++q) {
         FT x = acc[q];
 #pragma unroll
-        for (int d = kGroup / 2; d >= 1; d >>= 1) x += __shfl_xor(x, d, kGroup);
+        for (int d = GROUP / 2; d >= 1; d >>= 1) x += __shfl_xor(x, d, GROUP);
         acc[q] = x;
     }
     if constexpr (FUSED) {
 #pragma unroll
-        for (int d = kGroup / 2; d >= 1; d >>= 1) { acc_sc += __shfl_xor(acc_sc, d, kGroup); acc_m += __shfl_xor(acc_m, d, kGroup); }
+        for (int d = GROUP / 2; d >= 1; d >>= 1) { acc_sc += __shfl_xor(acc_sc, d, GROUP); acc_m += __shfl_xor(acc_m, d, GROUP); }
     }
     if (g == 0 && valid) {
         const FT f_wet = acc[6] == FT(0) ? FT(0) : acc[9] / acc[6];
@@ -562,12 +564,31 @@ __global__ __launch_bounds__(kBlock, 2) void p3_collision_kernel(const P3Consts<
 }
 
 // launch geometry: 256 lanes (32 states) per workgroup unless the per-state LDS caches (6n + 72 values) would not fit — then 128
-template <typename FT> static void collision_geometry(int nq, int64_t n, dim3 &grid, dim3 &block, size_t &lds) {
+template <typename FT> static void collision_geometry(int group, int nq, int64_t n, dim3 &grid, dim3 &block, size_t &lds) {
     int threads = kBlock;
-    auto bytes = [&](int t) { return sizeof(FT) * (size_t)(2 * nq + (t / kGroup) * (6 * nq + 72)); };
+    auto bytes = [&](int t) { return sizeof(FT) * (size_t)(2 * nq + (t / group) * (6 * nq + 72)); };
     while (threads > 64 && bytes(threads) > 150 * 1024) threads /= 2;
-    const int ppb = threads / kGroup;
+    const int ppb = threads / group;
     grid = dim3((unsigned)((n + ppb - 1) / ppb)); block = dim3(threads); lds = bytes(threads);
+}
+
+// one launch site for both entries: picks the group width from the quadrature order, sizes the workgroup so the LDS caches fit,
+// raises the dynamic-LDS limit when needed
+template <typename FT, typename QUAD, bool FUSED>
+static int32_t launch_collision_kernel(const P3Consts<FT> &c, const P3VelConsts<FT> &v, const P3ColConsts<FT> &k, const QUAD &quad,
+                                       const P3ColIO<FT> &io, int64_t n, bool aspect, hipStream_t st) {
+    const int group = collision_group(quad.n);
+    dim3 grid, block;
+    size_t lds;
+    collision_geometry<FT>(group, quad.n, n, grid, block, lds);
+    auto go = [&](auto kern) -> int32_t {
+        if (lds > 48 * 1024) CMX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, grid, block, lds, st, c, v, k, quad, io, n);
+        CMX_HIP_TRY(hipGetLastError());
+        return CMX_OK;
+    };
+    if (group == 8) return aspect ? go(&p3_collision_kernel<FT, QUAD, true, FUSED, 8>) : go(&p3_collision_kernel<FT, QUAD, false, FUSED, 8>);
+    return aspect ? go(&p3_collision_kernel<FT, QUAD, true, FUSED, 16>) : go(&p3_collision_kernel<FT, QUAD, false, FUSED, 16>);
 }
 
 template <typename FT, typename IP, typename AP, typename TH, typename QUAD>
@@ -590,22 +611,7 @@ static int32_t p3_collision_entry(const IP *ip, const AP *aps, const TH *tps, co
     io.rho_a = rho_a; io.T = T; io.loglam = loglam;
     for (int q = 0; q < 7; ++q) io.src[q] = sources ? sources[q] : nullptr;
     for (int q = 0; q < 10; ++q) io.rates[q] = rates ? rates[q] : nullptr;
-    dim3 grid, block;
-    size_t lds;
-    collision_geometry<FT>(quad->n, n, grid, block, lds);
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (lds > 48 * 1024) {   // large quadrature orders need more than the default dynamic-LDS limit
-        CMX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&p3_collision_kernel<FT, QUAD, false, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CMX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&p3_collision_kernel<FT, QUAD, true, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    if (flags & CMX_P3_NO_ASPECT_RATIO)
-        hipLaunchKernelGGL((p3_collision_kernel<FT, QUAD, false, false>), grid, block, lds, st, c, v, k, *quad, io, n);
-    else
-        hipLaunchKernelGGL((p3_collision_kernel<FT, QUAD, true, false>), grid, block, lds, st, c, v, k, *quad, io, n);
-    CMX_HIP_TRY(hipGetLastError());
-    return CMX_OK;
+    return launch_collision_kernel<FT, QUAD, false>(c, v, k, *quad, io, n, !(flags & CMX_P3_NO_ASPECT_RATIO), reinterpret_cast<hipStream_t>(stream));
 }
 
 // =====================================================================================================================
@@ -837,21 +843,7 @@ static int32_t mp2m_p3_entry(const WR *wr, const IP *ip, const TH *tps, uint32_t
     io.q_lcl = q_lcl; io.n_lcl = n_lcl; io.q_rai = q_rai; io.n_rai = n_rai; io.q_ice = q_ice; io.n_ice = n_ice; io.q_rim = q_rim; io.b_rim = b_rim;
     for (int q = 0; q < 8; ++q) io.out[q] = out[q];
     using QUAD = std::remove_cv_t<std::remove_reference_t<decltype(ip->quad)>>;
-    dim3 grid2, block2;
-    size_t lds;
-    collision_geometry<FT>(ip->quad.n, n, grid2, block2, lds);
-    if (lds > 48 * 1024) {
-        CMX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&p3_collision_kernel<FT, QUAD, false, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CMX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&p3_collision_kernel<FT, QUAD, true, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    if (flags & CMX_P3_NO_ASPECT_RATIO)
-        hipLaunchKernelGGL((p3_collision_kernel<FT, QUAD, false, true>), grid2, block2, lds, st, c, v, k, ip->quad, io, n);
-    else
-        hipLaunchKernelGGL((p3_collision_kernel<FT, QUAD, true, true>), grid2, block2, lds, st, c, v, k, ip->quad, io, n);
-    CMX_HIP_TRY(hipGetLastError());
-    return CMX_OK;
+    return launch_collision_kernel<FT, QUAD, true>(c, v, k, ip->quad, io, n, !(flags & CMX_P3_NO_ASPECT_RATIO), st);
 }
 
 }  // namespace cmx
