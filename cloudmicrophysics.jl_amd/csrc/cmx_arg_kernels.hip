@@ -46,6 +46,7 @@ template <typename FT> struct ArgConsts {
     FT cp_d, cpm_qt, cpm_ql, cpm_qi;
     FT inv_K, Rv_over_D, eps_1m, inv_eps_1m, eps_ft;
     FT g, rho_w, inv_rho_w, rho_i, A_c, p1, p2, two_pi_rho_w, four_pi, inv_43pi_rho_w, inv_43pi_rho_i;
+    FT l2_Ac_Ttr, l2_two_thirds, l2_two_pi_rho_w;   // log2(A_c/T_tr), log2(2/3), log2(2π ρw)
     ArgModeConsts<FT> m[CMX_ARG_MAX_MODES];
 };
 
@@ -72,6 +73,8 @@ static ArgConsts<FT> make_arg_consts(const AP &ap, const AD &ad, const AI &aip, 
     c.A_c = (FT)(2.0 * (double)ap.sigma * (double)ap.M_w / (double)ap.rho_w / (double)ap.R);   // A = A_c / T
     c.p1 = (FT)ap.p1; c.p2 = (FT)ap.p2;
     c.two_pi_rho_w = (FT)(2.0 * pi * (double)ap.rho_w); c.four_pi = (FT)(4.0 * pi);
+    c.l2_Ac_Ttr = (FT)std::log2(2.0 * (double)ap.sigma * (double)ap.M_w / (double)ap.rho_w / (double)ap.R / (double)tp.T_triple);
+    c.l2_two_thirds = (FT)std::log2(2.0 / 3.0); c.l2_two_pi_rho_w = (FT)std::log2(2.0 * pi * (double)ap.rho_w);
     c.inv_43pi_rho_w = (FT)(1.0 / (4.0 / 3.0 * pi * (double)ap.rho_w));
     c.inv_43pi_rho_i = (FT)(1.0 / (4.0 / 3.0 * pi * (double)ap.rho_i));
     for (int k = 0; k < ad.n_modes && k < CMX_ARG_MAX_MODES; ++k) {
@@ -145,14 +148,15 @@ __device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, cons
     const FT gamma = M::fma(ratio * R_m * L_v, LoRT * inv_cp * M::rcp(p), c.R_v * T * inv_pvs);          // AA:165
     const FT aw = alpha * w;
     const FT aw_over_G = aw * c.rho_w * inv_G_liq;
-    const FT sq = M::sqrt(aw_over_G);
-    const FT A = c.A_c * inv_T;                                                                          // AA:35-40
-    const FT zeta = FT(2.0 / 3.0) * A * sq;                                                               // AA:168
-    const FT l2_A15 = FT(1.5) * M::log2(A);
-    const FT l2_zeta = M::log2(zeta);
-    // η_i = sq³ / (2π ρw γ N_i)  →  log2 η_i = l2_X − log2 N_i
-    const FT X = sq * sq * sq * M::rcp(c.two_pi_rho_w * gamma);
-    const FT l2_X = M::log2(X);
+    // A = A_c/T (AA:35-40), ζ = ⅔ A √(αw/G) (AA:168) and X = (αw/G)^1.5/(2π ρw γ) (η_i = X/N_i) assembled in the log2 domain from
+    // log2(T/T_tr) (already formed for p_vs), log2(αw/G) and log2 γ: 4 transcendentals instead of sqrt + 3 log2 + rcp
+    const FT l2_awG = M::log2(aw_over_G);
+    const FT l2_A = c.l2_Ac_Ttr - l2_TT;
+    const FT l2_A15 = FT(1.5) * l2_A;
+    const FT l2_zeta = c.l2_two_thirds + l2_A + FT(0.5) * l2_awG;
+    const FT zeta = M::exp2(l2_zeta);
+    const FT l2_X = M::fma(FT(1.5), l2_awG, -(c.l2_two_pi_rho_w + M::log2(gamma)));
+    const FT X = M::exp2(l2_X);
     // Σ_i (1/Sm_i²)·[f_i (ζ/η_i)^p1 + g_i (Sm_i²/(η_i+3ζ))^p2] — AA:170-183.  Everything that depends only on the mode is
     // folded on the host (ArgModeConsts); per state three shared powers, per mode one log2 + one exp2.
     const FT Z1 = M::exp2(c.p1 * (l2_zeta - l2_X));            // (ζ/X)^p1
