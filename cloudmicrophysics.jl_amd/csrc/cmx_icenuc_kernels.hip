@@ -79,7 +79,9 @@ template <typename FT> __device__ __forceinline__ FT a_w_ice_dev(const IceNucCon
     return M::exp2(M::fma(c.aw_da, M::log2(T * c.inv_T_tr), M::fma(c.aw_db, c.inv_T_tr - inv_T, c.aw_d0)));
 }
 
-template <typename FT, bool LINEAR, int VEC>
+// RATES_ONLY: only the per-droplet rates J·4πr² / J·4⁄3πr³ are requested (the BASELINE configuration): the two exp2 for the bare
+// rate coefficients are then dead code — as a compile-time fact (with run-time nullable pointers they are always evaluated)
+template <typename FT, bool LINEAR, int VEC, bool RATES_ONLY = false>
 __global__ __launch_bounds__(kBlock) void ice_nucleation_kernel(const IceNucConsts<FT> c, const IceNucIO<FT> io,
                                                                 const int64_t nvec) {
     using M = Math<FT>;
@@ -109,17 +111,21 @@ __global__ __launch_bounds__(kBlock) void ice_nucleation_kernel(const IceNucCons
                 ok = (c.d_min <= d[k]) && (d[k] <= c.d_max);                       // DomainError → NaN  :558-562
                 nerr += ok ? 0 : 1;
             }
-            jh[k] = M::exp2(l2_jh);
-            jo[k] = ok ? M::exp2(l2_jo) : FT(__builtin_nan(""));
+            if constexpr (!RATES_ONLY) {
+                jh[k] = M::exp2(l2_jh);
+                jo[k] = ok ? M::exp2(l2_jo) : FT(__builtin_nan(""));
+            }
             // J·4πr² and J·4/3πr³ formed in the log2 domain: J_hom alone reaches 1e39 (Float32 overflow) for
             // Δa_w ≈ 0.4 with the linear fit while the per-droplet rate J·V stays O(1e16)
             const FT l2_r = M::log2(r[k]);
             rh[k] = M::exp2(l2_jh + M::fma(FT(2), l2_r, c.l2_four_pi));
             ro[k] = ok ? M::exp2(l2_jo + M::fma(FT(3), l2_r, c.l2_four_thirds_pi)) : FT(__builtin_nan(""));
         }
-        if (io.delta_a_w) store_col<FT, VEC>(io.delta_a_w, i, d);
-        if (io.J_het) store_col<FT, VEC>(io.J_het, i, jh);
-        if (io.J_hom) store_col<FT, VEC>(io.J_hom, i, jo);
+        if constexpr (!RATES_ONLY) {
+            if (io.delta_a_w) store_col<FT, VEC>(io.delta_a_w, i, d);
+            if (io.J_het) store_col<FT, VEC>(io.J_het, i, jh);
+            if (io.J_hom) store_col<FT, VEC>(io.J_hom, i, jo);
+        }
         if (io.rate_het) store_col<FT, VEC>(io.rate_het, i, rh);
         if (io.rate_hom) store_col<FT, VEC>(io.rate_hom, i, ro);
     }
@@ -180,7 +186,11 @@ static int32_t icenuc_entry(const TH *tps, const DU *dust, const KO *koop, uint3
                         off(rate_het, lo), off(rate_hom, lo), reinterpret_cast<unsigned long long *>(n_domain_errors)};
         const int64_t nv = count / V;
         const unsigned grid = (unsigned)((nv + kBlock - 1) / kBlock);
-        if (linear) hipLaunchKernelGGL((ice_nucleation_kernel<FT, true, V>), dim3(grid), dim3(kBlock), 0, s, c, io, nv);
+        const bool rates_only = !delta_a_w && !J_het && !J_hom && rate_het && rate_hom;
+        if (rates_only) {
+            if (linear) hipLaunchKernelGGL((ice_nucleation_kernel<FT, true, V, true>), dim3(grid), dim3(kBlock), 0, s, c, io, nv);
+            else hipLaunchKernelGGL((ice_nucleation_kernel<FT, false, V, true>), dim3(grid), dim3(kBlock), 0, s, c, io, nv);
+        } else if (linear) hipLaunchKernelGGL((ice_nucleation_kernel<FT, true, V>), dim3(grid), dim3(kBlock), 0, s, c, io, nv);
         else hipLaunchKernelGGL((ice_nucleation_kernel<FT, false, V>), dim3(grid), dim3(kBlock), 0, s, c, io, nv);
     };
     if (same_mis) {
