@@ -166,3 +166,58 @@ def test_million_states_water_budget(dev, ft):
         assert float(getattr(got, k)[m].abs().max()) == 0.0, k
     # ice number without ice mass is relaxed away by the number adjustment (BMT:1057-1064): dn_ice = (0 − n_ice)/τ, τ = 100 s
     assert torch.allclose(got.dn_ice_dt[m], -d["n_ice"][m] * 0.01, rtol=1e-6 if ft == "f64" else 1e-5, atol=0)
+
+
+def _reference_cases(ft):
+    """The states of test_bulk_microphysics_p3_tendencies (test/bulk_tendencies_tests.jl:1255-1420)."""
+    tps = P.ThermodynamicsParameters(ft)
+    Tf, rho = tps.T_freeze, 1.2
+
+    def q_sat_liq(T):
+        dcp = tps.cp_v - tps.cp_l
+        ps = tps.press_triple * (T / tps.T_triple) ** (dcp / tps.R_v) * np.exp((tps.LH_v0 - dcp * tps.T_0) / tps.R_v * (1 / tps.T_triple - 1 / T))
+        return ps / (rho * tps.R_v * T)
+    cases = {
+        # name: (T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice, n_ice, q_rim, b_rim)
+        "warm_rain": (Tf + 10, None, 2e-3, 1e8 / rho, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0),
+        "melting": (Tf + 5, None, 0.0, 0.0, 0.0, 0.0, 1e-4, 2e5 / rho, 0.5e-4, 1e-7),
+        "collisions": (Tf - 10, None, 1e-3, 1e8 / rho, 1e-5, 1e5 / rho, 1e-4, 2e5 / rho, 0.5e-4, 1e-7),
+        "finite": (Tf - 5, 0.015, 1e-3, 1e8 / rho, 1e-4, 1e5 / rho, 1e-4, 2e5 / rho, 0.3e-4, 5e-8),
+    }
+    out = {}
+    for k, (T, qt, ql, nl, qr, nr, qi, ni, qm, bm) in cases.items():
+        if qt is None:   # get_saturated_q_tot(tps, T, ρ, q_lcl, q_icl, q_rai, 0) — :14-17 (the melting case passes q_ice + q_rim as q_icl)
+            qt = q_sat_liq(T) + ql + (qi + qm if k == "melting" else qi) + qr
+        out[k] = (rho, T, qt, ql, nl, qr, nr, qi, ni, qm, bm)
+    return tps, out
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_reference_bulk_p3_cases(dev, oracle, ft):
+    """test/bulk_tendencies_tests.jl:1265-1420 case by case: warm rain without ice, melting above freezing, riming below, finiteness —
+    the reference's assertions on the device result, and the device result against the oracle."""
+    import cmx
+    tps, cases = _reference_cases(ft)
+    names = list(cases)
+    cols = [torch.tensor([cases[k][j] for k in names], dtype=DT[ft], device=dev) for j in range(11)]
+    mp = P.Microphysics2MParams(ft, with_ice=True, is_limited=True)
+    rho, q_ice, n_ice, q_rim, b_rim = cols[0], cols[7], cols[8], cols[9], cols[10]
+    # logλ = get_distribution_logλ(P3State(p3, L_ice, N_ice, F_rim = q_rim/q_ice, ρ_rim = q_rim/b_rim)) as in the reference's cases
+    F = torch.where(q_ice > 0, q_rim / q_ice.clamp(min=1e-30), torch.zeros_like(q_ice))
+    rr = torch.where(b_rim > 0, q_rim / b_rim.clamp(min=1e-30), torch.full_like(q_ice, 400.0))
+    ll = cmx.p3_shape(P.ParametersP3(ft), q_ice * rho, n_ice * rho, F, rr, from_state=True, want=("log_lambda",)).log_lambda
+    ll = torch.where(torch.isfinite(ll), ll, torch.full_like(ll, 10.0))          # "Dummy, not used without ice" (:1279)
+    got = cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), mp, tps, *cols, ll)
+    g = {k: {nm: float(getattr(got, nm)[i]) for nm in NAMES} for i, k in enumerate(names)}
+    assert g["warm_rain"]["dq_lcl_dt"] < 0 and g["warm_rain"]["dq_rai_dt"] > 0 and g["warm_rain"]["dn_rai_dt"] > 0      # :1299-1302
+    assert g["melting"]["dq_ice_dt"] < 0 and g["melting"]["dq_rai_dt"] > 0                                              # :1344-1345
+    assert g["collisions"]["dq_lcl_dt"] < 0 and g["collisions"]["dq_ice_dt"] >= 0                                       # :1386-1387
+    assert all(np.isfinite(v) for v in g["finite"].values())                                                            # :1425-1431
+    if ft == "f64":
+        mp64 = P.Microphysics2MParams("f64", with_ice=True)
+        c64 = [_np64(c) for c in cols]
+        ref, scale = oracle.microphysics_2m_p3_tendencies(_abi.F64, mp64.warm_rain.c, mp64.ice.c, P.ThermodynamicsParameters("f64"), mp64.ice.flags,
+                                                          *c64, _np64(ll))
+        for q, nm in enumerate(NAMES):
+            x = _np64(getattr(got, nm))
+            assert np.all(np.abs(x - ref[q]) <= parity.RTOL[ft] * np.abs(ref[q]) + parity.CTOL[ft] * scale[q]), nm
