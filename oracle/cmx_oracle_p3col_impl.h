@@ -505,3 +505,28 @@ void FN(cmxo_p3_het_ice_nucleation)(const TY(cmx_abifm_dust) * dust, const TY(cm
         dLdt[i] = FN(o_max)((FT)0, JA * q_lcl[i] * rho[i]);
     }
 }
+/* probe for the closed-form rain inner integral (test/p3_tests.jl:919-985): for P3State(L, N, F_rim, ρ_rim) at ρₐ and an outer diameter Dᵢ
+ * out = (∂ₜN_col, ∂ₜM_col, D*, v_i(Dᵢ), r_i(Dᵢ), D_min, D_max, N₀r, D̄_r) of closed_rain_inner_NM — src/P3_processes.jl:343-369 */
+void FN(cmxo_p3_closed_rain_probe)(const TY(cmx_p3_ice_params) * ip, const TY(cmx_air_properties) * aps, const TY(cmx_thermo) * tps, uint32_t flags,
+                                  FT L, FT N, FT F_rim, FT rho_rim, FT rho_a, FT loglam, FT L_r, FT N_r, FT Di, FT out[9]) {
+    TY(cmxo_thresholds) th = {M_EPS, M_EPS, (FT)0, M_EPS};
+    TY(cmxo_p3_state) s = FN(o_p3_state)(&ip->scheme, L, N, F_rim, rho_rim, M_EPS);
+    TY(cmxo_p3col) k;
+    FN(o_p3col_setup)(&k, ip, aps, tps, flags, &th, &s, (FT)0, (FT)0, L_r, N_r, rho_a, (FT)270, loglam);
+    FT v_i = FN(o_p3_particle_velocity)(&ip->scheme, &s, &k.vt, Di);
+    FT ri = M_SQRT(FN(o_p3_ice_area)(&ip->scheme, &s, Di) / (FT)M_PI);
+    FT K[3] = {(FT)M_PI * (ri * ri), (FT)M_PI * ri, (FT)(M_PI / 4)};
+    FT Nc = 0, Mc = 0;
+    if (!(k.N0r == 0 || !(k.r_hi > k.r_lo))) FN(o_closed_rain_inner_NM)(&k, v_i, K, &Nc, &Mc);
+    out[0] = Nc; out[1] = Mc; out[2] = FN(o_crossover_diameter)(v_i, k.ra, k.rb, k.rc, k.r_lo, k.r_hi, k.brent_iters);
+    out[3] = v_i; out[4] = ri; out[5] = k.r_lo; out[6] = k.r_hi; out[7] = k.N0r; out[8] = k.Dr_mean;
+}
+/* probe: P3.crossover_diameter for Chen2022 rain at ρₐ (src/P3_processes.jl:304-317); out = (D*, v_r(D*), v_r(D_min), v_r(D_max)) */
+void FN(cmxo_p3_crossover_probe)(const TY(cmx_chen2022_rain_vel) * c, FT rho_a, FT v_target, FT D_min, FT D_max, int maxiters, FT out[4]) {
+    FT a[3], b[3], cc[3];
+    FN(o_chen2022_rain_coeffs)(c, rho_a, a, b, cc);
+    out[0] = FN(o_crossover_diameter)(v_target, a, b, cc, D_min, D_max, maxiters);
+    out[1] = FN(o_chen_rain_particle_velocity)(a, b, cc, out[0]);
+    out[2] = FN(o_chen_rain_particle_velocity)(a, b, cc, D_min);
+    out[3] = FN(o_chen_rain_particle_velocity)(a, b, cc, D_max);
+}

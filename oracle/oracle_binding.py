@@ -578,3 +578,23 @@ def p3_het_ice_nucleation(fam, dust, tps, q_lcl, N_lcl, RH, T, rho):
     fn.restype = None
     fn(C.byref(dust), C.byref(tps), C.c_int64(n), *[p for _, p in ins], dN.ctypes.data_as(C.c_void_p), dL.ctypes.data_as(C.c_void_p))
     return dN, dL
+
+
+def p3_closed_rain_probe(fam, ice_params, aps, tps, flags, L, N, F_rim, rho_rim, rho_a, log_lambda, L_r, N_r, D_ice):
+    """closed_rain_inner_NM at one outer diameter: dict(N, M, Dstar, v_i, r_i, D_min, D_max, N0r, Dr_mean)."""
+    fn = getattr(lib(), f"cmxo_p3_closed_rain_probe_{fam.sfx}")
+    fn.restype = None
+    out = (fam.ft * 9)()
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32] + [fam.ft] * 9 + [C.c_void_p]
+    fn(C.addressof(ice_params), C.addressof(aps), C.addressof(tps), flags, L, N, F_rim, rho_rim, rho_a, log_lambda, L_r, N_r, D_ice, C.addressof(out))
+    return dict(zip(("N", "M", "Dstar", "v_i", "r_i", "D_min", "D_max", "N0r", "Dr_mean"), list(out)))
+
+
+def p3_crossover_probe(fam, chen, rho_a, v_target, D_min, D_max, maxiters=10):
+    """P3.crossover_diameter: (D*, v_r(D*), v_r(D_min), v_r(D_max))."""
+    fn = getattr(lib(), f"cmxo_p3_crossover_probe_{fam.sfx}")
+    fn.restype = None
+    fn.argtypes = [C.c_void_p] + [fam.ft] * 4 + [C.c_int, C.c_void_p]
+    out = (fam.ft * 4)()
+    fn(C.addressof(chen), rho_a, v_target, D_min, D_max, maxiters, C.addressof(out))
+    return tuple(out)

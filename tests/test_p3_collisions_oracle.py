@@ -216,3 +216,58 @@ def test_p3_het_ice_nucleation_kats(oracle):
     # a non-finite J (huge RH in Float32) counts as no nucleation (src/P3_processes.jl:37-41)
     dN32, dL32 = oracle.p3_het_ice_nucleation(F32, P.Illite("f32"), P.ThermodynamicsParameters("f32"), [2e-4], [1e8], [3.0], [244.0], [0.7])
     assert dN32[0] == 0 and dL32[0] == 0
+
+
+@pytest.mark.parametrize("state", [(1e-3, 1e6, 0.5, 500.0), (1e-2, 1e8, 0.95, 800.0), (1e-5, 1e4, 0.0, 200.0)])
+def test_closed_form_rain_inner_against_adaptive_quadrature(oracle, state):
+    """The reference's own check of closed_rain_inner_NM (test/p3_tests.jl:919-985): the incomplete-gamma closed form of the rain-side
+    collision integrals equals adaptive quadrature of σ(Dᵢ, D)·|vᵢ − v_r(D)|·n_r(D)·(1, m(D)) over the rain bounds, split at the
+    velocity crossover.  Here the adaptive rule is scipy's QUADPACK, an implementation independent of every line of the oracle's closed form."""
+    from scipy.integrate import quad
+    fam = _abi.family("f64")
+    ip = P.P3IceParams("f64", quad=P.ChebyshevGauss("f64", 40))
+    aps, tps = P.AirProperties("f64"), P.ThermodynamicsParameters("f64")
+    L, N, F_rim, rho_rim = state
+    ll = oracle.p3_shape(fam, ip.c.scheme, STATE, [L], [N], [F_rim], [rho_rim])["log_lambda"][0]
+    a, b, c = oracle.chen2022_rain_coeffs(fam, ip.c.vel_rain, 1.0)
+    rho_w = ip.c.rain_pdf.rho_w if hasattr(ip.c.rain_pdf, "rho_w") else 1000.0
+    checked = 0
+    for L_r, N_r in ((1e-6, 1e4), (1e-4, 1e3), (2e-3, 5e2)):
+        for Di in np.logspace(-5, -2, 5):
+            p = oracle.p3_closed_rain_probe(fam, ip.c, aps, tps, ip.flags | STATE, L, N, F_rim, rho_rim, 1.0, ll, L_r, N_r, float(Di))
+            v_r = lambda D: sum(a[j] * D ** b[j] * math.exp(-c[j] * D) for j in range(3))
+            n_r = lambda D: p["N0r"] * math.exp(-D / p["Dr_mean"])
+            base = lambda D: math.pi * (p["r_i"] + D / 2) ** 2 * abs(p["v_i"] - v_r(D)) * n_r(D)
+            mass = lambda D: base(D) * rho_w * math.pi / 6 * D ** 3
+            cuts = [p["D_min"]] + ([p["Dstar"]] if p["D_min"] < p["Dstar"] < p["D_max"] else []) + [p["D_max"]]
+            for f, closed in ((base, p["N"]), (mass, p["M"])):
+                ref = sum(quad(f, lo, hi, epsabs=0, epsrel=1e-13, limit=400)[0] for lo, hi in zip(cuts[:-1], cuts[1:]))
+                assert math.isclose(closed, ref, rel_tol=1e-10), (L_r, N_r, Di, closed, ref)
+                checked += 1
+    assert checked == 30
+
+
+@pytest.mark.parametrize("sfx", ["f64", "f32"])
+def test_crossover_diameter_bracket_ends(oracle, sfx):
+    """test/p3_tests.jl:1050-1063: a target velocity outside the rain band returns the nearer bracket end; an interior one is located to 1e-4."""
+    fam = _abi.family(sfx)
+    ip = P.P3IceParams(sfx, quad=P.GaussLegendre(sfx, 12))
+    D_min, D_max = 1e-5, 5e-3
+    f = np.float32 if sfx == "f32" else np.float64
+    lo = oracle.p3_crossover_probe(fam, ip.c.vel_rain, 1.0, -1.0, D_min, D_max)
+    hi = oracle.p3_crossover_probe(fam, ip.c.vel_rain, 1.0, 1e6, D_min, D_max)
+    assert lo[0] == f(D_min) and hi[0] == f(D_max)
+    v_mid = (lo[2] + lo[3]) / 2
+    for iters in (8, 10):
+        Dstar, v_at, _, _ = oracle.p3_crossover_probe(fam, ip.c.vel_rain, 1.0, v_mid, D_min, D_max, iters)
+        assert f(D_min) <= Dstar <= f(D_max)
+        assert math.isclose(v_at, v_mid, rel_tol=1e-4)
+    # finite-difference slope of D*(v) equals 1 / v_r'(D*) (:1037-1046): the root really tracks the target
+    if sfx == "f64":
+        hv = abs(v_mid) * 1e-4
+        dD = (oracle.p3_crossover_probe(fam, ip.c.vel_rain, 1.0, v_mid + hv, D_min, D_max, 30)[0]
+              - oracle.p3_crossover_probe(fam, ip.c.vel_rain, 1.0, v_mid - hv, D_min, D_max, 30)[0]) / (2 * hv)
+        D0 = oracle.p3_crossover_probe(fam, ip.c.vel_rain, 1.0, v_mid, D_min, D_max, 30)[0]
+        a, b, c = oracle.chen2022_rain_coeffs(fam, ip.c.vel_rain, 1.0)
+        vp = sum(a[j] * D0 ** b[j] * math.exp(-c[j] * D0) * (b[j] / D0 - c[j]) for j in range(3))
+        assert vp > 0 and math.isclose(dD, 1 / vp, rel_tol=1e-3)
