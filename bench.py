@@ -38,7 +38,7 @@ def parse():
                     help="untimed launches before the warm-up: after idle the first ≈15 launches run 5–20 %% slower while the clocks settle")
     ap.add_argument("--points", type=int, default=100_000_000, help="grid points per GPU")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--workload", choices=["sb2006", "icenuc", "mp1m", "mp1m_lin", "arg2000", "p3", "p3_selfcol", "mp2m_p3", "sb2006_aos", "sb2006_fields"], default="sb2006")
+    ap.add_argument("--workload", choices=["sb2006", "icenuc", "mp0m", "mp1m", "mp1m_lin", "arg2000", "p3", "p3_selfcol", "mp2m_p3", "sb2006_aos", "sb2006_fields"], default="sb2006")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the bounded baseline sample")
     ap.add_argument("--diagnostics", action="store_true",
@@ -190,6 +190,37 @@ def setup_icenuc(args, dev, dtype, rank):
         "cpu_threads": 1,
     }
     return list(state), step, desc, cpu_run
+
+
+def setup_mp0m(args, dev, dtype, rank):
+    import torch
+
+    import cmx
+    from cmx import _abi
+    from cmx import parameters as P
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    q_lcl = torch.rand(args.points, generator=g, device=dev, dtype=dtype) * 2e-3
+    q_icl = torch.rand(args.points, generator=g, device=dev, dtype=dtype) * 1e-3
+    mp = P.Microphysics0MParams(args.dtype)
+    out = torch.empty_like(q_lcl)
+    scheme = cmx.Microphysics0Moment()
+
+    def step():
+        cmx.bulk_microphysics_tendencies_0m(scheme, mp, None, q_lcl, q_lcl, q_icl, out=out)
+
+    def cpu_run(ob, cols, threads):
+        fam = _abi.family(args.dtype)
+        return lambda: ob.mp0m_tendencies(fam, mp.precip, *cols)   # scalar port: 1 thread
+
+    desc = {
+        "metric": "grid-points/sec 0-moment precipitation-removal sweep",
+        "bytes_per_point": {"f32": 12, "f64": 24}[args.dtype],      # 2 in + 1 out
+        "kernel": "mp0m_tendencies_kernel",
+        "workload": "BulkMicrophysicsTendencies Microphysics0Moment (qc_0 threshold) over (q_lcl, q_icl)",
+        "columns_in": 2, "columns_out": 1, "diag_cols": [out],
+        "cpu_threads": 1,
+    }
+    return [q_lcl, q_icl], step, desc, cpu_run
 
 
 def setup_mp1m(args, dev, dtype, rank):
@@ -452,7 +483,7 @@ def main():
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     n = args.points                                          # weak scaling: fixed work per GPU
     # rank r owns shard r of the global [0, world·n) index space: disjoint seeds, no exchange
-    setup = {"sb2006": setup_sb2006, "icenuc": setup_icenuc, "mp1m": setup_mp1m, "mp1m_lin": setup_mp1m_lin, "arg2000": setup_arg2000,
+    setup = {"sb2006": setup_sb2006, "icenuc": setup_icenuc, "mp0m": setup_mp0m, "mp1m": setup_mp1m, "mp1m_lin": setup_mp1m_lin, "arg2000": setup_arg2000,
              "p3": setup_p3, "p3_selfcol": setup_p3_selfcol, "mp2m_p3": setup_mp2m_p3, "sb2006_aos": setup_sb2006_layout, "sb2006_fields": setup_sb2006_layout}[args.workload]
     state, kernel_step, desc, cpu_run = setup(args, dev, dtype, rank)
     n = args.points                                          # a layout workload may round the size to whole field runs

@@ -2,6 +2,7 @@
 
 Host-side mirror of the reference's module layout for the hot path:
   cmx.parameters        ↔ CloudMicrophysics.Parameters (CMP)
+  cmx.microphysics0m    ↔ CloudMicrophysics.Microphysics0M (CM0) + the 0M methods of BMT
   cmx.bulk_tendencies   ↔ CloudMicrophysics.BulkMicrophysicsTendencies (BMT) + per-process CM2 rates
   cmx.synthetic         ↔ the state generator of test/gpu_performance.jl:80-136
   cmx.sharding          ↔ (no reference equivalent) one-process-per-GPU sharding + RCCL diagnostic sums
@@ -20,6 +21,9 @@ from .ice_nucleation import (IceNucleationRates, a_w_eT, a_w_ice, domain_error_c
 from .microphysics1m import (Instantaneous, LinearizedAverage, Microphysics1Moment, SedimentationVelocities, SourceTerms1M, Tendencies1M,  # noqa: F401
                              TerminalVelocities1M, bulk_microphysics_tendencies_1m, bulk_microphysics_tendencies_1m_fields,
                              microphysics_source_terms_1m, sedimentation_velocities, terminal_velocity_1m)
+
+from .microphysics0m import (Microphysics0Moment, bulk_microphysics_tendencies_0m, d_remove_precipitation_d_q_tot,  # noqa: F401
+                             remove_precipitation)
 
 from .aerosol import (ActivationResult, AerosolDistribution, ModeColumns, Mode_B, Mode_kappa, aerosol_activation,  # noqa: F401
                       aerosol_activation_columns)

@@ -173,6 +173,7 @@ def _family(ft, sfx):
     ns.quadrature = _struct(f"cmx_quadrature_{sfx}", [
         ("n", C.c_int32), ("reserved", C.c_int32), ("node", ft * CMX_QUAD_MAX), ("weight", ft * CMX_QUAD_MAX)])
     # ---- P3 liquid–ice collisions, immersion / deposition nucleation, P3IceParams
+    ns.parameters_0m = _struct(f"cmx_parameters_0m_{sfx}", s("tau_precip", "qc_0", "S_0"))
     ns.local_rime_density = _struct(f"cmx_local_rime_density_{sfx}", s("a", "b", "c", "rho_ice"))
     ns.rain_freezing = _struct(f"cmx_rain_freezing_{sfx}", s("het_a", "het_B"))
     ns.frostenberg2023 = _struct(f"cmx_frostenberg2023_{sfx}", s("sigma", "a", "b", "T_freeze", "log_a"))

@@ -54,6 +54,9 @@ def _declare(lib):
         f = getattr(lib, f"cmx_water_activity_{s}")
         f.restype = i32
         f.argtypes = [C.POINTER(fam.thermo), i64] + [vp] * 4 + [vp]
+        f = getattr(lib, f"cmx_mp0m_tendencies_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.parameters_0m), i64] + [vp] * 5 + [vp]
         f = getattr(lib, f"cmx_mp1m_tendencies_{s}")
         f.restype = i32
         f.argtypes = [C.POINTER(fam.microphysics_1m), C.POINTER(fam.thermo), u32, i64] + [vp] * 11 + [vp]

@@ -186,6 +186,10 @@ DEFAULT_PARAMETERS = {
     "Chen2022_table_B5_Fl": (0.515453, -0.0725042, -1.86810e19), "Chen2022_table_B5_Gl": (2.65236, 0.00158269, 259.935),
     "Chen2022_table_B5_Hl": (-0.346044, -7.17829e-11, -1.24394e20),
     "Chen2022_ice_cutoff": 0.000625,
+    # 0-moment scheme (src/parameters/Microphysics0M.jl:12-28).  ClimaParams' values, not pinned by a reference test: its 0M tests
+    # (test/microphysics0M_tests.jl, test/gpu_tests.jl:105-141) compare with the formula evaluated on the struct's own fields
+    "precipitation_timescale": 1000.0, "specific_humidity_precipitation_threshold": 5e-6,
+    "supersaturation_precipitation_threshold": 0.02,
     # Cober & List (1993) local rime density, Eq. 17 in kg/m³ — pinned by test/p3_tests.jl:719-726 (a + b + c = 159.5,
     # ρ′(8) = 51 + 114·8 − 5.5·64, ρ′(12) = ρ_ice)
     "CL1993_local_rime_density_constant_coeff": 51.0, "CL1993_local_rime_density_linear_coeff": 114.0,
@@ -672,6 +676,23 @@ def GaussLegendre(FT, n: int):
 def build_quadrature(FT, quadrature_order: int):
     """Quadrature.build_quadrature(FT, order) — src/Quadrature.jl:272-278: Gauss–Legendre for 16/32/40/64, else Chebyshev–Gauss."""
     return GaussLegendre(FT, quadrature_order) if quadrature_order in (16, 32, 40, 64) else ChebyshevGauss(FT, quadrature_order)
+
+
+def Parameters0M(FT, tau_precip=None, qc_0=None, S_0=None):
+    """CMP.Parameters0M — src/parameters/Microphysics0M.jl:12-28 (keyword overrides as the reference's constructor takes)."""
+    td = _td(FT)
+    return td.fam.parameters_0m(tau_precip=td["precipitation_timescale"] if tau_precip is None else tau_precip,
+                                qc_0=td["specific_humidity_precipitation_threshold"] if qc_0 is None else qc_0,
+                                S_0=td["supersaturation_precipitation_threshold"] if S_0 is None else S_0)
+
+
+class Microphysics0MParams:
+    """CMP.Microphysics0MParams — src/parameters/Microphysics0MParams.jl:4-27: the 0-moment parameter set, `.precip` = Parameters0M."""
+
+    def __init__(self, FT, **kw):
+        td = _td(FT)
+        self.fam = td.fam
+        self.precip = Parameters0M(td, **kw)
 
 
 def LocalRimeDensity(FT):

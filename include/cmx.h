@@ -251,6 +251,8 @@ typedef enum cmx_status {
         int32_t n, reserved;                                                                   \
         FT node[CMX_QUAD_MAX], weight[CMX_QUAD_MAX];                                           \
     } cmx_quadrature_##SFX;                                                                    \
+    /* Parameters0M — src/parameters/Microphysics0M.jl:12-28 */                                \
+    typedef struct cmx_parameters_0m_##SFX { FT tau_precip, qc_0, S_0; } cmx_parameters_0m_##SFX; \
     /* LocalRimeDensity — src/parameters/MicrophysicsP3.jl:202-239 (Cober & List 1993 Eq. 16-17) */ \
     typedef struct cmx_local_rime_density_##SFX { FT a, b, c, rho_ice; } cmx_local_rime_density_##SFX; \
     /* RainFreezing (Bigg 1953 / Barklie–Gokhale 1959) — src/parameters/IceNucleation.jl:129-146 */ \
@@ -772,6 +774,21 @@ int32_t cmx_microphysics_2m_p3_tendencies_f64(const cmx_warm_rain_2m_f64 *warm_r
                                               const double *n_lcl, const double *q_rai, const double *n_rai, const double *q_ice, const double *n_ice,
                                               const double *q_rim, const double *b_rim, const double *log_lambda, const double *inpc_log_shift,
                                               double *const *tendencies, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * (0) 0-moment entry of bulk_microphysics_tendencies (src/BulkMicrophysicsTendencies.jl:658-680; KA kernels
+ * test_bulk_tendencies_0m_kernel!, test_bulk_tendencies_0m_S0_kernel!, test/gpu_tests.jl:364-383, and
+ * test_0_moment_micro_kernel! / test_0M_derivatives_kernel!, test/gpu_tests.jl:105-141).  Replaces the broadcasts
+ *   BMT.bulk_microphysics_tendencies.(Microphysics0Moment(), mp, tps, T, q_lcl, q_icl[, q_vap_sat])
+ *   CM0.remove_precipitation.(p0m, q_lcl, q_icl[, q_vap_sat])   CM0.∂remove_precipitation_∂q_tot.(…)   src/Microphysics0M.jl:35-75
+ * dq_tot_dt = −max(0, q_lcl⁺ + q_icl⁺ − threshold)/τ_precip with threshold = qc_0 (q_vap_sat == NULL) or S_0·q_vap_sat;
+ * ddq_dq_tot (optional) = −1/τ_precip where condensate exceeds the threshold, else 0.  Negative q_lcl / q_icl are clamped to 0 as BMT
+ * does (a no-op for the non-negative inputs CM0's direct callers pass).  T is not read by the reference and is not an argument.
+ * ------------------------------------------------------------------------- */
+int32_t cmx_mp0m_tendencies_f32(const cmx_parameters_0m_f32 *p, int64_t n, const float *q_lcl, const float *q_icl,
+                                const float *q_vap_sat, float *dq_tot_dt, float *ddq_dq_tot, void *stream);
+int32_t cmx_mp0m_tendencies_f64(const cmx_parameters_0m_f64 *p, int64_t n, const double *q_lcl, const double *q_icl,
+                                const double *q_vap_sat, double *dq_tot_dt, double *ddq_dq_tot, void *stream);
 
 /* ---------------------------------------------------------------------------
  * (3) Optional diagnostic sums over one rank's shard: per-column

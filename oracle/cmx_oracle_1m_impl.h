@@ -472,3 +472,17 @@ void FN(cmxo_mp1m_terminal_velocity)(const TY(cmx_microphysics_1m) * mp, const T
     }
 }
 FT FN(cmxo_logistic_function_integral)(FT x, FT x_0, FT k, FT eps) { return FN(o_logistic_function_integral)(x, x_0, k, eps, NULL); }
+
+/* ---- 0-moment scheme: CM0.remove_precipitation / ∂remove_precipitation_∂q_tot — src/Microphysics0M.jl:35-75, behind the 0M methods
+ * of bulk_microphysics_tendencies (src/BulkMicrophysicsTendencies.jl:658-680: both condensate inputs clamped to ≥ 0 first).
+ * q_vap_sat == NULL selects the qc_0 threshold, otherwise S_0·q_vap_sat. */
+void FN(cmxo_mp0m_tendencies)(const TY(cmx_parameters_0m) * p, int64_t n, const FT *q_lcl, const FT *q_icl, const FT *q_vap_sat,
+                              FT *dq_tot_dt, FT *ddq_dq_tot) {
+    for (int64_t i = 0; i < n; ++i) {
+        FT ql = q_lcl[i] > 0 ? q_lcl[i] : (FT)0, qi = q_icl[i] > 0 ? q_icl[i] : (FT)0;
+        FT thr = q_vap_sat ? p->S_0 * q_vap_sat[i] : p->qc_0;
+        FT ex = ql + qi - thr;
+        dq_tot_dt[i] = -(ex > 0 ? ex : (FT)0) / p->tau_precip;
+        if (ddq_dq_tot) ddq_dq_tot[i] = ql + qi > thr ? (FT)-1 / p->tau_precip : (FT)0;
+    }
+}

@@ -598,3 +598,16 @@ def p3_crossover_probe(fam, chen, rho_a, v_target, D_min, D_max, maxiters=10):
     out = (fam.ft * 4)()
     fn(C.addressof(chen), rho_a, v_target, D_min, D_max, maxiters, C.addressof(out))
     return tuple(out)
+
+
+def mp0m_tendencies(fam, p0m, q_lcl, q_icl, q_vap_sat=None):
+    """Oracle twin of cmx_mp0m_tendencies_*: (dq_tot_dt, ∂dq_tot_dt/∂q_tot)."""
+    a, ap = _col(fam, q_lcl)
+    b, bp = _col(fam, q_icl)
+    s, sp = _col(fam, q_vap_sat) if q_vap_sat is not None else (None, None)
+    out = np.empty(a.size, dtype=NP[fam.sfx])
+    der = np.empty(a.size, dtype=NP[fam.sfx])
+    fn = getattr(lib(), f"cmxo_mp0m_tendencies_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(p0m), C.c_int64(a.size), ap, bp, sp, out.ctypes.data_as(C.c_void_p), der.ctypes.data_as(C.c_void_p))
+    return out, der

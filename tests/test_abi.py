@@ -46,7 +46,7 @@ def test_struct_layout_matches_c(tmp_path):
                      "cloud_ice", "rain", "snow", "blk1m_vel_rain", "blk1m_vel_snow", "process_params_1m",
                      "microphysics_1m", "aerosol_activation_params", "aerosol_mode", "aerosol_distribution",
                      "p3_params", "chen2022_small_ice_vel", "chen2022_large_ice_vel", "chen2022_ice_vel", "quadrature",
-                     "local_rime_density", "rain_freezing", "frostenberg2023", "morrison_milbrandt2014", "p3_ice_params"):
+                     "parameters_0m", "local_rime_density", "rain_freezing", "frostenberg2023", "morrison_milbrandt2014", "p3_ice_params"):
             st = getattr(fam, name)
             probes.append((f"cmx_{name}_{fam.sfx}", st))
     src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{REPO}/include/cmx.h"', "int main(void){"]
@@ -95,6 +95,11 @@ def test_argument_validation_without_gpu():
     mp1 = P.Microphysics1MParams("f32")
     assert h1(C.byref(mp1.c), C.byref(tps), mp1.flags, 2, 8, ins, st7, None, None, None, None) == _abi.CMX_ERR_BAD_ARG       # no output
     assert h1(C.byref(mp1.c), C.byref(tps), mp1.flags, 0, 8, ins, st7, outs, st4, None, None) == _abi.CMX_OK
+    z = lib.cmx_mp0m_tendencies_f64
+    p0 = P.Parameters0M("f64")
+    assert z(None, 4, None, None, None, None, None, None) == _abi.CMX_ERR_BAD_ARG
+    assert z(C.byref(p0), 4, None, None, None, None, None, None) == _abi.CMX_ERR_BAD_ARG     # null columns
+    assert z(C.byref(p0), 0, None, None, None, None, None, None) == _abi.CMX_OK
     g = lib.cmx_column_sums_f64
     assert g(-1, None, 0, None, None) == _abi.CMX_ERR_BAD_ARG
     assert g(0, None, 0, None, None) == _abi.CMX_OK
