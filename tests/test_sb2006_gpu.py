@@ -328,6 +328,40 @@ def test_full_size_1e8_f32_properties(dev, oracle):
     print(f"\n[parity 1e8 f32, {samp[0].size} sampled points] max scaled err {rep}")
 
 
+# ---- maximum sizes: more than 2^31 points in one call (64-bit indexing end to end) ----------------------------------
+def test_more_than_2_pow_31_points(dev):
+    """2^31 + 2^20 + 1003 Float32 states (≈95 GB of columns) through the north-star entry and ≈26 GB through the 0-moment entry: the array is a
+    2^20-point tile repeated, so every tile of the output — including the ones either side of index 2^31 and the ragged last one —
+    must be bit-identical to the first (a pointwise map whose result does not depend on position or alignment)."""
+    import cmx
+    from cmx import synthetic
+    if torch.cuda.mem_get_info()[0] < 130e9:
+        pytest.skip("needs ≈100 GB of free HBM")
+    tile, n = 1 << 20, (1 << 31) + (1 << 20) + 1003
+    reps = -(-n // tile)
+    base = synthetic.sb2006_state(tile, dtype=torch.float32, device=dev, seed=77)
+    cols = [c.repeat(reps)[:n].contiguous() for c in base]
+    assert cols[0].numel() == n > 2 ** 31
+    mp, tps = P.Microphysics2MParams("f32"), P.ThermodynamicsParameters("f32")
+    out = cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), mp, tps, *cols)
+    first = cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), mp, tps, *base)
+    torch.cuda.synchronize()
+    last_lo = (reps - 1) * tile
+    for a, b in zip(out[:4], first[:4]):
+        for k in (0, 1, reps // 2, (1 << 31) // tile - 1, (1 << 31) // tile):      # …, the tile below and the tile at index 2^31
+            assert torch.equal(a[k * tile:(k + 1) * tile], b), k
+        assert torch.equal(a[last_lo:], b[:n - last_lo])
+        # all tiles at once: the full-tile part viewed as (reps − 1, tile) equals the first tile in every row
+        assert bool((a[:last_lo].view(reps - 1, tile) == b[None, :]).all())
+    del out
+    p0 = P.Microphysics0MParams("f32")
+    o0 = cmx.bulk_microphysics_tendencies_0m(cmx.Microphysics0Moment(), p0, None, cols[1], cols[3], cols[5])
+    f0 = cmx.bulk_microphysics_tendencies_0m(cmx.Microphysics0Moment(), p0, None, base[1], base[3], base[5])
+    torch.cuda.synchronize()
+    assert bool((o0[:last_lo].view(reps - 1, tile) == f0[None, :]).all()) and torch.equal(o0[last_lo:], f0[:n - last_lo])
+    assert bool((o0 < 0).any())
+
+
 @pytest.mark.parametrize("ft", ["f64", "f32"])
 def test_cloud_terminal_velocity(dev, oracle, ft):
     """CM2.cloud_terminal_velocity over columns (Microphysics2M.jl:647-664): the reference's formula test
