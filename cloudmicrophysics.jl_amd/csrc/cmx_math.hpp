@@ -28,6 +28,7 @@ template <> struct Math<float> {
     static __device__ __forceinline__ float div(float a, float b) { return a * rcp(b); }
     static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
     static __device__ __forceinline__ float max(float a, float b) { return __builtin_fmaxf(a, b); }
+    static __device__ __forceinline__ float nan() { return __builtin_nanf(""); }
     static __device__ __forceinline__ float min(float a, float b) { return __builtin_fminf(a, b); }
     // Γ(z) for z in [1, 8]: shift into [2,3) and evaluate a minimax-quality polynomial
     // (only used by the Chen-2022 rain velocity: z = b_i(ρ)+1 ∈ [2.0, 3.4], z+3).
@@ -58,6 +59,7 @@ template <> struct Math<double> {
     static __device__ __forceinline__ double div(double a, double b) { return a * lean::rcp(b); }
     static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
     static __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }
+    static __device__ __forceinline__ double nan() { return __builtin_nan(""); }
     static __device__ __forceinline__ double min(double a, double b) { return __builtin_fmin(a, b); }
     static __device__ __forceinline__ double tgamma(double z) { return ::tgamma(z); }
     static __device__ __forceinline__ double log1p(double x) { return lean::log1p(x); }
@@ -67,6 +69,18 @@ template <> struct Math<double> {
 template <typename FT> __device__ __forceinline__ FT clampv(FT x, FT lo, FT hi) {
     // Base.clamp: x < lo ? lo : (x > hi ? hi : x)
     return Math<FT>::min(Math<FT>::max(x, lo), hi);
+}
+
+// NaN inputs.  The reference sanitises with Julia's max(0, x), which returns NaN for a NaN x, and its arithmetic then carries the NaN to
+// the tendencies; the hardware v_max returns the other operand and would hide it.  The bulk-tendency kernels therefore poison every output
+// of a point whose inputs hold a NaN: one unordered compare per pair of inputs.
+#ifndef CMX_NAN_POISON
+#define CMX_NAN_POISON 1
+#endif
+template <typename FT> __device__ __forceinline__ bool any_nan(FT a) { return CMX_NAN_POISON && a != a; }
+template <typename FT> __device__ __forceinline__ bool any_nan(FT a, FT b) { return CMX_NAN_POISON && __builtin_isunordered(a, b); }
+template <typename FT, typename... R> __device__ __forceinline__ bool any_nan(FT a, FT b, R... r) {
+    return (bool)((int)any_nan(a, b) | (int)any_nan(r...));   // bitwise on purpose: no branch
 }
 
 }  // namespace cmx

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(kBlock) void mp0m_tendencies_kernel(const FT tau_pr
         const FT thr = SAT ? S_0 * qs[k] : qc_0;
         out[k] = -Math<FT>::max(FT(0), qc - thr) / tau_precip;                         // CM0:35-46
         der[k] = qc > thr ? neg_inv_tau : FT(0);                                        // CM0:64-75
+        if (SAT ? any_nan(ql[k], qi[k], qs[k]) : any_nan(ql[k], qi[k])) out[k] = Math<FT>::nan();   // max(0, NaN) = NaN in the reference
     }
     store_col<FT, VEC>(io.dq_tot_dt, i, out);
     if constexpr (DERIV) store_col<FT, VEC>(io.ddq_dq_tot, i, der);

@@ -351,6 +351,7 @@ __global__ __launch_bounds__(kBlock) void mp1m_tendencies_kernel(const Mp1mConst
     for (int k = 0; k < VEC; ++k) {
         const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(c, rho[k], T[k], q_tot[k], q_lcl[k], q_icl[k], q_rai[k], q_sno[k]);
         mp1m_aggregate<FT>(p.s, dl[k], di[k], dr[k], ds[k]);
+        if (any_nan(rho[k], q_tot[k], q_lcl[k], q_icl[k], q_rai[k], q_sno[k], T[k])) dl[k] = di[k] = dr[k] = ds[k] = Math<FT>::nan();
     }
     store_col<FT, VEC>(out.dq_lcl, i, dl); store_col<FT, VEC>(out.dq_icl, i, di);
     store_col<FT, VEC>(out.dq_rai, i, dr); store_col<FT, VEC>(out.dq_sno, i, ds);
@@ -424,8 +425,9 @@ __global__ __launch_bounds__(kBlock) void mp1m_linearized_kernel(const Mp1mConst
         ql += dl * a.dt_sub; qi += di * a.dt_sub; qr += dr * a.dt_sub; qs += ds * a.dt_sub;
         T += (a.Lv_over_cp * (dl + dr) + a.Ls_over_cp * (di + ds)) * a.dt_sub;
     }
-    out.dq_lcl[i] = (ql - ql0) * a.inv_dt; out.dq_icl[i] = (qi - qi0) * a.inv_dt;
-    out.dq_rai[i] = (qr - qr0) * a.inv_dt; out.dq_sno[i] = (qs - qs0) * a.inv_dt;
+    const FT poison = any_nan(rho, q_tot, ql0, qi0, qr0, qs0, in.T[i]) ? M::nan() : FT(0);   // NaN in → NaN out (cmx_math.hpp any_nan)
+    out.dq_lcl[i] = (ql - ql0) * a.inv_dt + poison; out.dq_icl[i] = (qi - qi0) * a.inv_dt + poison;
+    out.dq_rai[i] = (qr - qr0) * a.inv_dt + poison; out.dq_sno[i] = (qs - qs0) * a.inv_dt + poison;
 }
 
 template <typename FT>
@@ -581,6 +583,7 @@ template <typename FT, uint32_t FLAGS> struct Mp1mLayoutPolicy {
     static __device__ __forceinline__ void point(const Consts &c, const FT (&x)[NIN], FT (&y)[NOUT]) {
         const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(c, x[0], x[1], x[2], x[3], x[4], x[5], x[6]);
         mp1m_aggregate<FT>(p.s, y[0], y[1], y[2], y[3]);
+        if (any_nan(x[0], x[2], x[3], x[4], x[5], x[6], x[1])) y[0] = y[1] = y[2] = y[3] = Math<FT>::nan();
     }
 };
 template <typename FT, typename MP, typename TH>

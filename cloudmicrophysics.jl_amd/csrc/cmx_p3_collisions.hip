@@ -774,8 +774,11 @@ __global__ __launch_bounds__(kBlock) void mp2m_p3_pointwise_kernel(const SbConst
         bigg_rain<FT, LIMITED>(k, J_bigg, rho, q_rai, n_rai, N_rai, T, rn, rq);
         dq_rai -= rq; dn_rai -= rn; dq_ice += rq; dn_ice += rn; dq_rim += rq; db_rim += rq * k.inv_rho_i;
     }
-    io.out[0][i] = dq_lcl; io.out[1][i] = dn_lcl; io.out[2][i] = dq_rai; io.out[3][i] = dn_rai;
-    io.out[4][i] = dq_ice; io.out[5][i] = dn_ice; io.out[6][i] = dq_rim; io.out[7][i] = db_rim;
+    // NaN in → NaN out (cmx_math.hpp any_nan); the collision kernel then adds to the poisoned columns
+    const FT poison = any_nan(io.rho[i], io.q_tot[i], io.q_lcl[i], io.n_lcl[i], io.q_rai[i], io.n_rai[i], io.q_ice[i], io.n_ice[i], io.q_rim[i],
+                              io.b_rim[i], T) ? M::nan() : FT(0);
+    io.out[0][i] = dq_lcl + poison; io.out[1][i] = dn_lcl + poison; io.out[2][i] = dq_rai + poison; io.out[3][i] = dn_rai + poison;
+    io.out[4][i] = dq_ice + poison; io.out[5][i] = dn_ice + poison; io.out[6][i] = dq_rim + poison; io.out[7][i] = db_rim + poison;
 }
 
 // stand-alone Bigg freezing rates (the KA kernel test_rain_freezing_kernel!, test/gpu_tests.jl:463-468): cloud = generalized-gamma PSD

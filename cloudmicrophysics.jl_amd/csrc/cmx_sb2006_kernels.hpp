@@ -60,6 +60,8 @@ __global__ __launch_bounds__(BS) void sb2006_tendencies_kernel(const SbConsts<FT
             const FT qr = M::max(FT(0), q_rai[t][k]);
             const FT nl = M::max(FT(0), n_lcl[t][k]);
             const FT nr = M::max(FT(0), n_rai[t][k]);
+            // a NaN in any input column poisons every output of the point (cmx_math.hpp any_nan)
+            const bool poisoned = any_nan(rho[t][k], q_tot[t][k], q_lcl[t][k], n_lcl[t][k], q_rai[t][k], n_rai[t][k], T[t][k]);
             // N = ρ n — BMT:718-719
             const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL>(c, r_, T[t][k], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
             // sums of warm_rain_tendencies_2m — BMT:738-779.  The per-m³ number rates are added first and divided by ρ once (the
@@ -71,6 +73,7 @@ __global__ __launch_bounds__(BS) void sb2006_tendencies_kernel(const SbConsts<FT
             dn_rai[k] = M::fma(((p.evN + p.au_dN_rai) + p.rsc) + p.rbr, p.inv_rho, p.na_rai);
             vt_n[k] = p.vt_n;
             vt_m[k] = p.vt_m;
+            if (poisoned) dq_lcl[k] = dn_lcl[k] = dq_rai[k] = dn_rai[k] = vt_n[k] = vt_m[k] = M::nan();
         }
         store_col<FT, VEC, NT>(out.dq_lcl, i, dq_lcl);
         store_col<FT, VEC, NT>(out.dn_lcl, i, dn_lcl);
@@ -96,6 +99,7 @@ template <typename FT, bool LIMITED> struct Sb2006LayoutPolicy {
         y[1] = M::fma(p.lsc_plus_au + p.ac_dN_lcl, p.inv_rho, p.na_lcl);
         y[2] = (p.evq + p.au_dq_rai) + p.ac_dq_rai;
         y[3] = M::fma(((p.evN + p.au_dN_rai) + p.rsc) + p.rbr, p.inv_rho, p.na_rai);
+        if (any_nan(x[0], x[2], x[3], x[4], x[5], x[6], x[1])) y[0] = y[1] = y[2] = y[3] = M::nan();
     }
 };
 

@@ -1,0 +1,66 @@
+"""NaN inputs.  The reference sanitises with Julia's `max(0, x)` (= NaN for a NaN x, src/Utilities.jl:296) and carries the NaN to the
+tendencies; the device clamps use v_max, which would return 0.  The bulk-tendency entries therefore poison every output of a point
+whose inputs hold a NaN, and leave all other points untouched (bit-identical to a run without the NaN)."""
+import pytest
+import torch
+
+from cmx import parameters as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda", 0)
+
+
+def _check(call, cols, n_out, lo=0):
+    clean = call(cols)
+    n = cols[0].numel()
+    for k in range(len(cols)):
+        bad = [c.clone() for c in cols]
+        idx = torch.arange(k, n, 37, device=cols[0].device)
+        bad[k][idx] = float("nan")
+        out = call(bad)
+        mask = torch.zeros(n, dtype=torch.bool, device=cols[0].device)
+        mask[idx] = True
+        mask = mask[lo:]
+        for a, b in zip(list(out)[:n_out], list(clean)[:n_out]):
+            assert bool(torch.isnan(a[mask]).all()), f"input column {k}: NaN not propagated"
+            assert torch.equal(torch.nan_to_num(a[~mask], nan=-7.0), torch.nan_to_num(b[~mask], nan=-7.0)), f"input column {k}: clean points changed"
+
+
+@pytest.mark.parametrize("sfx", ["f32", "f64"])
+def test_nan_in_any_input_poisons_the_point(dev, sfx):
+    import cmx
+    from cmx import synthetic
+    dt = torch.float32 if sfx == "f32" else torch.float64
+    n = 10_007
+    tps = P.ThermodynamicsParameters(sfx)
+    mp2, mp1, mp0 = P.Microphysics2MParams(sfx), P.Microphysics1MParams(sfx), P.Microphysics0MParams(sfx)
+    st2 = [c.clone() for c in synthetic.sb2006_state(n, dtype=dt, device=dev, seed=21)]
+    st1 = [c.clone() for c in synthetic.mp1m_state(n, dtype=dt, device=dev, seed=22)]
+    s2, s1, s0 = cmx.Microphysics2Moment(), cmx.Microphysics1Moment(), cmx.Microphysics0Moment()
+    _check(lambda c: cmx.bulk_microphysics_tendencies(s2, mp2, tps, *c, vel=cmx.SB2006VelType), st2, 6)
+    _check(lambda c: cmx.bulk_microphysics_tendencies(s2, mp2, tps, *[x[1:] for x in c]), st2, 4, lo=1)     # one-point-per-lane path
+    _check(lambda c: cmx.bulk_microphysics_tendencies_fields(s2, mp2, tps, *c), st2, 4)
+    _check(lambda c: cmx.bulk_microphysics_tendencies_1m(cmx.Instantaneous(), s1, mp1, tps, *c), st1, 4)
+    _check(lambda c: cmx.bulk_microphysics_tendencies_1m(cmx.LinearizedAverage(), s1, mp1, tps, *c, 10.0, 2), st1, 4)
+    _check(lambda c: cmx.bulk_microphysics_tendencies_1m_fields(cmx.Instantaneous(), s1, mp1, tps, *c), st1, 4)
+    _check(lambda c: (cmx.bulk_microphysics_tendencies_0m(s0, mp0, tps, c[0], c[0], c[1]),), [st1[3], st1[4]], 1)
+    _check(lambda c: (cmx.bulk_microphysics_tendencies_0m(s0, mp0, tps, c[0], c[0], c[1], c[2]),), [st1[3], st1[4], st1[2]], 1)
+
+
+def test_nan_in_the_2m_p3_entry(dev):
+    import cmx
+    from cmx import synthetic
+    n = 2048
+    mp, tps = P.Microphysics2MParams("f64", with_ice=True), P.ThermodynamicsParameters("f64")
+    st = [c.clone() for c in synthetic.sb2006_state(n, dtype=torch.float64, device=dev, seed=31)]
+    p3 = synthetic.p3_state(n, dtype=torch.float64, device=dev, seed=32)
+    rho = st[0]
+    ice = [p3.rho_q_ice / rho, p3.rho_n_ice / rho, p3.rho_q_rim / rho, p3.rho_b_rim / rho]
+    ll = cmx.p3_shape(P.ParametersP3("f64"), *p3, want=("log_lambda",)).log_lambda
+    _check(lambda c: cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), mp, tps, *c, ll), st + ice, 8)
