@@ -10,7 +10,7 @@ import json
 import sys
 from pathlib import Path
 
-BYTES_PER_POINT = {"sb2006": 13, "icenuc": 5, "mp0m": 3, "mp1m": 11, "arg2000": 9, "p3": 9}   # columns in + out
+BYTES_PER_POINT = {"sb2006": 13, "icenuc": 5, "mp0m": 3, "mp1m": 11, "arg2000": 9, "p3": 9, "sb2006_aos": 15, "sb2006_fields": 11, "mp2m_p3": 20}   # columns in + out
 
 
 def find(out, sub, suffix):
