@@ -191,7 +191,7 @@ __device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, cons
     } else {
         smax = S_arg;   // N_liq = N_ice = 0: K_liq = K_ice = 0 ⇒ S_max = S_max_ARG·αw/αw
     }
-    smax = M::max(FT(0), smax);                                                                            // AA:199
+    smax = smax < FT(0) ? FT(0) : smax;   // AA:199 max(0, S_max) with Julia's NaN rule: a NaN from any input reaches every output below
     o.smax = smax;
     const FT dl0 = l2_A15 - M::log2(smax);                       // log2(Sm_i / S_max) = l2_sm_c + dl0
 #pragma unroll

@@ -99,6 +99,8 @@ __global__ __launch_bounds__(kBlock) void p3_shape_kernel(const P3Consts<FT> c, 
         }
         loglam = b;
     }
+    // NaN in → NaN out (cmx_math.hpp any_nan): the gates and the regularised ratios above would map a NaN input to "no ice"
+    if (any_nan(io.rho_q[i], io.rho_n[i], io.x3[i], io.x4[i])) loglam = s.F_rim = s.rho_rim = Math<FT>::nan();
     if (io.F_rim) io.F_rim[i] = s.F_rim;
     if (io.rho_rim) io.rho_rim[i] = s.rho_rim;
     if (io.loglam) io.loglam[i] = loglam;

@@ -117,7 +117,9 @@ __global__ __launch_bounds__(kBlock) void sb2006_process_kernel(const SbConsts<F
         const FT inv_r = M::rcp(r_);
         const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL>(c, r_, T[i], q_tot[i], q_lcl[i], q_rai[i], N_lcl[i],
                                                              N_rai[i], N_lcl[i] * inv_r, N_rai[i] * inv_r);
-#define CMX_PUT(colid, v) if (out.col[colid]) out.col[colid][i] = (v)
+        // NaN in → NaN out (cmx_math.hpp any_nan): the max(x, ϵ) floors of the process functions would hide it
+        const FT poison = any_nan(q_tot[i], q_lcl[i], q_rai[i], N_lcl[i], N_rai[i], r_, T[i]) ? M::nan() : FT(0);
+#define CMX_PUT(colid, v) if (out.col[colid]) out.col[colid][i] = (v) + poison
         CMX_PUT(CMX_SB_ACNV_DQ_LCL, p.au_dq_lcl);
         CMX_PUT(CMX_SB_ACNV_DN_LCL, p.au_dN_lcl);
         CMX_PUT(CMX_SB_ACNV_DQ_RAI, p.au_dq_rai);

@@ -64,3 +64,25 @@ def test_nan_in_the_2m_p3_entry(dev):
     ice = [p3.rho_q_ice / rho, p3.rho_n_ice / rho, p3.rho_q_rim / rho, p3.rho_b_rim / rho]
     ll = cmx.p3_shape(P.ParametersP3("f64"), *p3, want=("log_lambda",)).log_lambda
     _check(lambda c: cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), mp, tps, *c, ll), st + ice, 8)
+
+
+def test_nan_in_the_other_entries(dev):
+    """ARG2000 (a NaN reaches S_max and through it every mode), the P3 shape solver and the SB2006 per-process entry."""
+    import cmx
+    from cmx import synthetic
+    sfx, dt, n = "f32", torch.float32, 4099
+    tps = P.ThermodynamicsParameters(sfx)
+    ap, aip, ad = P.AerosolActivationParameters(sfx), P.AirProperties(sfx), synthetic.arg_config3_distribution()
+    sta = [c.clone() for c in synthetic.arg_state(n, dtype=dt, device=dev, seed=41)]
+
+    def arg(c):
+        r = cmx.aerosol_activation(ap, ad, aip, tps, *c, want=("N_act", "M_act", "S_max"))
+        return tuple(r.N_act) + tuple(r.M_act) + (r.S_max,)
+    _check(arg, sta, 11)
+    _check(lambda c: tuple(cmx.aerosol_activation(ap, ad, aip, tps, *c).N_act), sta, 5)                  # the number-only instantiation
+    p3 = [c.clone() for c in synthetic.p3_state(n, dtype=torch.float64, device=dev, seed=42)]
+    _check(lambda c: tuple(cmx.p3_shape(P.ParametersP3("f64"), *c, want=("F_rim", "rho_rim", "log_lambda", "D_m", "log_N0"))), p3, 5)
+    st2 = [c.clone() for c in synthetic.sb2006_state(n, dtype=dt, device=dev, seed=43)]
+    rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai = st2
+    mp2 = P.Microphysics2MParams(sfx)
+    _check(lambda c: tuple(cmx.sb2006_process_rates(mp2, tps, *c)), [q_tot, q_lcl, q_rai, n_lcl * rho, n_rai * rho, rho, T], 17)
