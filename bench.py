@@ -6,9 +6,15 @@ out) over the rank's resident batch of synthetic grid points (default 1e8 Float3
 configuration BASELINE.json quotes the metric on).  Inputs are generated on the device before the timed
 region; nothing crosses PCIe inside it.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--points P] [--dtype f32|f64] [--workload sb2006|icenuc|mp1m|arg2000|p3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--points P] [--dtype f32|f64] [--scaling weak|strong]
+                    [--workload sb2006|sb2006_column|sb2006_aos|sb2006_fields|icenuc|mp0m|mp1m|mp1m_lin|arg2000|p3|p3_selfcol|mp2m_p3]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
+
+Both forms work for N > 1: called as a plain process with `--gpus N` (no WORLD_SIZE in the environment) this
+script is a launcher — before anything touches torch or the GPU it starts the second form as a child process
+(cmx/launcher.py), relays rank 0's JSON line and exits with the child's code.  `--scaling weak` (default) keeps
+`--points` per GPU; `--scaling strong` splits `--points` over the ranks with cmx.sharding.shard_bounds.
 
 Rank 0 prints ONE JSON line (contract: see the task statement; DESIGN.md §6 explains every field).
 `--workload` selects one of the other hot-path kernels for roofline measurements (same JSON shape); the default,
@@ -36,7 +42,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--settle", type=int, default=30,
                     help="untimed launches before the warm-up: after idle the first ≈15 launches run 5–20 %% slower while the clocks settle")
-    ap.add_argument("--points", type=int, default=100_000_000, help="grid points per GPU")
+    ap.add_argument("--points", type=int, default=100_000_000, help="grid points per GPU (weak scaling) or in total (strong scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --points per GPU; strong: --points in total, sharded over the ranks (cmx.sharding.shard_bounds)")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--workload", choices=["sb2006", "icenuc", "mp0m", "mp1m", "mp1m_lin", "arg2000", "p3", "p3_selfcol", "mp2m_p3", "sb2006_aos", "sb2006_fields"], default="sb2006")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -72,8 +80,8 @@ def pmc_traffic(workload: str, dtype: str, n: int):
         except (OSError, ValueError):
             continue
         if d.get("points") == n and d.get("dtype") == dtype:
-            return d.get("hbm_bytes_per_launch")
-    return None
+            return d.get("hbm_bytes_per_launch"), str(p.relative_to(REPO))
+    return None, None
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -462,8 +470,22 @@ def cpu_baseline(args, cols_np, desc, cpu_run):
                       f"{args.dtype} arithmetic, oracle/libcmx_oracle.so (gcc -O2, {cores} OpenMP thread(s)), {dt:.1f} s"}
 
 
+def load_launcher():
+    """cmx/launcher.py by file path: importing the `cmx` package would import torch, and the launcher process must
+    stay clear of torch and HIP (it only starts child processes)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("cmx_launcher", REPO / "cloudmicrophysics.jl_amd" / "cmx" / "launcher.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def main():
     args = parse()
+    launcher = load_launcher()
+    if launcher.needs_launch(args.gpus):
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (child processes; nothing here has touched the GPU)
+        sys.exit(launcher.launch(str(Path(__file__).resolve()), sys.argv[1:], args.gpus))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -473,16 +495,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and args.gpus > 1:
-        sys.exit("launch with torch.distributed.run for --gpus > 1 (one process per GPU)")
+    if world != max(1, args.gpus):
+        sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
 
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
-    n = args.points                                          # weak scaling: fixed work per GPU
-    # rank r owns shard r of the global [0, world·n) index space: disjoint seeds, no exchange
+    points_arg = args.points
+    if args.scaling == "strong":                             # fixed total work: rank r owns shard r of [0, points)
+        lo, hi = sharding.shard_bounds(points_arg, rank, world)
+        args.points = hi - lo
+    # weak scaling: fixed work per GPU; rank r owns shard r of the global [0, world·n) index space.
+    # Either way: disjoint seeds, no exchange
     setup = {"sb2006": setup_sb2006, "icenuc": setup_icenuc, "mp0m": setup_mp0m, "mp1m": setup_mp1m, "mp1m_lin": setup_mp1m_lin, "arg2000": setup_arg2000,
              "p3": setup_p3, "p3_selfcol": setup_p3_selfcol, "mp2m_p3": setup_mp2m_p3, "sb2006_aos": setup_sb2006_layout, "sb2006_fields": setup_sb2006_layout}[args.workload]
     state, kernel_step, desc, cpu_run = setup(args, dev, dtype, rank)
@@ -513,27 +539,32 @@ def main():
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(n)], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)     # the points all ranks processed per step (layout workloads round per rank)
     elapsed = float(t.item())
 
     if rank == 0:
-        total_points = n * world
+        total_points = int(tot.item())
         bpp = desc["bytes_per_point"]
         achieved = n * bpp / (kern_ms * 1e-3) / 1e9
+        traffic, traffic_source = pmc_traffic(args.workload, args.dtype, n)
         line = {
             "metric": desc["metric"],
             "value": total_points * args.steps / elapsed,
             "unit": "grid-points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": args.settle,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": desc["workload"], "points_per_gpu": n, "columns_in": desc["columns_in"],
+            "config": {"workload": desc["workload"], "points_per_gpu": n, "points_total": total_points, "columns_in": desc["columns_in"],
                        "columns_out": desc["columns_out"],
                        "parallelism": f"shard{world}" + ("+rccl-diag" if args.diagnostics else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.workload, args.dtype, n),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": (traffic_source + " (rocprofv3 PMC pass of this command on an earlier run; not measured in this run)")
+                                           if traffic_source else None,
                          "kernel": desc["kernel"], "kernel_ms": kern_ms, "bytes_per_point": bpp},
         }
         if "note" in desc:

@@ -1,0 +1,47 @@
+"""bench.py contract on the GPU box: the N = 1 line (weak and strong), and — where the box has ≥ 2 GPUs — the self-launched N = 2 job."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+REPO = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.gpu
+
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+        "data", "config", "roofline"}
+
+
+def _run(*extra, timeout=900):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--steps", "3", "--warmup", "1", "--settle", "2", "--points", "1000003",
+                        *extra], capture_output=True, text=True, env=env, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_single_gpu_line(scaling):
+    d = _run("--scaling", scaling, "--cpu-seconds", "0.5")
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["scaling"] == scaling and d["steps"] == 3
+    assert d["config"]["points_per_gpu"] == 1000003 and d["config"]["points_total"] == 1000003
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and "traffic_source" in rf
+    assert abs(rf["achieved"] - 1000003 * 52 / (rf["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    assert d["value"] == pytest.approx(1000003 * 3 / (d["ms_per_step"] * 3e-3), rel=1e-9)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_self_launched_two_rank_job(scaling):
+    d = _run("--gpus", "2", "--scaling", scaling, "--no-cpu-baseline")
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling
+    assert d["config"]["points_total"] == (2 * 1000003 if scaling == "weak" else 1000003)
