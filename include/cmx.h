@@ -28,6 +28,21 @@
  *  - `_f32` entry points compute in float with the reference's Float32
  *    thresholds (eps(Float32), cbrt(floatmin(Float32)) — src/Utilities.jl:318-340),
  *    `_f64` ones in double with the Float64 thresholds.
+ *
+ * What this boundary deliberately does NOT have (SURVEY.md §8b proposed them; the decision is recorded here so
+ * the header is the whole contract):
+ *  - no `cmx_ctx` / `cmx_context_create`: the library is STATELESS.  The device is the calling thread's current HIP
+ *    device, the stream is an argument, parameters are copied into the kernel arguments per call, nothing is
+ *    cached between calls (the only process-wide state is a per-device properties cache filled once under
+ *    std::call_once).  Every entry is therefore re-entrant, capturable into a HIP graph, and safe to call
+ *    concurrently from several host threads on several streams or devices;
+ *  - no `cmx_*_host` entry points taking host pointers: a host-pointer variant could only be a copy-in / copy-out
+ *    wrapper (PCIe 63 GB/s against 52 B/point: ≈ 90× below the HBM-resident rate) or a CPU
+ *    implementation, and a CPU path inside the product is ruled out (the CPU restatement lives in oracle/ as
+ *    test infrastructure only).  A caller with host data does hipMemcpyAsync on its own stream;
+ *  - no `cmx_multi_*` device-list entry points: the multi-GPU model is one PROCESS per GPU (torch.distributed /
+ *    RCCL, cmx/sharding.py); each rank calls the single-device entries on its contiguous shard of every column
+ *    and there is no data-path collective to hide behind an API.
  */
 #ifndef CMX_H
 #define CMX_H
@@ -285,6 +300,73 @@ typedef enum cmx_status {
 
 CMX_DECLARE_PARAM_STRUCTS(float, f32)
 CMX_DECLARE_PARAM_STRUCTS(double, f64)
+
+/* ---------------------------------------------------------------------------
+ * Size contract of every parameter struct: field count × sizeof(FT) (+ the 8-byte integer header of the two structs
+ * that carry a count).  No struct has padding — every member is an FT or an array / struct of FT — so a binding that
+ * declares the same fields in the same order (INTEGRATION.md §2 quotes these counts) has the same layout; a binding
+ * with a missing field (e.g. the 13th member `cv_l` of cmx_thermo_*) has a different sizeof and must not compile.
+ * tests/test_abi.py checks the same numbers from the Python side, tests/native/abi_caller.c from plain C.
+ * ------------------------------------------------------------------------- */
+#if defined(__cplusplus)
+#define CMX_STATIC_ASSERT(cond, msg) static_assert(cond, msg)
+#else
+#define CMX_STATIC_ASSERT(cond, msg) _Static_assert(cond, msg)
+#endif
+#define CMX_ASSERT_PARAM_STRUCT_SIZES(FT, SFX) \
+    CMX_STATIC_ASSERT(sizeof(cmx_abifm_dust_##SFX) == 2 * sizeof(FT), "cmx_abifm_dust");\
+    CMX_STATIC_ASSERT(sizeof(cmx_accr_sb2006_##SFX) == 4 * sizeof(FT), "cmx_accr_sb2006");\
+    CMX_STATIC_ASSERT(sizeof(cmx_acnv_1m_##SFX) == 3 * sizeof(FT), "cmx_acnv_1m");\
+    CMX_STATIC_ASSERT(sizeof(cmx_acnv_sb2006_##SFX) == 6 * sizeof(FT), "cmx_acnv_sb2006");\
+    CMX_STATIC_ASSERT(sizeof(cmx_aerosol_activation_params_##SFX) == 12 * sizeof(FT), "cmx_aerosol_activation_params");\
+    CMX_STATIC_ASSERT(sizeof(cmx_aerosol_distribution_##SFX) == 8 + 40 * sizeof(FT), "cmx_aerosol_distribution");\
+    CMX_STATIC_ASSERT(sizeof(cmx_aerosol_mode_##SFX) == 5 * sizeof(FT), "cmx_aerosol_mode");\
+    CMX_STATIC_ASSERT(sizeof(cmx_air_properties_##SFX) == 3 * sizeof(FT), "cmx_air_properties");\
+    CMX_STATIC_ASSERT(sizeof(cmx_b1994_##SFX) == 9 * sizeof(FT), "cmx_b1994");\
+    CMX_STATIC_ASSERT(sizeof(cmx_blk1m_vel_rain_##SFX) == 11 * sizeof(FT), "cmx_blk1m_vel_rain");\
+    CMX_STATIC_ASSERT(sizeof(cmx_blk1m_vel_snow_##SFX) == 8 * sizeof(FT), "cmx_blk1m_vel_snow");\
+    CMX_STATIC_ASSERT(sizeof(cmx_breakup_sb2006_##SFX) == 4 * sizeof(FT), "cmx_breakup_sb2006");\
+    CMX_STATIC_ASSERT(sizeof(cmx_bulk_2m_schemes_##SFX) == 28 * sizeof(FT), "cmx_bulk_2m_schemes");\
+    CMX_STATIC_ASSERT(sizeof(cmx_chen2022_ice_vel_##SFX) == 42 * sizeof(FT), "cmx_chen2022_ice_vel");\
+    CMX_STATIC_ASSERT(sizeof(cmx_chen2022_large_ice_vel_##SFX) == 22 * sizeof(FT), "cmx_chen2022_large_ice_vel");\
+    CMX_STATIC_ASSERT(sizeof(cmx_chen2022_rain_vel_##SFX) == 12 * sizeof(FT), "cmx_chen2022_rain_vel");\
+    CMX_STATIC_ASSERT(sizeof(cmx_chen2022_small_ice_vel_##SFX) == 20 * sizeof(FT), "cmx_chen2022_small_ice_vel");\
+    CMX_STATIC_ASSERT(sizeof(cmx_cloud_ice_##SFX) == 10 * sizeof(FT), "cmx_cloud_ice");\
+    CMX_STATIC_ASSERT(sizeof(cmx_cloud_liquid_##SFX) == 3 * sizeof(FT), "cmx_cloud_liquid");\
+    CMX_STATIC_ASSERT(sizeof(cmx_cloud_pdf_sb2006_##SFX) == 7 * sizeof(FT), "cmx_cloud_pdf_sb2006");\
+    CMX_STATIC_ASSERT(sizeof(cmx_evap_sb2006_##SFX) == 10 * sizeof(FT), "cmx_evap_sb2006");\
+    CMX_STATIC_ASSERT(sizeof(cmx_frostenberg2023_##SFX) == 5 * sizeof(FT), "cmx_frostenberg2023");\
+    CMX_STATIC_ASSERT(sizeof(cmx_kk2000_##SFX) == 7 * sizeof(FT), "cmx_kk2000");\
+    CMX_STATIC_ASSERT(sizeof(cmx_koop2000_##SFX) == 8 * sizeof(FT), "cmx_koop2000");\
+    CMX_STATIC_ASSERT(sizeof(cmx_ld2004_##SFX) == 4 * sizeof(FT), "cmx_ld2004");\
+    CMX_STATIC_ASSERT(sizeof(cmx_local_rime_density_##SFX) == 4 * sizeof(FT), "cmx_local_rime_density");\
+    CMX_STATIC_ASSERT(sizeof(cmx_microphysics_1m_##SFX) == 85 * sizeof(FT), "cmx_microphysics_1m");\
+    CMX_STATIC_ASSERT(sizeof(cmx_morrison_milbrandt2014_##SFX) == 6 * sizeof(FT), "cmx_morrison_milbrandt2014");\
+    CMX_STATIC_ASSERT(sizeof(cmx_numadj_horn2012_##SFX) == 1 * sizeof(FT), "cmx_numadj_horn2012");\
+    CMX_STATIC_ASSERT(sizeof(cmx_p3_ice_params_##SFX) == 8 + 354 * sizeof(FT), "cmx_p3_ice_params");\
+    CMX_STATIC_ASSERT(sizeof(cmx_p3_params_##SFX) == 13 * sizeof(FT), "cmx_p3_params");\
+    CMX_STATIC_ASSERT(sizeof(cmx_parameters_0m_##SFX) == 3 * sizeof(FT), "cmx_parameters_0m");\
+    CMX_STATIC_ASSERT(sizeof(cmx_particle_area_##SFX) == 4 * sizeof(FT), "cmx_particle_area");\
+    CMX_STATIC_ASSERT(sizeof(cmx_particle_mass_##SFX) == 6 * sizeof(FT), "cmx_particle_mass");\
+    CMX_STATIC_ASSERT(sizeof(cmx_process_params_1m_##SFX) == 18 * sizeof(FT), "cmx_process_params_1m");\
+    CMX_STATIC_ASSERT(sizeof(cmx_quadrature_##SFX) == 8 + 256 * sizeof(FT), "cmx_quadrature");\
+    CMX_STATIC_ASSERT(sizeof(cmx_rain_##SFX) == 13 * sizeof(FT), "cmx_rain");\
+    CMX_STATIC_ASSERT(sizeof(cmx_rain_freezing_##SFX) == 2 * sizeof(FT), "cmx_rain_freezing");\
+    CMX_STATIC_ASSERT(sizeof(cmx_rain_pdf_sb2006_##SFX) == 10 * sizeof(FT), "cmx_rain_pdf_sb2006");\
+    CMX_STATIC_ASSERT(sizeof(cmx_rain_vel_##SFX) == 19 * sizeof(FT), "cmx_rain_vel");\
+    CMX_STATIC_ASSERT(sizeof(cmx_sb2006_##SFX) == 45 * sizeof(FT), "cmx_sb2006");\
+    CMX_STATIC_ASSERT(sizeof(cmx_sb2006_vel_##SFX) == 7 * sizeof(FT), "cmx_sb2006_vel");\
+    CMX_STATIC_ASSERT(sizeof(cmx_selfcol_sb2006_##SFX) == 3 * sizeof(FT), "cmx_selfcol_sb2006");\
+    CMX_STATIC_ASSERT(sizeof(cmx_snow_##SFX) == 19 * sizeof(FT), "cmx_snow");\
+    CMX_STATIC_ASSERT(sizeof(cmx_stokes_vel_##SFX) == 3 * sizeof(FT), "cmx_stokes_vel");\
+    CMX_STATIC_ASSERT(sizeof(cmx_tc1980_##SFX) == 8 * sizeof(FT), "cmx_tc1980");\
+    CMX_STATIC_ASSERT(sizeof(cmx_thermo_##SFX) == 13 * sizeof(FT), "cmx_thermo");\
+    CMX_STATIC_ASSERT(sizeof(cmx_var_timescale_acnv_##SFX) == 3 * sizeof(FT), "cmx_var_timescale_acnv");\
+    CMX_STATIC_ASSERT(sizeof(cmx_ventilation_##SFX) == 2 * sizeof(FT), "cmx_ventilation");\
+    CMX_STATIC_ASSERT(sizeof(cmx_warm_rain_2m_##SFX) == 50 * sizeof(FT), "cmx_warm_rain_2m");
+
+CMX_ASSERT_PARAM_STRUCT_SIZES(float, f32)
+CMX_ASSERT_PARAM_STRUCT_SIZES(double, f64)
 
 /* ---------------------------------------------------------------------------
  * Library / device queries
