@@ -273,6 +273,7 @@ static int32_t arg_entry(const AP *ap, const AD *ad, const AI *aip, const TH *tp
                          const FT *w, const FT *q_tot, const FT *q_liq, const FT *q_ice, const FT *N_liq, const FT *N_ice,
                          FT *const *N_act, FT *const *M_act, FT *S_max, void *stream) {
     if (!ap || !ad || !aip || !tps || n < 0 || ad->n_modes < 1 || ad->n_modes > CMX_ARG_MAX_MODES) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (n == 0) return CMX_OK;
     if (!T || !p || !w || !q_tot) return CMX_ERR_BAD_ARG;
     const ArgConsts<FT> c = make_arg_consts<FT>(*ap, *ad, *aip, *tps);
@@ -364,6 +365,7 @@ static int32_t arg_columns_entry(const AP *ap, const AI *aip, const TH *tps, int
                                  const FT *const *r_dry, const FT *const *stdev, const FT *const *N_mode, const FT *const *hyg,
                                  const FT *const *mmix, FT *const *N_act, FT *const *M_act, FT *S_max, void *stream) {
     if (!ap || !aip || !tps || n < 0 || n_modes < 1 || n_modes > CMX_ARG_MAX_MODES) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (n == 0) return CMX_OK;
     if (!T || !p || !w || !q_tot || !r_dry || !stdev || !N_mode || !hyg) return CMX_ERR_BAD_ARG;
     if (M_act && !mmix) return CMX_ERR_BAD_ARG;

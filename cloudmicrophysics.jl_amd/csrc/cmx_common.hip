@@ -3,6 +3,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 #include "cmx_launch.hpp"
 
@@ -15,12 +16,14 @@ void set_hip_error(hipError_t e, const char *where) {
 }
 
 DeviceInfo device_info() {
-    // one entry per device ordinal; CMX_BLOCKS_PER_CU overrides the resident-workgroup factor
+    // one entry per device ordinal, each filled exactly once under its own std::once_flag: ctypes / ccall release the host
+    // runtime's lock around every cmx_* call, so two host threads (one per stream or device) may arrive here together.
+    // CMX_BLOCKS_PER_CU overrides the resident-workgroup factor.
     static DeviceInfo cache[64];
-    static bool have[64] = {};
+    static std::once_flag once[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return DeviceInfo{256, 8};
-    if (!have[dev]) {
+    std::call_once(once[dev], [dev] {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         int bpc = 8;
@@ -29,8 +32,7 @@ DeviceInfo device_info() {
             if (v > 0 && v <= 64) bpc = v;
         }
         cache[dev] = DeviceInfo{cus, bpc};
-        have[dev] = true;
-    }
+    });
     return cache[dev];
 }
 
@@ -58,12 +60,13 @@ template <typename FT>
 static int32_t column_sums(int32_t ncols, const FT *const *cols, int64_t n, double *sums, void *stream) {
     if (ncols < 0 || n < 0 || (ncols > 0 && (!cols || !sums))) return CMX_ERR_BAD_ARG;
     if (ncols == 0) return CMX_OK;
+    for (int32_t k = 0; k < ncols; ++k)
+        if (!cols[k]) return CMX_ERR_BAD_ARG;          // validate everything before the first enqueue
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     CMX_HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * (size_t)ncols, s));
     if (n == 0) return CMX_OK;
     const int grid = grid_for(n, kBlock * 8);
     for (int32_t k = 0; k < ncols; ++k) {
-        if (!cols[k]) return CMX_ERR_BAD_ARG;
         hipLaunchKernelGGL((column_sum_kernel<FT>), dim3(grid), dim3(kBlock), 0, s, cols[k], n, sums + k);
     }
     CMX_HIP_TRY(hipGetLastError());

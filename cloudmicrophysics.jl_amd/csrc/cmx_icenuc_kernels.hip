@@ -167,6 +167,7 @@ static int32_t icenuc_entry(const TH *tps, const DU *dust, const KO *koop, uint3
                             const FT *a_w, const FT *r, FT *delta_a_w, FT *J_het, FT *J_hom, FT *rate_het, FT *rate_hom,
                             int64_t *n_domain_errors, void *stream) {
     if (!tps || !dust || !koop || n < 0 || (flags & ~CMX_ICENUC_HOM_LINEAR)) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (n == 0) return CMX_OK;
     if (!T || !a_w || ((rate_het || rate_hom) && !r)) return CMX_ERR_BAD_ARG;
     const IceNucConsts<FT> c = make_icenuc_consts<FT>(*tps, dust, koop);
@@ -210,6 +211,7 @@ template <typename FT, typename TH>
 static int32_t water_activity_entry(const TH *tps, int64_t n, const FT *T, const FT *e, FT *a_w_ice, FT *a_w_eT,
                                     void *stream) {
     if (!tps || n < 0) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (n == 0) return CMX_OK;
     if (!T || (a_w_eT && !e)) return CMX_ERR_BAD_ARG;
     const IceNucConsts<FT> c =
@@ -242,6 +244,7 @@ template <typename FT, typename TH, typename DU>
 static int32_t p3_het_nucleation_entry(const DU *dust, const TH *tps, int64_t n, const FT *q_lcl, const FT *N_lcl, const FT *RH, const FT *T,
                                        const FT *rho, FT *dNdt, FT *dLdt, void *stream) {
     if (!dust || !tps || n < 0) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (n == 0) return CMX_OK;
     if (!q_lcl || !N_lcl || !RH || !T || !rho || (!dNdt && !dLdt)) return CMX_ERR_BAD_ARG;
     using KO = std::conditional_t<std::is_same_v<FT, float>, cmx_koop2000_f32, cmx_koop2000_f64>;

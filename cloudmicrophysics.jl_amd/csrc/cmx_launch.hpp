@@ -21,11 +21,12 @@ void set_hip_error(hipError_t e, const char *where);   // cmx_common.hip
     } while (0)
 
 // --- geometry ------------------------------------------------------------------------------
-// MI355X: 256 CUs in 8 XCDs.  Pointwise streaming kernels use 256-thread workgroups (4 waves, one
-// per SIMD) and a grid-stride loop over a grid of CUs × k resident workgroups, so that every CU
-// keeps ≥16 waves of independent 16-byte loads in flight and the grid is a multiple of the 8 XCDs
-// (workgroup b lands on XCD b % 8: consecutive workgroups stream consecutive 4 KiB tiles, each XCD
-// L2 sees a disjoint, dense address set).
+// MI355X: 256 CUs in 8 XCDs.  The streaming kernels are NON-persistent: one short-lived workgroup per tile
+// (256 lanes; 128 for the SB2006 sweep), one lane owns 16 bytes of every column, so the grid is ≫ 256 workgroups and
+// workgroup b lands on XCD b % 8 — consecutive workgroups stream consecutive tiles and each XCD L2 sees a disjoint,
+// dense address set.  (A grid-stride loop over CUs × k resident workgroups was measured slower with 13 concurrent
+// streams, DESIGN.md §4: every wave of the chip sits in the same load → compute → store phase.)  `grid_for` (capped,
+// grid-stride) is kept for the reduction kernel only; `tile_grid` sizes and range-checks the one-workgroup-per-tile grids.
 constexpr int kBlock = 256;
 
 struct DeviceInfo { int cus; int blocks_per_cu; };
@@ -38,6 +39,18 @@ inline int grid_for(int64_t work_items, int items_per_block = kBlock) {
     const int64_t g = need < cap ? need : cap;
     return (int)(g < 1 ? 1 : g);
 }
+
+// Number of workgroups for `work_items` items at `items_per_block` each, or -1 if that exceeds what one launch can
+// express (HIP: 2^31 − 1 workgroups in x).  Callers return CMX_ERR_UNSUPPORTED instead of silently truncating the grid.
+inline int64_t tile_grid(int64_t work_items, int64_t items_per_block) {
+    const int64_t g = (work_items + items_per_block - 1) / items_per_block;
+    return g > (int64_t)0x7fffffff ? -1 : (g < 1 ? 1 : g);
+}
+
+// Upper bound on the points / states of ONE call, checked by every entry point (CMX_ERR_UNSUPPORTED above it): the smallest
+// tile any kernel gives a workgroup is 16 states (p3_collision_kernel at 16 lanes per state), so n ≤ 16·(2^31 − 1) ≈ 3.4e10 keeps
+// every grid inside HIP's 2^31 − 1 workgroups; at ≥ 12 B per point that is beyond the 288 GB of HBM anyway.
+constexpr int64_t kMaxPoints = 16ll * 0x7fffffffll;
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -105,6 +105,7 @@ static int32_t launch_layout(const typename POLICY::Consts &c, int64_t n_seg, in
                              FT *const *out, const int64_t *out_stride, FT *aos, hipStream_t s) {
     constexpr int NIN = POLICY::NIN, NOUT = POLICY::NOUT, NAOS = POLICY::NAOS;
     if (n_seg < 0 || seg_len < 0 || !in) return CMX_ERR_BAD_ARG;
+    if (seg_len > 0 && n_seg > kMaxPoints / seg_len) return CMX_ERR_UNSUPPORTED;      // n_seg·seg_len must fit one launch (cmx_launch.hpp)
     if ((out != nullptr) == (aos != nullptr)) return CMX_ERR_BAD_ARG;                // exactly one output form
     const int64_t n = n_seg * seg_len;
     if (n == 0) return CMX_OK;

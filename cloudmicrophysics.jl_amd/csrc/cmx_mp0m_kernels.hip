@@ -41,6 +41,7 @@ template <typename FT, typename PR>
 static int32_t mp0m_entry(const PR *p, int64_t n, const FT *q_lcl, const FT *q_icl, const FT *q_vap_sat, FT *dq_tot_dt, FT *ddq_dq_tot,
                           void *stream) {
     if (!p || n < 0) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (n == 0) return CMX_OK;
     if (!q_lcl || !q_icl || !dq_tot_dt) return CMX_ERR_BAD_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

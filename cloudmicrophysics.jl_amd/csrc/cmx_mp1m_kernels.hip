@@ -541,6 +541,7 @@ static int32_t tendencies_1m_entry(const MP *mp, const TH *tps, uint32_t flags, 
                                    const FT *q_tot, const FT *q_lcl, const FT *q_icl, const FT *q_rai, const FT *q_sno,
                                    FT *dq_lcl, FT *dq_icl, FT *dq_rai, FT *dq_sno, void *stream) {
     if (!mp || !tps || n < 0) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (const int32_t st = check_flags_1m(flags)) return st;
     if (n == 0) return CMX_OK;
     if (!rho || !T || !q_tot || !q_lcl || !q_icl || !q_rai || !q_sno || !dq_lcl || !dq_icl || !dq_rai || !dq_sno) return CMX_ERR_BAD_ARG;
@@ -603,6 +604,7 @@ static int32_t linearized_1m_entry(const MP *mp, const TH *tps, uint32_t flags, 
                                    const FT *T, const FT *q_tot, const FT *q_lcl, const FT *q_icl, const FT *q_rai, const FT *q_sno,
                                    FT *dq_lcl, FT *dq_icl, FT *dq_rai, FT *dq_sno, void *stream) {
     if (!mp || !tps || n < 0 || nsub < 1 || !(dt > FT(0)) || !(q_min >= FT(0))) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (const int32_t st = check_flags_1m(flags)) return st;
     if (n == 0) return CMX_OK;
     if (!rho || !T || !q_tot || !q_lcl || !q_icl || !q_rai || !q_sno || !dq_lcl || !dq_icl || !dq_rai || !dq_sno) return CMX_ERR_BAD_ARG;
@@ -629,6 +631,7 @@ static int32_t sources_1m_entry(const MP *mp, const TH *tps, uint32_t flags, int
                                 const FT *q_tot, const FT *q_lcl, const FT *q_icl, const FT *q_rai, const FT *q_sno,
                                 FT *const out[CMX_MP1M_NSRC], void *stream) {
     if (!mp || !tps || !out || n < 0) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (const int32_t st = check_flags_1m(flags)) return st;
     if (n == 0) return CMX_OK;
     if (!rho || !T || !q_tot || !q_lcl || !q_icl || !q_rai || !q_sno) return CMX_ERR_BAD_ARG;
@@ -665,6 +668,7 @@ template <typename FT, typename MP, typename CH>
 static int32_t velocity_1m_entry(const MP *mp, const CH *chen, int64_t n, const FT *rho, const FT *q_rai, const FT *q_sno,
                                  FT *vt_rai, FT *vt_sno, FT *vt_chen, void *stream) {
     if (!mp || n < 0) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (n == 0) return CMX_OK;
     if (!rho || ((vt_rai || vt_chen) && !q_rai) || (vt_sno && !q_sno) || (vt_chen && !chen)) return CMX_ERR_BAD_ARG;
     const Vel1mConsts<FT> c = make_vel1m_consts<FT>(*mp, chen);
@@ -682,6 +686,7 @@ static int32_t sedimentation_entry(const MP *mp, const ST *stokes, const CH *che
                                    const FT *q_lcl, const FT *q_icl, const FT *q_rai, const FT *q_sno, FT *w_lcl, FT *w_icl, FT *w_rai,
                                    FT *w_sno, void *stream) {
     if (!mp || n < 0) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (n == 0) return CMX_OK;
     if (!rho || (w_lcl && (!q_lcl || !stokes)) || (w_icl && (!q_icl || !chen_ice)) || (w_rai && (!q_rai || !chen_rain)) ||
         (w_sno && (!q_sno || !chen_ice)))

@@ -598,6 +598,7 @@ static int32_t p3_collision_entry(const IP *ip, const AP *aps, const TH *tps, co
     if (!ip || !aps || !tps || !quad || n < 0 ||
         (flags & ~(CMX_P3_INPUT_IS_STATE | CMX_P3_SLOPE_CONSTANT | CMX_P3_NO_ASPECT_RATIO | CMX_P3_RAIN_PDF_LIMITED)))
         return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (quad->n < 1 || quad->n > CMX_QUAD_MAX) return CMX_ERR_BAD_ARG;
     if (n == 0) return CMX_OK;
     if (!rho_q || !rho_n || !x3 || !x4 || !L_c || !N_c || !L_r || !N_r || !rho_a || !T || !loglam || (!sources && !rates)) return CMX_ERR_BAD_ARG;
@@ -801,6 +802,7 @@ template <typename FT, typename IP, typename TH>
 static int32_t liquid_freezing_entry(const IP *ip, const TH *tps, uint32_t flags, int64_t n, const FT *q, const FT *rho, const FT *N, const FT *T,
                                      FT *dn, FT *dq, void *stream) {
     if (!ip || !tps || n < 0 || (flags & ~(uint32_t)(CMX_FREEZE_CLOUD_PSD | CMX_P3_RAIN_PDF_LIMITED))) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (n == 0) return CMX_OK;
     if (!q || !rho || !N || !T || (!dn && !dq)) return CMX_ERR_BAD_ARG;
     using WR = std::conditional_t<std::is_same_v<FT, float>, cmx_warm_rain_2m_f32, cmx_warm_rain_2m_f64>;
@@ -820,6 +822,7 @@ static int32_t mp2m_p3_entry(const WR *wr, const IP *ip, const TH *tps, uint32_t
                              const FT *q_lcl, const FT *n_lcl, const FT *q_rai, const FT *n_rai, const FT *q_ice, const FT *n_ice, const FT *q_rim,
                              const FT *b_rim, const FT *loglam, const FT *shift, FT *const *out, void *stream) {
     if (!wr || !ip || !tps || n < 0 || (flags & ~(CMX_P3_SLOPE_CONSTANT | CMX_P3_NO_ASPECT_RATIO | CMX_P3_RAIN_PDF_LIMITED))) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (ip->quad.n < 1 || ip->quad.n > CMX_QUAD_MAX) return CMX_ERR_BAD_ARG;
     if (n == 0) return CMX_OK;
     if (!rho || !T || !q_tot || !q_lcl || !n_lcl || !q_rai || !n_rai || !q_ice || !n_ice || !q_rim || !b_rim || !loglam || !out) return CMX_ERR_BAD_ARG;

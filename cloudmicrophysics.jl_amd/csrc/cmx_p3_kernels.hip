@@ -116,6 +116,7 @@ template <typename FT, typename PR>
 static int32_t p3_entry(const PR *params, uint32_t flags, int32_t brent_iters, int64_t n, const FT *rho_q, const FT *rho_n, const FT *x3, const FT *x4,
                         const FT *guess, FT *F_rim, FT *rho_rim, FT *loglam, FT *D_m, FT *logN0, void *stream) {
     if (!params || n < 0 || (flags & ~(CMX_P3_INPUT_IS_STATE | CMX_P3_SLOPE_CONSTANT | CMX_P3_NO_ASPECT_RATIO))) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (n == 0) return CMX_OK;
     if (!rho_q || !rho_n || !x3 || !x4) return CMX_ERR_BAD_ARG;
     P3Consts<FT> c = make_p3_consts<FT>(*params, flags);
@@ -235,6 +236,7 @@ static int32_t p3_velocity_entry(const PR *params, const VR *vel, const QUAD *qu
                                  void *stream) {
     if (!params || !vel || !quad || n < 0 || (flags & ~(CMX_P3_INPUT_IS_STATE | CMX_P3_SLOPE_CONSTANT | CMX_P3_NO_ASPECT_RATIO)))
         return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (quad->n < 1 || quad->n > CMX_QUAD_MAX || !(p > FT(0) && p < FT(0.5))) return CMX_ERR_BAD_ARG;
     if (n == 0) return CMX_OK;
     if (!rho_q || !rho_n || !x3 || !x4 || !rho_a || !loglam) return CMX_ERR_BAD_ARG;
@@ -259,6 +261,7 @@ static int32_t p3_melt_entry(const PR *params, const VR *vel, const AP *aps, con
     if (!params || !vel || !aps || !tps || !vent || !quad || n < 0 ||
         (flags & ~(CMX_P3_INPUT_IS_STATE | CMX_P3_SLOPE_CONSTANT | CMX_P3_NO_ASPECT_RATIO)))
         return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (quad->n < 1 || quad->n > CMX_QUAD_MAX || !(p > FT(0) && p < FT(0.5))) return CMX_ERR_BAD_ARG;
     if (n == 0) return CMX_OK;
     if (!rho_q || !rho_n || !x3 || !x4 || !rho_a || !T || !loglam) return CMX_ERR_BAD_ARG;
@@ -372,6 +375,7 @@ static int32_t p3_self_collection_entry(const PR *params, const VR *vel, const Q
                                         void *stream) {
     if (!params || !vel || !quad || n < 0 || (flags & ~(CMX_P3_INPUT_IS_STATE | CMX_P3_SLOPE_CONSTANT | CMX_P3_NO_ASPECT_RATIO)))
         return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (quad->n < 1 || quad->n > CMX_QUAD_MAX) return CMX_ERR_BAD_ARG;
     if (n == 0) return CMX_OK;
     if (!rho_q || !rho_n || !x3 || !x4 || !rho_a || !loglam || !dNdt) return CMX_ERR_BAD_ARG;

@@ -50,6 +50,7 @@ static int32_t tendencies_entry(const WR *wr, const TH *tps, const VL *vel, uint
                                 const FT *n_rai, FT *dq_lcl, FT *dn_lcl, FT *dq_rai, FT *dn_rai, FT *vt_n, FT *vt_m,
                                 void *stream) {
     if (!wr || !tps || n < 0) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (n == 0) return CMX_OK;
     if (!rho || !T || !q_tot || !q_lcl || !n_lcl || !q_rai || !n_rai || !dq_lcl || !dn_lcl || !dq_rai || !dn_rai)
         return CMX_ERR_BAD_ARG;
@@ -111,6 +112,7 @@ static int32_t process_entry(const WR *wr, const TH *tps, const VL *vel, uint32_
                              const FT *q_lcl, const FT *q_rai, const FT *N_lcl, const FT *N_rai, const FT *rho,
                              const FT *T, FT *const out[CMX_SB2006_NPROC], void *stream) {
     if (!wr || !tps || !out || n < 0) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (n == 0) return CMX_OK;
     if (!q_tot || !q_lcl || !q_rai || !N_lcl || !N_rai || !rho || !T) return CMX_ERR_BAD_ARG;
     const bool want_vel = out[CMX_SB_RAI_VEL_N] || out[CMX_SB_RAI_VEL_M];
@@ -164,6 +166,7 @@ template <typename FT, typename PDF, typename VEL>
 static int32_t cloud_velocity_entry(const PDF *pdf, const VEL *vel, int64_t n, const FT *q_liq, const FT *rho, const FT *N_liq, FT *vt_n,
                                     FT *vt_m, void *stream) {
     if (!pdf || !vel || n < 0) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (n == 0) return CMX_OK;
     if (!q_liq || !rho || !N_liq) return CMX_ERR_BAD_ARG;
     const double pi = 3.14159265358979323846, nu = pdf->nu_c, mu = pdf->mu_c, z1 = (nu + 1.0) / mu;
@@ -256,6 +259,7 @@ static int32_t bulk_2m_entry(const SC *p, uint32_t scheme, int64_t n, const FT *
                              FT *acnv, FT *accr, void *stream) {
     const uint32_t sch = scheme & 0xffu;
     if (!p || n < 0 || sch > CMX_2M_LD2004 || (scheme & ~(0xffu | CMX_2M_SMOOTH_TRANSITION))) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (sch == CMX_2M_LD2004 && accr) return CMX_ERR_BAD_ARG;
     if (n == 0) return CMX_OK;
     if (!q_lcl || !rho || (acnv && !N_d) || (accr && !q_rai) || (!acnv && !accr)) return CMX_ERR_BAD_ARG;

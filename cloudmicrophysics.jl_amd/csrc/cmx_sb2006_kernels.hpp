@@ -5,8 +5,8 @@
 // One lane owns VEC consecutive points (VEC·sizeof(FT) = 16 B), so each of the 7 input columns is
 // read with one global_load_dwordx4 per lane (1 KiB per wave-instruction, fully coalesced) and each
 // of the 4–6 output columns written with one global_store_dwordx4; loads and stores carry the
-// non-temporal hint (every byte is touched exactly once).  128-thread workgroups (CMX_TEND_BS), grid-stride over
-// CUs × k workgroups.  No LDS, no MFMA: there is no data reuse and no contraction on this path.
+// non-temporal hint (every byte is touched exactly once).  128-thread workgroups (kTendBS), one short-lived workgroup per
+// tile (non-persistent, see below).  No LDS, no MFMA: there is no data reuse and no contraction on this path.
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -100,8 +100,15 @@ def test_argument_validation_without_gpu():
     assert z(None, 4, None, None, None, None, None, None) == _abi.CMX_ERR_BAD_ARG
     assert z(C.byref(p0), 4, None, None, None, None, None, None) == _abi.CMX_ERR_BAD_ARG     # null columns
     assert z(C.byref(p0), 0, None, None, None, None, None, None) == _abi.CMX_OK
+    # a point count no single launch can express (> 16·(2^31 − 1), cmx_launch.hpp kMaxPoints) is refused, not silently truncated
+    huge = 16 * 0x7fffffff + 1
+    assert z(C.byref(p0), huge, None, None, None, None, None, None) == _abi.CMX_ERR_UNSUPPORTED
+    assert f(C.byref(wr.c), C.byref(tps), None, 1, huge, *null, None) == _abi.CMX_ERR_UNSUPPORTED
+    assert h(C.byref(wr.c), C.byref(tps), 1, 1 << 31, 1 << 31, ins, st7, outs, st4, None, None) == _abi.CMX_ERR_UNSUPPORTED
     g = lib.cmx_column_sums_f64
     assert g(-1, None, 0, None, None) == _abi.CMX_ERR_BAD_ARG
+    two = (C.c_void_p * 2)(4096, None)
+    assert g(2, two, 8, C.c_void_p(8192), None) == _abi.CMX_ERR_BAD_ARG          # a NULL column is caught before anything is enqueued
     assert g(0, None, 0, None, None) == _abi.CMX_OK
 
 

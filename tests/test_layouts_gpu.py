@@ -123,3 +123,70 @@ def test_mp1m_fields_and_aos(dev, ft):
         ref = cmx.bulk_microphysics_tendencies_1m(cmx.Instantaneous(), cmx.Microphysics1Moment(), mp, tps, *s1)
         aos = cmx.bulk_microphysics_tendencies_1m_fields(cmx.Instantaneous(), cmx.Microphysics1Moment(), mp, tps, *s1, aos=True)
         assert torch.equal(aos[:, 0], ref.dq_lcl_dt) and torch.equal(aos[:, 3], ref.dq_sno_dt)
+
+
+# ---- the layout entries against the ORACLE (not only against the SoA kernel) ------------------------------------------------------
+# Reference layouts: ClimaCore fields of test/gpu_clima_core_test.jl:16-30,100-114 (VIJFH storage) and the Vector{NamedTuple} result of
+# benchmark_2m_bulk_tendencies_kernel! / benchmark_1m_bulk_tendencies_kernel! (test/gpu_performance.jl:138-182,212-216).
+@pytest.mark.parametrize("ft", ["f32", "f64"])
+@pytest.mark.parametrize("layout", ["vijfh", "aos"])
+def test_2m_layout_entries_match_oracle(dev, oracle, ft, layout):
+    import cmx
+    import parity
+    from cmx import _abi
+    Nh, Nf, S = 41, 9, 74 * 16 + (0 if layout == "vijfh" else 3)      # the AoS case also gets a run length that is not a multiple of 4
+    Y = _state_field(Nh, Nf, S, ft, dev, seed=77)
+    mp, tps = P.Microphysics2MParams(ft), P.ThermodynamicsParameters(ft)
+    cols = [Y[:, f, :] for f in range(7)]
+    names = ("dq_lcl_dt", "dn_lcl_dt", "dq_rai_dt", "dn_rai_dt")
+    if layout == "vijfh":
+        Yt = torch.full((Nh, 5, S), float("nan"), dtype=DT[ft], device=dev)
+        cmx.bulk_microphysics_tendencies_fields(cmx.Microphysics2Moment(), mp, tps, *cols, out=[Yt[:, k, :] for k in (1, 2, 3, 4)])
+        torch.cuda.synchronize()
+        got = {name: Yt[:, k + 1, :].reshape(-1).cpu().numpy() for k, name in enumerate(names)}
+    else:
+        aos = cmx.bulk_microphysics_tendencies_fields(cmx.Microphysics2Moment(), mp, tps, *cols, aos=True)
+        torch.cuda.synchronize()
+        got = {name: aos[:, k].cpu().numpy() for k, name in enumerate(names)}
+        assert float(aos[:, 4:].abs().max()) == 0.0                     # the four identically-zero ice fields, BMT:852-853
+    cols_np = [c.contiguous().reshape(-1).cpu().numpy().astype(np.float64) for c in cols]
+    ref = oracle.sb2006_warm_rain_tendencies(_abi.F64, P.WarmRainParams2M("f64").c, P.ThermodynamicsParameters("f64"), None,
+                                             _abi.CMX_SB2006_LIMITED, *cols_np, float32_gates=(ft == "f32"), nthreads=8,
+                                             branch_margin=1e-5 if ft == "f32" else 1e-11)
+    rep = parity.assert_parity(got, ref, parity.RTOL[ft], names=names, what=f"2M {layout} {ft}")
+    print(f"\n[layout parity] 2M {layout} {ft} n={Nh * S}: {rep}")
+
+
+@pytest.mark.parametrize("ft", ["f32", "f64"])
+@pytest.mark.parametrize("layout", ["vijfh", "aos"])
+def test_1m_layout_entries_match_oracle(dev, oracle, ft, layout):
+    import cmx
+    import parity
+    from cmx import _abi, synthetic
+    tps = P.ThermodynamicsParameters(ft)
+    Nh, Nf, S = 37, 9, 74 * 16
+    st = synthetic.mp1m_state(Nh * S, dtype=DT[ft], seed=78)
+    Y = torch.full((Nh, Nf, S), float("nan"), dtype=DT[ft])
+    for f, c in enumerate(st):
+        Y[:, f + 1, :] = c.reshape(Nh, S)
+    Y = Y.to(dev)
+    cols = [Y[:, f + 1, :] for f in range(7)]
+    mp = P.Microphysics1MParams(ft)
+    names = ("dq_lcl_dt", "dq_icl_dt", "dq_rai_dt", "dq_sno_dt")
+    if layout == "vijfh":
+        Yt = torch.full((Nh, 6, S), float("nan"), dtype=DT[ft], device=dev)
+        cmx.bulk_microphysics_tendencies_1m_fields(cmx.Instantaneous(), cmx.Microphysics1Moment(), mp, tps, *cols,
+                                                   out=[Yt[:, k, :] for k in (0, 2, 3, 5)])
+        torch.cuda.synchronize()
+        got = {name: Yt[:, comp, :].reshape(-1).cpu().numpy() for name, comp in zip(names, (0, 2, 3, 5))}
+    else:
+        aos = cmx.bulk_microphysics_tendencies_1m_fields(cmx.Instantaneous(), cmx.Microphysics1Moment(), mp, tps, *cols, aos=True)
+        torch.cuda.synchronize()
+        got = {name: aos[:, k].cpu().numpy() for k, name in enumerate(names)}
+    mp64 = P.Microphysics1MParams("f64")
+    ref = oracle.mp1m(_abi.F64, mp64.c, P.ThermodynamicsParameters("f64"), mp64.flags, *[c.numpy().astype(np.float64) for c in st],
+                      float32_gates=(ft == "f32"), nthreads=8, want_sources=False)
+    tf = P.DEFAULT_PARAMETERS["temperature_water_freeze"]
+    ref["near_branch"] = np.abs(st[1].numpy().astype(np.float64) - tf) < (1e-4 if ft == "f32" else 1e-11)      # is_warm routing, BMT:171
+    rep = parity.assert_parity(got, ref, parity.RTOL[ft], names=names, what=f"1M {layout} {ft}")
+    print(f"\n[layout parity] 1M {layout} {ft} n={Nh * S}: {rep}")

@@ -1,29 +1,78 @@
 #!/bin/bash
-# One GPU-box session: full parity suite, every workload's bench line (f32 + f64), then profiles.
+# One GPU-box session: full parity suite FIRST (a failing suite aborts the session: no numbers are produced from a build whose
+# parity is red), then every workload's bench line (f32 + f64), then profiles.  Each step's rc is checked; a failed bench or
+# profile is reported and skipped, never summarised.
+#   usage: tools/gpu_round.sh <round-tag, e.g. r02> [notests]
+set -u
+set -o pipefail
+TAG=${1:-r02}
 mkdir -p gpurun_out/bench
-timeout 1500 python -m pytest tests -q -m gpu -x > gpurun_out/gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -3 gpurun_out/gpu_tests.log
-for wl in sb2006 icenuc mp0m mp1m arg2000; do
+FAILED=0
+
+if [ "${2:-}" != "notests" ]; then
+  timeout 2400 python -m pytest tests -q -m gpu -x > gpurun_out/gpu_tests.log 2>&1
+  rc=$?
+  echo "gpu tests rc=$rc"; tail -3 gpurun_out/gpu_tests.log
+  if [ $rc -ne 0 ]; then
+    echo "ABORT: the GPU parity suite failed — no benchmark or profile is taken from this build"
+    exit $rc
+  fi
+fi
+
+summ() {  # one-line summary of a bench JSON file; prints nothing useful (and says so) if the file holds no JSON line
+  python - "$1" <<'PY'
+import json, sys
+try:
+    lines = [l for l in open(sys.argv[1]).read().splitlines() if l.strip().startswith("{")]
+    d = json.loads(lines[-1])
+    print('%.3e pts/s  step %.3f ms  kern %.3f ms  frac %.3f  cpu %.3e' % (d['value'], d['ms_per_step'], d['roofline']['kernel_ms'],
+          d['roofline']['frac'], d.get('cpu_baseline', {}).get('value', 0)))
+except Exception as e:
+    print('NO RESULT (%s)' % type(e).__name__)
+PY
+}
+
+bench() {  # bench <name> <bench.py args…>
+  local name=$1; shift
+  timeout 900 python bench.py "$@" > gpurun_out/bench/${name}.json 2> gpurun_out/bench/${name}.err
+  local rc=$?
+  if [ $rc -ne 0 ]; then echo "$name: bench FAILED rc=$rc (see gpurun_out/bench/${name}.err)"; FAILED=$((FAILED+1)); return $rc; fi
+  echo "$name: $(summ gpurun_out/bench/${name}.json)"
+}
+
+prof() {  # prof <workload> <dtype> <points> [valu]
+  tools/profile.sh "$1" "$2" "$3" "$TAG" "${4:-}" > gpurun_out/prof_${1}_${2}.log 2>&1
+  local rc=$?
+  if [ $rc -ne 0 ]; then echo "profile $1 $2 FAILED rc=$rc"; FAILED=$((FAILED+1)); fi
+}
+
+bench default_driver --steps 20 --warmup 5
+bench default
+for wl in sb2006 sb2006_column icenuc mp0m mp1m arg2000; do
   for dt in f32 f64; do
-    timeout 600 python bench.py --workload $wl --dtype $dt --steps 20 --warmup 3 > gpurun_out/bench/${wl}_${dt}.json 2> gpurun_out/bench/${wl}_${dt}.err
-    echo "$wl $dt: $(python -c "import json,sys; d=json.loads(open('gpurun_out/bench/${wl}_${dt}.json').read().strip().splitlines()[-1]); print('%.3e pts/s  kern %.3f ms  frac %.3f  cpu %.3e' % (d['value'], d['roofline']['kernel_ms'], d['roofline']['frac'], d.get('cpu_baseline',{}).get('value',0)))" 2>&1 | tail -1)"
+    bench ${wl}_${dt} --workload $wl --dtype $dt --steps 20 --warmup 3
   done
 done
 for dt in f32 f64; do
-  timeout 600 python bench.py --workload p3 --dtype $dt --points 10000000 --steps 5 --warmup 1 > gpurun_out/bench/p3_${dt}.json 2> gpurun_out/bench/p3_${dt}.err
-  timeout 600 python bench.py --workload p3_selfcol --dtype $dt --points 1000000 --steps 3 --warmup 1 > gpurun_out/bench/p3_selfcol_${dt}.json 2> gpurun_out/bench/p3_selfcol_${dt}.err
-  timeout 600 python bench.py --workload mp1m_lin --dtype $dt --steps 10 --warmup 2 > gpurun_out/bench/mp1m_lin_${dt}.json 2> gpurun_out/bench/mp1m_lin_${dt}.err
-  timeout 600 python bench.py --workload mp2m_p3 --dtype $dt --points 1000000 --steps 3 --warmup 1 > gpurun_out/bench/mp2m_p3_${dt}.json 2> gpurun_out/bench/mp2m_p3_${dt}.err
-  timeout 600 python bench.py --workload sb2006_aos --dtype $dt --steps 20 --warmup 3 > gpurun_out/bench/sb2006_aos_${dt}.json 2> gpurun_out/bench/sb2006_aos_${dt}.err
-  timeout 600 python bench.py --workload sb2006_fields --dtype $dt --steps 20 --warmup 3 > gpurun_out/bench/sb2006_fields_${dt}.json 2> gpurun_out/bench/sb2006_fields_${dt}.err
+  bench p3_${dt} --workload p3 --dtype $dt --points 10000000 --steps 5 --warmup 1
+  bench p3_selfcol_${dt} --workload p3_selfcol --dtype $dt --points 1000000 --steps 3 --warmup 1
+  bench mp1m_lin_${dt} --workload mp1m_lin --dtype $dt --steps 10 --warmup 2
+  bench mp2m_p3_${dt} --workload mp2m_p3 --dtype $dt --points 1000000 --steps 3 --warmup 1
+  bench sb2006_aos_${dt} --workload sb2006_aos --dtype $dt --steps 20 --warmup 3
+  bench sb2006_fields_${dt} --workload sb2006_fields --dtype $dt --steps 20 --warmup 3
 done
-timeout 900 python bench.py > gpurun_out/bench/default.json 2> gpurun_out/bench/default.err
-tools/profile.sh sb2006 f32 100000000 > /dev/null
-tools/profile.sh mp0m f32 100000000 > /dev/null
-tools/profile.sh sb2006 f64 100000000 > /dev/null
-tools/profile.sh icenuc f32 100000000 > /dev/null
-tools/profile.sh mp1m f32 100000000 > /dev/null
-tools/profile.sh arg2000 f32 100000000 > /dev/null
-tools/profile.sh p3 f64 10000000 > /dev/null
-tools/profile.sh mp2m_p3 f64 1000000 r01 valu > /dev/null
-tools/profile.sh sb2006_aos f32 100000000 > /dev/null
+prof sb2006 f32 100000000 valu
+prof sb2006 f64 100000000 valu
+prof sb2006_column f32 100000000
+prof mp0m f32 100000000
+prof icenuc f32 100000000
+prof mp1m f32 100000000 valu
+prof mp1m f64 100000000
+prof arg2000 f32 100000000 valu
+prof arg2000 f64 100000000
+prof p3 f64 10000000
+prof mp2m_p3 f64 1000000 valu
+prof sb2006_aos f32 100000000
 ls gpurun_out/profiles
+echo "failed steps: $FAILED"
+exit $([ $FAILED -eq 0 ] && echo 0 || echo 1)

@@ -11,16 +11,22 @@ export TMPDIR=/tmp
 ARGS="$ROOT/bench.py --workload $WL --dtype $DT --points $N --steps 5 --warmup 1 --no-cpu-baseline"
 # the kernel-trace pass runs enough launches for its average to be the steady-state duration bench.py reports
 KTARGS="$ROOT/bench.py --workload $WL --dtype $DT --points $N --steps ${KT_STEPS:-40} --warmup 5 --no-cpu-baseline"
+run() {  # run <what> <cmd…>: a failed or timed-out profiler pass ends the script BEFORE any summary is written from partial data
+  local what=$1; shift
+  "$@"
+  local rc=$?
+  if [ $rc -ne 0 ]; then echo "profile.sh: $what failed (rc=$rc) for $WL $DT — no summary written" >&2; exit $rc; fi
+}
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 $KTARGS > "$OUT/kt.log" 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fetch -- python3 $ARGS > "$OUT/fetch.log" 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- python3 $ARGS > "$OUT/write.log" 2>&1
+run kernel-trace timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 $KTARGS > "$OUT/kt.log" 2>&1
+run pmc-fetch timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fetch -- python3 $ARGS > "$OUT/fetch.log" 2>&1
+run pmc-write timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- python3 $ARGS > "$OUT/write.log" 2>&1
 cd "$ROOT"
-python3 tools/pmc_summary.py "$WL" "$DT" "$N" "$OUT" "$R"
+run summary python3 tools/pmc_summary.py "$WL" "$DT" "$N" "$OUT" "$R"
 # compute-bound workloads: one more pass with the SQ instruction/cycle counters (VALU issue utilisation)
 if [ "$WL" = "p3" ] || [ "${5:-}" = "valu" ]; then
   cd /tmp
-  timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_INST_ANY SQ_INSTS_VALU_TRANS GRBM_GUI_ACTIVE --output-format csv -d "$OUT/sq" -o sq -- python3 $ARGS > "$OUT/sq.log" 2>&1
+  run pmc-sq timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_INST_ANY SQ_INSTS_VALU_TRANS GRBM_GUI_ACTIVE --output-format csv -d "$OUT/sq" -o sq -- python3 $ARGS > "$OUT/sq.log" 2>&1
   cd "$ROOT"
-  python3 tools/pmc_summary.py "$WL" "$DT" "$N" "$OUT" "$R" valu
+  run valu-summary python3 tools/pmc_summary.py "$WL" "$DT" "$N" "$OUT" "$R" valu
 fi
