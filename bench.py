@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --points per GPU; strong: --points in total, sharded over the ranks (cmx.sharding.shard_bounds)")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--workload", choices=["sb2006", "icenuc", "mp0m", "mp1m", "mp1m_lin", "arg2000", "p3", "p3_selfcol", "mp2m_p3", "sb2006_aos", "sb2006_fields"], default="sb2006")
+    ap.add_argument("--workload", choices=["sb2006", "sb2006_column", "icenuc", "mp0m", "mp1m", "mp1m_lin", "arg2000", "p3", "p3_selfcol", "mp2m_p3", "sb2006_aos", "sb2006_fields"], default="sb2006")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the bounded baseline sample")
     ap.add_argument("--diagnostics", action="store_true",
@@ -116,6 +116,48 @@ def setup_sb2006(args, dev, dtype, rank):
         "columns_in": 7, "columns_out": 6, "diag_cols": list(out[:4]),
     }
     return list(state), step, desc, cpu_run
+
+
+def setup_sb2006_column(args, dev, dtype, rank):
+    """the north-star tendencies fused with the host model's upwind sedimentation step, columns of 74 levels (the RCEMIP
+    column of test/gpu_clima_core_test.jl:88-100); 7 columns in, 4 out."""
+    import torch
+
+    import cmx
+    from cmx import _abi
+    from cmx import parameters as P
+    from cmx import synthetic
+    n_lev = 74
+    n_col = max(1, args.points // n_lev)
+    args.points = n_col * n_lev
+    st = synthetic.sb2006_state(args.points, dtype=dtype, device=dev, seed=1234 + rank)
+    cols = [c.reshape(n_col, n_lev) for c in st]
+    g = torch.Generator(device="cpu").manual_seed(7)
+    inv_dz_cpu = (1.0 / (30.0 + 470.0 * torch.rand(n_lev, generator=g, dtype=torch.float64))).to(dtype)
+    inv_dz = inv_dz_cpu.to(dev)
+    mp, tps = P.Microphysics2MParams(args.dtype), P.ThermodynamicsParameters(args.dtype)
+    out = cmx.ColumnTendencies2M(*[torch.empty_like(cols[0]) for _ in range(4)], None)
+
+    def step():
+        cmx.column_tendencies_sedimentation(mp, tps, inv_dz, *cols, vel=cmx.SB2006VelType, out=out)
+
+    def cpu_run(ob, c, threads):
+        fam = _abi.family(args.dtype)
+        wr, t, vel = P.WarmRainParams2M(args.dtype).c, P.ThermodynamicsParameters(args.dtype), P.rain_vel_params(args.dtype)
+        flags = _abi.CMX_SB2006_LIMITED | _abi.CMX_VEL_SB2006
+        m_col = c[0].size // n_lev
+        c2 = [a[:m_col * n_lev].reshape(m_col, n_lev) for a in c]
+        return lambda: ob.sb2006_column_tendencies_sedimentation(fam, wr, t, vel, None, flags, inv_dz_cpu.numpy(), *c2, nthreads=threads)
+
+    desc = {
+        "metric": "grid-points/sec SB2006 2M tendency + upwind sedimentation column sweep (74 levels)",
+        "bytes_per_point": {"f32": 44, "f64": 88}[args.dtype],     # 7 in + 4 out; the unfused sequence moves 88 / 176 B per point
+        "kernel": "sb2006_column_kernel",
+        "workload": "Microphysics2M SB2006 fused warm-rain tendencies + SB2006 rain fall speeds + first-order upwind sedimentation flux "
+                    "divergence of q_rai, n_rai per column of 74 levels (host-model step, SURVEY 8f-4)",
+        "columns_in": 7, "columns_out": 4, "diag_cols": list(out[:4]),
+    }
+    return list(st), step, desc, cpu_run
 
 
 def setup_sb2006_layout(args, dev, dtype, rank):
@@ -509,7 +551,7 @@ def main():
         args.points = hi - lo
     # weak scaling: fixed work per GPU; rank r owns shard r of the global [0, world·n) index space.
     # Either way: disjoint seeds, no exchange
-    setup = {"sb2006": setup_sb2006, "icenuc": setup_icenuc, "mp0m": setup_mp0m, "mp1m": setup_mp1m, "mp1m_lin": setup_mp1m_lin, "arg2000": setup_arg2000,
+    setup = {"sb2006": setup_sb2006, "sb2006_column": setup_sb2006_column, "icenuc": setup_icenuc, "mp0m": setup_mp0m, "mp1m": setup_mp1m, "mp1m_lin": setup_mp1m_lin, "arg2000": setup_arg2000,
              "p3": setup_p3, "p3_selfcol": setup_p3_selfcol, "mp2m_p3": setup_mp2m_p3, "sb2006_aos": setup_sb2006_layout, "sb2006_fields": setup_sb2006_layout}[args.workload]
     state, kernel_step, desc, cpu_run = setup(args, dev, dtype, rank)
     n = args.points                                          # a layout workload may round the size to whole field runs
@@ -570,7 +612,7 @@ def main():
         if "note" in desc:
             line["roofline"]["note"] = desc["note"]
         if not args.no_cpu_baseline and world == 1:
-            m = min(n, {"sb2006": 20_000_000, "sb2006_aos": 20_000_000, "sb2006_fields": 20_000_000, "p3": 100_000, "p3_selfcol": 2_000, "mp2m_p3": 20_000}.get(args.workload, 4_000_000))
+            m = min(n, {"sb2006": 20_000_000, "sb2006_column": 74 * 270_000, "sb2006_aos": 20_000_000, "sb2006_fields": 20_000_000, "p3": 100_000, "p3_selfcol": 2_000, "mp2m_p3": 20_000}.get(args.workload, 4_000_000))
             cols_np = [np.ascontiguousarray(c[:m].cpu().numpy()) for c in state]
             line["cpu_baseline"] = cpu_baseline(args, cols_np, desc, cpu_run)
         print(json.dumps(line), flush=True)

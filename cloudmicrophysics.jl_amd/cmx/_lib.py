@@ -74,6 +74,10 @@ def _declare(lib):
         f = getattr(lib, f"cmx_sb2006_cloud_terminal_velocity_{s}")
         f.restype = i32
         f.argtypes = [C.POINTER(fam.cloud_pdf_sb2006), C.POINTER(fam.stokes_vel), i64] + [vp] * 5 + [vp]
+        f = getattr(lib, f"cmx_sb2006_column_tendencies_sedimentation_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.warm_rain_2m), C.POINTER(fam.thermo), C.POINTER(fam.rain_vel), C.POINTER(fam.stokes_vel), u32, i64, i32] \
+            + [vp] * 13 + [vp]
         f = getattr(lib, f"cmx_mp1m_linearized_average_{s}")
         f.restype = i32
         f.argtypes = [C.POINTER(fam.microphysics_1m), C.POINTER(fam.thermo), u32, fam.ft, fam.ft, i32, i64] + [vp] * 11 + [vp]

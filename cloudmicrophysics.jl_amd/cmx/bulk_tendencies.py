@@ -308,6 +308,51 @@ def cloud_terminal_velocity(pdf_c, vel, q_liq, rho, N_liq, *, stream=None) -> Cl
     return out
 
 
+ColumnTendencies2M = namedtuple("ColumnTendencies2M", ["dq_lcl_dt", "dn_lcl_dt", "dq_rai_dt", "dn_rai_dt", "precip_flux"])
+
+
+def column_tendencies_sedimentation(mp, tps, inv_dz, rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, *, vel=SB2006VelType, cloud_vel=None,
+                                    want_precip_flux: bool = False, out: Optional[ColumnTendencies2M] = None,
+                                    stream=None) -> ColumnTendencies2M:
+    """SURVEY §8f-4 — the fused column step behind `cmx_sb2006_column_tendencies_sedimentation_*`: per column of `n_lev`
+    contiguous levels (state tensors of shape (n_col, n_lev), level 0 = lowest)
+
+        BMT.bulk_microphysics_tendencies(Microphysics2Moment(), mp, tps, ρ, T, q_tot, q_lcl, n_lcl, q_rai, n_rai)   BMT:820-854
+        CM2.rain_terminal_velocity(sb, vel, q_rai, ρ, ρ n_rai)  [+ CM2.cloud_terminal_velocity iff `cloud_vel`]     CM2:685-719, 647-664
+
+    plus the host model's first-order upwind sedimentation flux divergence ∂χ/∂t += (F_{k+1} − F_k)/(ρ_k Δz_k), F = ρ χ w
+    (the flux scheme is the host model's, not the reference's: include/cmx.h).  `inv_dz`: the n_lev values 1/Δz_k.
+    `cloud_vel` = parameters.StokesRegimeVelType(FT) adds cloud-droplet sedimentation of q_lcl / n_lcl."""
+    wr = _warm_rain(mp)
+    cols = (rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai)
+    ref = _check_cols(cols, ("rho", "T", "q_tot", "q_lcl", "n_lcl", "q_rai", "n_rai"))
+    if ref.dim() != 2:
+        raise ValueError("state columns must have shape (n_col, n_lev)")
+    n_col, n_lev = ref.shape
+    fam = _fam_of(ref)
+    if fam is not wr.fam or not isinstance(tps, fam.thermo) or (cloud_vel is not None and not isinstance(cloud_vel, fam.stokes_vel)):
+        raise TypeError("parameter float type does not match the state columns")
+    if inv_dz.dtype != ref.dtype or inv_dz.device != ref.device or inv_dz.numel() != n_lev or not inv_dz.is_contiguous():
+        raise ValueError("inv_dz must be a contiguous device vector of n_lev values of the state dtype")
+    flag = _vel_flag(vel)
+    if not flag:
+        raise ValueError("the column step needs a rain fall-speed scheme (SB2006VelType or Chen2022VelTypeRain)")
+    if out is None:
+        out = ColumnTendencies2M(*[torch.empty_like(ref) for _ in range(4)],
+                                 torch.empty(n_col, dtype=ref.dtype, device=ref.device) if want_precip_flux else None)
+    else:
+        _check_cols([ref, *out[:4]], ["rho", *ColumnTendencies2M._fields[:4]])
+    flags = (_abi.CMX_SB2006_LIMITED if wr.is_limited else 0) | flag
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_sb2006_column_tendencies_sedimentation_{fam.sfx}")
+    velp = rain_vel_params(fam.sfx)
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(wr.c), C.byref(tps), C.byref(velp), C.byref(cloud_vel) if cloud_vel is not None else None, flags, n_col, n_lev,
+                _ptr(inv_dz), *[_ptr(t) for t in cols], *[_ptr(t) for t in out[:4]], _ptr(out.precip_flux), C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return out
+
+
 _SCHEMES_2M = {"KK2000": _abi.CMX_2M_KK2000, "B1994": _abi.CMX_2M_B1994, "TC1980": _abi.CMX_2M_TC1980, "LD2004": _abi.CMX_2M_LD2004}
 CloudToRain2M = namedtuple("CloudToRain2M", ["acnv", "accr"])
 

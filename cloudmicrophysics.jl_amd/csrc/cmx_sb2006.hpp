@@ -200,6 +200,105 @@ template <typename FT> struct SbRates {
     FT inv_rho;
 };
 
+// ---- CM2.cloud_terminal_velocity — Microphysics2M.jl:647-664 ----------------------------------------------------------------
+// With B = (x̄ Γ(z₁)/Γ(z₂))^(−μ) (log_pdf_cloud_parameters_mass :174-192) the two moments collapse to one power of the mean
+// droplet mass x̄ = ρq/N:  vt_n = pref·K₂₃·x̄^(2/3),  vt_m = pref·K₅₃·x̄^(5/3)·N/(ρq) = pref·K₅₃·x̄^(2/3),
+// K_n = (Γ(z₁)/Γ(z₂))^n · Γ(z₁ + n/μ)/Γ(z₁) parameter-only (host, double).
+template <typename FT> struct CloudVelConsts { FT pre_c, rho_w, K23, K53; };
+template <typename FT, typename PDF, typename VEL>
+inline CloudVelConsts<FT> make_cloud_vel_consts(const PDF &pdf, const VEL &vel) {
+    const double pi = 3.14159265358979323846, nu = pdf.nu_c, mu = pdf.mu_c, z1 = (nu + 1.0) / mu;
+    const double dlg = (double)pdf.loggamma_z1 - (double)pdf.loggamma_z2;   // log Γ(z₁)/Γ(z₂)
+    CloudVelConsts<FT> c;
+    c.rho_w = (FT)vel.rho_w;
+    c.pre_c = (FT)(1.0 / 18.0 * std::cbrt(std::pow(6.0 / (double)vel.rho_w / pi, 2.0)) * (double)vel.grav / (double)vel.nu_air);
+    c.K23 = (FT)std::exp(2.0 / 3.0 * dlg + std::lgamma(z1 + 2.0 / 3.0 / mu) - std::lgamma(z1));
+    c.K53 = (FT)std::exp(5.0 / 3.0 * dlg + std::lgamma(z1 + 5.0 / 3.0 / mu) - std::lgamma(z1));
+    return c;
+}
+template <typename FT>
+__device__ __forceinline__ void sb2006_cloud_velocity(const CloudVelConsts<FT> &c, FT q, FT r, FT N, FT &vt_n, FT &vt_m) {
+    using M = Math<FT>;
+    const FT sq = M::max(q, M::eps()), sN = M::max(N, M::eps());
+    const FT x23 = M::exp2(FT(2.0 / 3.0) * M::log2(r * sq * M::rcp(sN)));
+    const FT pref = c.pre_c * (c.rho_w * M::rcp(r) - FT(1));
+    const bool none = N < M::eps() || q < M::eps();
+    vt_n = none ? FT(0) : pref * c.K23 * x23;
+    vt_m = none ? FT(0) : pref * c.K53 * x23;
+}
+
+// ---- rain PSD parameters (CM2:67-110) from the safe values, in the log2 domain ------------------------------
+// All four limiters (Eq. 94-97) are clamps of monotone power laws of L_rai and N_rai, so they are applied to the
+// log2 values: two log2 in, then every derived quantity is one exp2 (11 → 5-6 transcendentals).
+// Shared by the point function and by the flux-only evaluation of the column kernel (same instruction sequence → same bits).
+template <typename FT> struct SbRainPsd { FT l2_xr, l2_lam; };
+template <typename FT, bool LIMITED>
+__device__ __forceinline__ SbRainPsd<FT> sb2006_rain_psd(const SbConsts<FT> &c, FT L_rai, FT sN_rai) {
+    using M = Math<FT>;
+    const FT l2_L = M::log2(L_rai), l2_N = M::log2(sN_rai);
+    SbRainPsd<FT> p;
+    if constexpr (LIMITED) {
+        const FT l2_xt = clampv(l2_L - l2_N, c.l2_xr_min, c.l2_xr_max);                               // Eq. 94
+        const FT l2_N0 = clampv(l2_N + (c.l2_pi_rho_w - l2_xt) * FT(1.0 / 3.0), c.l2_N0_min, c.l2_N0_max);   // Eq. 95
+        p.l2_lam = clampv((c.l2_pi_rho_w + l2_N0 - l2_L) * FT(0.25), c.l2_lam_min, c.l2_lam_max);     // Eq. 96
+        p.l2_xr = clampv(l2_L + p.l2_lam - l2_N0, c.l2_xr_min, c.l2_xr_max);                          // Eq. 97
+    } else {
+        p.l2_xr = l2_L - l2_N;
+        p.l2_lam = (c.l2_pi_rho_w - p.l2_xr) * FT(1.0 / 3.0);
+    }
+    return p;
+}
+
+// ---- rain terminal velocity (CM2:685-719) from log2 λ; gated like the reference -----------------------------------------------
+template <typename FT, bool LIMITED, int VEL>
+__device__ __forceinline__ void sb2006_rain_velocity(const SbConsts<FT> &c, FT rho, FT rs_rho, FT l2_lam, bool no_N_rai, bool no_q_rai,
+                                                     FT &vt_n, FT &vt_m) {
+    using M = Math<FT>;
+    vt_n = FT(0);
+    vt_m = FT(0);
+    if constexpr (VEL == VEL_SB) {   // CM2:685-702, helper :720-739
+        const FT Dr_mean = M::exp2(-l2_lam);
+        FT pa0 = FT(1), pb0 = FT(1), pa1 = FT(1), pb1 = FT(1);
+        if constexpr (!LIMITED) {
+            const FT lam = M::exp2(l2_lam);
+            const FT ta = c.rc2 * lam, tb = c.rc2 * (lam + c.cR);
+            pa0 = M::exp2(ta * FT(-1.4426950408889634));
+            pb0 = pa0 * c.e_rc2cR;
+            pa1 = (((ta + FT(3)) * ta + FT(6)) * ta + FT(6)) * pa0 * FT(1.0 / 6.0);
+            pb1 = (((tb + FT(3)) * tb + FT(6)) * tb + FT(6)) * pb0 * FT(1.0 / 6.0);
+        }
+        const FT s = c.vel_s * rs_rho;
+        const FT inv_d1 = M::rcp(M::fma(c.cR, Dr_mean, FT(1)));
+        const FT inv_d2 = inv_d1 * inv_d1;
+        const FT vt0 = M::max(FT(0), s * (c.aR * pa0 - c.bR * pb0 * inv_d1));
+        const FT vt1 = M::max(FT(0), s * (c.aR * pa1 - c.bR * pb1 * (inv_d2 * inv_d2)));
+        vt_n = no_N_rai ? FT(0) : vt0;
+        vt_m = no_q_rai ? FT(0) : vt1;
+    } else if constexpr (VEL == VEL_CHEN) {   // CM2:703-719, Common.jl:290-302, 414-422
+        const FT lam = M::exp2(l2_lam);
+        const FT rho_c = M::max(rho, FT(0));
+        const FT l2_q = c.ch_rho0_l2e * rho_c;                  // log2 exp(ρ0 ρ)
+        const FT l2_rho = M::log2(rho_c);
+        const FT l2_lam_inv = -l2_lam;                          // log2 Dr_mean
+        FT vt0 = FT(0), vt3 = FT(0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const FT bi = M::fma(-c.ch_b_rho, rho_c, c.ch_b[i]);
+            // aiu = a_i·q·(ρ^a3_pow for i = 3)·1000^b_i ; sign kept outside the log
+            FT l2_mag = l2_q + bi * c.l2_1000 + (i == 2 ? c.ch_a3_pow * l2_rho : FT(0));
+            const FT l2_den = M::log2(lam + c.ch_c1000[i]);     // log2(1/λ_inv + c)
+            const FT g1 = M::tgamma(bi + FT(1));
+            // k = 0: δ = 1;  k = 3: δ = 4, Γ(b+4) = (b+3)(b+2)(b+1)Γ(b+1), /3!
+            const FT e0 = M::exp2(l2_mag - l2_lam_inv - (bi + FT(1)) * l2_den);
+            const FT e3 = M::exp2(l2_mag - FT(4) * l2_lam_inv - (bi + FT(4)) * l2_den);
+            vt0 = M::fma(c.ch_a[i] * e0, g1, vt0);
+            vt3 = M::fma(c.ch_a[i] * e3, g1 * (bi + FT(3)) * (bi + FT(2)) * (bi + FT(1)) * FT(1.0 / 6.0), vt3);
+        }
+        vt_n = no_N_rai ? FT(0) : M::max(FT(0), vt0);
+        vt_m = no_q_rai ? FT(0) : M::max(FT(0), vt3);
+    }
+}
+
 // `n_lcl`, `n_rai` are per-kg numbers (BMT), `N_*` = ρ n_* per m³ (CM2).  No input clamping here:
 // the fused entry clamps first (BMT:828-837), the per-process entry passes raw values like the
 // reference's KA wrapper does.
@@ -292,20 +391,8 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
     }
 
     // ---- rain PSD parameters, once (CM2:67-110), from the safe values ----------
-    // All four limiters (Eq. 94-97) are clamps of monotone power laws of L_rai and N_rai, so they are applied to the
-    // log2 values: two log2 in, then every derived quantity is one exp2 (11 → 5-6 transcendentals).
-    const FT l2_L = M::log2(L_rai), l2_N = M::log2(sN_rai);
-    FT l2_xr, l2_lam;
-    if constexpr (LIMITED) {
-        const FT l2_xt = clampv(l2_L - l2_N, c.l2_xr_min, c.l2_xr_max);                               // Eq. 94
-        const FT l2_N0 = clampv(l2_N + (c.l2_pi_rho_w - l2_xt) * FT(1.0 / 3.0), c.l2_N0_min, c.l2_N0_max);   // Eq. 95
-        l2_lam = clampv((c.l2_pi_rho_w + l2_N0 - l2_L) * FT(0.25), c.l2_lam_min, c.l2_lam_max);       // Eq. 96
-        l2_xr = clampv(l2_L + l2_lam - l2_N0, c.l2_xr_min, c.l2_xr_max);                              // Eq. 97
-    } else {
-        l2_xr = l2_L - l2_N;
-        l2_lam = (c.l2_pi_rho_w - l2_xr) * FT(1.0 / 3.0);
-    }
-    const FT lam = M::exp2(l2_lam), Dr_mean = M::exp2(-l2_lam);
+    const SbRainPsd<FT> psd = sb2006_rain_psd<FT, LIMITED>(c, L_rai, sN_rai);
+    const FT l2_xr = psd.l2_xr, l2_lam = psd.l2_lam;
     const FT l2_Dr = (l2_xr + c.l2_Drc) * FT(1.0 / 3.0);
     const FT Dr = M::exp2(l2_Dr);                       // ∛(6 x̄_r/(π ρw)): CM2:588 and :809
     const bool no_N_rai = N_rai < eps;
@@ -348,46 +435,7 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
         r.na_rai = (tr - n_rai) * c.inv_tau_na;
     }
     // ---- rain terminal velocity (optional columns) ----------------------------------------------
-    r.vt_n = FT(0);
-    r.vt_m = FT(0);
-    if constexpr (VEL == VEL_SB) {   // CM2:685-702, helper :720-739
-        FT pa0 = FT(1), pb0 = FT(1), pa1 = FT(1), pb1 = FT(1);
-        if constexpr (!LIMITED) {
-            const FT ta = c.rc2 * lam, tb = c.rc2 * (lam + c.cR);
-            pa0 = M::exp2(ta * FT(-1.4426950408889634));
-            pb0 = pa0 * c.e_rc2cR;
-            pa1 = (((ta + FT(3)) * ta + FT(6)) * ta + FT(6)) * pa0 * FT(1.0 / 6.0);
-            pb1 = (((tb + FT(3)) * tb + FT(6)) * tb + FT(6)) * pb0 * FT(1.0 / 6.0);
-        }
-        const FT s = c.vel_s * rs_rho;
-        const FT inv_d1 = M::rcp(M::fma(c.cR, Dr_mean, FT(1)));
-        const FT inv_d2 = inv_d1 * inv_d1;
-        const FT vt0 = M::max(FT(0), s * (c.aR * pa0 - c.bR * pb0 * inv_d1));
-        const FT vt1 = M::max(FT(0), s * (c.aR * pa1 - c.bR * pb1 * (inv_d2 * inv_d2)));
-        r.vt_n = no_N_rai ? FT(0) : vt0;
-        r.vt_m = no_q_rai ? FT(0) : vt1;
-    } else if constexpr (VEL == VEL_CHEN) {   // CM2:703-719, Common.jl:290-302, 414-422
-        const FT rho_c = M::max(rho, FT(0));
-        const FT l2_q = c.ch_rho0_l2e * rho_c;                  // log2 exp(ρ0 ρ)
-        const FT l2_rho = M::log2(rho_c);
-        const FT l2_lam_inv = -l2_lam;                          // log2 Dr_mean
-        FT vt0 = FT(0), vt3 = FT(0);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const FT bi = M::fma(-c.ch_b_rho, rho_c, c.ch_b[i]);
-            // aiu = a_i·q·(ρ^a3_pow for i = 3)·1000^b_i ; sign kept outside the log
-            FT l2_mag = l2_q + bi * c.l2_1000 + (i == 2 ? c.ch_a3_pow * l2_rho : FT(0));
-            const FT l2_den = M::log2(lam + c.ch_c1000[i]);     // log2(1/λ_inv + c)
-            const FT g1 = M::tgamma(bi + FT(1));
-            // k = 0: δ = 1;  k = 3: δ = 4, Γ(b+4) = (b+3)(b+2)(b+1)Γ(b+1), /3!
-            const FT e0 = M::exp2(l2_mag - l2_lam_inv - (bi + FT(1)) * l2_den);
-            const FT e3 = M::exp2(l2_mag - FT(4) * l2_lam_inv - (bi + FT(4)) * l2_den);
-            vt0 = M::fma(c.ch_a[i] * e0, g1, vt0);
-            vt3 = M::fma(c.ch_a[i] * e3, g1 * (bi + FT(3)) * (bi + FT(2)) * (bi + FT(1)) * FT(1.0 / 6.0), vt3);
-        }
-        r.vt_n = no_N_rai ? FT(0) : M::max(FT(0), vt0);
-        r.vt_m = no_q_rai ? FT(0) : M::max(FT(0), vt3);
-    }
+    sb2006_rain_velocity<FT, LIMITED, VEL>(c, rho, rs_rho, l2_lam, no_N_rai, no_q_rai, r.vt_n, r.vt_m);
     return r;
 }
 

@@ -141,25 +141,17 @@ static int32_t process_entry(const WR *wr, const TH *tps, const VL *vel, uint32_
     return CMX_OK;
 }
 
-// CM2.cloud_terminal_velocity — Microphysics2M.jl:647-664.  With B = (x̄ Γ(z₁)/Γ(z₂))^(−μ) (log_pdf_cloud_parameters_mass
-// :174-192) the two moments collapse to one power of the mean droplet mass x̄ = ρq/N:
-//   vt_n = pref·K₂₃·x̄^(2/3),  vt_m = pref·K₅₃·x̄^(5/3)·N/(ρq) = pref·K₅₃·x̄^(2/3),
-// K_n = (Γ(z₁)/Γ(z₂))^n · Γ(z₁ + n/μ)/Γ(z₁) parameter-only (host, double).  20 B/point (f32), one point per lane.
-template <typename FT> struct CloudVelConsts { FT pre_c, rho_w, K23, K53; };
+// CM2.cloud_terminal_velocity — Microphysics2M.jl:647-664 (point function and constants: cmx_sb2006.hpp).  20 B/point (f32), one point per lane.
 template <typename FT>
 __global__ __launch_bounds__(kBlock) void sb2006_cloud_velocity_kernel(const CloudVelConsts<FT> c, const FT *__restrict__ q_liq,
                                                                        const FT *__restrict__ rho, const FT *__restrict__ N_liq,
                                                                        FT *__restrict__ vt_n, FT *__restrict__ vt_m, const int64_t n) {
-    using M = Math<FT>;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const FT q = q_liq[i], r = rho[i], N = N_liq[i];
-    const FT sq = M::max(q, M::eps()), sN = M::max(N, M::eps());
-    const FT x23 = M::exp2(FT(2.0 / 3.0) * M::log2(r * sq * M::rcp(sN)));
-    const FT pref = c.pre_c * (c.rho_w * M::rcp(r) - FT(1));
-    const bool none = N < M::eps() || q < M::eps();
-    if (vt_n) vt_n[i] = none ? FT(0) : pref * c.K23 * x23;
-    if (vt_m) vt_m[i] = none ? FT(0) : pref * c.K53 * x23;
+    FT v0, v1;
+    sb2006_cloud_velocity(c, q_liq[i], rho[i], N_liq[i], v0, v1);
+    if (vt_n) vt_n[i] = v0;
+    if (vt_m) vt_m[i] = v1;
 }
 
 template <typename FT, typename PDF, typename VEL>
@@ -169,13 +161,7 @@ static int32_t cloud_velocity_entry(const PDF *pdf, const VEL *vel, int64_t n, c
     if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (n == 0) return CMX_OK;
     if (!q_liq || !rho || !N_liq) return CMX_ERR_BAD_ARG;
-    const double pi = 3.14159265358979323846, nu = pdf->nu_c, mu = pdf->mu_c, z1 = (nu + 1.0) / mu;
-    const double dlg = (double)pdf->loggamma_z1 - (double)pdf->loggamma_z2;   // log Γ(z₁)/Γ(z₂)
-    CloudVelConsts<FT> c;
-    c.rho_w = (FT)vel->rho_w;
-    c.pre_c = (FT)(1.0 / 18.0 * std::cbrt(std::pow(6.0 / (double)vel->rho_w / pi, 2.0)) * (double)vel->grav / (double)vel->nu_air);
-    c.K23 = (FT)std::exp(2.0 / 3.0 * dlg + std::lgamma(z1 + 2.0 / 3.0 / mu) - std::lgamma(z1));
-    c.K53 = (FT)std::exp(5.0 / 3.0 * dlg + std::lgamma(z1 + 5.0 / 3.0 / mu) - std::lgamma(z1));
+    const CloudVelConsts<FT> c = make_cloud_vel_consts<FT>(*pdf, *vel);
     hipLaunchKernelGGL((sb2006_cloud_velocity_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                        reinterpret_cast<hipStream_t>(stream), c, q_liq, rho, N_liq, vt_n, vt_m, n);
     CMX_HIP_TRY(hipGetLastError());

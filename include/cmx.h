@@ -484,6 +484,37 @@ int32_t cmx_sb2006_cloud_terminal_velocity_f64(const cmx_cloud_pdf_sb2006_f64 *p
                                                const double *q_liq, const double *rho, const double *N_liq, double *vt_n, double *vt_m,
                                                void *stream);
 
+/* ---------------------------------------------------------------------------
+ * (2b) Fused COLUMN kernel: the north-star tendencies + the sedimentation step a host model applies
+ * right after them, in one pass: 7 columns in, 4 out (44 B/point f32) instead of 88 B/point for the unfused sequence.
+ *
+ * Replaces, per column of n_lev contiguous levels (level 0 = lowest; flat index i = col·n_lev + k — a ClimaCore VF /
+ * VIJFH(Ni = Nj = 1) column field; test/gpu_clima_core_test.jl:16-30 builds such spaces):
+ *   tend = BMT.bulk_microphysics_tendencies(Microphysics2Moment(), mp, tps, ρ, T, q_tot, q_lcl, n_lcl, q_rai, n_rai)   BMT:820-854
+ *   (w_n, w_m) = CM2.rain_terminal_velocity(sb, vel, q_rai, ρ, ρ n_rai)                                                CM2:685-719
+ *   (c_n, c_m) = CM2.cloud_terminal_velocity(sb.pdf_c, cloud_vel, q_lcl, ρ, ρ n_lcl)    [iff cloud_vel != NULL]        CM2:647-664
+ * followed by the host model's first-order upwind ("right-biased": the value of the cell above) flux divergence
+ *   F_k = ρ_k χ_k w_k,   ∂χ_k/∂t += (F_{k+1} − F_k) · inv_dz[k] / ρ_k,   F_{n_lev} = 0,
+ * for χ = q_rai (w_m), n_rai (w_n) and — with cloud_vel — q_lcl (c_m), n_lcl (c_n).  The flux scheme is the host model's
+ * (ClimaAtmos precipitation advection), NOT part of the reference package: its oracle is a restatement of the formula
+ * above ("parity unpinned" for the flux step; the tendencies and fall speeds it consumes are pinned as in (1)).
+ * flags: CMX_SB2006_LIMITED and exactly one of CMX_VEL_SB2006 / CMX_VEL_CHEN2022.  inv_dz: n_lev values 1/Δz_k [1/m].
+ * precip_flux (optional, n_col values): F_0 of q_rai, the surface precipitation mass flux [kg m⁻² s⁻¹].
+ * Results do not depend on tile boundaries or alignment (bit-identical to a one-point-per-lane evaluation).
+ * ------------------------------------------------------------------------- */
+int32_t cmx_sb2006_column_tendencies_sedimentation_f32(
+    const cmx_warm_rain_2m_f32 *warm_rain, const cmx_thermo_f32 *tps, const cmx_rain_vel_f32 *vel,
+    const cmx_stokes_vel_f32 *cloud_vel, uint32_t flags, int64_t n_col, int32_t n_lev, const float *inv_dz,
+    const float *rho, const float *T, const float *q_tot, const float *q_lcl, const float *n_lcl, const float *q_rai,
+    const float *n_rai, float *dq_lcl_dt, float *dn_lcl_dt, float *dq_rai_dt, float *dn_rai_dt, float *precip_flux,
+    void *stream);
+int32_t cmx_sb2006_column_tendencies_sedimentation_f64(
+    const cmx_warm_rain_2m_f64 *warm_rain, const cmx_thermo_f64 *tps, const cmx_rain_vel_f64 *vel,
+    const cmx_stokes_vel_f64 *cloud_vel, uint32_t flags, int64_t n_col, int32_t n_lev, const double *inv_dz,
+    const double *rho, const double *T, const double *q_tot, const double *q_lcl, const double *n_lcl, const double *q_rai,
+    const double *n_rai, double *dq_lcl_dt, double *dn_lcl_dt, double *dq_rai_dt, double *dn_rai_dt, double *precip_flux,
+    void *stream);
+
 /* Bulk cloud → rain conversion of the other two-moment schemes — src/Microphysics2M.jl:920-1003:
  *   acnv = CM2.conv_q_lcl_to_q_rai(scheme, q_lcl, ρ, N_d[, smooth_transition])     KK2000 | B1994 | TC1980 | LD2004
  *   accr = CM2.accretion(scheme, q_lcl, q_rai, ρ)                                   KK2000 | B1994 | TC1980

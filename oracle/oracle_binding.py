@@ -98,6 +98,35 @@ def sb2006_warm_rain_tendencies(fam, wr, tps, vel, flags, rho, T, q_tot, q_lcl, 
     return outs
 
 
+def sb2006_column_tendencies_sedimentation(fam, wr, tps, vel, cloud_vel, flags, inv_dz, rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, *,
+                                           float32_gates=None, nthreads=1, branch_margin=1e-5):
+    """Oracle twin of cmx_sb2006_column_tendencies_sedimentation_* (flux step: parity unpinned, see cmx_oracle_column_impl.h).
+    State arrays of shape (n_col, n_lev); returns the 4 tendencies (flat), `precip_flux` (n_col), `scale`, `near_branch`."""
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    n_col, n_lev = np.shape(rho)
+    ins = [_col(fam, np.reshape(a, -1)) for a in (rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai)]
+    dz = _col(fam, inv_dz)
+    n = n_col * n_lev
+    names = ["dq_lcl_dt", "dn_lcl_dt", "dq_rai_dt", "dn_rai_dt"]
+    outs = [np.empty(n, dtype=NP[fam.sfx]) for _ in names]
+    scale = [np.empty(n, dtype=NP[fam.sfx]) for _ in names]
+    precip = np.empty(n_col, dtype=NP[fam.sfx])
+    near = np.zeros(n, dtype=np.uint8)
+    fn = getattr(lib(), f"cmxo_sb2006_column_tendencies_sedimentation_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(wr), C.byref(tps), C.byref(vel), C.byref(cloud_vel) if cloud_vel is not None else None, C.c_uint32(flags), C.byref(th),
+       C.c_int64(n_col), C.c_int32(n_lev), dz[1], *[p for _, p in ins], *[o.ctypes.data_as(C.c_void_p) for o in outs],
+       precip.ctypes.data_as(C.c_void_p), (C.c_void_p * 4)(*[c.ctypes.data for c in scale]), near.ctypes.data_as(C.c_void_p),
+       fam.ft(branch_margin), C.c_int32(nthreads))
+    res = dict(zip(names, outs))
+    res["precip_flux"] = precip
+    res["scale"] = dict(zip(names, scale))
+    res["near_branch"] = near.astype(bool)
+    return res
+
+
 def sb2006_process_rates(fam, wr, tps, vel, flags, q_tot, q_lcl, q_rai, N_lcl, N_rai, rho, T, *, float32_gates=None):
     """Oracle twin of cmx_sb2006_process_rates_* (SB2006_2M_kernel, test/gpu_tests.jl:220-235)."""
     if float32_gates is None:

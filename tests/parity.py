@@ -124,5 +124,5 @@ def assert_parity(got: dict, ref: dict, rtol: float, names=OUT_NAMES, what="", f
         assert ps["worst_wellcond"] <= rtol, (
             f"{what} {k}: well-conditioned point (|ref| > {WELLCOND[ft]:g}·scale) with plain relative error {ps['worst_wellcond']:.3e} > {rtol:g}")
     if near is not None and near.size:
-        assert near.mean() < 1e-4, f"{what}: implausibly many near-branch points ({near.sum()})"
+        assert near.mean() < 1e-4 or near.sum() <= 2, f"{what}: implausibly many near-branch points ({near.sum()})"
     return report
