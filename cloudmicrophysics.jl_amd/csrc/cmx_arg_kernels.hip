@@ -207,6 +207,7 @@ __device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, cons
 // the two wants as run-time flags the compiler keeps both erfc chains and their selects alive (1212 → 729 VALU per 4 points).
 template <typename FT, int NM, bool SINKS, int VEC, bool N_ONLY = false>
 __global__ __launch_bounds__(kBlock) void arg_activation_kernel(const ArgConsts<FT> c, const ArgIO<FT> io, const int64_t nvec) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= nvec) return;
     FT T[VEC], p[VEC], w[VEC], qt[VEC], ql[VEC] = {}, qi[VEC] = {}, Nl[VEC] = {}, Ni[VEC] = {};
@@ -340,6 +341,7 @@ template <typename FT, int NM, bool SINKS>
 __global__ __launch_bounds__(kBlock) void arg_activation_columns_kernel(const ArgConsts<FT> c, const FT f1, const FT f2, const FT g1,
                                                                         const FT g2, const ArgIO<FT> io, const ArgColIO<FT> mc,
                                                                         const int64_t n) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     ArgModeConsts<FT> cm[NM];

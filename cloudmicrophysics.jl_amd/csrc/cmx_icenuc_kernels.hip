@@ -84,6 +84,7 @@ template <typename FT> __device__ __forceinline__ FT a_w_ice_dev(const IceNucCon
 template <typename FT, bool LINEAR, int VEC, bool RATES_ONLY = false>
 __global__ __launch_bounds__(kBlock) void ice_nucleation_kernel(const IceNucConsts<FT> c, const IceNucIO<FT> io,
                                                                 const int64_t nvec) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using M = Math<FT>;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool active = i < nvec;
@@ -151,6 +152,7 @@ template <typename FT> struct WaterActIO { const FT *T, *e; FT *a_w_ice, *a_w_eT
 template <typename FT>
 __global__ __launch_bounds__(kBlock) void water_activity_kernel(const IceNucConsts<FT> c, const WaterActIO<FT> io,
                                                                 const int64_t n) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using M = Math<FT>;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -230,6 +232,7 @@ __global__ __launch_bounds__(kBlock) void p3_het_nucleation_kernel(const IceNucC
                                                                   const FT *__restrict__ N_lcl, const FT *__restrict__ RH,
                                                                   const FT *__restrict__ T, const FT *__restrict__ rho, FT *__restrict__ dNdt,
                                                                   FT *__restrict__ dLdt, const int64_t n) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using M = Math<FT>;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;

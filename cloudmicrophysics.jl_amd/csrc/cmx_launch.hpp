@@ -52,6 +52,15 @@ inline int64_t tile_grid(int64_t work_items, int64_t items_per_block) {
 // every grid inside HIP's 2^31 − 1 workgroups; at ≥ 12 B per point that is beyond the 288 GB of HBM anyway.
 constexpr int64_t kMaxPoints = 16ll * 0x7fffffffll;
 
+// The two heaviest Float64 kernels (SB2006, 1-moment) run one point per lane (8-byte loads) instead of two (16-byte): they are
+// VALU-bound, not HBM-bound, and the two-points-per-lane variants spend VALU instructions on SGPR-spill traffic for the 2-SGPR
+// Float64 constants (SB2006: 1307 vs 1048 instructions per point in round 1; 1-moment 4.60 → 4.36 ms per 1e8 points in a same-box
+// A/B, round 2).  The lighter ones keep two points per lane (same A/B: ARG 3.25 vs 3.50 ms, ice nucleation 0.73 vs 0.88 with one).
+// A/B switch for the 1-moment kernel: -DCMX_F64_ONE_POINT_PER_LANE=0.
+#ifndef CMX_F64_ONE_POINT_PER_LANE
+#define CMX_F64_ONE_POINT_PER_LANE 1
+#endif
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // --- vector column access --------------------------------------------------------------------

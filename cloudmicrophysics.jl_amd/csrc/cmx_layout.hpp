@@ -37,6 +37,7 @@ constexpr int kLayoutBS = 128;   // lanes per workgroup of the adapter kernel
 template <typename FT, typename POLICY, int VEC, bool SEG, bool AOS, int BS = kLayoutBS>
 __global__ __launch_bounds__(BS) void tendencies_layout_kernel(const typename POLICY::Consts c,
                                                                const LayoutIO<FT, POLICY::NIN, POLICY::NOUT> io, const int64_t nvec) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     constexpr int NIN = POLICY::NIN, NOUT = POLICY::NOUT, NAOS = POLICY::NAOS;
     constexpr int CH = 16 / (int)sizeof(FT);                  // elements per 16-byte chunk
     constexpr int ROW = VEC * NAOS + CH;                      // LDS row of one lane (+1 chunk of padding against bank conflicts)

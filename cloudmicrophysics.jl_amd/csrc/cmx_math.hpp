@@ -10,6 +10,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+
 #include "cmx_lean_f64.hpp"
 
 namespace cmx {
@@ -20,6 +22,7 @@ template <> struct Math<float> {
     static constexpr int VEC = 4;
     static constexpr float eps() { return 1.1920928955078125e-07f; }          // eps(Float32)
     static constexpr float eps_1m() { return 2.2737367544323206e-13f; }       // cbrt(floatmin(Float32))
+    static __device__ __forceinline__ void prepare() {}                       // Float32 runs on the hardware transcendental unit: nothing to set up
     static __device__ __forceinline__ float exp2(float x) { return __builtin_amdgcn_exp2f(x); }
     static __device__ __forceinline__ float log2(float x) { return __builtin_amdgcn_logf(x); }
     static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -51,6 +54,9 @@ template <> struct Math<double> {
     static constexpr int VEC = 2;
     static constexpr double eps() { return 2.220446049250313e-16; }            // eps(Float64)
     static constexpr double eps_1m() { return 2.8126442852362996e-103; }      // cbrt(floatmin(Float64))
+    // FIRST statement of every kernel that evaluates Float64 functions, executed by every thread of the workgroup: copies the
+    // exp2 / log2 tables of cmx_lean_f64.hpp into LDS (3 KiB) and synchronises
+    static __device__ __forceinline__ void prepare() { lean::tables_init(); }
     static __device__ __forceinline__ double exp2(double x) { return lean::exp2(x); }
     static __device__ __forceinline__ double log2(double x) { return lean::log2(x); }
     static __device__ __forceinline__ double rcp(double x) { return lean::rcp(x); }
@@ -65,6 +71,13 @@ template <> struct Math<double> {
     static __device__ __forceinline__ double log1p(double x) { return lean::log1p(x); }
     static __device__ __forceinline__ double expm1(double x) { return lean::expm1(x); }
 };
+
+// Where the Float64 kernels' constants live (measured, round 2, one box, tools/ab_bench.sh): a Float64 kernel's 60–100 host-folded
+// parameters overflow the 102-SGPR file and the overflow is parked in VGPR lanes (v_writelane / v_readlane).  Staging the parameter
+// struct in LDS instead (uniform-address ds_read_b64) removed every readlane — and was SLOWER: the compiler hoists all those loads
+// to the top of the kernel, 243 VGPRs, 2 waves per SIMD, and the dependent Float64 chains are no longer covered (SB2006 3.23 → 3.68 ms,
+// 1-moment 4.60 → 5.72, ARG 3.23 → 3.45, ice nucleation 0.72 → 0.82); capping the registers turns the hoisted loads into scratch
+// spills (14.6 ms).  The parameters therefore stay kernel arguments for both float types.
 
 template <typename FT> __device__ __forceinline__ FT clampv(FT x, FT lo, FT hi) {
     // Base.clamp: x < lo ? lo : (x > hi ? hi : x)

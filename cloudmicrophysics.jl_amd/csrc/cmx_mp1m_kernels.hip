@@ -340,6 +340,7 @@ template <typename FT> __device__ __forceinline__ void mp1m_aggregate(const FT *
 template <typename FT, int VEC, uint32_t FLAGS = kRuntimeFlags>
 __global__ __launch_bounds__(kBlock) void mp1m_tendencies_kernel(const Mp1mConsts<FT> c, const Mp1mIn<FT> in,
                                                                  const Mp1mOut<FT> out, const int64_t nvec) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= nvec) return;
     FT rho[VEC], T[VEC], q_tot[VEC], q_lcl[VEC], q_icl[VEC], q_rai[VEC], q_sno[VEC];
@@ -368,6 +369,7 @@ template <typename FT> struct Mp1mLinArgs { FT q_min, dt, dt_sub, inv_dt_sub, in
 template <typename FT, uint32_t FLAGS = kRuntimeFlags>
 __global__ __launch_bounds__(kBlock) void mp1m_linearized_kernel(const Mp1mConsts<FT> c, const Mp1mLinArgs<FT> a, const Mp1mIn<FT> in,
                                                                  const Mp1mOut<FT> out, const int64_t n) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using M = Math<FT>;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -433,6 +435,7 @@ __global__ __launch_bounds__(kBlock) void mp1m_linearized_kernel(const Mp1mConst
 template <typename FT>
 __global__ __launch_bounds__(kBlock) void mp1m_sources_kernel(const Mp1mConsts<FT> c, const Mp1mIn<FT> in,
                                                               const Mp1mSrcOut<FT> out, const int64_t n) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const Mp1mSrc<FT> p = mp1m_point<FT>(c, in.rho[i], in.T[i], in.q_tot[i], in.q_lcl[i], in.q_icl[i], in.q_rai[i], in.q_sno[i]);
@@ -461,6 +464,7 @@ template <typename FT> struct Vel1mIO {
 
 template <typename FT>
 __global__ __launch_bounds__(kBlock) void mp1m_velocity_kernel(const Vel1mConsts<FT> c, const Vel1mIO<FT> io, const int64_t n) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using M = Math<FT>;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -547,7 +551,7 @@ static int32_t tendencies_1m_entry(const MP *mp, const TH *tps, uint32_t flags, 
     if (!rho || !T || !q_tot || !q_lcl || !q_icl || !q_rai || !q_sno || !dq_lcl || !dq_icl || !dq_rai || !dq_sno) return CMX_ERR_BAD_ARG;
     const Mp1mConsts<FT> c = make_mp1m_consts<FT>(*mp, *tps, flags, (double)Math<FT>::eps_1m());
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    constexpr int VEC = Math<FT>::VEC;
+    constexpr int VEC = (sizeof(FT) == 8 && CMX_F64_ONE_POINT_PER_LANE) ? 1 : Math<FT>::VEC;
     const void *ptrs[] = {rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno, dq_lcl, dq_icl, dq_rai, dq_sno};
     const uintptr_t mis0 = reinterpret_cast<uintptr_t>(rho) & 15u;
     bool same_mis = (mis0 % sizeof(FT)) == 0;

@@ -171,6 +171,7 @@ template <typename FT> struct ColLds {
 template <typename FT, typename QUAD, bool ASPECT, bool FUSED, int GROUP>
 __global__ __launch_bounds__(kBlock, 2) void p3_collision_kernel(const P3Consts<FT> c, const P3VelConsts<FT> v, const P3ColConsts<FT> k,
                                                              const QUAD quad, const P3ColIO<FT> io, const int64_t n) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using P = PM<FT>;
     using M = Math<FT>;
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -706,6 +707,7 @@ template <typename FT> struct FusedIO {
 template <typename FT, bool LIMITED>
 __global__ __launch_bounds__(kBlock) void mp2m_p3_pointwise_kernel(const SbConsts<FT> sc, const P3Consts<FT> c, const PointwiseConsts<FT> k,
                                                                   const FusedIO<FT> io, const int64_t n) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using P = PM<FT>;
     using M = Math<FT>;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -787,6 +789,7 @@ template <typename FT, bool CLOUD, bool LIMITED>
 __global__ __launch_bounds__(kBlock) void liquid_freezing_kernel(const PointwiseConsts<FT> k, const FT *__restrict__ q, const FT *__restrict__ rho,
                                                                 const FT *__restrict__ N, const FT *__restrict__ T, FT *__restrict__ dn,
                                                                 FT *__restrict__ dq, const int64_t n) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using P = PM<FT>;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;

@@ -27,6 +27,7 @@ namespace cmx {
 
 template <typename FT>
 __global__ __launch_bounds__(kBlock) void p3_shape_kernel(const P3Consts<FT> c, const P3IO<FT> io, const int64_t n) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using P = PM<FT>;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -137,6 +138,7 @@ template <typename FT, typename QUAD> struct P3VelIO {
 template <typename FT, typename QUAD, bool ASPECT, bool MELT = false>
 __global__ __launch_bounds__(kBlock) void p3_velocity_kernel(const P3Consts<FT> c, const P3VelConsts<FT> v, const QUAD quad,
                                                             const P3VelIO<FT, QUAD> io, const int64_t n) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using P = PM<FT>;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -294,6 +296,7 @@ template <typename FT, typename QUAD> struct P3SelfIO { const FT *rho_q, *rho_n,
 template <typename FT, typename QUAD, bool ASPECT>
 __global__ __launch_bounds__(kBlock) void p3_self_collection_kernel(const P3Consts<FT> c, const P3VelConsts<FT> v, const QUAD quad,
                                                                    const P3SelfIO<FT, QUAD> io, const int64_t n) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using P = PM<FT>;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;

@@ -79,8 +79,9 @@ __device__ __forceinline__ SedFlux<FT> sed_fluxes_of_point(const SbConsts<FT> &c
 }
 
 template <typename FT, bool LIMITED, int VEL, bool CLOUD, int VEC, int BS>
-__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(5))) void sb2006_column_kernel(const SbConsts<FT> c, const CloudVelConsts<FT> cv, const SbColIO<FT> io,
+__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(sizeof(FT) == 4 ? 5 : 2))) void sb2006_column_kernel(const SbConsts<FT> c, const CloudVelConsts<FT> cv, const SbColIO<FT> io,
                                                            const int64_t first, const int64_t nvec) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using M = Math<FT>;
     // fluxes of every lane's FIRST point, + slot BS for the point that follows the tile
     __shared__ __align__(16) FT halo[BS + 1][4];

@@ -146,6 +146,7 @@ template <typename FT>
 __global__ __launch_bounds__(kBlock) void sb2006_cloud_velocity_kernel(const CloudVelConsts<FT> c, const FT *__restrict__ q_liq,
                                                                        const FT *__restrict__ rho, const FT *__restrict__ N_liq,
                                                                        FT *__restrict__ vt_n, FT *__restrict__ vt_m, const int64_t n) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     FT v0, v1;
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(kBlock) void bulk_2m_cloud_to_rain_kernel(const Bul
                                                                        const FT *__restrict__ q_rai, const FT *__restrict__ rho,
                                                                        const FT *__restrict__ N_d, FT *__restrict__ acnv,
                                                                        FT *__restrict__ accr, const int64_t n) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using M = Math<FT>;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;

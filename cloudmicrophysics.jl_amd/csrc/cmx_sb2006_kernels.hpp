@@ -30,6 +30,7 @@ template <typename FT> struct SbProcOut { FT *col[CMX_SB2006_NPROC]; };
 template <typename FT, bool LIMITED, int VEL, int VEC, int BS = kBlock, int C = 1, bool NT = true>
 __global__ __launch_bounds__(BS) void sb2006_tendencies_kernel(const SbConsts<FT> c, const SbIn<FT> in,
                                                                const SbOut<FT> out, const int64_t nvec) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using M = Math<FT>;
     const int64_t base = ((int64_t)blockIdx.x * C) * BS + threadIdx.x;
     FT rho[C][VEC], T[C][VEC], q_tot[C][VEC], q_lcl[C][VEC], n_lcl[C][VEC], q_rai[C][VEC], n_rai[C][VEC];
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(kBlock) void sb2006_process_kernel(const SbConsts<F
                                                                 const FT *__restrict__ N_lcl, const FT *__restrict__ N_rai,
                                                                 const FT *__restrict__ rho, const FT *__restrict__ T,
                                                                 const SbProcOut<FT> out, const int64_t n) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using M = Math<FT>;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {

@@ -68,3 +68,42 @@ def test_special_values(lean):
         np.testing.assert_array_equal(lean(EXPM1, [0.0, inf, -inf, nan, -800.0]), [0.0, inf, -1.0, nan, -1.0])
         np.testing.assert_array_equal(lean(LOG1P, [0.0, inf, nan, -1.0, -2.0]), [0.0, inf, nan, -inf, nan])
         assert np.isnan(lean(SQRT, [-1.0])[0])
+
+
+# ---- the same functions ON THE DEVICE (cmx_lean_eval_f64: LDS tables, hardware rcp / rsq seeds, v_ldexp / v_frexp) -------------------
+@pytest.fixture(scope="module")
+def dev_lean():
+    import torch
+
+    from cmx import _lib
+    assert torch.cuda.is_available()
+    lib = _lib.lib()
+
+    def ev(which, x):
+        xd = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64)).cuda()
+        yd = torch.empty_like(xd)
+        st = lib.cmx_lean_eval_f64(which, xd.numel(), C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), None)
+        assert st == 0
+        torch.cuda.synchronize()
+        return yd.cpu().numpy()
+    return ev
+
+
+@pytest.mark.gpu
+def test_device_accuracy_in_ulps(dev_lean):
+    test_accuracy_in_ulps.__wrapped__(dev_lean) if hasattr(test_accuracy_in_ulps, "__wrapped__") else test_accuracy_in_ulps(dev_lean)
+    rng = np.random.default_rng(5)
+    n = 2_000_000
+    x = rng.uniform(-1000, 1000, n)
+    assert ulps(dev_lean(EXP2, x), np.exp2(x)) <= 1
+    x = np.exp(rng.uniform(-700, 700, n))
+    assert ulps(dev_lean(LOG2, x), np.log2(x)) <= 2
+    x = 1 + rng.uniform(-1e-3, 1e-3, n)                # the table interval around 1 has c = 1: relative accuracy is kept
+    assert ulps(dev_lean(LOG2, x), np.log2(x)) <= 2 and ulps(dev_lean(LOG, x), np.log(x)) <= 3
+    x = 10.0 ** rng.uniform(-320, -300, 100_000)       # subnormal arguments take the rescue path
+    assert ulps(dev_lean(LOG2, x), np.log2(x)) <= 2
+
+
+@pytest.mark.gpu
+def test_device_special_values(dev_lean):
+    test_special_values(dev_lean)
