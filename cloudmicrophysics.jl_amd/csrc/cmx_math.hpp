@@ -33,9 +33,26 @@ template <> struct Math<float> {
     static __device__ __forceinline__ float max(float a, float b) { return __builtin_fmaxf(a, b); }
     static __device__ __forceinline__ float nan() { return __builtin_nanf(""); }
     static __device__ __forceinline__ float min(float a, float b) { return __builtin_fminf(a, b); }
-    // Γ(z) for z in [1, 8]: shift into [2,3) and evaluate a minimax-quality polynomial
-    // (only used by the Chen-2022 rain velocity: z = b_i(ρ)+1 ∈ [2.0, 3.4], z+3).
-    static __device__ __forceinline__ float tgamma(float z) { return ::tgammaf(z); }
+    // Γ(z), used by the Chen-2022 rain velocity only, where z = b_i(ρ) + 1 ∈ [2.0, 3.4] (b = 1.15 / 2.30 − 0.038 ρ, Common.jl:290-302):
+    // a degree-10 interpolating polynomial in t = (z − 2.75)/1.25 on [1.5, 4] (3.3e-7 relative in Float32 Horner; OCML's tgammaf
+    // costs ≈ 110 instructions and made the Chen variant of the fused kernel compute-bound: 1.37 ms per 1e8 points in round 1).
+    // Outside [1.5, 4] (exotic parameter overrides) OCML is called — a branch no lane takes with the reference's parameters.
+    static __device__ __forceinline__ float tgamma(float z) {
+        const float t = fma(z, 0.8f, -2.2f);
+        float p = 0.000606461835549f;
+        p = fma(p, t, 0.000949070487934f);
+        p = fma(p, t, 0.00527334298015f);
+        p = fma(p, t, 0.015461039999f);
+        p = fma(p, t, 0.0556865757496f);
+        p = fma(p, t, 0.142589333556f);
+        p = fma(p, t, 0.380736919836f);
+        p = fma(p, t, 0.751528528131f);
+        p = fma(p, t, 1.39245065912f);
+        p = fma(p, t, 1.64635862269f);
+        p = fma(p, t, 1.60835942199f);
+        if (!(z >= 1.5f && z <= 4.0f)) p = ::tgammaf(z);
+        return p;
+    }
     // log1p / expm1 accurate near 0 without the OCML double-float expansions (≈250 instructions each):
     // 4-term series below |x| = 1/32, the hardware log2/exp2 above (where 1+x / eˣ−1 no longer cancel: ≤4e-6 rel.)
     static __device__ __forceinline__ float log1p(float x) {
@@ -67,7 +84,21 @@ template <> struct Math<double> {
     static __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }
     static __device__ __forceinline__ double nan() { return __builtin_nan(""); }
     static __device__ __forceinline__ double min(double a, double b) { return __builtin_fmin(a, b); }
-    static __device__ __forceinline__ double tgamma(double z) { return ::tgamma(z); }
+    // Γ(z) on [1.5, 4] (see the Float32 twin): degree-22 interpolating polynomial, 9e-15 relative; OCML outside
+    static __device__ __forceinline__ double tgamma(double z) {
+        const double t = fma(z, 0.8, -2.2);
+        const double k[23] = {1.6083594219855455584, 1.6463589739909790518, 1.3924499187912875802, 0.75152171904830877759,
+                              0.38075160368679774603, 0.14262439063517987378, 0.055606088443515184361, 0.015394396819926214053,
+                              0.0054496056318177296227, 0.00098897444374469870313, 0.00044573752011233748607, 0.000010932744047535149967,
+                              0.000043139914396103166238, -9.7546600621484357892e-6, 6.4693602774412672403e-6, -2.243298262749311333e-6,
+                              1.0854823652885385946e-6, -8.4496532802657781764e-7, 3.894405396736869375e-7, 7.7776820822669398175e-8,
+                              -3.6483865756254320843e-8, -8.5261728750953385182e-8, 3.8953586756712331112e-8};
+        double p = k[22];
+#pragma unroll
+        for (int i = 21; i >= 0; --i) p = fma(p, t, k[i]);
+        if (!(z >= 1.5 && z <= 4.0)) p = ::tgamma(z);
+        return p;
+    }
     static __device__ __forceinline__ double log1p(double x) { return lean::log1p(x); }
     static __device__ __forceinline__ double expm1(double x) { return lean::expm1(x); }
 };
@@ -78,6 +109,21 @@ template <> struct Math<double> {
 // to the top of the kernel, 243 VGPRs, 2 waves per SIMD, and the dependent Float64 chains are no longer covered (SB2006 3.23 → 3.68 ms,
 // 1-moment 4.60 → 5.72, ARG 3.23 → 3.45, ice nucleation 0.72 → 0.82); capping the registers turns the hoisted loads into scratch
 // spills (14.6 ms).  The parameters therefore stay kernel arguments for both float types.
+
+// `keep(x)`: x is computed HERE, unconditionally.  The gates of the rate functions are selects (`gate ? 0 : rate`), exactly the
+// reference's `ifelse`; when `rate` ends in a transcendental the compiler prefers a branch around it (v_exp / v_log are "expensive"
+// in its cost model) — per point, 3–4 branches in the SB2006 kernel.  A lane owns 4 independent points whose instruction streams
+// should interleave; every branch ends a basic block, costs 4–6 scalar instructions and a pipeline bubble, and in a wave of 64
+// different states both sides run anyway.  The empty asm makes the value opaque at this point, so it cannot be sunk behind the gate.
+#ifndef CMX_KEEP
+#define CMX_KEEP 1
+#endif
+template <typename FT> __device__ __forceinline__ FT keep(FT x) {
+#if CMX_KEEP
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
 
 template <typename FT> __device__ __forceinline__ FT clampv(FT x, FT lo, FT hi) {
     // Base.clamp: x < lo ? lo : (x > hi ? hi : x)

@@ -488,7 +488,8 @@ __global__ __launch_bounds__(kBlock) void mp1m_velocity_kernel(const Vel1mConsts
                 const FT l2_mag = l2_q + bi * c.l2_1000 + (k == 2 ? c.ch_a3_pow * l2_rho : FT(0));
                 const FT l2_den = M::log2(lam + c.ch_c1000[k]);
                 const FT e3 = M::exp2(l2_mag - FT(4) * l2_lam_inv - (bi + FT(4)) * l2_den);
-                w = M::fma(c.ch_a[k] * e3, M::tgamma(bi + FT(4)) * FT(1.0 / 6.0), w);
+                // Γ(b+4)/3! = (b+3)(b+2)(b+1)·Γ(b+1)/6 with Γ on its polynomial range (cmx_math.hpp)
+                w = M::fma(c.ch_a[k] * e3, M::tgamma(bi + FT(1)) * (bi + FT(3)) * (bi + FT(2)) * (bi + FT(1)) * FT(1.0 / 6.0), w);
             }
             io.vt_chen[i] = q > eps ? M::max(FT(0), w) : FT(0);
         }

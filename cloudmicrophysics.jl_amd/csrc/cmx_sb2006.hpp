@@ -362,7 +362,8 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
     {   // autoconversion CM2:396-427
         const FT x_lcl = M::min(c.x_star, x_lcl_raw);
         const FT tau_a = M::exp2(c.acnv_a * l2_tau);
-        const FT phi_au = no_q_rai ? FT(0) : c.acnv_A * tau_a * M::exp2(c.acnv_b * M::log2(FT(1) - tau_a));
+        const FT phi_raw = keep(c.acnv_A * tau_a * M::exp2(c.acnv_b * M::log2(FT(1) - tau_a)));
+        const FT phi_au = no_q_rai ? FT(0) : phi_raw;
         const FT u = (L_lcl * x_lcl) * c.sqrt_kfac;   // √(kcc/20/x*·ν-terms)·L·x̄: keeps L²x̄² inside the f32 range
         const FT inv_omt = M::rcp(one_m_tau);
         const FT dL_rai = (u * u) * M::fma(phi_au, inv_omt * inv_omt, FT(1)) * (c.acnv_rho0 * inv_rho);
@@ -381,13 +382,14 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
         r.lsc_plus_au = no_q_lcl ? FT(0) : -c.ksc * inv_rho * (Lr * Lr);
     }
     {   // accretion CM2:445-470
-        const FT phi_ac = M::exp2(c.accr_c * (l2_tau - M::log2(tau + c.tau_0)));
-        const FT dL_rai = c.kcr_s * rs_rho * L_lcl * L_rai * phi_ac;
+        const FT phi_ac = keep(M::exp2(c.accr_c * (l2_tau - M::log2(tau + c.tau_0))));
+        const FT k_ac = c.kcr_s * rs_rho * L_rai * phi_ac;
+        const FT dq = keep(k_ac * L_lcl * inv_rho);          // dL_rai/ρ with dL_rai = kcr √(ρ0/ρ) L_lcl L_rai ϕ_ac
+        const FT dN = keep(-k_ac * sN_lcl);                  // −dL_rai / x̄_c with x̄_c = L_lcl / N_lcl: the L_lcl of dL_rai cancels
         const bool gate = no_q_lcl || no_q_rai || no_N_lcl;
-        r.ac_dq_rai = gate ? FT(0) : dL_rai * inv_rho;
+        r.ac_dq_rai = gate ? FT(0) : dq;
         r.ac_dq_lcl = -r.ac_dq_rai;
-        // −dL_rai / x̄_c with x̄_c = L_lcl / N_lcl: the L_lcl of dL_rai cancels
-        r.ac_dN_lcl = gate ? FT(0) : -(c.kcr_s * rs_rho * L_rai * phi_ac) * sN_lcl;
+        r.ac_dN_lcl = gate ? FT(0) : dN;
     }
 
     // ---- rain PSD parameters, once (CM2:67-110), from the safe values ----------
@@ -403,8 +405,8 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
         const bool gate = no_q_rai || no_N_rai;
         r.rsc = gate ? FT(0) : sc;
         const FT dD = Dr - c.Deq;
-        const FT phi_br = (Dr < c.Dr_th) ? FT(-1)
-                                         : ((Dr <= c.Deq) ? c.kbr * dD : M::exp2(c.kappa_br_l2e * dD) - FT(1));
+        const FT br_lin = keep(c.kbr * dD), br_exp = keep(M::exp2(c.kappa_br_l2e * dD) - FT(1));
+        const FT phi_br = (Dr < c.Dr_th) ? FT(-1) : ((Dr <= c.Deq) ? br_lin : br_exp);
         r.rbr = gate ? FT(0) : -(phi_br + FT(1)) * r.rsc;
     }
     {   // rain_evaporation CM2:780-828

@@ -14,6 +14,10 @@
 #include "cmx_layout.hpp"
 #include "cmx_sb2006.hpp"
 
+#ifndef CMX_POINT_FENCE
+#define CMX_POINT_FENCE 0      // A/B switch (round 2): a scheduling fence between the points of a lane did not pay (0.89 vs 0.86 ms)
+#endif
+
 namespace cmx {
 
 template <typename FT> struct SbIn { const FT *rho, *T, *q_tot, *q_lcl, *n_lcl, *q_rai, *n_rai; };
@@ -74,7 +78,12 @@ __global__ __launch_bounds__(BS) void sb2006_tendencies_kernel(const SbConsts<FT
             dn_rai[k] = M::fma(((p.evN + p.au_dN_rai) + p.rsc) + p.rbr, p.inv_rho, p.na_rai);
             vt_n[k] = p.vt_n;
             vt_m[k] = p.vt_m;
-            if (poisoned) dq_lcl[k] = dn_lcl[k] = dq_rai[k] = dn_rai[k] = vt_n[k] = vt_m[k] = M::nan();
+            // branch-free: x + NaN = NaN, x + 0 = x (a −0 result becomes +0, the same in every variant of this kernel)
+            const FT poison = poisoned ? M::nan() : FT(0);
+            dq_lcl[k] += poison; dn_lcl[k] += poison; dq_rai[k] += poison; dn_rai[k] += poison; vt_n[k] += poison; vt_m[k] += poison;
+#if CMX_POINT_FENCE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         store_col<FT, VEC, NT>(out.dq_lcl, i, dq_lcl);
         store_col<FT, VEC, NT>(out.dn_lcl, i, dn_lcl);
@@ -100,7 +109,8 @@ template <typename FT, bool LIMITED> struct Sb2006LayoutPolicy {
         y[1] = M::fma(p.lsc_plus_au + p.ac_dN_lcl, p.inv_rho, p.na_lcl);
         y[2] = (p.evq + p.au_dq_rai) + p.ac_dq_rai;
         y[3] = M::fma(((p.evN + p.au_dN_rai) + p.rsc) + p.rbr, p.inv_rho, p.na_rai);
-        if (any_nan(x[0], x[2], x[3], x[4], x[5], x[6], x[1])) y[0] = y[1] = y[2] = y[3] = M::nan();
+        const FT poison = any_nan(x[0], x[2], x[3], x[4], x[5], x[6], x[1]) ? M::nan() : FT(0);
+        y[0] += poison; y[1] += poison; y[2] += poison; y[3] += poison;
     }
 };
 
