@@ -491,9 +491,31 @@ def setup_mp2m_p3(args, dev, dtype, rank):
     return cols + [ll], step, desc, cpu_run
 
 
+def native_oracle_build():
+    """Build the oracle for THIS machine (gcc -O3 -march=native, oracle/Makefile target `native`) into a scratch directory and return
+    (path, flags text); (None, reason) if there is no compiler — the portable -O2 build that ships with the repo is used then."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("gcc") or not shutil.which("make"):
+        return None, "no gcc/make on this machine"
+    out = Path(tempfile.mkdtemp(prefix="cmx_oracle_native_"))
+    r = subprocess.run(["make", "-C", str(REPO / "oracle"), "native", f"NATIVE_DIR={out}"], capture_output=True, text=True)
+    so = out / "libcmx_oracle_native.so"
+    if r.returncode != 0 or not so.exists():
+        return None, "native build failed: " + r.stderr.strip()[-200:]
+    return so, "gcc -O3 -march=native -ffp-contract=off"
+
+
 def cpu_baseline(args, cols_np, desc, cpu_run):
     """The oracle — a C restatement of the reference's scalar arithmetic (kind 'port'; the Julia reference cannot
-    run here) — timed on the host cores over repeated passes of a bounded sample of the same synthetic workload."""
+    run here) — timed on the host cores over repeated passes of a bounded sample of the same synthetic workload.  It is built
+    for the machine it runs on (-O3 -march=native) just before it is timed; it is the checker nowhere."""
+    native, flags = native_oracle_build()
+    if native is not None:
+        os.environ["CMX_ORACLE_LIB"] = str(native)
+    else:
+        flags = f"gcc -O2 (portable build: {flags})"
     sys.path.insert(0, str(REPO / "oracle"))
     import oracle_binding as ob
     cores = desc.get("cpu_threads") or usable_cores()
@@ -509,7 +531,7 @@ def cpu_baseline(args, cols_np, desc, cpu_run):
     m = cols_np[0].size
     return {"value": passes * m / dt, "unit": "grid-points/s", "cores": cores, "kind": "port",
             "sample": f"{passes} passes over {m} of the same synthetic points ({passes * m} point evaluations), "
-                      f"{args.dtype} arithmetic, oracle/libcmx_oracle.so (gcc -O2, {cores} OpenMP thread(s)), {dt:.1f} s"}
+                      f"{args.dtype} arithmetic, oracle C restatement ({flags}, {cores} OpenMP thread(s)), {dt:.1f} s"}
 
 
 def load_launcher():

@@ -19,8 +19,16 @@ template <> struct PM<double> {
     // one-argument forms: OCML.  In the shape solver (a dozen call sites around the incomplete-gamma loops) the inlined lean
     // routines push the kernel from 2 waves/SIMD to 1 (24 → 30 ms per 1e7 columns); the quadrature loops use the
     // register-pinned lean forms below.
+#ifndef CMX_P3_LEAN_ONEARG
+#define CMX_P3_LEAN_ONEARG 0
+#endif
+#if CMX_P3_LEAN_ONEARG
+    static __device__ __forceinline__ double log(double x) { return lean::log(x); }
+    static __device__ __forceinline__ double exp(double x) { return lean::exp(x); }
+#else
     static __device__ __forceinline__ double log(double x) { return ::log(x); }
     static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
+#endif
     static __device__ __forceinline__ double lgamma(double x) { return ::lgamma(x); }
     static __device__ __forceinline__ double expm1(double x) { return ::expm1(x); }
     static __device__ __forceinline__ double log1p(double x) { return ::log1p(x); }
@@ -32,9 +40,18 @@ template <> struct PM<double> {
     // 1/d to ≈1 ulp: v_rcp_f64 (≈2⁻²⁴ relative) + two Newton steps — no div_scale / div_fmas / div_fixup sequence.
     // Only for finite, normal d (the incomplete-gamma loops: d = a + k, or a rescaled continued-fraction denominator).
     static __device__ __forceinline__ double rcp(double d) { return lean::rcp_finite(d); }
-    // hot-loop variants with register-pinned constants (cmx_lean_f64.hpp)
+    // hot-loop variants with register-pinned constants (cmx_lean_f64.hpp): table-driven (round 2; -DCMX_P3_TABLE_MATH=0 restores the
+    // round-1 polynomial forms for A/B runs).  The kernels call Math<FT>::prepare() first (tables → LDS).
+#ifndef CMX_P3_TABLE_MATH
+#define CMX_P3_TABLE_MATH 1
+#endif
+#if CMX_P3_TABLE_MATH
+    using Coefs = lean::TabCoefs;
+    static __device__ __forceinline__ Coefs coefs() { return lean::tab_coefs(); }
+#else
     using Coefs = lean::PinnedCoefs;
     static __device__ __forceinline__ Coefs coefs() { return lean::pinned_coefs(); }
+#endif
     static __device__ __forceinline__ void pin(double &x) { lean::pin(x); }
     static __device__ __forceinline__ double exp(double x, const Coefs &k) { return lean::exp(x, k); }
     static __device__ __forceinline__ double log(double x, const Coefs &k) { return lean::log(x, k); }

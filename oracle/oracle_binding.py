@@ -20,7 +20,11 @@ REPO = ORACLE_DIR.parent
 sys.path.insert(0, str(REPO / "cloudmicrophysics.jl_amd"))
 from cmx import _abi  # noqa: E402
 
-LIB_PATH = ORACLE_DIR / "libcmx_oracle.so"
+import os  # noqa: E402
+
+# CMX_ORACLE_LIB: bench.py's cpu_baseline leg points this at a copy built on the box it runs on (`make -C oracle native`:
+# -O3 -march=native); the tests always use the portable default build.
+LIB_PATH = Path(os.environ.get("CMX_ORACLE_LIB", ORACLE_DIR / "libcmx_oracle.so"))
 _lib = None
 
 

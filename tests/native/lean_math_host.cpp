@@ -17,3 +17,9 @@ extern "C" void lean_eval(int which, int64_t n, const double *x, double *y) {
         }
     }
 }
+// the register-pinned table-driven forms the P3 quadrature loops use
+extern "C" void lean_eval_pinned(int which, int64_t n, const double *x, double *y) {
+    namespace L = cmx::lean;
+    const L::TabCoefs k = L::tab_coefs();
+    for (int64_t i = 0; i < n; ++i) y[i] = which == 2 ? L::exp(x[i], k) : L::log(x[i], k);
+}

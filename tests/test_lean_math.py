@@ -18,10 +18,11 @@ def lean(tmp_path_factory):
                     str(REPO / "tests" / "native" / "lean_math_host.cpp")], check=True)
     lib = C.CDLL(str(so))
 
-    def ev(which, x):
+    def ev(which, x, pinned=False):
         x = np.ascontiguousarray(x, dtype=np.float64)
         y = np.empty_like(x)
-        lib.lean_eval(C.c_int(which), C.c_int64(x.size), x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p))
+        (lib.lean_eval_pinned if pinned else lib.lean_eval)(C.c_int(which), C.c_int64(x.size), x.ctypes.data_as(C.c_void_p),
+                                                            y.ctypes.data_as(C.c_void_p))
         return y
     return ev
 
@@ -53,6 +54,20 @@ def test_accuracy_in_ulps(lean):
     for lo, hi in ((-1e-5, 1e-5), (-0.9, 0.9), (0, 1e6)):
         x = rng.uniform(lo, hi, n)
         assert ulps(lean(LOG1P, x), np.log1p(x)) <= 5
+
+
+def test_pinned_table_forms(lean):
+    """exp(x, TabCoefs) / log(x, TabCoefs): the forms the P3 quadrature loops call."""
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-700, 700, 400_000)
+    assert ulps(lean(EXP, x, pinned=True), np.exp(x)) <= 2
+    x = np.exp(rng.uniform(-700, 700, 400_000))
+    assert ulps(lean(LOG, x, pinned=True), np.log(x)) <= 3
+    x = 1 + rng.uniform(-1e-3, 1e-3, 100_000)
+    assert ulps(lean(LOG, x, pinned=True), np.log(x)) <= 3
+    with np.errstate(all="ignore"):
+        np.testing.assert_array_equal(lean(EXP, [0.0, np.inf, -np.inf, np.nan, 800.0, -800.0], pinned=True), [1.0, np.inf, 0.0, np.nan, np.inf, 0.0])
+        np.testing.assert_array_equal(lean(LOG, [0.0, np.inf, np.nan, -1.0, 1.0, 5e-324], pinned=True)[:5], [-np.inf, np.inf, np.nan, np.nan, 0.0])
 
 
 def test_special_values(lean):
