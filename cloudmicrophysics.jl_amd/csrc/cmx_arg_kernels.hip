@@ -113,6 +113,29 @@ template <> __device__ __forceinline__ float erfc_dev<float>(float x) {
     return x >= 0.0f ? e : 2.0f - e;
 }
 template <> __device__ __forceinline__ double erfc_dev<double>(double x) { return ::erfc(x); }
+// erfc with RELATIVE accuracy, for the activated mass: the reference evaluates M_act with erfc itself (AA:319), so a small activated
+// fraction keeps its leading digits there (N_act is ½(1 − erf u), AA:257: absolute accuracy in the reference too, A&S above is its
+// match).  Float32: t·exp(−x² + P(t)), t = 1/(1 + x/2) (Chebyshev fit of Numerical Recipes' erfcc, fractional error < 1.2e-7; the
+// exponent is formed in Float32, so the relative error grows like 6e-8·x²: 5e-6 at erfc = 1e-30).  Float64: OCML.
+template <typename FT> __device__ __forceinline__ FT erfc_rel_dev(FT x);
+template <> __device__ __forceinline__ float erfc_rel_dev<float>(float x) {
+    using M = Math<float>;
+    const float z = __builtin_fabsf(x);
+    const float t = M::rcp(M::fma(0.5f, z, 1.0f));
+    float p = 0.17087277f;
+    p = M::fma(p, t, -0.82215223f);
+    p = M::fma(p, t, 1.48851587f);
+    p = M::fma(p, t, -1.13520398f);
+    p = M::fma(p, t, 0.27886807f);
+    p = M::fma(p, t, -0.18628806f);
+    p = M::fma(p, t, 0.09678418f);
+    p = M::fma(p, t, 0.37409196f);
+    p = M::fma(p, t, 1.00002368f);
+    p = M::fma(p, t, -1.26551223f);
+    const float e = t * M::exp2(M::fma(-z, z, p) * 1.4426950408889634f);
+    return x >= 0.0f ? e : 2.0f - e;
+}
+template <> __device__ __forceinline__ double erfc_rel_dev<double>(double x) { return ::erfc(x); }
 
 template <typename FT> struct ArgIO {
     const FT *T, *p, *w, *q_tot, *q_liq, *q_ice, *N_liq, *N_ice;
@@ -198,7 +221,7 @@ __device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, cons
     for (int k = 0; k < NM; ++k) {
         const FT u = M::fma(cm[k].u_c, dl0, cm[k].uc_sm);       // AA:255   (= ln(sm/smax)/fac, AA:316)
         o.n[k] = want_N ? cm[k].half_N * erfc_dev<FT>(u) : FT(0);                  // N ½ (1 − erf u)      AA:257
-        o.m[k] = want_M ? cm[k].half_M * erfc_dev<FT>(u - cm[k].fac) : FT(0);     // M/2 erfc(u − fac)    AA:319
+        o.m[k] = want_M ? cm[k].half_M * erfc_rel_dev<FT>(u - cm[k].fac) : FT(0); // M/2 erfc(u − fac)    AA:319
     }
     return o;
 }

@@ -129,6 +129,9 @@ template <typename FT> __device__ __forceinline__ FT clampv(FT x, FT lo, FT hi) 
     // Base.clamp: x < lo ? lo : (x > hi ? hi : x)
     return Math<FT>::min(Math<FT>::max(x, lo), hi);
 }
+// the same for lo ≤ hi as ONE instruction (v_med3_f32: the median of three is the clamp); Float64 has no med3
+__device__ __forceinline__ float clamp_ordered(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+__device__ __forceinline__ double clamp_ordered(double x, double lo, double hi) { return clampv(x, lo, hi); }
 
 // NaN inputs.  The reference sanitises with Julia's max(0, x), which returns NaN for a NaN x, and its arithmetic then carries the NaN to
 // the tendencies; the hardware v_max returns the other operand and would hide it.  The bulk-tendency kernels therefore poison every output

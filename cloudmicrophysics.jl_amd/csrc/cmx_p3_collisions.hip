@@ -832,6 +832,7 @@ static int32_t mp2m_p3_entry(const WR *wr, const IP *ip, const TH *tps, uint32_t
     for (int q = 0; q < 8; ++q) if (!out[q]) return CMX_ERR_BAD_ARG;
     const bool limited = (flags & CMX_P3_RAIN_PDF_LIMITED) != 0;
     using RV = std::conditional_t<std::is_same_v<FT, float>, cmx_rain_vel_f32, cmx_rain_vel_f64>;
+    if ((flags & CMX_P3_RAIN_PDF_LIMITED) && !sb_limiters_ok(*wr)) return CMX_ERR_BAD_ARG;      // clamp_ordered needs ordered limiter pairs
     const SbConsts<FT> sc = make_sb_consts<FT>(*wr, *tps, (const RV *)nullptr, (double)Math<FT>::eps_1m());
     P3Consts<FT> c = make_p3_consts<FT>(ip->scheme, flags & CMX_P3_SLOPE_CONSTANT);
     c.brent_iters = 0;

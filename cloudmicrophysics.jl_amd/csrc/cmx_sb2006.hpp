@@ -60,6 +60,13 @@ template <typename FT> struct SbConsts {
     FT ch_rho0_l2e, ch_a[3], ch_a3_pow, ch_b[3], ch_b_rho, ch_c1000[3], l2_1000;
 };
 
+// The limited rain PSD clamps with v_med3 (clamp_ordered): every (min, max) pair of the limiters must be ordered and positive.
+// Entry points return CMX_ERR_BAD_ARG otherwise (Base.clamp with lo > hi is not a clamp either).
+template <typename WR> inline bool sb_limiters_ok(const WR &wr) {
+    const auto &p = wr.seifert_beheng.pdf_r;
+    return p.xr_min > 0 && p.xr_min <= p.xr_max && p.N0_min > 0 && p.N0_min <= p.N0_max && p.lambda_min > 0 && p.lambda_min <= p.lambda_max;
+}
+
 template <typename FT, typename WR, typename TH, typename VL>
 inline SbConsts<FT> make_sb_consts(const WR &wr, const TH &tp, const VL *vel, double eps_1m) {
     SbConsts<FT> c{};
@@ -238,10 +245,12 @@ __device__ __forceinline__ SbRainPsd<FT> sb2006_rain_psd(const SbConsts<FT> &c, 
     const FT l2_L = M::log2(L_rai), l2_N = M::log2(sN_rai);
     SbRainPsd<FT> p;
     if constexpr (LIMITED) {
-        const FT l2_xt = clampv(l2_L - l2_N, c.l2_xr_min, c.l2_xr_max);                               // Eq. 94
-        const FT l2_N0 = clampv(l2_N + (c.l2_pi_rho_w - l2_xt) * FT(1.0 / 3.0), c.l2_N0_min, c.l2_N0_max);   // Eq. 95
-        p.l2_lam = clampv((c.l2_pi_rho_w + l2_N0 - l2_L) * FT(0.25), c.l2_lam_min, c.l2_lam_max);     // Eq. 96
-        p.l2_xr = clampv(l2_L + p.l2_lam - l2_N0, c.l2_xr_min, c.l2_xr_max);                          // Eq. 97
+        // the limiter pairs are ordered (xr_min ≤ xr_max, N0_min ≤ N0_max, λ_min ≤ λ_max: checked by the entry point), so each clamp
+        // is one v_med3_f32
+        const FT l2_xt = clamp_ordered(l2_L - l2_N, c.l2_xr_min, c.l2_xr_max);                               // Eq. 94
+        const FT l2_N0 = clamp_ordered(l2_N + (c.l2_pi_rho_w - l2_xt) * FT(1.0 / 3.0), c.l2_N0_min, c.l2_N0_max);   // Eq. 95
+        p.l2_lam = clamp_ordered((c.l2_pi_rho_w + l2_N0 - l2_L) * FT(0.25), c.l2_lam_min, c.l2_lam_max);     // Eq. 96
+        p.l2_xr = clamp_ordered(l2_L + p.l2_lam - l2_N0, c.l2_xr_min, c.l2_xr_max);                          // Eq. 97
     } else {
         p.l2_xr = l2_L - l2_N;
         p.l2_lam = (c.l2_pi_rho_w - p.l2_xr) * FT(1.0 / 3.0);

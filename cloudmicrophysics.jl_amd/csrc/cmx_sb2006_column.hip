@@ -219,6 +219,7 @@ static int32_t column_entry(const WR *wr, const TH *tps, const VL *vel, const ST
     if (n == 0) return CMX_OK;
     if (!inv_dz || !rho || !T || !q_tot || !q_lcl || !n_lcl || !q_rai || !n_rai || !dq_lcl || !dn_lcl || !dq_rai || !dn_rai)
         return CMX_ERR_BAD_ARG;
+    if ((flags & CMX_SB2006_LIMITED) && !sb_limiters_ok(*wr)) return CMX_ERR_BAD_ARG;      // clamp_ordered needs ordered limiter pairs
     const SbConsts<FT> c = make_sb_consts<FT>(*wr, *tps, vel, (double)Math<FT>::eps_1m());
     CloudVelConsts<FT> cv{};
     if (cloud_vel) cv = make_cloud_vel_consts<FT>(wr->seifert_beheng.pdf_c, *cloud_vel);

@@ -58,6 +58,7 @@ static int32_t tendencies_entry(const WR *wr, const TH *tps, const VL *vel, uint
     const int velk = decode_vel(flags, want_vel);
     if (velk < 0 || (want_vel && !vel)) return CMX_ERR_BAD_ARG;
     const bool limited = flags & CMX_SB2006_LIMITED;
+    if ((flags & CMX_SB2006_LIMITED) && !sb_limiters_ok(*wr)) return CMX_ERR_BAD_ARG;      // clamp_ordered needs ordered limiter pairs
     const SbConsts<FT> c = make_sb_consts<FT>(*wr, *tps, vel, (double)Math<FT>::eps_1m());
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // Float64: one point per lane (8-byte loads).  The kernel is VALU-bound there and the two-points-per-lane variant spends 14 % of
@@ -100,6 +101,7 @@ template <typename FT, typename WR, typename TH>
 static int32_t fields_entry(const WR *wr, const TH *tps, uint32_t flags, int64_t n_seg, int64_t seg_len, const FT *const *in,
                             const int64_t *in_stride, FT *const *out, const int64_t *out_stride, FT *aos, void *stream) {
     if (!wr || !tps || (flags & ~(uint32_t)CMX_SB2006_LIMITED)) return CMX_ERR_BAD_ARG;
+    if ((flags & CMX_SB2006_LIMITED) && !sb_limiters_ok(*wr)) return CMX_ERR_BAD_ARG;      // clamp_ordered needs ordered limiter pairs
     const SbConsts<FT> c = make_sb_consts<FT>(*wr, *tps, (const std::conditional_t<std::is_same_v<FT, float>, cmx_rain_vel_f32, cmx_rain_vel_f64> *)nullptr,
                                               (double)Math<FT>::eps_1m());
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -119,6 +121,7 @@ static int32_t process_entry(const WR *wr, const TH *tps, const VL *vel, uint32_
     const int velk = decode_vel(flags, want_vel);
     if (velk < 0 || (want_vel && !vel)) return CMX_ERR_BAD_ARG;
     const bool limited = flags & CMX_SB2006_LIMITED;
+    if ((flags & CMX_SB2006_LIMITED) && !sb_limiters_ok(*wr)) return CMX_ERR_BAD_ARG;      // clamp_ordered needs ordered limiter pairs
     const SbConsts<FT> c = make_sb_consts<FT>(*wr, *tps, vel, (double)Math<FT>::eps_1m());
     SbProcOut<FT> o;
     for (int k = 0; k < CMX_SB2006_NPROC; ++k) o.col[k] = out[k];

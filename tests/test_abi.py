@@ -100,6 +100,12 @@ def test_argument_validation_without_gpu():
     assert z(None, 4, None, None, None, None, None, None) == _abi.CMX_ERR_BAD_ARG
     assert z(C.byref(p0), 4, None, None, None, None, None, None) == _abi.CMX_ERR_BAD_ARG     # null columns
     assert z(C.byref(p0), 0, None, None, None, None, None, None) == _abi.CMX_OK
+    # limited rain PSD with an unordered limiter pair: refused (the kernel clamps with v_med3, which needs lo <= hi)
+    bad = P.WarmRainParams2M("f32")
+    bad.c.seifert_beheng.pdf_r.lambda_min, bad.c.seifert_beheng.pdf_r.lambda_max = 1e4, 1e3
+    assert f(C.byref(bad.c), C.byref(tps), None, 1, 0, *null, None) == _abi.CMX_OK             # n = 0 returns before the parameters matter
+    assert f(C.byref(bad.c), C.byref(tps), None, 1, 10, *([C.c_void_p(4096)] * 11), None, None, None) == _abi.CMX_ERR_BAD_ARG
+    assert f(C.byref(bad.c), C.byref(tps), None, 0, 10, *null, None) == _abi.CMX_ERR_BAD_ARG   # (not limited: falls through to the null-column check)
     # a point count no single launch can express (> 16·(2^31 − 1), cmx_launch.hpp kMaxPoints) is refused, not silently truncated
     huge = 16 * 0x7fffffff + 1
     assert z(C.byref(p0), huge, None, None, None, None, None, None) == _abi.CMX_ERR_UNSUPPORTED

@@ -250,3 +250,34 @@ def test_spatially_varying_aerosol_columns(dev, oracle, ft):
         assert np.max(np.abs(got.N_act[k].cpu().numpy() - ref["N_act"][k]) / Nk) <= tol
         Mk = rm[k][4].numpy().astype(np.float64)
         assert np.max(np.abs(got.M_act[k].cpu().numpy() - ref["M_act"][k]) / Mk) <= tol
+
+
+def test_small_activated_mass_fractions_keep_relative_accuracy_f32(dev, oracle):
+    """The reference forms M_act with erfc itself (AA:319), so a weakly activated mode keeps its leading digits; the Float32 kernel
+    must too (a relative-accuracy erfc, not the absolute-accuracy A&S 7.1.26 it uses for N_act = N/2 (1 − erf u), AA:257).
+    Weak updraughts: activated mass fractions from 1e-1 down to 1e-12 of the mode, pure relative bound 1e-3."""
+    import cmx
+    from cmx import synthetic
+    ft, n = "f32", 400_000
+    st = synthetic.arg_state(n, dtype=DT[ft], seed=99)
+    g = torch.Generator().manual_seed(5)
+    w = torch.exp(torch.log(torch.tensor(1e-4)) + torch.rand(n, generator=g) * torch.log(torch.tensor(3e3))).to(DT[ft])     # 1e-4 … 0.3 m/s
+    st = st._replace(w=w)
+    ad = synthetic.arg_config3_distribution()
+    ap, aip, tps = _params(ft)
+    r = cmx.aerosol_activation(ap, ad, aip, tps, *[c.to(dev) for c in st], want=("N_act", "M_act"))
+    torch.cuda.synchronize()
+    a64, i64, t64 = _params("f64")
+    adc = ad.c_struct(a64, _abi.F64)
+    ref = oracle.arg2000_activation(_abi.F64, a64, adc, i64, t64, *[c.numpy().astype(np.float64) for c in st], nthreads=8, float32_gates=True)
+    checked = small = 0
+    for k in range(5):
+        got = r.M_act[k].cpu().numpy().astype(np.float64)
+        exp = ref["M_act"][k]
+        total = exp.max()                                          # scale of the mode's activated mass in this sample
+        sel = exp > 1e-30
+        rel = np.abs(got[sel] - exp[sel]) / exp[sel]
+        assert rel.max() <= 1e-3, (k, rel.max())
+        checked += int(sel.sum())
+        small += int((exp[sel] < 1e-4 * total).sum())
+    assert checked > n and small > 1000          # the test did reach weakly activated states

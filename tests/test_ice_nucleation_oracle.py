@@ -90,3 +90,13 @@ def test_against_numpy_restatement(oracle):
     assert np.isnan(out["J_hom"][~ok]).all() and out["n_domain_errors"] == int((~ok).sum())
     # monotonicity asserted by the reference (test/homogeneous_ice_nucleation_tests.jl:26-35): colder → larger J
     assert np.all(np.diff(J[ok][np.argsort(d[ok])]) > 0)
+
+
+def test_homogeneous_J_linear_coefficients_are_the_references_literals():
+    """Both Linear_J_hom coefficients are literals in the reference tree (papers/ice_nucleation_2024/calibration_setup.jl:149,
+    calibration.jl:271-272); the parameter table must hold exactly those, and they must reproduce the reference's combined KAT."""
+    g = G["homogeneous_J_linear_coefficients"]
+    k = P.Koop2000("f64")
+    assert k.linear_c2 == g["linear_c2_slope"] and k.linear_c1 == g["linear_c1_intercept"]
+    J = 10.0 ** (g["linear_c2_slope"] * g["kat"]["delta_a_w"] + g["linear_c1_intercept"]) * 1e6      # [cm⁻³ s⁻¹] → [m⁻³ s⁻¹]
+    assert math.isclose(J, g["kat"]["J_linear"], rel_tol=g["kat"]["rtol"])       # 9.3e-8: the residual stated in the fixture's note

@@ -2,6 +2,8 @@
 (test/bulk_tendencies_tests.jl:840-1150) re-stated on the oracle (CPU) and, marked gpu, through the C ABI, plus
 random-state parity of the HIP kernel against the oracle."""
 import numpy as np
+
+LIN_AMPLIFY = 4      # operand-error amplification allowed for the implicit substeps (see the parity test below)
 import pytest
 
 from cmx import _abi
@@ -134,15 +136,26 @@ def test_gpu_parity_with_the_oracle(oracle, ft, dt, nsub):
     scale = sum(inst["scale"].values())
     near = np.abs(c64[1] - T_FREEZE) < (1e-3 if ft == "f32" else 1e-9)
     eps = {"f64": 2.2e-16, "f32": 1.2e-7}[ft]
-    worst = {}
+    worst, worst1 = {}, {}
     for k, q0 in zip(NAMES, c64[3:]):
         x, r = got._asdict()[k].cpu().numpy().astype(np.float64), ref[k]
         assert np.all(np.isfinite(x)), k
-        tol = parity.RTOL[ft] * np.abs(r) + 4 * parity.CTOL[ft] * scale + 8 * eps * (q0 + np.abs(r) * dt) / dt
+        # The average tendency is (q_new − q_old)/Δt after nsub implicit substeps: each substep solves a 4×4 system whose matrix and
+        # right-hand side both carry the operand errors of the source terms, so the allowance is LIN_AMPLIFY × the Instantaneous one
+        # (measured below: the worst error in units of the 1× tolerance is printed and recorded next to the plain-bound statistics).
+        floor = 8 * eps * (q0 + np.abs(r) * dt) / dt
+        tol1 = parity.RTOL[ft] * np.abs(r) + parity.CTOL[ft] * scale + floor
+        tol = parity.RTOL[ft] * np.abs(r) + LIN_AMPLIFY * parity.CTOL[ft] * scale + floor
         e = (np.abs(x - r) / np.maximum(tol, 1e-300))[~near]
         worst[k] = float(e.max())
+        worst1[k] = float((np.abs(x - r) / np.maximum(tol1, 1e-300))[~near].max())
         assert worst[k] <= 1.0, (k, worst)
-    print(f"\n[1M LinearizedAverage parity, error / tolerance] {ft} dt={dt} nsub={nsub}: {worst} (excluded near T_freeze: {int(near.sum())})")
+        ps = parity.plain_stats(x, r, scale, parity.RTOL[ft], parity.FLOOR[ft], parity.CEIL[ft], ~near, parity.WELLCOND[ft])
+        parity.REPORTS.append({"what": f"1M LinearizedAverage {ft} dt={dt} nsub={nsub}", "output": k, "ft": ft, "rtol": parity.RTOL[ft],
+                               "worst_normalised": worst[k] * parity.RTOL[ft], "worst_in_units_of_1x_tolerance": worst1[k], **ps})
+        assert ps["frac_within"] >= parity.MIN_FRAC_WITHIN[ft] and ps["worst_wellcond"] <= parity.RTOL[ft], (k, ps)
+    print(f"\n[1M LinearizedAverage parity, error / tolerance] {ft} dt={dt} nsub={nsub}: {worst}; in units of the Instantaneous (1x) tolerance: "
+          f"{worst1} (excluded near T_freeze: {int(near.sum())})")
 
 
 @pytest.mark.gpu
