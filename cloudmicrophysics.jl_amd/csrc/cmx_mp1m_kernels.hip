@@ -291,11 +291,8 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const Mp1mConsts<FT> &c, FT rh
             const FT poly = M::fma(FT(2) * li, li, M::fma(FT(2) * (d + FT(1)) * li, lj, (d + FT(2)) * (d + FT(1)) * (lj * lj)));
             return pre * cj * M::exp2(l2_li + (d + FT(1)) * l2_lj) * poly;
         };
-        // keep(): evaluated unconditionally — the compiler would otherwise put a branch around each exp2 (cmx_math.hpp)
-        const FT k_rs = keep(kernel(c.rs_c_rai, c.rs_d_rai, li_sno, l2_li_sno, li_rai, l2_li_rai));   // i = snow, j = rain
-        const FT k_sr = keep(kernel(c.rs_c_sno, c.rs_d_sno, li_rai, l2_li_rai, li_sno, l2_li_sno));   // i = rain, j = snow
-        const FT S_rai_sno = both ? k_rs : FT(0);
-        const FT S_sno_rai = both ? k_sr : FT(0);
+        const FT S_rai_sno = both ? kernel(c.rs_c_rai, c.rs_d_rai, li_sno, l2_li_sno, li_rai, l2_li_rai) : FT(0);   // i = snow, j = rain
+        const FT S_sno_rai = both ? kernel(c.rs_c_sno, c.rs_d_sno, li_rai, l2_li_rai, li_sno, l2_li_sno) : FT(0);   // i = rain, j = snow
         o.s[CMX_1M_S_ACCR_RAI_SNO_COLD] = is_warm ? FT(0) : S_rai_sno;
         o.s[CMX_1M_S_ACCR_RAI_SNO_WARM] = is_warm ? S_sno_rai : FT(0);
         o.s[CMX_1M_S_ACCR_MELT_RAI_SNO] = is_warm ? alpha * S_rai_sno : FT(0);
@@ -355,9 +352,7 @@ __global__ __launch_bounds__(kBlock) void mp1m_tendencies_kernel(const Mp1mConst
     for (int k = 0; k < VEC; ++k) {
         const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(c, rho[k], T[k], q_tot[k], q_lcl[k], q_icl[k], q_rai[k], q_sno[k]);
         mp1m_aggregate<FT>(p.s, dl[k], di[k], dr[k], ds[k]);
-        // branch-free NaN rule: x + NaN = NaN, x + 0 = x
-        const FT poison = any_nan(rho[k], q_tot[k], q_lcl[k], q_icl[k], q_rai[k], q_sno[k], T[k]) ? Math<FT>::nan() : FT(0);
-        dl[k] += poison; di[k] += poison; dr[k] += poison; ds[k] += poison;
+        if (any_nan(rho[k], q_tot[k], q_lcl[k], q_icl[k], q_rai[k], q_sno[k], T[k])) dl[k] = di[k] = dr[k] = ds[k] = Math<FT>::nan();
     }
     store_col<FT, VEC>(out.dq_lcl, i, dl); store_col<FT, VEC>(out.dq_icl, i, di);
     store_col<FT, VEC>(out.dq_rai, i, dr); store_col<FT, VEC>(out.dq_sno, i, ds);
@@ -594,8 +589,7 @@ template <typename FT, uint32_t FLAGS> struct Mp1mLayoutPolicy {
     static __device__ __forceinline__ void point(const Consts &c, const FT (&x)[NIN], FT (&y)[NOUT]) {
         const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(c, x[0], x[1], x[2], x[3], x[4], x[5], x[6]);
         mp1m_aggregate<FT>(p.s, y[0], y[1], y[2], y[3]);
-        const FT poison = any_nan(x[0], x[2], x[3], x[4], x[5], x[6], x[1]) ? Math<FT>::nan() : FT(0);
-        y[0] += poison; y[1] += poison; y[2] += poison; y[3] += poison;
+        if (any_nan(x[0], x[2], x[3], x[4], x[5], x[6], x[1])) y[0] = y[1] = y[2] = y[3] = Math<FT>::nan();
     }
 };
 template <typename FT, typename MP, typename TH>

@@ -3,7 +3,7 @@
 random-state parity of the HIP kernel against the oracle."""
 import numpy as np
 
-LIN_AMPLIFY = 4      # operand-error amplification allowed for the implicit substeps (see the parity test below)
+LIN_AMPLIFY = 1      # no extra allowance: measured worst error 0.21 × the Instantaneous tolerance (f32, Δt = 0.01 s); round 1 used 4
 import pytest
 
 from cmx import _abi
@@ -140,9 +140,9 @@ def test_gpu_parity_with_the_oracle(oracle, ft, dt, nsub):
     for k, q0 in zip(NAMES, c64[3:]):
         x, r = got._asdict()[k].cpu().numpy().astype(np.float64), ref[k]
         assert np.all(np.isfinite(x)), k
-        # The average tendency is (q_new − q_old)/Δt after nsub implicit substeps: each substep solves a 4×4 system whose matrix and
-        # right-hand side both carry the operand errors of the source terms, so the allowance is LIN_AMPLIFY × the Instantaneous one
-        # (measured below: the worst error in units of the 1× tolerance is printed and recorded next to the plain-bound statistics).
+        # The average tendency is (q_new − q_old)/Δt after nsub implicit substeps of a 4×4 system built from the source terms; the
+        # allowance is the Instantaneous one (LIN_AMPLIFY = 1) plus the rounding floor of the difference quotient.  The worst error in
+        # units of that tolerance is printed and recorded next to the plain-bound statistics.
         floor = 8 * eps * (q0 + np.abs(r) * dt) / dt
         tol1 = parity.RTOL[ft] * np.abs(r) + parity.CTOL[ft] * scale + floor
         tol = parity.RTOL[ft] * np.abs(r) + LIN_AMPLIFY * parity.CTOL[ft] * scale + floor
@@ -153,7 +153,11 @@ def test_gpu_parity_with_the_oracle(oracle, ft, dt, nsub):
         ps = parity.plain_stats(x, r, scale, parity.RTOL[ft], parity.FLOOR[ft], parity.CEIL[ft], ~near, parity.WELLCOND[ft])
         parity.REPORTS.append({"what": f"1M LinearizedAverage {ft} dt={dt} nsub={nsub}", "output": k, "ft": ft, "rtol": parity.RTOL[ft],
                                "worst_normalised": worst[k] * parity.RTOL[ft], "worst_in_units_of_1x_tolerance": worst1[k], **ps})
-        assert ps["frac_within"] >= parity.MIN_FRAC_WITHIN[ft] and ps["worst_wellcond"] <= parity.RTOL[ft], (k, ps)
+        # plain bound: asserted for Float64 as everywhere (≥ 0.999).  Float32: recorded only — the average tendency is (q_new − q_old)/Δt,
+        # whose rounding floor eps·q/Δt alone exceeds 1e-3·|tendency| for 1–8 % of the states at Δt = 0.01 s (measured: 0.989 for q_lcl,
+        # 0.918 for q_rai), which no Float32 evaluation of that difference can avoid; the operand-aware bound above is the test
+        if ft == "f64":
+            assert ps["frac_within"] >= 0.999 and ps["worst_wellcond"] <= parity.RTOL[ft], (k, ps)
     print(f"\n[1M LinearizedAverage parity, error / tolerance] {ft} dt={dt} nsub={nsub}: {worst}; in units of the Instantaneous (1x) tolerance: "
           f"{worst1} (excluded near T_freeze: {int(near.sum())})")
 
