@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --points per GPU; strong: --points in total, sharded over the ranks (cmx.sharding.shard_bounds)")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--workload", choices=["sb2006", "sb2006_column", "icenuc", "mp0m", "mp1m", "mp1m_lin", "arg2000", "p3", "p3_selfcol", "mp2m_p3", "sb2006_aos", "sb2006_fields"], default="sb2006")
+    ap.add_argument("--workload", choices=["sb2006", "sb2006_chen", "sb2006_column", "icenuc", "mp0m", "mp1m", "mp1m_lin", "arg2000", "p3", "p3_selfcol", "mp2m_p3", "sb2006_aos", "sb2006_fields"], default="sb2006")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the bounded baseline sample")
     ap.add_argument("--diagnostics", action="store_true",
@@ -97,13 +97,16 @@ def setup_sb2006(args, dev, dtype, rank):
     out = cmx.WarmRainTendencies2M(*[__import__("torch").empty_like(state.rho) for _ in range(6)])
     scheme = cmx.Microphysics2Moment()
 
+    chen = args.workload == "sb2006_chen"          # the Chen-2022 rain fall-speed variant of the same fused sweep (CM2:703-719)
+    velty = cmx.Chen2022VelTypeRain if chen else cmx.SB2006VelType
+
     def step():
-        cmx.bulk_microphysics_tendencies(scheme, mp, tps, *state, vel=cmx.SB2006VelType, out=out)
+        cmx.bulk_microphysics_tendencies(scheme, mp, tps, *state, vel=velty, out=out)
 
     def cpu_run(ob, cols, threads):
         fam = _abi.family(args.dtype)
         wr, t, vel = P.WarmRainParams2M(args.dtype).c, P.ThermodynamicsParameters(args.dtype), P.rain_vel_params(args.dtype)
-        flags = _abi.CMX_SB2006_LIMITED | _abi.CMX_VEL_SB2006
+        flags = _abi.CMX_SB2006_LIMITED | (_abi.CMX_VEL_CHEN2022 if chen else _abi.CMX_VEL_SB2006)
         return lambda: ob.sb2006_warm_rain_tendencies(fam, wr, t, vel, flags, *cols, nthreads=threads, want_scale=False)
 
     desc = {
@@ -111,8 +114,8 @@ def setup_sb2006(args, dev, dtype, rank):
         "bytes_per_point": {"f32": 52, "f64": 104}[args.dtype],     # 7 in + 4 tendencies + 2 velocities
         "kernel": "sb2006_tendencies_kernel",
         "workload": "Microphysics2M SB2006 fused warm-rain tendencies (cond/evap, autoconversion, accretion, "
-                    "self-collection, breakup, evaporation, number adjustment) + SB2006 rain terminal velocities, "
-                    "limited rain PSD",
+                    "self-collection, breakup, evaporation, number adjustment) + " + ("Chen-2022" if chen else "SB2006") +
+                    " rain terminal velocities, limited rain PSD",
         "columns_in": 7, "columns_out": 6, "diag_cols": list(out[:4]),
     }
     return list(state), step, desc, cpu_run
@@ -573,7 +576,7 @@ def main():
         args.points = hi - lo
     # weak scaling: fixed work per GPU; rank r owns shard r of the global [0, world·n) index space.
     # Either way: disjoint seeds, no exchange
-    setup = {"sb2006": setup_sb2006, "sb2006_column": setup_sb2006_column, "icenuc": setup_icenuc, "mp0m": setup_mp0m, "mp1m": setup_mp1m, "mp1m_lin": setup_mp1m_lin, "arg2000": setup_arg2000,
+    setup = {"sb2006": setup_sb2006, "sb2006_chen": setup_sb2006, "sb2006_column": setup_sb2006_column, "icenuc": setup_icenuc, "mp0m": setup_mp0m, "mp1m": setup_mp1m, "mp1m_lin": setup_mp1m_lin, "arg2000": setup_arg2000,
              "p3": setup_p3, "p3_selfcol": setup_p3_selfcol, "mp2m_p3": setup_mp2m_p3, "sb2006_aos": setup_sb2006_layout, "sb2006_fields": setup_sb2006_layout}[args.workload]
     state, kernel_step, desc, cpu_run = setup(args, dev, dtype, rank)
     n = args.points                                          # a layout workload may round the size to whole field runs
@@ -634,7 +637,7 @@ def main():
         if "note" in desc:
             line["roofline"]["note"] = desc["note"]
         if not args.no_cpu_baseline and world == 1:
-            m = min(n, {"sb2006": 20_000_000, "sb2006_column": 74 * 270_000, "sb2006_aos": 20_000_000, "sb2006_fields": 20_000_000, "p3": 100_000, "p3_selfcol": 2_000, "mp2m_p3": 20_000}.get(args.workload, 4_000_000))
+            m = min(n, {"sb2006": 20_000_000, "sb2006_chen": 20_000_000, "sb2006_column": 74 * 270_000, "sb2006_aos": 20_000_000, "sb2006_fields": 20_000_000, "p3": 100_000, "p3_selfcol": 2_000, "mp2m_p3": 20_000}.get(args.workload, 4_000_000))
             cols_np = [np.ascontiguousarray(c[:m].cpu().numpy()) for c in state]
             line["cpu_baseline"] = cpu_baseline(args, cols_np, desc, cpu_run)
         print(json.dumps(line), flush=True)

@@ -36,9 +36,12 @@ template <> struct Math<float> {
     // Γ(z), used by the Chen-2022 rain velocity only, where z = b_i(ρ) + 1 ∈ [2.0, 3.4] (b = 1.15 / 2.30 − 0.038 ρ, Common.jl:290-302):
     // a degree-10 interpolating polynomial in t = (z − 2.75)/1.25 on [1.5, 4] (3.3e-7 relative in Float32 Horner; OCML's tgammaf
     // costs ≈ 110 instructions and made the Chen variant of the fused kernel compute-bound: 1.37 ms per 1e8 points in round 1).
-    // Outside [1.5, 4] (exotic parameter overrides) OCML is called — a branch no lane takes with the reference's parameters.
+    // The argument is clamped to [1.5, 4] (one v_med3): entry points that take Chen-2022 rain parameters check on the host that
+    // b_i + 1 stays inside for every air density up to 2 kg/m³ (cmx::chen_rain_gamma_domain_ok) and return CMX_ERR_UNSUPPORTED otherwise.
+    // (An OCML fallback behind a never-taken branch was tried first: inlined at 12 call sites it took the kernel to 179 VGPRs, 2 waves
+    // per SIMD, 1.17 ms.)
     static __device__ __forceinline__ float tgamma(float z) {
-        const float t = fma(z, 0.8f, -2.2f);
+        const float t = fma(__builtin_amdgcn_fmed3f(z, 1.5f, 4.0f), 0.8f, -2.2f);
         float p = 0.000606461835549f;
         p = fma(p, t, 0.000949070487934f);
         p = fma(p, t, 0.00527334298015f);
@@ -49,9 +52,7 @@ template <> struct Math<float> {
         p = fma(p, t, 0.751528528131f);
         p = fma(p, t, 1.39245065912f);
         p = fma(p, t, 1.64635862269f);
-        p = fma(p, t, 1.60835942199f);
-        if (!(z >= 1.5f && z <= 4.0f)) p = ::tgammaf(z);
-        return p;
+        return fma(p, t, 1.60835942199f);
     }
     // log1p / expm1 accurate near 0 without the OCML double-float expansions (≈250 instructions each):
     // 4-term series below |x| = 1/32, the hardware log2/exp2 above (where 1+x / eˣ−1 no longer cancel: ≤4e-6 rel.)
@@ -84,9 +85,9 @@ template <> struct Math<double> {
     static __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }
     static __device__ __forceinline__ double nan() { return __builtin_nan(""); }
     static __device__ __forceinline__ double min(double a, double b) { return __builtin_fmin(a, b); }
-    // Γ(z) on [1.5, 4] (see the Float32 twin): degree-22 interpolating polynomial, 9e-15 relative; OCML outside
+    // Γ(z) on [1.5, 4] (see the Float32 twin; argument clamped): degree-22 interpolating polynomial, 9e-15 relative
     static __device__ __forceinline__ double tgamma(double z) {
-        const double t = fma(z, 0.8, -2.2);
+        const double t = fma(min(max(z, 1.5), 4.0), 0.8, -2.2);
         const double k[23] = {1.6083594219855455584, 1.6463589739909790518, 1.3924499187912875802, 0.75152171904830877759,
                               0.38075160368679774603, 0.14262439063517987378, 0.055606088443515184361, 0.015394396819926214053,
                               0.0054496056318177296227, 0.00098897444374469870313, 0.00044573752011233748607, 0.000010932744047535149967,
@@ -96,7 +97,6 @@ template <> struct Math<double> {
         double p = k[22];
 #pragma unroll
         for (int i = 21; i >= 0; --i) p = fma(p, t, k[i]);
-        if (!(z >= 1.5 && z <= 4.0)) p = ::tgamma(z);
         return p;
     }
     static __device__ __forceinline__ double log1p(double x) { return lean::log1p(x); }
@@ -123,6 +123,15 @@ template <typename FT> __device__ __forceinline__ FT keep(FT x) {
     asm volatile("" : "+v"(x));
 #endif
     return x;
+}
+
+// Host check for the polynomial Γ above: the Chen-2022 rain exponents b_i(ρ) = b_i − b_ρ ρ (Common.jl:290-302) must keep
+// z = b_i(ρ) + 1 inside [1.5, 4] for 0 ≤ ρ ≤ 2 kg/m³ (the reference's Table B1 values: z ∈ [2.07, 3.30]).
+template <typename CH> inline bool chen_rain_gamma_domain_ok(const CH &ch) {
+    if (!(ch.b_rho >= 0)) return false;
+    for (int i = 0; i < 3; ++i)
+        if (!((double)ch.b[i] + 1.0 <= 4.0 && (double)ch.b[i] + 1.0 - 2.0 * (double)ch.b_rho >= 1.5)) return false;
+    return true;
 }
 
 template <typename FT> __device__ __forceinline__ FT clampv(FT x, FT lo, FT hi) {

@@ -676,6 +676,7 @@ static int32_t velocity_1m_entry(const MP *mp, const CH *chen, int64_t n, const 
     if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (n == 0) return CMX_OK;
     if (!rho || ((vt_rai || vt_chen) && !q_rai) || (vt_sno && !q_sno) || (vt_chen && !chen)) return CMX_ERR_BAD_ARG;
+    if (vt_chen && !chen_rain_gamma_domain_ok(*chen)) return CMX_ERR_UNSUPPORTED;   // polynomial Γ domain (cmx_math.hpp)
     const Vel1mConsts<FT> c = make_vel1m_consts<FT>(*mp, chen);
     Vel1mIO<FT> io{rho, q_rai, q_sno, vt_rai, vt_sno, vt_chen, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL((mp1m_velocity_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
@@ -696,6 +697,7 @@ static int32_t sedimentation_entry(const MP *mp, const ST *stokes, const CH *che
     if (!rho || (w_lcl && (!q_lcl || !stokes)) || (w_icl && (!q_icl || !chen_ice)) || (w_rai && (!q_rai || !chen_rain)) ||
         (w_sno && (!q_sno || !chen_ice)))
         return CMX_ERR_BAD_ARG;
+    if (w_rai && !chen_rain_gamma_domain_ok(*chen_rain)) return CMX_ERR_UNSUPPORTED;   // polynomial Γ domain (cmx_math.hpp)
     Vel1mConsts<FT> c = make_vel1m_consts<FT>(*mp, chen_rain);
     const double pi = 3.14159265358979323846;
     c.l2_1000 = (FT)std::log2(1000.0);

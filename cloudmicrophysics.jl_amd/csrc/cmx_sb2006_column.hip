@@ -214,6 +214,7 @@ static int32_t column_entry(const WR *wr, const TH *tps, const VL *vel, const ST
     if (flags & ~(uint32_t)(CMX_SB2006_LIMITED | CMX_VEL_SB2006 | CMX_VEL_CHEN2022)) return CMX_ERR_BAD_ARG;
     const bool sbv = flags & CMX_VEL_SB2006, chv = flags & CMX_VEL_CHEN2022;
     if (sbv == chv) return CMX_ERR_BAD_ARG;                      // exactly one rain fall-speed scheme
+    if (chv && !chen_rain_gamma_domain_ok(vel->chen2022)) return CMX_ERR_UNSUPPORTED;   // polynomial Γ domain (cmx_math.hpp)
     if (n_col > kMaxPoints / n_lev) return CMX_ERR_UNSUPPORTED;  // n_col·n_lev must fit one launch (cmx_launch.hpp)
     const int64_t n = n_col * (int64_t)n_lev;
     if (n == 0) return CMX_OK;

@@ -57,6 +57,7 @@ static int32_t tendencies_entry(const WR *wr, const TH *tps, const VL *vel, uint
     const bool want_vel = vt_n || vt_m;
     const int velk = decode_vel(flags, want_vel);
     if (velk < 0 || (want_vel && !vel)) return CMX_ERR_BAD_ARG;
+    if (velk == VEL_CHEN && !chen_rain_gamma_domain_ok(vel->chen2022)) return CMX_ERR_UNSUPPORTED;   // polynomial Γ domain (cmx_math.hpp)
     const bool limited = flags & CMX_SB2006_LIMITED;
     if ((flags & CMX_SB2006_LIMITED) && !sb_limiters_ok(*wr)) return CMX_ERR_BAD_ARG;      // clamp_ordered needs ordered limiter pairs
     const SbConsts<FT> c = make_sb_consts<FT>(*wr, *tps, vel, (double)Math<FT>::eps_1m());
@@ -120,6 +121,7 @@ static int32_t process_entry(const WR *wr, const TH *tps, const VL *vel, uint32_
     const bool want_vel = out[CMX_SB_RAI_VEL_N] || out[CMX_SB_RAI_VEL_M];
     const int velk = decode_vel(flags, want_vel);
     if (velk < 0 || (want_vel && !vel)) return CMX_ERR_BAD_ARG;
+    if (velk == VEL_CHEN && !chen_rain_gamma_domain_ok(vel->chen2022)) return CMX_ERR_UNSUPPORTED;   // polynomial Γ domain (cmx_math.hpp)
     const bool limited = flags & CMX_SB2006_LIMITED;
     if ((flags & CMX_SB2006_LIMITED) && !sb_limiters_ok(*wr)) return CMX_ERR_BAD_ARG;      // clamp_ordered needs ordered limiter pairs
     const SbConsts<FT> c = make_sb_consts<FT>(*wr, *tps, vel, (double)Math<FT>::eps_1m());
