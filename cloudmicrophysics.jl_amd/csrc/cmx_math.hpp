@@ -138,6 +138,11 @@ template <typename FT> __device__ __forceinline__ FT clampv(FT x, FT lo, FT hi) 
     // Base.clamp: x < lo ? lo : (x > hi ? hi : x)
     return Math<FT>::min(Math<FT>::max(x, lo), hi);
 }
+// clamp_to_nonneg of a LOADED value: max(0, x) through v_med3_f32(x, 0, +Inf).  A plain fmax on a value that comes straight from
+// memory costs two instructions in IEEE mode (the compiler must quiet a possible signalling NaN first: v_max x, x); the median does
+// not need that, returns 0 for a NaN like v_max does (the NaN rule is applied separately), and its result counts as canonical.
+__device__ __forceinline__ float max0(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+__device__ __forceinline__ double max0(double x) { return Math<double>::max(0.0, x); }
 // the same for lo ≤ hi as ONE instruction (v_med3_f32: the median of three is the clamp); Float64 has no med3
 __device__ __forceinline__ float clamp_ordered(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 __device__ __forceinline__ double clamp_ordered(double x, double lo, double hi) { return clampv(x, lo, hi); }

@@ -190,8 +190,8 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const Mp1mConsts<FT> &c, FT rh
     const uint32_t fl = FLAGS == kRuntimeFlags ? c.flags : FLAGS;
     const FT eps = c.eps_1m;   // ϵ_numerics(FT) = cbrt(floatmin(FT))  Utilities.jl:318
     // clamp_to_nonneg — BMT:147-152 (T is not clamped)
-    rho = M::max(FT(0), rho); q_tot = M::max(FT(0), q_tot); q_lcl = M::max(FT(0), q_lcl);
-    q_icl = M::max(FT(0), q_icl); q_rai = M::max(FT(0), q_rai); q_sno = M::max(FT(0), q_sno);
+    rho = max0(rho); q_tot = max0(q_tot); q_lcl = max0(q_lcl);
+    q_icl = max0(q_icl); q_rai = max0(q_rai); q_sno = max0(q_sno);
     const FT inv_rho = M::rcp(rho), inv_T = M::rcp(T);
     const bool has_lcl = q_lcl > eps, has_icl = q_icl > eps, has_rai = q_rai > eps, has_sno = q_sno > eps;
 

@@ -163,13 +163,18 @@ template <typename FT> struct P3ColIO {
     FT *out[8];
 };
 
+#ifndef CMX_COL_WAVES
+#define CMX_COL_WAVES 3      // min waves per SIMD the register allocator must leave room for: 168 VGPRs + 544 B scratch at 3 waves (what the
+                             // 43 KB of LDS per workgroup admit) beat 256 VGPRs + 224 B at 2 (2M + P3, Float64: 29.9 → 28.0 ms per 1e6 states,
+                             // same-box A/B; Float32 unchanged; 1 wave: 46 ms)
+#endif
 // LDS per group, in FT units: quadrature copy is per block
 template <typename FT> struct ColLds {
     static __device__ __forceinline__ int per_group(int n) { return 6 * n + 72; }
 };
 
 template <typename FT, typename QUAD, bool ASPECT, bool FUSED, int GROUP>
-__global__ __launch_bounds__(kBlock, 2) void p3_collision_kernel(const P3Consts<FT> c, const P3VelConsts<FT> v, const P3ColConsts<FT> k,
+__global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(const P3Consts<FT> c, const P3VelConsts<FT> v, const P3ColConsts<FT> k,
                                                              const QUAD quad, const P3ColIO<FT> io, const int64_t n) {
     Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using P = PM<FT>;

@@ -65,8 +65,8 @@ __device__ __forceinline__ SedFlux<FT> sed_fluxes_of_point(const SbConsts<FT> &c
                                                           FT q_rai, FT n_rai) {
     using M = Math<FT>;
     const FT eps = M::eps();
-    const FT r_ = M::max(FT(0), rho), ql = M::max(FT(0), q_lcl), nl = M::max(FT(0), n_lcl);
-    const FT qr = M::max(FT(0), q_rai), nr = M::max(FT(0), n_rai);
+    const FT r_ = max0(rho), ql = max0(q_lcl), nl = max0(n_lcl);
+    const FT qr = max0(q_rai), nr = max0(n_rai);
     const FT rs_rho = M::rsqrt(r_);
     const FT N_rai = r_ * nr;
     const FT L_rai = r_ * M::max(qr, eps);
@@ -129,8 +129,8 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(sizeof(FT) =
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             // clamp_to_nonneg — BMT:828-837 (T is not clamped)
-            const FT r_ = M::max(FT(0), rho[k]), qt = M::max(FT(0), q_tot[k]), ql = M::max(FT(0), q_lcl[k]);
-            const FT qr = M::max(FT(0), q_rai[k]), nl = M::max(FT(0), n_lcl[k]), nr = M::max(FT(0), n_rai[k]);
+            const FT r_ = max0(rho[k]), qt = max0(q_tot[k]), ql = max0(q_lcl[k]);
+            const FT qr = max0(q_rai[k]), nl = max0(n_lcl[k]), nr = max0(n_rai[k]);
             const bool poisoned = any_nan(rho[k], q_tot[k], q_lcl[k], n_lcl[k], q_rai[k], n_rai[k], T[k]);
             const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL>(c, r_, T[k], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
             F[k] = sed_fluxes<FT, CLOUD>(cv, r_, ql, nl, qr, nr, p.vt_n, p.vt_m);

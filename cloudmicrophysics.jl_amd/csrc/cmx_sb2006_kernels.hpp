@@ -59,12 +59,12 @@ __global__ __launch_bounds__(BS) void sb2006_tendencies_kernel(const SbConsts<FT
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             // clamp_to_nonneg — BMT:828-837 (T is not clamped)
-            const FT r_ = M::max(FT(0), rho[t][k]);
-            const FT qt = M::max(FT(0), q_tot[t][k]);
-            const FT ql = M::max(FT(0), q_lcl[t][k]);
-            const FT qr = M::max(FT(0), q_rai[t][k]);
-            const FT nl = M::max(FT(0), n_lcl[t][k]);
-            const FT nr = M::max(FT(0), n_rai[t][k]);
+            const FT r_ = max0(rho[t][k]);
+            const FT qt = max0(q_tot[t][k]);
+            const FT ql = max0(q_lcl[t][k]);
+            const FT qr = max0(q_rai[t][k]);
+            const FT nl = max0(n_lcl[t][k]);
+            const FT nr = max0(n_rai[t][k]);
             // a NaN in any input column poisons every output of the point (cmx_math.hpp any_nan)
             const bool poisoned = any_nan(rho[t][k], q_tot[t][k], q_lcl[t][k], n_lcl[t][k], q_rai[t][k], n_rai[t][k], T[t][k]);
             // N = ρ n — BMT:718-719
@@ -102,8 +102,8 @@ template <typename FT, bool LIMITED> struct Sb2006LayoutPolicy {
     using Consts = SbConsts<FT>;
     static __device__ __forceinline__ void point(const Consts &c, const FT (&x)[NIN], FT (&y)[NOUT]) {
         using M = Math<FT>;
-        const FT r_ = M::max(FT(0), x[0]), qt = M::max(FT(0), x[2]), ql = M::max(FT(0), x[3]);
-        const FT nl = M::max(FT(0), x[4]), qr = M::max(FT(0), x[5]), nr = M::max(FT(0), x[6]);
+        const FT r_ = max0(x[0]), qt = max0(x[2]), ql = max0(x[3]);
+        const FT nl = max0(x[4]), qr = max0(x[5]), nr = max0(x[6]);
         const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL_NONE>(c, r_, x[1], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
         y[0] = (p.cond + p.au_dq_lcl) + p.ac_dq_lcl;
         y[1] = M::fma(p.lsc_plus_au + p.ac_dN_lcl, p.inv_rho, p.na_lcl);

@@ -182,6 +182,7 @@ int main(int argc, char **argv) {
     const bool separate = argc > 3 && std::string(argv[3]) == "separate";      // 13 hipMallocs (what a caching allocator does) instead of one slab
     const bool random = argc > 4 && std::string(argv[4]) == "random";          // full-entropy data instead of a 1024-periodic ramp
     const bool quick = argc > 5 && std::string(argv[5]) == "quick";            // only the headline rows
+    const bool writes = argc > 5 && std::string(argv[5]) == "writes";          // the write-path matrix (box calibration)
     g_n = n;
     const int64_t nvec = n / 4;
     const size_t colbytes = ((size_t)n * 4 + (2u << 20) - 1) / (2u << 20) * (2u << 20);   // 2-MiB granules, like a caching allocator
@@ -213,6 +214,18 @@ int main(int argc, char **argv) {
         const int g = (int)((nvec + BS - 1) / BS);                                                                            \
         std::snprintf(label, sizeof label, "np BS=%d ld[%s] st[%s] work=%d%s %s", BS, POLNAME[LP], POLNAME[SP], WORK, PRIO ? " prio" : "", text); \
         report(label, time_ms([&] { hipLaunchKernelGGL((np13<BS, LP, SP, WORK, PRIO, NR, NW>), dim3(g), dim3(BS), 0, 0, in, out, nvec); }, reps), bpp); \
+    }
+    if (writes) {   // what does THIS box's write path deliver, and does any shape or policy change it?
+        RUN_NP(128, P_NT, P_NT, 0, false, 7, 0, 28.0, "read-only 7")
+        RUN_NP(128, P_NT, P_NT, 0, false, 0, 1, 4.0, "write-only 1") RUN_NP(128, P_NT, P_NT, 0, false, 0, 2, 8.0, "write-only 2")
+        RUN_NP(128, P_NT, P_NT, 0, false, 0, 3, 12.0, "write-only 3") RUN_NP(128, P_NT, P_NT, 0, false, 0, 6, 24.0, "write-only 6")
+        RUN_NP(128, P_NT, P_PLAIN, 0, false, 0, 6, 24.0, "write-only 6") RUN_NP(128, P_NT, P_SC1, 0, false, 0, 6, 24.0, "write-only 6")
+        RUN_NP(128, P_NT, P_SC0SC1, 0, false, 0, 6, 24.0, "write-only 6") RUN_NP(128, P_NT, P_SC1NT, 0, false, 0, 6, 24.0, "write-only 6")
+        RUN_NP(64, P_NT, P_NT, 0, false, 0, 6, 24.0, "write-only 6") RUN_NP(256, P_NT, P_NT, 0, false, 0, 6, 24.0, "write-only 6")
+        RUN_NP(1024, P_NT, P_NT, 0, false, 0, 6, 24.0, "write-only 6")
+        RUN_NP(128, P_NT, P_NT, 0, false, 1, 1, 8.0, "copy 1r/1w") RUN_NP(128, P_NT, P_NT, 0, false, 7, 6, 52.0, "7r/6w")
+        RUN_NP(128, P_NT, P_NT, 256, false, 7, 6, 52.0, "7r/6w") RUN_NP(128, P_NT, P_SC1NT, 256, false, 7, 6, 52.0, "7r/6w")
+        return 0;
     }
     if (quick) {
         for (int rep = 0; rep < 3; ++rep) {
