@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --points per GPU; strong: --points in total, sharded over the ranks (cmx.sharding.shard_bounds)")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--workload", choices=["sb2006", "sb2006_chen", "sb2006_column", "icenuc", "mp0m", "mp1m", "mp1m_lin", "arg2000", "p3", "p3_selfcol", "mp2m_p3", "sb2006_aos", "sb2006_fields"], default="sb2006")
+    ap.add_argument("--workload", choices=["sb2006", "sb2006_chen", "sb2006_column", "icenuc", "mp0m", "mp1m", "mp1m_lin", "arg2000", "p3", "p3_fused", "p3_selfcol", "mp2m_p3", "sb2006_aos", "sb2006_fields"], default="sb2006")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the bounded baseline sample")
     ap.add_argument("--diagnostics", action="store_true",
@@ -378,7 +378,12 @@ def setup_p3(args, dev, dtype, rank):
     quad = P.ChebyshevGauss(args.dtype, 100)          # the reference's default rule (src/P3_terminal_velocity.jl:74)
     holder = {}
 
+    fused = args.workload == "p3_fused"       # the same pass as one launch (cmx_p3_shape_terminal_velocities_*)
+
     def step():   # (ρq_ice, ρn_ice, ρq_rim, ρb_rim, ρₐ) → (logλ, D_m, v_n, v_m)
+        if fused:
+            holder["out"] = cmx.p3_shape_and_terminal_velocities(p, vel, rho_a, *st, quad=quad)
+            return
         shp = cmx.p3_shape(p, *st)
         holder["out"] = (shp, cmx.p3_terminal_velocities(p, vel, rho_a, *st, shp.log_lambda, quad=quad))
 
@@ -394,7 +399,7 @@ def setup_p3(args, dev, dtype, rank):
     desc = {
         "metric": "grid-points/sec P3 shape solve + integral properties (log-lambda, D_m, v_n, v_m)",
         "bytes_per_point": {"f32": 36, "f64": 72}[args.dtype],      # 5 in + 4 out
-        "kernel": "p3_shape_kernel + p3_velocity_kernel",
+        "kernel": "p3_velocity_kernel<SOLVE> (one launch)" if fused else "p3_shape_kernel + p3_velocity_kernel",
         "workload": "P3Scheme state_from_prognostic + get_distribution_logλ (Brent root, incomplete-gamma moments) + D_m + "
                     "number/mass-weighted Chen-2022 fall speeds (ChebyshevGauss(100) x 4 segments, gamma_inc_inv bounds)",
         "columns_in": 5, "columns_out": 4, "diag_cols": [],
@@ -577,7 +582,7 @@ def main():
     # weak scaling: fixed work per GPU; rank r owns shard r of the global [0, world·n) index space.
     # Either way: disjoint seeds, no exchange
     setup = {"sb2006": setup_sb2006, "sb2006_chen": setup_sb2006, "sb2006_column": setup_sb2006_column, "icenuc": setup_icenuc, "mp0m": setup_mp0m, "mp1m": setup_mp1m, "mp1m_lin": setup_mp1m_lin, "arg2000": setup_arg2000,
-             "p3": setup_p3, "p3_selfcol": setup_p3_selfcol, "mp2m_p3": setup_mp2m_p3, "sb2006_aos": setup_sb2006_layout, "sb2006_fields": setup_sb2006_layout}[args.workload]
+             "p3": setup_p3, "p3_fused": setup_p3, "p3_selfcol": setup_p3_selfcol, "mp2m_p3": setup_mp2m_p3, "sb2006_aos": setup_sb2006_layout, "sb2006_fields": setup_sb2006_layout}[args.workload]
     state, kernel_step, desc, cpu_run = setup(args, dev, dtype, rank)
     n = args.points                                          # a layout workload may round the size to whole field runs
 
@@ -637,7 +642,7 @@ def main():
         if "note" in desc:
             line["roofline"]["note"] = desc["note"]
         if not args.no_cpu_baseline and world == 1:
-            m = min(n, {"sb2006": 20_000_000, "sb2006_chen": 20_000_000, "sb2006_column": 74 * 270_000, "sb2006_aos": 20_000_000, "sb2006_fields": 20_000_000, "p3": 100_000, "p3_selfcol": 2_000, "mp2m_p3": 20_000}.get(args.workload, 4_000_000))
+            m = min(n, {"sb2006": 20_000_000, "sb2006_chen": 20_000_000, "sb2006_column": 74 * 270_000, "sb2006_aos": 20_000_000, "sb2006_fields": 20_000_000, "p3": 100_000, "p3_fused": 100_000, "p3_selfcol": 2_000, "mp2m_p3": 20_000}.get(args.workload, 4_000_000))
             cols_np = [np.ascontiguousarray(c[:m].cpu().numpy()) for c in state]
             line["cpu_baseline"] = cpu_baseline(args, cols_np, desc, cpu_run)
         print(json.dumps(line), flush=True)

@@ -29,7 +29,7 @@ from .microphysics0m import (Microphysics0Moment, bulk_microphysics_tendencies_0
 from .aerosol import (ActivationResult, AerosolDistribution, ModeColumns, Mode_B, Mode_kappa, aerosol_activation,  # noqa: F401
                       aerosol_activation_columns)
 
-from .p3 import (P3Melt, P3Shape, P3Velocities, p3_het_ice_nucleation, p3_ice_melt, p3_ice_self_collection, p3_liquid_ice_collisions,  # noqa: F401
+from .p3 import (P3Melt, P3Shape, P3ShapeVelocities, P3Velocities, p3_shape_and_terminal_velocities, p3_het_ice_nucleation, p3_ice_melt, p3_ice_self_collection, p3_liquid_ice_collisions,  # noqa: F401
                  p3_shape, p3_terminal_velocities)
 
 __version__ = "0.1.0"

@@ -100,6 +100,10 @@ def _declare(lib):
         f.restype = i32
         f.argtypes = [C.POINTER(fam.p3_params), C.POINTER(fam.chen2022_ice_vel), C.POINTER(fam.quadrature), u32, fam.ft, i64] \
             + [vp] * 8 + [vp]
+        f = getattr(lib, f"cmx_p3_shape_terminal_velocities_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.p3_params), C.POINTER(fam.chen2022_ice_vel), C.POINTER(fam.quadrature), u32, i32, fam.ft, i64] \
+            + [vp] * 10 + [vp]
         f = getattr(lib, f"cmx_p3_ice_melt_{s}")
         f.restype = i32
         f.argtypes = [C.POINTER(fam.p3_params), C.POINTER(fam.chen2022_ice_vel), C.POINTER(fam.air_properties), C.POINTER(fam.thermo),

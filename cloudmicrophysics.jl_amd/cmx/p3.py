@@ -93,6 +93,40 @@ def p3_terminal_velocities(params: ParametersP3, velocity_params, rho_air, rho_q
     return P3Velocities(outs["v_n"], outs["v_m"])
 
 
+P3ShapeVelocities = namedtuple("P3ShapeVelocities", ["log_lambda", "D_m", "v_n", "v_m"])
+
+
+def p3_shape_and_terminal_velocities(params: ParametersP3, velocity_params, rho_air, rho_q_ice, rho_n_ice, x3, x4, *, log_lambda_guess=None,
+                                     from_state=False, aspect_ratio=True, brent_iters=0, p=1e-6, quad=None, stream=None) -> P3ShapeVelocities:
+    """`p3_shape` (log λ, D_m) followed by `p3_terminal_velocities` as ONE launch (`cmx_p3_shape_terminal_velocities_*`) — BASELINE
+    config 5: `P3.get_distribution_logλ(state)`, `P3.D_m`, `P3.ice_terminal_velocity_number_weighted / _mass_weighted` on the same
+    columns (src/P3_size_distribution.jl:284-320, :56-61, src/P3_terminal_velocity.jl:72-137).  Bit-identical to the two calls."""
+    if not isinstance(params, ParametersP3):
+        raise TypeError("params must be ParametersP3")
+    cols = (rho_q_ice, rho_n_ice, x3, x4, rho_air)
+    ref = _check_cols(cols, ("rho_q_ice", "rho_n_ice", "x3", "x4", "rho_air"))
+    fam = _fam_of(ref)
+    if fam is not params.fam or not isinstance(velocity_params, fam.chen2022_ice_vel):
+        raise TypeError("parameter float type does not match the state columns")
+    guess = log_lambda_guess
+    if guess is not None:
+        _check_cols([ref, guess], ["rho_q_ice", "log_lambda_guess"])
+    if quad is None:
+        from .parameters import ChebyshevGauss
+        quad = ChebyshevGauss(fam.sfx, 100)
+    if not isinstance(quad, fam.quadrature):
+        raise TypeError("quadrature float type does not match the state columns")
+    out = P3ShapeVelocities(*[torch.empty_like(ref) for _ in range(4)])
+    flags = params.flags | (_abi.CMX_P3_INPUT_IS_STATE if from_state else 0) | (0 if aspect_ratio else _abi.CMX_P3_NO_ASPECT_RATIO)
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_p3_shape_terminal_velocities_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(params.c), C.byref(velocity_params), C.byref(quad), flags, int(brent_iters), p, ref.numel(), *[_ptr(t) for t in cols],
+                _ptr(guess), *[_ptr(t) for t in out], C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return out
+
+
 P3Melt = namedtuple("P3Melt", ["dNdt", "dLdt"])
 
 

@@ -25,17 +25,13 @@
 namespace cmx {
 
 
+// get_distribution_logλ :284-320 for one state (shared by the shape kernel and the fused shape → fall-speed kernel).  `guess` may be
+// nullptr (no warm start).  All residual evaluations (the two bracket ends, the optional warm-start guess of _narrow_bracket :336-353,
+// the Brent iterations) go through ONE inlined call site: steps −3, −2, −1, 0 … — three separate inlined copies of the residual
+// doubled the VGPR count (255, occupancy 1).
 template <typename FT>
-__global__ __launch_bounds__(kBlock) void p3_shape_kernel(const P3Consts<FT> c, const P3IO<FT> io, const int64_t n) {
-    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
+__device__ __forceinline__ FT p3_solve_loglam(const P3Consts<FT> &c, const P3Point<FT> &s, const FT *__restrict__ guess, const int64_t i) {
     using P = PM<FT>;
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    P3Point<FT> s;
-    p3_make_point<FT>(c, io.rho_q[i], io.rho_n[i], io.x3[i], io.x4[i], s);
-    // get_distribution_logλ :284-320.  All residual evaluations (the two bracket ends, the optional warm-start guess
-    // of _narrow_bracket :336-353, the Brent iterations) go through ONE inlined call site: steps −3, −2, −1, 0 … —
-    // three separate inlined copies of the residual doubled the VGPR count (255, occupancy 1).
     FT loglam;
     if (s.rho_n < P::eps() || s.rho_q < P::eps()) {
         loglam = -INFINITY;
@@ -43,7 +39,7 @@ __global__ __launch_bounds__(kBlock) void p3_shape_kernel(const P3Consts<FT> c, 
         const FT target = P::log(s.rho_q) - P::log(s.rho_n);
         FT a = FT(2), b = FT(17), fa = FT(0), fb = FT(0), cc = FT(0), fc = FT(0), d = FT(0);
         bool mflag = true, active = true, guess_valid = false;
-        const int first = io.guess ? -3 : -2;          // wave-uniform
+        const int first = guess ? -3 : -2;          // wave-uniform
         for (int it = first; it < c.brent_iters; ++it) {
             // which abscissa this step evaluates
             FT sx;
@@ -51,7 +47,7 @@ __global__ __launch_bounds__(kBlock) void p3_shape_kernel(const P3Consts<FT> c, 
             if (step == -3) sx = a;
             else if (step == -2) sx = b;
             else if (step == -1) {
-                const FT pg = io.guess[i];
+                const FT pg = guess[i];
                 guess_valid = isfinite(pg) && (a < pg && pg < b);
                 sx = guess_valid ? pg : a;
             } else {
@@ -93,13 +89,25 @@ __global__ __launch_bounds__(kBlock) void p3_shape_kernel(const P3Consts<FT> c, 
                 if (P::abs(fa) < P::abs(fb)) { FT t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
             }
             // entering the Brent phase: order the bracket so that b is the better end, c = a
-            if (step < 0 && (io.guess ? step == -1 : step == -2) && active) {
+            if (step < 0 && (guess ? step == -1 : step == -2) && active) {
                 if (P::abs(fa) < P::abs(fb)) { FT t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
                 cc = a; fc = fa; d = FT(0); mflag = true;
             }
         }
         loglam = b;
     }
+    return loglam;
+}
+
+template <typename FT>
+__global__ __launch_bounds__(kBlock) void p3_shape_kernel(const P3Consts<FT> c, const P3IO<FT> io, const int64_t n) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
+    using P = PM<FT>;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    P3Point<FT> s;
+    p3_make_point<FT>(c, io.rho_q[i], io.rho_n[i], io.x3[i], io.x4[i], s);
+    FT loglam = p3_solve_loglam<FT>(c, s, io.guess, i);
     // NaN in → NaN out (cmx_math.hpp any_nan): the gates and the regularised ratios above would map a NaN input to "no ice"
     if (any_nan(io.rho_q[i], io.rho_n[i], io.x3[i], io.x4[i])) loglam = s.F_rim = s.rho_rim = Math<FT>::nan();
     if (io.F_rim) io.F_rim[i] = s.F_rim;
@@ -133,9 +141,12 @@ static int32_t p3_entry(const PR *params, uint32_t flags, int32_t brent_iters, i
 template <typename FT, typename QUAD> struct P3VelIO {
     const FT *rho_q, *rho_n, *x3, *x4, *rho_a, *loglam; FT *v_n, *v_m;
     const FT *T; FT *dNdt, *dLdt;     // MELT mode
+    const FT *guess; FT *loglam_out, *D_m_out;   // SOLVE mode (fused shape → fall speeds): optional warm start, optional logλ / D_m outputs
 };
 
-template <typename FT, typename QUAD, bool ASPECT, bool MELT = false>
+// SOLVE: the shape solve (get_distribution_logλ) runs in this launch instead of reading a log λ column — one launch for the whole
+// BASELINE config-5 pass: no second read of the state, no log λ round trip through HBM (cmx_p3_shape_terminal_velocities_*).
+template <typename FT, typename QUAD, bool ASPECT, bool MELT = false, bool SOLVE = false>
 __global__ __launch_bounds__(kBlock) void p3_velocity_kernel(const P3Consts<FT> c, const P3VelConsts<FT> v, const QUAD quad,
                                                             const P3VelIO<FT, QUAD> io, const int64_t n) {
     Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
@@ -145,8 +156,20 @@ __global__ __launch_bounds__(kBlock) void p3_velocity_kernel(const P3Consts<FT> 
     P3Point<FT> s;
     p3_make_point<FT>(c, io.rho_q[i], io.rho_n[i], io.x3[i], io.x4[i], s);
     FT vn = FT(0), vm = FT(0);
+    FT loglam_in = FT(0);
+    if constexpr (SOLVE) {
+        loglam_in = p3_solve_loglam<FT>(c, s, io.guess, i);
+        // NaN in → NaN out, as in p3_shape_kernel
+        if (any_nan(io.rho_q[i], io.rho_n[i], io.x3[i], io.x4[i])) loglam_in = s.F_rim = s.rho_rim = Math<FT>::nan();
+        if (io.loglam_out) io.loglam_out[i] = loglam_in;
+        if (io.D_m_out) {
+            const FT mu = p3_mu<FT>(c, loglam_in);
+            const FT logN0 = P::log(s.rho_n) - (-(mu + FT(1)) * loglam_in + P::lgamma(mu + FT(1)));   // get_logN₀ :233-237
+            io.D_m_out[i] = P::exp(logN0 + p3_logmass_moment<FT>(c, s, mu, loglam_in, FT(1))) / s.rho_q;   // D_m :56-61
+        }
+    }
     if (!(s.rho_n < P::eps() || s.rho_q < P::eps())) {
-        const FT loglam = io.loglam[i], lam = P::exp(loglam), mu = p3_mu<FT>(c, loglam);
+        const FT loglam = SOLVE ? loglam_in : io.loglam[i], lam = P::exp(loglam), mu = p3_mu<FT>(c, loglam);
         const FT logN0 = P::log(s.rho_n) - (-(mu + FT(1)) * loglam + P::lgamma(mu + FT(1)));
         // Chen-2022 coefficients at this air density — Common.jl:304-350
         const FT rho_a = Math<FT>::max(io.rho_a[i], FT(0)), lra = P::log(rho_a);
@@ -245,13 +268,38 @@ static int32_t p3_velocity_entry(const PR *params, const VR *vel, const QUAD *qu
     P3Consts<FT> c = make_p3_consts<FT>(*params, flags);
     c.brent_iters = 0;
     const P3VelConsts<FT> v = make_p3_vel_consts<FT>(*params, *vel, (double)p);
-    P3VelIO<FT, QUAD> io{rho_q, rho_n, x3, x4, rho_a, loglam, v_n, v_m, nullptr, nullptr, nullptr};
+    P3VelIO<FT, QUAD> io{rho_q, rho_n, x3, x4, rho_a, loglam, v_n, v_m, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (flags & CMX_P3_NO_ASPECT_RATIO)
         hipLaunchKernelGGL((p3_velocity_kernel<FT, QUAD, false>), grid, block, 0, st, c, v, *quad, io, n);
     else
         hipLaunchKernelGGL((p3_velocity_kernel<FT, QUAD, true>), grid, block, 0, st, c, v, *quad, io, n);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+
+// cmx_p3_shape_terminal_velocities_*: shape solve + D_m + number- / mass-weighted fall speeds in ONE launch (BASELINE config 5)
+template <typename FT, typename PR, typename VR, typename QUAD>
+static int32_t p3_shape_velocity_entry(const PR *params, const VR *vel, const QUAD *quad, uint32_t flags, int32_t brent_iters, FT p, int64_t n,
+                                       const FT *rho_q, const FT *rho_n, const FT *x3, const FT *x4, const FT *rho_a, const FT *guess,
+                                       FT *loglam, FT *D_m, FT *v_n, FT *v_m, void *stream) {
+    if (!params || !vel || !quad || n < 0 || (flags & ~(CMX_P3_INPUT_IS_STATE | CMX_P3_SLOPE_CONSTANT | CMX_P3_NO_ASPECT_RATIO)))
+        return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
+    if (quad->n < 1 || quad->n > CMX_QUAD_MAX || !(p > FT(0) && p < FT(0.5))) return CMX_ERR_BAD_ARG;
+    if (n == 0) return CMX_OK;
+    if (!rho_q || !rho_n || !x3 || !x4 || !rho_a) return CMX_ERR_BAD_ARG;
+    P3Consts<FT> c = make_p3_consts<FT>(*params, flags);
+    c.brent_iters = brent_iters > 0 ? brent_iters : PM<FT>::kBrent;
+    const P3VelConsts<FT> v = make_p3_vel_consts<FT>(*params, *vel, (double)p);
+    P3VelIO<FT, QUAD> io{rho_q, rho_n, x3, x4, rho_a, nullptr, v_n, v_m, nullptr, nullptr, nullptr, guess, loglam, D_m};
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (flags & CMX_P3_NO_ASPECT_RATIO)
+        hipLaunchKernelGGL((p3_velocity_kernel<FT, QUAD, false, false, true>), grid, block, 0, st, c, v, *quad, io, n);
+    else
+        hipLaunchKernelGGL((p3_velocity_kernel<FT, QUAD, true, false, true>), grid, block, 0, st, c, v, *quad, io, n);
     CMX_HIP_TRY(hipGetLastError());
     return CMX_OK;
 }
@@ -275,7 +323,7 @@ static int32_t p3_melt_entry(const PR *params, const VR *vel, const AP *aps, con
     v.K4 = (FT)(4.0 * (double)aps->K_therm);
     v.LH_f0 = (FT)((double)tps->LH_s0 - (double)tps->LH_v0); v.dcp_f = (FT)((double)tps->cp_l - (double)tps->cp_i);
     v.T_0 = (FT)tps->T_0; v.T_freeze = (FT)params->T_freeze;
-    P3VelIO<FT, QUAD> io{rho_q, rho_n, x3, x4, rho_a, loglam, nullptr, nullptr, T, dNdt, dLdt};
+    P3VelIO<FT, QUAD> io{rho_q, rho_n, x3, x4, rho_a, loglam, nullptr, nullptr, T, dNdt, dLdt, nullptr, nullptr, nullptr};
     const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (flags & CMX_P3_NO_ASPECT_RATIO)
@@ -424,6 +472,22 @@ int32_t cmx_p3_terminal_velocities_f64(const cmx_p3_params_f64 *params, const cm
                                        const double *rho_n_ice, const double *x3, const double *x4, const double *rho_air,
                                        const double *log_lambda, double *v_n, double *v_m, void *stream) {
     return cmx::p3_velocity_entry<double>(params, vel, quad, flags, p, n, rho_q_ice, rho_n_ice, x3, x4, rho_air, log_lambda, v_n, v_m, stream);
+}
+
+int32_t cmx_p3_shape_terminal_velocities_f32(const cmx_p3_params_f32 *params, const cmx_chen2022_ice_vel_f32 *vel, const cmx_quadrature_f32 *quad,
+                                             uint32_t flags, int32_t brent_iters, float p, int64_t n, const float *rho_q_ice, const float *rho_n_ice,
+                                             const float *x3, const float *x4, const float *rho_air, const float *log_lambda_guess,
+                                             float *log_lambda, float *D_m, float *v_n, float *v_m, void *stream) {
+    return cmx::p3_shape_velocity_entry<float>(params, vel, quad, flags, brent_iters, p, n, rho_q_ice, rho_n_ice, x3, x4, rho_air, log_lambda_guess,
+                                               log_lambda, D_m, v_n, v_m, stream);
+}
+int32_t cmx_p3_shape_terminal_velocities_f64(const cmx_p3_params_f64 *params, const cmx_chen2022_ice_vel_f64 *vel, const cmx_quadrature_f64 *quad,
+                                             uint32_t flags, int32_t brent_iters, double p, int64_t n, const double *rho_q_ice,
+                                             const double *rho_n_ice, const double *x3, const double *x4, const double *rho_air,
+                                             const double *log_lambda_guess, double *log_lambda, double *D_m, double *v_n, double *v_m,
+                                             void *stream) {
+    return cmx::p3_shape_velocity_entry<double>(params, vel, quad, flags, brent_iters, p, n, rho_q_ice, rho_n_ice, x3, x4, rho_air,
+                                                log_lambda_guess, log_lambda, D_m, v_n, v_m, stream);
 }
 
 int32_t cmx_p3_ice_melt_f32(const cmx_p3_params_f32 *params, const cmx_chen2022_ice_vel_f32 *vel, const cmx_air_properties_f32 *aps,

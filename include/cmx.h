@@ -796,6 +796,21 @@ int32_t cmx_p3_terminal_velocities_f64(const cmx_p3_params_f64 *params, const cm
                                        const double *rho_q_ice, const double *rho_n_ice, const double *x3, const double *x4,
                                        const double *rho_air, const double *log_lambda, double *v_n, double *v_m, void *stream);
 
+/* BASELINE config 5 as ONE launch: cmx_p3_shape_* (log λ, D_m) followed by cmx_p3_terminal_velocities_* on the same columns, without the
+ * log λ round trip through HBM and without reading the state twice (36 → 28 B/point of traffic in f32; the pass is compute-bound, so
+ * the gain is the launch and the re-read, not bandwidth).  Same arithmetic as the two separate entries, bit for bit.  log_lambda_guess,
+ * log_lambda and D_m may be NULL; brent_iters = 0 keeps the reference's fixed budget. */
+int32_t cmx_p3_shape_terminal_velocities_f32(const cmx_p3_params_f32 *params, const cmx_chen2022_ice_vel_f32 *vel,
+                                             const cmx_quadrature_f32 *quad, uint32_t flags, int32_t brent_iters, float p, int64_t n,
+                                             const float *rho_q_ice, const float *rho_n_ice, const float *x3, const float *x4,
+                                             const float *rho_air, const float *log_lambda_guess, float *log_lambda, float *D_m,
+                                             float *v_n, float *v_m, void *stream);
+int32_t cmx_p3_shape_terminal_velocities_f64(const cmx_p3_params_f64 *params, const cmx_chen2022_ice_vel_f64 *vel,
+                                             const cmx_quadrature_f64 *quad, uint32_t flags, int32_t brent_iters, double p, int64_t n,
+                                             const double *rho_q_ice, const double *rho_n_ice, const double *x3, const double *x4,
+                                             const double *rho_air, const double *log_lambda_guess, double *log_lambda, double *D_m,
+                                             double *v_n, double *v_m, void *stream);
+
 /* P3 melting rate (QIMLT of Morrison & Milbrandt 2015): replaces, per point,
  *   (; dNdt, dLdt) = P3.ice_melt(vel, aps, tps, T, ρₐ, state, logλ; quad)                  src/P3_processes.jl:64-94
  * dL/dt = max(0, 4 K_therm / L_f(T) · (T − T_freeze) ∫ ∂m/∂D · F_v(D) · N′(D)/D dD) over the same bounds / segments as the fall

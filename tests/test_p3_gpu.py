@@ -11,6 +11,7 @@ With a converged budget (brent_iters = 40) the same holds against the converged 
 certified to be a genuine root of the residual (|residual| ≤ 1e-6), i.e. another solution of the same equation."""
 import itertools
 import json
+import math
 from pathlib import Path
 
 import numpy as np
@@ -381,3 +382,30 @@ def test_ice_self_collection(dev, oracle, ft):
         e = np.abs(x[nz] - ref[nz]) / ref[nz]
         print(f"\n[P3 self-collection] {ft} aspect={aspect}: max rel err {e.max():.2e}")
         assert e.max() <= RTOL[ft] and np.all(x >= 0)
+
+
+@pytest.mark.parametrize("ft", ["f32", "f64"])
+def test_fused_shape_and_velocities_is_the_two_calls(dev, ft):
+    """cmx_p3_shape_terminal_velocities_* (BASELINE config 5 as one launch) against cmx_p3_shape_* followed by
+    cmx_p3_terminal_velocities_*: the same device functions, so log λ, D_m, v_n, v_m must agree bit for bit; with and without a warm-start
+    guess, absent ice, NaN inputs."""
+    import cmx
+    from cmx import synthetic
+    n = 20_011
+    st = synthetic.p3_state(n, dtype=DT[ft], device=dev, seed=321)
+    rho_a = synthetic.p3_air_density(n, dtype=DT[ft], device=dev, seed=123)
+    st = [c.clone() for c in st]
+    st[0][5] = 0.0                      # absent ice
+    st[1][7] = float("nan")             # NaN input
+    p, vel = P.ParametersP3(ft), P.Chen2022VelTypeIce(ft)
+    quad = P.GaussLegendre(ft, 20)
+    for guess in (None, torch.full((n,), 9.0, dtype=DT[ft], device=dev)):
+        shp = cmx.p3_shape(p, *st, log_lambda_guess=guess)
+        v = cmx.p3_terminal_velocities(p, vel, rho_a, *st, shp.log_lambda, quad=quad)
+        f = cmx.p3_shape_and_terminal_velocities(p, vel, rho_a, *st, log_lambda_guess=guess, quad=quad)
+        torch.cuda.synchronize()
+        eq = lambda a, b: bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all())  # noqa: E731
+        assert eq(f.log_lambda, shp.log_lambda) and eq(f.D_m, shp.D_m)
+        assert eq(f.v_n, v.v_n) and eq(f.v_m, v.v_m)
+        assert f.log_lambda[5].item() == float("-inf") and f.v_n[5].item() == 0.0
+        assert math.isnan(f.log_lambda[7].item())
