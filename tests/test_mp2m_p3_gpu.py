@@ -61,7 +61,7 @@ def _states(n, seed=11, f32_safe=False):
 @pytest.mark.parametrize("limited", [True, False])
 def test_fused_entry_parity(dev, oracle, ft, limited):
     import cmx
-    n = 3000
+    n = 24_000 if limited else 6_000        # ≈3 s of 8-thread oracle time for the large case (the oracle does 8e3 states/s on 16 threads)
     s = _states(n, f32_safe=(ft == "f32"))
     cols = {k: torch.from_numpy(v).to(DT[ft]) for k, v in s.items()}
     d = {k: v.to(dev) for k, v in cols.items()}
@@ -80,15 +80,26 @@ def test_fused_entry_parity(dev, oracle, ft, limited):
                                                       *c64, _np64(ll), _np64(shift), float32_gates=(ft == "f32"), nthreads=8)
     ok = np.ones(n, bool)
     worst = {}
+    eps_ft = {"f32": 1.2e-7, "f64": 2.2e-16}[ft]
+    T_freeze = P.DEFAULT_PARAMETERS["temperature_water_freeze"]
+    dT_rel = eps_ft * s["T"] / np.maximum(np.abs(s["T"] - T_freeze), eps_ft * s["T"])
     for q, k in enumerate(NAMES):
         x = _np64(getattr(got, k))
         assert np.all(np.isfinite(x)), k
-        tol = parity.RTOL[ft] * np.abs(ref[q]) + parity.CTOL[ft] * scale[q]
+        # + the T − T_freeze operand: the maximum freezing rate (wet / dry growth split, P3_processes.jl:96-140) and the melting terms are
+        # ∝ (T_freeze − T), whose relative rounding error in the kernel's float type is eps·T/|T − T_freeze| (1e-4 at 0.3 K from
+        # freezing in Float32) on every term it multiplies — found at 24 000 states: two states 0.3 K below freezing with 2 % ice
+        tol = parity.RTOL[ft] * np.abs(ref[q]) + (parity.CTOL[ft] + 2 * dT_rel) * scale[q]
         err = np.abs(x - ref[q]) / np.maximum(tol, 1e-300)
         err[(x == 0) & (ref[q] == 0)] = 0
         worst[k] = err[ok].max()
         j = int(np.argmax(np.where(ok, err, 0)))
         assert worst[k] <= 1.0, (k, j, x[j], ref[q][j], scale[q][j], {kk: s[kk][j] for kk in s})
+        ps = parity.plain_stats(x, ref[q], scale[q], parity.RTOL[ft], parity.FLOOR[ft], parity.CEIL[ft], ok, parity.WELLCOND[ft])
+        parity.REPORTS.append({"what": f"2M+P3 fused {ft} limited={limited}", "output": k, "ft": ft, "rtol": parity.RTOL[ft],
+                               "worst_normalised": float(worst[k]) * parity.RTOL[ft], **ps})
+        if ft == "f64":
+            assert ps["frac_within"] >= 0.999 and ps["worst_wellcond"] <= parity.RTOL[ft], (k, ps)
     print(f"\n[2M+P3 fused] {ft} limited={limited}: worst err/tol " + " ".join(f"{k}={v:.2f}" for k, v in worst.items()) + f" (compared {ok.mean():.1%})")
     # every process family is exercised
     ice = (s["q_ice"] > 0)
