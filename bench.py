@@ -47,6 +47,9 @@ def parse():
                     help="weak: --points per GPU; strong: --points in total, sharded over the ranks (cmx.sharding.shard_bounds)")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--workload", choices=["sb2006", "sb2006_chen", "sb2006_column", "icenuc", "mp0m", "mp1m", "mp1m_lin", "arg2000", "p3", "p3_fused", "p3_selfcol", "mp2m_p3", "sb2006_aos", "sb2006_fields"], default="sb2006")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend for N > 1: nccl (= RCCL over xGMI; the measured configuration) or gloo (TEST MODE: ranks may share "
+                         "a device — local_rank modulo the device count — so the N > 1 code path can be exercised on a 1-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the bounded baseline sample")
     ap.add_argument("--diagnostics", action="store_true",
@@ -569,10 +572,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(1, args.gpus):
         sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")                  # test mode: host-side barrier / reductions, ranks may share a device
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     points_arg = args.points
@@ -610,8 +618,8 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    tot = torch.tensor([float(n)], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    tot = torch.tensor([float(n)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)     # the points all ranks processed per step (layout workloads round per rank)
@@ -632,7 +640,8 @@ def main():
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": desc["workload"], "points_per_gpu": n, "points_total": total_points, "columns_in": desc["columns_in"],
                        "columns_out": desc["columns_out"],
-                       "parallelism": f"shard{world}" + ("+rccl-diag" if args.diagnostics else "")},
+                       "parallelism": f"shard{world}" + ("+rccl-diag" if args.diagnostics else "") +
+                                      ("" if args.backend == "nccl" or world == 1 else " (gloo test mode: ranks may share a device)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": (traffic_source + " (rocprofv3 PMC pass of this command on an earlier run; not measured in this run)")

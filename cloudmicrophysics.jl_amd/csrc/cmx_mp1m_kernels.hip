@@ -163,16 +163,28 @@ static Mp1mConsts<FT> make_mp1m_consts(const MP &mp, const TH &tp, uint32_t flag
 
 template <typename FT> struct Mp1mSrc { FT s[CMX_MP1M_NSRC]; FT qsat_l, qsat_i; };   // + q_sat over liquid / ice (LinearizedAverage)
 
-// CO.logistic_function_integral (Common.jl:157-173) in a cancellation-free form: with t = −log(1−e^{−k})/k,
-//   (log1pexp(k(x/x0 − 1 + t))/k − t)·x0  =  log1p(e^{−k}·expm1(k x/x0)) · x0/k
+// CO.logistic_function_integral (Common.jl:157-173): with t = −log(1−e^{−k})/k,
+//   (log1pexp(k(x/x0 − 1 + t))/k − t)·x0  =  log(1 + e^{−k}(e^{y} − 1))·x0/k  =  log((1 − e^{−k}) + e^{−k} e^{y})·x0/k,   y = k x/x0.
+// The reference forms the left side — a difference of two terms of size t·x0 — in FT arithmetic, so its own absolute accuracy is
+// eps(FT)·t·x0 (the oracle reports 2 t x0 as the operand scale of this term); the right side has absolute error eps(FT)·x0/k from the
+// rounding of its argument near 1, the same class, for two transcendentals and four other instructions.  (Round 1 used the
+// compensated expm1 / log1p pair: 25 instructions per integral; LEGACY_LOGISTIC=1 restores it for A/B runs.)
+#ifndef CMX_LEGACY_LOGISTIC
+#define CMX_LEGACY_LOGISTIC 0
+#endif
 template <typename FT> __device__ __forceinline__ FT logistic_integral(FT x, FT x0, FT k, FT emk, FT k_over_x0, FT x0_over_k, FT eps) {
     using M = Math<FT>;
     x = M::max(FT(0), x);
     const FT xs = M::max(x, eps);
-    // beyond y = k x/x0 = 60 the same quantity is (y − k) + log1p(e^{k−y} − e^{−y}) = y − k to 1e-25 (and expm1
+    // beyond y = k x/x0 = 60 the same quantity is (y − k) + log1p(e^{k−y} − e^{−y}) = y − k to 1e-25 (and e^{y}
     // cannot overflow below it); k/max(x0, ϵ) and its inverse are parameter-only (host-folded)
     const FT y = xs * k_over_x0;
+#if CMX_LEGACY_LOGISTIC
     const FT lg = M::log1p(emk * M::expm1(M::min(y, FT(60))));
+#else
+    const FT ey = M::exp2(M::min(y, FT(60)) * FT(1.4426950408889634));
+    const FT lg = M::log2(M::fma(emk, ey, FT(1) - emk)) * FT(0.6931471805599453);
+#endif
     const FT r = (y > FT(60) ? y - k : lg) * x0_over_k;
     return x < eps ? FT(0) : (x0 < eps ? x : r);
 }

@@ -45,3 +45,16 @@ def test_self_launched_two_rank_job(scaling):
     d = _run("--gpus", "2", "--scaling", scaling, "--no-cpu-baseline")
     assert d["n_gpus"] == 2 and d["scaling"] == scaling
     assert d["config"]["points_total"] == (2 * 1000003 if scaling == "weak" else 1000003)
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_two_ranks_sharing_this_gpu_gloo_test_mode(scaling):
+    """The N = 2 code path of bench.py (launcher → torch.distributed.run → two ranks, shard arithmetic, max-over-ranks timing, the
+    summed point count, rank-0 JSON) on whatever box this is: with `--backend gloo` the two ranks may share GPU 0.  Not a scaling
+    measurement — the JSON says so in config.parallelism."""
+    d = _run("--gpus", "2", "--scaling", scaling, "--backend", "gloo", "--no-cpu-baseline")
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and "gloo test mode" in d["config"]["parallelism"]
+    assert d["config"]["points_total"] == (2 * 1000003 if scaling == "weak" else 1000003)
+    per = d["config"]["points_per_gpu"]
+    assert per == (1000003 if scaling == "weak" else 500224)        # shard_bounds(1000003, 0, 2): 256-point-aligned halves
+    assert d["value"] == pytest.approx(d["config"]["points_total"] * 3 / (d["ms_per_step"] * 3e-3), rel=1e-9)
