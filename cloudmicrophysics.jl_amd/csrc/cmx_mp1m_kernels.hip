@@ -161,7 +161,11 @@ static Mp1mConsts<FT> make_mp1m_consts(const MP &mp, const TH &tp, uint32_t flag
     return c;
 }
 
-template <typename FT> struct Mp1mSrc { FT s[CMX_MP1M_NSRC]; FT qsat_l, qsat_i; };   // + q_sat over liquid / ice (LinearizedAverage)
+template <typename FT> struct Mp1mSrc {
+    FT s[CMX_MP1M_NSRC]; FT qsat_l, qsat_i;   // + q_sat over liquid / ice (LinearizedAverage)
+    // the temperature-routed accretion terms before the warm / cold split, for the direct aggregation of the tendencies kernel
+    FT S_lcl_sno, S_rai_sno, S_sno_rai, alpha; bool is_warm;
+};
 
 // CO.logistic_function_integral (Common.jl:157-173): with t = −log(1−e^{−k})/k,
 //   (log1pexp(k(x/x0 − 1 + t))/k − t)·x0  =  log(1 + e^{−k}(e^{y} − 1))·x0/k  =  log((1 − e^{−k}) + e^{−k} e^{y})·x0/k,   y = k x/x0.
@@ -279,8 +283,10 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const Mp1mConsts<FT> &c, FT rh
     const FT acc_rai = c.n0_rai * v0_rai * M::exp2(c.acc_e_rai * l2_li_rai);
     const FT acc_sno = n0_sno * v0_sno * M::exp2(c.acc_e_sno * l2_li_sno);
     if (fl & CMX_1M_ACCR_LCL_RAI) o.s[CMX_1M_S_ACCR_LCL_RAI] = (has_lcl && has_rai) ? q_lcl * c.acc_c_lcl_rai * acc_rai : FT(0);
+    o.S_lcl_sno = o.S_rai_sno = o.S_sno_rai = FT(0); o.alpha = alpha; o.is_warm = is_warm;
     if (fl & CMX_1M_ACCR_LCL_SNO) {
         const FT S = (has_lcl && has_sno) ? q_lcl * c.acc_c_lcl_sno * acc_sno : FT(0);
+        o.S_lcl_sno = S;
         o.s[CMX_1M_S_ACCR_LCL_SNO_COLD] = is_warm ? FT(0) : S;
         o.s[CMX_1M_S_ACCR_LCL_SNO_WARM] = is_warm ? S : FT(0);
         o.s[CMX_1M_S_ACCR_MELT_LCL_SNO] = alpha * S;
@@ -305,6 +311,7 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const Mp1mConsts<FT> &c, FT rh
         };
         const FT S_rai_sno = both ? kernel(c.rs_c_rai, c.rs_d_rai, li_sno, l2_li_sno, li_rai, l2_li_rai) : FT(0);   // i = snow, j = rain
         const FT S_sno_rai = both ? kernel(c.rs_c_sno, c.rs_d_sno, li_rai, l2_li_rai, li_sno, l2_li_sno) : FT(0);   // i = rain, j = snow
+        o.S_rai_sno = S_rai_sno; o.S_sno_rai = S_sno_rai;
         o.s[CMX_1M_S_ACCR_RAI_SNO_COLD] = is_warm ? FT(0) : S_rai_sno;
         o.s[CMX_1M_S_ACCR_RAI_SNO_WARM] = is_warm ? S_sno_rai : FT(0);
         o.s[CMX_1M_S_ACCR_MELT_RAI_SNO] = is_warm ? alpha * S_rai_sno : FT(0);
@@ -348,6 +355,24 @@ template <typename FT> __device__ __forceinline__ void mp1m_aggregate(const FT *
              s[CMX_1M_S_PHASE_CHANGE_VAP_SNO]) - s[CMX_1M_S_MELT_SNO_RAI];
 }
 
+// The same sums for the tendencies kernels, formed from the UNSPLIT accretion terms: of each warm / cold pair one member is exactly 0
+// (BMT:171-198 routes by T ≥ T_freeze), so Σ is the same set of non-zero terms with one select per tendency instead of six
+// selects and ten additions of zeros (different association of the additions: agreement with mp1m_aggregate to rounding).
+template <typename FT> __device__ __forceinline__ void mp1m_aggregate_direct(const Mp1mSrc<FT> &p, FT &dl, FT &di, FT &dr, FT &ds) {
+    const FT *s = p.s;
+    dl = (((s[CMX_1M_S_PHASE_CHANGE_VAP_LCL] - s[CMX_1M_S_ACNV_LCL_RAI]) - s[CMX_1M_S_ACCR_LCL_RAI]) - p.S_lcl_sno) + s[CMX_1M_S_MELT_ICL_LCL];
+    di = (((s[CMX_1M_S_PHASE_CHANGE_VAP_ICL] - s[CMX_1M_S_ACNV_ICL_SNO]) - s[CMX_1M_S_ACCR_ICL_RAI]) - s[CMX_1M_S_ACCR_ICL_SNO]) -
+         s[CMX_1M_S_MELT_ICL_LCL];
+    // warm: liquid collected by snow is shed as rain (+ melt), rain collects snow;  cold: snow collects rain
+    const FT melted = p.alpha * (p.S_lcl_sno + p.S_rai_sno);                 // α = 0 at and below T_freeze
+    const FT to_rai = p.is_warm ? (p.S_lcl_sno + p.S_sno_rai) + melted : -p.S_rai_sno;
+    const FT to_sno = p.is_warm ? -(p.S_sno_rai + melted) : p.S_lcl_sno + p.S_rai_sno;
+    dr = ((((s[CMX_1M_S_ACNV_LCL_RAI] + s[CMX_1M_S_ACCR_LCL_RAI]) - s[CMX_1M_S_ACCR_FREEZE_ICL_RAI]) + to_rai) +
+          s[CMX_1M_S_PHASE_CHANGE_VAP_RAI]) + s[CMX_1M_S_MELT_SNO_RAI];
+    ds = (((((s[CMX_1M_S_ACNV_ICL_SNO] + s[CMX_1M_S_ACCR_ICL_RAI]) + s[CMX_1M_S_ACCR_FREEZE_ICL_RAI]) + s[CMX_1M_S_ACCR_ICL_SNO]) + to_sno) +
+          s[CMX_1M_S_PHASE_CHANGE_VAP_SNO]) - s[CMX_1M_S_MELT_SNO_RAI];
+}
+
 // bulk_microphysics_tendencies(Instantaneous(), Microphysics1Moment(), …) over columns — BMT:505-514
 template <typename FT, int VEC, uint32_t FLAGS = kRuntimeFlags>
 __global__ __launch_bounds__(kBlock) void mp1m_tendencies_kernel(const Mp1mConsts<FT> c, const Mp1mIn<FT> in,
@@ -363,7 +388,7 @@ __global__ __launch_bounds__(kBlock) void mp1m_tendencies_kernel(const Mp1mConst
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
         const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(c, rho[k], T[k], q_tot[k], q_lcl[k], q_icl[k], q_rai[k], q_sno[k]);
-        mp1m_aggregate<FT>(p.s, dl[k], di[k], dr[k], ds[k]);
+        mp1m_aggregate_direct<FT>(p, dl[k], di[k], dr[k], ds[k]);
         if (any_nan(rho[k], q_tot[k], q_lcl[k], q_icl[k], q_rai[k], q_sno[k], T[k])) dl[k] = di[k] = dr[k] = ds[k] = Math<FT>::nan();
     }
     store_col<FT, VEC>(out.dq_lcl, i, dl); store_col<FT, VEC>(out.dq_icl, i, di);
@@ -600,7 +625,7 @@ template <typename FT, uint32_t FLAGS> struct Mp1mLayoutPolicy {
     using Consts = Mp1mConsts<FT>;
     static __device__ __forceinline__ void point(const Consts &c, const FT (&x)[NIN], FT (&y)[NOUT]) {
         const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(c, x[0], x[1], x[2], x[3], x[4], x[5], x[6]);
-        mp1m_aggregate<FT>(p.s, y[0], y[1], y[2], y[3]);
+        mp1m_aggregate_direct<FT>(p, y[0], y[1], y[2], y[3]);
         if (any_nan(x[0], x[2], x[3], x[4], x[5], x[6], x[1])) y[0] = y[1] = y[2] = y[3] = Math<FT>::nan();
     }
 };
