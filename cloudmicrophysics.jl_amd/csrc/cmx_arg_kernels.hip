@@ -230,17 +230,19 @@ __device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, cons
 // the two wants as run-time flags the compiler keeps both erfc chains and their selects alive (1212 → 729 VALU per 4 points).
 template <typename FT, int NM, bool SINKS, int VEC, bool N_ONLY = false>
 __global__ __launch_bounds__(kBlock) void arg_activation_kernel(const ArgConsts<FT> c, const ArgIO<FT> io, const int64_t nvec) {
-    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= nvec) return;
     FT T[VEC], p[VEC], w[VEC], qt[VEC], ql[VEC] = {}, qi[VEC] = {}, Nl[VEC] = {}, Ni[VEC] = {};
-    load_col<FT, VEC>(io.T, i, T); load_col<FT, VEC>(io.p, i, p); load_col<FT, VEC>(io.w, i, w); load_col<FT, VEC>(io.q_tot, i, qt);
-    if (io.q_liq) load_col<FT, VEC>(io.q_liq, i, ql);
-    if (io.q_ice) load_col<FT, VEC>(io.q_ice, i, qi);
-    if constexpr (SINKS) {
-        if (io.N_liq) load_col<FT, VEC>(io.N_liq, i, Nl);
-        if (io.N_ice) load_col<FT, VEC>(io.N_ice, i, Ni);
+    if (i < nvec) {
+        load_col<FT, VEC>(io.T, i, T); load_col<FT, VEC>(io.p, i, p); load_col<FT, VEC>(io.w, i, w); load_col<FT, VEC>(io.q_tot, i, qt);
+        if (io.q_liq) load_col<FT, VEC>(io.q_liq, i, ql);
+        if (io.q_ice) load_col<FT, VEC>(io.q_ice, i, qi);
+        if constexpr (SINKS) {
+            if (io.N_liq) load_col<FT, VEC>(io.N_liq, i, Nl);
+            if (io.N_ice) load_col<FT, VEC>(io.N_ice, i, Ni);
+        }
     }
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS while the loads fly (every lane of the workgroup reaches the barrier inside); no-op for Float32
+    if (i >= nvec) return;
     FT sm[VEC], na[NM][VEC], ma[NM][VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {

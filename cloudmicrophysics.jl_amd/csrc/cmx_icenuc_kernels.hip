@@ -84,17 +84,19 @@ template <typename FT> __device__ __forceinline__ FT a_w_ice_dev(const IceNucCon
 template <typename FT, bool LINEAR, int VEC, bool RATES_ONLY = false>
 __global__ __launch_bounds__(kBlock) void ice_nucleation_kernel(const IceNucConsts<FT> c, const IceNucIO<FT> io,
                                                                 const int64_t nvec) {
-    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using M = Math<FT>;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool active = i < nvec;
     int nerr = 0;
+    const bool want_rates = io.rate_het || io.rate_hom;
+    FT T[VEC], aw[VEC], r[VEC] = {};
     if (active) {
-        const bool want_rates = io.rate_het || io.rate_hom;
-        FT T[VEC], aw[VEC], r[VEC] = {};
         load_col<FT, VEC>(io.T, i, T);
         load_col<FT, VEC>(io.a_w, i, aw);
         if (want_rates) load_col<FT, VEC>(io.r, i, r);
+    }
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS while the loads fly (every lane of the workgroup reaches the barrier inside); no-op for Float32
+    if (active) {
         FT d[VEC], jh[VEC], jo[VEC], rh[VEC], ro[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {

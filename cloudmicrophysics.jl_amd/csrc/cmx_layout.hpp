@@ -37,7 +37,6 @@ constexpr int kLayoutBS = 128;   // lanes per workgroup of the adapter kernel
 template <typename FT, typename POLICY, int VEC, bool SEG, bool AOS, int BS = kLayoutBS>
 __global__ __launch_bounds__(BS) void tendencies_layout_kernel(const typename POLICY::Consts c,
                                                                const LayoutIO<FT, POLICY::NIN, POLICY::NOUT> io, const int64_t nvec) {
-    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     constexpr int NIN = POLICY::NIN, NOUT = POLICY::NOUT, NAOS = POLICY::NAOS;
     constexpr int CH = 16 / (int)sizeof(FT);                  // elements per 16-byte chunk
     constexpr int ROW = VEC * NAOS + CH;                      // LDS row of one lane (+1 chunk of padding against bank conflicts)
@@ -54,16 +53,19 @@ __global__ __launch_bounds__(BS) void tendencies_layout_kernel(const typename PO
         if (off < 0) { --seg; off += io.seg_len; }
         if (off >= io.seg_len) { ++seg; off -= io.seg_len; }
     }
+    FT x[NIN][VEC];
     if (active) {
-        FT x[NIN][VEC];
 #pragma unroll
         for (int k = 0; k < NIN; ++k) load_col<FT, VEC, true>(io.in[k] + (SEG ? seg * io.in_stride[k] : 0), off / VEC, x[k]);
+    }
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS while the loads fly (every lane of the workgroup reaches the barrier inside); no-op for Float32
+    if (active) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             FT xi[NIN];
 #pragma unroll
             for (int q = 0; q < NIN; ++q) xi[q] = x[q][k];
-            POLICY::point(c, xi, y[k]);
+            POLICY::point(front_consts<FT>(c), xi, y[k]);   // Float64: phase-local constants (cmx_math.hpp); c is the first argument
         }
     }
     if constexpr (!AOS) {

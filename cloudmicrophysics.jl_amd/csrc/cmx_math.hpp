@@ -141,11 +141,63 @@ template <typename FT> __device__ __forceinline__ FT clampv(FT x, FT lo, FT hi) 
 // clamp_to_nonneg of a LOADED value: max(0, x) through v_med3_f32(x, 0, +Inf).  A plain fmax on a value that comes straight from
 // memory costs two instructions in IEEE mode (the compiler must quiet a possible signalling NaN first: v_max x, x); the median does
 // not need that, returns 0 for a NaN like v_max does (the NaN rule is applied separately), and its result counts as canonical.
-__device__ __forceinline__ float max0(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+#ifndef CMX_MAX0_ASM
+#define CMX_MAX0_ASM 1
+#endif
+__device__ __forceinline__ float max0(float x) {
+#if CMX_MAX0_ASM
+    // written as an instruction: in some kernels the optimiser rewrites the builtin with these constants to canonicalize + v_max
+    float r;
+    asm("v_med3_f32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(__builtin_inff()));
+    return r;
+#else
+    return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff());
+#endif
+}
 __device__ __forceinline__ double max0(double x) { return Math<double>::max(0.0, x); }
 // the same for lo ≤ hi as ONE instruction (v_med3_f32: the median of three is the clamp); Float64 has no med3
 __device__ __forceinline__ float clamp_ordered(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 __device__ __forceinline__ double clamp_ordered(double x, double lo, double hi) { return clampv(x, lo, hi); }
+
+// ---- phase-local constants (Float64) --------------------------------------------------------------------------------------------
+// The constants struct of a Float64 kernel is large: SbConsts<double> is ≈ 95 doubles = 190 SGPRs; the register file has 102.
+// Left alone the compiler loads the whole kernel-argument struct in the entry block and spills it to VGPR lanes: the Float64 SB2006
+// tendencies kernel carried 72 v_writelane + 136 v_readlane per point (17 % of its VALU instructions — and the Float64 kernels are
+// VALU-issue-bound), the 1-moment kernel 148 + 340 of 1656.  The Float64 kernels therefore read the constants through a
+// constant-address-space pointer to the kernel-argument segment (front_consts) and pass it through consts_after(c, x) at the phase
+// boundaries of the point function: an empty asm that makes the pointer depend on a value the previous phase computed, so the
+// scalar loads of a phase cannot be hoisted above it and only that phase's constants are live.  Float32 (95 SGPRs) needs none of it.
+#ifndef CMX_PHASE_CONSTS
+#define CMX_PHASE_CONSTS 1
+#endif
+// CMX_PHASE_DEP(late, early): the value a phase's constants wait for — the LAST value of the previous phase (only one phase's
+// constants live), or with CMX_PHASE_PREFETCH an EARLY value of the previous phase (the loads overlap that phase's arithmetic; two
+// phases' constants live).
+#ifndef CMX_PHASE_PREFETCH
+#define CMX_PHASE_PREFETCH 0
+#endif
+#if CMX_PHASE_PREFETCH
+#define CMX_PHASE_DEP(late, early) early
+#else
+#define CMX_PHASE_DEP(late, early) late
+#endif
+template <typename T> using KernArg = const __attribute__((address_space(4))) T;
+template <typename T> struct is_kernarg { static constexpr bool value = false; };
+template <typename T> struct is_kernarg<const __attribute__((address_space(4))) T> { static constexpr bool value = true; };
+// the constants struct must be the FIRST kernel argument
+template <typename FT, typename CT> __device__ __forceinline__ decltype(auto) front_consts(const CT &c) {
+    if constexpr (sizeof(FT) == 8 && CMX_PHASE_CONSTS) return (*(KernArg<CT> *)__builtin_amdgcn_kernarg_segment_ptr());
+    else return (c);
+}
+// (a plain reference passes through: laundering the address of a by-value kernel argument would force a private copy of the struct)
+template <typename C, typename FT> __device__ __forceinline__ const C &consts_after(const C &c, FT dep) {
+    if constexpr (is_kernarg<const C>::value) {
+        const C *p = &c;
+        asm volatile("" : "+s"(p) : "v"(dep));
+        return *p;
+    } else
+        return c;
+}
 
 // NaN inputs.  The reference sanitises with Julia's max(0, x), which returns NaN for a NaN x, and its arithmetic then carries the NaN to
 // the tendencies; the hardware v_max returns the other operand and would hide it.  The bulk-tendency kernels therefore poison every output

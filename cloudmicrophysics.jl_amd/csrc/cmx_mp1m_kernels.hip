@@ -178,8 +178,8 @@ template <typename FT> struct Mp1mSrc {
 #endif
 template <typename FT> __device__ __forceinline__ FT logistic_integral(FT x, FT x0, FT k, FT emk, FT k_over_x0, FT x0_over_k, FT eps) {
     using M = Math<FT>;
-    x = M::max(FT(0), x);
-    const FT xs = M::max(x, eps);
+    // x arrives clamped to ≥ 0 (mp1m_point); the reference's max(x, ϵ) only matters below ϵ, where the result is the 0 of the last line
+    const FT xs = x;
     // beyond y = k x/x0 = 60 the same quantity is (y − k) + log1p(e^{k−y} − e^{−y}) = y − k to 1e-25 (and e^{y}
     // cannot overflow below it); k/max(x0, ϵ) and its inverse are parameter-only (host-folded)
     const FT y = xs * k_over_x0;
@@ -196,15 +196,16 @@ template <typename FT> __device__ __forceinline__ FT logistic_integral(FT x, FT 
 // FLAGS: the Microphysics1MOptions bits as a compile-time constant (the default option set gets its own instantiation:
 // one straight-line basic block, the unselected variants removed), or kRuntimeFlags to read them from the constants.
 constexpr uint32_t kRuntimeFlags = 0xffffffffu;
-template <typename FT, uint32_t FLAGS = kRuntimeFlags>
-__device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const Mp1mConsts<FT> &c, FT rho, FT T, FT q_tot, FT q_lcl, FT q_icl,
+template <typename FT, uint32_t FLAGS = kRuntimeFlags, typename C>
+__device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT q_tot, FT q_lcl, FT q_icl,
                                                   FT q_rai, FT q_sno) {
     using M = Math<FT>;
+    const C *c = &c0;   // Float64: re-derived at the phase boundaries (consts_after, cmx_math.hpp) so only a phase's constants are live
     Mp1mSrc<FT> o;
 #pragma unroll
     for (int k = 0; k < CMX_MP1M_NSRC; ++k) o.s[k] = FT(0);
-    const uint32_t fl = FLAGS == kRuntimeFlags ? c.flags : FLAGS;
-    const FT eps = c.eps_1m;   // ϵ_numerics(FT) = cbrt(floatmin(FT))  Utilities.jl:318
+    const uint32_t fl = FLAGS == kRuntimeFlags ? c->flags : FLAGS;
+    const FT eps = c->eps_1m;   // ϵ_numerics(FT) = cbrt(floatmin(FT))  Utilities.jl:318
     // clamp_to_nonneg — BMT:147-152 (T is not clamped)
     rho = max0(rho); q_tot = max0(q_tot); q_lcl = max0(q_lcl);
     q_icl = max0(q_icl); q_rai = max0(q_rai); q_sno = max0(q_sno);
@@ -212,80 +213,84 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const Mp1mConsts<FT> &c, FT rh
     const bool has_lcl = q_lcl > eps, has_icl = q_icl > eps, has_rai = q_rai > eps, has_sno = q_sno > eps;
 
     // ---- thermodynamics, once -------------------------------------------------------------------------------
-    const FT l2_TT = M::log2(T * c.inv_T_tr), dinvT = c.inv_T_tr - inv_T;
-    const FT psat_l = M::exp2(M::fma(c.psl_a, l2_TT, M::fma(c.psl_b, dinvT, c.ps_c0)));
-    const FT psat_i = M::exp2(M::fma(c.psi_a, l2_TT, M::fma(c.psi_b, dinvT, c.ps_c0)));
-    const FT dT0 = T - c.T_0;
-    const FT L_v = M::fma(c.dcp_l, dT0, c.LH_v0), L_s = M::fma(c.dcp_i, dT0, c.LH_s0), L_f = M::fma(c.dcp_f, dT0, c.LH_f0);
+    const FT l2_TT = M::log2(T * c->inv_T_tr), dinvT = c->inv_T_tr - inv_T;
+    const FT psat_l = M::exp2(M::fma(c->psl_a, l2_TT, M::fma(c->psl_b, dinvT, c->ps_c0)));
+    const FT psat_i = M::exp2(M::fma(c->psi_a, l2_TT, M::fma(c->psi_b, dinvT, c->ps_c0)));
+    const FT dT0 = T - c->T_0;
+    const FT L_v = M::fma(c->dcp_l, dT0, c->LH_v0), L_s = M::fma(c->dcp_i, dT0, c->LH_s0), L_f = M::fma(c->dcp_f, dT0, c->LH_f0);
     const FT q_liq = q_lcl + q_rai, q_ice = q_icl + q_sno;
     const FT q_vap = M::max(FT(0), (q_tot - q_liq) - q_ice);                     // TDI.q_vap :60
-    const FT rho_RvT = rho * (c.R_v * T);
+    const FT rho_RvT = rho * (c->R_v * T);
     const FT inv_rho_RvT = M::rcp(rho_RvT);
-    const FT cp_air = M::fma(c.cpm_qi, q_ice, M::fma(c.cpm_ql, q_liq, M::fma(c.cpm_qt, q_tot, c.cp_d)));
+    const FT cp_air = M::fma(c->cpm_qi, q_ice, M::fma(c->cpm_ql, q_liq, M::fma(c->cpm_qt, q_tot, c->cp_d)));
     const FT inv_cp = M::rcp(cp_air);
-    const FT inv_RT = c.inv_R_v * inv_T;
-    const bool above_freezing = T > c.T_freeze;
-    const FT dTf = T - c.T_freeze;
+    const FT inv_RT = c->inv_R_v * inv_T;
+    const bool above_freezing = T > c->T_freeze;
+    const FT dTf = T - c->T_freeze;
     o.qsat_l = psat_l * inv_rho_RvT; o.qsat_i = psat_i * inv_rho_RvT;
     if (fl & CMX_1M_CLOUD_LIQUID_FORMATION) {   // NonEq:117-140
         const FT q_sat = psat_l * inv_rho_RvT;
         const FT dq_dT = q_sat * (L_v * inv_RT * inv_T - inv_T);
-        const FT inv_ts = M::rcp(c.tau_l * M::fma(L_v * inv_cp, dq_dT, FT(1)));
+        const FT inv_ts = M::rcp(c->tau_l * M::fma(L_v * inv_cp, dq_dT, FT(1)));
         const FT ex = q_vap - q_sat;
         o.s[CMX_1M_S_PHASE_CHANGE_VAP_LCL] = (ex < FT(0) ? -M::min(-ex, q_lcl) : ex) * inv_ts;
     }
     if (fl & CMX_1M_CLOUD_ICE_FORMATION_CONST) {   // NonEq:168-193 + INP_limiter :56-58
         const FT q_sat = psat_i * inv_rho_RvT;
         const FT dq_dT = q_sat * (L_s * inv_RT * inv_T - inv_T);
-        const FT inv_ts = M::rcp(c.tau_i * M::fma(L_s * inv_cp, dq_dT, FT(1)));
+        const FT inv_ts = M::rcp(c->tau_i * M::fma(L_s * inv_cp, dq_dT, FT(1)));
         const FT ex = q_vap - q_sat;
         const FT tend = (ex < FT(0) ? -M::min(-ex, q_icl) : ex) * inv_ts;
         o.s[CMX_1M_S_PHASE_CHANGE_VAP_ICL] = (above_freezing && tend > FT(0)) ? FT(0) : tend;
     }
+    c = &consts_after(*c, o.qsat_i);
     const FT inv_ps_l = M::rcp(psat_l), inv_ps_i = M::rcp(psat_i);
     const FT S_l = M::fma(q_vap * rho_RvT, inv_ps_l, FT(-1));                      // TDI.supersaturation_over_liquid
     const FT S_i = M::fma(q_vap * rho_RvT, inv_ps_i, FT(-1));                      // …over_ice
     const FT LoRT_v = L_v * inv_RT, LoRT_s = L_s * inv_RT;
     // 1/max(p_sat, ϵ) = min(1/p_sat, 1/ϵ): the reciprocal is shared with the supersaturation
-    const FT G_l = M::rcp(M::fma(L_v * c.inv_K * inv_T, LoRT_v - FT(1), c.Rv_over_D * T * M::min(inv_ps_l, c.inv_eps)));   // Common.jl:47-63
-    const FT G_i = M::rcp(M::fma(L_s * c.inv_K * inv_T, LoRT_s - FT(1), c.Rv_over_D * T * M::min(inv_ps_i, c.inv_eps)));   // :83-102
+    const FT G_l = M::rcp(M::fma(L_v * c->inv_K * inv_T, LoRT_v - FT(1), c->Rv_over_D * T * M::min(inv_ps_l, c->inv_eps)));   // Common.jl:47-63
+    const FT G_i = M::rcp(M::fma(L_s * c->inv_K * inv_T, LoRT_s - FT(1), c->Rv_over_D * T * M::min(inv_ps_i, c->inv_eps)));   // :83-102
 
+    c = &consts_after(*c, G_i);
     // ---- size_distr_parameters — CM1:375-388 ------------------------------------------------------------------
     const FT l2_rq_rai = M::log2(rho * q_rai), l2_rq_sno = M::log2(rho * q_sno), l2_rq_icl = M::log2(rho * q_icl);
-    const FT l2_li_rai = M::max(c.lam_floor_rai, (l2_rq_rai + c.lam_c_rai) * c.lam_e_rai);
-    const FT l2_li_icl = M::max(c.lam_floor_icl, (l2_rq_icl + c.lam_c_icl) * c.lam_e_icl);
+    const FT l2_li_rai = M::max(c->lam_floor_rai, (l2_rq_rai + c->lam_c_rai) * c->lam_e_rai);
+    const FT l2_li_icl = M::max(c->lam_floor_icl, (l2_rq_icl + c->lam_c_icl) * c->lam_e_icl);
     // snow: n0 = μ (ρ max(q, ϵ))^ν if q > ϵ else 0 (get_n0 :83-86); λ⁻¹ uses max(n0, ϵ)
     // (for q_sno > ϵ, ρ·max(q_sno, ϵ) = ρ q_sno: its log2 is l2_rq_sno)
-    const FT l2_n0_sno = has_sno ? M::fma(c.sno_nu, l2_rq_sno, c.sno_l2_mu) : c.l2_eps;
+    const FT l2_n0_sno = has_sno ? M::fma(c->sno_nu, l2_rq_sno, c->sno_l2_mu) : c->l2_eps;
     const FT n0_sno = has_sno ? M::exp2(l2_n0_sno) : FT(0);
-    const FT l2_li_sno = M::max(c.lam_floor_sno, (l2_rq_sno + c.lam_c_sno - M::max(l2_n0_sno, c.l2_eps)) * c.lam_e_sno);
+    const FT l2_li_sno = M::max(c->lam_floor_sno, (l2_rq_sno + c->lam_c_sno - M::max(l2_n0_sno, c->l2_eps)) * c->lam_e_sno);
     const FT li_rai = M::exp2(l2_li_rai), li_sno = M::exp2(l2_li_sno), li_icl = M::exp2(l2_li_icl);
-    const FT v0_rai = c.v0c_rai * M::sqrt(M::max(c.rho_w * inv_rho - FT(1), FT(0)));   // get_v0 :101-104
-    const FT v0_sno = c.v0_sno;
+    const FT v0_rai = c->v0c_rai * M::sqrt(M::max(c->rho_w * inv_rho - FT(1), FT(0)));   // get_v0 :101-104
+    const FT v0_sno = c->v0_sno;
 
+    c = &consts_after(*c, li_icl);
     // ---- autoconversion — CM1:354-364, 414-446 ------------------------------------------------------------------
     if (fl & CMX_1M_RAIN_ACNV_KESSLER)
-        o.s[CMX_1M_S_ACNV_LCL_RAI] = logistic_integral<FT>(q_lcl, c.ka_qthr, c.ka_k, c.ka_emk, c.ka_k_over_x0, c.ka_x0_over_k, eps) * c.ka_inv_tau;
+        o.s[CMX_1M_S_ACNV_LCL_RAI] = logistic_integral<FT>(q_lcl, c->ka_qthr, c->ka_k, c->ka_emk, c->ka_k_over_x0, c->ka_x0_over_k, eps) * c->ka_inv_tau;
     else if (fl & CMX_1M_RAIN_ACNV_PRESCRIBED_ND)
-        o.s[CMX_1M_S_ACNV_LCL_RAI] = q_lcl * c.nd_coeff;
+        o.s[CMX_1M_S_ACNV_LCL_RAI] = q_lcl * c->nd_coeff;
     if (fl & CMX_1M_SNOW_ACNV_NO_SUPERSAT) {
-        o.s[CMX_1M_S_ACNV_ICL_SNO] = logistic_integral<FT>(q_icl, c.ks_qthr, c.ks_k, c.ks_emk, c.ks_k_over_x0, c.ks_x0_over_k, eps) * c.ks_inv_tau;
+        o.s[CMX_1M_S_ACNV_ICL_SNO] = logistic_integral<FT>(q_icl, c->ks_qthr, c->ks_k, c->ks_emk, c->ks_k_over_x0, c->ks_x0_over_k, eps) * c->ks_inv_tau;
     } else if (fl & CMX_1M_SNOW_ACNV_WITH_SUPERSAT) {
-        const FT x = c.r_is * M::rcp(li_icl);
-        const FT rate = c.four_pi * S_i * G_i * c.n0_icl * inv_rho * M::exp2(x * FT(-1.4426950408889634)) *
-                        M::fma(c.r_is * c.r_is, c.inv_me_dm_icl, (x + FT(1)) * (li_icl * li_icl));
-        o.s[CMX_1M_S_ACNV_ICL_SNO] = (has_icl && S_i > FT(0) && T < c.T_freeze) ? rate : FT(0);
+        const FT x = c->r_is * M::rcp(li_icl);
+        const FT rate = c->four_pi * S_i * G_i * c->n0_icl * inv_rho * M::exp2(x * FT(-1.4426950408889634)) *
+                        M::fma(c->r_is * c->r_is, c->inv_me_dm_icl, (x + FT(1)) * (li_icl * li_icl));
+        o.s[CMX_1M_S_ACNV_ICL_SNO] = (has_icl && S_i > FT(0) && T < c->T_freeze) ? rate : FT(0);
     }
 
+    c = &consts_after(*c, o.s[CMX_1M_S_ACNV_ICL_SNO]);
     // ---- accretion — CM1:491-897, routed by temperature as in BMT:171-198 ----------------------------------------
-    const bool is_warm = T >= c.T_freeze;
-    const FT alpha = (T <= c.T_freeze) ? FT(0) : c.cv_l * M::rcp(L_f) * dTf;    // warm_accretion_melt_factor :458-465
-    const FT acc_rai = c.n0_rai * v0_rai * M::exp2(c.acc_e_rai * l2_li_rai);
-    const FT acc_sno = n0_sno * v0_sno * M::exp2(c.acc_e_sno * l2_li_sno);
-    if (fl & CMX_1M_ACCR_LCL_RAI) o.s[CMX_1M_S_ACCR_LCL_RAI] = (has_lcl && has_rai) ? q_lcl * c.acc_c_lcl_rai * acc_rai : FT(0);
+    const bool is_warm = T >= c->T_freeze;
+    const FT alpha = (T <= c->T_freeze) ? FT(0) : c->cv_l * M::rcp(L_f) * dTf;    // warm_accretion_melt_factor :458-465
+    const FT acc_rai = c->n0_rai * v0_rai * M::exp2(c->acc_e_rai * l2_li_rai);
+    const FT acc_sno = n0_sno * v0_sno * M::exp2(c->acc_e_sno * l2_li_sno);
+    if (fl & CMX_1M_ACCR_LCL_RAI) o.s[CMX_1M_S_ACCR_LCL_RAI] = (has_lcl && has_rai) ? q_lcl * c->acc_c_lcl_rai * acc_rai : FT(0);
     o.S_lcl_sno = o.S_rai_sno = o.S_sno_rai = FT(0); o.alpha = alpha; o.is_warm = is_warm;
     if (fl & CMX_1M_ACCR_LCL_SNO) {
-        const FT S = (has_lcl && has_sno) ? q_lcl * c.acc_c_lcl_sno * acc_sno : FT(0);
+        const FT S = (has_lcl && has_sno) ? q_lcl * c->acc_c_lcl_sno * acc_sno : FT(0);
         o.S_lcl_sno = S;
         o.s[CMX_1M_S_ACCR_LCL_SNO_COLD] = is_warm ? FT(0) : S;
         o.s[CMX_1M_S_ACCR_LCL_SNO_WARM] = is_warm ? S : FT(0);
@@ -293,44 +298,46 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const Mp1mConsts<FT> &c, FT rh
     }
     if (fl & CMX_1M_ACCR_ICL_RAI) {
         const bool both = has_icl && has_rai;
-        o.s[CMX_1M_S_ACCR_ICL_RAI] = both ? q_icl * c.acc_c_icl_rai * acc_rai : FT(0);
-        o.s[CMX_1M_S_ACCR_FREEZE_ICL_RAI] = both ? c.sink_c * inv_rho * v0_rai * li_icl * M::exp2(c.sink_e * l2_li_rai) : FT(0);
+        o.s[CMX_1M_S_ACCR_ICL_RAI] = both ? q_icl * c->acc_c_icl_rai * acc_rai : FT(0);
+        o.s[CMX_1M_S_ACCR_FREEZE_ICL_RAI] = both ? c->sink_c * inv_rho * v0_rai * li_icl * M::exp2(c->sink_e * l2_li_rai) : FT(0);
     }
-    if (fl & CMX_1M_ACCR_ICL_SNO) o.s[CMX_1M_S_ACCR_ICL_SNO] = (has_icl && has_sno) ? q_icl * c.acc_c_icl_sno * acc_sno : FT(0);
+    if (fl & CMX_1M_ACCR_ICL_SNO) o.s[CMX_1M_S_ACCR_ICL_SNO] = (has_icl && has_sno) ? q_icl * c->acc_c_icl_sno * acc_sno : FT(0);
+    c = &consts_after(*c, acc_sno);
     if (fl & CMX_1M_ACCR_RAI_SNO) {   // CM1:604-644, 815-867
-        const FT v_rai = has_rai ? c.vt_c_rai * v0_rai * M::exp2(c.vt_e_rai * l2_li_rai) : FT(0);
-        const FT v_sno = has_sno ? c.vt_c_sno * v0_sno * M::exp2(c.vt_e_sno * l2_li_sno) : FT(0);
+        const FT v_rai = has_rai ? c->vt_c_rai * v0_rai * M::exp2(c->vt_e_rai * l2_li_rai) : FT(0);
+        const FT v_sno = has_sno ? c->vt_c_sno * v0_sno * M::exp2(c->vt_e_sno * l2_li_sno) : FT(0);
         const FT dv = v_sno - v_rai;
-        const FT dv_eff = M::sqrt(M::fma(dv, dv, c.coeff_disp * M::fma(v_sno, v_sno, v_rai * v_rai)));
-        const FT pre = inv_rho * c.n0_rai * n0_sno * dv_eff;
+        const FT dv_eff = M::sqrt(M::fma(dv, dv, c->coeff_disp * M::fma(v_sno, v_sno, v_rai * v_rai)));
+        const FT pre = inv_rho * c->n0_rai * n0_sno * dv_eff;
         const bool both = has_rai && has_sno;
         // Σ = 2 λi³ λj^(δ+1) + 2(δ+1) λi² λj^(δ+2) + (δ+2)(δ+1) λi λj^(δ+3) = λi λj^(δ+1) (2λi² + 2(δ+1)λiλj + (δ+2)(δ+1)λj²)
         auto kernel = [&](FT cj, FT d, FT li, FT l2_li, FT lj, FT l2_lj) {
             const FT poly = M::fma(FT(2) * li, li, M::fma(FT(2) * (d + FT(1)) * li, lj, (d + FT(2)) * (d + FT(1)) * (lj * lj)));
             return pre * cj * M::exp2(l2_li + (d + FT(1)) * l2_lj) * poly;
         };
-        const FT S_rai_sno = both ? kernel(c.rs_c_rai, c.rs_d_rai, li_sno, l2_li_sno, li_rai, l2_li_rai) : FT(0);   // i = snow, j = rain
-        const FT S_sno_rai = both ? kernel(c.rs_c_sno, c.rs_d_sno, li_rai, l2_li_rai, li_sno, l2_li_sno) : FT(0);   // i = rain, j = snow
+        const FT S_rai_sno = both ? kernel(c->rs_c_rai, c->rs_d_rai, li_sno, l2_li_sno, li_rai, l2_li_rai) : FT(0);   // i = snow, j = rain
+        const FT S_sno_rai = both ? kernel(c->rs_c_sno, c->rs_d_sno, li_rai, l2_li_rai, li_sno, l2_li_sno) : FT(0);   // i = rain, j = snow
         o.S_rai_sno = S_rai_sno; o.S_sno_rai = S_sno_rai;
         o.s[CMX_1M_S_ACCR_RAI_SNO_COLD] = is_warm ? FT(0) : S_rai_sno;
         o.s[CMX_1M_S_ACCR_RAI_SNO_WARM] = is_warm ? S_sno_rai : FT(0);
         o.s[CMX_1M_S_ACCR_MELT_RAI_SNO] = is_warm ? alpha * S_rai_sno : FT(0);
     }
 
+    c = &consts_after(*c, o.S_sno_rai);
     // ---- ventilated vapour exchange and melting — CM1:917-1139 ---------------------------------------------------
-    const FT F_rai = M::fma(c.vent_b_rai * M::sqrt(v0_rai), M::exp2(c.vent_e_rai * l2_li_rai), c.vent_a_rai);
-    const FT F_sno = M::fma(c.vent_b_sno * c.sqrt_v0_sno, M::exp2(c.vent_e_sno * l2_li_sno), c.vent_a_sno);
-    const FT mp_rai = c.four_pi * c.n0_rai * inv_rho * (li_rai * li_rai) * F_rai;      // 4π n0/ρ λ⁻² F
-    const FT mp_sno = c.four_pi * n0_sno * inv_rho * (li_sno * li_sno) * F_sno;
+    const FT F_rai = M::fma(c->vent_b_rai * M::sqrt(v0_rai), M::exp2(c->vent_e_rai * l2_li_rai), c->vent_a_rai);
+    const FT F_sno = M::fma(c->vent_b_sno * c->sqrt_v0_sno, M::exp2(c->vent_e_sno * l2_li_sno), c->vent_a_sno);
+    const FT mp_rai = c->four_pi * c->n0_rai * inv_rho * (li_rai * li_rai) * F_rai;      // 4π n0/ρ λ⁻² F
+    const FT mp_sno = c->four_pi * n0_sno * inv_rho * (li_sno * li_sno) * F_sno;
     if (fl & CMX_1M_RAIN_EVAPORATION)
         o.s[CMX_1M_S_PHASE_CHANGE_VAP_RAI] = M::min(FT(0), (has_rai && S_l < FT(0)) ? mp_rai * S_l * G_l : FT(0));
     if (fl & (CMX_1M_SNOW_SUBLIMATION_ONLY | CMX_1M_SNOW_DEP_AND_SUBL)) {
         const FT rate = has_sno ? mp_sno * S_i * G_i : FT(0);
         o.s[CMX_1M_S_PHASE_CHANGE_VAP_SNO] = (fl & CMX_1M_SNOW_DEP_AND_SUBL) ? rate : M::min(FT(0), rate);
     }
-    const FT melt_f = c.K_therm * M::rcp(L_f) * dTf;
+    const FT melt_f = c->K_therm * M::rcp(L_f) * dTf;
     if (fl & CMX_1M_CLOUD_ICE_MELT)
-        o.s[CMX_1M_S_MELT_ICL_LCL] = (has_icl && above_freezing) ? c.four_pi * c.n0_icl * inv_rho * melt_f * (li_icl * li_icl) : FT(0);
+        o.s[CMX_1M_S_MELT_ICL_LCL] = (has_icl && above_freezing) ? c->four_pi * c->n0_icl * inv_rho * melt_f * (li_icl * li_icl) : FT(0);
     if (fl & CMX_1M_SNOW_MELT) o.s[CMX_1M_S_MELT_SNO_RAI] = (has_sno && above_freezing) ? mp_sno * melt_f : FT(0);
     return o;
 }
@@ -377,17 +384,19 @@ template <typename FT> __device__ __forceinline__ void mp1m_aggregate_direct(con
 template <typename FT, int VEC, uint32_t FLAGS = kRuntimeFlags>
 __global__ __launch_bounds__(kBlock) void mp1m_tendencies_kernel(const Mp1mConsts<FT> c, const Mp1mIn<FT> in,
                                                                  const Mp1mOut<FT> out, const int64_t nvec) {
-    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= nvec) return;
     FT rho[VEC], T[VEC], q_tot[VEC], q_lcl[VEC], q_icl[VEC], q_rai[VEC], q_sno[VEC];
-    load_col<FT, VEC>(in.rho, i, rho); load_col<FT, VEC>(in.T, i, T); load_col<FT, VEC>(in.q_tot, i, q_tot);
-    load_col<FT, VEC>(in.q_lcl, i, q_lcl); load_col<FT, VEC>(in.q_icl, i, q_icl); load_col<FT, VEC>(in.q_rai, i, q_rai);
-    load_col<FT, VEC>(in.q_sno, i, q_sno);
+    if (i < nvec) {
+        load_col<FT, VEC>(in.rho, i, rho); load_col<FT, VEC>(in.T, i, T); load_col<FT, VEC>(in.q_tot, i, q_tot);
+        load_col<FT, VEC>(in.q_lcl, i, q_lcl); load_col<FT, VEC>(in.q_icl, i, q_icl); load_col<FT, VEC>(in.q_rai, i, q_rai);
+        load_col<FT, VEC>(in.q_sno, i, q_sno);
+    }
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS while the loads fly (every lane of the workgroup reaches the barrier inside); no-op for Float32
+    if (i >= nvec) return;
     FT dl[VEC], di[VEC], dr[VEC], ds[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
-        const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(c, rho[k], T[k], q_tot[k], q_lcl[k], q_icl[k], q_rai[k], q_sno[k]);
+        const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(front_consts<FT>(c), rho[k], T[k], q_tot[k], q_lcl[k], q_icl[k], q_rai[k], q_sno[k]);
         mp1m_aggregate_direct<FT>(p, dl[k], di[k], dr[k], ds[k]);
         if (any_nan(rho[k], q_tot[k], q_lcl[k], q_icl[k], q_rai[k], q_sno[k], T[k])) dl[k] = di[k] = dr[k] = ds[k] = Math<FT>::nan();
     }
@@ -414,7 +423,7 @@ __global__ __launch_bounds__(kBlock) void mp1m_linearized_kernel(const Mp1mConst
     const FT ql0 = in.q_lcl[i], qi0 = in.q_icl[i], qr0 = in.q_rai[i], qs0 = in.q_sno[i];
     FT T = in.T[i], ql = ql0, qi = qi0, qr = qr0, qs = qs0;
     for (int k = 0; k < a.nsub; ++k) {
-        const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(c, rho, T, q_tot, ql, qi, qr, qs);
+        const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(front_consts<FT>(c), rho, T, q_tot, ql, qi, qr, qs);
         const FT *S = p.s;
         // _linearize — BMT:269-379
         const FT il = M::rcp(M::max(a.q_min, ql)), ii = M::rcp(M::max(a.q_min, qi)), ir = M::rcp(M::max(a.q_min, qr)),
@@ -475,7 +484,7 @@ __global__ __launch_bounds__(kBlock) void mp1m_sources_kernel(const Mp1mConsts<F
     Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const Mp1mSrc<FT> p = mp1m_point<FT>(c, in.rho[i], in.T[i], in.q_tot[i], in.q_lcl[i], in.q_icl[i], in.q_rai[i], in.q_sno[i]);
+    const Mp1mSrc<FT> p = mp1m_point<FT>(front_consts<FT>(c), in.rho[i], in.T[i], in.q_tot[i], in.q_lcl[i], in.q_icl[i], in.q_rai[i], in.q_sno[i]);
 #pragma unroll
     for (int k = 0; k < CMX_MP1M_NSRC; ++k)
         if (out.col[k]) out.col[k][i] = p.s[k];
@@ -623,7 +632,7 @@ static int32_t tendencies_1m_entry(const MP *mp, const TH *tps, uint32_t flags, 
 template <typename FT, uint32_t FLAGS> struct Mp1mLayoutPolicy {
     static constexpr int NIN = 7, NOUT = 4, NAOS = 4;   // rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno → (dq_lcl_dt, dq_icl_dt, dq_rai_dt, dq_sno_dt)
     using Consts = Mp1mConsts<FT>;
-    static __device__ __forceinline__ void point(const Consts &c, const FT (&x)[NIN], FT (&y)[NOUT]) {
+    template <typename C> static __device__ __forceinline__ void point(const C &c, const FT (&x)[NIN], FT (&y)[NOUT]) {
         const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(c, x[0], x[1], x[2], x[3], x[4], x[5], x[6]);
         mp1m_aggregate_direct<FT>(p, y[0], y[1], y[2], y[3]);
         if (any_nan(x[0], x[2], x[3], x[4], x[5], x[6], x[1])) y[0] = y[1] = y[2] = y[3] = Math<FT>::nan();

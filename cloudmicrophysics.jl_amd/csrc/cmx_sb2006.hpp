@@ -239,8 +239,8 @@ __device__ __forceinline__ void sb2006_cloud_velocity(const CloudVelConsts<FT> &
 // log2 values: two log2 in, then every derived quantity is one exp2 (11 → 5-6 transcendentals).
 // Shared by the point function and by the flux-only evaluation of the column kernel (same instruction sequence → same bits).
 template <typename FT> struct SbRainPsd { FT l2_xr, l2_lam; };
-template <typename FT, bool LIMITED>
-__device__ __forceinline__ SbRainPsd<FT> sb2006_rain_psd(const SbConsts<FT> &c, FT L_rai, FT sN_rai) {
+template <typename FT, bool LIMITED, typename C>
+__device__ __forceinline__ SbRainPsd<FT> sb2006_rain_psd(const C &c, FT L_rai, FT sN_rai) {
     using M = Math<FT>;
     const FT l2_L = M::log2(L_rai), l2_N = M::log2(sN_rai);
     SbRainPsd<FT> p;
@@ -259,8 +259,8 @@ __device__ __forceinline__ SbRainPsd<FT> sb2006_rain_psd(const SbConsts<FT> &c, 
 }
 
 // ---- rain terminal velocity (CM2:685-719) from log2 λ; gated like the reference -----------------------------------------------
-template <typename FT, bool LIMITED, int VEL>
-__device__ __forceinline__ void sb2006_rain_velocity(const SbConsts<FT> &c, FT rho, FT rs_rho, FT l2_lam, bool no_N_rai, bool no_q_rai,
+template <typename FT, bool LIMITED, int VEL, typename C>
+__device__ __forceinline__ void sb2006_rain_velocity(const C &c, FT rho, FT rs_rho, FT l2_lam, bool no_N_rai, bool no_q_rai,
                                                      FT &vt_n, FT &vt_m) {
     using M = Math<FT>;
     vt_n = FT(0);
@@ -312,8 +312,8 @@ __device__ __forceinline__ void sb2006_rain_velocity(const SbConsts<FT> &c, FT r
 // the fused entry clamps first (BMT:828-837), the per-process entry passes raw values like the
 // reference's KA wrapper does.
 // ICE: the 2M+P3 entry passes the ice content into the vapour budget and cp_m (BMT:942 → :731-744); the warm-only entry has q_ice ≡ 0.
-template <typename FT, bool LIMITED, int VEL, bool ICE = false>
-__device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rho, FT T, FT q_tot,
+template <typename FT, bool LIMITED, int VEL, bool ICE = false, typename C>
+__device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, FT q_tot,
                                                     FT q_lcl, FT q_rai, FT N_lcl, FT N_rai,
                                                     FT n_lcl, FT n_rai, FT q_ice = FT(0), FT cpm_qi = FT(0)) {
     using M = Math<FT>;
@@ -325,6 +325,7 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
     r.inv_rho = inv_rho;
 
     // ---- thermodynamics: one p_sat(T) shared by cond/evap, S and G -----------------------------
+    const C &c = c0;
     const FT inv_T = M::rcp(T);
     const FT L_v = M::fma(c.dcp, T - c.T_0, c.LH_v0);                       // TD.latent_heat_vapor
     const FT l2_ps = M::fma(c.ps_a, M::log2(T * c.inv_T_tr), M::fma(c.ps_b, c.inv_T_tr - inv_T, c.ps_c0));
@@ -369,6 +370,7 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
     const FT one_m_tau = sq_lcl * inv_qsum;
     const FT l2_tau = M::log2(tau);
     {   // autoconversion CM2:396-427
+        const C &c = consts_after(c0, CMX_PHASE_DEP(G, inv_T));
         const FT x_lcl = M::min(c.x_star, x_lcl_raw);
         const FT tau_a = M::exp2(c.acnv_a * l2_tau);
         const FT phi_raw = keep(c.acnv_A * tau_a * M::exp2(c.acnv_b * M::log2(FT(1) - tau_a)));
@@ -384,6 +386,7 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
         r.au_dN_lcl = FT(-2) * r.au_dN_rai;
     }
     {   // cloud_liquid_self_collection CM2:488-501 (raw L_lcl = ρ q_lcl)
+        const C &c = consts_after(c0, CMX_PHASE_DEP(G, inv_T));
         const FT Lr = rho * q_lcl;
         const FT sc = -c.ksc * inv_rho * (Lr * Lr) - r.au_dN_lcl;
         r.lsc = no_q_lcl ? FT(0) : sc;
@@ -391,6 +394,7 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
         r.lsc_plus_au = no_q_lcl ? FT(0) : -c.ksc * inv_rho * (Lr * Lr);
     }
     {   // accretion CM2:445-470
+        const C &c = consts_after(c0, CMX_PHASE_DEP(G, inv_T));
         const FT phi_ac = keep(M::exp2(c.accr_c * (l2_tau - M::log2(tau + c.tau_0))));
         const FT k_ac = c.kcr_s * rs_rho * L_rai * phi_ac;
         const FT dq = keep(k_ac * L_lcl * inv_rho);          // dL_rai/ρ with dL_rai = kcr √(ρ0/ρ) L_lcl L_rai ϕ_ac
@@ -402,12 +406,14 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
     }
 
     // ---- rain PSD parameters, once (CM2:67-110), from the safe values ----------
-    const SbRainPsd<FT> psd = sb2006_rain_psd<FT, LIMITED>(c, L_rai, sN_rai);
+    const C &c_psd = consts_after(c0, CMX_PHASE_DEP(r.ac_dN_lcl, l2_tau));
+    const SbRainPsd<FT> psd = sb2006_rain_psd<FT, LIMITED>(c_psd, L_rai, sN_rai);
     const FT l2_xr = psd.l2_xr, l2_lam = psd.l2_lam;
-    const FT l2_Dr = (l2_xr + c.l2_Drc) * FT(1.0 / 3.0);
+    const FT l2_Dr = (l2_xr + c_psd.l2_Drc) * FT(1.0 / 3.0);
     const FT Dr = M::exp2(l2_Dr);                       // ∛(6 x̄_r/(π ρw)): CM2:588 and :809
     const bool no_N_rai = N_rai < eps;
     {   // rain_self_collection CM2:545-560 + rain_breakup CM2:579-601
+        const C &c = consts_after(c0, CMX_PHASE_DEP(r.ac_dN_lcl, l2_tau));
         // 1/Br = ∛(x̄_r/6) = Dr·∛(π ρw/36): κ_rr/Br = kappa_rr_K·Dr
         const FT pw = M::exp2(c.self_d * M::log2(M::fma(c.kappa_rr_K, Dr, FT(1))));
         const FT sc = -c.krr_s * rs_rho * N_rai * L_rai * pw;
@@ -419,6 +425,7 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
         r.rbr = gate ? FT(0) : -(phi_br + FT(1)) * r.rsc;
     }
     {   // rain_evaporation CM2:780-828
+        const C &c = consts_after(c0, CMX_PHASE_DEP(r.rbr, l2_xr));
         const FT l2_t = (c.l2_6xstar - l2_xr) * FT(1.0 / 3.0);            // t* = ∛(6 x*/x̄_r)
         const FT t_star = M::exp2(l2_t);
         // e^{−t*}/x̄_r in one exponential: both factors enter the number tendency only (Γ_incl does not appear in the mass one);
@@ -440,13 +447,14 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const SbConsts<FT> &c, FT rh
         r.evq = gate_q ? FT(0) : dq;
     }
     {   // number_tendency_from_mass_limits CM2:882-891 (cloud: xc_min/xc_max, rain: xr_min/xr_max)
+        const C &c = consts_after(c0, CMX_PHASE_DEP(r.evq, Dr));
         const FT tl = no_q_lcl ? FT(0) : clampv(n_lcl, q_lcl * c.inv_xc_max, q_lcl * c.inv_xc_min);
         r.na_lcl = (tl - n_lcl) * c.inv_tau_na;
         const FT tr = no_q_rai ? FT(0) : clampv(n_rai, q_rai * c.inv_xr_max, q_rai * c.inv_xr_min);
         r.na_rai = (tr - n_rai) * c.inv_tau_na;
     }
     // ---- rain terminal velocity (optional columns) ----------------------------------------------
-    sb2006_rain_velocity<FT, LIMITED, VEL>(c, rho, rs_rho, l2_lam, no_N_rai, no_q_rai, r.vt_n, r.vt_m);
+    sb2006_rain_velocity<FT, LIMITED, VEL>(consts_after(c0, CMX_PHASE_DEP(r.evq, Dr)), rho, rs_rho, l2_lam, no_N_rai, no_q_rai, r.vt_n, r.vt_m);
     return r;
 }
 

@@ -60,8 +60,8 @@ __device__ __forceinline__ SedFlux<FT> sed_fluxes(const CloudVelConsts<FT> &cv, 
 
 // flux-only evaluation of a raw point (the point after a workgroup's tile): clamps, rain PSD, fall speeds — the inline functions the
 // point function itself calls, on the same operands
-template <typename FT, bool LIMITED, int VEL, bool CLOUD>
-__device__ __forceinline__ SedFlux<FT> sed_fluxes_of_point(const SbConsts<FT> &c, const CloudVelConsts<FT> &cv, FT rho, FT q_lcl, FT n_lcl,
+template <typename FT, bool LIMITED, int VEL, bool CLOUD, typename C>
+__device__ __forceinline__ SedFlux<FT> sed_fluxes_of_point(const C &c, const CloudVelConsts<FT> &cv, FT rho, FT q_lcl, FT n_lcl,
                                                           FT q_rai, FT n_rai) {
     using M = Math<FT>;
     const FT eps = M::eps();
@@ -81,7 +81,6 @@ __device__ __forceinline__ SedFlux<FT> sed_fluxes_of_point(const SbConsts<FT> &c
 template <typename FT, bool LIMITED, int VEL, bool CLOUD, int VEC, int BS>
 __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(sizeof(FT) == 4 ? 5 : 2))) void sb2006_column_kernel(const SbConsts<FT> c, const CloudVelConsts<FT> cv, const SbColIO<FT> io,
                                                            const int64_t first, const int64_t nvec) {
-    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using M = Math<FT>;
     // fluxes of every lane's FIRST point, + slot BS for the point that follows the tile
     __shared__ __align__(16) FT halo[BS + 1][4];
@@ -102,12 +101,13 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(sizeof(FT) =
         load_col<FT, VEC, true>(io.q_rai + first, v, q_rai);
         load_col<FT, VEC, true>(io.n_rai + first, v, n_rai);
     }
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS while the loads fly (every lane of the workgroup reaches the barrier inside); no-op for Float32
     // the point after the tile (another workgroup's, or another launch's, first point) is evaluated here from the raw columns —
     // before the lane's own points, while nothing else is live in registers
     if (threadIdx.x == BS - 1) {
         const int64_t e = first + (tile0 + nvalid) * VEC;
         SedFlux<FT> f{FT(0), FT(0), FT(0), FT(0)};
-        if (e < io.n) f = sed_fluxes_of_point<FT, LIMITED, VEL, CLOUD>(c, cv, io.rho[e], io.q_lcl[e], io.n_lcl[e], io.q_rai[e], io.n_rai[e]);
+        if (e < io.n) f = sed_fluxes_of_point<FT, LIMITED, VEL, CLOUD>(front_consts<FT>(c), cv, io.rho[e], io.q_lcl[e], io.n_lcl[e], io.q_rai[e], io.n_rai[e]);
         halo[BS][0] = f.q_rai;
         halo[BS][1] = f.n_rai;
         halo[BS][2] = f.q_lcl;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(sizeof(FT) =
             const FT r_ = max0(rho[k]), qt = max0(q_tot[k]), ql = max0(q_lcl[k]);
             const FT qr = max0(q_rai[k]), nl = max0(n_lcl[k]), nr = max0(n_rai[k]);
             const bool poisoned = any_nan(rho[k], q_tot[k], q_lcl[k], n_lcl[k], q_rai[k], n_rai[k], T[k]);
-            const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL>(c, r_, T[k], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
+            const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL>(front_consts<FT>(c), r_, T[k], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
             F[k] = sed_fluxes<FT, CLOUD>(cv, r_, ql, nl, qr, nr, p.vt_n, p.vt_m);
             g[k] = io.inv_dz[lv] * p.inv_rho;                                  // 1/(ρ_k Δz_k)
             if (++lv == io.n_lev) lv = 0;

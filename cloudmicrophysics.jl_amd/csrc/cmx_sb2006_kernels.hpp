@@ -31,10 +31,13 @@ template <typename FT> struct SbProcOut { FT *col[CMX_SB2006_NPROC]; };
 // points, 13 concurrent HBM streams): a grid-stride loop over CUs×k resident workgroups keeps every wave of the
 // chip in the same load→compute→store phase and sustains only ≈59 % of the 8 TB/s peak, the same bytes moved by
 // short-lived workgroups ≈70–73 % (new waves start loading while older ones store; profiles/r01_probe.txt).
+// Float64 is VALU-bound (≈ 800 dependent instructions per point at 4 waves per SIMD).  A software-pipelined shape for it — a workgroup
+// walking 4 or 8 tiles in a loop, tile t+1's loads issued before tile t is computed, the table copy paid once — was measured in round
+// 2 and rejected: the loop carries the prefetched columns and hoisted invariants, 167–198 VGPRs against 125, 2–3 waves per SIMD
+// instead of 4, 3.50 ms against 3.06 (tools/valu_probe: a dependent v_fma_f64 issues every 11 cycles; what hides that is waves).
 template <typename FT, bool LIMITED, int VEL, int VEC, int BS = kBlock, int C = 1, bool NT = true>
 __global__ __launch_bounds__(BS) void sb2006_tendencies_kernel(const SbConsts<FT> c, const SbIn<FT> in,
                                                                const SbOut<FT> out, const int64_t nvec) {
-    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using M = Math<FT>;
     const int64_t base = ((int64_t)blockIdx.x * C) * BS + threadIdx.x;
     FT rho[C][VEC], T[C][VEC], q_tot[C][VEC], q_lcl[C][VEC], n_lcl[C][VEC], q_rai[C][VEC], n_rai[C][VEC];
@@ -51,6 +54,9 @@ __global__ __launch_bounds__(BS) void sb2006_tendencies_kernel(const SbConsts<FT
             load_col<FT, VEC, NT>(in.n_rai, i, n_rai[t]);
         }
     }
+    // Float64: exp2 / log2 tables → LDS while the loads fly (every lane of the workgroup reaches the barrier inside; same-box A/B
+    // 3.18 → 3.06 ms against the copy in front of the loads); no-op for Float32
+    Math<FT>::prepare();
 #pragma unroll
     for (int t = 0; t < C; ++t) {
         const int64_t i = base + (int64_t)t * BS;
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(BS) void sb2006_tendencies_kernel(const SbConsts<FT
             // a NaN in any input column poisons every output of the point (cmx_math.hpp any_nan)
             const bool poisoned = any_nan(rho[t][k], q_tot[t][k], q_lcl[t][k], n_lcl[t][k], q_rai[t][k], n_rai[t][k], T[t][k]);
             // N = ρ n — BMT:718-719
-            const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL>(c, r_, T[t][k], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
+            const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL>(front_consts<FT>(c), r_, T[t][k], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
             // sums of warm_rain_tendencies_2m — BMT:738-779.  The per-m³ number rates are added first and divided by ρ once (the
             // reference divides each term: same value to rounding, five multiplies fewer); autoconversion's −2·dN_rai cancels
             // against the same term inside cloud self-collection (CM2:499), so their sum is formed directly.
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(BS) void sb2006_tendencies_kernel(const SbConsts<FT
 template <typename FT, bool LIMITED> struct Sb2006LayoutPolicy {
     static constexpr int NIN = 7, NOUT = 4, NAOS = 8;       // rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai → dq_lcl, dn_lcl, dq_rai, dn_rai (+4 zero fields)
     using Consts = SbConsts<FT>;
-    static __device__ __forceinline__ void point(const Consts &c, const FT (&x)[NIN], FT (&y)[NOUT]) {
+    template <typename C> static __device__ __forceinline__ void point(const C &c, const FT (&x)[NIN], FT (&y)[NOUT]) {
         using M = Math<FT>;
         const FT r_ = max0(x[0]), qt = max0(x[2]), ql = max0(x[3]);
         const FT nl = max0(x[4]), qr = max0(x[5]), nr = max0(x[6]);
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void sb2006_process_kernel(const SbConsts<F
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const FT r_ = rho[i];
         const FT inv_r = M::rcp(r_);
-        const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL>(c, r_, T[i], q_tot[i], q_lcl[i], q_rai[i], N_lcl[i],
+        const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL>(front_consts<FT>(c), r_, T[i], q_tot[i], q_lcl[i], q_rai[i], N_lcl[i],
                                                              N_rai[i], N_lcl[i] * inv_r, N_rai[i] * inv_r);
         // NaN in → NaN out (cmx_math.hpp any_nan): the max(x, ϵ) floors of the process functions would hide it
         const FT poison = any_nan(q_tot[i], q_lcl[i], q_rai[i], N_lcl[i], N_rai[i], r_, T[i]) ? M::nan() : FT(0);

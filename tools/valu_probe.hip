@@ -22,6 +22,24 @@ template <int MODE> __global__ __launch_bounds__(256) void probe(float *out, flo
             if constexpr (MODE == 6) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[k]) : "v"((double)a), "v"((double)b));
             if constexpr (MODE == 7) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(v[k]) : "v"(f32x2{a, a}));
             if constexpr (MODE == 8) asm volatile("v_mul_f32 %0, %0, %1\n\tv_max_f32 %0, %0, %2" : "+v"(x[k]) : "v"(a), "v"(b));
+            // Float64 paths (round 2): what the table-driven exp2 / log2 and the Newton reciprocals are made of
+            if constexpr (MODE == 10) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[k]) : "v"((double)a));
+            if constexpr (MODE == 11) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[k]) : "v"((double)b));
+            if constexpr (MODE == 12) asm volatile("v_rcp_f64 %0, %0" : "+v"(d[k]));
+            if constexpr (MODE == 13) asm volatile("v_rsq_f64 %0, %0" : "+v"(d[k]));
+            if constexpr (MODE == 14) asm volatile("v_sqrt_f64 %0, %0" : "+v"(d[k]));
+            if constexpr (MODE == 15) asm volatile("v_ldexp_f64 %0, %0, %1" : "+v"(d[k]) : "v"(1));
+            if constexpr (MODE == 16) asm volatile("v_rndne_f64 %0, %0" : "+v"(d[k]));
+            if constexpr (MODE == 17) asm volatile("v_cvt_i32_f64 %1, %0\n\tv_cvt_f64_i32 %0, %1" : "+v"(d[k]), "+v"(x[k]));
+            if constexpr (MODE == 18) asm volatile("v_cmp_class_f64 vcc, %0, %1" : : "v"(d[k]), "v"(0x3) : "vcc");
+            if constexpr (MODE == 19) asm volatile("v_max_f64 %0, %0, %1" : "+v"(d[k]) : "v"((double)b));
+            if constexpr (MODE == 20) asm volatile("v_cmp_gt_f64 vcc, %0, %1\n\tv_cndmask_b32 %2, %2, %3, vcc" : "+v"(d[k]) : "v"((double)b), "v"(x[k]), "v"(a) : "vcc");
+            if constexpr (MODE == 21) asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(d[k]) : "v"((double)a), "v"((double)b));
+            if constexpr (MODE == 22) asm volatile("v_log_f32 %0, %0" : "+v"(x[k]));
+            if constexpr (MODE == 23) asm volatile("v_sqrt_f32 %0, %0" : "+v"(x[k]));
+            if constexpr (MODE == 24) asm volatile("v_cvt_f32_f64 %1, %0\n\tv_cvt_f64_f32 %0, %1" : "+v"(d[k]), "+v"(x[k]));
+            if constexpr (MODE == 25) asm volatile("v_readlane_b32 s20, %0, 3" : : "v"(x[k]) : "s20");
+            if constexpr (MODE == 26) asm volatile("v_mov_b32 %0, %1" : "+v"(x[k]) : "s"(a));
         }
     }
     float s = 0;
@@ -40,10 +58,47 @@ template <int MODE> void run(const char *name, int instr_per_iter, float *out) {
     const double instr_per_simd = waves_per_simd * (double)kIters * kUnroll * instr_per_iter;
     printf("%-14s %8.3f ms  -> %.2f cycles per wave64 instruction per SIMD (at 2.4 GHz)\n", name, ms, ms * 1e-3 * 2.4e9 / instr_per_simd);
 }
+// dependent-issue latency: CH independent v_fma_f64 (or v_fma_f32) chains per wave, W waves per SIMD
+template <int CH, bool F64> __global__ __launch_bounds__(64) void chain_probe(float *out, float a, float b, int iters) {
+    double d[CH]; float x[CH];
+    for (int k = 0; k < CH; ++k) { d[k] = threadIdx.x * 1e-3 + k; x[k] = (float)d[k]; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                if constexpr (F64) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[k]) : "v"((double)a), "v"((double)b));
+                else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[k]) : "v"(a), "v"(b));
+            }
+    }
+    float s = 0;
+    for (int k = 0; k < CH; ++k) s += (float)d[k] + x[k];
+    out[blockIdx.x * 64 + threadIdx.x] = s;
+}
+template <int CH, bool F64> void run_chain(int waves_per_simd, float *out) {
+    const int iters = 2048;
+    const int blocks = 256 * 4 * waves_per_simd;   // one-wave workgroups: W per SIMD when they spread evenly
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((chain_probe<CH, F64>), dim3(blocks), dim3(64), 0, 0, out, 1.0001f, 0.5f, iters);
+    hipEventRecord(e0);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((chain_probe<CH, F64>), dim3(blocks), dim3(64), 0, 0, out, 1.0001f, 0.5f, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    const double instr_per_wave = (double)iters * 8 * CH;
+    printf("%s chains/wave %d waves/SIMD %d: %.3f ms -> %.2f cycles per instruction per wave, %.2f per SIMD (at 2.4 GHz)\n", F64 ? "v_fma_f64" : "v_fma_f32", CH,
+           waves_per_simd, ms, ms * 1e-3 * 2.4e9 / instr_per_wave, ms * 1e-3 * 2.4e9 / (instr_per_wave * waves_per_simd));
+}
 int main() {
     float *out; hipMalloc(&out, 256 * 8 * 256 * sizeof(float));
     run<0>("v_fma_f32", 1, out); run<1>("v_pk_fma_f32", 1, out); run<2>("v_mul_f32", 1, out); run<7>("v_pk_mul_f32", 1, out);
     run<3>("v_exp_f32", 1, out); run<4>("v_rcp_f32", 1, out); run<5>("cmp+cndmask", 2, out); run<8>("mul+max", 2, out);
     run<6>("v_fma_f64", 1, out);
+    run<21>("v_fmac_f64", 1, out); run<10>("v_mul_f64", 1, out); run<11>("v_add_f64", 1, out); run<19>("v_max_f64", 1, out);
+    run<12>("v_rcp_f64", 1, out); run<13>("v_rsq_f64", 1, out); run<14>("v_sqrt_f64", 1, out); run<15>("v_ldexp_f64", 1, out);
+    run<16>("v_rndne_f64", 1, out); run<17>("cvt i32<->f64", 2, out); run<24>("cvt f32<->f64", 2, out); run<18>("v_cmp_class_f64", 1, out);
+    run<20>("cmp_f64+cndmask", 2, out); run<22>("v_log_f32", 1, out); run<23>("v_sqrt_f32", 1, out); run<25>("v_readlane_b32", 1, out);
+    run<26>("v_mov_b32 v,s", 1, out);
+    for (int w : {1, 2, 3, 4, 8}) { run_chain<1, true>(w, out); run_chain<2, true>(w, out); run_chain<4, true>(w, out); }
+    for (int w : {1, 2, 4}) { run_chain<1, false>(w, out); run_chain<2, false>(w, out); }
     return 0;
 }
