@@ -32,6 +32,9 @@ template <typename FT, int NIN, int NOUT> struct LayoutIO {
     double inv_seg_len;
 };
 
+#ifndef CMX_LAYOUT_F64_VEC
+#define CMX_LAYOUT_F64_VEC 1     // A/B switch (2: 16-byte accesses for Float64 as well)
+#endif
 constexpr int kLayoutBS = 128;   // lanes per workgroup of the adapter kernel
 
 template <typename FT, typename POLICY, int VEC, bool SEG, bool AOS, int BS = kLayoutBS>
@@ -113,7 +116,8 @@ static int32_t launch_layout(const typename POLICY::Consts &c, int64_t n_seg, in
     const int64_t n = n_seg * seg_len;
     if (n == 0) return CMX_OK;
     if (n_seg > 1 && (!in_stride || (out && !out_stride))) return CMX_ERR_BAD_ARG;
-    constexpr int VEC = Math<FT>::VEC;
+    // Float64: one point per lane, like the column kernels (VALU-bound; two points per lane are 290–300 VGPRs — 1 wave per SIMD)
+    constexpr int VEC = sizeof(FT) == 8 ? CMX_LAYOUT_F64_VEC : Math<FT>::VEC;
     bool vec_ok = seg_len % VEC == 0;
     LayoutIO<FT, NIN, NOUT> io{};
     for (int k = 0; k < NIN; ++k) {

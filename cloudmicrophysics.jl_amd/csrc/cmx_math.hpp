@@ -141,19 +141,9 @@ template <typename FT> __device__ __forceinline__ FT clampv(FT x, FT lo, FT hi) 
 // clamp_to_nonneg of a LOADED value: max(0, x) through v_med3_f32(x, 0, +Inf).  A plain fmax on a value that comes straight from
 // memory costs two instructions in IEEE mode (the compiler must quiet a possible signalling NaN first: v_max x, x); the median does
 // not need that, returns 0 for a NaN like v_max does (the NaN rule is applied separately), and its result counts as canonical.
-#ifndef CMX_MAX0_ASM
-#define CMX_MAX0_ASM 1
-#endif
-__device__ __forceinline__ float max0(float x) {
-#if CMX_MAX0_ASM
-    // written as an instruction: in some kernels the optimiser rewrites the builtin with these constants to canonicalize + v_max
-    float r;
-    asm("v_med3_f32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(__builtin_inff()));
-    return r;
-#else
-    return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff());
-#endif
-}
+// (Written as an inline-asm v_med3_f32 so that the optimiser cannot turn it back into canonicalize + v_max — it does in the 1-moment
+// kernels — it measured no faster there and 6 % slower in the LinearizedAverage kernel, round 2: the builtin stays.)
+__device__ __forceinline__ float max0(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
 __device__ __forceinline__ double max0(double x) { return Math<double>::max(0.0, x); }
 // the same for lo ≤ hi as ONE instruction (v_med3_f32: the median of three is the clamp); Float64 has no med3
 __device__ __forceinline__ float clamp_ordered(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
