@@ -175,8 +175,9 @@ template <typename T> using KernArg = const __attribute__((address_space(4))) T;
 template <typename T> struct is_kernarg { static constexpr bool value = false; };
 template <typename T> struct is_kernarg<const __attribute__((address_space(4))) T> { static constexpr bool value = true; };
 // the constants struct must be the FIRST kernel argument
-template <typename FT, typename CT> __device__ __forceinline__ decltype(auto) front_consts(const CT &c) {
-    if constexpr (sizeof(FT) == 8 && CMX_PHASE_CONSTS) return (*(KernArg<CT> *)__builtin_amdgcn_kernarg_segment_ptr());
+// (ALSO: a Float32 kernel whose constants overflow the SGPR file too — the 1-moment kernels with run-time option flags)
+template <typename FT, bool ALSO = false, typename CT> __device__ __forceinline__ decltype(auto) front_consts(const CT &c) {
+    if constexpr ((sizeof(FT) == 8 || ALSO) && CMX_PHASE_CONSTS) return (*(KernArg<CT> *)__builtin_amdgcn_kernarg_segment_ptr());
     else return (c);
 }
 // (a plain reference passes through: laundering the address of a by-value kernel argument would force a private copy of the struct)

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(kBlock) void mp1m_tendencies_kernel(const Mp1mConst
     FT dl[VEC], di[VEC], dr[VEC], ds[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
-        const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(front_consts<FT>(c), rho[k], T[k], q_tot[k], q_lcl[k], q_icl[k], q_rai[k], q_sno[k]);
+        const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(front_consts<FT, FLAGS == kRuntimeFlags>(c), rho[k], T[k], q_tot[k], q_lcl[k], q_icl[k], q_rai[k], q_sno[k]);
         mp1m_aggregate_direct<FT>(p, dl[k], di[k], dr[k], ds[k]);
         if (any_nan(rho[k], q_tot[k], q_lcl[k], q_icl[k], q_rai[k], q_sno[k], T[k])) dl[k] = di[k] = dr[k] = ds[k] = Math<FT>::nan();
     }
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(kBlock) void mp1m_linearized_kernel(const Mp1mConst
     const FT ql0 = in.q_lcl[i], qi0 = in.q_icl[i], qr0 = in.q_rai[i], qs0 = in.q_sno[i];
     FT T = in.T[i], ql = ql0, qi = qi0, qr = qr0, qs = qs0;
     for (int k = 0; k < a.nsub; ++k) {
-        const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(front_consts<FT>(c), rho, T, q_tot, ql, qi, qr, qs);
+        const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(front_consts<FT, FLAGS == kRuntimeFlags>(c), rho, T, q_tot, ql, qi, qr, qs);
         const FT *S = p.s;
         // _linearize — BMT:269-379
         const FT il = M::rcp(M::max(a.q_min, ql)), ii = M::rcp(M::max(a.q_min, qi)), ir = M::rcp(M::max(a.q_min, qr)),

@@ -53,7 +53,9 @@ for wl in sb2006 sb2006_column icenuc mp0m mp1m arg2000; do
     bench ${wl}_${dt} --workload $wl --dtype $dt --steps 20 --warmup 3
   done
 done
+bench sb2006_chen_f32 --workload sb2006_chen --dtype f32 --steps 20 --warmup 3
 for dt in f32 f64; do
+  bench p3_fused_${dt} --workload p3_fused --dtype $dt --points 10000000 --steps 5 --warmup 1
   bench p3_${dt} --workload p3 --dtype $dt --points 10000000 --steps 5 --warmup 1
   bench p3_selfcol_${dt} --workload p3_selfcol --dtype $dt --points 1000000 --steps 3 --warmup 1
   bench mp1m_lin_${dt} --workload mp1m_lin --dtype $dt --steps 10 --warmup 2
@@ -67,12 +69,15 @@ prof sb2006_column f32 100000000
 prof mp0m f32 100000000
 prof icenuc f32 100000000
 prof mp1m f32 100000000 valu
-prof mp1m f64 100000000
+prof mp1m f64 100000000 valu
 prof arg2000 f32 100000000 valu
 prof arg2000 f64 100000000
 prof p3 f64 10000000
 prof mp2m_p3 f64 1000000 valu
 prof sb2006_aos f32 100000000
+# instruction issue rates and dependent-issue latency (tools/valu_probe.hip), stream ceilings (tools/stream_probe.hip quick)
+[ -x tools/valu_probe ] && timeout 120 tools/valu_probe > gpurun_out/profiles/${TAG}_probe_valu.txt 2>&1
+[ -x tools/stream_probe ] && timeout 300 tools/stream_probe 100000000 20 slab pattern quick > gpurun_out/profiles/${TAG}_probe_streams.txt 2>&1
 ls gpurun_out/profiles
 echo "failed steps: $FAILED"
 exit $([ $FAILED -eq 0 ] && echo 0 || echo 1)
