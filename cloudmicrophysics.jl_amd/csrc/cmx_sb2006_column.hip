@@ -78,8 +78,11 @@ __device__ __forceinline__ SedFlux<FT> sed_fluxes_of_point(const C &c, const Clo
     return f;
 }
 
+#ifndef CMX_COL_F64_WAVES
+#define CMX_COL_F64_WAVES 2      // A/B switch: waves per SIMD the Float64 instantiation is compiled for
+#endif
 template <typename FT, bool LIMITED, int VEL, bool CLOUD, int VEC, int BS>
-__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(sizeof(FT) == 4 ? 5 : 2))) void sb2006_column_kernel(const SbConsts<FT> c, const CloudVelConsts<FT> cv, const SbColIO<FT> io,
+__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(sizeof(FT) == 4 ? 5 : CMX_COL_F64_WAVES))) void sb2006_column_kernel(const SbConsts<FT> c, const CloudVelConsts<FT> cv, const SbColIO<FT> io,
                                                            const int64_t first, const int64_t nvec) {
     using M = Math<FT>;
     // fluxes of every lane's FIRST point, + slot BS for the point that follows the tile
