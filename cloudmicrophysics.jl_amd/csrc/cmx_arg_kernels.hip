@@ -102,7 +102,7 @@ static ArgConsts<FT> make_arg_consts(const AP &ap, const AD &ad, const AI &aip, 
     return c;
 }
 
-// erfc for the activated fractions.  Float32: A&S 7.1.26 (|ε| ≤ 1.5e-7); Float64: OCML.
+// erfc for the activated NUMBER fractions.  Float32: A&S 7.1.26 (|ε| ≤ 1.5e-7); Float64: table-driven (below).
 template <typename FT> __device__ __forceinline__ FT erfc_dev(FT x);
 template <> __device__ __forceinline__ float erfc_dev<float>(float x) {
     using M = Math<float>;
@@ -112,7 +112,12 @@ template <> __device__ __forceinline__ float erfc_dev<float>(float x) {
     const float e = poly * M::exp2(-(ax * ax) * 1.4426950408889634f);
     return x >= 0.0f ? e : 2.0f - e;
 }
-template <> __device__ __forceinline__ double erfc_dev<double>(double x) { return ::erfc(x); }
+#ifndef CMX_ARG_LEAN_ERFC
+#define CMX_ARG_LEAN_ERFC 1      // 0: OCML erfc (A/B switch)
+#endif
+// Float64: the table-driven lean::erfc (cmx_lean_f64.hpp: relative error ≤ (2 + x²)·2e-16 up to 6.5; the reference's ½(1 − erf u) is
+// exactly 0 beyond u = 5.9) — 45 instructions against OCML's 135, five calls per state
+template <> __device__ __forceinline__ double erfc_dev<double>(double x) { return CMX_ARG_LEAN_ERFC ? lean::erfc(x) : ::erfc(x); }
 // erfc with RELATIVE accuracy, for the activated mass: the reference evaluates M_act with erfc itself (AA:319), so a small activated
 // fraction keeps its leading digits there (N_act is ½(1 − erf u), AA:257: absolute accuracy in the reference too, A&S above is its
 // match).  Float32: t·exp(−x² + P(t)), t = 1/(1 + x/2) (Chebyshev fit of Numerical Recipes' erfcc, fractional error < 1.2e-7; the
@@ -221,6 +226,10 @@ __device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, cons
     for (int k = 0; k < NM; ++k) {
         const FT u = M::fma(cm[k].u_c, dl0, cm[k].uc_sm);       // AA:255   (= ln(sm/smax)/fac, AA:316)
         o.n[k] = want_N ? cm[k].half_N * erfc_dev<FT>(u) : FT(0);                  // N ½ (1 − erf u)      AA:257
+        // Float64: one mode's erfc at a time — left alone the NM independent table-driven evaluations are interleaved and all their
+        // LDS reads hoisted (422 VGPRs for 5 modes × 2 states: one wave per SIMD).  The asm pins the mode's result here and, with its
+        // memory clobber, keeps the next mode's table reads behind it.
+        if constexpr (sizeof(FT) == 8 && CMX_ARG_LEAN_ERFC) asm volatile("" : "+v"(o.n[k]) : : "memory");
         o.m[k] = want_M ? cm[k].half_M * erfc_rel_dev<FT>(u - cm[k].fac) : FT(0); // M/2 erfc(u − fac)    AA:319
     }
     return o;
@@ -241,6 +250,7 @@ __global__ __launch_bounds__(kBlock) void arg_activation_kernel(const ArgConsts<
             if (io.N_ice) load_col<FT, VEC>(io.N_ice, i, Ni);
         }
     }
+    if constexpr (sizeof(FT) == 8 && CMX_ARG_LEAN_ERFC) lean::erfc_tab_fill();   // published by the barrier inside prepare()
     Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS while the loads fly (every lane of the workgroup reaches the barrier inside); no-op for Float32
     if (i >= nvec) return;
     FT sm[VEC], na[NM][VEC], ma[NM][VEC];
@@ -366,6 +376,7 @@ template <typename FT, int NM, bool SINKS>
 __global__ __launch_bounds__(kBlock) void arg_activation_columns_kernel(const ArgConsts<FT> c, const FT f1, const FT f2, const FT g1,
                                                                         const FT g2, const ArgIO<FT> io, const ArgColIO<FT> mc,
                                                                         const int64_t n) {
+    if constexpr (sizeof(FT) == 8 && CMX_ARG_LEAN_ERFC) lean::erfc_tab_fill();   // published by the barrier inside prepare()
     Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;

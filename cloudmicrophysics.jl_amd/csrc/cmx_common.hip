@@ -77,6 +77,7 @@ static int32_t column_sums(int32_t ncols, const FT *const *cols, int64_t n, doub
 // Diagnostic: the Float64 elementary functions of cmx_lean_f64.hpp evaluated on the device (tests/test_lean_math.py compares them with
 // libm in ulps; the host build of the same header is checked there too).
 __global__ __launch_bounds__(kBlock) void lean_eval_kernel(const int which, const int64_t n, const double *__restrict__ x, double *__restrict__ y) {
+    lean::erfc_tab_fill();
     Math<double>::prepare();
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(kBlock) void lean_eval_kernel(const int which, cons
         case 6: r = lean::rsqrt(v); break;
         case 7: r = lean::expm1(v); break;
         case 8: r = lean::log1p(v); break;
+        case 9: r = lean::erfc(v); break;
         default: break;
     }
     y[i] = r;
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void lean_eval_kernel(const int which, cons
 extern "C" {
 
 int32_t cmx_lean_eval_f64(int32_t which, int64_t n, const double *x, double *y, void *stream) {
-    if (which < 0 || which > 8 || n < 0) return CMX_ERR_BAD_ARG;
+    if (which < 0 || which > 9 || n < 0) return CMX_ERR_BAD_ARG;
     if (n > cmx::kMaxPoints) return CMX_ERR_UNSUPPORTED;
     if (n == 0) return CMX_OK;
     if (!x || !y) return CMX_ERR_BAD_ARG;
