@@ -16,11 +16,13 @@ namespace cmx {
 // (cmx_lean_f64.hpp) in Float64, OCML for the rest and for Float32
 template <typename FT> struct PM;
 template <> struct PM<double> {
-    // one-argument forms: OCML.  In the shape solver (a dozen call sites around the incomplete-gamma loops) the inlined lean
-    // routines push the kernel from 2 waves/SIMD to 1 (24 → 30 ms per 1e7 columns); the quadrature loops use the
-    // register-pinned lean forms below.
+    // one-argument forms (the shape solver's dozen call sites around the incomplete-gamma loops; the quadrature loops use the
+    // register-pinned lean forms below): the table-driven lean routines where the translation unit keeps their polynomial coefficients
+    // as SGPR literals (cmx_lean_f64.hpp CMX_LEAN_COEFS_IN_LDS = 0: 253 VGPRs, 2 waves per SIMD like the OCML build, 10 % fewer
+    // instructions — shape + fall speeds 41.7 → 38.5 ms per 1e7 columns, 2M + P3 27.9 → 26.7 ms per 1e6 states, same-box A/B round 2);
+    // OCML where the coefficients live in LDS (there the inlined lean routines cost 286 VGPRs — 1 wave per SIMD, 24 → 30 ms).
 #ifndef CMX_P3_LEAN_ONEARG
-#define CMX_P3_LEAN_ONEARG 0
+#define CMX_P3_LEAN_ONEARG (!CMX_LEAN_COEFS_IN_LDS)
 #endif
 #if CMX_P3_LEAN_ONEARG
     static __device__ __forceinline__ double log(double x) { return lean::log(x); }
