@@ -113,17 +113,41 @@ template <typename FT, typename PR> static P3Consts<FT> make_p3_consts(const PR 
 
 // UT.gamma_inc — Utilities.jl:93-144: series for x < a+1, Lentz continued fraction otherwise, both with a FIXED
 // number of terms (20 Float32 / 30 Float64).  The device evaluates the same truncations in cheaper arithmetic:
-//   * series: Σ_k x^k / (a(a+1)…(a+k)) with the reciprocal of (a+k) from rcp() instead of an IEEE division;
+//   * series: Σ_k x^k / (a(a+1)…(a+k)) as a fraction carried from the last term inwards (no division per term, see below);
 //   * continued fraction: the n-th convergent h_n = A_n/B_n of  1/(b₀+ a₁/(b₁+ a₂/(b₂+…)))  by the forward (Wallis)
 //     recurrence A_n = b_n A_{n−1} + a_n A_{n−2} — the value modified Lentz produces with two divisions per term —
 //     rescaled every kRescale terms; one reciprocal at the end.
 // `gamma_series` / `gamma_cf` return the bracketed sums WITHOUT the prefactor x^a e^{−x}/Γ(a).
+#ifndef CMX_P3_SERIES_NODIV
+#define CMX_P3_SERIES_NODIV 1      // 0: term-by-term with one reciprocal per term (round 1; A/B switch)
+#endif
 template <typename FT> __device__ __forceinline__ FT gamma_series_sum(FT a, FT x) {
     using P = PM<FT>;
+#if CMX_P3_SERIES_NODIV
+    // Σ_{k=0}^{K} x^k/(a(a+1)…(a+k)) = T₁/a with T_k = 1 + x T_{k+1}/(a+k), T_{K+1} = 1, carried as a fraction p/q from the last term
+    // inwards: p ← q(a+k) + x p, q ← q(a+k) — three instructions per term and NO reciprocal (the term-by-term form spends one per
+    // term: 8 instructions + a quarter-rate v_rcp in Float64), rescaled every kSeriesRescale terms ((a+k) ≤ 60: 6e17 / 8e8 growth).
+    constexpr int R = sizeof(FT) == 8 ? 10 : 5;
+    static_assert(P::kGammaIters % R == 0, "rescale period must divide the term count");
+    FT p = FT(1), q = FT(1);
+#pragma unroll 1
+    for (int k0 = P::kGammaIters; k0 > 0; k0 -= R) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const FT qa = q * (a + FT(k0 - j));
+            p = Math<FT>::fma(x, p, qa);
+            q = qa;
+        }
+        p *= P::rcp(q);
+        q = FT(1);
+    }
+    return p * P::rcp(a);
+#else
     FT term = P::rcp(a), sum = term;
 #pragma unroll 2
     for (int k = 1; k <= P::kGammaIters; ++k) { term *= x * P::rcp(a + FT(k)); sum += term; }
     return sum;
+#endif
 }
 template <typename FT> __device__ __forceinline__ FT gamma_cf_value(FT a, FT x) {
     using P = PM<FT>;
