@@ -94,6 +94,7 @@ __global__ __launch_bounds__(kBlock) void lean_eval_kernel(const int which, cons
         case 7: r = lean::expm1(v); break;
         case 8: r = lean::log1p(v); break;
         case 9: r = lean::erfc(v); break;
+        case 10: r = lean::lgamma_pos(v); break;
         default: break;
     }
     y[i] = r;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(kBlock) void lean_eval_kernel(const int which, cons
 extern "C" {
 
 int32_t cmx_lean_eval_f64(int32_t which, int64_t n, const double *x, double *y, void *stream) {
-    if (which < 0 || which > 9 || n < 0) return CMX_ERR_BAD_ARG;
+    if (which < 0 || which > 10 || n < 0) return CMX_ERR_BAD_ARG;
     if (n > cmx::kMaxPoints) return CMX_ERR_UNSUPPORTED;
     if (n == 0) return CMX_OK;
     if (!x || !y) return CMX_ERR_BAD_ARG;

@@ -31,7 +31,11 @@ template <> struct PM<double> {
     static __device__ __forceinline__ double log(double x) { return ::log(x); }
     static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
 #endif
+#if CMX_P3_LEAN_ONEARG
+    static __device__ __forceinline__ double lgamma(double x) { return lean::lgamma_pos(x); }   // every argument here is > 0 (μ + 1, μ + b + n + 1, 1 + b_j)
+#else
     static __device__ __forceinline__ double lgamma(double x) { return ::lgamma(x); }
+#endif
     static __device__ __forceinline__ double expm1(double x) { return ::expm1(x); }
     static __device__ __forceinline__ double log1p(double x) { return ::log1p(x); }
     static __device__ __forceinline__ double pow(double x, double y) { return ::pow(x, y); }

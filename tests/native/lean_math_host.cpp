@@ -15,6 +15,7 @@ extern "C" void lean_eval(int which, int64_t n, const double *x, double *y) {
             case 7: y[i] = L::expm1(x[i]); break;
             case 8: y[i] = L::log1p(x[i]); break;
             case 9: y[i] = L::erfc(x[i]); break;
+            case 10: y[i] = L::lgamma_pos(x[i]); break;
         }
     }
 }

@@ -27,7 +27,7 @@ def lean(tmp_path_factory):
     return ev
 
 
-EXP2, LOG2, EXP, LOG, RCP, SQRT, RSQRT, EXPM1, LOG1P, ERFC = range(10)
+EXP2, LOG2, EXP, LOG, RCP, SQRT, RSQRT, EXPM1, LOG1P, ERFC, LGAMMA = range(11)
 
 
 def ulps(y, r):
@@ -77,6 +77,20 @@ def test_erfc(lean):
     assert np.all(y >= r * (1 - 1e-13)) and np.all(y <= r * (x / 6.5) * (1 + 1e-13)) and np.all(y < 4.1e-20)
     with np.errstate(all="ignore"):
         np.testing.assert_array_equal(lean(ERFC, [0.0, -0.0, np.inf, -np.inf, np.nan, 40.0, -40.0]), [1.0, 1.0, 0.0, 2.0, np.nan, 0.0, 2.0])
+
+
+def test_lgamma_pos(lean):
+    """ln Γ(z), z > 0 (Stirling at z + 7): absolute error ≤ 1.5e-14 on (0, 12] — the P3 shape solver's range — and relative ≤ 1e-15
+    beyond 12, against mpmath."""
+    import mpmath as mp
+    mp.mp.dps = 40
+    rng = np.random.default_rng(13)
+    x = np.concatenate([rng.uniform(1e-6, 12, 4000), [1.0, 2.0, 0.5, 7.999999, 8.0, 8.000001]])
+    y = lean(LGAMMA, x)
+    assert max(abs(float(mp.mpf(float(yi)) - mp.loggamma(mp.mpf(float(xi))))) for xi, yi in zip(x, y)) < 1.5e-14
+    x = np.exp(rng.uniform(np.log(12), np.log(1e12), 2000))
+    y = lean(LGAMMA, x)
+    assert max(abs(float((mp.mpf(float(yi)) - mp.loggamma(mp.mpf(float(xi)))) / mp.loggamma(mp.mpf(float(xi))))) for xi, yi in zip(x, y)) < 1e-15
 
 
 def test_pinned_table_forms(lean):
@@ -150,3 +164,8 @@ def test_device_special_values(dev_lean):
 @pytest.mark.gpu
 def test_device_erfc(dev_lean):
     test_erfc(dev_lean)
+
+
+@pytest.mark.gpu
+def test_device_lgamma_pos(dev_lean):
+    test_lgamma_pos(dev_lean)
