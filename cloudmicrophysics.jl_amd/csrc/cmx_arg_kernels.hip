@@ -142,6 +142,9 @@ template <> __device__ __forceinline__ float erfc_rel_dev<float>(float x) {
 }
 template <> __device__ __forceinline__ double erfc_rel_dev<double>(double x) { return ::erfc(x); }
 
+#ifndef CMX_ARG_P2_ROOTS
+#define CMX_ARG_P2_ROOTS 1      // A/B switch for the p2 = ¾ path of the Float64 S_max sum (arg_point)
+#endif
 template <typename FT> struct ArgIO {
     const FT *T, *p, *w, *q_tot, *q_liq, *q_ice, *N_liq, *N_ice;
     FT *N_act[CMX_ARG_MAX_MODES], *M_act[CMX_ARG_MAX_MODES], *S_max;
@@ -194,10 +197,21 @@ __device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, cons
     // multiply, one FMA, one log2, one exp2 and one accumulating FMA
     FT sum1 = FT(0), sum2 = FT(0);
 #pragma unroll
-    for (int k = 0; k < NM; ++k) {
-        sum1 += cm[k].c1;
-        const FT eta = X * cm[k].inv_N;
-        sum2 = M::fma(cm[k].c2, M::exp2(-c.p2 * M::log2(M::fma(FT(3), zeta, eta))), sum2);
+    for (int k = 0; k < NM; ++k) sum1 += cm[k].c1;
+    if (sizeof(FT) == 8 && CMX_ARG_P2_ROOTS && c.p2 == FT(0.75)) {
+        // Float64 with ARG2000's own exponent p2 = ¾ (a wave-uniform test): y^(−¾) = t·√t with t = 1/√y — a reciprocal square root and
+        // a square root (hardware seed + Newton steps, ≈ 30 instructions) instead of a table-driven log2 and exp2 (≈ 45) per mode
+#pragma unroll
+        for (int k = 0; k < NM; ++k) {
+            const FT t = M::rsqrt(M::fma(FT(3), zeta, X * cm[k].inv_N));
+            sum2 = M::fma(cm[k].c2, t * M::sqrt(t), sum2);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NM; ++k) {
+            const FT eta = X * cm[k].inv_N;
+            sum2 = M::fma(cm[k].c2, M::exp2(-c.p2 * M::log2(M::fma(FT(3), zeta, eta))), sum2);
+        }
     }
     const FT tmp = (Am15 * Am15) * M::fma(A3p2, sum2, Z1 * sum1);
     const FT S_arg = M::rsqrt(tmp);                                                                        // AA:185
