@@ -51,6 +51,15 @@ template <> struct PM<double> {
 #ifndef CMX_P3_TABLE_MATH
 #define CMX_P3_TABLE_MATH 1
 #endif
+#ifndef CMX_P3_SCALAR_COEFS
+#define CMX_P3_SCALAR_COEFS 0      // 1: the hot loops call the one-argument forms with SGPR-literal coefficients (needs CMX_LEAN_COEFS_IN_LDS=0)
+#endif
+#if CMX_P3_SCALAR_COEFS
+    struct Coefs {};
+    static __device__ __forceinline__ Coefs coefs() { return {}; }
+    static __device__ __forceinline__ double exp(double x, const Coefs &) { return lean::exp(x); }
+    static __device__ __forceinline__ double log(double x, const Coefs &) { return lean::log(x); }
+#else
 #if CMX_P3_TABLE_MATH
     using Coefs = lean::TabCoefs;
     static __device__ __forceinline__ Coefs coefs() { return lean::tab_coefs(); }
@@ -58,9 +67,10 @@ template <> struct PM<double> {
     using Coefs = lean::PinnedCoefs;
     static __device__ __forceinline__ Coefs coefs() { return lean::pinned_coefs(); }
 #endif
-    static __device__ __forceinline__ void pin(double &x) { lean::pin(x); }
     static __device__ __forceinline__ double exp(double x, const Coefs &k) { return lean::exp(x, k); }
     static __device__ __forceinline__ double log(double x, const Coefs &k) { return lean::log(x, k); }
+#endif
+    static __device__ __forceinline__ void pin(double &x) { lean::pin(x); }
     static constexpr int kBrent = 10, kGammaIters = 30;      // P3_size_distribution.jl:311, Utilities.jl:104
     static constexpr int kRescale = 6;                        // continued-fraction rescale period (b ≤ 1e8 → 1e48 growth)
     static constexpr double eps() { return 2.220446049250313e-16; }
