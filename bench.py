@@ -575,7 +575,10 @@ def main():
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # CMX_BENCH_FORCE_DIST=1 (tests/test_bench_gpu.py, under torchrun with one rank): take the process-group path at world size 1 too,
+    # so that the RCCL initialisation, barrier and reductions of the N > 1 job run on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("CMX_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
         else:
@@ -600,7 +603,7 @@ def main():
             sharding.global_diagnostics(desc["diag_cols"])
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -620,7 +623,7 @@ def main():
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     tot = torch.tensor([float(n)], dtype=torch.float64, device=red_dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)     # the points all ranks processed per step (layout workloads round per rank)
     elapsed = float(t.item())
@@ -655,7 +658,7 @@ def main():
             cols_np = [np.ascontiguousarray(c[:m].cpu().numpy()) for c in state]
             line["cpu_baseline"] = cpu_baseline(args, cols_np, desc, cpu_run)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

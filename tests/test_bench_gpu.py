@@ -58,3 +58,24 @@ def test_two_ranks_sharing_this_gpu_gloo_test_mode(scaling):
     per = d["config"]["points_per_gpu"]
     assert per == (1000003 if scaling == "weak" else 500224)        # shard_bounds(1000003, 0, 2): 256-point-aligned halves
     assert d["value"] == pytest.approx(d["config"]["points_total"] * 3 / (d["ms_per_step"] * 3e-3), rel=1e-9)
+
+
+def test_rccl_process_group_path_with_one_rank():
+    """The process-group calls of the N > 1 job — `init_process_group("nccl", device_id=…)` (RCCL), the barrier, the MAX / SUM
+    all-reduces on device tensors, `destroy_process_group` — on a 1-GPU box: bench.py under torchrun with ONE rank and
+    CMX_BENCH_FORCE_DIST=1 (two ranks cannot share a GPU under RCCL; the two-rank arithmetic is the gloo test above)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, CMX_BENCH_FORCE_DIST="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(REPO / "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--settle", "2",
+                        "--points", "1000003", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["points_total"] == 1000003 and d["value"] > 0
