@@ -30,6 +30,14 @@ def lean(tmp_path_factory):
 EXP2, LOG2, EXP, LOG, RCP, SQRT, RSQRT, EXPM1, LOG1P, ERFC, LGAMMA = range(11)
 
 
+@pytest.mark.parametrize("script", ["gen_lean_tables.py", "gen_erfc_table.py"])
+def test_generated_tables_are_current(script):
+    """csrc/cmx_lean_tables.inc and csrc/cmx_erfc_table.inc are what their generators (mpmath) write."""
+    import sys
+    r = subprocess.run([sys.executable, str(REPO / "tools" / script), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def ulps(y, r):
     with np.errstate(all="ignore"):
         return np.nanmax(np.abs(y - r) / np.spacing(np.abs(r)))
