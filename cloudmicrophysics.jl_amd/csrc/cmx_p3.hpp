@@ -132,6 +132,9 @@ template <typename FT, typename PR> static P3Consts<FT> make_p3_consts(const PR 
 //     recurrence A_n = b_n A_{n−1} + a_n A_{n−2} — the value modified Lentz produces with two divisions per term —
 //     rescaled every kRescale terms; one reciprocal at the end.
 // `gamma_series` / `gamma_cf` return the bracketed sums WITHOUT the prefactor x^a e^{−x}/Γ(a).
+#ifndef CMX_P3_CF_EARLY_EXIT
+#define CMX_P3_CF_EARLY_EXIT 1      // A/B switch
+#endif
 #ifndef CMX_P3_SERIES_NODIV
 #define CMX_P3_SERIES_NODIV 1      // 0: term-by-term with one reciprocal per term (round 1; A/B switch)
 #endif
@@ -169,6 +172,9 @@ template <typename FT> __device__ __forceinline__ FT gamma_cf_value(FT a, FT x) 
     // h₀ = 1/b₀:  A₀ = 1, B₀ = b₀;  A₋₁ = 0, B₋₁ = 1
     const FT b0 = x + FT(1) - a;
     FT Am = FT(0), Bm = FT(1), A = FT(1), B = b0;
+#if CMX_P3_CF_EARLY_EXIT
+    FT A_prev = FT(0);
+#endif
 #pragma unroll 1
     for (int k0 = 0; k0 < P::kGammaIters; k0 += P::kRescale) {
 #pragma unroll
@@ -180,6 +186,16 @@ template <typename FT> __device__ __forceinline__ FT gamma_cf_value(FT a, FT x) 
         }
         const FT r = P::rcp(B);
         A *= r; Am *= r; Bm *= r; B = FT(1);
+#if CMX_P3_CF_EARLY_EXIT
+        // the reference's 20 / 30 terms are an upper bound: stop once the convergent no longer moves for ANY lane of the wave that is in
+        // this loop (after a rescale A IS the convergent; a NaN compares unequal forever and runs the full count)
+        // Float32 only (same-box A/B, shape + fall speeds per 1e7 columns: 13.1 → 11.75 ms; Float64 reaches eps only near the full count:
+        // 29.5 → 29.6 ms with the test)
+        if constexpr (sizeof(FT) == 4) {
+            if (__all(P::abs(A - A_prev) <= P::eps() * P::abs(A))) break;
+            A_prev = A;
+        }
+#endif
     }
     return A;
 }
