@@ -135,6 +135,9 @@ template <typename FT, typename PR> static P3Consts<FT> make_p3_consts(const PR 
 #ifndef CMX_P3_CF_EARLY_EXIT
 #define CMX_P3_CF_EARLY_EXIT 1      // A/B switch
 #endif
+#ifndef CMX_P3_SERIES_FWD_F32
+#define CMX_P3_SERIES_FWD_F32 1      // A/B switch
+#endif
 #ifndef CMX_P3_SERIES_NODIV
 #define CMX_P3_SERIES_NODIV 1      // 0: term-by-term with one reciprocal per term (round 1; A/B switch)
 #endif
@@ -146,6 +149,28 @@ template <typename FT> __device__ __forceinline__ FT gamma_series_sum(FT a, FT x
     // term: 8 instructions + a quarter-rate v_rcp in Float64), rescaled every kSeriesRescale terms ((a+k) ≤ 60: 6e17 / 8e8 growth).
     constexpr int R = sizeof(FT) == 8 ? 10 : 5;
     static_assert(P::kGammaIters % R == 0, "rescale period must divide the term count");
+#if CMX_P3_SERIES_FWD_F32
+    if constexpr (sizeof(FT) == 4) {
+        // Float32: forwards, S_k = M_k/D_k with M_k = M_{k−1}(a+k) + x^k, D_k = D_{k−1}(a+k) — four instructions per term, but the
+        // terms fall monotonically (x < a + 1), so the wave can stop once x^k ≤ eps·M_k for all of its lanes in this loop
+        FT M = FT(1), D = a, X = FT(1);
+#pragma unroll 1
+        for (int k0 = 0; k0 < P::kGammaIters; k0 += R) {
+#pragma unroll
+            for (int j = 1; j <= R; ++j) {
+                const FT ak = a + FT(k0 + j);
+                X *= x;
+                M = Math<FT>::fma(M, ak, X);
+                D *= ak;
+            }
+            const bool done = X <= P::eps() * M;
+            const FT r = P::rcp(D);
+            M *= r; X *= r; D = FT(1);
+            if (__all(done)) break;
+        }
+        return M;       // D == 1
+    }
+#endif
     FT p = FT(1), q = FT(1);
 #pragma unroll 1
     for (int k0 = P::kGammaIters; k0 > 0; k0 -= R) {
