@@ -413,7 +413,7 @@ __global__ __launch_bounds__(kBlock) void mp1m_tendencies_kernel(const Mp1mConst
 template <typename FT> struct Mp1mLinArgs { FT q_min, dt, dt_sub, inv_dt_sub, inv_dt, Lv_over_cp, Ls_over_cp; int32_t nsub; };
 
 template <typename FT, uint32_t FLAGS = kRuntimeFlags>
-__global__ __launch_bounds__(kBlock) void mp1m_linearized_kernel(const Mp1mConsts<FT> c, const Mp1mLinArgs<FT> a, const Mp1mIn<FT> in,
+__global__ __launch_bounds__(kBlock) void mp1m_linearized_kernel(const Mp1mConsts<FT> c, const Mp1mLinArgs<FT> a0, const Mp1mIn<FT> in,
                                                                  const Mp1mOut<FT> out, const int64_t n) {
     Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using M = Math<FT>;
@@ -422,9 +422,13 @@ __global__ __launch_bounds__(kBlock) void mp1m_linearized_kernel(const Mp1mConst
     const FT rho = in.rho[i], q_tot = in.q_tot[i];
     const FT ql0 = in.q_lcl[i], qi0 = in.q_icl[i], qr0 = in.q_rai[i], qs0 = in.q_sno[i];
     FT T = in.T[i], ql = ql0, qi = qi0, qr = qr0, qs = qs0;
-    for (int k = 0; k < a.nsub; ++k) {
+    constexpr size_t kArgsOffset = (sizeof(Mp1mConsts<FT>) + alignof(Mp1mLinArgs<FT>) - 1) / alignof(Mp1mLinArgs<FT>) * alignof(Mp1mLinArgs<FT>);
+    const int nsub = a0.nsub;
+    for (int k = 0; k < nsub; ++k) {
         const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(front_consts<FT, FLAGS == kRuntimeFlags>(c), rho, T, q_tot, ql, qi, qr, qs);
         const FT *S = p.s;
+        // Float64: the step's own constants (second kernel argument) are read after the point function, like a phase of it
+        const auto &a = consts_after(kernarg_at<FT, kArgsOffset>(a0), p.qsat_i);
         // _linearize — BMT:269-379
         const FT il = M::rcp(M::max(a.q_min, ql)), ii = M::rcp(M::max(a.q_min, qi)), ir = M::rcp(M::max(a.q_min, qr)),
                  is = M::rcp(M::max(a.q_min, qs));
@@ -474,8 +478,8 @@ __global__ __launch_bounds__(kBlock) void mp1m_linearized_kernel(const Mp1mConst
         T += (a.Lv_over_cp * (dl + dr) + a.Ls_over_cp * (di + ds)) * a.dt_sub;
     }
     const FT poison = any_nan(rho, q_tot, ql0, qi0, qr0, qs0, in.T[i]) ? M::nan() : FT(0);   // NaN in → NaN out (cmx_math.hpp any_nan)
-    out.dq_lcl[i] = (ql - ql0) * a.inv_dt + poison; out.dq_icl[i] = (qi - qi0) * a.inv_dt + poison;
-    out.dq_rai[i] = (qr - qr0) * a.inv_dt + poison; out.dq_sno[i] = (qs - qs0) * a.inv_dt + poison;
+    out.dq_lcl[i] = (ql - ql0) * a0.inv_dt + poison; out.dq_icl[i] = (qi - qi0) * a0.inv_dt + poison;
+    out.dq_rai[i] = (qr - qr0) * a0.inv_dt + poison; out.dq_sno[i] = (qs - qs0) * a0.inv_dt + poison;
 }
 
 template <typename FT>
