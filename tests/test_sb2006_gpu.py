@@ -283,12 +283,14 @@ def test_column_sums(dev):
 
 
 # ---- BASELINE.json full size: 1e8 Float32 points, size-independent properties -----------------------
-def test_full_size_1e8_f32_properties(dev, oracle):
+@pytest.mark.parametrize("ft", ["f32", "f64"])
+def test_full_size_1e8_properties(dev, oracle, ft):
+    """BASELINE config 2 at its full size: 1e8 Float32 points, and the same in Float64 (the reference's own precision: "+F64 run")."""
     import cmx
     from cmx import synthetic
     n = 100_000_000
-    st = synthetic.sb2006_state(n, dtype=torch.float32, device=dev, seed=1234)
-    mp, tps = P.Microphysics2MParams("f32"), P.ThermodynamicsParameters("f32")
+    st = synthetic.sb2006_state(n, dtype=torch.float32 if ft == "f32" else torch.float64, device=dev, seed=1234)
+    mp, tps = P.Microphysics2MParams(ft), P.ThermodynamicsParameters(ft)
     call = lambda cols: cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), mp, tps, *cols, vel=cmx.SB2006VelType)  # noqa: E731
     full = call(st)
     torch.cuda.synchronize()
@@ -322,10 +324,10 @@ def test_full_size_1e8_f32_properties(dev, oracle):
     # (5) oracle on a strided sample of ~1e6 of the SAME points (inputs copied back bit-for-bit)
     stride = 97
     samp = [c[::stride].contiguous().cpu().numpy() for c in st]
-    ref = _oracle_fused(oracle, "f32", True, "sb", samp)
+    ref = _oracle_fused(oracle, ft, True, "sb", samp)
     got = {k: v[::stride].contiguous().cpu().numpy() for k, v in full._asdict().items()}
-    rep = parity.assert_parity(got, ref, parity.RTOL["f32"], what="1e8 f32 strided sample")
-    print(f"\n[parity 1e8 f32, {samp[0].size} sampled points] max scaled err {rep}")
+    rep = parity.assert_parity(got, ref, parity.RTOL[ft], what=f"1e8 {ft} strided sample")
+    print(f"\n[parity 1e8 {ft}, {samp[0].size} sampled points] max scaled err {rep}")
 
 
 # ---- maximum sizes: more than 2^31 points in one call (64-bit indexing end to end) ----------------------------------
