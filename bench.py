@@ -6,8 +6,8 @@ out) over the rank's resident batch of synthetic grid points (default 1e8 Float3
 configuration BASELINE.json quotes the metric on).  Inputs are generated on the device before the timed
 region; nothing crosses PCIe inside it.
 
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--points P] [--dtype f32|f64] [--scaling weak|strong]
                     [--workload sb2006|sb2006_chen|sb2006_column|sb2006_aos|sb2006_fields|icenuc|mp0m|mp1m|mp1m_lin|arg2000|p3|p3_fused|p3_selfcol|mp2m_p3]
-                    [--workload sb2006|sb2006_column|sb2006_aos|sb2006_fields|icenuc|mp0m|mp1m|mp1m_lin|arg2000|p3|p3_selfcol|mp2m_p3]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
