@@ -89,8 +89,20 @@ template <> struct PM<float> {
     struct Coefs {};
     static __device__ __forceinline__ Coefs coefs() { return {}; }
     static __device__ __forceinline__ void pin(float &) {}
+    // hot-loop forms (quadrature integrands): the hardware v_exp_f32 / v_log_f32 with one multiply — 2 instructions instead of OCML's 15
+    // (expf) and 14 (logf), which spend the rest on the last ulp and on subnormals; the product x·log₂e is rounded once, so the
+    // relative error is ≈ 6e-8·(1 + |x| log₂e) (1e-5 at |x| = 100) — an integrand weight, well inside the 1e-3 Float32 bound.  The shape
+    // solver and the set-up code keep the one-argument OCML forms.  A/B switch: -DCMX_P3_F32_FAST_LOOPS=0.
+#ifndef CMX_P3_F32_FAST_LOOPS
+#define CMX_P3_F32_FAST_LOOPS 1
+#endif
+#if CMX_P3_F32_FAST_LOOPS
+    static __device__ __forceinline__ float exp(float x, const Coefs &) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+    static __device__ __forceinline__ float log(float x, const Coefs &) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+#else
     static __device__ __forceinline__ float exp(float x, const Coefs &) { return ::expf(x); }
     static __device__ __forceinline__ float log(float x, const Coefs &) { return ::logf(x); }
+#endif
     static __device__ __forceinline__ float rcp(float d) {
         const float r = __builtin_amdgcn_rcpf(d);
         return __builtin_fmaf(r, __builtin_fmaf(-d, r, 1.0f), r);
