@@ -382,6 +382,7 @@ template <typename FT> struct P3VelConsts {
     FT g0, g1;          // unrimed / dense-rimed aspect factor: cbrt ϕ = exp(g0 + g1 logD)
     FT h0_num;          // partially rimed: cbrt ϕ = exp((h0_num − log Fu)/3 + β/3 logD − ½ log area)
     FT pi_4, gamma_area, sigma_area;
+    FT sqrt_gamma_pi, half_sigma;                        // collision radius of the non-spherical regime: √(γ/π)·D^(σ/2)
     FT p_lo, p_hi;      // FT(p), FT(1 − p)
     // ice_melt (P3_processes.jl:64-94): F_v = vent_a + vent_bc √(D v), vent_bc = b_v ∛(ν/D_v)/√ν; L_f(T) = LH_f0 + dcp_f (T − T_0)
     FT vent_a, vent_bc, K4, LH_f0, dcp_f, T_0, T_freeze;
@@ -415,6 +416,7 @@ static P3VelConsts<FT> make_p3_vel_consts(const PR &pr, const VR &vel, double p)
     v.g1 = (FT)((be - 1.5 * si) / 3.0);
     v.h0_num = (FT)std::log(3.0 * std::sqrt(pi) * al / (4.0 * ri));
     v.pi_4 = (FT)(pi / 4.0); v.gamma_area = (FT)ga; v.sigma_area = (FT)si;
+    v.sqrt_gamma_pi = (FT)std::sqrt(ga / pi); v.half_sigma = (FT)(0.5 * si);
     v.p_lo = (FT)p; v.p_hi = (FT)(1.0 - p);
     return v;
 }

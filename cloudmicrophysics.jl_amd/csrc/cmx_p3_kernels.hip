@@ -372,19 +372,23 @@ __global__ __launch_bounds__(kBlock) void p3_self_collection_kernel(const P3Cons
         auto eval = [&](FT x, FT &vv, FT &rr, FT &nn) {
             const FT logD = P::log(x, kc);
             const int reg = x < s.bnd[1] ? 0 : (unrimed ? 1 : (x < s.bnd[2] ? 1 : (x < s.bnd[3] ? 2 : 3)));
-            const FT sph = v.pi_4 * x * x;
-            FT area = sph, eA = FT(0);
-            if (reg == 1 || reg == 3) {
-                const FT non = v.gamma_area * P::exp(v.sigma_area * logD, kc);
-                area = reg == 1 ? non : s.F_rim * sph + (FT(1) - s.F_rim) * non;
-                if (ASPECT) eA = reg == 1 ? v.g0 + v.g1 * logD : h0 + h1 * logD - FT(0.5) * P::log(area, kc);
+            // collision radius r = √(area/π) and aspect factor: spherical regimes r = D/2 exactly; unrimed non-spherical area = γ D^σ:
+            // r = √(γ/π)·D^(σ/2) (one exponential, no square root); only the partially rimed regime needs the mixed area and its root
+            FT eA = FT(0);
+            rr = FT(0.5) * x;
+            if (reg == 1) {
+                rr = v.sqrt_gamma_pi * P::exp(v.half_sigma * logD, kc);
+                if (ASPECT) eA = v.g0 + v.g1 * logD;
+            } else if (reg == 3) {
+                const FT area = s.F_rim * (v.pi_4 * x * x) + (FT(1) - s.F_rim) * (v.gamma_area * P::exp(v.sigma_area * logD, kc));
+                rr = Math<FT>::sqrt(area * inv_pi);
+                if (ASPECT) eA = h0 + h1 * logD - FT(0.5) * P::log(area, kc);
             }
             const bool small = x <= v.cutoff;
             const FT E1 = small ? se + sb * logD : le1 + v.l_b1 * logD;
             const FT dE = small ? -v.s_c2 * x : (le2 - le1) + (v.l_b2 - v.l_b1) * logD - v.l_c2 * x;
             const FT A1 = small ? v.s_E : v.l_a1, A2 = small ? v.s_F : v.l_a2;
             vv = P::exp(eA + E1, kc) * (A1 + A2 * P::exp(dE, kc));
-            rr = Math<FT>::sqrt(area * inv_pi);
             nn = P::exp(logN0 + mu * logD - lam * x, kc);
         };
         FT total = FT(0);
