@@ -72,8 +72,9 @@ template <> struct Math<double> {
     static constexpr int VEC = 2;
     static constexpr double eps() { return 2.220446049250313e-16; }            // eps(Float64)
     static constexpr double eps_1m() { return 2.8126442852362996e-103; }      // cbrt(floatmin(Float64))
-    // FIRST statement of every kernel that evaluates Float64 functions, executed by every thread of the workgroup: copies the
-    // exp2 / log2 tables of cmx_lean_f64.hpp into LDS (3 KiB) and synchronises
+    // Once per kernel that evaluates Float64 functions, before the first of them and executed by EVERY thread of the workgroup (the
+    // streaming kernels issue their column loads first): copies the exp2 / log2 tables of cmx_lean_f64.hpp into LDS (3 KiB) and
+    // synchronises
     static __device__ __forceinline__ void prepare() { lean::tables_init(); }
     static __device__ __forceinline__ double exp2(double x) { return lean::exp2(x); }
     static __device__ __forceinline__ double log2(double x) { return lean::log2(x); }
