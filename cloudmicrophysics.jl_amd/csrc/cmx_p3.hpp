@@ -71,6 +71,8 @@ template <> struct PM<double> {
     static __device__ __forceinline__ double log(double x, const Coefs &k) { return lean::log(x, k); }
 #endif
     static __device__ __forceinline__ void pin(double &x) { lean::pin(x); }
+    static __device__ __forceinline__ double exp_fast(double x) { return exp(x); }       // Float64: the one-argument forms above
+    static __device__ __forceinline__ double log_fast(double x) { return log(x); }
     static constexpr int kBrent = 10, kGammaIters = 30;      // P3_size_distribution.jl:311, Utilities.jl:104
     static constexpr int kRescale = 6;                        // continued-fraction rescale period (b ≤ 1e8 → 1e48 growth)
     static constexpr double eps() { return 2.220446049250313e-16; }
@@ -89,6 +91,18 @@ template <> struct PM<float> {
     struct Coefs {};
     static __device__ __forceinline__ Coefs coefs() { return {}; }
     static __device__ __forceinline__ void pin(float &) {}
+    // the incomplete-gamma prefactor e^(a ln x − x − ln Γ(a)) — eight per residual evaluation of the shape solver: CMX_P3_F32_FAST_PREFACTOR=1
+    // takes the hardware forms there too (A/B switch)
+#ifndef CMX_P3_F32_FAST_PREFACTOR
+#define CMX_P3_F32_FAST_PREFACTOR 1
+#endif
+#if CMX_P3_F32_FAST_PREFACTOR
+    static __device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+    static __device__ __forceinline__ float log_fast(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+#else
+    static __device__ __forceinline__ float exp_fast(float x) { return ::expf(x); }
+    static __device__ __forceinline__ float log_fast(float x) { return ::logf(x); }
+#endif
     // hot-loop forms (quadrature integrands): the hardware v_exp_f32 / v_log_f32 with one multiply — 2 instructions instead of OCML's 15
     // (expf) and 14 (logf), which spend the rest on the last ulp and on subnormals; the product x·log₂e is rounded once, so the
     // relative error is ≈ 6e-8·(1 + |x| log₂e) (1e-5 at |x| = 100) — an integrand weight, well inside the 1e-3 Float32 bound.  The shape
@@ -240,7 +254,7 @@ template <typename FT> __device__ FT gamma_inc_dev(FT a, FT x, FT lgam_a, bool w
     using P = PM<FT>;
     if (x <= FT(0)) return want_P ? FT(0) : FT(1);
     if (isinf(x)) return want_P ? FT(1) : FT(0);
-    const FT factor = P::exp(a * P::log(x) - x - lgam_a);
+    const FT factor = P::exp_fast(a * P::log_fast(x) - x - lgam_a);
     const bool series = x < a + FT(1);
     const FT body = series ? gamma_series_sum<FT>(a, x) : gamma_cf_value<FT>(a, x);
     const FT pq = Math<FT>::min(Math<FT>::max(factor * body, FT(0)), FT(1));   // P on the series branch, Q on the other
