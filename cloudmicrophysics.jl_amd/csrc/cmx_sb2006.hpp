@@ -312,7 +312,15 @@ __device__ __forceinline__ void sb2006_rain_velocity(const C &c, FT rho, FT rs_r
 // the fused entry clamps first (BMT:828-837), the per-process entry passes raw values like the
 // reference's KA wrapper does.
 // ICE: the 2M+P3 entry passes the ice content into the vapour budget and cp_m (BMT:942 → :731-744); the warm-only entry has q_ice ≡ 0.
-template <typename FT, bool LIMITED, int VEL, bool ICE = false, typename C>
+// INTPOW: the three SB2006 exponents that are small integers in the published scheme — (1 − τᵃ)ᵇ with b = 3 (Eq. 6), (τ/(τ+τ₀))ᶜ with
+// c = 4 (Eq. 8), (1 + κ_rr/Br)ᵈ with d = −5 (Eq. 11) — by multiplication instead of exp2(e·log2 x): exact integer powers, and in
+// Float64 three table-driven log2 + exp2 pairs (≈ 45 instructions each) become 2–4 multiplies and one reciprocal.  The entry points set
+// it when the parameter struct holds exactly these values (sb_integer_exponents), otherwise the general form runs.
+template <typename WR> inline bool sb_integer_exponents(const WR &wr) {
+    const auto &sb = wr.seifert_beheng;
+    return sb.acnv.b == 3 && sb.accr.c == 4 && sb.self.d == -5;
+}
+template <typename FT, bool LIMITED, int VEL, bool ICE = false, bool INTPOW = false, typename C>
 __device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, FT q_tot,
                                                     FT q_lcl, FT q_rai, FT N_lcl, FT N_rai,
                                                     FT n_lcl, FT n_rai, FT q_ice = FT(0), FT cpm_qi = FT(0)) {
@@ -373,7 +381,10 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, F
         const C &c = consts_after(c0, CMX_PHASE_DEP(G, inv_T));
         const FT x_lcl = M::min(c.x_star, x_lcl_raw);
         const FT tau_a = M::exp2(c.acnv_a * l2_tau);
-        const FT phi_raw = keep(c.acnv_A * tau_a * M::exp2(c.acnv_b * M::log2(FT(1) - tau_a)));
+        FT pow_b;
+        if constexpr (INTPOW) { const FT u = FT(1) - tau_a; pow_b = u * u * u; }
+        else pow_b = M::exp2(c.acnv_b * M::log2(FT(1) - tau_a));
+        const FT phi_raw = keep(c.acnv_A * tau_a * pow_b);
         const FT phi_au = no_q_rai ? FT(0) : phi_raw;
         const FT u = (L_lcl * x_lcl) * c.sqrt_kfac;   // √(kcc/20/x*·ν-terms)·L·x̄: keeps L²x̄² inside the f32 range
         const FT inv_omt = M::rcp(one_m_tau);
@@ -395,7 +406,10 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, F
     }
     {   // accretion CM2:445-470
         const C &c = consts_after(c0, CMX_PHASE_DEP(G, inv_T));
-        const FT phi_ac = keep(M::exp2(c.accr_c * (l2_tau - M::log2(tau + c.tau_0))));
+        FT pow_c;
+        if constexpr (INTPOW) { const FT t = tau * M::rcp(tau + c.tau_0), t2 = t * t; pow_c = t2 * t2; }
+        else pow_c = M::exp2(c.accr_c * (l2_tau - M::log2(tau + c.tau_0)));
+        const FT phi_ac = keep(pow_c);
         const FT k_ac = c.kcr_s * rs_rho * L_rai * phi_ac;
         const FT dq = keep(k_ac * L_lcl * inv_rho);          // dL_rai/ρ with dL_rai = kcr √(ρ0/ρ) L_lcl L_rai ϕ_ac
         const FT dN = keep(-k_ac * sN_lcl);                  // −dL_rai / x̄_c with x̄_c = L_lcl / N_lcl: the L_lcl of dL_rai cancels
@@ -415,7 +429,9 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, F
     {   // rain_self_collection CM2:545-560 + rain_breakup CM2:579-601
         const C &c = consts_after(c0, CMX_PHASE_DEP(r.ac_dN_lcl, l2_tau));
         // 1/Br = ∛(x̄_r/6) = Dr·∛(π ρw/36): κ_rr/Br = kappa_rr_K·Dr
-        const FT pw = M::exp2(c.self_d * M::log2(M::fma(c.kappa_rr_K, Dr, FT(1))));
+        FT pw;
+        if constexpr (INTPOW) { const FT r1 = M::rcp(M::fma(c.kappa_rr_K, Dr, FT(1))), r2 = r1 * r1; pw = r2 * r2 * r1; }
+        else pw = M::exp2(c.self_d * M::log2(M::fma(c.kappa_rr_K, Dr, FT(1))));
         const FT sc = -c.krr_s * rs_rho * N_rai * L_rai * pw;
         const bool gate = no_q_rai || no_N_rai;
         r.rsc = gate ? FT(0) : sc;

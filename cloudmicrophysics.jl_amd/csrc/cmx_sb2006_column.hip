@@ -81,7 +81,7 @@ __device__ __forceinline__ SedFlux<FT> sed_fluxes_of_point(const C &c, const Clo
 #ifndef CMX_COL_F64_WAVES
 #define CMX_COL_F64_WAVES 2      // A/B switch: waves per SIMD the Float64 instantiation is compiled for
 #endif
-template <typename FT, bool LIMITED, int VEL, bool CLOUD, int VEC, int BS>
+template <typename FT, bool LIMITED, int VEL, bool CLOUD, int VEC, int BS, bool INTPOW = false>
 __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(sizeof(FT) == 4 ? 5 : CMX_COL_F64_WAVES))) void sb2006_column_kernel(const SbConsts<FT> c, const CloudVelConsts<FT> cv, const SbColIO<FT> io,
                                                            const int64_t first, const int64_t nvec) {
     using M = Math<FT>;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(sizeof(FT) =
             const FT r_ = max0(rho[k]), qt = max0(q_tot[k]), ql = max0(q_lcl[k]);
             const FT qr = max0(q_rai[k]), nl = max0(n_lcl[k]), nr = max0(n_rai[k]);
             const bool poisoned = any_nan(rho[k], q_tot[k], q_lcl[k], n_lcl[k], q_rai[k], n_rai[k], T[k]);
-            const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL>(front_consts<FT>(c), r_, T[k], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
+            const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL, false, INTPOW>(front_consts<FT>(c), r_, T[k], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
             F[k] = sed_fluxes<FT, CLOUD>(cv, r_, ql, nl, qr, nr, p.vt_n, p.vt_m);
             g[k] = io.inv_dz[lv] * p.inv_rho;                                  // 1/(ρ_k Δz_k)
             if (++lv == io.n_lev) lv = 0;
@@ -191,12 +191,16 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(sizeof(FT) =
 constexpr int kColBS = CMX_COLUMN_BS;
 
 template <typename FT, int VEC>
-static void launch_column(bool limited, int vel, bool cloud, const SbConsts<FT> &c, const CloudVelConsts<FT> &cv, const SbColIO<FT> &io,
+static void launch_column(bool limited, int vel, bool cloud, bool intpow, const SbConsts<FT> &c, const CloudVelConsts<FT> &cv, const SbColIO<FT> &io,
                           int64_t first, int64_t nvec, hipStream_t s) {
     if (nvec <= 0) return;
     const int64_t grid = (nvec + kColBS - 1) / kColBS;
-#define CMX_LAUNCH(L, V, C) \
-    hipLaunchKernelGGL((sb2006_column_kernel<FT, L, V, C, VEC, kColBS>), dim3((unsigned)grid), dim3(kColBS), 0, s, c, cv, io, first, nvec)
+    // intpow: the integer-exponent instantiation of the point function (cmx_sb2006.hpp INTPOW)
+#define CMX_LAUNCH(L, V, C)                                                                                                                          \
+    do {                                                                                                                                             \
+        if (intpow) hipLaunchKernelGGL((sb2006_column_kernel<FT, L, V, C, VEC, kColBS, true>), dim3((unsigned)grid), dim3(kColBS), 0, s, c, cv, io, first, nvec); \
+        else hipLaunchKernelGGL((sb2006_column_kernel<FT, L, V, C, VEC, kColBS>), dim3((unsigned)grid), dim3(kColBS), 0, s, c, cv, io, first, nvec);   \
+    } while (0)
 #define CMX_PICK(L, V) do { if (cloud) CMX_LAUNCH(L, V, true); else CMX_LAUNCH(L, V, false); } while (0)
     if (limited) {
         if (vel == VEL_SB) CMX_PICK(true, VEL_SB);
@@ -225,6 +229,7 @@ static int32_t column_entry(const WR *wr, const TH *tps, const VL *vel, const ST
         return CMX_ERR_BAD_ARG;
     if ((flags & CMX_SB2006_LIMITED) && !sb_limiters_ok(*wr)) return CMX_ERR_BAD_ARG;      // clamp_ordered needs ordered limiter pairs
     const SbConsts<FT> c = make_sb_consts<FT>(*wr, *tps, vel, (double)Math<FT>::eps_1m());
+    const bool intpow = sb_integer_exponents(*wr);
     CloudVelConsts<FT> cv{};
     if (cloud_vel) cv = make_cloud_vel_consts<FT>(wr->seifert_beheng.pdf_c, *cloud_vel);
     const SbColIO<FT> io{rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, dq_lcl, dn_lcl, dq_rai, dn_rai, inv_dz, precip, n, n_lev, 1.0 / (double)n_lev};
@@ -242,11 +247,11 @@ static int32_t column_entry(const WR *wr, const TH *tps, const VL *vel, const ST
     if (same_mis && VEC > 1) {
         const int64_t head = std::min<int64_t>(n, mis0 ? (int64_t)((16 - mis0) / sizeof(FT)) : 0);
         const int64_t body = ((n - head) / VEC) * VEC;
-        launch_column<FT, 1>(limited, velk, cloud, c, cv, io, 0, head, s);
-        launch_column<FT, VEC>(limited, velk, cloud, c, cv, io, head, body / VEC, s);
-        launch_column<FT, 1>(limited, velk, cloud, c, cv, io, head + body, n - head - body, s);
+        launch_column<FT, 1>(limited, velk, cloud, intpow, c, cv, io, 0, head, s);
+        launch_column<FT, VEC>(limited, velk, cloud, intpow, c, cv, io, head, body / VEC, s);
+        launch_column<FT, 1>(limited, velk, cloud, intpow, c, cv, io, head + body, n - head - body, s);
     } else {
-        launch_column<FT, 1>(limited, velk, cloud, c, cv, io, 0, n, s);
+        launch_column<FT, 1>(limited, velk, cloud, intpow, c, cv, io, 0, n, s);
     }
     CMX_HIP_TRY(hipGetLastError());
     return CMX_OK;

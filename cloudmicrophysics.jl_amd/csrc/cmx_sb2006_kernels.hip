@@ -24,14 +24,23 @@ constexpr int kTendBS = CMX_TEND_BS;   // lanes per workgroup of the fused tende
                                        // 263-instruction point function, 1e8 f32 points, three runs on one box: 128 → 0.883–0.885 ms, 64 → 0.887–0.902,
                                        // 512 → 0.894–0.923, 256 → 0.915–0.962 (256 was the optimum of the 350-instruction version)
 
+#ifndef CMX_SB_INTPOW
+#define CMX_SB_INTPOW 1      // A/B switch for the integer-exponent instantiations (cmx_sb2006.hpp INTPOW)
+#endif
 template <typename FT, int VEC>
-static void launch_tendencies(bool limited, int vel, const SbConsts<FT> &c, const SbIn<FT> &in, const SbOut<FT> &out,
+static void launch_tendencies(bool limited, int vel, bool intpow, const SbConsts<FT> &c, const SbIn<FT> &in, const SbOut<FT> &out,
                               int64_t nvec, hipStream_t s) {
     // one short-lived workgroup per tile of kTendBS lanes (see the kernel's header comment)
     const int64_t grid = (nvec + kTendBS - 1) / kTendBS;
-#define CMX_LAUNCH(L, V)                                                                                              \
-    hipLaunchKernelGGL((sb2006_tendencies_kernel<FT, L, V, VEC, kTendBS>), dim3((unsigned)grid), dim3(kTendBS), 0, s, c, in, \
-                       out, nvec)
+#define CMX_LAUNCH(L, V)                                                                                                                   \
+    do {                                                                                                                                   \
+        if (intpow && CMX_SB_INTPOW)                                                                                                       \
+            hipLaunchKernelGGL((sb2006_tendencies_kernel<FT, L, V, VEC, kTendBS, 1, true, true>), dim3((unsigned)grid), dim3(kTendBS), 0, s, c, in, \
+                               out, nvec);                                                                                                 \
+        else                                                                                                                               \
+            hipLaunchKernelGGL((sb2006_tendencies_kernel<FT, L, V, VEC, kTendBS>), dim3((unsigned)grid), dim3(kTendBS), 0, s, c, in, out,  \
+                               nvec);                                                                                                      \
+    } while (0)
     if (limited) {
         if (vel == VEL_NONE) CMX_LAUNCH(true, VEL_NONE);
         else if (vel == VEL_SB) CMX_LAUNCH(true, VEL_SB);
@@ -61,6 +70,7 @@ static int32_t tendencies_entry(const WR *wr, const TH *tps, const VL *vel, uint
     const bool limited = flags & CMX_SB2006_LIMITED;
     if ((flags & CMX_SB2006_LIMITED) && !sb_limiters_ok(*wr)) return CMX_ERR_BAD_ARG;      // clamp_ordered needs ordered limiter pairs
     const SbConsts<FT> c = make_sb_consts<FT>(*wr, *tps, vel, (double)Math<FT>::eps_1m());
+    const bool intpow = sb_integer_exponents(*wr);        // b = 3, c = 4, d = −5: the integer-power instantiation (cmx_sb2006.hpp)
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     // Float64: one point per lane (8-byte loads).  The kernel is VALU-bound there and the two-points-per-lane variant spends 14 % of
     // its instructions on SGPR spill traffic (60 Float64 constants = 120 SGPRs): 1307 vs 1048 VALU instructions per point.
@@ -81,7 +91,7 @@ static int32_t tendencies_entry(const WR *wr, const TH *tps, const VL *vel, uint
         SbIn<FT> in{rho + lo, T + lo, q_tot + lo, q_lcl + lo, n_lcl + lo, q_rai + lo, n_rai + lo};
         SbOut<FT> out{dq_lcl + lo, dn_lcl + lo, dq_rai + lo, dn_rai + lo, vt_n ? vt_n + lo : nullptr,
                       vt_m ? vt_m + lo : nullptr};
-        launch_tendencies<FT, V>(limited, velk, c, in, out, count / V, s);
+        launch_tendencies<FT, V>(limited, velk, intpow, c, in, out, count / V, s);
     };
     if (same_mis) {
         const int64_t head = std::min<int64_t>(n, mis0 ? (int64_t)((16 - mis0) / sizeof(FT)) : 0);
@@ -106,6 +116,10 @@ static int32_t fields_entry(const WR *wr, const TH *tps, uint32_t flags, int64_t
     const SbConsts<FT> c = make_sb_consts<FT>(*wr, *tps, (const std::conditional_t<std::is_same_v<FT, float>, cmx_rain_vel_f32, cmx_rain_vel_f64> *)nullptr,
                                               (double)Math<FT>::eps_1m());
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (sb_integer_exponents(*wr) && CMX_SB_INTPOW) {     // the integer-exponent instantiation of the point function (cmx_sb2006.hpp INTPOW)
+        if (flags & CMX_SB2006_LIMITED) return launch_layout<FT, Sb2006LayoutPolicy<FT, true, true>>(c, n_seg, seg_len, in, in_stride, out, out_stride, aos, s);
+        return launch_layout<FT, Sb2006LayoutPolicy<FT, false, true>>(c, n_seg, seg_len, in, in_stride, out, out_stride, aos, s);
+    }
     if (flags & CMX_SB2006_LIMITED) return launch_layout<FT, Sb2006LayoutPolicy<FT, true>>(c, n_seg, seg_len, in, in_stride, out, out_stride, aos, s);
     return launch_layout<FT, Sb2006LayoutPolicy<FT, false>>(c, n_seg, seg_len, in, in_stride, out, out_stride, aos, s);
 }

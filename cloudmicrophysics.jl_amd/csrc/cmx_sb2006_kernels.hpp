@@ -35,7 +35,7 @@ template <typename FT> struct SbProcOut { FT *col[CMX_SB2006_NPROC]; };
 // walking 4 or 8 tiles in a loop, tile t+1's loads issued before tile t is computed, the table copy paid once — was measured in round
 // 2 and rejected: the loop carries the prefetched columns and hoisted invariants, 167–198 VGPRs against 125, 2–3 waves per SIMD
 // instead of 4, 3.50 ms against 3.06 (tools/valu_probe: a dependent v_fma_f64 issues every 11 cycles; what hides that is waves).
-template <typename FT, bool LIMITED, int VEL, int VEC, int BS = kBlock, int C = 1, bool NT = true>
+template <typename FT, bool LIMITED, int VEL, int VEC, int BS = kBlock, int C = 1, bool NT = true, bool INTPOW = false>
 __global__ __launch_bounds__(BS) void sb2006_tendencies_kernel(const SbConsts<FT> c, const SbIn<FT> in,
                                                                const SbOut<FT> out, const int64_t nvec) {
     using M = Math<FT>;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(BS) void sb2006_tendencies_kernel(const SbConsts<FT
             // a NaN in any input column poisons every output of the point (cmx_math.hpp any_nan)
             const bool poisoned = any_nan(rho[t][k], q_tot[t][k], q_lcl[t][k], n_lcl[t][k], q_rai[t][k], n_rai[t][k], T[t][k]);
             // N = ρ n — BMT:718-719
-            const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL>(front_consts<FT>(c), r_, T[t][k], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
+            const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL, false, INTPOW>(front_consts<FT>(c), r_, T[t][k], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
             // sums of warm_rain_tendencies_2m — BMT:738-779.  The per-m³ number rates are added first and divided by ρ once (the
             // reference divides each term: same value to rounding, five multiplies fewer); autoconversion's −2·dN_rai cancels
             // against the same term inside cloud self-collection (CM2:499), so their sum is formed directly.
@@ -103,14 +103,14 @@ __global__ __launch_bounds__(BS) void sb2006_tendencies_kernel(const SbConsts<FT
 }
 
 // ---- host-model layouts: the VEL_NONE tendencies as a policy of the generic adapter kernel (cmx_layout.hpp) ---
-template <typename FT, bool LIMITED> struct Sb2006LayoutPolicy {
+template <typename FT, bool LIMITED, bool INTPOW = false> struct Sb2006LayoutPolicy {
     static constexpr int NIN = 7, NOUT = 4, NAOS = 8;       // rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai → dq_lcl, dn_lcl, dq_rai, dn_rai (+4 zero fields)
     using Consts = SbConsts<FT>;
     template <typename C> static __device__ __forceinline__ void point(const C &c, const FT (&x)[NIN], FT (&y)[NOUT]) {
         using M = Math<FT>;
         const FT r_ = max0(x[0]), qt = max0(x[2]), ql = max0(x[3]);
         const FT nl = max0(x[4]), qr = max0(x[5]), nr = max0(x[6]);
-        const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL_NONE>(c, r_, x[1], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
+        const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL_NONE, false, INTPOW>(c, r_, x[1], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
         y[0] = (p.cond + p.au_dq_lcl) + p.ac_dq_lcl;
         y[1] = M::fma(p.lsc_plus_au + p.ac_dN_lcl, p.inv_rho, p.na_lcl);
         y[2] = (p.evq + p.au_dq_rai) + p.ac_dq_rai;
