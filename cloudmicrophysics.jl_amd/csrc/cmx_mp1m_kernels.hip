@@ -196,6 +196,20 @@ template <typename FT> __device__ __forceinline__ FT logistic_integral(FT x, FT 
 // FLAGS: the Microphysics1MOptions bits as a compile-time constant (the default option set gets its own instantiation:
 // one straight-line basic block, the unselected variants removed), or kRuntimeFlags to read them from the constants.
 constexpr uint32_t kRuntimeFlags = 0xffffffffu;
+// Internal (not an ABI flag): set in the compile-time FLAGS of the default instantiation when the slope-parameter exponents are the
+// default set — rain: fall speed ½, accretion 3½, ice-rain sink 6½, snow–rain kernel 4, ventilation ¾ (all multiples of ¼); snow:
+// ¼, 3¼, 3, ⅝ (multiples of ⅛).  The eleven powers of the two λ⁻¹ are then products of ONE exp2 each (r = λ⁻¹^¼, s = λ⁻¹^⅛: 9 + 7
+// multiplies) instead of eleven exp2 — in Float64 ≈ 180 of the ≈ 990 instructions of a point.  mp1m_default_exponents() decides on the
+// host; any other parameter set takes the run-time-flags kernels with the general exp2(e·log2 λ⁻¹) forms.
+constexpr uint32_t kDefExpBit = 0x40000000u;
+static_assert((CMX_1M_DEFAULT_OPTIONS & kDefExpBit) == 0, "internal bit collides with an option flag");
+#ifndef CMX_1M_DEFEXP
+#define CMX_1M_DEFEXP 1      // A/B switch
+#endif
+template <typename CT> inline bool mp1m_default_exponents(const CT &c) {
+    return CMX_1M_DEFEXP && c.vt_e_rai == 0.5 && c.acc_e_rai == 3.5 && c.sink_e == 6.5 && c.rs_d_rai == 3 && c.vent_e_rai == 0.75 && c.vt_e_sno == 0.25 &&
+           c.acc_e_sno == 3.25 && c.rs_d_sno == 2 && c.vent_e_sno == 0.625;
+}
 template <typename FT, uint32_t FLAGS = kRuntimeFlags, typename C>
 __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT q_tot, FT q_lcl, FT q_icl,
                                                   FT q_rai, FT q_sno) {
@@ -205,6 +219,7 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
 #pragma unroll
     for (int k = 0; k < CMX_MP1M_NSRC; ++k) o.s[k] = FT(0);
     const uint32_t fl = FLAGS == kRuntimeFlags ? c->flags : FLAGS;
+    constexpr bool DEFEXP = FLAGS != kRuntimeFlags && (FLAGS & kDefExpBit) != 0;
     const FT eps = c->eps_1m;   // ϵ_numerics(FT) = cbrt(floatmin(FT))  Utilities.jl:318
     // clamp_to_nonneg — BMT:147-152 (T is not clamped)
     rho = max0(rho); q_tot = max0(q_tot); q_lcl = max0(q_lcl);
@@ -262,7 +277,17 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     const FT l2_n0_sno = has_sno ? M::fma(c->sno_nu, l2_rq_sno, c->sno_l2_mu) : c->l2_eps;
     const FT n0_sno = has_sno ? M::exp2(l2_n0_sno) : FT(0);
     const FT l2_li_sno = M::max(c->lam_floor_sno, (l2_rq_sno + c->lam_c_sno - M::max(l2_n0_sno, c->l2_eps)) * c->lam_e_sno);
-    const FT li_rai = M::exp2(l2_li_rai), li_sno = M::exp2(l2_li_sno), li_icl = M::exp2(l2_li_icl);
+    // powers of the two slope parameters (see kDefExpBit): rain r = λ⁻¹^¼, snow s = λ⁻¹^⅛
+    FT li_rai, li_sno, pr_half = FT(0), pr_075 = FT(0), pr_3h = FT(0), pr_4 = FT(0), pr_6h = FT(0), ps_q = FT(0), ps_58 = FT(0), ps_3 = FT(0), ps_3q = FT(0);
+    if constexpr (DEFEXP) {
+        const FT r = M::exp2(FT(0.25) * l2_li_rai), r2 = r * r, r4 = r2 * r2, r8 = r4 * r4, r16 = r8 * r8;
+        li_rai = r4; pr_half = r2; pr_075 = r2 * r; pr_4 = r16; pr_3h = (r8 * r4) * r2; pr_6h = (r16 * r8) * r2;
+        const FT s = M::exp2(FT(0.125) * l2_li_sno), s2 = s * s, s4 = s2 * s2, s8 = s4 * s4, s16 = s8 * s8, s24 = s16 * s8;
+        li_sno = s8; ps_q = s2; ps_58 = s4 * s; ps_3 = s24; ps_3q = s24 * s2;
+    } else {
+        li_rai = M::exp2(l2_li_rai); li_sno = M::exp2(l2_li_sno);
+    }
+    const FT li_icl = M::exp2(l2_li_icl);
     const FT v0_rai = c->v0c_rai * M::sqrt(M::max(c->rho_w * inv_rho - FT(1), FT(0)));   // get_v0 :101-104
     const FT v0_sno = c->v0_sno;
 
@@ -285,8 +310,8 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     // ---- accretion — CM1:491-897, routed by temperature as in BMT:171-198 ----------------------------------------
     const bool is_warm = T >= c->T_freeze;
     const FT alpha = (T <= c->T_freeze) ? FT(0) : c->cv_l * M::rcp(L_f) * dTf;    // warm_accretion_melt_factor :458-465
-    const FT acc_rai = c->n0_rai * v0_rai * M::exp2(c->acc_e_rai * l2_li_rai);
-    const FT acc_sno = n0_sno * v0_sno * M::exp2(c->acc_e_sno * l2_li_sno);
+    const FT acc_rai = c->n0_rai * v0_rai * (DEFEXP ? pr_3h : M::exp2(c->acc_e_rai * l2_li_rai));
+    const FT acc_sno = n0_sno * v0_sno * (DEFEXP ? ps_3q : M::exp2(c->acc_e_sno * l2_li_sno));
     if (fl & CMX_1M_ACCR_LCL_RAI) o.s[CMX_1M_S_ACCR_LCL_RAI] = (has_lcl && has_rai) ? q_lcl * c->acc_c_lcl_rai * acc_rai : FT(0);
     o.S_lcl_sno = o.S_rai_sno = o.S_sno_rai = FT(0); o.alpha = alpha; o.is_warm = is_warm;
     if (fl & CMX_1M_ACCR_LCL_SNO) {
@@ -299,24 +324,25 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     if (fl & CMX_1M_ACCR_ICL_RAI) {
         const bool both = has_icl && has_rai;
         o.s[CMX_1M_S_ACCR_ICL_RAI] = both ? q_icl * c->acc_c_icl_rai * acc_rai : FT(0);
-        o.s[CMX_1M_S_ACCR_FREEZE_ICL_RAI] = both ? c->sink_c * inv_rho * v0_rai * li_icl * M::exp2(c->sink_e * l2_li_rai) : FT(0);
+        o.s[CMX_1M_S_ACCR_FREEZE_ICL_RAI] = both ? c->sink_c * inv_rho * v0_rai * li_icl * (DEFEXP ? pr_6h : M::exp2(c->sink_e * l2_li_rai)) : FT(0);
     }
     if (fl & CMX_1M_ACCR_ICL_SNO) o.s[CMX_1M_S_ACCR_ICL_SNO] = (has_icl && has_sno) ? q_icl * c->acc_c_icl_sno * acc_sno : FT(0);
     c = &consts_after(*c, acc_sno);
     if (fl & CMX_1M_ACCR_RAI_SNO) {   // CM1:604-644, 815-867
-        const FT v_rai = has_rai ? c->vt_c_rai * v0_rai * M::exp2(c->vt_e_rai * l2_li_rai) : FT(0);
-        const FT v_sno = has_sno ? c->vt_c_sno * v0_sno * M::exp2(c->vt_e_sno * l2_li_sno) : FT(0);
+        const FT v_rai = has_rai ? c->vt_c_rai * v0_rai * (DEFEXP ? pr_half : M::exp2(c->vt_e_rai * l2_li_rai)) : FT(0);
+        const FT v_sno = has_sno ? c->vt_c_sno * v0_sno * (DEFEXP ? ps_q : M::exp2(c->vt_e_sno * l2_li_sno)) : FT(0);
         const FT dv = v_sno - v_rai;
         const FT dv_eff = M::sqrt(M::fma(dv, dv, c->coeff_disp * M::fma(v_sno, v_sno, v_rai * v_rai)));
         const FT pre = inv_rho * c->n0_rai * n0_sno * dv_eff;
         const bool both = has_rai && has_sno;
         // Σ = 2 λi³ λj^(δ+1) + 2(δ+1) λi² λj^(δ+2) + (δ+2)(δ+1) λi λj^(δ+3) = λi λj^(δ+1) (2λi² + 2(δ+1)λiλj + (δ+2)(δ+1)λj²)
-        auto kernel = [&](FT cj, FT d, FT li, FT l2_li, FT lj, FT l2_lj) {
+        // pw = λi⁻¹ λj⁻¹^(δ+1): δ = 3 (rain), 2 (snow) in the default set
+        auto kernel = [&](FT cj, FT d, FT li, FT l2_li, FT lj, FT l2_lj, FT pw_default) {
             const FT poly = M::fma(FT(2) * li, li, M::fma(FT(2) * (d + FT(1)) * li, lj, (d + FT(2)) * (d + FT(1)) * (lj * lj)));
-            return pre * cj * M::exp2(l2_li + (d + FT(1)) * l2_lj) * poly;
+            return pre * cj * (DEFEXP ? pw_default : M::exp2(l2_li + (d + FT(1)) * l2_lj)) * poly;
         };
-        const FT S_rai_sno = both ? kernel(c->rs_c_rai, c->rs_d_rai, li_sno, l2_li_sno, li_rai, l2_li_rai) : FT(0);   // i = snow, j = rain
-        const FT S_sno_rai = both ? kernel(c->rs_c_sno, c->rs_d_sno, li_rai, l2_li_rai, li_sno, l2_li_sno) : FT(0);   // i = rain, j = snow
+        const FT S_rai_sno = both ? kernel(c->rs_c_rai, c->rs_d_rai, li_sno, l2_li_sno, li_rai, l2_li_rai, li_sno * pr_4) : FT(0);   // i = snow, j = rain
+        const FT S_sno_rai = both ? kernel(c->rs_c_sno, c->rs_d_sno, li_rai, l2_li_rai, li_sno, l2_li_sno, li_rai * ps_3) : FT(0);   // i = rain, j = snow
         o.S_rai_sno = S_rai_sno; o.S_sno_rai = S_sno_rai;
         o.s[CMX_1M_S_ACCR_RAI_SNO_COLD] = is_warm ? FT(0) : S_rai_sno;
         o.s[CMX_1M_S_ACCR_RAI_SNO_WARM] = is_warm ? S_sno_rai : FT(0);
@@ -325,8 +351,8 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
 
     c = &consts_after(*c, o.S_sno_rai);
     // ---- ventilated vapour exchange and melting — CM1:917-1139 ---------------------------------------------------
-    const FT F_rai = M::fma(c->vent_b_rai * M::sqrt(v0_rai), M::exp2(c->vent_e_rai * l2_li_rai), c->vent_a_rai);
-    const FT F_sno = M::fma(c->vent_b_sno * c->sqrt_v0_sno, M::exp2(c->vent_e_sno * l2_li_sno), c->vent_a_sno);
+    const FT F_rai = M::fma(c->vent_b_rai * M::sqrt(v0_rai), DEFEXP ? pr_075 : M::exp2(c->vent_e_rai * l2_li_rai), c->vent_a_rai);
+    const FT F_sno = M::fma(c->vent_b_sno * c->sqrt_v0_sno, DEFEXP ? ps_58 : M::exp2(c->vent_e_sno * l2_li_sno), c->vent_a_sno);
     const FT mp_rai = c->four_pi * c->n0_rai * inv_rho * (li_rai * li_rai) * F_rai;      // 4π n0/ρ λ⁻² F
     const FT mp_sno = c->four_pi * n0_sno * inv_rho * (li_sno * li_sno) * F_sno;
     if (fl & CMX_1M_RAIN_EVAPORATION)
@@ -614,8 +640,8 @@ static int32_t tendencies_1m_entry(const MP *mp, const TH *tps, uint32_t flags, 
         Mp1mOut<FT> out{dq_lcl + lo, dq_icl + lo, dq_rai + lo, dq_sno + lo};
         const int64_t nv = count / V;
         const dim3 grid((unsigned)((nv + kBlock - 1) / kBlock));
-        if (flags == CMX_1M_DEFAULT_OPTIONS)
-            hipLaunchKernelGGL((mp1m_tendencies_kernel<FT, V, CMX_1M_DEFAULT_OPTIONS>), grid, dim3(kBlock), 0, s, c, in, out, nv);
+        if (flags == CMX_1M_DEFAULT_OPTIONS && mp1m_default_exponents(c))
+            hipLaunchKernelGGL((mp1m_tendencies_kernel<FT, V, CMX_1M_DEFAULT_OPTIONS | kDefExpBit>), grid, dim3(kBlock), 0, s, c, in, out, nv);
         else
             hipLaunchKernelGGL((mp1m_tendencies_kernel<FT, V>), grid, dim3(kBlock), 0, s, c, in, out, nv);
     };
@@ -649,8 +675,8 @@ static int32_t fields_1m_entry(const MP *mp, const TH *tps, uint32_t flags, int6
     if (const int32_t st = check_flags_1m(flags)) return st;
     const Mp1mConsts<FT> c = make_mp1m_consts<FT>(*mp, *tps, flags, (double)Math<FT>::eps_1m());
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (flags == CMX_1M_DEFAULT_OPTIONS)
-        return launch_layout<FT, Mp1mLayoutPolicy<FT, CMX_1M_DEFAULT_OPTIONS>>(c, n_seg, seg_len, in, in_stride, out, out_stride, aos, s);
+    if (flags == CMX_1M_DEFAULT_OPTIONS && mp1m_default_exponents(c))
+        return launch_layout<FT, Mp1mLayoutPolicy<FT, CMX_1M_DEFAULT_OPTIONS | kDefExpBit>>(c, n_seg, seg_len, in, in_stride, out, out_stride, aos, s);
     return launch_layout<FT, Mp1mLayoutPolicy<FT, kRuntimeFlags>>(c, n_seg, seg_len, in, in_stride, out, out_stride, aos, s);
 }
 
@@ -671,8 +697,8 @@ static int32_t linearized_1m_entry(const MP *mp, const TH *tps, uint32_t flags, 
     a.Lv_over_cp = (FT)tps->LH_v0 / (FT)tps->cp_d; a.Ls_over_cp = (FT)tps->LH_s0 / (FT)tps->cp_d;
     Mp1mIn<FT> in{rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno};
     Mp1mOut<FT> out{dq_lcl, dq_icl, dq_rai, dq_sno};
-    if (flags == CMX_1M_DEFAULT_OPTIONS)
-        hipLaunchKernelGGL((mp1m_linearized_kernel<FT, CMX_1M_DEFAULT_OPTIONS>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+    if (flags == CMX_1M_DEFAULT_OPTIONS && mp1m_default_exponents(c))
+        hipLaunchKernelGGL((mp1m_linearized_kernel<FT, CMX_1M_DEFAULT_OPTIONS | kDefExpBit>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                            reinterpret_cast<hipStream_t>(stream), c, a, in, out, n);
     else
         hipLaunchKernelGGL((mp1m_linearized_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
