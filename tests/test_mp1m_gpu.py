@@ -136,6 +136,37 @@ def test_config1_autoconversion_and_terminal_velocity_1e6_f64(dev, oracle):
 
 
 @pytest.mark.parametrize("ft", ["f32", "f64"])
+def test_non_default_slope_exponents_take_the_general_kernels(dev, oracle, ft):
+    """The default option set with Δv = 0.1 on the rain and snow fall-speed relations: the slope-parameter exponents are no longer the
+    multiples of ¼ / ⅛ the default instantiation multiplies out (csrc/cmx_mp1m_kernels.hip kDefExpBit), so the entry points must take
+    the general exp2(e·log2 λ⁻¹) kernels — same oracle, same bound."""
+    import cmx
+    from cmx import synthetic
+    n = 100_003
+    st = synthetic.mp1m_state(n, dtype=DT[ft], seed=77)
+    tps = P.ThermodynamicsParameters(ft)
+    mp, mp64 = P.Microphysics1MParams(ft), P.Microphysics1MParams("f64")
+    for m in (mp, mp64):
+        m.c.vel_rain.delta_v = 0.1
+        m.c.vel_snow.delta_v = 0.1
+    dcols = [c.to(dev) for c in st]
+    tend = cmx.bulk_microphysics_tendencies_1m(cmx.Instantaneous(), cmx.Microphysics1Moment(), mp, tps, *dcols)
+    lin = cmx.bulk_microphysics_tendencies_1m(cmx.LinearizedAverage(), cmx.Microphysics1Moment(), mp, tps, *dcols, 20.0, 2)
+    torch.cuda.synchronize()
+    ref = oracle.mp1m(_abi.F64, mp64.c, P.ThermodynamicsParameters("f64"), mp64.flags, *[c.numpy().astype(np.float64) for c in st],
+                      float32_gates=(ft == "f32"), nthreads=8)
+    tf = P.DEFAULT_PARAMETERS["temperature_water_freeze"]
+    ref["near_branch"] = np.abs(st[1].numpy().astype(np.float64) - tf) < (1e-4 if ft == "f32" else 1e-11)
+    got = {k: getattr(tend, k).cpu().numpy() for k in TN}
+    rep = parity.assert_parity(got, ref, parity.RTOL[ft], names=TN, what=f"1M {ft} delta_v=0.1")
+    print(f"\n[1M parity, non-default exponents] {ft}: {rep}")
+    assert all(bool(torch.isfinite(getattr(lin, k)).all()) for k in TN)
+    # and the result differs from the default-parameter one (the perturbation is seen)
+    base = cmx.bulk_microphysics_tendencies_1m(cmx.Instantaneous(), cmx.Microphysics1Moment(), P.Microphysics1MParams(ft), tps, *dcols)
+    assert not torch.equal(base.dq_rai_dt, tend.dq_rai_dt)
+
+
+@pytest.mark.parametrize("ft", ["f32", "f64"])
 @pytest.mark.parametrize("n", [0, 1, 3, 5, 257, 1023])
 def test_ragged_sizes(dev, oracle, ft, n):
     import cmx

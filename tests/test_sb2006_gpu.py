@@ -137,6 +137,22 @@ def test_fused_tendencies_override_parameter_set(dev, oracle, ft):
 
 
 @pytest.mark.parametrize("ft", ["f32", "f64"])
+def test_non_integer_exponent_takes_the_general_kernel(dev, oracle, ft):
+    """d = −5.25 instead of the published −5 in (1 + κ_rr/Br)ᵈ: the parameter struct no longer holds the integer exponents that the
+    INTPOW instantiations multiply out (csrc/cmx_sb2006.hpp sb_integer_exponents), so the entries must run the general
+    exp2(e·log2 x) forms — same oracle, same bound; and the result differs from the default one."""
+    from cmx import synthetic
+    ov = {"SB2006_raindrops_self-collection_coeff_d": -5.25}
+    st = synthetic.sb2006_state(200_000, dtype=DT[ft], seed=78)
+    dcols = [c.to(dev) for c in st]
+    got = _np(_run_fused(ft, True, "sb", dcols, override=ov))
+    ref = _oracle_fused(oracle, ft, True, "sb", [c.numpy() for c in st], override=ov)
+    parity.assert_parity(got, ref, parity.RTOL[ft], what=f"{ft} non-integer d")
+    base = _np(_run_fused(ft, True, "sb", dcols))
+    assert not np.array_equal(base["dn_rai_dt"], got["dn_rai_dt"])
+
+
+@pytest.mark.parametrize("ft", ["f32", "f64"])
 @pytest.mark.parametrize("limited", [True, False])
 def test_process_rates_match_oracle(dev, oracle, ft, limited):
     """Every individual process column vs the oracle, on states away from the two cancellations
