@@ -708,12 +708,15 @@ __device__ __forceinline__ void bigg_rain(const PointwiseConsts<FT> &k, FT J_big
     }
 }
 
+#ifndef CMX_SB_INTPOW_P3
+#define CMX_SB_INTPOW_P3 1
+#endif
 template <typename FT> struct FusedIO {
     const FT *rho, *T, *q_tot, *q_lcl, *n_lcl, *q_rai, *n_rai, *q_ice, *n_ice, *q_rim, *b_rim, *shift;
     FT *out[8];
 };
 
-template <typename FT, bool LIMITED>
+template <typename FT, bool LIMITED, bool INTPOW = false>      // INTPOW: the integer-exponent warm-rain point function (cmx_sb2006.hpp), as the 2M entry
 __global__ __launch_bounds__(kBlock) void mp2m_p3_pointwise_kernel(const SbConsts<FT> sc, const P3Consts<FT> c, const PointwiseConsts<FT> k,
                                                                   const FusedIO<FT> io, const int64_t n) {
     Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
@@ -729,7 +732,7 @@ __global__ __launch_bounds__(kBlock) void mp2m_p3_pointwise_kernel(const SbConst
     const FT shift = io.shift ? io.shift[i] : FT(0);
     const FT N_lcl = rho * n_lcl, N_rai = rho * n_rai, inv_rho = FT(1) / rho;
     // warm rain — BMT:942 → warm_rain_tendencies_2m :707-782
-    const SbRates<FT> w = sb2006_point<FT, LIMITED, VEL_NONE, true>(sc, rho, T, q_tot, q_lcl, q_rai, N_lcl, N_rai, n_lcl, n_rai, q_ice, k.cpm_qi);
+    const SbRates<FT> w = sb2006_point<FT, LIMITED, VEL_NONE, true, INTPOW>(sc, rho, T, q_tot, q_lcl, q_rai, N_lcl, N_rai, n_lcl, n_rai, q_ice, k.cpm_qi);
     FT dq_lcl = (w.cond + w.au_dq_lcl) + w.ac_dq_lcl;
     FT dn_lcl = M::fma(w.lsc_plus_au + w.ac_dN_lcl, w.inv_rho, w.na_lcl);
     FT dq_rai = (w.evq + w.au_dq_rai) + w.ac_dq_rai;
@@ -850,8 +853,14 @@ static int32_t mp2m_p3_entry(const WR *wr, const IP *ip, const TH *tps, uint32_t
     for (int q = 0; q < 8; ++q) fio.out[q] = out[q];
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const dim3 block(kBlock), grid1((unsigned)((n + kBlock - 1) / kBlock));
-    if (limited) hipLaunchKernelGGL((mp2m_p3_pointwise_kernel<FT, true>), grid1, block, 0, st, sc, c, pk, fio, n);
-    else hipLaunchKernelGGL((mp2m_p3_pointwise_kernel<FT, false>), grid1, block, 0, st, sc, c, pk, fio, n);
+    // the same warm-rain instantiation as cmx_sb2006_warm_rain_tendencies_* picks (without ice the two entries agree bit for bit)
+    if (sb_integer_exponents(*wr) && CMX_SB_INTPOW_P3) {
+        if (limited) hipLaunchKernelGGL((mp2m_p3_pointwise_kernel<FT, true, true>), grid1, block, 0, st, sc, c, pk, fio, n);
+        else hipLaunchKernelGGL((mp2m_p3_pointwise_kernel<FT, false, true>), grid1, block, 0, st, sc, c, pk, fio, n);
+    } else {
+        if (limited) hipLaunchKernelGGL((mp2m_p3_pointwise_kernel<FT, true>), grid1, block, 0, st, sc, c, pk, fio, n);
+        else hipLaunchKernelGGL((mp2m_p3_pointwise_kernel<FT, false>), grid1, block, 0, st, sc, c, pk, fio, n);
+    }
     CMX_HIP_TRY(hipGetLastError());
     // ice processes
     P3VelConsts<FT> v = make_p3_vel_consts<FT>(ip->scheme, ip->vel_ice, 1e-5);
