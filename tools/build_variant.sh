@@ -6,6 +6,6 @@ tag=$1; shift
 src=$(cd "$(dirname "$0")/../cloudmicrophysics.jl_amd/csrc" && pwd)
 obj=$(mktemp -d)
 trap 'rm -rf "$obj"' EXIT
-make -s -C "$src" -f "$src/Makefile" -j8 VPATH="$src" OUT="$src/libcmx_$tag.so" OBJDIR="$obj" LITCOEF_EXTRA="${LITCOEF_EXTRA:-}" VARIANT_FLAGS="$*" \
+make -s -C "$src" -f "$src/Makefile" -j8 VPATH="$src" OUT="$src/libcmx_$tag.so" OBJDIR="$obj" LITCOEF_EXTRA="${LITCOEF_EXTRA:-}" NOSLP_EXTRA="${NOSLP_EXTRA:-}" VARIANT_FLAGS="$*" \
      CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function $*" variant
 echo "$src/libcmx_$tag.so"
