@@ -54,6 +54,7 @@ template <typename FT> struct Mp1mConsts {
     // ventilation: F = a + b' √v0 exp2(e · log2 λ⁻¹)
     FT vent_a_rai, vent_b_rai, vent_e_rai, vent_a_sno, vent_b_sno, vent_e_sno;
     FT four_pi;
+    FT fourpi_n0_rai, fourpi_n0_icl, vent_bs_sno;   // host-folded products of two constants (a product of two kernel arguments is a VALU multiply per point)
 };
 
 template <typename FT, typename MP, typename TH>
@@ -158,6 +159,8 @@ static Mp1mConsts<FT> make_mp1m_consts(const MP &mp, const TH &tp, uint32_t flag
     vent(mp.rain.vent, vr, mp.rain.mass, c.vent_a_rai, c.vent_b_rai, c.vent_e_rai);
     vent(mp.snow.vent, vs, mp.snow.mass, c.vent_a_sno, c.vent_b_sno, c.vent_e_sno);
     c.four_pi = (FT)(4.0 * pi);
+    c.fourpi_n0_rai = (FT)(4.0 * pi * (double)mp.rain.n0); c.fourpi_n0_icl = (FT)(4.0 * pi * (double)mp.cloud_ice.n0);
+    c.vent_bs_sno = (FT)((double)c.vent_b_sno * std::sqrt((double)vs.v0));
     return c;
 }
 
@@ -352,8 +355,8 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     c = &consts_after(*c, o.S_sno_rai);
     // ---- ventilated vapour exchange and melting — CM1:917-1139 ---------------------------------------------------
     const FT F_rai = M::fma(c->vent_b_rai * M::sqrt(v0_rai), DEFEXP ? pr_075 : M::exp2(c->vent_e_rai * l2_li_rai), c->vent_a_rai);
-    const FT F_sno = M::fma(c->vent_b_sno * c->sqrt_v0_sno, DEFEXP ? ps_58 : M::exp2(c->vent_e_sno * l2_li_sno), c->vent_a_sno);
-    const FT mp_rai = c->four_pi * c->n0_rai * inv_rho * (li_rai * li_rai) * F_rai;      // 4π n0/ρ λ⁻² F
+    const FT F_sno = M::fma(c->vent_bs_sno, DEFEXP ? ps_58 : M::exp2(c->vent_e_sno * l2_li_sno), c->vent_a_sno);
+    const FT mp_rai = c->fourpi_n0_rai * inv_rho * (li_rai * li_rai) * F_rai;      // 4π n0/ρ λ⁻² F
     const FT mp_sno = c->four_pi * n0_sno * inv_rho * (li_sno * li_sno) * F_sno;
     if (fl & CMX_1M_RAIN_EVAPORATION)
         o.s[CMX_1M_S_PHASE_CHANGE_VAP_RAI] = M::min(FT(0), (has_rai && S_l < FT(0)) ? mp_rai * S_l * G_l : FT(0));
@@ -363,7 +366,7 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     }
     const FT melt_f = c->K_therm * M::rcp(L_f) * dTf;
     if (fl & CMX_1M_CLOUD_ICE_MELT)
-        o.s[CMX_1M_S_MELT_ICL_LCL] = (has_icl && above_freezing) ? c->four_pi * c->n0_icl * inv_rho * melt_f * (li_icl * li_icl) : FT(0);
+        o.s[CMX_1M_S_MELT_ICL_LCL] = (has_icl && above_freezing) ? c->fourpi_n0_icl * inv_rho * melt_f * (li_icl * li_icl) : FT(0);
     if (fl & CMX_1M_SNOW_MELT) o.s[CMX_1M_S_MELT_SNO_RAI] = (has_sno && above_freezing) ? mp_sno * melt_f : FT(0);
     return o;
 }

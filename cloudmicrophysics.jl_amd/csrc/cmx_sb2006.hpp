@@ -44,6 +44,7 @@ template <typename FT> struct SbConsts {
     FT gb_c1, gb_e1, gb_c2, gb_e2;      // Γ_incl(β_vent_0, t)
     FT a_vent_1, bSc_vent_1;            // b·∛Sc folded (the order-0 pair lives in ga_c*, gb_c*)
     FT sqrt_alpha_nu, beta, ev_rho0_q;  // √(α/ν_air), β, ρ0^(1/4)
+    FT sqrt_alpha_nu_rho0q;             // their product, folded on the host (a product of two kernel arguments is a VALU multiply per point)
     FT two_pi, l2_gate_N;               // log2(eps(FT)·x*) of the evaporation number gate
     // autoconversion / cloud self-collection (CM2:396-427, 488-501)
     FT sqrt_kfac, x_star, inv_x_star, acnv_A, acnv_a, acnv_b, acnv_rho0, ksc;
@@ -133,6 +134,7 @@ inline SbConsts<FT> make_sb_consts(const WR &wr, const TH &tp, const VL *vel, do
     c.sqrt_alpha_nu = (FT)std::sqrt((double)ev.alpha / (double)wr.air_properties.nu_air);
     c.beta = (FT)ev.beta;
     c.ev_rho0_q = (FT)std::sqrt(std::sqrt((double)ev.rho_0));
+    c.sqrt_alpha_nu_rho0q = (FT)(std::sqrt((double)ev.alpha / (double)wr.air_properties.nu_air) * std::sqrt(std::sqrt((double)ev.rho_0)));
     c.two_pi = (FT)(2.0 * pi);
     c.l2_gate_N = (FT)std::log2((double)Math<FT>::eps() * x_star_ev);
     // autoconversion
@@ -450,7 +452,7 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, F
         const FT g_a = M::rcp(M::fma(c.ga_c1, M::exp2(c.ga_e1 * l2_t), c.ga_c2 * M::exp2(c.ga_e2 * l2_t)));   // a_vent_0·Γ_incl(−1, t*)·e^{t*}
         const FT g_b = M::rcp(M::fma(c.gb_c1, M::exp2(c.gb_e1 * l2_t), c.gb_c2 * M::exp2(c.gb_e2 * l2_t)));   // b_vent_0 ∛Sc·Γ_incl(β, t*)·e^{t*}
         // √N_Re = √(α/ν)·(ρ0/ρ)^¼·√(x̄^β·Dr)
-        const FT sqrt_N_Re = c.sqrt_alpha_nu * c.ev_rho0_q * M::sqrt(rs_rho) *
+        const FT sqrt_N_Re = c.sqrt_alpha_nu_rho0q * M::sqrt(rs_rho) *
                              M::exp2(FT(0.5) * M::fma(c.beta, l2_xr, l2_Dr));
         const FT Fv0 = M::fma(g_b, sqrt_N_Re, g_a);
         const FT Fv1 = M::fma(c.bSc_vent_1, sqrt_N_Re, c.a_vent_1);
