@@ -251,9 +251,13 @@ __device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, cons
 
 // N_ONLY: the number-activation-only request (N_act columns, no M_act — the BASELINE configuration) as a compile-time fact; with
 // the two wants as run-time flags the compiler keeps both erfc chains and their selects alive (1212 → 729 VALU per 4 points).
+#ifndef CMX_ARG_BS
+#define CMX_ARG_BS 128
+#endif
+constexpr int kArgBS = CMX_ARG_BS;   // lanes per workgroup of the activation kernel: 128 (same-box A/B, f32: 256 → 0.650 ms, 128 → 0.638, 512 → 0.637–0.655; f64 indifferent)
 template <typename FT, int NM, bool SINKS, int VEC, bool N_ONLY = false>
-__global__ __launch_bounds__(kBlock) void arg_activation_kernel(const ArgConsts<FT> c, const ArgIO<FT> io, const int64_t nvec) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+__global__ __launch_bounds__(kArgBS) void arg_activation_kernel(const ArgConsts<FT> c, const ArgIO<FT> io, const int64_t nvec) {
+    const int64_t i = (int64_t)blockIdx.x * kArgBS + threadIdx.x;
     FT T[VEC], p[VEC], w[VEC], qt[VEC], ql[VEC] = {}, qi[VEC] = {}, Nl[VEC] = {}, Ni[VEC] = {};
     if (i < nvec) {
         load_col<FT, VEC>(io.T, i, T); load_col<FT, VEC>(io.p, i, p); load_col<FT, VEC>(io.w, i, w); load_col<FT, VEC>(io.q_tot, i, qt);
@@ -303,9 +307,9 @@ static void launch_arg(const ArgConsts<FT> &c, const ArgIO<FT> &io0, int64_t n, 
         io.S_max = off(io.S_max, lo);
         for (int j = 0; j < CMX_ARG_MAX_MODES; ++j) { io.N_act[j] = off(io.N_act[j], lo); io.M_act[j] = off(io.M_act[j], lo); }
         const int64_t nv = count / V;
-        const dim3 grid((unsigned)((nv + kBlock - 1) / kBlock));
-        if (io.want_N && !io.want_M) hipLaunchKernelGGL((arg_activation_kernel<FT, NM, SINKS, V, true>), grid, dim3(kBlock), 0, s, c, io, nv);
-        else hipLaunchKernelGGL((arg_activation_kernel<FT, NM, SINKS, V, false>), grid, dim3(kBlock), 0, s, c, io, nv);
+        const dim3 grid((unsigned)((nv + kArgBS - 1) / kArgBS));
+        if (io.want_N && !io.want_M) hipLaunchKernelGGL((arg_activation_kernel<FT, NM, SINKS, V, true>), grid, dim3(kArgBS), 0, s, c, io, nv);
+        else hipLaunchKernelGGL((arg_activation_kernel<FT, NM, SINKS, V, false>), grid, dim3(kArgBS), 0, s, c, io, nv);
     };
     if (same_mis) {
         const int64_t head = std::min<int64_t>(n, mis0 ? (int64_t)((16 - mis0) / sizeof(FT)) : 0);
