@@ -145,9 +145,10 @@ def _family(ft, sfx):
                                   "gamma_accr", "gamma_accr_rain_sink"))
     ns.blk1m_vel_snow = _struct(f"cmx_blk1m_vel_snow_{sfx}",
                                 s("r0", "ve", "delta_v", "chi_v", "v0", "gamma_vent", "gamma_term", "gamma_accr"))
+    ns.frostenberg2023 = _struct(f"cmx_frostenberg2023_{sfx}", s("sigma", "a", "b", "T_freeze", "log_a"))
     ns.process_params_1m = _struct(f"cmx_process_params_1m_{sfx}", s(
         "cloud_liquid_formation_tau_relax", "cloud_ice_formation_tau_relax") + [
-        ("rain_autoconversion", ns.acnv_1m), ("rain_autoconversion_nd", ns.var_timescale_acnv),
+        ("cloud_ice_formation_frostenberg", ns.frostenberg2023), ("rain_autoconversion", ns.acnv_1m), ("rain_autoconversion_nd", ns.var_timescale_acnv),
         ("snow_autoconversion", ns.acnv_1m)] + s(
         "r_ice_snow", "e_lcl_rai", "e_lcl_sno", "e_icl_rai", "e_icl_sno", "e_rai_sno", "coeff_disp"))
     ns.microphysics_1m = _struct(f"cmx_microphysics_1m_{sfx}", [
@@ -176,7 +177,6 @@ def _family(ft, sfx):
     ns.parameters_0m = _struct(f"cmx_parameters_0m_{sfx}", s("tau_precip", "qc_0", "S_0"))
     ns.local_rime_density = _struct(f"cmx_local_rime_density_{sfx}", s("a", "b", "c", "rho_ice"))
     ns.rain_freezing = _struct(f"cmx_rain_freezing_{sfx}", s("het_a", "het_B"))
-    ns.frostenberg2023 = _struct(f"cmx_frostenberg2023_{sfx}", s("sigma", "a", "b", "T_freeze", "log_a"))
     ns.morrison_milbrandt2014 = _struct(f"cmx_morrison_milbrandt2014_{sfx}", s("T_dep_thres", "c1", "c2", "T0", "het_a", "het_B"))
     ns.p3_ice_params = _struct(f"cmx_p3_ice_params_{sfx}", [
         ("scheme", ns.p3_params), ("vent", ns.ventilation), ("rho_rim_local", ns.local_rime_density),

@@ -466,7 +466,7 @@ def _opt(name, flag, doc):
 
 CloudLiquidFormation = _opt("CloudLiquidFormation", _abi.CMX_1M_CLOUD_LIQUID_FORMATION, "Microphysics1MOptions.jl:75-82")
 ConstantTimescale = _opt("ConstantTimescale", _abi.CMX_1M_CLOUD_ICE_FORMATION_CONST, ":84-91")
-TemperatureDependent = _opt("TemperatureDependent", _abi.CMX_1M_CLOUD_ICE_FORMATION_TDEP, ":93-100 (unsupported on this path)")
+TemperatureDependent = _opt("TemperatureDependent", _abi.CMX_1M_CLOUD_ICE_FORMATION_TDEP, ":98-105: Frostenberg (2023) INP timescale for deposition, constant for sublimation")
 CloudIceMelt = _opt("CloudIceMelt", _abi.CMX_1M_CLOUD_ICE_MELT, ":199")
 Kessler1M = _opt("Kessler1M", _abi.CMX_1M_RAIN_ACNV_KESSLER, ":102-109")
 PrescribedNd = _opt("PrescribedNd", _abi.CMX_1M_RAIN_ACNV_PRESCRIBED_ND, ":111-118")
@@ -583,6 +583,7 @@ class Microphysics1MParams:
         pp = c.process_params
         pp.cloud_liquid_formation_tau_relax = g("condensation_evaporation_timescale")
         pp.cloud_ice_formation_tau_relax = g("sublimation_deposition_timescale")
+        pp.cloud_ice_formation_frostenberg = Frostenberg2023(td)     # TemperatureDependent (Microphysics1MOptions.jl:314-318)
         k = g("threshold_smooth_transition_steepness")
         pp.rain_autoconversion = fam.acnv_1m(tau=g("rain_autoconversion_timescale"), k=k, q_threshold=g(
             "cloud_liquid_water_specific_humidity_autoconversion_threshold"))

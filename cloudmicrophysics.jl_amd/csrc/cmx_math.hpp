@@ -8,8 +8,18 @@
 // transcendental unit: it uses the lean routines of cmx_lean_f64.hpp (20–35 VALU
 // instructions, ≤ 4 ulp) instead of OCML's 50–150-instruction ones.
 #pragma once
+// CMX_HOST_BUILD: the point functions compiled by g++ for the HOST (tests/native/point_host.cpp) so that their algebra can be checked
+// against the oracle without a GPU.  Test infrastructure only — libcmx.so is never built this way and has no CPU path.
+#if defined(CMX_HOST_BUILD)
+#include <cmath>
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#else
 #include <hip/hip_runtime.h>
+#endif
 
+#include <cmath>
 #include <cstdint>
 
 #include "cmx_lean_f64.hpp"
@@ -18,16 +28,35 @@ namespace cmx {
 
 template <typename FT> struct Math;
 
+// the hardware transcendental / median instructions (host build: libm stand-ins of the same functions)
+namespace hw {
+#if defined(CMX_HOST_BUILD)
+inline float exp2(float x) { return std::exp2(x); }
+inline float log2(float x) { return std::log2(x); }
+inline float rcp(float x) { return 1.0f / x; }
+inline float sqrt(float x) { return std::sqrt(x); }
+inline float rsq(float x) { return 1.0f / std::sqrt(x); }
+inline float med3(float a, float b, float c) { return std::fmax(std::fmin(a, b), std::fmin(std::fmax(a, b), c)); }
+#else
+__device__ __forceinline__ float exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+#endif
+}  // namespace hw
+
 template <> struct Math<float> {
     static constexpr int VEC = 4;
     static constexpr float eps() { return 1.1920928955078125e-07f; }          // eps(Float32)
     static constexpr float eps_1m() { return 2.2737367544323206e-13f; }       // cbrt(floatmin(Float32))
     static __device__ __forceinline__ void prepare() {}                       // Float32 runs on the hardware transcendental unit: nothing to set up
-    static __device__ __forceinline__ float exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-    static __device__ __forceinline__ float log2(float x) { return __builtin_amdgcn_logf(x); }
-    static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-    static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-    static __device__ __forceinline__ float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+    static __device__ __forceinline__ float exp2(float x) { return hw::exp2(x); }
+    static __device__ __forceinline__ float log2(float x) { return hw::log2(x); }
+    static __device__ __forceinline__ float rcp(float x) { return hw::rcp(x); }
+    static __device__ __forceinline__ float sqrt(float x) { return hw::sqrt(x); }
+    static __device__ __forceinline__ float rsqrt(float x) { return hw::rsq(x); }
     static __device__ __forceinline__ float div(float a, float b) { return a * rcp(b); }
     static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
     static __device__ __forceinline__ float max(float a, float b) { return __builtin_fmaxf(a, b); }
@@ -41,7 +70,7 @@ template <> struct Math<float> {
     // (An OCML fallback behind a never-taken branch was tried first: inlined at 12 call sites it took the kernel to 179 VGPRs, 2 waves
     // per SIMD, 1.17 ms.)
     static __device__ __forceinline__ float tgamma(float z) {
-        const float t = fma(__builtin_amdgcn_fmed3f(z, 1.5f, 4.0f), 0.8f, -2.2f);
+        const float t = fma(hw::med3(z, 1.5f, 4.0f), 0.8f, -2.2f);
         float p = 0.000606461835549f;
         p = fma(p, t, 0.000949070487934f);
         p = fma(p, t, 0.00527334298015f);
@@ -120,7 +149,7 @@ template <> struct Math<double> {
 #define CMX_KEEP 1
 #endif
 template <typename FT> __device__ __forceinline__ FT keep(FT x) {
-#if CMX_KEEP
+#if CMX_KEEP && !defined(CMX_HOST_BUILD)
     asm volatile("" : "+v"(x));
 #endif
     return x;
@@ -135,6 +164,25 @@ template <typename CH> inline bool chen_rain_gamma_domain_ok(const CH &ch) {
     return true;
 }
 
+// Γ(z) for ANY argument (the reference evaluates SF.gamma at run time, Common.jl:414-422): OCML's tgamma — ≈ 110 (Float32) / 300
+// (Float64) instructions, used only by the GENERAL instantiations that parameter sets outside the polynomial window above select
+template <typename FT> __device__ __forceinline__ FT tgamma_general(FT z) {
+#if defined(CMX_HOST_BUILD)
+    return (FT)std::tgamma((double)z);
+#else
+    if constexpr (sizeof(FT) == 8) return ::tgamma(z);
+    else return ::tgammaf(z);
+#endif
+}
+// largest air density for which every z = b_i − b_ρ ρ + 1 of a Chen-2022 rain table stays inside the polynomial window [1.5, 4]
+// (b_ρ ≥ 0: z falls with ρ).  The fast instantiations poison the fall speeds of points above it with NaN instead of clamping.
+template <typename CH> inline double chen_rain_gamma_rho_max(const CH &ch) {
+    double r = 1e300;
+    for (int i = 0; i < 3; ++i)
+        if ((double)ch.b_rho > 0) r = std::fmin(r, ((double)ch.b[i] + 1.0 - 1.5) / (double)ch.b_rho);
+    return r;
+}
+
 template <typename FT> __device__ __forceinline__ FT clampv(FT x, FT lo, FT hi) {
     // Base.clamp: x < lo ? lo : (x > hi ? hi : x)
     return Math<FT>::min(Math<FT>::max(x, lo), hi);
@@ -144,10 +192,10 @@ template <typename FT> __device__ __forceinline__ FT clampv(FT x, FT lo, FT hi) 
 // not need that, returns 0 for a NaN like v_max does (the NaN rule is applied separately), and its result counts as canonical.
 // (Written as an inline-asm v_med3_f32 so that the optimiser cannot turn it back into canonicalize + v_max — it does in the 1-moment
 // kernels — it measured no faster there and 6 % slower in the LinearizedAverage kernel, round 2: the builtin stays.)
-__device__ __forceinline__ float max0(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()); }
+__device__ __forceinline__ float max0(float x) { return hw::med3(x, 0.0f, __builtin_inff()); }
 __device__ __forceinline__ double max0(double x) { return Math<double>::max(0.0, x); }
 // the same for lo ≤ hi as ONE instruction (v_med3_f32: the median of three is the clamp); Float64 has no med3
-__device__ __forceinline__ float clamp_ordered(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+__device__ __forceinline__ float clamp_ordered(float x, float lo, float hi) { return hw::med3(x, lo, hi); }
 __device__ __forceinline__ double clamp_ordered(double x, double lo, double hi) { return clampv(x, lo, hi); }
 
 // ---- phase-local constants (Float64) --------------------------------------------------------------------------------------------
@@ -172,11 +220,23 @@ __device__ __forceinline__ double clamp_ordered(double x, double lo, double hi) 
 #else
 #define CMX_PHASE_DEP(late, early) late
 #endif
+#if defined(CMX_HOST_BUILD)
+#undef CMX_PHASE_CONSTS
+#define CMX_PHASE_CONSTS 0
+template <typename T> using KernArg = const T;
+template <typename T> struct is_kernarg { static constexpr bool value = false; };
+#else
 template <typename T> using KernArg = const __attribute__((address_space(4))) T;
 template <typename T> struct is_kernarg { static constexpr bool value = false; };
 template <typename T> struct is_kernarg<const __attribute__((address_space(4))) T> { static constexpr bool value = true; };
+#endif
 // the constants struct must be the FIRST kernel argument
 // (ALSO: a Float32 kernel whose constants overflow the SGPR file too — the 1-moment kernels with run-time option flags)
+#if defined(CMX_HOST_BUILD)
+template <typename FT, bool ALSO = false, typename CT> inline const CT &front_consts(const CT &c) { return c; }
+template <typename FT, size_t OFFSET, typename CT> inline const CT &kernarg_at(const CT &c) { return c; }
+template <typename C, typename FT> inline const C &consts_after(const C &c, FT) { return c; }
+#else
 template <typename FT, bool ALSO = false, typename CT> __device__ __forceinline__ decltype(auto) front_consts(const CT &c) {
     if constexpr ((sizeof(FT) == 8 || ALSO) && CMX_PHASE_CONSTS) return (*(KernArg<CT> *)__builtin_amdgcn_kernarg_segment_ptr());
     else return (c);
@@ -197,6 +257,7 @@ template <typename C, typename FT> __device__ __forceinline__ const C &consts_af
     } else
         return c;
 }
+#endif
 
 // NaN inputs.  The reference sanitises with Julia's max(0, x), which returns NaN for a NaN x, and its arithmetic then carries the NaN to
 // the tendencies; the hardware v_max returns the other operand and would hide it.  The bulk-tendency kernels therefore poison every output

@@ -204,10 +204,13 @@ typedef enum cmx_status {
     typedef struct cmx_blk1m_vel_snow_##SFX {                                                  \
         FT r0, ve, delta_v, chi_v, v0, gamma_vent, gamma_term, gamma_accr;                     \
     } cmx_blk1m_vel_snow_##SFX;                                                                \
+    /* Frostenberg2023 — src/parameters/IceNucleation.jl:171-193 (log_a = log(a), host-derived) */ \
+    typedef struct cmx_frostenberg2023_##SFX { FT sigma, a, b, T_freeze, log_a; } cmx_frostenberg2023_##SFX; \
     /* process_params of Microphysics1MParams (src/parameters/Microphysics1MOptions.jl:296-   */ \
     /* 395), flattened: every variant's parameters are present, `flags` says which are read */  \
     typedef struct cmx_process_params_1m_##SFX {                                               \
         FT cloud_liquid_formation_tau_relax, cloud_ice_formation_tau_relax;                    \
+        cmx_frostenberg2023_##SFX cloud_ice_formation_frostenberg; /* TemperatureDependent :314-318 */ \
         cmx_acnv_1m_##SFX rain_autoconversion;             /* Kessler1M          */            \
         cmx_var_timescale_acnv_##SFX rain_autoconversion_nd; /* PrescribedNd     */            \
         cmx_acnv_1m_##SFX snow_autoconversion;             /* NoSupersaturation  */            \
@@ -272,8 +275,6 @@ typedef enum cmx_status {
     typedef struct cmx_local_rime_density_##SFX { FT a, b, c, rho_ice; } cmx_local_rime_density_##SFX; \
     /* RainFreezing (Bigg 1953 / Barklie–Gokhale 1959) — src/parameters/IceNucleation.jl:129-146 */ \
     typedef struct cmx_rain_freezing_##SFX { FT het_a, het_B; } cmx_rain_freezing_##SFX;       \
-    /* Frostenberg2023 — src/parameters/IceNucleation.jl:171-193 (log_a = log(a), host-derived) */ \
-    typedef struct cmx_frostenberg2023_##SFX { FT sigma, a, b, T_freeze, log_a; } cmx_frostenberg2023_##SFX; \
     /* MorrisonMilbrandt2014 — src/parameters/IceNucleation.jl:80-107 */                       \
     typedef struct cmx_morrison_milbrandt2014_##SFX { FT T_dep_thres, c1, c2, T0, het_a, het_B; } \
         cmx_morrison_milbrandt2014_##SFX;                                                      \
@@ -340,7 +341,7 @@ CMX_DECLARE_PARAM_STRUCTS(double, f64)
     CMX_STATIC_ASSERT(sizeof(cmx_koop2000_##SFX) == 8 * sizeof(FT), "cmx_koop2000");\
     CMX_STATIC_ASSERT(sizeof(cmx_ld2004_##SFX) == 4 * sizeof(FT), "cmx_ld2004");\
     CMX_STATIC_ASSERT(sizeof(cmx_local_rime_density_##SFX) == 4 * sizeof(FT), "cmx_local_rime_density");\
-    CMX_STATIC_ASSERT(sizeof(cmx_microphysics_1m_##SFX) == 85 * sizeof(FT), "cmx_microphysics_1m");\
+    CMX_STATIC_ASSERT(sizeof(cmx_microphysics_1m_##SFX) == 90 * sizeof(FT), "cmx_microphysics_1m");\
     CMX_STATIC_ASSERT(sizeof(cmx_morrison_milbrandt2014_##SFX) == 6 * sizeof(FT), "cmx_morrison_milbrandt2014");\
     CMX_STATIC_ASSERT(sizeof(cmx_numadj_horn2012_##SFX) == 1 * sizeof(FT), "cmx_numadj_horn2012");\
     CMX_STATIC_ASSERT(sizeof(cmx_p3_ice_params_##SFX) == 8 + 354 * sizeof(FT), "cmx_p3_ice_params");\
@@ -348,7 +349,7 @@ CMX_DECLARE_PARAM_STRUCTS(double, f64)
     CMX_STATIC_ASSERT(sizeof(cmx_parameters_0m_##SFX) == 3 * sizeof(FT), "cmx_parameters_0m");\
     CMX_STATIC_ASSERT(sizeof(cmx_particle_area_##SFX) == 4 * sizeof(FT), "cmx_particle_area");\
     CMX_STATIC_ASSERT(sizeof(cmx_particle_mass_##SFX) == 6 * sizeof(FT), "cmx_particle_mass");\
-    CMX_STATIC_ASSERT(sizeof(cmx_process_params_1m_##SFX) == 18 * sizeof(FT), "cmx_process_params_1m");\
+    CMX_STATIC_ASSERT(sizeof(cmx_process_params_1m_##SFX) == 23 * sizeof(FT), "cmx_process_params_1m");\
     CMX_STATIC_ASSERT(sizeof(cmx_quadrature_##SFX) == 8 + 256 * sizeof(FT), "cmx_quadrature");\
     CMX_STATIC_ASSERT(sizeof(cmx_rain_##SFX) == 13 * sizeof(FT), "cmx_rain");\
     CMX_STATIC_ASSERT(sizeof(cmx_rain_freezing_##SFX) == 2 * sizeof(FT), "cmx_rain_freezing");\
@@ -586,12 +587,12 @@ int32_t cmx_water_activity_f64(const cmx_thermo_f64 *tps, int64_t n, const doubl
  *
  * `flags` = the reference's Microphysics1MOptions (src/parameters/Microphysics1MOptions.jl:257-286):
  * one bit per process / variant; a cleared bit is the reference's `nothing` (process disabled).
- * CMX_1M_DEFAULT_OPTIONS reproduces `Microphysics1MOptions()`.  TemperatureDependent cloud-ice formation
- * (Frostenberg INP timescale) is not on this path: CMX_ERR_UNSUPPORTED.
+ * CMX_1M_DEFAULT_OPTIONS reproduces `Microphysics1MOptions()`.  Exactly one variant bit of a process may be set
+ * (CMX_ERR_BAD_ARG otherwise).
  * ------------------------------------------------------------------------- */
 #define CMX_1M_CLOUD_LIQUID_FORMATION     (1u << 0)   /* CloudLiquidFormation        NonEq:104-140 */
 #define CMX_1M_CLOUD_ICE_FORMATION_CONST  (1u << 1)   /* ConstantTimescale           NonEq:163-193 */
-#define CMX_1M_CLOUD_ICE_FORMATION_TDEP   (1u << 2)   /* TemperatureDependent — unsupported */
+#define CMX_1M_CLOUD_ICE_FORMATION_TDEP   (1u << 2)   /* TemperatureDependent          NonEq:32-50,194-224 */
 #define CMX_1M_CLOUD_ICE_MELT             (1u << 3)   /* CloudIceMelt                CM1:1055-1077 */
 #define CMX_1M_RAIN_ACNV_KESSLER          (1u << 4)   /* Kessler1M                   CM1:354-358   */
 #define CMX_1M_RAIN_ACNV_PRESCRIBED_ND    (1u << 5)   /* PrescribedNd                CM1:359-364   */
@@ -653,6 +654,15 @@ int32_t cmx_mp1m_linearized_average_f64(const cmx_microphysics_1m_f64 *mp, const
                                         double dt, int32_t nsub, int64_t n, const double *rho, const double *T, const double *q_tot,
                                         const double *q_lcl, const double *q_icl, const double *q_rai, const double *q_sno,
                                         double *dq_lcl_dt, double *dq_icl_dt, double *dq_rai_dt, double *dq_sno_dt, void *stream);
+
+/* … and behind the host model's layouts, exactly as cmx_mp1m_tendencies_fields_* (segmented columns in place, SoA or the reference's
+ * array-of-NamedTuples output).  Bit-identical to cmx_mp1m_linearized_average_*. */
+int32_t cmx_mp1m_linearized_average_fields_f32(const cmx_microphysics_1m_f32 *mp, const cmx_thermo_f32 *tps, uint32_t flags, float q_min, float dt,
+                                               int32_t nsub, int64_t n_seg, int64_t seg_len, const float *const *in, const int64_t *in_seg_stride,
+                                               float *const *out, const int64_t *out_seg_stride, float *out_aos, void *stream);
+int32_t cmx_mp1m_linearized_average_fields_f64(const cmx_microphysics_1m_f64 *mp, const cmx_thermo_f64 *tps, uint32_t flags, double q_min, double dt,
+                                               int32_t nsub, int64_t n_seg, int64_t seg_len, const double *const *in, const int64_t *in_seg_stride,
+                                               double *const *out, const int64_t *out_seg_stride, double *out_aos, void *stream);
 
 /* The individual 1M source terms — `_microphysics_source_terms` (BMT:141-217), same inputs (clamped the
  * same way), `out` = host array of CMX_MP1M_NSRC device column pointers (NULL = skip). */

@@ -65,6 +65,43 @@ static inline FT FN(o_conv_q_vap_to_q_icl_const)(FT tau, const TY(cmx_thermo) * 
     return limiter ? (FT)0 : tendency;
 }
 
+/* CMI_het.INP_concentration_mean — src/IceNucleation.jl:250-253 */
+static inline FT FN(o_INP_concentration_mean)(const TY(cmx_frostenberg2023) * ip, FT T) {
+    FT T_celsius = FN(o_min)(T - ip->T_freeze, (FT)0);
+    return 9 * M_LOG(-ip->b * T_celsius / 10) - ip->log_a;
+}
+/* CMNonEq.τ_relax — src/MicrophysicsNonEq.jl:32-50 (cbrt from libm, as Julia's) */
+static inline FT FN(o_tau_relax)(FT rho_i, FT D_vapor, const TY(cmx_frostenberg2023) * ip, FT q_icl, FT T, FT eps) {
+    FT N_icl = M_EXP(FN(o_INP_concentration_mean)(ip, T));
+    FT safe_N_icl = FN(o_max)(N_icl, eps);
+    FT r = N_icl > eps ? M_CBRT((3 * q_icl) / (4 * (FT)M_PI * safe_N_icl * rho_i)) : (FT)0;
+    FT r0 = (FT)1e-6;
+    FT r_safe = FN(o_max)(r, r0);
+    return 1 / (4 * (FT)M_PI * D_vapor * N_icl * r_safe);
+}
+/* CMNonEq.conv_q_vap_to_q_icl(::TemperatureDependent, …) — src/MicrophysicsNonEq.jl:194-224 */
+static inline FT FN(o_conv_q_vap_to_q_icl_tdep)(const TY(cmx_microphysics_1m) * mp, const TY(cmx_thermo) * tps, FT q_tot, FT q_lcl,
+                                               FT q_icl, FT q_rai, FT q_sno, FT rho, FT T, FT eps, FT *scale) {
+    const TY(cmx_process_params_1m) *pp = &mp->process_params;
+    FT tau_sub = pp->cloud_ice_formation_tau_relax;
+    FT tau_dep = FN(o_tau_relax)(mp->cloud_ice.rho_i, mp->air_properties.D_vapor, &pp->cloud_ice_formation_frostenberg, q_icl, T, eps);
+    FT R_v = tps->R_v;
+    FT L_s = FN(o_latent_heat_sublim)(tps, T);
+    FT cp_air = FN(o_cp_m)(tps, q_tot, q_lcl + q_rai, q_icl + q_sno);
+    FT q_v = FN(o_q_vap)(q_tot, q_lcl + q_rai, q_icl + q_sno);
+    FT q_sat = FN(o_qsat_ice)(tps, T, rho);
+    FT dqsi_dT = q_sat * (L_s / (R_v * (T * T)) - 1 / T);
+    FT Gamma_i = 1 + (L_s / cp_air) * dqsi_dT;
+    FT sat_excess = q_v - q_sat;
+    FT sublimation_timescale = tau_sub * Gamma_i;
+    FT deposition_timescale = tau_dep * Gamma_i;
+    if (scale) *scale = (M_ABS(q_v) + M_ABS(q_sat)) / M_ABS(sat_excess < 0 ? sublimation_timescale : deposition_timescale);
+    FT tendency = sat_excess < 0 ? -FN(o_min)(-sat_excess, FN(o_max)((FT)0, q_icl)) / sublimation_timescale
+                                 : sat_excess / deposition_timescale;
+    int limiter = (T > tps->T_freeze) && (tendency > 0);
+    return limiter ? (FT)0 : tendency;
+}
+
 /* CM1.get_n0(::ParticlePDFSnow) — src/Microphysics1M.jl:83-86 */
 static inline FT FN(o_get_n0_snow)(const TY(cmx_snow) * s, FT q_sno, FT rho, FT eps) {
     FT safe_q = FN(o_max)(q_sno, eps);
@@ -188,6 +225,9 @@ static inline TY(cmxo_src_1m) FN(o_source_terms_1m)(const TY(cmx_microphysics_1m
     if (flags & CMX_1M_CLOUD_ICE_FORMATION_CONST)
         o.s[CMX_1M_S_PHASE_CHANGE_VAP_ICL] = FN(o_conv_q_vap_to_q_icl_const)(
             pp->cloud_ice_formation_tau_relax, tps, q_tot, q_lcl, q_icl, q_rai, q_sno, rho, T, &o.scale_vap_icl);
+    else if (flags & CMX_1M_CLOUD_ICE_FORMATION_TDEP)
+        o.s[CMX_1M_S_PHASE_CHANGE_VAP_ICL] =
+            FN(o_conv_q_vap_to_q_icl_tdep)(mp, tps, q_tot, q_lcl, q_icl, q_rai, q_sno, rho, T, eps, &o.scale_vap_icl);
     /* rain autoconversion — CM1:354-364 */
     if (flags & CMX_1M_RAIN_ACNV_KESSLER) {
         o.s[CMX_1M_S_ACNV_LCL_RAI] = FN(o_logistic_function_integral)(q_lcl, pp->rain_autoconversion.q_threshold,

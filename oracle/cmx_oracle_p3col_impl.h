@@ -307,11 +307,7 @@ static inline FT FN(o_P3_het_N_i)(const TY(cmx_morrison_milbrandt2014) * ip, FT 
     FT Ts = ip->T0 - T;
     return N_l * (1 - M_EXP(-ip->het_B * V_l * dt * M_EXP(ip->het_a * Ts)));
 }
-/* INP_concentration_mean — :250-253;  INP_concentration_frequency — :221-226 */
-static inline FT FN(o_INP_concentration_mean)(const TY(cmx_frostenberg2023) * ip, FT T) {
-    FT T_celsius = FN(o_min)(T - ip->T_freeze, (FT)0);
-    return 9 * M_LOG(-ip->b * T_celsius / 10) - ip->log_a;
-}
+/* INP_concentration_mean — :250-253: restated in cmx_oracle_1m_impl.h (first user);  INP_concentration_frequency — :221-226 */
 static inline FT FN(o_INP_concentration_frequency)(const TY(cmx_frostenberg2023) * ip, FT INPC, FT T) {
     if (T >= ip->T_freeze) return 0;
     FT mu = FN(o_INP_concentration_mean)(ip, T);

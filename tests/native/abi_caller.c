@@ -21,7 +21,7 @@
 /* the layout contract, asserted again from the caller's side (C11 _Static_assert; cmx.h carries the full list) */
 _Static_assert(sizeof(cmx_thermo_f32) == 13 * 4 && sizeof(cmx_thermo_f64) == 13 * 8, "cmx_thermo_*: 13 fields (cv_l is the 13th)");
 _Static_assert(sizeof(cmx_warm_rain_2m_f32) == 50 * 4 && sizeof(cmx_warm_rain_2m_f64) == 50 * 8, "cmx_warm_rain_2m_*: 50 fields");
-_Static_assert(sizeof(cmx_microphysics_1m_f64) == 85 * 8, "cmx_microphysics_1m_*: 85 fields");
+_Static_assert(sizeof(cmx_microphysics_1m_f64) == 90 * 8, "cmx_microphysics_1m_*: 90 fields");
 _Static_assert(sizeof(cmx_rain_vel_f64) == 19 * 8, "cmx_rain_vel_*: 7 + 12 fields");
 
 #define N 8   /* identical points, as the reference's KA tests launch ndrange = 10 copies (test/gpu_tests.jl:825-833) */

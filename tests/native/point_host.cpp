@@ -1,0 +1,77 @@
+// point_host.cpp — TEST INFRASTRUCTURE: the device point functions of csrc/ compiled by g++ for the HOST (CMX_HOST_BUILD: libm stand-ins
+// for the hardware transcendental instructions, no kernel-argument tricks) so that their algebra — host-folded constants, log2-domain
+// rewrites, gates — can be checked against the oracle in the CPU test suite (tests/test_point_host.py), without a GPU.  It is NOT part
+// of libcmx.so, nothing in the package loads it, and it is no CPU fallback: the product has none (cmx._lib raises without libcmx.so).
+// Rounding differs from the device (libm exp2f/log2f vs v_exp_f32/v_log_f32, 1/x vs v_rcp_f32), so this checks formulas at the parity
+// tolerances, not bits; the -m gpu suite remains the parity gate.
+#define CMX_HOST_BUILD 1
+#include <cstdint>
+
+#include "../../cloudmicrophysics.jl_amd/csrc/cmx_mp1m.hpp"
+#include "../../cloudmicrophysics.jl_amd/csrc/cmx_mp1m_vel.hpp"
+
+namespace {
+using namespace cmx;
+
+template <typename FT, typename MP, typename TH>
+int32_t tendencies(const MP *mp, const TH *tps, uint32_t flags, int64_t n, const FT *const *x, FT *const *y) {
+    const Mp1mConsts<FT> c = make_mp1m_consts<FT>(*mp, *tps, flags, (double)Math<FT>::eps_1m());
+    const bool def = flags == CMX_1M_DEFAULT_OPTIONS && mp1m_default_exponents(c);
+    for (int64_t i = 0; i < n; ++i) {
+        if (def) mp1m_tendencies_point<FT, CMX_1M_DEFAULT_OPTIONS | kDefExpBit>(c, x[0][i], x[1][i], x[2][i], x[3][i], x[4][i], x[5][i], x[6][i], y[0][i], y[1][i], y[2][i], y[3][i]);
+        else mp1m_tendencies_point<FT>(c, x[0][i], x[1][i], x[2][i], x[3][i], x[4][i], x[5][i], x[6][i], y[0][i], y[1][i], y[2][i], y[3][i]);
+    }
+    return def ? 1 : 0;
+}
+template <typename FT, typename MP, typename TH>
+int32_t sources(const MP *mp, const TH *tps, uint32_t flags, int64_t n, const FT *const *x, FT *const *s) {
+    const Mp1mConsts<FT> c = make_mp1m_consts<FT>(*mp, *tps, flags, (double)Math<FT>::eps_1m());
+    const bool def = flags == CMX_1M_DEFAULT_OPTIONS && mp1m_default_exponents(c);
+    for (int64_t i = 0; i < n; ++i) {
+        const Mp1mSrc<FT> p = def ? mp1m_point<FT, CMX_1M_DEFAULT_OPTIONS | kDefExpBit>(c, x[0][i], x[1][i], x[2][i], x[3][i], x[4][i], x[5][i], x[6][i])
+                                  : mp1m_point<FT>(c, x[0][i], x[1][i], x[2][i], x[3][i], x[4][i], x[5][i], x[6][i]);
+        FT e[CMX_MP1M_NSRC];
+        mp1m_expand<FT>(p, e);
+        for (int k = 0; k < CMX_MP1M_NSRC; ++k) s[k][i] = e[k];
+    }
+    return def ? 1 : 0;
+}
+template <typename FT, typename MP, typename TH>
+int32_t linearized(const MP *mp, const TH *tps, uint32_t flags, FT q_min, FT dt, int32_t nsub, int64_t n, const FT *const *x, FT *const *y) {
+    const Mp1mConsts<FT> c = make_mp1m_consts<FT>(*mp, *tps, flags, (double)Math<FT>::eps_1m());
+    const Mp1mLinArgs<FT> a = make_mp1m_lin_args<FT>(q_min, dt, nsub, (FT)tps->LH_v0, (FT)tps->LH_s0, (FT)tps->cp_d);
+    const bool def = flags == CMX_1M_DEFAULT_OPTIONS && mp1m_default_exponents(c);
+    auto args = [&](FT) -> const Mp1mLinArgs<FT> & { return a; };
+    for (int64_t i = 0; i < n; ++i) {
+        if (def) mp1m_linearized_point<FT, CMX_1M_DEFAULT_OPTIONS | kDefExpBit>(c, args, nsub, x[0][i], x[1][i], x[2][i], x[3][i], x[4][i], x[5][i], x[6][i], y[0][i], y[1][i], y[2][i], y[3][i]);
+        else mp1m_linearized_point<FT>(c, args, nsub, x[0][i], x[1][i], x[2][i], x[3][i], x[4][i], x[5][i], x[6][i], y[0][i], y[1][i], y[2][i], y[3][i]);
+    }
+    return def ? 1 : 0;
+}
+// the four sedimentation velocities (w_lcl, w_icl, w_rai, w_sno) of (rho, q_lcl, q_icl, q_rai, q_sno)
+template <typename FT, typename MP, typename ST, typename CH, typename CI>
+int32_t sedimentation(const MP *mp, const ST *stokes, const CH *chen_rain, const CI *chen_ice, int general_gamma, int64_t n, const FT *const *x, FT *const *w) {
+    Vel1mConsts<FT> c = make_vel1m_consts<FT>(*mp, chen_rain);
+    add_sedimentation_consts<FT>(c, *mp, stokes, chen_ice);
+    for (int64_t i = 0; i < n; ++i) {
+        const FT rho = x[0][i], rp = Math<FT>::max(FT(0), rho);
+        w[0][i] = vel_lcl_stokes<FT>(c, rho, x[1][i]);
+        w[1][i] = vel_icl_chen<FT>(c, rho, rp, x[2][i]);
+        const FT l2r = vel_l2_li_rain<FT>(c, rp, x[3][i]);
+        w[2][i] = general_gamma ? vel_rain_chen<FT, true>(c, rp, l2r, x[3][i]) : vel_rain_chen<FT, false>(c, rp, l2r, x[3][i]);
+        w[3][i] = vel_snow_chen<FT>(c, rp, vel_l2_li_snow<FT>(c, rp, x[4][i]), x[4][i]);
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+int32_t host_mp1m_tendencies_f32(const cmx_microphysics_1m_f32 *mp, const cmx_thermo_f32 *tps, uint32_t flags, int64_t n, const float *const *x, float *const *y) { return tendencies<float>(mp, tps, flags, n, x, y); }
+int32_t host_mp1m_tendencies_f64(const cmx_microphysics_1m_f64 *mp, const cmx_thermo_f64 *tps, uint32_t flags, int64_t n, const double *const *x, double *const *y) { return tendencies<double>(mp, tps, flags, n, x, y); }
+int32_t host_mp1m_sources_f32(const cmx_microphysics_1m_f32 *mp, const cmx_thermo_f32 *tps, uint32_t flags, int64_t n, const float *const *x, float *const *s) { return sources<float>(mp, tps, flags, n, x, s); }
+int32_t host_mp1m_sources_f64(const cmx_microphysics_1m_f64 *mp, const cmx_thermo_f64 *tps, uint32_t flags, int64_t n, const double *const *x, double *const *s) { return sources<double>(mp, tps, flags, n, x, s); }
+int32_t host_mp1m_linearized_f32(const cmx_microphysics_1m_f32 *mp, const cmx_thermo_f32 *tps, uint32_t flags, float q_min, float dt, int32_t nsub, int64_t n, const float *const *x, float *const *y) { return linearized<float>(mp, tps, flags, q_min, dt, nsub, n, x, y); }
+int32_t host_mp1m_linearized_f64(const cmx_microphysics_1m_f64 *mp, const cmx_thermo_f64 *tps, uint32_t flags, double q_min, double dt, int32_t nsub, int64_t n, const double *const *x, double *const *y) { return linearized<double>(mp, tps, flags, q_min, dt, nsub, n, x, y); }
+int32_t host_sedimentation_f32(const cmx_microphysics_1m_f32 *mp, const cmx_stokes_vel_f32 *st, const cmx_chen2022_rain_vel_f32 *cr, const cmx_chen2022_ice_vel_f32 *ci, int general_gamma, int64_t n, const float *const *x, float *const *w) { return sedimentation<float>(mp, st, cr, ci, general_gamma, n, x, w); }
+int32_t host_sedimentation_f64(const cmx_microphysics_1m_f64 *mp, const cmx_stokes_vel_f64 *st, const cmx_chen2022_rain_vel_f64 *cr, const cmx_chen2022_ice_vel_f64 *ci, int general_gamma, int64_t n, const double *const *x, double *const *w) { return sedimentation<double>(mp, st, cr, ci, general_gamma, n, x, w); }
+}

@@ -22,6 +22,8 @@ OPTION_SETS = {
     "alt": dict(snow_autoconversion=P.WithSupersaturation(), snow_deposition_sublimation=P.SublimationOnly(),
                 rain_autoconversion=P.PrescribedNd()),
     "sparse": dict(rain_snow_accretion=None, cloud_ice_melt=None, cloud_liquid_snow_accretion=None, snow_melt=None),
+    # TemperatureDependent cloud-ice formation (Frostenberg 2023 INP timescale, NonEq:32-50,194-224): round 3
+    "tdep": dict(cloud_ice_formation=P.TemperatureDependent()),
 }
 
 
@@ -72,9 +74,14 @@ def test_kats_through_the_abi(dev, ft):
     r = cmx.microphysics_source_terms_1m(nd, tps, col(1.0), col(280.0), col(0.0), torch.tensor([g["q_lcl"], 0.0], dtype=DT[ft], device=dev),
                                          col(0.0), col(0.0), col(0.0))
     assert math.isclose(r.S_acnv_lcl_rai[0].item(), g["expected"], rel_tol=g["rtol"]) and r.S_acnv_lcl_rai[1].item() == 0
-    with pytest.raises(cmx.CmxStatusError):   # TemperatureDependent is CMX_ERR_UNSUPPORTED
-        cmx.microphysics_source_terms_1m(P.Microphysics1MParams(ft, cloud_ice_formation=P.TemperatureDependent()), tps,
-                                         *[col(1.0)] * 7)
+    with pytest.raises(cmx.CmxStatusError):   # two variants of one process → CMX_ERR_BAD_ARG
+        both = P.Microphysics1MParams(ft)
+        fn = getattr(cmx._lib.lib(), f"cmx_mp1m_source_terms_{ft}")
+        import ctypes as C
+        arr = (C.c_void_p * _abi.CMX_MP1M_NSRC)()
+        z = col(1.0)
+        cmx._lib.check("cmx_mp1m_source_terms", fn(C.byref(both.c), C.byref(tps), both.flags | _abi.CMX_1M_CLOUD_ICE_FORMATION_TDEP, 2,
+                                                   *[C.c_void_p(z.data_ptr())] * 7, arr, None))
 
 
 @pytest.mark.parametrize("ft", ["f32", "f64"])

@@ -106,6 +106,52 @@ def test_mass_budget_and_nonnegativity_on_random_states(oracle):
         assert np.all(q0 + dt * t[k] >= -1e-18), k
 
 
+
+
+def check_linearized_parity(ft, got, ref, inst, c64, dt, what):
+    """Parity of average tendencies `got` (name → array) against the oracle's `ref`, shared by the GPU test below and by the host
+    build of the point functions (tests/test_point_host.py).
+
+    Tolerance = the library's parity metric (tests/parity.py): RTOL·|ref| + CTOL·scale, where scale = Σ|operand terms| of the source
+    terms the step is built from (q_v − q_sat, T − T_freeze, … cancel in Float32: the Instantaneous tendency of such a state already
+    differs by 10 % between Float32 and Float64 arithmetic), plus the rounding floor of (q_new − q_old)/Δt, eps·q/Δt (the reference's
+    own remark, test/bulk_tendencies_tests.jl:924-926).  States within rounding of T_freeze may route warm/cold differently in
+    another precision (genuine discontinuity): excluded and counted.
+
+    The PLAIN north-star bound |x − ref| ≤ RTOL·|ref| is asserted as everywhere else (fraction inside ≥ MIN_FRAC_WITHIN, worst
+    well-conditioned point ≤ RTOL) — for Float32 on the points where it is attainable: the average tendency is a difference quotient
+    (q_new − q_old)/Δt whose Float32 rounding floor eps·q/Δt no evaluation can avoid, so points whose floor exceeds RTOL·|tendency|
+    are set aside, counted, and must stay below 10 % of the states at operational time steps (20 % at the Δt = 0.01 s probe)."""
+    import parity
+    scale = sum(inst["scale"].values())
+    near = np.abs(c64[1] - T_FREEZE) < (1e-3 if ft == "f32" else 1e-9)
+    eps = {"f64": 2.2e-16, "f32": 1.2e-7}[ft]
+    worst = {}
+    for k, q0 in zip(NAMES, c64[3:]):
+        x, r = np.asarray(got[k], dtype=np.float64), ref[k]
+        assert np.all(np.isfinite(x)), k
+        floor = 8 * eps * (q0 + np.abs(r) * dt) / dt
+        tol = parity.RTOL[ft] * np.abs(r) + LIN_AMPLIFY * parity.CTOL[ft] * scale + floor
+        worst[k] = float((np.abs(x - r) / np.maximum(tol, 1e-300))[~near].max())
+        assert worst[k] <= 1.0, (k, worst)
+        # one rounding of q in (q_new − q_old)/Δt is eps·q/Δt; the worst-point statistic needs the margin of a second one (the substep
+        # update q += (q* − q)/Δt_sub · Δt_sub, BMT:606-617, rounds q again)
+        attainable, attainable2 = eps * q0 / dt <= parity.RTOL[ft] * np.abs(r), 2 * eps * q0 / dt <= parity.RTOL[ft] * np.abs(r)
+        f64 = ft == "f64"
+        frac_set_aside = 0.0 if f64 else float((~attainable & ~near).sum()) / max(int((~near).sum()), 1)
+        ps = parity.plain_stats(x, r, scale, parity.RTOL[ft], parity.FLOOR[ft], parity.CEIL[ft], ~near & (attainable | f64), parity.WELLCOND[ft])
+        ps2 = parity.plain_stats(x, r, scale, parity.RTOL[ft], parity.FLOOR[ft], parity.CEIL[ft], ~near & (attainable2 | f64), parity.WELLCOND[ft])
+        ps["worst_wellcond"], ps["n_wellcond"] = ps2["worst_wellcond"], ps2["n_wellcond"]
+        parity.REPORTS.append({"what": what, "output": k, "ft": ft, "rtol": parity.RTOL[ft], "worst_normalised": worst[k] * parity.RTOL[ft],
+                               "frac_below_difference_quotient_floor": frac_set_aside, **ps})
+        # measured (host build of the point function, 200 003 states): 16 % of the q_rai tendencies and 10 % of the q_sno ones sit below
+        # their floor at the Δt = 0.01 s probe (the reference's "small Δt → Instantaneous" test), < 0.3 % at Δt = 20 s and 60 s
+        assert frac_set_aside < (0.10 if dt >= 1.0 else 0.20), (k, frac_set_aside)
+        assert ps["frac_within"] >= parity.MIN_FRAC_WITHIN[ft] and ps["worst_wellcond"] <= parity.RTOL[ft], (k, ps, frac_set_aside)
+    print(f"\n[{what}: error / tolerance] {worst} (excluded near T_freeze: {int(near.sum())})")
+    return worst
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("ft", ["f64", "f32"])
@@ -125,41 +171,9 @@ def test_gpu_parity_with_the_oracle(oracle, ft, dt, nsub):
     mp64 = P.Microphysics1MParams("f64")
     ref = oracle.mp1m_linearized_average(F64, mp64.c, P.ThermodynamicsParameters("f64"), mp64.flags, Q_MIN, dt, nsub, *c64,
                                          float32_gates=(ft == "f32"), nthreads=8)
-    # Tolerance = the library's parity metric (tests/parity.py): RTOL·|ref| + CTOL·scale, where scale = Σ|operand terms| of
-    # the source terms the step is built from (q_v − q_sat, T − T_freeze, … cancel in Float32: the Instantaneous tendency
-    # of such a state already differs by 10 % between Float32 and Float64 arithmetic), plus the rounding floor of
-    # (q_new − q_old)/Δt, eps·q/Δt (the reference's own remark, test/bulk_tendencies_tests.jl:924-926).
-    # States within rounding of T_freeze may route warm/cold differently in another precision (genuine discontinuity).
-    import parity
     inst = oracle.mp1m(F64, mp64.c, P.ThermodynamicsParameters("f64"), mp64.flags, *c64, float32_gates=(ft == "f32"), nthreads=8,
                        want_sources=False)
-    scale = sum(inst["scale"].values())
-    near = np.abs(c64[1] - T_FREEZE) < (1e-3 if ft == "f32" else 1e-9)
-    eps = {"f64": 2.2e-16, "f32": 1.2e-7}[ft]
-    worst, worst1 = {}, {}
-    for k, q0 in zip(NAMES, c64[3:]):
-        x, r = got._asdict()[k].cpu().numpy().astype(np.float64), ref[k]
-        assert np.all(np.isfinite(x)), k
-        # The average tendency is (q_new − q_old)/Δt after nsub implicit substeps of a 4×4 system built from the source terms; the
-        # allowance is the Instantaneous one (LIN_AMPLIFY = 1) plus the rounding floor of the difference quotient.  The worst error in
-        # units of that tolerance is printed and recorded next to the plain-bound statistics.
-        floor = 8 * eps * (q0 + np.abs(r) * dt) / dt
-        tol1 = parity.RTOL[ft] * np.abs(r) + parity.CTOL[ft] * scale + floor
-        tol = parity.RTOL[ft] * np.abs(r) + LIN_AMPLIFY * parity.CTOL[ft] * scale + floor
-        e = (np.abs(x - r) / np.maximum(tol, 1e-300))[~near]
-        worst[k] = float(e.max())
-        worst1[k] = float((np.abs(x - r) / np.maximum(tol1, 1e-300))[~near].max())
-        assert worst[k] <= 1.0, (k, worst)
-        ps = parity.plain_stats(x, r, scale, parity.RTOL[ft], parity.FLOOR[ft], parity.CEIL[ft], ~near, parity.WELLCOND[ft])
-        parity.REPORTS.append({"what": f"1M LinearizedAverage {ft} dt={dt} nsub={nsub}", "output": k, "ft": ft, "rtol": parity.RTOL[ft],
-                               "worst_normalised": worst[k] * parity.RTOL[ft], "worst_in_units_of_1x_tolerance": worst1[k], **ps})
-        # plain bound: asserted for Float64 as everywhere (≥ 0.999).  Float32: recorded only — the average tendency is (q_new − q_old)/Δt,
-        # whose rounding floor eps·q/Δt alone exceeds 1e-3·|tendency| for 1–8 % of the states at Δt = 0.01 s (measured: 0.989 for q_lcl,
-        # 0.918 for q_rai), which no Float32 evaluation of that difference can avoid; the operand-aware bound above is the test
-        if ft == "f64":
-            assert ps["frac_within"] >= 0.999 and ps["worst_wellcond"] <= parity.RTOL[ft], (k, ps)
-    print(f"\n[1M LinearizedAverage parity, error / tolerance] {ft} dt={dt} nsub={nsub}: {worst}; in units of the Instantaneous (1x) tolerance: "
-          f"{worst1} (excluded near T_freeze: {int(near.sum())})")
+    check_linearized_parity(ft, {k: got._asdict()[k].cpu().numpy() for k in NAMES}, ref, inst, c64, dt, f"1M LinearizedAverage {ft} dt={dt} nsub={nsub}")
 
 
 @pytest.mark.gpu

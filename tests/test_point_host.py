@@ -1,0 +1,147 @@
+"""CPU check of the DEVICE point functions' algebra: csrc/cmx_mp1m.hpp / cmx_mp1m_vel.hpp compiled by g++ for the host
+(tests/native/point_host.cpp, CMX_HOST_BUILD: libm stand-ins for v_exp_f32 / v_log_f32 / v_rcp_f32) against the oracle on the same
+random states the GPU parity tests use.  This is test infrastructure — it is not linked into libcmx.so, nothing in the package loads
+it, and it proves formulas (host-folded constants, log2-domain rewrites, gates), not device bits: the -m gpu suite is the parity gate."""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import parity
+from cmx import _abi, synthetic
+from cmx import parameters as P
+from test_mp1m_linearized import NAMES, Q_MIN, _random_state, check_linearized_parity
+
+REPO = Path(__file__).resolve().parent.parent
+NPT = {"f32": np.float32, "f64": np.float64}
+CT = {"f32": C.c_float, "f64": C.c_double}
+T_FREEZE = P.DEFAULT_PARAMETERS["temperature_water_freeze"]
+OPTION_SETS = {
+    "default": {},
+    "alt": dict(snow_autoconversion=P.WithSupersaturation(), snow_deposition_sublimation=P.SublimationOnly(),
+                rain_autoconversion=P.PrescribedNd()),
+    "sparse": dict(rain_snow_accretion=None, cloud_ice_melt=None, cloud_liquid_snow_accretion=None, snow_melt=None),
+    "tdep": dict(cloud_ice_formation=P.TemperatureDependent()),
+}
+
+
+@pytest.fixture(scope="module")
+def host():
+    out = REPO / "tests" / "native" / "_build"
+    out.mkdir(exist_ok=True)
+    so = out / "libpoint_host.so"
+    subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-o", str(so),
+                    str(REPO / "tests" / "native" / "point_host.cpp")], check=True)
+    return C.CDLL(str(so))
+
+
+def _ptrs(arrs, ft):
+    return (C.POINTER(CT[ft]) * len(arrs))(*[a.ctypes.data_as(C.POINTER(CT[ft])) for a in arrs])
+
+
+def _call(host, name, ft, head, cols, nout):
+    x = [np.ascontiguousarray(c, dtype=NPT[ft]) for c in cols]
+    y = [np.empty_like(x[0]) for _ in range(nout)]
+    fn = getattr(host, f"{name}_{ft}")
+    fn.restype = C.c_int32
+    rc = fn(*head, C.c_int64(x[0].size), _ptrs(x, ft), _ptrs(y, ft))
+    return rc, y
+
+
+def _oracle_1m(oracle, ft, opts, cols, **kw):
+    mp = P.Microphysics1MParams("f64", **opts)
+    r = oracle.mp1m(_abi.F64, mp.c, P.ThermodynamicsParameters("f64"), mp.flags, *[np.asarray(c, dtype=np.float64) for c in cols],
+                    float32_gates=(ft == "f32"), nthreads=8, **kw)
+    r["near_branch"] = np.abs(np.asarray(cols[1], dtype=np.float64) - T_FREEZE) < (1e-4 if ft == "f32" else 1e-11)
+    return r
+
+
+@pytest.mark.parametrize("ft", ["f32", "f64"])
+@pytest.mark.parametrize("optset", list(OPTION_SETS))
+def test_mp1m_tendencies_and_sources(host, oracle, ft, optset):
+    opts = OPTION_SETS[optset]
+    n = 60_000
+    st = [c.numpy() for c in synthetic.mp1m_state(n, dtype=getattr(torch, {"f32": "float32", "f64": "float64"}[ft]), seed=1234)]
+    mp, tps = P.Microphysics1MParams(ft, **opts), P.ThermodynamicsParameters(ft)
+    head = (C.byref(mp.c), C.byref(tps), C.c_uint32(mp.flags))
+    rc, tend = _call(host, "host_mp1m_tendencies", ft, head, st, 4)
+    assert rc == (1 if optset == "default" else 0)          # the default set takes the default-exponent instantiation
+    _, src = _call(host, "host_mp1m_sources", ft, head, st, _abi.CMX_MP1M_NSRC)
+    ref = _oracle_1m(oracle, ft, opts, st)
+    rep = parity.assert_parity(dict(zip(NAMES, tend)), ref, parity.RTOL[ft], names=list(NAMES), what=f"host-build 1M {ft} {optset}")
+    keep = ~ref["near_branch"]
+    cancel = {"S_phase_change_vap_lcl": "dq_lcl_dt", "S_phase_change_vap_icl": "dq_icl_dt", "S_phase_change_vap_rai": "dq_rai_dt",
+              "S_phase_change_vap_sno": "dq_sno_dt", "S_melt_icl_lcl": "dq_icl_dt", "S_melt_sno_rai": "dq_sno_dt",
+              "S_accr_melt_lcl_sno": "dq_sno_dt", "S_accr_melt_rai_sno": "dq_sno_dt", "S_acnv_icl_sno": "dq_icl_dt",
+              "S_acnv_lcl_rai": "dq_lcl_dt"}
+    for k, got in zip(_abi.MP1M_SOURCE_COLUMNS, src):
+        sc = ref["scale"][cancel[k]] if k in cancel else None
+        e = parity.scaled_err(got, ref["sources"][k], sc, parity.FLOOR[ft], parity.CEIL[ft], parity.CTOL[ft] / parity.RTOL[ft])[keep]
+        assert float(np.nan_to_num(e, nan=np.inf).max()) <= parity.RTOL[ft], (k, optset, ft)
+    print(f"\n[host build, 1M {ft} {optset}] worst normalised error per tendency {rep}")
+
+
+def test_mp1m_general_exponent_instantiation_matches_default(host, oracle):
+    """A parameter set one ulp away from the default exponents takes the general exp2(e·log2 λ⁻¹) forms: same numbers."""
+    n = 20_000
+    st = [c.numpy() for c in synthetic.mp1m_state(n, dtype=torch.float64, seed=7)]
+    tps = P.ThermodynamicsParameters("f64")
+    mp = P.Microphysics1MParams("f64")
+    head = (C.byref(mp.c), C.byref(tps), C.c_uint32(mp.flags))
+    rc0, a = _call(host, "host_mp1m_tendencies", "f64", head, st, 4)
+    mp2 = P.Microphysics1MParams("f64")
+    mp2.c.vel_rain.ve = np.nextafter(mp2.c.vel_rain.ve, 1.0)
+    rc1, b = _call(host, "host_mp1m_tendencies", "f64", (C.byref(mp2.c), C.byref(tps), C.c_uint32(mp2.flags)), st, 4)
+    assert (rc0, rc1) == (1, 0)
+    for x, y in zip(a, b):
+        np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-30)
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+@pytest.mark.parametrize("dt,nsub", [(1e-2, 1), (20.0, 1), (60.0, 4)])
+def test_mp1m_linearized_average(host, oracle, ft, dt, nsub):
+    n = 40_000
+    st = [c.astype(NPT[ft]) for c in _random_state(n, seed=21)]
+    mp, tps = P.Microphysics1MParams(ft), P.ThermodynamicsParameters(ft)
+    head = (C.byref(mp.c), C.byref(tps), C.c_uint32(mp.flags), CT[ft](Q_MIN), CT[ft](dt), C.c_int32(nsub))
+    _, got = _call(host, "host_mp1m_linearized", ft, head, st, 4)
+    c64 = [c.astype(np.float64) for c in st]
+    mp64 = P.Microphysics1MParams("f64")
+    ref = oracle.mp1m_linearized_average(_abi.F64, mp64.c, P.ThermodynamicsParameters("f64"), mp64.flags, Q_MIN, dt, nsub, *c64,
+                                         float32_gates=(ft == "f32"), nthreads=8)
+    inst = oracle.mp1m(_abi.F64, mp64.c, P.ThermodynamicsParameters("f64"), mp64.flags, *c64, float32_gates=(ft == "f32"), nthreads=8,
+                       want_sources=False)
+    check_linearized_parity(ft, dict(zip(NAMES, got)), ref, inst, c64, dt, f"host-build 1M LinearizedAverage {ft} dt={dt} nsub={nsub}")
+
+
+@pytest.mark.parametrize("ft", ["f32", "f64"])
+@pytest.mark.parametrize("general", [0, 1])
+def test_sedimentation_velocities(host, oracle, ft, general):
+    """The four fall speeds a host model precomputes, both Γ instantiations of the Chen-2022 rain term."""
+    n = 50_000
+    rng = np.random.default_rng(3)
+    rho = rng.uniform(0.3, 1.3, n)
+    q = [np.where(rng.random(n) < 0.2, 0.0, 10 ** rng.uniform(-8, -2.5, n)) for _ in range(4)]
+    mp = P.Microphysics1MParams(ft)
+    stokes, cr, ci = P.StokesRegimeVelType(ft), P.Chen2022VelTypeRain(ft), P.Chen2022VelTypeIce(ft)
+    head = (C.byref(mp.c), C.byref(stokes), C.byref(cr), C.byref(ci), C.c_int(general))
+    _, w = _call(host, "host_sedimentation", ft, head, [rho] + q, 4)
+    mp64 = P.Microphysics1MParams("f64")
+    x64 = [np.asarray(c, dtype=NPT[ft]).astype(np.float64) for c in [rho] + q]
+    ref = oracle.sedimentation_velocities(_abi.F64, mp64.c, P.StokesRegimeVelType("f64"), P.Chen2022VelTypeRain("f64"), P.Chen2022VelTypeIce("f64"),
+                                          *x64, float32_gates=(ft == "f32"))
+    # the Chen-2022 ice curves are differences of two terms that cancel near the zero crossing (E + F e^{−cD} with E ≈ −F): conditioning
+    # scale = the positive term alone (oracle evaluated with the negative amplitude switched off), as in tests/test_mp1m_gpu.py
+    pos = P.Chen2022VelTypeIce("f64")
+    pos.small_ice.F[0] = -1e30
+    pos.large_ice.E[0], pos.large_ice.E[1], pos.large_ice.E[2] = 0.0, 0.0, 0.0
+    scale = oracle.sedimentation_velocities(_abi.F64, mp64.c, P.StokesRegimeVelType("f64"), P.Chen2022VelTypeRain("f64"), pos, *x64,
+                                            float32_gates=(ft == "f32"))
+    for k, got in zip(("w_lcl", "w_icl", "w_rai", "w_sno"), w):
+        rr = ref[k]
+        sc = scale[k] if k in ("w_icl", "w_sno") else np.abs(rr)
+        tol = parity.RTOL[ft] * 0.1 * np.abs(rr) + parity.CTOL[ft] * sc
+        assert np.all(np.abs(got.astype(np.float64) - rr) <= tol + 1e-300), (k, float(np.max(np.abs(got - rr) / (tol + 1e-300))))
