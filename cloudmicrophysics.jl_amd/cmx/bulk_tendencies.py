@@ -179,7 +179,7 @@ def _segments(t: torch.Tensor, name: str):
     raise TypeError(f"{name}: expected a contiguous 1-D column or a (n_seg, seg_len) view with contiguous rows")
 
 
-def _fields_call(fn_name, params_c, tps, flags, cols, names, n_out, n_aos, out, aos, stream):
+def _fields_call(fn_name, params_c, tps, flags, cols, names, n_out, n_aos, out, aos, stream, extra=()):
     """Shared driver of the `_fields` entry points (segmented columns in; segmented columns or an (n, n_aos) array of rows out)."""
     ref = cols[0]
     fam = _fam_of(ref)
@@ -214,7 +214,7 @@ def _fields_call(fn_name, params_c, tps, flags, cols, names, n_out, n_aos, out, 
     s = stream if stream is not None else torch.cuda.current_stream(ref.device)
     fn = getattr(_lib.lib(), f"{fn_name}_{fam.sfx}")
     with torch.cuda.device(ref.device):
-        st = fn(C.byref(params_c), C.byref(tps), flags, n_seg, seg_len, in_p, in_s, out_p, out_s, C.c_void_p(aos_t.data_ptr()) if aos else None,
+        st = fn(C.byref(params_c), C.byref(tps), flags, *extra, n_seg, seg_len, in_p, in_s, out_p, out_s, C.c_void_p(aos_t.data_ptr()) if aos else None,
                 C.c_void_p(s.cuda_stream))
     _lib.check(fn.__name__, st)
     return aos_t if aos else out

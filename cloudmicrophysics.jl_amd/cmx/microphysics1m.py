@@ -86,20 +86,32 @@ def bulk_microphysics_tendencies_1m(mode, scheme, mp, tps, rho, T, q_tot, q_lcl,
     return out
 
 
-def bulk_microphysics_tendencies_1m_fields(mode, scheme, mp, tps, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno, *, out=None, aos=False, stream=None):
-    """The Instantaneous 1-moment tendencies on the host model's own storage (`cmx_mp1m_tendencies_fields_*`): every column
+def bulk_microphysics_tendencies_1m_fields(mode, scheme, mp, tps, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno, dt=None, nsub=1, *, q_min=None, out=None,
+                                           aos=False, stream=None):
+    """The 1-moment tendencies — Instantaneous, or LinearizedAverage with `dt` [, `nsub`] — on the host model's own storage (SURVEY §8f-3,
+    `cmx_mp1m_tendencies_fields_*` / `cmx_mp1m_linearized_average_fields_*`): every column
     a contiguous 1-D tensor or a (n_seg, seg_len) view with contiguous rows (a ClimaCore `VIJFH` field component in place); the result
     goes into `out` (4 tensors of the same shape → `Tendencies1M`) or, with `aos=True`, into the reference's own result layout — an
     (n, 4) tensor of NamedTuple rows (dq_lcl_dt, dq_icl_dt, dq_rai_dt, dq_sno_dt).  Bit-identical to `bulk_microphysics_tendencies_1m`."""
-    if not isinstance(scheme, Microphysics1Moment) or not isinstance(mode, Instantaneous):
-        raise TypeError("mode must be Instantaneous() and scheme Microphysics1Moment()")
+    if not isinstance(scheme, Microphysics1Moment) or not isinstance(mode, (Instantaneous, LinearizedAverage)):
+        raise TypeError("mode must be Instantaneous() or LinearizedAverage() and scheme Microphysics1Moment()")
     if not isinstance(mp, Microphysics1MParams):
         raise TypeError("mp must be Microphysics1MParams")
     fam = _fam_of(rho)
     if fam is not mp.fam or not isinstance(tps, fam.thermo):
         raise TypeError("parameter float type does not match the state columns")
-    r = _fields_call("cmx_mp1m_tendencies_fields", mp.c, tps, mp.flags, (rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno),
-                     ("rho", "T", "q_tot", "q_lcl", "q_icl", "q_rai", "q_sno"), 4, 4, out, aos, stream)
+    name, extra = "cmx_mp1m_tendencies_fields", ()
+    if isinstance(mode, LinearizedAverage):     # cmx_mp1m_linearized_average_fields_*: (q_min, Δt, nsub) after the flags
+        if dt is None or not dt > 0 or int(nsub) < 1:
+            raise ValueError("LinearizedAverage needs dt > 0 and nsub >= 1")
+        if q_min is None:
+            from .parameters import DEFAULT_PARAMETERS
+            q_min = DEFAULT_PARAMETERS["specific_humidity_minimum"]
+        name, extra = "cmx_mp1m_linearized_average_fields", (fam.ft(q_min), fam.ft(dt), C.c_int32(int(nsub)))
+    elif dt is not None:
+        raise TypeError("Instantaneous() takes no dt")
+    r = _fields_call(name, mp.c, tps, mp.flags, (rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno),
+                     ("rho", "T", "q_tot", "q_lcl", "q_icl", "q_rai", "q_sno"), 4, 4, out, aos, stream, extra)
     return r if aos else Tendencies1M(*r)
 
 

@@ -72,7 +72,8 @@ static_assert((CMX_1M_DEFAULT_OPTIONS & kDefExpBit) == 0, "internal bit collides
 #endif
 template <typename CT> inline bool mp1m_default_exponents(const CT &c) {
     return CMX_1M_DEFEXP && c.vt_e_rai == 0.5 && c.acc_e_rai == 3.5 && c.sink_e == 6.5 && c.rs_dp1_rai == 4 && c.ven_e_rai == 0.75 && c.vt_e_sno == 0.25 &&
-           c.acc_e_sno == 3.25 && c.rs_dp1_sno == 3 && c.ven_e_sno == 0.625;
+           c.acc_e_sno == 3.25 && c.rs_dp1_sno == 3 && c.ven_e_sno == 0.625 &&
+           c.ka_qthr >= c.eps_1m && c.ks_qthr >= c.eps_1m;   // … and regular autoconversion thresholds (logistic_rate)
 }
 
 template <typename FT, typename MP, typename TH>
@@ -206,10 +207,15 @@ template <typename FT> struct Mp1mSrc {
 // The reference forms the left side — a difference of two terms of size t·x0 — in FT arithmetic, so its own absolute accuracy is
 // eps(FT)·t·x0 (the oracle reports 2 t x0 as the operand scale of this term); the right side has absolute error eps(FT)·x0/k from the
 // rounding of its argument near 1, the same class.  x arrives clamped to ≥ 0; x0 < ϵ (a parameter-only case: the reference returns x)
-// takes a wave-uniform branch.
-template <typename FT> __device__ __forceinline__ FT logistic_rate(FT x, FT qthr, FT y2c, FT emk, FT omemk, FT kl2e, FT out, FT inv_tau, FT eps) {
+// takes a wave-uniform branch of the run-time-flags instantiations.
+template <typename FT, bool REGULAR> __device__ __forceinline__ FT logistic_rate(FT x, FT qthr, FT y2c, FT emk, FT omemk, FT kl2e, FT out, FT inv_tau, FT eps) {
     using M = Math<FT>;
-    if (qthr < eps) return x < eps ? FT(0) : x * inv_tau;
+    // REGULAR: the host has checked x0 ≥ ϵ (mp1m_default_exponents) — no branch in the default Float32 instantiation, whose four points
+    // per lane then stay one basic block.  (The Float64 default instantiation keeps the never-taken scalar branch: without it the
+    // scheduler hoists the autoconversion constants across the phase boundary and spills 38 SGPR pairs to VGPR lanes, 933 → 1000
+    // instructions per point.)
+    if constexpr (!REGULAR)
+        if (qthr < eps) return x < eps ? FT(0) : x * inv_tau;
     const FT y2 = x * y2c;
     const FT lg2 = M::log2(M::fma(emk, M::exp2(M::min(y2, FT(60.0 * 1.4426950408889634))), omemk));
     return x < eps ? FT(0) : M::max(lg2, y2 - kl2e) * out;
@@ -312,11 +318,11 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     c = &consts_after(*c, sq);
     // ---- autoconversion — CM1:354-364, 414-446 ------------------------------------------------------------------
     if (fl & CMX_1M_RAIN_ACNV_KESSLER)
-        o.acnv_lcl_rai = logistic_rate<FT>(q_lcl, c->ka_qthr, c->ka_y2, c->ka_emk, c->ka_omemk, c->ka_kl2e, c->ka_out, c->ka_inv_tau, eps);
+        o.acnv_lcl_rai = logistic_rate<FT, DEFEXP && sizeof(FT) == 4>(q_lcl, c->ka_qthr, c->ka_y2, c->ka_emk, c->ka_omemk, c->ka_kl2e, c->ka_out, c->ka_inv_tau, eps);
     else if (fl & CMX_1M_RAIN_ACNV_PRESCRIBED_ND)
         o.acnv_lcl_rai = q_lcl * c->nd_coeff;
     if (fl & CMX_1M_SNOW_ACNV_NO_SUPERSAT) {
-        o.acnv_icl_sno = logistic_rate<FT>(q_icl, c->ks_qthr, c->ks_y2, c->ks_emk, c->ks_omemk, c->ks_kl2e, c->ks_out, c->ks_inv_tau, eps);
+        o.acnv_icl_sno = logistic_rate<FT, DEFEXP && sizeof(FT) == 4>(q_icl, c->ks_qthr, c->ks_y2, c->ks_emk, c->ks_omemk, c->ks_kl2e, c->ks_out, c->ks_inv_tau, eps);
     } else if (fl & CMX_1M_SNOW_ACNV_WITH_SUPERSAT) {
         const FT x = c->r_is * M::rcp(li_icl);
         const FT rate = c->four_pi_n0_icl * SG_i * inv_rho * M::exp2(x * FT(-1.4426950408889634)) *
@@ -406,6 +412,21 @@ template <typename FT> __device__ __forceinline__ void mp1m_aggregate(const Mp1m
     const FT to_sno = p.is_warm ? -(p.S_sno_rai + melted) : p.S_lcl_sno + p.S_rai_sno;
     dr = ((((p.acnv_lcl_rai + p.accr_lcl_rai) - p.freeze_icl_rai) + to_rai) + p.vap_rai) + p.melt_sno;
     ds = (((((p.acnv_icl_sno + p.accr_icl_rai) + p.freeze_icl_rai) + p.accr_icl_sno) + to_sno) + p.vap_sno) - p.melt_sno;
+}
+
+// A lane of the Float32 vector kernels evaluates 4 points.  An instruction reads at most one SGPR, so every `a·x + b` with both a and b
+// kernel constants costs a v_mov_b32 of b per POINT (the compiler rematerialises it rather than keep a VGPR live: 12 of the 266
+// instructions of a point).  CMX_1M_HOIST (default on) parks those additive constants in VGPRs once per lane: 70 → 76 VGPRs, same-box
+// A/B with CMX_MAX0_INT 0.782–0.793 → 0.778–0.779 ms per 1e8 points.
+#ifndef CMX_1M_HOIST
+#define CMX_1M_HOIST 1
+#endif
+template <typename FT> __device__ __forceinline__ void mp1m_hoist_consts(Mp1mConsts<FT> &c) {
+#if CMX_1M_HOIST
+    c.ps_c0 = keep(c.ps_c0); c.LH_v0 = keep(c.LH_v0); c.LH_s0 = keep(c.LH_s0); c.LH_f0 = keep(c.LH_f0); c.cp_d = keep(c.cp_d);
+    c.lam_b_icl = keep(c.lam_b_icl); c.lamp_b_rai = keep(c.lamp_b_rai); c.lamp_b_sno = keep(c.lamp_b_sno); c.sno_l2_mu = keep(c.sno_l2_mu);
+    c.ka_omemk = keep(c.ka_omemk); c.ks_omemk = keep(c.ks_omemk); c.ven_a_rai = keep(c.ven_a_rai); c.ven_a_sno = keep(c.ven_a_sno);
+#endif
 }
 
 // bulk_microphysics_tendencies(Instantaneous(), Microphysics1Moment(), …) of one point — BMT:505-514.  NaN in → NaN out (cmx_math.hpp any_nan)

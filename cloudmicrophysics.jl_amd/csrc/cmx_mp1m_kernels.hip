@@ -29,10 +29,14 @@ namespace cmx {
 
 
 // bulk_microphysics_tendencies(Instantaneous(), Microphysics1Moment(), …) over columns — BMT:505-514
+#ifndef CMX_1M_BLOCK
+#define CMX_1M_BLOCK 256      // lanes per workgroup of the tendencies kernel (A/B switch)
+#endif
+constexpr int kBlock1m = CMX_1M_BLOCK;
 template <typename FT, int VEC, uint32_t FLAGS = kRuntimeFlags>
-__global__ __launch_bounds__(kBlock) void mp1m_tendencies_kernel(const Mp1mConsts<FT> c, const Mp1mIn<FT> in,
-                                                                 const Mp1mOut<FT> out, const int64_t nvec) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+__global__ __launch_bounds__(kBlock1m) void mp1m_tendencies_kernel(const Mp1mConsts<FT> c, const Mp1mIn<FT> in,
+                                                                   const Mp1mOut<FT> out, const int64_t nvec) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock1m + threadIdx.x;
     FT rho[VEC], T[VEC], q_tot[VEC], q_lcl[VEC], q_icl[VEC], q_rai[VEC], q_sno[VEC];
     if (i < nvec) {
         load_col<FT, VEC>(in.rho, i, rho); load_col<FT, VEC>(in.T, i, T); load_col<FT, VEC>(in.q_tot, i, q_tot);
@@ -42,10 +46,18 @@ __global__ __launch_bounds__(kBlock) void mp1m_tendencies_kernel(const Mp1mConst
     Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS while the loads fly (every lane of the workgroup reaches the barrier inside); no-op for Float32
     if (i >= nvec) return;
     FT dl[VEC], di[VEC], dr[VEC], ds[VEC];
+    if constexpr (CMX_1M_HOIST && sizeof(FT) == 4 && VEC == 4 && FLAGS != kRuntimeFlags) {
+        Mp1mConsts<FT> ch = c;
+        mp1m_hoist_consts<FT>(ch);
 #pragma unroll
-    for (int k = 0; k < VEC; ++k)
-        mp1m_tendencies_point<FT, FLAGS>(front_consts<FT, FLAGS == kRuntimeFlags>(c), rho[k], T[k], q_tot[k], q_lcl[k], q_icl[k], q_rai[k], q_sno[k], dl[k],
-                                         di[k], dr[k], ds[k]);
+        for (int k = 0; k < VEC; ++k)
+            mp1m_tendencies_point<FT, FLAGS>(ch, rho[k], T[k], q_tot[k], q_lcl[k], q_icl[k], q_rai[k], q_sno[k], dl[k], di[k], dr[k], ds[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+            mp1m_tendencies_point<FT, FLAGS>(front_consts<FT, FLAGS == kRuntimeFlags>(c), rho[k], T[k], q_tot[k], q_lcl[k], q_icl[k], q_rai[k], q_sno[k], dl[k],
+                                             di[k], dr[k], ds[k]);
+    }
     store_col<FT, VEC>(out.dq_lcl, i, dl); store_col<FT, VEC>(out.dq_icl, i, di);
     store_col<FT, VEC>(out.dq_rai, i, dr); store_col<FT, VEC>(out.dq_sno, i, ds);
 }
@@ -159,11 +171,11 @@ static int32_t tendencies_1m_entry(const MP *mp, const TH *tps, uint32_t flags, 
         Mp1mIn<FT> in{rho + lo, T + lo, q_tot + lo, q_lcl + lo, q_icl + lo, q_rai + lo, q_sno + lo};
         Mp1mOut<FT> out{dq_lcl + lo, dq_icl + lo, dq_rai + lo, dq_sno + lo};
         const int64_t nv = count / V;
-        const dim3 grid((unsigned)((nv + kBlock - 1) / kBlock));
+        const dim3 grid((unsigned)((nv + kBlock1m - 1) / kBlock1m));
         if (flags == CMX_1M_DEFAULT_OPTIONS && mp1m_default_exponents(c))
-            hipLaunchKernelGGL((mp1m_tendencies_kernel<FT, V, CMX_1M_DEFAULT_OPTIONS | kDefExpBit>), grid, dim3(kBlock), 0, s, c, in, out, nv);
+            hipLaunchKernelGGL((mp1m_tendencies_kernel<FT, V, CMX_1M_DEFAULT_OPTIONS | kDefExpBit>), grid, dim3(kBlock1m), 0, s, c, in, out, nv);
         else
-            hipLaunchKernelGGL((mp1m_tendencies_kernel<FT, V>), grid, dim3(kBlock), 0, s, c, in, out, nv);
+            hipLaunchKernelGGL((mp1m_tendencies_kernel<FT, V>), grid, dim3(kBlock1m), 0, s, c, in, out, nv);
     };
     if (same_mis) {
         const int64_t head = std::min<int64_t>(n, mis0 ? (int64_t)((16 - mis0) / sizeof(FT)) : 0);

@@ -125,6 +125,40 @@ def test_mp1m_fields_and_aos(dev, ft):
         assert torch.equal(aos[:, 0], ref.dq_lcl_dt) and torch.equal(aos[:, 3], ref.dq_sno_dt)
 
 
+@pytest.mark.parametrize("ft", ["f32", "f64"])
+def test_mp1m_linearized_average_fields_and_aos(dev, ft):
+    """cmx_mp1m_linearized_average_fields_* (round 3): the operational LinearizedAverage mode on VIJFH components in place and as the
+    reference's NamedTuple rows, bit-exact vs the SoA entry; ragged sizes through the AoS path."""
+    import cmx
+    from cmx import synthetic
+    tps, mp = P.ThermodynamicsParameters(ft), P.Microphysics1MParams(ft)
+    mode, scheme = cmx.LinearizedAverage(), cmx.Microphysics1Moment()
+    Nh, Nf, S = 7, 9, 37 * 16
+    st = synthetic.mp1m_state(Nh * S, dtype=DT[ft], seed=22)
+    Y = torch.full((Nh, Nf, S), float("nan"), dtype=DT[ft])
+    for f, c in enumerate(st):
+        Y[:, f + 1, :] = c.reshape(Nh, S)
+    Y = Y.to(dev)
+    cols = [Y[:, f + 1, :] for f in range(7)]
+    flat = [c.contiguous().reshape(-1) for c in cols]
+    for dt, nsub in ((20.0, 1), (60.0, 3)):
+        ref = cmx.bulk_microphysics_tendencies_1m(mode, scheme, mp, tps, *flat, dt, nsub)
+        Yt = torch.full((Nh, 6, S), float("nan"), dtype=DT[ft], device=dev)
+        cmx.bulk_microphysics_tendencies_1m_fields(mode, scheme, mp, tps, *cols, dt, nsub, out=[Yt[:, k, :] for k in (0, 2, 3, 5)])
+        aos = cmx.bulk_microphysics_tendencies_1m_fields(mode, scheme, mp, tps, *cols, dt, nsub, aos=True)
+        for k, (name, comp) in enumerate(zip(("dq_lcl_dt", "dq_icl_dt", "dq_rai_dt", "dq_sno_dt"), (0, 2, 3, 5))):
+            assert torch.equal(Yt[:, comp, :].reshape(-1), getattr(ref, name)), name
+            assert torch.equal(aos[:, k], getattr(ref, name)), name
+        assert torch.isnan(Yt[:, 1, :]).all() and torch.isnan(Yt[:, 4, :]).all()
+    for n in (1, 5, 1023, 4099):
+        s1 = synthetic.mp1m_state(n, dtype=DT[ft], device=dev, seed=n)
+        ref = cmx.bulk_microphysics_tendencies_1m(mode, scheme, mp, tps, *s1, 30.0, 2)
+        aos = cmx.bulk_microphysics_tendencies_1m_fields(mode, scheme, mp, tps, *s1, 30.0, 2, aos=True)
+        assert torch.equal(aos[:, 0], ref.dq_lcl_dt) and torch.equal(aos[:, 3], ref.dq_sno_dt)
+    with pytest.raises(ValueError):
+        cmx.bulk_microphysics_tendencies_1m_fields(mode, scheme, mp, tps, *flat)            # LinearizedAverage needs dt
+
+
 # ---- the layout entries against the ORACLE (not only against the SoA kernel) ------------------------------------------------------
 # Reference layouts: ClimaCore fields of test/gpu_clima_core_test.jl:16-30,100-114 (VIJFH storage) and the Vector{NamedTuple} result of
 # benchmark_2m_bulk_tendencies_kernel! / benchmark_1m_bulk_tendencies_kernel! (test/gpu_performance.jl:138-182,212-216).

@@ -40,6 +40,31 @@ template <int MODE> __global__ __launch_bounds__(256) void probe(float *out, flo
             if constexpr (MODE == 24) asm volatile("v_cvt_f32_f64 %1, %0\n\tv_cvt_f64_f32 %0, %1" : "+v"(d[k]), "+v"(x[k]));
             if constexpr (MODE == 25) asm volatile("v_readlane_b32 s20, %0, 3" : : "v"(x[k]) : "s20");
             if constexpr (MODE == 26) asm volatile("v_mov_b32 %0, %1" : "+v"(x[k]) : "s"(a));
+            // round 3: encoding / operand-source variants (which of VOP3, an SGPR operand, a literal costs issue time?)
+            if constexpr (MODE == 30) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(x[k]) : "s"(a));
+            if constexpr (MODE == 31) asm volatile("v_mul_f32 %0, 0x3fb8aa3b, %0" : "+v"(x[k]));
+            if constexpr (MODE == 32) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[k]) : "v"(b));
+            if constexpr (MODE == 33) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x[k]) : "v"(a), "v"(b));
+            if constexpr (MODE == 34) asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(x[k]) : "s"(a), "v"(b));
+            if constexpr (MODE == 35) asm volatile("v_fmamk_f32 %0, %0, 0x3f000000, %1" : "+v"(x[k]) : "v"(b));
+            if constexpr (MODE == 36) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(x[k]) : "v"(b) : );
+            if constexpr (MODE == 37) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(x[k]) : "v"(b));
+            if constexpr (MODE == 38) asm volatile("v_cmp_gt_f32_e32 vcc, %0, %1" : : "v"(x[k]), "v"(b) : "vcc");
+            if constexpr (MODE == 39) asm volatile("v_cmp_gt_f32_e64 s[20:21], %0, %1" : : "v"(x[k]), "v"(b) : "s20", "s21");
+            if constexpr (MODE == 40) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(x[k]) : "v"(a), "v"(b));
+            if constexpr (MODE == 41) asm volatile("v_max_f32 %0, %0, %1" : "+v"(x[k]) : "v"(b));
+            if constexpr (MODE == 42) asm volatile("v_mov_b32 %0, %1" : "+v"(x[k]) : "v"(b));
+            if constexpr (MODE == 43) asm volatile("v_max_i32 %0, 0, %0" : "+v"(x[k]));
+            if constexpr (MODE == 44) asm volatile("v_fma_f32 %0, %0, %1, 1.0" : "+v"(x[k]) : "v"(a));
+            if constexpr (MODE == 45) asm volatile("v_mul_f32_e64 %0, %0, %1" : "+v"(x[k]) : "v"(a));
+            if constexpr (MODE == 46) asm volatile("v_add_f32_e64 %0, %0, -%1" : "+v"(x[k]) : "v"(b));
+            if constexpr (MODE == 47) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[k]) : "s"((double)a));
+            if constexpr (MODE == 48) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[k]) : "s"((double)a), "v"((double)b));
+            if constexpr (MODE == 49) asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(x[k]) : "v"(1));
+            if constexpr (MODE == 50) asm volatile("v_mul_f32 %0, %0, %1\n\ts_mul_i32 s22, s22, s23" : "+v"(x[k]) : "v"(a) : "s22");
+            if constexpr (MODE == 51) asm volatile("v_rsq_f32 %0, %0" : "+v"(x[k]));
+            if constexpr (MODE == 52) asm volatile("v_fma_f32 %0, %0, %0, %1" : "+v"(x[k]) : "v"(b));
+            if constexpr (MODE == 53) { float t = v[k].x; asm volatile("v_mul_f32 %0, %0, %2\n\tv_mul_f32 %0, %0, %2\n\tv_mul_f32 %0, %0, %2\n\tv_exp_f32 %1, %1" : "+v"(x[k]), "+v"(t) : "v"(a)); v[k].x = t; }
         }
     }
     float s = 0;
@@ -98,6 +123,13 @@ int main() {
     run<16>("v_rndne_f64", 1, out); run<17>("cvt i32<->f64", 2, out); run<24>("cvt f32<->f64", 2, out); run<18>("v_cmp_class_f64", 1, out);
     run<20>("cmp_f64+cndmask", 2, out); run<22>("v_log_f32", 1, out); run<23>("v_sqrt_f32", 1, out); run<25>("v_readlane_b32", 1, out);
     run<26>("v_mov_b32 v,s", 1, out);
+    run<30>("v_mul_f32 s,v", 1, out); run<31>("v_mul_f32 lit,v", 1, out); run<45>("v_mul_f32_e64", 1, out); run<32>("v_add_f32", 1, out);
+    run<46>("v_add_f32 neg", 1, out); run<33>("v_fmac_f32", 1, out); run<34>("v_fma_f32 s,v,v", 1, out); run<44>("v_fma_f32 ..,1.0", 1, out);
+    run<52>("v_fma_f32 x,x,b", 1, out); run<35>("v_fmamk_f32", 1, out); run<36>("v_cndmask e32", 1, out); run<37>("v_cndmask e64", 1, out);
+    run<38>("v_cmp e32", 1, out); run<39>("v_cmp e64", 1, out); run<40>("v_med3_f32", 1, out); run<41>("v_max_f32", 1, out);
+    run<42>("v_mov_b32 v,v", 1, out); run<43>("v_max_i32", 1, out); run<49>("v_ldexp_f32", 1, out); run<51>("v_rsq_f32", 1, out);
+    run<47>("v_mul_f64 s,v", 1, out); run<48>("v_fma_f64 s,v,v", 1, out); run<50>("v_mul+s_mul", 1, out);
+    run<53>("3 v_mul + v_exp", 4, out);   // does a transcendental overlap with ordinary VALU issue?
     for (int w : {1, 2, 3, 4, 8}) { run_chain<1, true>(w, out); run_chain<2, true>(w, out); run_chain<4, true>(w, out); }
     for (int w : {1, 2, 4}) { run_chain<1, false>(w, out); run_chain<2, false>(w, out); }
     return 0;
