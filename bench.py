@@ -7,7 +7,7 @@ configuration BASELINE.json quotes the metric on).  Inputs are generated on the 
 region; nothing crosses PCIe inside it.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--points P] [--dtype f32|f64] [--scaling weak|strong]
-                    [--workload sb2006|sb2006_chen|sb2006_column|sb2006_aos|sb2006_fields|icenuc|mp0m|mp1m|mp1m_lin|arg2000|p3|p3_fused|p3_selfcol|mp2m_p3]
+                    [--workload sb2006|sb2006_chen|sb2006_column|sb2006_aos|sb2006_fields|icenuc|mp0m|mp1m|mp1m_lin|mp1m_column|mp1m_column_lin|arg2000|p3|p3_fused|p3_selfcol|mp2m_p3]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --points per GPU; strong: --points in total, sharded over the ranks (cmx.sharding.shard_bounds)")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--workload", choices=["sb2006", "sb2006_chen", "sb2006_column", "icenuc", "mp0m", "mp1m", "mp1m_lin", "arg2000", "p3", "p3_fused", "p3_selfcol", "mp2m_p3", "sb2006_aos", "sb2006_fields"], default="sb2006")
+    ap.add_argument("--workload", choices=["sb2006", "sb2006_chen", "sb2006_column", "icenuc", "mp0m", "mp1m", "mp1m_lin", "mp1m_column", "mp1m_column_lin", "arg2000", "p3", "p3_fused", "p3_selfcol", "mp2m_p3", "sb2006_aos", "sb2006_fields"], default="sb2006")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend for N > 1: nccl (= RCCL over xGMI; the measured configuration) or gloo (TEST MODE: ranks may share "
                          "a device — local_rank modulo the device count — so the N > 1 code path can be exercised on a 1-GPU box)")
@@ -84,6 +84,26 @@ def pmc_traffic(workload: str, dtype: str, n: int):
             continue
         if d.get("points") == n and d.get("dtype") == dtype:
             return d.get("hbm_bytes_per_launch"), str(p.relative_to(REPO))
+    return None, None
+
+
+VALU_PEAK_GINST = 1024 * 2.4e9 / 4 / 1e9     # wave64 VALU instructions per second the chip can issue: 256 CUs × 4 SIMDs, one per 4 cycles at 2.4 GHz
+
+
+def pmc_valu(workload: str, dtype: str, n: int):
+    """Wave64 VALU instructions per launch (SQ_INSTS_VALU, summed over the kernels of one step) from the committed rocprofv3 PMC pass of
+    this exact workload (tools/profile.sh … valu → profiles/rNN_pmc_valu_<workload>_<dtype>.json), newest round first; (None, None) if
+    no committed profile matches the size.  The count is a property of the code and the input distribution, not of the box."""
+    for p in sorted((REPO / "profiles").glob(f"r*_pmc_valu_{workload}_{dtype}.json"), reverse=True):
+        try:
+            d = json.loads(p.read_text())
+        except (OSError, ValueError):
+            continue
+        if d.get("points") != n:
+            continue
+        insts = [k.get("counters", {}).get("SQ_INSTS_VALU") for k in d.get("kernels", {}).values()]
+        if insts and all(v is not None for v in insts):
+            return float(sum(insts)), str(p.relative_to(REPO))
     return None, None
 
 
@@ -332,12 +352,60 @@ def setup_mp1m_lin(args, dev, dtype, rank):
     desc = {
         "metric": "grid-points/sec 1-moment LinearizedAverage tendency sweep (dt = 30 s, nsub = 2)",
         "bytes_per_point": {"f32": 44, "f64": 88}[args.dtype],      # 7 in + 4 out
-        "kernel": "mp1m_linearized_kernel",
+        "kernel": "mp1m_linearized_kernel", "bound": "valu",
         "workload": "Microphysics1M LinearizedAverage bulk tendencies: 2 linearized implicit substeps (13 processes, 4x4 sparse solve, "
                     "T update) per point",
         "columns_in": 7, "columns_out": 4, "diag_cols": list(out),
     }
     return list(state), step, desc, cpu_run
+
+
+def setup_mp1m_column(args, dev, dtype, rank):
+    """The operational 1-moment column step in one pass (cmx_mp1m_column_tendencies_sedimentation_*): tendencies (Instantaneous, or
+    LinearizedAverage Δt = 30 s, nsub = 2 for `mp1m_column_lin`) + the four sedimentation velocities + the host model's upwind flux
+    divergence, columns of 74 levels (the RCEMIP column of test/gpu_clima_core_test.jl:88-100); 7 columns in, 4 out."""
+    import torch
+
+    import cmx
+    from cmx import _abi
+    from cmx import parameters as P
+    from cmx import synthetic
+    n_lev = 74
+    n_col = max(1, args.points // n_lev)
+    args.points = n_col * n_lev
+    st = synthetic.mp1m_state(args.points, dtype=dtype, device=dev, seed=1234 + rank)
+    cols = [c.reshape(n_col, n_lev) for c in st]
+    g = torch.Generator(device="cpu").manual_seed(7)
+    inv_dz_cpu = (1.0 / (30.0 + 470.0 * torch.rand(n_lev, generator=g, dtype=torch.float64))).to(dtype)
+    inv_dz = inv_dz_cpu.to(dev)
+    mp, tps = P.Microphysics1MParams(args.dtype), P.ThermodynamicsParameters(args.dtype)
+    vel = (P.StokesRegimeVelType(args.dtype), P.Chen2022VelTypeRain(args.dtype), P.Chen2022VelTypeIce(args.dtype))
+    lin = args.workload == "mp1m_column_lin"
+    mode, scheme = (cmx.LinearizedAverage() if lin else cmx.Instantaneous()), cmx.Microphysics1Moment()
+    dt, nsub, q_min = (30.0, 2) if lin else (None, 1), None, P.DEFAULT_PARAMETERS["specific_humidity_minimum"]
+    dt, nsub = dt
+    holder = {}
+
+    def step():
+        holder["out"] = cmx.column_tendencies_sedimentation_1m(mode, scheme, mp, tps, *vel, inv_dz, *cols, dt, nsub)
+
+    def cpu_run(ob, c, threads):
+        fam = _abi.family(args.dtype)
+        m_col = c[0].size // n_lev
+        c2 = [a[:m_col * n_lev].reshape(m_col, n_lev) for a in c]
+        return lambda: ob.mp1m_column_tendencies_sedimentation(fam, mp.c, tps, *vel, mp.flags, inv_dz_cpu.numpy(), *c2, q_min=q_min, dt=dt or 0.0,
+                                                               nsub=nsub if lin else 0, nthreads=threads)
+
+    step()
+    desc = {
+        "metric": "grid-points/sec 1-moment " + ("LinearizedAverage (dt = 30 s, nsub = 2) " if lin else "") + "tendency + 4-species upwind sedimentation column sweep (74 levels)",
+        "bytes_per_point": {"f32": 44, "f64": 88}[args.dtype],     # 7 in + 4 out; the unfused sequence moves 148 / 296 B per point
+        "kernel": "mp1m_column_kernel", "bound": "valu",
+        "workload": "Microphysics1M " + ("LinearizedAverage" if lin else "Instantaneous") + " bulk tendencies + Stokes / Chen-2022 fall speeds of cloud liquid, "
+                    "cloud ice, rain, snow + first-order upwind sedimentation flux divergence per column of 74 levels (host-model step)",
+        "columns_in": 7, "columns_out": 4, "diag_cols": [],
+    }
+    return list(st), step, desc, cpu_run
 
 
 def setup_arg2000(args, dev, dtype, rank):
@@ -402,12 +470,10 @@ def setup_p3(args, dev, dtype, rank):
     desc = {
         "metric": "grid-points/sec P3 shape solve + integral properties (log-lambda, D_m, v_n, v_m)",
         "bytes_per_point": {"f32": 36, "f64": 72}[args.dtype],      # 5 in + 4 out
-        "kernel": "p3_velocity_kernel<SOLVE> (one launch)" if fused else "p3_shape_kernel + p3_velocity_kernel",
+        "kernel": "p3_velocity_kernel<SOLVE> (one launch)" if fused else "p3_shape_kernel + p3_velocity_kernel", "bound": "valu",
         "workload": "P3Scheme state_from_prognostic + get_distribution_logλ (Brent root, incomplete-gamma moments) + D_m + "
                     "number/mass-weighted Chen-2022 fall speeds (ChebyshevGauss(100) x 4 segments, gamma_inc_inv bounds)",
         "columns_in": 5, "columns_out": 4, "diag_cols": [],
-        "note": "FP64/FP32-vector compute-bound (DESIGN.md §4.5): the HBM fraction is tiny by nature; see "
-                "profiles/r01_pmc_valu_p3_*.json for the VALU-issue utilisation of the two kernels",
     }
     return list(st) + [rho_a], step, desc, cpu_run
 
@@ -447,11 +513,10 @@ def setup_p3_selfcol(args, dev, dtype, rank):
     desc = {
         "metric": "states/sec P3 benchmark kernel (log-lambda + ice self-collection, GaussLegendre(40))",
         "bytes_per_point": {"f32": 28, "f64": 56}[args.dtype],      # 5 in + 2 out
-        "kernel": "p3_shape_kernel + p3_self_collection_kernel",
+        "kernel": "p3_shape_kernel + p3_self_collection_kernel", "bound": "valu",
         "workload": "P3State + get_distribution_logλ + ice_self_collection (double quadrature, 8 n² = 12800 integrand evaluations per "
                     "state) — the reference's benchmark_p3_kernel!",
         "columns_in": 5, "columns_out": 2, "diag_cols": [],
-        "note": "FP64/FP32-vector compute-bound (≈3e6 VALU instructions per state); the HBM fraction is tiny by nature",
     }
     return cols + [rho_a], step, desc, cpu_run
 
@@ -493,11 +558,9 @@ def setup_mp2m_p3(args, dev, dtype, rank):
     desc = {
         "metric": "grid-points/sec 2M + P3 fused tendencies (warm rain + collisions + aggregation + melting + nucleation, GaussLegendre(16))",
         "bytes_per_point": {"f32": 112, "f64": 224}[args.dtype],      # 12 in + 8 out (the second launch re-reads and re-writes the 8)
-        "kernel": "mp2m_p3_pointwise_kernel + p3_collision_kernel<FUSED>",
+        "kernel": "mp2m_p3_pointwise_kernel + p3_collision_kernel<FUSED>", "bound": "valu",
         "workload": "bulk_microphysics_tendencies(Microphysics2Moment(), mp{WarmRain, P3IceParams}, …) — BMT:898-1083, quadrature_order 16",
         "columns_in": 12, "columns_out": 8, "diag_cols": [],
-        "note": "FP64/FP32-vector compute-bound (liquid–ice collisions: 64 outer × (16 + 16 inner nodes + closed-form rain integral) "
-                "per state with ice); the HBM fraction is tiny by nature",
     }
     return cols + [ll], step, desc, cpu_run
 
@@ -592,7 +655,7 @@ def main():
         args.points = hi - lo
     # weak scaling: fixed work per GPU; rank r owns shard r of the global [0, world·n) index space.
     # Either way: disjoint seeds, no exchange
-    setup = {"sb2006": setup_sb2006, "sb2006_chen": setup_sb2006, "sb2006_column": setup_sb2006_column, "icenuc": setup_icenuc, "mp0m": setup_mp0m, "mp1m": setup_mp1m, "mp1m_lin": setup_mp1m_lin, "arg2000": setup_arg2000,
+    setup = {"sb2006": setup_sb2006, "sb2006_chen": setup_sb2006, "sb2006_column": setup_sb2006_column, "icenuc": setup_icenuc, "mp0m": setup_mp0m, "mp1m": setup_mp1m, "mp1m_lin": setup_mp1m_lin, "mp1m_column": setup_mp1m_column, "mp1m_column_lin": setup_mp1m_column, "arg2000": setup_arg2000,
              "p3": setup_p3, "p3_fused": setup_p3, "p3_selfcol": setup_p3_selfcol, "mp2m_p3": setup_mp2m_p3, "sb2006_aos": setup_sb2006_layout, "sb2006_fields": setup_sb2006_layout}[args.workload]
     state, kernel_step, desc, cpu_run = setup(args, dev, dtype, rank)
     n = args.points                                          # a layout workload may round the size to whole field runs
@@ -607,9 +670,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.settle + args.warmup):
+    # the first five launches after the inputs are generated, timed one by one (clocks not settled: the cold figure next to settle_steps)
+    cold = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+    for a, b in cold:
+        a.record()
+        step()
+        b.record()
+    for _ in range(max(0, args.settle - 5) + args.warmup):
         step()
     fence()
+    cold_ms = sum(a.elapsed_time(b) for a, b in cold) / len(cold)
     # per-launch kernel duration from HIP events recorded on the stream the kernel is launched on
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
@@ -645,16 +715,32 @@ def main():
                        "columns_out": desc["columns_out"],
                        "parallelism": f"shard{world}" + ("+rccl-diag" if args.diagnostics else "") +
                                       ("" if args.backend == "nccl" or world == 1 else " (gloo test mode: ranks may share a device)")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": (traffic_source + " (rocprofv3 PMC pass of this command on an earlier run; not measured in this run)")
-                                           if traffic_source else None,
-                         "kernel": desc["kernel"], "kernel_ms": kern_ms, "bytes_per_point": bpp},
+            "roofline": None,
         }
+        line["cold_ms_first5"] = cold_ms      # mean kernel time of the first five launches (HIP events), before the settle launches
+        hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+               "traffic_source": (traffic_source + " (rocprofv3 PMC pass of this command on an earlier run; not measured in this run)")
+                                 if traffic_source else None,
+               "kernel": desc["kernel"], "kernel_ms": kern_ms, "bytes_per_point": bpp}
+        insts, insts_source = pmc_valu(args.workload, args.dtype, n)
+        valu = None
+        if insts is not None:
+            rate = insts / (kern_ms * 1e-3) / 1e9
+            valu = {"bound": "valu", "achieved": rate, "peak": VALU_PEAK_GINST, "unit": "G wave64-VALU-instructions/s", "frac": rate / VALU_PEAK_GINST,
+                    "traffic": None, "insts_per_point": insts * 64 / n, "insts_source": insts_source + " (SQ_INSTS_VALU of a rocprofv3 PMC pass of this "
+                    "command; a property of the code and the inputs, not of the box)", "kernel": desc["kernel"], "kernel_ms": kern_ms,
+                    "peak_formula": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction"}
+        if desc.get("bound") == "valu" and valu is not None:
+            # compute-bound line: the VALU-issue fraction is the roofline, the HBM fraction a secondary field
+            line["roofline"] = dict(valu, hbm={k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "traffic", "traffic_source", "bytes_per_point")})
+        else:
+            line["roofline"] = dict(hbm, valu=({k: valu[k] for k in ("achieved", "peak", "unit", "frac", "insts_per_point", "insts_source")} if valu else None))
+            if desc.get("bound") == "valu":
+                line["roofline"]["note"] = "compute-bound workload, but no committed PMC instruction count matches this size: HBM fraction shown"
         if "note" in desc:
             line["roofline"]["note"] = desc["note"]
         if not args.no_cpu_baseline and world == 1:
-            m = min(n, {"sb2006": 20_000_000, "sb2006_chen": 20_000_000, "sb2006_column": 74 * 270_000, "sb2006_aos": 20_000_000, "sb2006_fields": 20_000_000, "p3": 100_000, "p3_fused": 100_000, "p3_selfcol": 2_000, "mp2m_p3": 20_000}.get(args.workload, 4_000_000))
+            m = min(n, {"sb2006": 20_000_000, "sb2006_chen": 20_000_000, "sb2006_column": 74 * 270_000, "mp1m_column": 74 * 54_000, "mp1m_column_lin": 74 * 27_000, "sb2006_aos": 20_000_000, "sb2006_fields": 20_000_000, "p3": 100_000, "p3_fused": 100_000, "p3_selfcol": 2_000, "mp2m_p3": 20_000}.get(args.workload, 4_000_000))
             cols_np = [np.ascontiguousarray(c[:m].cpu().numpy()) for c in state]
             line["cpu_baseline"] = cpu_baseline(args, cols_np, desc, cpu_run)
         print(json.dumps(line), flush=True)

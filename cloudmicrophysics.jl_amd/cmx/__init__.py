@@ -21,7 +21,8 @@ from .ice_nucleation import (IceNucleationRates, a_w_eT, a_w_ice, domain_error_c
 
 from .microphysics1m import (Instantaneous, LinearizedAverage, Microphysics1Moment, SedimentationVelocities, SourceTerms1M, Tendencies1M,  # noqa: F401
                              TerminalVelocities1M, bulk_microphysics_tendencies_1m, bulk_microphysics_tendencies_1m_fields,
-                             microphysics_source_terms_1m, sedimentation_velocities, terminal_velocity_1m)
+                             microphysics_source_terms_1m, sedimentation_velocities, terminal_velocity_1m, ColumnStep1M,
+                             column_tendencies_sedimentation_1m)
 
 from .microphysics0m import (Microphysics0Moment, bulk_microphysics_tendencies_0m, d_remove_precipitation_d_q_tot,  # noqa: F401
                              remove_precipitation)

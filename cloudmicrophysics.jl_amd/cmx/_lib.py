@@ -125,6 +125,10 @@ def _declare(lib):
         f.restype = i32
         f.argtypes = [C.POINTER(fam.warm_rain_2m), C.POINTER(fam.thermo), u32, i64, i64, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp),
                       C.POINTER(i64), vp, vp]
+        f = getattr(lib, f"cmx_mp1m_column_tendencies_sedimentation_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.microphysics_1m), C.POINTER(fam.thermo), C.POINTER(fam.stokes_vel), C.POINTER(fam.chen2022_rain_vel),
+                      C.POINTER(fam.chen2022_ice_vel), u32, fam.ft, fam.ft, i32, i64, i32, vp, C.POINTER(vp), C.POINTER(vp), vp, vp, vp]
         f = getattr(lib, f"cmx_mp1m_linearized_average_fields_{s}")
         f.restype = i32
         f.argtypes = [C.POINTER(fam.microphysics_1m), C.POINTER(fam.thermo), u32, fam.ft, fam.ft, i32, i64, i64, C.POINTER(vp), C.POINTER(i64),

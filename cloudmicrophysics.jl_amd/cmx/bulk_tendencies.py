@@ -119,7 +119,7 @@ def _bulk_tendencies_2m_p3(mp, tps, rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q
 
 
 def bulk_microphysics_tendencies(scheme, mp, tps, rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice=None, n_ice=None, q_rim=None,
-                                 b_rim=None, log_lambda=None, inpc_log_shift=None, *, vel=None, aspect_ratio=True,
+                                 b_rim=None, log_lambda=None, inpc_log_shift=None, *, vel=None, vel_params=None, aspect_ratio=True,
                                  out: Optional[WarmRainTendencies2M] = None, stream=None):
     """2-moment tendencies over columns.
 
@@ -129,7 +129,8 @@ def bulk_microphysics_tendencies(scheme, mp, tps, rho, T, q_tot, q_lcl, n_lcl, q
     2-moment warm-rain tendencies over columns — BMT:820-854 → warm_rain_tendencies_2m BMT:707-782.
 
     `vel` (None | SB2006VelType | Chen2022VelTypeRain) additionally fuses
-    CM2.rain_terminal_velocity (CM2:685-719) into the same pass (two more output columns).
+    CM2.rain_terminal_velocity (CM2:685-719) into the same pass (two more output columns); `vel_params` = a `cmx_rain_vel` struct
+    with non-default tables (default: `parameters.rain_vel_params(FT)`).
     `out` lets the caller provide the output columns (KA-kernel style, test/gpu_tests.jl:407-415).
     Asynchronous on `stream` (default: torch's current stream)."""
     if not isinstance(scheme, Microphysics2Moment):
@@ -156,7 +157,9 @@ def bulk_microphysics_tendencies(scheme, mp, tps, rho, T, q_tot, q_lcl, n_lcl, q
     else:
         _check_cols([ref] + [o for o in out if o is not None], ["rho"] + ["out"] * 6)
     flags = (_abi.CMX_SB2006_LIMITED if wr.is_limited else 0) | vflag
-    velp = rain_vel_params(fam.sfx) if vflag else None
+    velp = (vel_params if vel_params is not None else rain_vel_params(fam.sfx)) if vflag else None
+    if velp is not None and not isinstance(velp, fam.rain_vel):
+        raise TypeError("vel_params must be the cmx_rain_vel struct of the state's float type")
     s = stream if stream is not None else torch.cuda.current_stream(ref.device)
     fn = getattr(_lib.lib(), f"cmx_sb2006_warm_rain_tendencies_{fam.sfx}")
     with torch.cuda.device(ref.device):

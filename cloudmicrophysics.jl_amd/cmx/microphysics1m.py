@@ -179,3 +179,45 @@ def sedimentation_velocities(mp, stokes, chen_rain, chen_ice, rho, q_lcl=None, q
                 *[_ptr(q) for q in qs], *[_ptr(o) for o in outs], C.c_void_p(s.cuda_stream))
     _lib.check(fn.__name__, st)
     return SedimentationVelocities(*outs)
+
+
+ColumnStep1M = namedtuple("ColumnStep1M", ["dq_lcl_dt", "dq_icl_dt", "dq_rai_dt", "dq_sno_dt", "precip_rai", "precip_sno"])
+
+
+def column_tendencies_sedimentation_1m(mode, scheme, mp, tps, stokes, chen_rain, chen_ice, inv_dz, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno,
+                                       dt=None, nsub=1, *, q_min=None, precip=True, stream=None) -> ColumnStep1M:
+    """The operational 1-moment column step in one pass (`cmx_mp1m_column_tendencies_sedimentation_*`): the 1-moment tendencies
+    (Instantaneous, or LinearizedAverage with `dt` [, `nsub`]) + the four sedimentation velocities (`sedimentation_velocities`) + the host
+    model's first-order upwind flux divergence of q_lcl, q_icl, q_rai, q_sno.  State tensors of shape (n_col, n_lev), level 0 lowest,
+    contiguous; `inv_dz` = n_lev values 1/Δz.  Returns the four total tendencies and (precip=True) the surface rain / snow fluxes."""
+    if not isinstance(scheme, Microphysics1Moment) or not isinstance(mode, (Instantaneous, LinearizedAverage)):
+        raise TypeError("mode must be Instantaneous() or LinearizedAverage() and scheme Microphysics1Moment()")
+    cols = (rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno)
+    if rho.dim() != 2:
+        raise ValueError("state tensors must have shape (n_col, n_lev)")
+    flat = [c.reshape(-1) for c in cols]
+    ref, fam = _prep(mp, tps, flat)
+    n_col, n_lev = rho.shape
+    if inv_dz.numel() != n_lev or inv_dz.dtype != ref.dtype or inv_dz.device != ref.device or not inv_dz.is_contiguous():
+        raise ValueError("inv_dz: n_lev contiguous values of the state's dtype on the state's device")
+    lin = isinstance(mode, LinearizedAverage)
+    if lin:
+        if dt is None or not dt > 0 or int(nsub) < 1:
+            raise ValueError("LinearizedAverage needs dt > 0 and nsub >= 1")
+        if q_min is None:
+            from .parameters import DEFAULT_PARAMETERS
+            q_min = DEFAULT_PARAMETERS["specific_humidity_minimum"]
+    elif dt is not None:
+        raise TypeError("Instantaneous() takes no dt")
+    out = [torch.empty_like(rho) for _ in range(4)]
+    pr = [torch.empty(n_col, dtype=ref.dtype, device=ref.device) if precip else None for _ in range(2)]
+    in_p = (C.c_void_p * 7)(*[c.data_ptr() for c in flat])
+    out_p = (C.c_void_p * 4)(*[o.data_ptr() for o in out])
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_mp1m_column_tendencies_sedimentation_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(mp.c), C.byref(tps), C.byref(stokes), C.byref(chen_rain), C.byref(chen_ice), mp.flags, q_min if lin else 0.0,
+                dt if lin else 0.0, int(nsub) if lin else 0, n_col, n_lev, _ptr(inv_dz), in_p, out_p, _ptr(pr[0]), _ptr(pr[1]),
+                C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return ColumnStep1M(*out, *pr)

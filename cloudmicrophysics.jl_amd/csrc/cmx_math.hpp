@@ -62,27 +62,6 @@ template <> struct Math<float> {
     static __device__ __forceinline__ float max(float a, float b) { return __builtin_fmaxf(a, b); }
     static __device__ __forceinline__ float nan() { return __builtin_nanf(""); }
     static __device__ __forceinline__ float min(float a, float b) { return __builtin_fminf(a, b); }
-    // Γ(z), used by the Chen-2022 rain velocity only, where z = b_i(ρ) + 1 ∈ [2.0, 3.4] (b = 1.15 / 2.30 − 0.038 ρ, Common.jl:290-302):
-    // a degree-10 interpolating polynomial in t = (z − 2.75)/1.25 on [1.5, 4] (3.3e-7 relative in Float32 Horner; OCML's tgammaf
-    // costs ≈ 110 instructions and made the Chen variant of the fused kernel compute-bound: 1.37 ms per 1e8 points in round 1).
-    // The argument is clamped to [1.5, 4] (one v_med3): entry points that take Chen-2022 rain parameters check on the host that
-    // b_i + 1 stays inside for every air density up to 2 kg/m³ (cmx::chen_rain_gamma_domain_ok) and return CMX_ERR_UNSUPPORTED otherwise.
-    // (An OCML fallback behind a never-taken branch was tried first: inlined at 12 call sites it took the kernel to 179 VGPRs, 2 waves
-    // per SIMD, 1.17 ms.)
-    static __device__ __forceinline__ float tgamma(float z) {
-        const float t = fma(hw::med3(z, 1.5f, 4.0f), 0.8f, -2.2f);
-        float p = 0.000606461835549f;
-        p = fma(p, t, 0.000949070487934f);
-        p = fma(p, t, 0.00527334298015f);
-        p = fma(p, t, 0.015461039999f);
-        p = fma(p, t, 0.0556865757496f);
-        p = fma(p, t, 0.142589333556f);
-        p = fma(p, t, 0.380736919836f);
-        p = fma(p, t, 0.751528528131f);
-        p = fma(p, t, 1.39245065912f);
-        p = fma(p, t, 1.64635862269f);
-        return fma(p, t, 1.60835942199f);
-    }
     // log1p / expm1 accurate near 0 without the OCML double-float expansions (≈250 instructions each):
     // 4-term series below |x| = 1/32, the hardware log2/exp2 above (where 1+x / eˣ−1 no longer cancel: ≤4e-6 rel.)
     static __device__ __forceinline__ float log1p(float x) {
@@ -115,20 +94,6 @@ template <> struct Math<double> {
     static __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }
     static __device__ __forceinline__ double nan() { return __builtin_nan(""); }
     static __device__ __forceinline__ double min(double a, double b) { return __builtin_fmin(a, b); }
-    // Γ(z) on [1.5, 4] (see the Float32 twin; argument clamped): degree-22 interpolating polynomial, 9e-15 relative
-    static __device__ __forceinline__ double tgamma(double z) {
-        const double t = fma(min(max(z, 1.5), 4.0), 0.8, -2.2);
-        const double k[23] = {1.6083594219855455584, 1.6463589739909790518, 1.3924499187912875802, 0.75152171904830877759,
-                              0.38075160368679774603, 0.14262439063517987378, 0.055606088443515184361, 0.015394396819926214053,
-                              0.0054496056318177296227, 0.00098897444374469870313, 0.00044573752011233748607, 0.000010932744047535149967,
-                              0.000043139914396103166238, -9.7546600621484357892e-6, 6.4693602774412672403e-6, -2.243298262749311333e-6,
-                              1.0854823652885385946e-6, -8.4496532802657781764e-7, 3.894405396736869375e-7, 7.7776820822669398175e-8,
-                              -3.6483865756254320843e-8, -8.5261728750953385182e-8, 3.8953586756712331112e-8};
-        double p = k[22];
-#pragma unroll
-        for (int i = 21; i >= 0; --i) p = fma(p, t, k[i]);
-        return p;
-    }
     static __device__ __forceinline__ double log1p(double x) { return lean::log1p(x); }
     static __device__ __forceinline__ double expm1(double x) { return lean::expm1(x); }
 };
@@ -155,13 +120,63 @@ template <typename FT> __device__ __forceinline__ FT keep(FT x) {
     return x;
 }
 
-// Host check for the polynomial Γ above: the Chen-2022 rain exponents b_i(ρ) = b_i − b_ρ ρ (Common.jl:290-302) must keep
-// z = b_i(ρ) + 1 inside [1.5, 4] for 0 ≤ ρ ≤ 2 kg/m³ (the reference's Table B1 values: z ∈ [2.07, 3.30]).
-template <typename CH> inline bool chen_rain_gamma_domain_ok(const CH &ch) {
-    if (!(ch.b_rho >= 0)) return false;
-    for (int i = 0; i < 3; ++i)
-        if (!((double)ch.b[i] + 1.0 <= 4.0 && (double)ch.b[i] + 1.0 - 2.0 * (double)ch.b_rho >= 1.5)) return false;
-    return true;
+// ---- Γ of the Chen-2022 rain exponents as polynomials in the air density (round 3) ----------------------------------------------------
+// The three exponents of a Chen-2022 rain table depend on the state only through the air density, b_i(ρ) = b_i − b_ρ ρ (Common.jl:290-302),
+// and over 0 ≤ ρ ≤ 2 kg/m³ each moves by b_ρ·2 ≈ 0.08: Γ(b_i(ρ) + 1) is a short polynomial in ρ there, fitted on the HOST for the
+// parameter set at hand (Chebyshev interpolation in t = ρ − 1 ∈ [−1, 1], degree 3 for Float32 / 8 for Float64, converted to monomials;
+// the nearest singularity of Γ is two units away, so the error falls by ≈ 100× per degree).  Any parameter set with positive
+// arguments is covered — no fixed polynomial window — and a Γ costs 3 (8) fma instead of 13 (24).  make_chen_gamma() returns false if
+// the fit misses its accuracy at the probe points (a pole inside the range: b_i + 1 ≤ 2 b_ρ, or a huge b_ρ); the entry points then
+// take the GENERAL instantiation (tgamma_general below).  Beyond ρ = kChenGammaRhoMax the fast instantiations return NaN fall speeds.
+constexpr double kChenGammaRhoMax = 2.0;
+template <typename FT> struct ChenGamma {
+    static constexpr int D = sizeof(FT) == 4 ? 3 : 8;
+    FT c[3][D + 1];      // Γ(b_i − b_ρ ρ + 1) = Σ_m c[i][m] (ρ − 1)^m
+};
+template <typename FT, typename CH> inline bool make_chen_gamma(const CH &ch, ChenGamma<FT> &g) {
+    constexpr int D = ChenGamma<FT>::D, N = D + 1;
+    const double pi = 3.14159265358979323846, half = 0.5 * kChenGammaRhoMax;
+    bool ok = true;
+    for (int i = 0; i < 3; ++i) {
+        auto f = [&](double t) { return std::tgamma((double)ch.b[i] - (double)ch.b_rho * (half + half * t) + 1.0); };
+        if (!((double)ch.b[i] + 1.0 - (double)ch.b_rho * kChenGammaRhoMax > 0.05) || !((double)ch.b[i] + 1.0 < 30.0)) ok = false;
+        // Chebyshev coefficients from the N Chebyshev nodes, then Σ a_k T_k(t) → monomials by the recurrence T_{k+1} = 2 t T_k − T_{k−1}
+        double a[N], fx[N], mono[N] = {0}, Tkm1[N] = {0}, Tk[N] = {0};
+        for (int j = 0; j < N; ++j) fx[j] = f(std::cos(pi * (j + 0.5) / N));
+        for (int k = 0; k < N; ++k) {
+            double sum = 0;
+            for (int j = 0; j < N; ++j) sum += fx[j] * std::cos(pi * k * (j + 0.5) / N);
+            a[k] = (k == 0 ? 1.0 : 2.0) / N * sum;
+        }
+        Tkm1[0] = 1.0;                        // T_0
+        for (int m = 0; m < N; ++m) mono[m] += a[0] * Tkm1[m];
+        if (N > 1) {
+            Tk[1] = 1.0;                      // T_1
+            for (int m = 0; m < N; ++m) mono[m] += a[1] * Tk[m];
+            for (int k = 2; k < N; ++k) {
+                double Tn[N] = {0};
+                for (int m = 0; m < N; ++m) Tn[m] = (m > 0 ? 2.0 * Tk[m - 1] : 0.0) - Tkm1[m];
+                for (int m = 0; m < N; ++m) { mono[m] += a[k] * Tn[m]; Tkm1[m] = Tk[m]; Tk[m] = Tn[m]; }
+            }
+        }
+        // t = (ρ − half)/half: fold 1/half^m into the coefficients so that the kernel evaluates in (ρ − half) directly
+        double scale = 1.0;
+        for (int m = 0; m < N; ++m) { g.c[i][m] = (FT)(mono[m] * scale); scale /= half; }
+        for (double t : {-0.97, -0.41, 0.13, 0.58, 0.99}) {      // off-node probes
+            double p = 0;
+            for (int m = N - 1; m >= 0; --m) p = p * t + mono[m];
+            if (!(std::fabs(p - f(t)) <= (sizeof(FT) == 4 ? 2e-7 : 4e-15) * std::fabs(f(t)))) ok = false;
+        }
+    }
+    return ok;
+}
+// (G: ChenGamma<FT>, possibly in the constant address space — the Float64 kernels read their constants through the kernel-argument pointer)
+template <typename FT, typename G> __device__ __forceinline__ FT chen_gamma_eval(const G &g, int i, FT rho_c) {
+    const FT t = rho_c - FT(0.5 * kChenGammaRhoMax);
+    FT p = g.c[i][ChenGamma<FT>::D];
+#pragma unroll
+    for (int m = ChenGamma<FT>::D - 1; m >= 0; --m) p = Math<FT>::fma(p, t, g.c[i][m]);
+    return p;
 }
 
 // Γ(z) for ANY argument (the reference evaluates SF.gamma at run time, Common.jl:414-422): OCML's tgamma — ≈ 110 (Float32) / 300
@@ -174,15 +189,6 @@ template <typename FT> __device__ __forceinline__ FT tgamma_general(FT z) {
     else return ::tgammaf(z);
 #endif
 }
-// largest air density for which every z = b_i − b_ρ ρ + 1 of a Chen-2022 rain table stays inside the polynomial window [1.5, 4]
-// (b_ρ ≥ 0: z falls with ρ).  The fast instantiations poison the fall speeds of points above it with NaN instead of clamping.
-template <typename CH> inline double chen_rain_gamma_rho_max(const CH &ch) {
-    double r = 1e300;
-    for (int i = 0; i < 3; ++i)
-        if ((double)ch.b_rho > 0) r = std::fmin(r, ((double)ch.b[i] + 1.0 - 1.5) / (double)ch.b_rho);
-    return r;
-}
-
 template <typename FT> __device__ __forceinline__ FT clampv(FT x, FT lo, FT hi) {
     // Base.clamp: x < lo ? lo : (x > hi ? hi : x)
     return Math<FT>::min(Math<FT>::max(x, lo), hi);

@@ -502,6 +502,21 @@ template <typename FT> inline Mp1mLinArgs<FT> make_mp1m_lin_args(FT q_min, FT dt
     return a;
 }
 
+// Both constant structs of the LinearizedAverage kernels travel as ONE by-value kernel argument, so that the phase-local reads of the
+// Float64 instantiations (front_consts: the FIRST kernel argument) address members of one struct — no hand-computed offsets into the
+// kernel-argument segment.
+template <typename FT> struct Mp1mLinKernArgs { Mp1mConsts<FT> c; Mp1mLinArgs<FT> a; };
+
+// Microphysics1MOptions as flags (include/cmx.h §5): at most one variant of a process
+inline int32_t check_flags_1m(uint32_t flags) {
+    if ((flags & CMX_1M_CLOUD_ICE_FORMATION_CONST) && (flags & CMX_1M_CLOUD_ICE_FORMATION_TDEP)) return CMX_ERR_BAD_ARG;
+    if ((flags & CMX_1M_RAIN_ACNV_KESSLER) && (flags & CMX_1M_RAIN_ACNV_PRESCRIBED_ND)) return CMX_ERR_BAD_ARG;
+    if ((flags & CMX_1M_SNOW_ACNV_NO_SUPERSAT) && (flags & CMX_1M_SNOW_ACNV_WITH_SUPERSAT)) return CMX_ERR_BAD_ARG;
+    if ((flags & CMX_1M_SNOW_SUBLIMATION_ONLY) && (flags & CMX_1M_SNOW_DEP_AND_SUBL)) return CMX_ERR_BAD_ARG;
+    if (flags >> 17) return CMX_ERR_BAD_ARG;
+    return CMX_OK;
+}
+
 template <typename FT> struct Mp1mIn { const FT *rho, *T, *q_tot, *q_lcl, *q_icl, *q_rai, *q_sno; };
 template <typename FT> struct Mp1mOut { FT *dq_lcl, *dq_icl, *dq_rai, *dq_sno; };
 template <typename FT> struct Mp1mSrcOut { FT *col[CMX_MP1M_NSRC]; };

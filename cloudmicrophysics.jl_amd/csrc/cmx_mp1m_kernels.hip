@@ -66,7 +66,6 @@ __global__ __launch_bounds__(kBlock1m) void mp1m_tendencies_kernel(const Mp1mCon
 // mp1m_linearized_point).  One point per lane (the substep loop carries five state variables).  Both constant structs travel as ONE
 // by-value kernel argument so that the phase-local reads of the Float64 instantiation (front_consts: the FIRST kernel argument)
 // address members of one struct — no hand-computed offsets into the kernel-argument segment.
-template <typename FT> struct Mp1mLinKernArgs { Mp1mConsts<FT> c; Mp1mLinArgs<FT> a; };
 template <typename FT> struct Mp1mLinIO { const FT *in[7]; FT *out[4]; };
 
 // `at(column pointer, k)`: element of column k (0–6 state, 7–10 tendencies) this lane owns
@@ -108,7 +107,6 @@ __global__ __launch_bounds__(kBlock) void mp1m_sources_kernel(const Mp1mConsts<F
 template <typename FT> struct Vel1mIO {
     const FT *rho, *q_rai, *q_sno; FT *vt_rai, *vt_sno, *vt_chen;
     const FT *q_lcl, *q_icl; FT *w_lcl, *w_icl, *w_sno_chen;
-    FT chen_rho_max;   // fast Γ instantiation: fall speed = NaN above this air density (cmx_math.hpp chen_rain_gamma_rho_max)
 };
 
 // GENERAL_GAMMA: the Chen-2022 rain table's exponents leave the polynomial-Γ window → run-time Γ for any argument
@@ -124,10 +122,7 @@ __global__ __launch_bounds__(kBlock) void mp1m_velocity_kernel(const Vel1mConsts
         const FT q = io.q_rai[i];
         const FT l2_li = vel_l2_li_rain<FT>(c, rp, q);
         if (io.vt_rai) io.vt_rai[i] = vel_rain_blk1m<FT>(c, rho, l2_li, q);
-        if (io.vt_chen) {
-            const FT w = vel_rain_chen<FT, GENERAL_GAMMA>(c, rp, l2_li, q);
-            io.vt_chen[i] = (!GENERAL_GAMMA && rp > io.chen_rho_max) ? M::nan() : w;
-        }
+        if (io.vt_chen) io.vt_chen[i] = vel_rain_chen<FT, GENERAL_GAMMA>(c, rp, l2_li, q);
     }
     if (io.vt_sno || io.w_sno_chen) {
         const FT q = io.q_sno[i];
@@ -140,15 +135,6 @@ __global__ __launch_bounds__(kBlock) void mp1m_velocity_kernel(const Vel1mConsts
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------
-static int32_t check_flags_1m(uint32_t flags) {
-    if ((flags & CMX_1M_CLOUD_ICE_FORMATION_CONST) && (flags & CMX_1M_CLOUD_ICE_FORMATION_TDEP)) return CMX_ERR_BAD_ARG;
-    if ((flags & CMX_1M_RAIN_ACNV_KESSLER) && (flags & CMX_1M_RAIN_ACNV_PRESCRIBED_ND)) return CMX_ERR_BAD_ARG;
-    if ((flags & CMX_1M_SNOW_ACNV_NO_SUPERSAT) && (flags & CMX_1M_SNOW_ACNV_WITH_SUPERSAT)) return CMX_ERR_BAD_ARG;
-    if ((flags & CMX_1M_SNOW_SUBLIMATION_ONLY) && (flags & CMX_1M_SNOW_DEP_AND_SUBL)) return CMX_ERR_BAD_ARG;
-    if (flags >> 17) return CMX_ERR_BAD_ARG;
-    return CMX_OK;
-}
-
 template <typename FT, typename MP, typename TH>
 static int32_t tendencies_1m_entry(const MP *mp, const TH *tps, uint32_t flags, int64_t n, const FT *rho, const FT *T,
                                    const FT *q_tot, const FT *q_lcl, const FT *q_icl, const FT *q_rai, const FT *q_sno,
@@ -292,10 +278,9 @@ static int32_t velocity_1m_entry(const MP *mp, const CH *chen, int64_t n, const 
     if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (n == 0) return CMX_OK;
     if (!rho || ((vt_rai || vt_chen) && !q_rai) || (vt_sno && !q_sno) || (vt_chen && !chen)) return CMX_ERR_BAD_ARG;
-    const Vel1mConsts<FT> c = make_vel1m_consts<FT>(*mp, chen);
-    Vel1mIO<FT> io{rho, q_rai, q_sno, vt_rai, vt_sno, vt_chen, nullptr, nullptr, nullptr, nullptr, nullptr, FT(0)};
-    const bool general = vt_chen && !chen_rain_gamma_domain_ok(*chen);
-    if (vt_chen && !general) io.chen_rho_max = (FT)std::fmin(chen_rain_gamma_rho_max(*chen), 1e30);
+    bool general = false;
+    const Vel1mConsts<FT> c = make_vel1m_consts<FT>(*mp, chen, &general);
+    Vel1mIO<FT> io{rho, q_rai, q_sno, vt_rai, vt_sno, vt_chen, nullptr, nullptr, nullptr, nullptr, nullptr};
     launch_velocity<FT>(general, c, io, n, stream);
     CMX_HIP_TRY(hipGetLastError());
     return CMX_OK;
@@ -313,11 +298,10 @@ static int32_t sedimentation_entry(const MP *mp, const ST *stokes, const CH *che
     if (!rho || (w_lcl && (!q_lcl || !stokes)) || (w_icl && (!q_icl || !chen_ice)) || (w_rai && (!q_rai || !chen_rain)) ||
         (w_sno && (!q_sno || !chen_ice)))
         return CMX_ERR_BAD_ARG;
-    Vel1mConsts<FT> c = make_vel1m_consts<FT>(*mp, chen_rain);
+    bool general = false;
+    Vel1mConsts<FT> c = make_vel1m_consts<FT>(*mp, chen_rain, &general);
     add_sedimentation_consts<FT>(c, *mp, stokes, chen_ice);
-    Vel1mIO<FT> io{rho, q_rai, q_sno, nullptr, nullptr, w_rai, q_lcl, q_icl, w_lcl, w_icl, w_sno, FT(0)};
-    const bool general = w_rai && !chen_rain_gamma_domain_ok(*chen_rain);
-    if (w_rai && !general) io.chen_rho_max = (FT)std::fmin(chen_rain_gamma_rho_max(*chen_rain), 1e30);
+    Vel1mIO<FT> io{rho, q_rai, q_sno, nullptr, nullptr, w_rai, q_lcl, q_icl, w_lcl, w_icl, w_sno};
     launch_velocity<FT>(general, c, io, n, stream);
     CMX_HIP_TRY(hipGetLastError());
     return CMX_OK;

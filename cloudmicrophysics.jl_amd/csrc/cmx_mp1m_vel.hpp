@@ -12,6 +12,7 @@ template <typename FT> struct Vel1mConsts {
     FT eps_1m, l2_eps, lam_a_rai, lam_b_rai, lam_floor_rai, lam_a_sno, lam_b_sno, lam_floor_sno, sno_l2_mu, sno_nu;
     FT rho_w, vt_k_rai, vt_e_rai, vt_k_sno, vt_e_sno;
     FT ch_rho0_l2e, ch_a[3], ch_a3_pow, ch_b[3], ch_b_rho, ch_c1000[3], l2_1000;
+    ChenGamma<FT> chg;   // Γ(b_i(ρ) + 1) as polynomials in ρ (cmx_math.hpp)
     // cloud liquid, Stokes (NonEq:250-265): v = st_pref (ρw/ρ − 1) D², D³ = st_D3 ρ q
     FT st_pref, st_rho_w, st_D3;
     // cloud ice, Chen-2022 small ice reduced at ρᵢ(cloud ice) (NonEq:267-281, Common.jl:304-325): D³ = ci_D3 ρ q
@@ -21,30 +22,32 @@ template <typename FT> struct Vel1mConsts {
     FT sn_A, sn_a1, sn_b1, sn_a2, sn_H, sn_b2, sn_c2;
 };
 
+// (VC below: Vel1mConsts<FT>, possibly in the constant address space — kernels whose constants overflow the SGPR file read them through the
+// kernel-argument pointer, cmx_math.hpp front_consts)
 // log2 λ⁻¹ of rain / snow (CM1.lambda_inverse :126-152, get_n0 :83-86) from ρ⁺ = max(0, ρ) and q
-template <typename FT> __device__ __forceinline__ FT vel_l2_li_rain(const Vel1mConsts<FT> &c, FT rp, FT q) {
+template <typename FT, typename VC> __device__ __forceinline__ FT vel_l2_li_rain(const VC &c, FT rp, FT q) {
     using M = Math<FT>;
     return M::max(c.lam_floor_rai, M::fma(M::log2(rp * M::max(FT(0), q)), c.lam_a_rai, c.lam_b_rai));
 }
-template <typename FT> __device__ __forceinline__ FT vel_l2_li_snow(const Vel1mConsts<FT> &c, FT rp, FT q) {
+template <typename FT, typename VC> __device__ __forceinline__ FT vel_l2_li_snow(const VC &c, FT rp, FT q) {
     using M = Math<FT>;
     const FT l2_rq = M::log2(rp * M::max(FT(0), q));
     const FT l2_n0 = q > c.eps_1m ? M::fma(c.sno_nu, l2_rq, c.sno_l2_mu) : c.l2_eps;
     return M::max(c.lam_floor_sno, M::fma(l2_rq - M::max(l2_n0, c.l2_eps), c.lam_a_sno, c.lam_b_sno));
 }
 // CM1.terminal_velocity(::Rain / ::Snow, ::Blk1MVelType, ρ, q) — CM1:223-249
-template <typename FT> __device__ __forceinline__ FT vel_rain_blk1m(const Vel1mConsts<FT> &c, FT rho, FT l2_li, FT q) {
+template <typename FT, typename VC> __device__ __forceinline__ FT vel_rain_blk1m(const VC &c, FT rho, FT l2_li, FT q) {
     using M = Math<FT>;
     const FT sq = M::sqrt(M::max(c.rho_w * M::rcp(rho) - FT(1), FT(0)));
     return q > c.eps_1m ? (c.vt_k_rai * sq) * M::exp2(c.vt_e_rai * l2_li) : FT(0);
 }
-template <typename FT> __device__ __forceinline__ FT vel_snow_blk1m(const Vel1mConsts<FT> &c, FT l2_li, FT q) {
+template <typename FT, typename VC> __device__ __forceinline__ FT vel_snow_blk1m(const VC &c, FT l2_li, FT q) {
     using M = Math<FT>;
     return q > c.eps_1m ? c.vt_k_sno * M::exp2(c.vt_e_sno * l2_li) : FT(0);
 }
-// Chen 2022 rain, mass-weighted (k = 3), diameter slope = 2 λ⁻¹ — CM1:251-270, Common.jl:290-302,414-422.  GENERAL: Γ(b+1) by the
-// Lanczos form valid for any b + 1 > 0 (parameter sets whose exponents leave the polynomial window of Math::tgamma)
-template <typename FT, bool GENERAL = false> __device__ __forceinline__ FT vel_rain_chen(const Vel1mConsts<FT> &c, FT rp, FT l2_li, FT q) {
+// Chen 2022 rain, mass-weighted (k = 3), diameter slope = 2 λ⁻¹ — CM1:251-270, Common.jl:290-302,414-422.  Γ(b+1) from the host-fitted
+// polynomials in ρ (NaN fall speed beyond their range, ρ > 2 kg/m³); GENERAL: run-time Γ for parameter sets the fit cannot represent
+template <typename FT, bool GENERAL = false, typename VC> __device__ __forceinline__ FT vel_rain_chen(const VC &c, FT rp, FT l2_li, FT q) {
     using M = Math<FT>;
     const FT l2_lam_inv = l2_li + FT(1);
     const FT lam = M::exp2(-l2_lam_inv);
@@ -57,19 +60,21 @@ template <typename FT, bool GENERAL = false> __device__ __forceinline__ FT vel_r
         const FT l2_den = M::log2(lam + c.ch_c1000[k]);
         const FT e3 = M::exp2(l2_mag - FT(4) * l2_lam_inv - (bi + FT(4)) * l2_den);
         // Γ(b+4)/3! = (b+3)(b+2)(b+1)·Γ(b+1)/6
-        const FT g = GENERAL ? tgamma_general<FT>(bi + FT(1)) : M::tgamma(bi + FT(1));
+        const FT g = GENERAL ? tgamma_general<FT>(bi + FT(1)) : chen_gamma_eval<FT>(c.chg, k, rp);
         w = M::fma(c.ch_a[k] * e3, g * (bi + FT(3)) * (bi + FT(2)) * (bi + FT(1)) * FT(1.0 / 6.0), w);
     }
-    return q > c.eps_1m ? M::max(FT(0), w) : FT(0);
+    w = M::max(FT(0), w);
+    if (!GENERAL && rp > FT(kChenGammaRhoMax)) w = M::nan();       // outside the range of the fitted Γ: no silent extrapolation
+    return q > c.eps_1m ? w : FT(0);
 }
 // CMNonEq.terminal_velocity(::CloudLiquid, ::StokesRegimeVelType, ρ, q): Stokes at the mean-volume diameter — NonEq:250-265
-template <typename FT> __device__ __forceinline__ FT vel_lcl_stokes(const Vel1mConsts<FT> &c, FT rho, FT q) {
+template <typename FT, typename VC> __device__ __forceinline__ FT vel_lcl_stokes(const VC &c, FT rho, FT q) {
     using M = Math<FT>;
     const FT D2 = M::exp2(FT(2.0 / 3.0) * M::log2(c.st_D3 * rho * M::max(FT(0), q)));
     return q > c.eps_1m ? c.st_pref * (c.st_rho_w * M::rcp(rho) - FT(1)) * D2 : FT(0);
 }
 // CMNonEq.terminal_velocity(::CloudIce, ::Chen2022VelTypeSmallIce, ρ, q): Σ aₖ D^bₖ e^{−cₖD} at that diameter — NonEq:267-281
-template <typename FT> __device__ __forceinline__ FT vel_icl_chen(const Vel1mConsts<FT> &c, FT rho, FT rp, FT q) {
+template <typename FT, typename VC> __device__ __forceinline__ FT vel_icl_chen(const VC &c, FT rho, FT rp, FT q) {
     using M = Math<FT>;
     const FT l2_D = FT(1.0 / 3.0) * M::log2(c.ci_D3 * rho * M::max(FT(0), q));
     const FT D = M::exp2(l2_D);
@@ -79,7 +84,7 @@ template <typename FT> __device__ __forceinline__ FT vel_icl_chen(const Vel1mCon
     return q > c.eps_1m ? M::max(FT(0), w) : FT(0);
 }
 // CM1.terminal_velocity(::Snow, ::Chen2022VelTypeLargeIce, ρ, q): mass-weighted (k = 3), λ_D⁻¹ = 2 λ⁻¹ — CM1:272-297
-template <typename FT> __device__ __forceinline__ FT vel_snow_chen(const Vel1mConsts<FT> &c, FT rp, FT l2_li, FT q) {
+template <typename FT, typename VC> __device__ __forceinline__ FT vel_snow_chen(const VC &c, FT rp, FT l2_li, FT q) {
     using M = Math<FT>;
     const FT l2_ld = l2_li + FT(1), lam = M::exp2(-l2_ld);
     const FT l2_ra = c.sn_A * M::log2(rp);
@@ -89,8 +94,33 @@ template <typename FT> __device__ __forceinline__ FT vel_snow_chen(const Vel1mCo
     return q > c.eps_1m ? M::max(FT(0), t1 + t2) : FT(0);
 }
 
+// ---- sedimentation fluxes of the fused column step (cmx_mp1m_column.hip) ------------------------------------------------------------
+template <typename FT> struct SedFlux4 { FT f[4]; };   // lcl, icl, rai, sno
+
+// F = ρ⁺ χ⁺ w(ρ⁺, χ⁺) of the four species of one raw point
+template <typename FT, bool GENERAL_GAMMA, typename VC>
+__device__ __forceinline__ SedFlux4<FT> mp1m_sed_fluxes(const VC &vc, FT rho, FT q_lcl, FT q_icl, FT q_rai, FT q_sno) {
+    using M = Math<FT>;
+    const FT r_ = max0(rho), ql = max0(q_lcl), qi = max0(q_icl), qr = max0(q_rai), qs = max0(q_sno);
+    SedFlux4<FT> F;
+    // one species after the other (consts_after: only one species' constants live where they are read through the kernel-argument pointer)
+    F.f[0] = (r_ * ql) * vel_lcl_stokes<FT>(vc, r_, ql);
+    const VC &v1 = consts_after(vc, F.f[0]);
+    F.f[1] = (r_ * qi) * vel_icl_chen<FT>(v1, r_, r_, qi);
+    const VC &v2 = consts_after(v1, F.f[1]);
+    F.f[2] = (r_ * qr) * vel_rain_chen<FT, GENERAL_GAMMA>(v2, r_, vel_l2_li_rain<FT>(v2, r_, qr), qr);
+    const VC &v3 = consts_after(v2, F.f[2]);
+    F.f[3] = (r_ * qs) * vel_snow_chen<FT>(v3, r_, vel_l2_li_snow<FT>(v3, r_, qs), qs);
+    const FT q[4] = {q_lcl, q_icl, q_rai, q_sno};
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (any_nan(rho, q[s])) F.f[s] = M::nan();
+    return F;
+}
+
+// *chen_general (optional): true when the Chen-2022 rain table needs the GENERAL instantiation (the Γ fit is not accurate for it)
 template <typename FT, typename MP, typename CH>
-static Vel1mConsts<FT> make_vel1m_consts(const MP &mp, const CH *chen) {
+static Vel1mConsts<FT> make_vel1m_consts(const MP &mp, const CH *chen, bool *chen_general = nullptr) {
     // reuse the folding of the tendencies kernel (thermo part unused): a neutral thermo struct keeps it well-defined
     cmx_thermo_f64 tp{461.5, 287.0, 1004.5, 1859.0, 4181.0, 2070.0, 2.5008e6, 2.8344e6, 273.16, 273.16, 611.657, 273.15, 4181.0};
     const Mp1mConsts<FT> m = make_mp1m_consts<FT>(mp, tp, 0u, (double)Math<FT>::eps_1m());
@@ -103,6 +133,10 @@ static Vel1mConsts<FT> make_vel1m_consts(const MP &mp, const CH *chen) {
         c.ch_rho0_l2e = (FT)((double)chen->rho_0 * 1.4426950408889634074);
         for (int k = 0; k < 3; ++k) { c.ch_a[k] = (FT)chen->a[k]; c.ch_b[k] = (FT)chen->b[k]; c.ch_c1000[k] = (FT)((double)chen->c[k] * 1000.0); }
         c.ch_a3_pow = (FT)chen->a3_pow; c.ch_b_rho = (FT)chen->b_rho;
+        const bool fit_ok = make_chen_gamma<FT>(*chen, c.chg);
+        if (chen_general) *chen_general = !fit_ok;
+    } else if (chen_general) {
+        *chen_general = false;
     }
     return c;
 }

@@ -204,10 +204,12 @@ static void launch_column(bool limited, int vel, bool cloud, bool intpow, const 
 #define CMX_PICK(L, V) do { if (cloud) CMX_LAUNCH(L, V, true); else CMX_LAUNCH(L, V, false); } while (0)
     if (limited) {
         if (vel == VEL_SB) CMX_PICK(true, VEL_SB);
-        else CMX_PICK(true, VEL_CHEN);
+        else if (vel == VEL_CHEN) CMX_PICK(true, VEL_CHEN);
+        else CMX_PICK(true, VEL_CHEN_GEN);
     } else {
         if (vel == VEL_SB) CMX_PICK(false, VEL_SB);
-        else CMX_PICK(false, VEL_CHEN);
+        else if (vel == VEL_CHEN) CMX_PICK(false, VEL_CHEN);
+        else CMX_PICK(false, VEL_CHEN_GEN);
     }
 #undef CMX_PICK
 #undef CMX_LAUNCH
@@ -221,7 +223,6 @@ static int32_t column_entry(const WR *wr, const TH *tps, const VL *vel, const ST
     if (flags & ~(uint32_t)(CMX_SB2006_LIMITED | CMX_VEL_SB2006 | CMX_VEL_CHEN2022)) return CMX_ERR_BAD_ARG;
     const bool sbv = flags & CMX_VEL_SB2006, chv = flags & CMX_VEL_CHEN2022;
     if (sbv == chv) return CMX_ERR_BAD_ARG;                      // exactly one rain fall-speed scheme
-    if (chv && !chen_rain_gamma_domain_ok(vel->chen2022)) return CMX_ERR_UNSUPPORTED;   // polynomial Γ domain (cmx_math.hpp)
     if (n_col > kMaxPoints / n_lev) return CMX_ERR_UNSUPPORTED;  // n_col·n_lev must fit one launch (cmx_launch.hpp)
     const int64_t n = n_col * (int64_t)n_lev;
     if (n == 0) return CMX_OK;
@@ -235,7 +236,7 @@ static int32_t column_entry(const WR *wr, const TH *tps, const VL *vel, const ST
     const SbColIO<FT> io{rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, dq_lcl, dn_lcl, dq_rai, dn_rai, inv_dz, precip, n, n_lev, 1.0 / (double)n_lev};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool limited = flags & CMX_SB2006_LIMITED;
-    const int velk = sbv ? VEL_SB : VEL_CHEN;
+    const int velk = sbv ? VEL_SB : chen_vel_kind<FT>(vel->chen2022);   // fitted Γ(b(ρ)+1) or the general instantiation (cmx_math.hpp ChenGamma)
     constexpr int VEC = sizeof(FT) == 8 ? 1 : Math<FT>::VEC;     // Float64: one point per lane, as in the pointwise kernel
     // alignment dispatch as in cmx_sb2006_warm_rain_tendencies_*: a scalar head up to the common 16-byte boundary, the vector body,
     // a scalar tail; the halo point of each range is read from the full columns, so the three launches compose exactly

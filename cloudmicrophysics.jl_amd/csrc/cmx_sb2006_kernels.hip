@@ -44,11 +44,13 @@ static void launch_tendencies(bool limited, int vel, bool intpow, const SbConsts
     if (limited) {
         if (vel == VEL_NONE) CMX_LAUNCH(true, VEL_NONE);
         else if (vel == VEL_SB) CMX_LAUNCH(true, VEL_SB);
-        else CMX_LAUNCH(true, VEL_CHEN);
+        else if (vel == VEL_CHEN) CMX_LAUNCH(true, VEL_CHEN);
+        else CMX_LAUNCH(true, VEL_CHEN_GEN);
     } else {
         if (vel == VEL_NONE) CMX_LAUNCH(false, VEL_NONE);
         else if (vel == VEL_SB) CMX_LAUNCH(false, VEL_SB);
-        else CMX_LAUNCH(false, VEL_CHEN);
+        else if (vel == VEL_CHEN) CMX_LAUNCH(false, VEL_CHEN);
+        else CMX_LAUNCH(false, VEL_CHEN_GEN);
     }
 #undef CMX_LAUNCH
 }
@@ -64,9 +66,9 @@ static int32_t tendencies_entry(const WR *wr, const TH *tps, const VL *vel, uint
     if (!rho || !T || !q_tot || !q_lcl || !n_lcl || !q_rai || !n_rai || !dq_lcl || !dn_lcl || !dq_rai || !dn_rai)
         return CMX_ERR_BAD_ARG;
     const bool want_vel = vt_n || vt_m;
-    const int velk = decode_vel(flags, want_vel);
+    int velk = decode_vel(flags, want_vel);
     if (velk < 0 || (want_vel && !vel)) return CMX_ERR_BAD_ARG;
-    if (velk == VEL_CHEN && !chen_rain_gamma_domain_ok(vel->chen2022)) return CMX_ERR_UNSUPPORTED;   // polynomial Γ domain (cmx_math.hpp)
+    if (velk == VEL_CHEN) velk = chen_vel_kind<FT>(vel->chen2022);   // fitted Γ(b(ρ)+1), or the general instantiation (cmx_math.hpp ChenGamma)
     const bool limited = flags & CMX_SB2006_LIMITED;
     if ((flags & CMX_SB2006_LIMITED) && !sb_limiters_ok(*wr)) return CMX_ERR_BAD_ARG;      // clamp_ordered needs ordered limiter pairs
     const SbConsts<FT> c = make_sb_consts<FT>(*wr, *tps, vel, (double)Math<FT>::eps_1m());
@@ -133,9 +135,9 @@ static int32_t process_entry(const WR *wr, const TH *tps, const VL *vel, uint32_
     if (n == 0) return CMX_OK;
     if (!q_tot || !q_lcl || !q_rai || !N_lcl || !N_rai || !rho || !T) return CMX_ERR_BAD_ARG;
     const bool want_vel = out[CMX_SB_RAI_VEL_N] || out[CMX_SB_RAI_VEL_M];
-    const int velk = decode_vel(flags, want_vel);
+    int velk = decode_vel(flags, want_vel);
     if (velk < 0 || (want_vel && !vel)) return CMX_ERR_BAD_ARG;
-    if (velk == VEL_CHEN && !chen_rain_gamma_domain_ok(vel->chen2022)) return CMX_ERR_UNSUPPORTED;   // polynomial Γ domain (cmx_math.hpp)
+    if (velk == VEL_CHEN) velk = chen_vel_kind<FT>(vel->chen2022);   // fitted Γ(b(ρ)+1), or the general instantiation (cmx_math.hpp ChenGamma)
     const bool limited = flags & CMX_SB2006_LIMITED;
     if ((flags & CMX_SB2006_LIMITED) && !sb_limiters_ok(*wr)) return CMX_ERR_BAD_ARG;      // clamp_ordered needs ordered limiter pairs
     const SbConsts<FT> c = make_sb_consts<FT>(*wr, *tps, vel, (double)Math<FT>::eps_1m());
@@ -149,11 +151,13 @@ static int32_t process_entry(const WR *wr, const TH *tps, const VL *vel, uint32_
     if (limited) {
         if (velk == VEL_NONE) CMX_LAUNCH(true, VEL_NONE);
         else if (velk == VEL_SB) CMX_LAUNCH(true, VEL_SB);
-        else CMX_LAUNCH(true, VEL_CHEN);
+        else if (velk == VEL_CHEN) CMX_LAUNCH(true, VEL_CHEN);
+        else CMX_LAUNCH(true, VEL_CHEN_GEN);
     } else {
         if (velk == VEL_NONE) CMX_LAUNCH(false, VEL_NONE);
         else if (velk == VEL_SB) CMX_LAUNCH(false, VEL_SB);
-        else CMX_LAUNCH(false, VEL_CHEN);
+        else if (velk == VEL_CHEN) CMX_LAUNCH(false, VEL_CHEN);
+        else CMX_LAUNCH(false, VEL_CHEN_GEN);
     }
 #undef CMX_LAUNCH
     CMX_HIP_TRY(hipGetLastError());

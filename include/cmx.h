@@ -664,6 +664,29 @@ int32_t cmx_mp1m_linearized_average_fields_f64(const cmx_microphysics_1m_f64 *mp
                                                int32_t nsub, int64_t n_seg, int64_t seg_len, const double *const *in, const int64_t *in_seg_stride,
                                                double *const *out, const int64_t *out_seg_stride, double *out_aos, void *stream);
 
+/* The OPERATIONAL 1-moment column step in one pass (SURVEY §8f-1 + §8f-4): per grid point of n_col columns × n_lev contiguous levels
+ * (flat index col·n_lev + k, level 0 = lowest — `parent(field)` of a ClimaCore column field)
+ *   tend  = BMT.bulk_microphysics_tendencies(mode, Microphysics1Moment(), mp, tps, ρ, T, q_tot, q_lcl, q_icl, q_rai, q_sno[, Δt, nsub])
+ *           mode = Instantaneous() when nsub = 0 (BMT:505-514), LinearizedAverage() when nsub ≥ 1 (BMT:572-632; q_min, dt as there)
+ *   w     = the four bulk fall speeds a host model precomputes — exactly cmx_sedimentation_velocities_* on the clamped state
+ *           (CMNonEq.terminal_velocity cloud liquid / cloud ice, CM1.terminal_velocity Chen-2022 rain / snow; NonEq:250-281, CM1:251-297)
+ * followed by the host model's first-order upwind ("right-biased") flux divergence of the four species
+ *   F_k = ρ_k χ_k w_k,   ∂χ_k/∂t += (F_{k+1} − F_k) · inv_dz[k] / ρ_k,   F_{n_lev} = 0,    χ = q_lcl, q_icl, q_rai, q_sno.
+ * The flux scheme is the host model's (ClimaAtmos precipitation advection; column spaces test/gpu_clima_core_test.jl:16-45), NOT part
+ * of the reference package: "parity unpinned" for the flux step, as for cmx_sb2006_column_tendencies_sedimentation_*.
+ * in = HOST array of the 7 device columns (rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno), out = HOST array of the 4 device tendency
+ * columns; precip_rai / precip_sno (optional, n_col values): the surface fluxes F_0 of rain and snow [kg m⁻² s⁻¹].  44 B/point (f32)
+ * instead of the 148 B/point of the three unfused steps.  Results do not depend on tile boundaries or alignment; a NaN in ρ or in a
+ * species' q gives a NaN flux of that species (and a NaN tendency of that species in the cell below). */
+int32_t cmx_mp1m_column_tendencies_sedimentation_f32(const cmx_microphysics_1m_f32 *mp, const cmx_thermo_f32 *tps, const cmx_stokes_vel_f32 *stokes,
+                                                     const cmx_chen2022_rain_vel_f32 *chen_rain, const cmx_chen2022_ice_vel_f32 *chen_ice, uint32_t flags,
+                                                     float q_min, float dt, int32_t nsub, int64_t n_col, int32_t n_lev, const float *inv_dz,
+                                                     const float *const *in, float *const *out, float *precip_rai, float *precip_sno, void *stream);
+int32_t cmx_mp1m_column_tendencies_sedimentation_f64(const cmx_microphysics_1m_f64 *mp, const cmx_thermo_f64 *tps, const cmx_stokes_vel_f64 *stokes,
+                                                     const cmx_chen2022_rain_vel_f64 *chen_rain, const cmx_chen2022_ice_vel_f64 *chen_ice, uint32_t flags,
+                                                     double q_min, double dt, int32_t nsub, int64_t n_col, int32_t n_lev, const double *inv_dz,
+                                                     const double *const *in, double *const *out, double *precip_rai, double *precip_sno, void *stream);
+
 /* The individual 1M source terms — `_microphysics_source_terms` (BMT:141-217), same inputs (clamped the
  * same way), `out` = host array of CMX_MP1M_NSRC device column pointers (NULL = skip). */
 typedef enum cmx_mp1m_source_column {

@@ -244,6 +244,33 @@ def sedimentation_velocities(fam, mp, stokes, chen_rain, chen_ice, rho, q_lcl, q
     return dict(zip(names, outs))
 
 
+def mp1m_column_tendencies_sedimentation(fam, mp, tps, stokes, chen_rain, chen_ice, flags, inv_dz, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno, *,
+                                         q_min=0.0, dt=0.0, nsub=0, chen_ice_scale=None, float32_gates=None, nthreads=1):
+    """Oracle twin of cmx_mp1m_column_tendencies_sedimentation_* (flux step: parity unpinned, see cmx_oracle_column_impl.h).  State
+    arrays of shape (n_col, n_lev); nsub = 0: Instantaneous tendencies.  Returns the 4 tendencies (flat), the two surface fluxes, `scale`."""
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    n_col, n_lev = np.shape(rho)
+    ins = [_col(fam, np.reshape(a, -1)) for a in (rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno)]
+    dz = _col(fam, inv_dz)
+    n = n_col * n_lev
+    names = ["dq_lcl_dt", "dq_icl_dt", "dq_rai_dt", "dq_sno_dt"]
+    outs = [np.empty(n, dtype=NP[fam.sfx]) for _ in names]
+    scale = [np.empty(n, dtype=NP[fam.sfx]) for _ in names]
+    pr, ps = np.empty(n_col, dtype=NP[fam.sfx]), np.empty(n_col, dtype=NP[fam.sfx])
+    fn = getattr(lib(), f"cmxo_mp1m_column_tendencies_sedimentation_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(mp), C.byref(tps), C.byref(stokes), C.byref(chen_rain), C.byref(chen_ice), C.byref(chen_ice_scale) if chen_ice_scale is not None else None,
+       C.c_uint32(flags), C.byref(th), fam.ft(q_min), fam.ft(dt), C.c_int32(nsub), C.c_int64(n_col), C.c_int32(n_lev), dz[1], *[p for _, p in ins],
+       (C.c_void_p * 4)(*[c.ctypes.data for c in outs]), pr.ctypes.data_as(C.c_void_p), ps.ctypes.data_as(C.c_void_p),
+       (C.c_void_p * 4)(*[c.ctypes.data for c in scale]), C.c_int32(nthreads))
+    res = dict(zip(names, outs))
+    res["precip_rai"], res["precip_sno"] = pr, ps
+    res["scale"] = dict(zip(names, scale))
+    return res
+
+
 def mp1m_terminal_velocity(fam, mp, chen, rho, q_rai, q_sno, float32_gates=None):
     if float32_gates is None:
         float32_gates = fam.sfx == "f32"

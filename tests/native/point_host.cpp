@@ -51,8 +51,10 @@ int32_t linearized(const MP *mp, const TH *tps, uint32_t flags, FT q_min, FT dt,
 // the four sedimentation velocities (w_lcl, w_icl, w_rai, w_sno) of (rho, q_lcl, q_icl, q_rai, q_sno)
 template <typename FT, typename MP, typename ST, typename CH, typename CI>
 int32_t sedimentation(const MP *mp, const ST *stokes, const CH *chen_rain, const CI *chen_ice, int general_gamma, int64_t n, const FT *const *x, FT *const *w) {
-    Vel1mConsts<FT> c = make_vel1m_consts<FT>(*mp, chen_rain);
+    bool fit_general = false;
+    Vel1mConsts<FT> c = make_vel1m_consts<FT>(*mp, chen_rain, &fit_general);
     add_sedimentation_consts<FT>(c, *mp, stokes, chen_ice);
+    if (general_gamma < 0) general_gamma = fit_general;      // −1: what the entry points would pick
     for (int64_t i = 0; i < n; ++i) {
         const FT rho = x[0][i], rp = Math<FT>::max(FT(0), rho);
         w[0][i] = vel_lcl_stokes<FT>(c, rho, x[1][i]);
@@ -60,6 +62,38 @@ int32_t sedimentation(const MP *mp, const ST *stokes, const CH *chen_rain, const
         const FT l2r = vel_l2_li_rain<FT>(c, rp, x[3][i]);
         w[2][i] = general_gamma ? vel_rain_chen<FT, true>(c, rp, l2r, x[3][i]) : vel_rain_chen<FT, false>(c, rp, l2r, x[3][i]);
         w[3][i] = vel_snow_chen<FT>(c, rp, vel_l2_li_snow<FT>(c, rp, x[4][i]), x[4][i]);
+    }
+    return fit_general ? 1 : 0;
+}
+// the fused 1-moment column step, level by level from the model top (the kernel's per-point functions in a plain loop)
+template <typename FT, typename MP, typename TH, typename ST, typename CH, typename CI>
+int32_t column(const MP *mp, const TH *tps, const ST *stokes, const CH *chen_rain, const CI *chen_ice, uint32_t flags, FT q_min, FT dt, int32_t nsub,
+               int64_t n_col, int32_t n_lev, const FT *inv_dz, const FT *const *x, FT *const *y, FT *precip_rai, FT *precip_sno) {
+    using M = Math<FT>;
+    const Mp1mConsts<FT> c = make_mp1m_consts<FT>(*mp, *tps, flags, (double)M::eps_1m());
+    const Mp1mLinArgs<FT> a = nsub > 0 ? make_mp1m_lin_args<FT>(q_min, dt, nsub, (FT)tps->LH_v0, (FT)tps->LH_s0, (FT)tps->cp_d) : Mp1mLinArgs<FT>{};
+    bool general = false;
+    Vel1mConsts<FT> vc = make_vel1m_consts<FT>(*mp, chen_rain, &general);
+    add_sedimentation_consts<FT>(vc, *mp, stokes, chen_ice);
+    auto args = [&](FT) -> const Mp1mLinArgs<FT> & { return a; };
+    for (int64_t col = 0; col < n_col; ++col) {
+        SedFlux4<FT> up{{FT(0), FT(0), FT(0), FT(0)}};
+        for (int32_t k = n_lev - 1; k >= 0; --k) {
+            const int64_t i = col * n_lev + k;
+            FT t[4];
+            if (nsub > 0) mp1m_linearized_point<FT>(c, args, nsub, x[0][i], x[1][i], x[2][i], x[3][i], x[4][i], x[5][i], x[6][i], t[0], t[1], t[2], t[3]);
+            else mp1m_tendencies_point<FT>(c, x[0][i], x[1][i], x[2][i], x[3][i], x[4][i], x[5][i], x[6][i], t[0], t[1], t[2], t[3]);
+            const SedFlux4<FT> F = general ? mp1m_sed_fluxes<FT, true>(vc, x[0][i], x[3][i], x[4][i], x[5][i], x[6][i])
+                                           : mp1m_sed_fluxes<FT, false>(vc, x[0][i], x[3][i], x[4][i], x[5][i], x[6][i]);
+            const FT g = inv_dz[k] * M::rcp(max0(x[0][i]));
+            for (int s = 0; s < 4; ++s) {
+                const FT A = M::fma(-F.f[s], g, t[s]);
+                y[s][i] = k == n_lev - 1 ? A : M::fma(up.f[s], g, A);
+            }
+            if (k == 0 && precip_rai) precip_rai[col] = F.f[2];
+            if (k == 0 && precip_sno) precip_sno[col] = F.f[3];
+            up = F;
+        }
     }
     return 0;
 }
@@ -74,4 +108,6 @@ int32_t host_mp1m_linearized_f32(const cmx_microphysics_1m_f32 *mp, const cmx_th
 int32_t host_mp1m_linearized_f64(const cmx_microphysics_1m_f64 *mp, const cmx_thermo_f64 *tps, uint32_t flags, double q_min, double dt, int32_t nsub, int64_t n, const double *const *x, double *const *y) { return linearized<double>(mp, tps, flags, q_min, dt, nsub, n, x, y); }
 int32_t host_sedimentation_f32(const cmx_microphysics_1m_f32 *mp, const cmx_stokes_vel_f32 *st, const cmx_chen2022_rain_vel_f32 *cr, const cmx_chen2022_ice_vel_f32 *ci, int general_gamma, int64_t n, const float *const *x, float *const *w) { return sedimentation<float>(mp, st, cr, ci, general_gamma, n, x, w); }
 int32_t host_sedimentation_f64(const cmx_microphysics_1m_f64 *mp, const cmx_stokes_vel_f64 *st, const cmx_chen2022_rain_vel_f64 *cr, const cmx_chen2022_ice_vel_f64 *ci, int general_gamma, int64_t n, const double *const *x, double *const *w) { return sedimentation<double>(mp, st, cr, ci, general_gamma, n, x, w); }
+int32_t host_mp1m_column_f32(const cmx_microphysics_1m_f32 *mp, const cmx_thermo_f32 *tps, const cmx_stokes_vel_f32 *st, const cmx_chen2022_rain_vel_f32 *cr, const cmx_chen2022_ice_vel_f32 *ci, uint32_t flags, float q_min, float dt, int32_t nsub, int64_t n_col, int32_t n_lev, const float *inv_dz, const float *const *x, float *const *y, float *pr, float *ps) { return column<float>(mp, tps, st, cr, ci, flags, q_min, dt, nsub, n_col, n_lev, inv_dz, x, y, pr, ps); }
+int32_t host_mp1m_column_f64(const cmx_microphysics_1m_f64 *mp, const cmx_thermo_f64 *tps, const cmx_stokes_vel_f64 *st, const cmx_chen2022_rain_vel_f64 *cr, const cmx_chen2022_ice_vel_f64 *ci, uint32_t flags, double q_min, double dt, int32_t nsub, int64_t n_col, int32_t n_lev, const double *inv_dz, const double *const *x, double *const *y, double *pr, double *ps) { return column<double>(mp, tps, st, cr, ci, flags, q_min, dt, nsub, n_col, n_lev, inv_dz, x, y, pr, ps); }
 }

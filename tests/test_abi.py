@@ -106,14 +106,12 @@ def test_argument_validation_without_gpu():
     assert f(C.byref(bad.c), C.byref(tps), None, 1, 0, *null, None) == _abi.CMX_OK             # n = 0 returns before the parameters matter
     assert f(C.byref(bad.c), C.byref(tps), None, 1, 10, *([C.c_void_p(4096)] * 11), None, None, None) == _abi.CMX_ERR_BAD_ARG
     assert f(C.byref(bad.c), C.byref(tps), None, 0, 10, *null, None) == _abi.CMX_ERR_BAD_ARG   # (not limited: falls through to the null-column check)
-    # Chen-2022 rain fall speeds: Γ(b_i(ρ) + 1) is a polynomial on [1.5, 4]; parameter sets that leave it for ρ ≤ 2 kg/m³ are refused
+    # Chen-2022 rain fall speeds: every parameter set is accepted (round 3: Γ(b_i(ρ) + 1) fitted per parameter set, general instantiation
+    # otherwise — tests/test_sb2006_gpu.py::test_chen2022_parameter_sets_outside_the_old_window); n = 0 returns before any launch
     velp = P.rain_vel_params("f32")
     cols11 = [C.c_void_p(4096)] * 11
-    ok = f(C.byref(wr.c), C.byref(tps), C.byref(velp), 1 | _abi.CMX_VEL_CHEN2022, 0, *cols11, C.c_void_p(4096), C.c_void_p(4096), None)
-    assert ok == _abi.CMX_OK
-    velp.chen2022.b[2] = 0.3                                     # z = 1.3 − 0.0385 ρ < 1.5
-    assert f(C.byref(wr.c), C.byref(tps), C.byref(velp), 1 | _abi.CMX_VEL_CHEN2022, 10, *cols11, C.c_void_p(4096), C.c_void_p(4096),
-             None) == _abi.CMX_ERR_UNSUPPORTED
+    velp.chen2022.b[2] = 0.3
+    assert f(C.byref(wr.c), C.byref(tps), C.byref(velp), 1 | _abi.CMX_VEL_CHEN2022, 0, *cols11, C.c_void_p(4096), C.c_void_p(4096), None) == _abi.CMX_OK
     # a point count no single launch can express (> 16·(2^31 − 1), cmx_launch.hpp kMaxPoints) is refused, not silently truncated
     huge = 16 * 0x7fffffff + 1
     assert z(C.byref(p0), huge, None, None, None, None, None, None) == _abi.CMX_ERR_UNSUPPORTED

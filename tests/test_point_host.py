@@ -117,21 +117,34 @@ def test_mp1m_linearized_average(host, oracle, ft, dt, nsub):
     check_linearized_parity(ft, dict(zip(NAMES, got)), ref, inst, c64, dt, f"host-build 1M LinearizedAverage {ft} dt={dt} nsub={nsub}")
 
 
+def _chen_table(ft, variant):
+    """default: Table B1;  low_b: an exponent below the round-2 polynomial window (b₃ + 1 = 1.3 — the host-fitted Γ covers it);
+    steep: b_ρ = 0.6, Γ's argument moves by 1.2 over 0 ≤ ρ ≤ 2 → the fit misses its accuracy → general (run-time Γ) instantiation."""
+    cr = P.Chen2022VelTypeRain(ft)
+    if variant == "low_b":
+        cr.b[2] = 0.3
+    elif variant == "steep":
+        cr.b_rho = 0.6
+    return cr
+
+
 @pytest.mark.parametrize("ft", ["f32", "f64"])
-@pytest.mark.parametrize("general", [0, 1])
-def test_sedimentation_velocities(host, oracle, ft, general):
-    """The four fall speeds a host model precomputes, both Γ instantiations of the Chen-2022 rain term."""
+@pytest.mark.parametrize("general,variant", [(0, "default"), (1, "default"), (-1, "low_b"), (-1, "steep")])
+def test_sedimentation_velocities(host, oracle, ft, general, variant):
+    """The four fall speeds a host model precomputes; the Chen-2022 rain term with the host-fitted Γ polynomials (0), the run-time Γ (1),
+    and (−1) whichever instantiation the entry points pick for a modified table."""
     n = 50_000
     rng = np.random.default_rng(3)
     rho = rng.uniform(0.3, 1.3, n)
     q = [np.where(rng.random(n) < 0.2, 0.0, 10 ** rng.uniform(-8, -2.5, n)) for _ in range(4)]
     mp = P.Microphysics1MParams(ft)
-    stokes, cr, ci = P.StokesRegimeVelType(ft), P.Chen2022VelTypeRain(ft), P.Chen2022VelTypeIce(ft)
+    stokes, cr, ci = P.StokesRegimeVelType(ft), _chen_table(ft, variant), P.Chen2022VelTypeIce(ft)
     head = (C.byref(mp.c), C.byref(stokes), C.byref(cr), C.byref(ci), C.c_int(general))
-    _, w = _call(host, "host_sedimentation", ft, head, [rho] + q, 4)
+    picked_general, w = _call(host, "host_sedimentation", ft, head, [rho] + q, 4)
+    assert picked_general == (1 if variant == "steep" else 0)
     mp64 = P.Microphysics1MParams("f64")
     x64 = [np.asarray(c, dtype=NPT[ft]).astype(np.float64) for c in [rho] + q]
-    ref = oracle.sedimentation_velocities(_abi.F64, mp64.c, P.StokesRegimeVelType("f64"), P.Chen2022VelTypeRain("f64"), P.Chen2022VelTypeIce("f64"),
+    ref = oracle.sedimentation_velocities(_abi.F64, mp64.c, P.StokesRegimeVelType("f64"), _chen_table("f64", variant), P.Chen2022VelTypeIce("f64"),
                                           *x64, float32_gates=(ft == "f32"))
     # the Chen-2022 ice curves are differences of two terms that cancel near the zero crossing (E + F e^{−cD} with E ≈ −F): conditioning
     # scale = the positive term alone (oracle evaluated with the negative amplitude switched off), as in tests/test_mp1m_gpu.py

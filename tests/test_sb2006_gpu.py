@@ -127,6 +127,46 @@ def test_fused_tendencies_match_oracle(dev, oracle, ft, limited, vel):
 
 
 @pytest.mark.parametrize("ft", ["f32", "f64"])
+@pytest.mark.parametrize("variant", ["low_b", "steep"])
+def test_chen2022_parameter_sets_outside_the_old_window(dev, oracle, ft, variant):
+    """Round 2 refused Chen-2022 rain tables whose exponents left the fixed polynomial-Γ window (CMX_ERR_UNSUPPORTED).  Round 3:
+    `low_b` (b₃ + 1 = 1.3) is covered by the Γ polynomials fitted on the host for the parameter set at hand; `steep` (b_ρ = 0.6: the
+    argument of Γ moves by 1.2 over 0 ≤ ρ ≤ 2) cannot be fitted to accuracy and takes the general instantiation (run-time Γ)."""
+    import cmx
+    from cmx import synthetic
+
+    def table(f):
+        v = P.rain_vel_params(f)
+        if variant == "low_b":
+            v.chen2022.b[2] = 0.3
+        else:
+            v.chen2022.b_rho = 0.6
+        return v
+    n = 100_003
+    st = synthetic.sb2006_state(n, dtype=DT[ft], seed=99)
+    mp = P.Microphysics2MParams(ft)
+    got = cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), mp, P.ThermodynamicsParameters(ft), *[c.to(dev) for c in st],
+                                           vel=cmx.Chen2022VelTypeRain, vel_params=table(ft))
+    torch.cuda.synchronize()
+    ref = oracle.sb2006_warm_rain_tendencies(
+        _abi.F64, P.WarmRainParams2M("f64", True).c, P.ThermodynamicsParameters("f64"), table("f64"), _abi.CMX_SB2006_LIMITED | _abi.CMX_VEL_CHEN2022,
+        *[c.numpy().astype(np.float64) for c in st], float32_gates=(ft == "f32"), nthreads=8, branch_margin=1e-5 if ft == "f32" else 1e-11)
+    rep = parity.assert_parity(_np(got), ref, parity.RTOL[ft], what=f"Chen-2022 table {variant} {ft}")
+    assert float(got.vt_rai_m.max()) > 0.5
+    print(f"\n[parity] Chen-2022 table {variant} {ft}: {rep}")
+    # beyond the range of the fitted Γ (ρ > 2 kg/m³) the fitted instantiation returns NaN fall speeds instead of extrapolating
+    cols = [c[:8].clone().to(dev) for c in st]
+    cols[0][:] = 2.5
+    r = cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), mp, P.ThermodynamicsParameters(ft), *cols, vel=cmx.Chen2022VelTypeRain,
+                                         vel_params=table(ft))
+    has_rain = (cols[5] > 1e-6) & (cols[6] > 1e-6)
+    if variant == "low_b" and bool(has_rain.any()):
+        assert bool(torch.isnan(r.vt_rai_m[has_rain]).all())
+    if variant == "steep":
+        assert bool(torch.isfinite(r.vt_rai_m).all())
+
+
+@pytest.mark.parametrize("ft", ["f32", "f64"])
 def test_fused_tendencies_override_parameter_set(dev, oracle, ft):
     """The reference's CPU tests run with src/parameters/toml/SB2006_limiters.toml; so do we."""
     from cmx import synthetic

@@ -10,7 +10,8 @@ import json
 import sys
 from pathlib import Path
 
-BYTES_PER_POINT = {"sb2006": 13, "sb2006_column": 11, "icenuc": 5, "mp0m": 3, "mp1m": 11, "arg2000": 9, "p3": 9, "sb2006_aos": 15, "sb2006_fields": 11, "mp2m_p3": 20}   # columns in + out
+BYTES_PER_POINT = {"sb2006": 13, "sb2006_column": 11, "icenuc": 5, "mp0m": 3, "mp1m": 11, "mp1m_lin": 11, "mp1m_column": 11, "mp1m_column_lin": 11, "arg2000": 9, "p3": 9,
+                   "p3_fused": 9, "p3_selfcol": 7, "sb2006_aos": 15, "sb2006_fields": 11, "mp2m_p3": 20}   # columns in + out
 
 
 def find(out, sub, suffix):
@@ -30,23 +31,42 @@ def valu_summary(wl, dt, n, out, rnd):
         d = acc.setdefault(k, {"vgpr": r["VGPR_Count"], "accum_vgpr": r["Accum_VGPR_Count"], "sgpr": r["SGPR_Count"],
                                "scratch": r["Scratch_Size"], "counters": {}})
         d["counters"].setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    res = {"round": rnd, "workload": wl, "dtype": dt, "points": n, "kernels": {}}
+    # mean duration of each kernel from the --kernel-trace --stats pass of the same tools/profile.sh run (un-instrumented launches)
+    avg_ns = {}
+    stats = find(out, "kt", "kernel_stats.csv")
+    if stats:
+        for r in list(csv.reader(open(stats)))[1:]:
+            if r and "cmx::" in r[0]:
+                avg_ns[r[0].split("(")[0]] = float(r[3])
+    res = {"round": rnd, "workload": wl, "dtype": dt, "points": n,
+           "valu_issue_utilisation_formula": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel_avg_ns x 2.4 GHz): the share of the chip's "
+                                             "one-wave64-VALU-instruction-per-4-cycles issue slots the kernel fills (kernel_avg_ns from the "
+                                             "kernel-trace pass of the same profile run; 2.4 GHz = the spec clock, so DVFS shows up as a lower "
+                                             "figure; instructions that issue in fewer than 4 cycles can push it above what a mix of 4-cycle "
+                                             "instructions could reach — tools/valu_probe.hip has the per-instruction issue times)",
+           "kernels": {}}
+    tot_insts = tot_ns = 0.0
     for k, d in acc.items():
         c = {name: sum(v) / len(v) for name, v in d["counters"].items()}
         d["counters"] = c
-        d["launches"] = len(next(iter(acc[k]["counters"].values()), [])) if False else None
         if "SQ_INSTS_VALU" in c and n:
-            d["valu_wave_instructions_per_point"] = c["SQ_INSTS_VALU"] * 64 / n / 64     # wave-instr ≙ one per lane
+            d["valu_instructions_per_point"] = c["SQ_INSTS_VALU"] * 64 / n               # per-lane VALU instructions per grid point / state
         if c.get("SQ_WAVE_CYCLES"):
             d["valu_active_over_wave_cycles"] = c.get("SQ_ACTIVE_INST_VALU", 0.0) / c["SQ_WAVE_CYCLES"]
+        if k in avg_ns and "SQ_INSTS_VALU" in c:
+            d["kernel_avg_ns"] = avg_ns[k]
+            d["valu_issue_utilisation"] = c["SQ_INSTS_VALU"] * 4 / (1024 * avg_ns[k] * 1e-9 * 2.4e9)
+            tot_insts += c["SQ_INSTS_VALU"]; tot_ns += avg_ns[k]
         res["kernels"][k] = d
+    if tot_ns:
+        res["valu_issue_utilisation"] = tot_insts * 4 / (1024 * tot_ns * 1e-9 * 2.4e9)     # all kernels of one step together
     (dst / f"{rnd}_pmc_valu_{wl}_{dt}.json").write_text(json.dumps(res, indent=1))
     print(json.dumps(res))
 
 
 def main():
     wl, dt, n, out, rnd = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5]
-    if wl == "sb2006_column":
+    if wl in ("sb2006_column", "mp1m_column", "mp1m_column_lin"):
         n = n // 74 * 74          # bench.py rounds to whole 74-level columns
     if len(sys.argv) > 6 and sys.argv[6] == "valu":
         return valu_summary(wl, dt, n, out, rnd)

@@ -24,7 +24,7 @@ run pmc-write timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OU
 cd "$ROOT"
 run summary python3 tools/pmc_summary.py "$WL" "$DT" "$N" "$OUT" "$R"
 # compute-bound workloads: one more pass with the SQ instruction/cycle counters (VALU issue utilisation)
-if [ "$WL" = "p3" ] || [ "${5:-}" = "valu" ]; then
+if [ "${5:-}" = "valu" ]; then
   cd /tmp
   run pmc-sq timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_INST_ANY SQ_INSTS_VALU_TRANS GRBM_GUI_ACTIVE --output-format csv -d "$OUT/sq" -o sq -- python3 $ARGS > "$OUT/sq.log" 2>&1
   cd "$ROOT"
