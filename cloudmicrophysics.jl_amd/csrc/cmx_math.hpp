@@ -131,14 +131,16 @@ template <typename FT> __device__ __forceinline__ FT keep(FT x) {
 constexpr double kChenGammaRhoMax = 2.0;
 template <typename FT> struct ChenGamma {
     static constexpr int D = sizeof(FT) == 4 ? 3 : 8;
-    FT c[3][D + 1];      // Γ(b_i − b_ρ ρ + 1) = Σ_m c[i][m] (ρ − 1)^m
+    FT c[3][D + 1];      // Γ(b_i − b_ρ ρ + 1 [+ 3])[/3!] = Σ_m c[i][m] (ρ − 1)^m
 };
-template <typename FT, typename CH> inline bool make_chen_gamma(const CH &ch, ChenGamma<FT> &g) {
+// KSHIFT = 0: Γ(b + 1) (number-weighted, k = 0);  KSHIFT = 3: Γ(b + 4)/3! (mass-weighted, k = 3 — Chen2022_exponential_pdf, Common.jl:414-422)
+template <typename FT, typename CH> inline bool make_chen_gamma(const CH &ch, ChenGamma<FT> &g, int kshift = 0) {
     constexpr int D = ChenGamma<FT>::D, N = D + 1;
     const double pi = 3.14159265358979323846, half = 0.5 * kChenGammaRhoMax;
     bool ok = true;
     for (int i = 0; i < 3; ++i) {
-        auto f = [&](double t) { return std::tgamma((double)ch.b[i] - (double)ch.b_rho * (half + half * t) + 1.0); };
+        const double kfact = kshift == 3 ? 6.0 : 1.0;
+        auto f = [&](double t) { return std::tgamma((double)ch.b[i] - (double)ch.b_rho * (half + half * t) + 1.0 + kshift) / kfact; };
         if (!((double)ch.b[i] + 1.0 - (double)ch.b_rho * kChenGammaRhoMax > 0.05) || !((double)ch.b[i] + 1.0 < 30.0)) ok = false;
         // Chebyshev coefficients from the N Chebyshev nodes, then Σ a_k T_k(t) → monomials by the recurrence T_{k+1} = 2 t T_k − T_{k−1}
         double a[N], fx[N], mono[N] = {0}, Tkm1[N] = {0}, Tk[N] = {0};

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(BS) void mp1m_column_kernel(const Mp1mColKernArgs<F
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const FT upf = (p + 1 < VEC) ? F[p + 1 < VEC ? p + 1 : 0].f[s] : halo[up][s];
-            o[s][p] = top ? A[p][s] : M::fma(upf, g[p], A[p][s]);
+            o[s][p] = M::fma(top ? FT(0) : upf, g[p], A[p][s]);      // a select, not a branch per species
         }
         if (lev == 0) {                             // surface precipitation fluxes of the column
             if (io.precip_rai) io.precip_rai[col] = F[p].f[2];

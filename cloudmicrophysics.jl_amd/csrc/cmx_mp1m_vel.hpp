@@ -12,7 +12,7 @@ template <typename FT> struct Vel1mConsts {
     FT eps_1m, l2_eps, lam_a_rai, lam_b_rai, lam_floor_rai, lam_a_sno, lam_b_sno, lam_floor_sno, sno_l2_mu, sno_nu;
     FT rho_w, vt_k_rai, vt_e_rai, vt_k_sno, vt_e_sno;
     FT ch_rho0_l2e, ch_a[3], ch_a3_pow, ch_b[3], ch_b_rho, ch_c1000[3], l2_1000;
-    ChenGamma<FT> chg;   // Γ(b_i(ρ) + 1) as polynomials in ρ (cmx_math.hpp)
+    ChenGamma<FT> chg;   // Γ(b_i(ρ) + 4)/3! as polynomials in ρ (cmx_math.hpp)
     // cloud liquid, Stokes (NonEq:250-265): v = st_pref (ρw/ρ − 1) D², D³ = st_D3 ρ q
     FT st_pref, st_rho_w, st_D3;
     // cloud ice, Chen-2022 small ice reduced at ρᵢ(cloud ice) (NonEq:267-281, Common.jl:304-325): D³ = ci_D3 ρ q
@@ -56,12 +56,13 @@ template <typename FT, bool GENERAL = false, typename VC> __device__ __forceinli
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const FT bi = M::fma(-c.ch_b_rho, rp, c.ch_b[k]);
-        const FT l2_mag = l2_q + bi * c.l2_1000 + (k == 2 ? c.ch_a3_pow * l2_rho : FT(0));
+        FT l2_mag = M::fma(bi, c.l2_1000, l2_q);
+        if (k == 2) l2_mag = M::fma(c.ch_a3_pow, l2_rho, l2_mag);
         const FT l2_den = M::log2(lam + c.ch_c1000[k]);
         const FT e3 = M::exp2(l2_mag - FT(4) * l2_lam_inv - (bi + FT(4)) * l2_den);
-        // Γ(b+4)/3! = (b+3)(b+2)(b+1)·Γ(b+1)/6
-        const FT g = GENERAL ? tgamma_general<FT>(bi + FT(1)) : chen_gamma_eval<FT>(c.chg, k, rp);
-        w = M::fma(c.ch_a[k] * e3, g * (bi + FT(3)) * (bi + FT(2)) * (bi + FT(1)) * FT(1.0 / 6.0), w);
+        // Γ(b+4)/3!: the fitted polynomial in ρ, or (b+3)(b+2)(b+1)·Γ(b+1)/6 with the run-time Γ
+        const FT g = GENERAL ? tgamma_general<FT>(bi + FT(1)) * (bi + FT(3)) * (bi + FT(2)) * (bi + FT(1)) * FT(1.0 / 6.0) : chen_gamma_eval<FT>(c.chg, k, rp);
+        w = k == 0 ? (c.ch_a[k] * e3) * g : M::fma(c.ch_a[k] * e3, g, w);
     }
     w = M::max(FT(0), w);
     if (!GENERAL && rp > FT(kChenGammaRhoMax)) w = M::nan();       // outside the range of the fitted Γ: no silent extrapolation
@@ -133,7 +134,7 @@ static Vel1mConsts<FT> make_vel1m_consts(const MP &mp, const CH *chen, bool *che
         c.ch_rho0_l2e = (FT)((double)chen->rho_0 * 1.4426950408889634074);
         for (int k = 0; k < 3; ++k) { c.ch_a[k] = (FT)chen->a[k]; c.ch_b[k] = (FT)chen->b[k]; c.ch_c1000[k] = (FT)((double)chen->c[k] * 1000.0); }
         c.ch_a3_pow = (FT)chen->a3_pow; c.ch_b_rho = (FT)chen->b_rho;
-        const bool fit_ok = make_chen_gamma<FT>(*chen, c.chg);
+        const bool fit_ok = make_chen_gamma<FT>(*chen, c.chg, 3);
         if (chen_general) *chen_general = !fit_ok;
     } else if (chen_general) {
         *chen_general = false;

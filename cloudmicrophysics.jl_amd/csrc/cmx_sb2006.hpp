@@ -61,7 +61,7 @@ template <typename FT> struct SbConsts {
     FT vel_s, aR, bR, cR, rc2, e_rc2cR; // √ρ0(vel), …, 2·r_c, exp(−2 r_c c_R)
     // Chen-2022 rain velocity (Common.jl:290-302, 414-422)
     FT ch_rho0_l2e, ch_a[3], ch_a3_pow, ch_b[3], ch_b_rho, ch_c1000[3], l2_1000;
-    ChenGamma<FT> chg;
+    ChenGamma<FT> chg, chg3;   // Γ(b_i(ρ) + 1) and Γ(b_i(ρ) + 4)/3! as polynomials in ρ (cmx_math.hpp)
 };
 
 // The limited rain PSD clamps with v_med3 (clamp_ordered): every (min, max) pair of the limiters must be ordered and positive.
@@ -191,7 +191,8 @@ inline SbConsts<FT> make_sb_consts(const WR &wr, const TH &tp, const VL *vel, do
         c.ch_a3_pow = (FT)ch.a3_pow;
         c.ch_b_rho = (FT)ch.b_rho;
         c.l2_1000 = (FT)std::log2(1000.0);
-        (void)make_chen_gamma<FT>(ch, c.chg);   // the entry points test the fit themselves (chen_vel_kind)
+        (void)make_chen_gamma<FT>(ch, c.chg, 0);   // the entry points test the fits themselves (chen_vel_kind)
+        (void)make_chen_gamma<FT>(ch, c.chg3, 3);
     }
     return c;
 }
@@ -307,7 +308,8 @@ __device__ __forceinline__ void sb2006_rain_velocity(const C &c, FT rho, FT rs_r
             const FT e0 = M::exp2(l2_mag - l2_lam_inv - (bi + FT(1)) * l2_den);
             const FT e3 = M::exp2(l2_mag - FT(4) * l2_lam_inv - (bi + FT(4)) * l2_den);
             vt0 = M::fma(c.ch_a[i] * e0, g1, vt0);
-            vt3 = M::fma(c.ch_a[i] * e3, g1 * (bi + FT(3)) * (bi + FT(2)) * (bi + FT(1)) * FT(1.0 / 6.0), vt3);
+            const FT g4 = VEL == VEL_CHEN_GEN ? g1 * (bi + FT(3)) * (bi + FT(2)) * (bi + FT(1)) * FT(1.0 / 6.0) : chen_gamma_eval<FT>(c.chg3, i, rho_c);
+            vt3 = M::fma(c.ch_a[i] * e3, g4, vt3);
         }
         vt0 = M::max(FT(0), vt0);
         vt3 = M::max(FT(0), vt3);
@@ -320,7 +322,7 @@ __device__ __forceinline__ void sb2006_rain_velocity(const C &c, FT rho, FT rs_r
 // which Chen-2022 instantiation a parameter set takes (host): the fitted-Γ one, or the general one when the fit is not accurate
 template <typename FT, typename CH> inline int chen_vel_kind(const CH &ch) {
     ChenGamma<FT> g;
-    return make_chen_gamma<FT>(ch, g) ? VEL_CHEN : VEL_CHEN_GEN;
+    return make_chen_gamma<FT>(ch, g, 0) && make_chen_gamma<FT>(ch, g, 3) ? VEL_CHEN : VEL_CHEN_GEN;
 }
 
 // `n_lcl`, `n_rai` are per-kg numbers (BMT), `N_*` = ρ n_* per m³ (CM2).  No input clamping here:
