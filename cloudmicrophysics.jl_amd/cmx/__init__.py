@@ -17,7 +17,8 @@ from .bulk_tendencies import (Chen2022VelTypeRain, Microphysics2Moment, SB2006Pr
                               ColumnTendencies2M, column_tendencies_sedimentation)
 
 from .ice_nucleation import (IceNucleationRates, a_w_eT, a_w_ice, domain_error_count,  # noqa: F401
-                             ice_nucleation_rates, liquid_freezing_rate)
+                             ice_nucleation_rates, liquid_freezing_rate, h2so4_solution, mohler2006_deposition, MohlerDeposition, deposition_J,
+                             INP_concentration_frequency)
 
 from .microphysics1m import (Instantaneous, LinearizedAverage, Microphysics1Moment, SedimentationVelocities, SourceTerms1M, Tendencies1M,  # noqa: F401
                              TerminalVelocities1M, bulk_microphysics_tendencies_1m, bulk_microphysics_tendencies_1m_fields,
@@ -28,7 +29,7 @@ from .microphysics0m import (Microphysics0Moment, bulk_microphysics_tendencies_0
                              remove_precipitation)
 
 from .aerosol import (ActivationResult, AerosolDistribution, ModeColumns, Mode_B, Mode_kappa, aerosol_activation,  # noqa: F401
-                      aerosol_activation_columns)
+                      aerosol_activation_columns, total_activated)
 
 from .p3 import (P3Melt, P3Shape, P3ShapeVelocities, P3Velocities, p3_shape_and_terminal_velocities, p3_het_ice_nucleation, p3_ice_melt, p3_ice_self_collection, p3_liquid_ice_collisions,  # noqa: F401
                  p3_shape, p3_terminal_velocities)

@@ -78,6 +78,7 @@ SB2006_PROCESS_COLUMNS = (
     "evap_dN_rai_dt", "evap_dq_rai_dt",
     "numadj_rai", "numadj_lcl",
     "condevap",
+    "devap_dN_rai", "devap_dq_rai",
 )
 CMX_SB2006_NPROC = len(SB2006_PROCESS_COLUMNS)
 
@@ -177,6 +178,10 @@ def _family(ft, sfx):
     ns.parameters_0m = _struct(f"cmx_parameters_0m_{sfx}", s("tau_precip", "qc_0", "S_0"))
     ns.local_rime_density = _struct(f"cmx_local_rime_density_{sfx}", s("a", "b", "c", "rho_ice"))
     ns.rain_freezing = _struct(f"cmx_rain_freezing_{sfx}", s("het_a", "het_B"))
+    ns.mohler2006 = _struct(f"cmx_mohler2006_{sfx}", s("S_i_max", "T_thr"))
+    ns.mohler_dust = _struct(f"cmx_mohler_dust_{sfx}", s("S0_warm", "S0_cold", "a_warm", "a_cold"))
+    ns.deposition_dust = _struct(f"cmx_deposition_dust_{sfx}", s("deposition_m", "deposition_c"))
+    ns.h2so4_solution_params = _struct(f"cmx_h2so4_solution_params_{sfx}", s("T_max", "T_min", "w_2", "c1", "c2", "c3", "c4", "c5", "c6", "c7"))
     ns.morrison_milbrandt2014 = _struct(f"cmx_morrison_milbrandt2014_{sfx}", s("T_dep_thres", "c1", "c2", "T0", "het_a", "het_B"))
     ns.p3_ice_params = _struct(f"cmx_p3_ice_params_{sfx}", [
         ("scheme", ns.p3_params), ("vent", ns.ventilation), ("rho_rim_local", ns.local_rime_density),

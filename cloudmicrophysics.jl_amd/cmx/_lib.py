@@ -56,6 +56,26 @@ def _declare(lib):
         f = getattr(lib, f"cmx_water_activity_{s}")
         f.restype = i32
         f.argtypes = [C.POINTER(fam.thermo), i64] + [vp] * 4 + [vp]
+        f = getattr(lib, f"cmx_ice_nucleation_rates_xT_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.thermo), C.POINTER(fam.abifm_dust), C.POINTER(fam.koop2000), C.POINTER(fam.h2so4_solution_params), u32, i64] + [vp] * 8 \
+            + [vp, vp]
+        f = getattr(lib, f"cmx_h2so4_solution_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.h2so4_solution_params), C.POINTER(fam.thermo), i64] + [vp] * 4 + [vp]
+        f = getattr(lib, f"cmx_mohler2006_deposition_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.mohler_dust), C.POINTER(fam.mohler2006), i64] + [vp] * 7 + [vp]
+        f = getattr(lib, f"cmx_deposition_J_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.deposition_dust), i64, vp, vp, vp]
+        f = getattr(lib, f"cmx_inp_concentration_frequency_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.frostenberg2023), i64, vp, vp, vp, vp]
+        f = getattr(lib, f"cmx_arg2000_total_activated_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.aerosol_activation_params), C.POINTER(fam.aerosol_distribution), C.POINTER(fam.air_properties),
+                      C.POINTER(fam.thermo), i64] + [vp] * 8 + [vp, vp, vp]
         f = getattr(lib, f"cmx_mp0m_tendencies_{s}")
         f.restype = i32
         f.argtypes = [C.POINTER(fam.parameters_0m), i64] + [vp] * 5 + [vp]

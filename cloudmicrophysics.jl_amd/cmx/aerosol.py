@@ -115,6 +115,27 @@ def aerosol_activation(ap, ad: AerosolDistribution, aip, tps, T, p, w, q_tot, q_
     return ActivationResult(n_act, m_act, s_max)
 
 
+def total_activated(ap, ad: AerosolDistribution, aip, tps, T, p, w, q_tot, q_liq=None, q_ice=None, N_liq=None, N_ice=None, *,
+                    want=("N", "M"), stream=None):
+    """(AA.total_N_activated.(…), AA.total_M_activated.(…)) — src/AerosolActivation.jl:355-433: the sums over the modes, formed in the
+    activation kernel (`cmx_arg2000_total_activated_*`).  `want` ⊆ {"N", "M"}; the other member of the result is None."""
+    cols = [c for c in (T, p, w, q_tot, q_liq, q_ice, N_liq, N_ice) if c is not None]
+    ref = _check_cols(cols, ["T", "p", "w", "q_tot", "q_liq", "q_ice", "N_liq", "N_ice"])
+    fam = _fam_of(ref)
+    if not (isinstance(ap, fam.aerosol_activation_params) and isinstance(aip, fam.air_properties) and isinstance(tps, fam.thermo)):
+        raise TypeError("parameter float type does not match the state columns")
+    adc = ad.c_struct(ap, fam)
+    n_tot = torch.empty_like(ref) if "N" in want else None
+    m_tot = torch.empty_like(ref) if "M" in want else None
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_arg2000_total_activated_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(ap), C.byref(adc), C.byref(aip), C.byref(tps), ref.numel(), _ptr(T), _ptr(p), _ptr(w), _ptr(q_tot),
+                _ptr(q_liq), _ptr(q_ice), _ptr(N_liq), _ptr(N_ice), _ptr(n_tot), _ptr(m_tot), C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return n_tot, m_tot
+
+
 ModeColumns = namedtuple("ModeColumns", ["r_dry", "stdev", "N", "hygroscopicity", "molar_mass_mix"], defaults=(None,))
 ModeColumns.__doc__ = """One aerosol mode whose descriptors vary in space: device columns r_dry [m], stdev, N [1/m³], the mode's mean
 hygroscopicity (B̄ of Mode_B or κ̄ of Mode_κ: `Mode_B.hygroscopicity` / `Mode_kappa.hygroscopicity` work elementwise on

@@ -148,6 +148,7 @@ template <> __device__ __forceinline__ double erfc_rel_dev<double>(double x) { r
 template <typename FT> struct ArgIO {
     const FT *T, *p, *w, *q_tot, *q_liq, *q_ice, *N_liq, *N_ice;
     FT *N_act[CMX_ARG_MAX_MODES], *M_act[CMX_ARG_MAX_MODES], *S_max;
+    FT *N_tot, *M_tot;   // total_N_activated / total_M_activated: Σ over the modes, left to right like Julia's sum of the tuple (AA:355-433)
     bool want_N, want_M;
 };
 
@@ -288,6 +289,28 @@ __global__ __launch_bounds__(kArgBS) void arg_activation_kernel(const ArgConsts<
             if (io.want_M && io.M_act[j]) store_col<FT, VEC>(io.M_act[j], i, ma[j]);
         }
     }
+    if (io.N_tot) {
+        FT t[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            t[k] = na[0][k];
+#pragma unroll
+            for (int j = 1; j < NM; ++j) t[k] += na[j][k];
+        }
+        store_col<FT, VEC>(io.N_tot, i, t);
+    }
+    if constexpr (!N_ONLY) {
+        if (io.M_tot) {
+            FT t[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                t[k] = ma[0][k];
+#pragma unroll
+                for (int j = 1; j < NM; ++j) t[k] += ma[j][k];
+            }
+            store_col<FT, VEC>(io.M_tot, i, t);
+        }
+    }
 }
 
 template <typename FT, int NM, bool SINKS>
@@ -304,7 +327,7 @@ static void launch_arg(const ArgConsts<FT> &c, const ArgIO<FT> &io0, int64_t n, 
         ArgIO<FT> io = io0;
         io.T += lo; io.p += lo; io.w += lo; io.q_tot += lo;
         io.q_liq = off(io.q_liq, lo); io.q_ice = off(io.q_ice, lo); io.N_liq = off(io.N_liq, lo); io.N_ice = off(io.N_ice, lo);
-        io.S_max = off(io.S_max, lo);
+        io.S_max = off(io.S_max, lo); io.N_tot = off(io.N_tot, lo); io.M_tot = off(io.M_tot, lo);
         for (int j = 0; j < CMX_ARG_MAX_MODES; ++j) { io.N_act[j] = off(io.N_act[j], lo); io.M_act[j] = off(io.M_act[j], lo); }
         const int64_t nv = count / V;
         const dim3 grid((unsigned)((nv + kArgBS - 1) / kArgBS));
@@ -325,7 +348,7 @@ static void launch_arg(const ArgConsts<FT> &c, const ArgIO<FT> &io0, int64_t n, 
 template <typename FT, typename AP, typename AD, typename AI, typename TH>
 static int32_t arg_entry(const AP *ap, const AD *ad, const AI *aip, const TH *tps, int64_t n, const FT *T, const FT *p,
                          const FT *w, const FT *q_tot, const FT *q_liq, const FT *q_ice, const FT *N_liq, const FT *N_ice,
-                         FT *const *N_act, FT *const *M_act, FT *S_max, void *stream) {
+                         FT *const *N_act, FT *const *M_act, FT *S_max, void *stream, FT *N_tot = nullptr, FT *M_tot = nullptr) {
     if (!ap || !ad || !aip || !tps || n < 0 || ad->n_modes < 1 || ad->n_modes > CMX_ARG_MAX_MODES) return CMX_ERR_BAD_ARG;
     if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (n == 0) return CMX_OK;
@@ -333,9 +356,10 @@ static int32_t arg_entry(const AP *ap, const AD *ad, const AI *aip, const TH *tp
     const ArgConsts<FT> c = make_arg_consts<FT>(*ap, *ad, *aip, *tps);
     ArgIO<FT> io{};
     io.T = T; io.p = p; io.w = w; io.q_tot = q_tot; io.q_liq = q_liq; io.q_ice = q_ice; io.N_liq = N_liq; io.N_ice = N_ice;
-    io.S_max = S_max; io.want_N = N_act != nullptr; io.want_M = M_act != nullptr;
-    const void *ptrs[8 + 2 * CMX_ARG_MAX_MODES + 1] = {T, p, w, q_tot, q_liq, q_ice, N_liq, N_ice, S_max};
-    int np = 9;
+    io.S_max = S_max; io.want_N = N_act != nullptr || N_tot != nullptr; io.want_M = M_act != nullptr || M_tot != nullptr;
+    io.N_tot = N_tot; io.M_tot = M_tot;
+    const void *ptrs[8 + 2 * CMX_ARG_MAX_MODES + 3] = {T, p, w, q_tot, q_liq, q_ice, N_liq, N_ice, S_max, N_tot, M_tot};
+    int np = 11;
     for (int j = 0; j < ad->n_modes; ++j) {
         io.N_act[j] = N_act ? N_act[j] : nullptr;
         io.M_act[j] = M_act ? M_act[j] : nullptr;
@@ -494,6 +518,22 @@ int32_t cmx_arg2000_activation_columns_f64(const cmx_aerosol_activation_params_f
                                            void *stream) {
     return cmx::arg_columns_entry<double>(ap, aip, tps, n_modes, n, T, p, w, q_tot, q_liq, q_ice, N_liq, N_ice, r_dry, stdev, N_mode,
                                           hygroscopicity, molar_mass, N_act, M_act, S_max, stream);
+}
+
+// AA.total_N_activated / total_M_activated — src/AerosolActivation.jl:355-433: Σ over the modes, formed in the activation kernel itself
+int32_t cmx_arg2000_total_activated_f32(const cmx_aerosol_activation_params_f32 *ap, const cmx_aerosol_distribution_f32 *ad,
+                                        const cmx_air_properties_f32 *aip, const cmx_thermo_f32 *tps, int64_t n, const float *T, const float *p,
+                                        const float *w, const float *q_tot, const float *q_liq, const float *q_ice, const float *N_liq,
+                                        const float *N_ice, float *N_total, float *M_total, void *stream) {
+    if (!N_total && !M_total) return CMX_ERR_BAD_ARG;
+    return cmx::arg_entry<float>(ap, ad, aip, tps, n, T, p, w, q_tot, q_liq, q_ice, N_liq, N_ice, nullptr, nullptr, nullptr, stream, N_total, M_total);
+}
+int32_t cmx_arg2000_total_activated_f64(const cmx_aerosol_activation_params_f64 *ap, const cmx_aerosol_distribution_f64 *ad,
+                                        const cmx_air_properties_f64 *aip, const cmx_thermo_f64 *tps, int64_t n, const double *T, const double *p,
+                                        const double *w, const double *q_tot, const double *q_liq, const double *q_ice, const double *N_liq,
+                                        const double *N_ice, double *N_total, double *M_total, void *stream) {
+    if (!N_total && !M_total) return CMX_ERR_BAD_ARG;
+    return cmx::arg_entry<double>(ap, ad, aip, tps, n, T, p, w, q_tot, q_liq, q_ice, N_liq, N_ice, nullptr, nullptr, nullptr, stream, N_total, M_total);
 }
 
 }  // extern "C"

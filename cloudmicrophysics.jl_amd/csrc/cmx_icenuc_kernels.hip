@@ -35,7 +35,31 @@ template <typename FT> struct IceNucConsts {
     FT lin_c1_l2, lin_c2_l2;          // (linear_c2 Δ + linear_c1 + 6)·log2(10)
     FT d_min, d_max;
     FT l2_four_pi, l2_four_thirds_pi;
+    // H2SO4 solution (Common.jl:188-220): log2 p_sol[Pa] = hp1(x) + hp2(x)/T,  hp1 = Σ hp1[m] x^m (m ≤ 3), hp2 = Σ hp2[m] x^m (m ≤ 2)
+    FT hp1[4], hp2[3];
 };
+
+template <typename FT, typename HS> static void add_h2so4_consts(IceNucConsts<FT> &c, const HS &h) {
+    const double l2e = 1.4426950408889634074, w2 = h.w_2;
+    c.hp1[0] = (FT)((double)h.c1 * l2e + std::log2(100.0));   // ·100: mbar → Pa
+    c.hp1[1] = (FT)(-(double)h.c2 * l2e);
+    c.hp1[2] = (FT)((double)h.c3 * w2 * l2e);                  // c3 x w_h, w_h = w_2 x
+    c.hp1[3] = (FT)(-(double)h.c4 * w2 * w2 * l2e);            // −c4 x w_h²
+    c.hp2[0] = (FT)((double)h.c5 * l2e);
+    c.hp2[1] = (FT)((double)h.c6 * l2e);
+    c.hp2[2] = (FT)(-(double)h.c7 * w2 * l2e);                 // −c7 x w_h
+}
+// log2 of CO.H2SO4_soln_saturation_vapor_pressure(prs, x, T) [Pa]
+template <typename FT> __device__ __forceinline__ FT l2_p_sol_dev(const IceNucConsts<FT> &c, FT x, FT inv_T) {
+    using M = Math<FT>;
+    const FT p1 = M::fma(M::fma(M::fma(c.hp1[3], x, c.hp1[2]), x, c.hp1[1]), x, c.hp1[0]);
+    const FT p2 = M::fma(M::fma(c.hp2[2], x, c.hp2[1]), x, c.hp2[0]);
+    return M::fma(p2, inv_T, p1);
+}
+template <typename FT> __device__ __forceinline__ FT l2_p_sat_liq_dev(const IceNucConsts<FT> &c, FT T, FT inv_T) {
+    using M = Math<FT>;
+    return M::fma(c.ps_a, M::log2(T * c.inv_T_tr), M::fma(c.ps_b, c.inv_T_tr - inv_T, c.ps_c0));
+}
 
 template <typename FT, typename TH, typename DU, typename KO>
 static IceNucConsts<FT> make_icenuc_consts(const TH &tp, const DU *dust, const KO *koop) {
@@ -81,7 +105,9 @@ template <typename FT> __device__ __forceinline__ FT a_w_ice_dev(const IceNucCon
 
 // RATES_ONLY: only the per-droplet rates J·4πr² / J·4⁄3πr³ are requested (the BASELINE configuration): the two exp2 for the bare
 // rate coefficients are then dead code — as a compile-time fact (with run-time nullable pointers they are always evaluated)
-template <typename FT, bool LINEAR, int VEC, bool RATES_ONLY = false>
+// FROM_X: the second input column is the H2SO4 weight fraction x of the solution droplets and a_w = CO.a_w_xT(prs, tps, x, T) is formed here
+// (cmx_ice_nucleation_rates_xT_*: config 4 as the parcel model drives it, parcel/ParcelTendencies.jl:120-133)
+template <typename FT, bool LINEAR, int VEC, bool RATES_ONLY = false, bool FROM_X = false>
 __global__ __launch_bounds__(kBlock) void ice_nucleation_kernel(const IceNucConsts<FT> c, const IceNucIO<FT> io,
                                                                 const int64_t nvec) {
     using M = Math<FT>;
@@ -101,6 +127,7 @@ __global__ __launch_bounds__(kBlock) void ice_nucleation_kernel(const IceNucCons
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             const FT inv_T = M::rcp(T[k]);
+            if constexpr (FROM_X) aw[k] = M::exp2(l2_p_sol_dev<FT>(c, aw[k], inv_T) - l2_p_sat_liq_dev<FT>(c, T[k], inv_T));   // a_w_xT  Common.jl:235-246
             d[k] = aw[k] - a_w_ice_dev<FT>(c, T[k], inv_T);                        // Δa_w
             const FT l2_jh = M::fma(c.abifm_m_l2, d[k], c.abifm_c_l2);            // ABIFM_J  IceNucleation.jl:124-134
             FT l2_jo;
@@ -166,15 +193,16 @@ __global__ __launch_bounds__(kBlock) void water_activity_kernel(const IceNucCons
     }
 }
 
-template <typename FT, typename TH, typename DU, typename KO>
-static int32_t icenuc_entry(const TH *tps, const DU *dust, const KO *koop, uint32_t flags, int64_t n, const FT *T,
+template <typename FT, typename TH, typename DU, typename KO, typename HS>
+static int32_t icenuc_entry(const TH *tps, const DU *dust, const KO *koop, const HS *h2so4, bool from_x, uint32_t flags, int64_t n, const FT *T,
                             const FT *a_w, const FT *r, FT *delta_a_w, FT *J_het, FT *J_hom, FT *rate_het, FT *rate_hom,
                             int64_t *n_domain_errors, void *stream) {
-    if (!tps || !dust || !koop || n < 0 || (flags & ~CMX_ICENUC_HOM_LINEAR)) return CMX_ERR_BAD_ARG;
+    if (!tps || !dust || !koop || n < 0 || (flags & ~CMX_ICENUC_HOM_LINEAR) || (from_x && !h2so4)) return CMX_ERR_BAD_ARG;
     if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (n == 0) return CMX_OK;
     if (!T || !a_w || ((rate_het || rate_hom) && !r)) return CMX_ERR_BAD_ARG;
-    const IceNucConsts<FT> c = make_icenuc_consts<FT>(*tps, dust, koop);
+    IceNucConsts<FT> c = make_icenuc_consts<FT>(*tps, dust, koop);
+    if (from_x) add_h2so4_consts<FT>(c, *h2so4);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     constexpr int VEC = Math<FT>::VEC;
     const void *ptrs[] = {T, a_w, r, delta_a_w, J_het, J_hom, rate_het, rate_hom};
@@ -192,7 +220,10 @@ static int32_t icenuc_entry(const TH *tps, const DU *dust, const KO *koop, uint3
         const int64_t nv = count / V;
         const unsigned grid = (unsigned)((nv + kBlock - 1) / kBlock);
         const bool rates_only = !delta_a_w && !J_het && !J_hom && rate_het && rate_hom;
-        if (rates_only) {
+        if (from_x) {   // the solution-droplet input mode: one instantiation per homogeneous-rate form
+            if (linear) hipLaunchKernelGGL((ice_nucleation_kernel<FT, true, V, false, true>), dim3(grid), dim3(kBlock), 0, s, c, io, nv);
+            else hipLaunchKernelGGL((ice_nucleation_kernel<FT, false, V, false, true>), dim3(grid), dim3(kBlock), 0, s, c, io, nv);
+        } else if (rates_only) {
             if (linear) hipLaunchKernelGGL((ice_nucleation_kernel<FT, true, V, true>), dim3(grid), dim3(kBlock), 0, s, c, io, nv);
             else hipLaunchKernelGGL((ice_nucleation_kernel<FT, false, V, true>), dim3(grid), dim3(kBlock), 0, s, c, io, nv);
         } else if (linear) hipLaunchKernelGGL((ice_nucleation_kernel<FT, true, V>), dim3(grid), dim3(kBlock), 0, s, c, io, nv);
@@ -260,6 +291,132 @@ static int32_t p3_het_nucleation_entry(const DU *dust, const TH *tps, int64_t n,
     return CMX_OK;
 }
 
+// ---- round 3: the remaining public functions of the subsystems this library replaces (VERDICT r02 row g) ------------------------------
+// One point per lane; each is a handful of instructions per point.
+
+// CO.H2SO4_soln_saturation_vapor_pressure / CO.a_w_xT — Common.jl:188-246
+template <typename FT>
+__global__ __launch_bounds__(kBlock) void h2so4_solution_kernel(const IceNucConsts<FT> c, const FT *__restrict__ x, const FT *__restrict__ T,
+                                                               FT *__restrict__ p_sol, FT *__restrict__ a_w, const int64_t n) {
+    Math<FT>::prepare();
+    using M = Math<FT>;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const FT Ti = T[i], inv_T = M::rcp(Ti);
+    const FT l2p = l2_p_sol_dev<FT>(c, x[i], inv_T);
+    if (p_sol) p_sol[i] = M::exp2(l2p);
+    if (a_w) a_w[i] = M::exp2(l2p - l2_p_sat_liq_dev<FT>(c, Ti, inv_T));
+}
+
+// CMI_het.dust_activated_number_fraction / MohlerDepositionRate — IceNucleation.jl:44-79
+template <typename FT> struct MohlerConsts { FT S_i_max, T_thr, S0_warm, S0_cold, a_warm_l2e, a_cold_l2e, a_warm, a_cold; };
+template <typename FT>
+__global__ __launch_bounds__(kBlock) void mohler_deposition_kernel(const MohlerConsts<FT> c, const FT *__restrict__ S_i, const FT *__restrict__ T,
+                                                                  const FT *__restrict__ dSi_dt, const FT *__restrict__ N_aer,
+                                                                  FT *__restrict__ act_frac, FT *__restrict__ dep_rate,
+                                                                  unsigned long long *__restrict__ n_err, const int64_t n) {
+    Math<FT>::prepare();
+    using M = Math<FT>;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    bool bad = false;
+    if (i < n) {
+        const FT Si = S_i[i];
+        const bool warm = T[i] > c.T_thr;
+        bad = !(Si < c.S_i_max);                                  // the reference's @assert Si < ip.Sᵢ_max
+        if (act_frac) {
+            const FT f = M::max(FT(0), M::exp2((warm ? c.a_warm_l2e : c.a_cold_l2e) * (Si - (warm ? c.S0_warm : c.S0_cold))) - FT(1));
+            act_frac[i] = bad ? M::nan() : f;
+        }
+        if (dep_rate) {
+            const FT rate = M::max(FT(0), N_aer[i] * (warm ? c.a_warm : c.a_cold) * dSi_dt[i]);
+            dep_rate[i] = bad ? M::nan() : rate;
+        }
+    }
+    if (n_err) {   // wave-uniform; one atomic per wave that holds a domain error (rare)
+        const unsigned long long m = __ballot(bad);
+        if (m && (threadIdx.x & 63) == 0) atomicAdd(n_err, (unsigned long long)__popcll(m));
+    }
+}
+
+// CMI_het.deposition_J — IceNucleation.jl:81-102
+template <typename FT>
+__global__ __launch_bounds__(kBlock) void deposition_J_kernel(const FT m_l2, const FT c_l2, const FT *__restrict__ d, FT *__restrict__ J, const int64_t n) {
+    Math<FT>::prepare();
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) J[i] = Math<FT>::exp2(Math<FT>::fma(m_l2, d[i], c_l2));
+}
+
+// CMI_het.INP_concentration_frequency — IceNucleation.jl:219-226 with INP_concentration_mean :250-253
+template <typename FT> struct InpFreqConsts { FT T_freeze, b10, log_a, ln2, inv_2s2_l2e, inv_norm; };
+template <typename FT>
+__global__ __launch_bounds__(kBlock) void inp_frequency_kernel(const InpFreqConsts<FT> c, const FT *__restrict__ INPC, const FT *__restrict__ T,
+                                                              FT *__restrict__ freq, const int64_t n) {
+    Math<FT>::prepare();
+    using M = Math<FT>;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const FT Ti = T[i];
+    const FT Tc = M::min(Ti - c.T_freeze, FT(0));
+    const FT mu = M::fma(FT(9) * c.ln2, M::log2(-(c.b10 * Tc)), -c.log_a);          // 9 log(−b T_c/10) − log a
+    const FT dl = M::fma(c.ln2, M::log2(INPC[i]), -mu);                              // log(INPC) − μ
+    const FT f = M::exp2(-(dl * dl) * c.inv_2s2_l2e) * c.inv_norm;                   // exp(−(…)²/2σ²)/√(2πσ²)
+    freq[i] = Ti >= c.T_freeze ? FT(0) : f;
+}
+
+template <typename FT, typename HS, typename TH>
+static int32_t h2so4_entry(const HS *prs, const TH *tps, int64_t n, const FT *x, const FT *T, FT *p_sol, FT *a_w, void *stream) {
+    if (!prs || n < 0 || (a_w && !tps) || (!p_sol && !a_w)) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;
+    if (n == 0) return CMX_OK;
+    if (!x || !T) return CMX_ERR_BAD_ARG;
+    IceNucConsts<FT> c{};
+    if (tps) c = make_icenuc_consts<FT>(*tps, (const cmx_abifm_dust_f64 *)nullptr, (const cmx_koop2000_f64 *)nullptr);
+    add_h2so4_consts<FT>(c, *prs);
+    hipLaunchKernelGGL((h2so4_solution_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), c,
+                       x, T, p_sol, a_w, n);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+template <typename FT, typename DU, typename IP>
+static int32_t mohler_entry(const DU *dust, const IP *ip, int64_t n, const FT *S_i, const FT *T, const FT *dSi_dt, const FT *N_aer, FT *act_frac,
+                            FT *dep_rate, int64_t *n_err, void *stream) {
+    if (!dust || !ip || n < 0 || (!act_frac && !dep_rate)) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;
+    if (n == 0) return CMX_OK;
+    if (!S_i || !T || (dep_rate && (!dSi_dt || !N_aer))) return CMX_ERR_BAD_ARG;
+    const double l2e = 1.4426950408889634074;
+    const MohlerConsts<FT> c{(FT)ip->S_i_max, (FT)ip->T_thr, (FT)dust->S0_warm, (FT)dust->S0_cold, (FT)((double)dust->a_warm * l2e),
+                             (FT)((double)dust->a_cold * l2e), (FT)dust->a_warm, (FT)dust->a_cold};
+    hipLaunchKernelGGL((mohler_deposition_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream),
+                       c, S_i, T, dSi_dt, N_aer, act_frac, dep_rate, reinterpret_cast<unsigned long long *>(n_err), n);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+template <typename FT, typename DU> static int32_t deposition_J_entry(const DU *dust, int64_t n, const FT *d, FT *J, void *stream) {
+    if (!dust || n < 0) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;
+    if (n == 0) return CMX_OK;
+    if (!d || !J) return CMX_ERR_BAD_ARG;
+    const double l2_10 = 3.3219280948873623479;
+    hipLaunchKernelGGL((deposition_J_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream),
+                       (FT)((double)dust->deposition_m * l2_10), (FT)(((double)dust->deposition_c + 4.0) * l2_10), d, J, n);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+template <typename FT, typename IP> static int32_t inp_frequency_entry(const IP *ip, int64_t n, const FT *INPC, const FT *T, FT *freq, void *stream) {
+    if (!ip || n < 0) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;
+    if (n == 0) return CMX_OK;
+    if (!INPC || !T || !freq) return CMX_ERR_BAD_ARG;
+    const double l2e = 1.4426950408889634074, pi = 3.14159265358979323846, two_s2 = 2.0 * (double)ip->sigma * (double)ip->sigma;
+    const InpFreqConsts<FT> c{(FT)ip->T_freeze, (FT)((double)ip->b / 10.0), (FT)ip->log_a, (FT)0.69314718055994530942, (FT)(l2e / two_s2),
+                              (FT)(1.0 / std::sqrt(pi * two_s2))};
+    hipLaunchKernelGGL((inp_frequency_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), c,
+                       INPC, T, freq, n);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+
 }  // namespace cmx
 
 extern "C" {
@@ -268,15 +425,15 @@ int32_t cmx_ice_nucleation_rates_f32(const cmx_thermo_f32 *tps, const cmx_abifm_
                                      uint32_t flags, int64_t n, const float *T, const float *a_w, const float *r,
                                      float *delta_a_w, float *J_het, float *J_hom, float *rate_het, float *rate_hom,
                                      int64_t *n_domain_errors, void *stream) {
-    return cmx::icenuc_entry<float>(tps, dust, koop, flags, n, T, a_w, r, delta_a_w, J_het, J_hom, rate_het, rate_hom,
-                                    n_domain_errors, stream);
+    return cmx::icenuc_entry<float>(tps, dust, koop, (const cmx_h2so4_solution_params_f32 *)nullptr, false, flags, n, T, a_w, r, delta_a_w, J_het, J_hom,
+                                    rate_het, rate_hom, n_domain_errors, stream);
 }
 int32_t cmx_ice_nucleation_rates_f64(const cmx_thermo_f64 *tps, const cmx_abifm_dust_f64 *dust, const cmx_koop2000_f64 *koop,
                                      uint32_t flags, int64_t n, const double *T, const double *a_w, const double *r,
                                      double *delta_a_w, double *J_het, double *J_hom, double *rate_het, double *rate_hom,
                                      int64_t *n_domain_errors, void *stream) {
-    return cmx::icenuc_entry<double>(tps, dust, koop, flags, n, T, a_w, r, delta_a_w, J_het, J_hom, rate_het, rate_hom,
-                                     n_domain_errors, stream);
+    return cmx::icenuc_entry<double>(tps, dust, koop, (const cmx_h2so4_solution_params_f64 *)nullptr, false, flags, n, T, a_w, r, delta_a_w, J_het, J_hom,
+                                     rate_het, rate_hom, n_domain_errors, stream);
 }
 int32_t cmx_water_activity_f32(const cmx_thermo_f32 *tps, int64_t n, const float *T, const float *e, float *a_w_ice,
                                float *a_w_eT, void *stream) {
@@ -296,6 +453,49 @@ int32_t cmx_p3_het_ice_nucleation_f64(const cmx_abifm_dust_f64 *dust, const cmx_
                                       const double *N_lcl, const double *RH, const double *T, const double *rho_air, double *dNdt,
                                       double *dLdt, void *stream) {
     return cmx::p3_het_nucleation_entry<double>(dust, tps, n, q_lcl, N_lcl, RH, T, rho_air, dNdt, dLdt, stream);
+}
+
+int32_t cmx_ice_nucleation_rates_xT_f32(const cmx_thermo_f32 *tps, const cmx_abifm_dust_f32 *dust, const cmx_koop2000_f32 *koop,
+                                        const cmx_h2so4_solution_params_f32 *h2so4, uint32_t flags, int64_t n, const float *T, const float *x_sulph,
+                                        const float *r, float *delta_a_w, float *J_het, float *J_hom, float *rate_het, float *rate_hom,
+                                        int64_t *n_domain_errors, void *stream) {
+    return cmx::icenuc_entry<float>(tps, dust, koop, h2so4, true, flags, n, T, x_sulph, r, delta_a_w, J_het, J_hom, rate_het, rate_hom, n_domain_errors, stream);
+}
+int32_t cmx_ice_nucleation_rates_xT_f64(const cmx_thermo_f64 *tps, const cmx_abifm_dust_f64 *dust, const cmx_koop2000_f64 *koop,
+                                        const cmx_h2so4_solution_params_f64 *h2so4, uint32_t flags, int64_t n, const double *T, const double *x_sulph,
+                                        const double *r, double *delta_a_w, double *J_het, double *J_hom, double *rate_het, double *rate_hom,
+                                        int64_t *n_domain_errors, void *stream) {
+    return cmx::icenuc_entry<double>(tps, dust, koop, h2so4, true, flags, n, T, x_sulph, r, delta_a_w, J_het, J_hom, rate_het, rate_hom, n_domain_errors, stream);
+}
+int32_t cmx_h2so4_solution_f32(const cmx_h2so4_solution_params_f32 *prs, const cmx_thermo_f32 *tps, int64_t n, const float *x_sulph, const float *T,
+                               float *p_sol, float *a_w, void *stream) {
+    return cmx::h2so4_entry<float>(prs, tps, n, x_sulph, T, p_sol, a_w, stream);
+}
+int32_t cmx_h2so4_solution_f64(const cmx_h2so4_solution_params_f64 *prs, const cmx_thermo_f64 *tps, int64_t n, const double *x_sulph, const double *T,
+                               double *p_sol, double *a_w, void *stream) {
+    return cmx::h2so4_entry<double>(prs, tps, n, x_sulph, T, p_sol, a_w, stream);
+}
+int32_t cmx_mohler2006_deposition_f32(const cmx_mohler_dust_f32 *dust, const cmx_mohler2006_f32 *ip, int64_t n, const float *S_i, const float *T,
+                                      const float *dSi_dt, const float *N_aer, float *act_frac, float *dep_rate, int64_t *n_domain_errors,
+                                      void *stream) {
+    return cmx::mohler_entry<float>(dust, ip, n, S_i, T, dSi_dt, N_aer, act_frac, dep_rate, n_domain_errors, stream);
+}
+int32_t cmx_mohler2006_deposition_f64(const cmx_mohler_dust_f64 *dust, const cmx_mohler2006_f64 *ip, int64_t n, const double *S_i, const double *T,
+                                      const double *dSi_dt, const double *N_aer, double *act_frac, double *dep_rate, int64_t *n_domain_errors,
+                                      void *stream) {
+    return cmx::mohler_entry<double>(dust, ip, n, S_i, T, dSi_dt, N_aer, act_frac, dep_rate, n_domain_errors, stream);
+}
+int32_t cmx_deposition_J_f32(const cmx_deposition_dust_f32 *dust, int64_t n, const float *delta_a_w, float *J, void *stream) {
+    return cmx::deposition_J_entry<float>(dust, n, delta_a_w, J, stream);
+}
+int32_t cmx_deposition_J_f64(const cmx_deposition_dust_f64 *dust, int64_t n, const double *delta_a_w, double *J, void *stream) {
+    return cmx::deposition_J_entry<double>(dust, n, delta_a_w, J, stream);
+}
+int32_t cmx_inp_concentration_frequency_f32(const cmx_frostenberg2023_f32 *ip, int64_t n, const float *INPC, const float *T, float *freq, void *stream) {
+    return cmx::inp_frequency_entry<float>(ip, n, INPC, T, freq, stream);
+}
+int32_t cmx_inp_concentration_frequency_f64(const cmx_frostenberg2023_f64 *ip, int64_t n, const double *INPC, const double *T, double *freq, void *stream) {
+    return cmx::inp_frequency_entry<double>(ip, n, INPC, T, freq, stream);
 }
 
 }  // extern "C"

@@ -155,6 +155,9 @@ __global__ __launch_bounds__(kBlock) void sb2006_process_kernel(const SbConsts<F
         CMX_PUT(CMX_SB_NUMADJ_RAI, p.na_rai);
         CMX_PUT(CMX_SB_NUMADJ_LCL, p.na_lcl);
         CMX_PUT(CMX_SB_CONDEVAP, p.cond);
+        // ∂rain_evaporation_∂N_rai_∂q_rai — CM2:844-855: the evaporation tendencies over N_rai / q_rai above ϵ, 0 otherwise
+        CMX_PUT(CMX_SB_DEVAP_DN_RAI, N_rai[i] > M::eps() ? p.evN * M::rcp(N_rai[i]) : FT(0));
+        CMX_PUT(CMX_SB_DEVAP_DQ_RAI, q_rai[i] > M::eps() ? p.evq * M::rcp(q_rai[i]) : FT(0));
 #undef CMX_PUT
     }
 }

@@ -168,6 +168,15 @@ typedef enum cmx_status {
     /* the two ABIFM fields of a dust type (Kaolinite, Illite, DesertDust, …:                */ \
     /* src/parameters/AerosolKaolinite.jl:19-21 etc.): log10 J = m·Δa_w + c  [cm⁻² s⁻¹]      */ \
     typedef struct cmx_abifm_dust_##SFX { FT ABIFM_m, ABIFM_c; } cmx_abifm_dust_##SFX;          \
+    /* Mohler2006 (Sᵢ_max, T_thr) — src/parameters/IceNucleation.jl:13-18; the four deposition fields of DesertDust /       */ \
+    /* ArizonaTestDust (S₀_warm, S₀_cold, a_warm, a_cold) — src/parameters/AerosolDesertDust.jl:13-21, AerosolATD.jl:12-20   */ \
+    typedef struct cmx_mohler2006_##SFX { FT S_i_max, T_thr; } cmx_mohler2006_##SFX;           \
+    typedef struct cmx_mohler_dust_##SFX { FT S0_warm, S0_cold, a_warm, a_cold; } cmx_mohler_dust_##SFX; \
+    /* the two deposition fields of a mineral (Kaolinite, Feldspar, Ferrihydrite, …: src/parameters/AerosolKaolinite.jl etc.): */ \
+    /* log10 J = m·Δa_w + c  [cm⁻² s⁻¹]                                                                                   */ \
+    typedef struct cmx_deposition_dust_##SFX { FT deposition_m, deposition_c; } cmx_deposition_dust_##SFX; \
+    /* H2SO4SolutionParameters — src/parameters/Aerosol_H2SO4_Solution.jl (Luo et al. 1995) */  \
+    typedef struct cmx_h2so4_solution_params_##SFX { FT T_max, T_min, w_2, c1, c2, c3, c4, c5, c6, c7; } cmx_h2so4_solution_params_##SFX; \
     /* ---- 1-moment scheme: src/parameters/Microphysics1M.jl ---------------------------- */   \
     /* ParticleMass — m(r) = m0 χm (r/r0)^(me+Δm); gamma_coeff = Γ(me+Δm+1) host-derived */     \
     typedef struct cmx_particle_mass_##SFX { FT r0, m0, me, delta_m, chi_m, gamma_coeff; }     \
@@ -316,6 +325,10 @@ CMX_DECLARE_PARAM_STRUCTS(double, f64)
 #endif
 #define CMX_ASSERT_PARAM_STRUCT_SIZES(FT, SFX) \
     CMX_STATIC_ASSERT(sizeof(cmx_abifm_dust_##SFX) == 2 * sizeof(FT), "cmx_abifm_dust");\
+    CMX_STATIC_ASSERT(sizeof(cmx_mohler2006_##SFX) == 2 * sizeof(FT), "cmx_mohler2006");\
+    CMX_STATIC_ASSERT(sizeof(cmx_mohler_dust_##SFX) == 4 * sizeof(FT), "cmx_mohler_dust");\
+    CMX_STATIC_ASSERT(sizeof(cmx_deposition_dust_##SFX) == 2 * sizeof(FT), "cmx_deposition_dust");\
+    CMX_STATIC_ASSERT(sizeof(cmx_h2so4_solution_params_##SFX) == 10 * sizeof(FT), "cmx_h2so4_solution_params");\
     CMX_STATIC_ASSERT(sizeof(cmx_accr_sb2006_##SFX) == 4 * sizeof(FT), "cmx_accr_sb2006");\
     CMX_STATIC_ASSERT(sizeof(cmx_acnv_1m_##SFX) == 3 * sizeof(FT), "cmx_acnv_1m");\
     CMX_STATIC_ASSERT(sizeof(cmx_acnv_sb2006_##SFX) == 6 * sizeof(FT), "cmx_acnv_sb2006");\
@@ -464,6 +477,8 @@ typedef enum cmx_sb2006_process_column {
     CMX_SB_NUMADJ_RAI,       /* number_tendency_from_mass_limits(rain; q_rai, N_rai/ρ) CM2:882-891 */
     CMX_SB_NUMADJ_LCL,       /* same for cloud (xc_min, xc_max; q_lcl, N_lcl/ρ)     */
     CMX_SB_CONDEVAP,         /* _conv_q_vap_to_q_lcl_const        NonEq:117-140 */
+    CMX_SB_DEVAP_DN_RAI,     /* ∂rain_evaporation_∂N_rai_∂q_rai(…).∂N_rai = ∂ₜρn_rai / N_rai  [1/s]  CM2:844-855 */
+    CMX_SB_DEVAP_DQ_RAI,     /*                                   .∂q_rai = ∂ₜq_rai / q_rai   [1/s]              */
     CMX_SB2006_NPROC
 } cmx_sb2006_process_column;
 
@@ -573,6 +588,49 @@ int32_t cmx_ice_nucleation_rates_f64(
     uint32_t flags, int64_t n, const double *T, const double *a_w, const double *r,
     double *delta_a_w, double *J_het, double *J_hom, double *rate_het, double *rate_hom,
     int64_t *n_domain_errors, void *stream);
+
+/* The same with the water activity of a sulphuric-acid solution droplet computed in the kernel, as the parcel model drives it
+ * (parcel/ParcelTendencies.jl:120-133: a_w = CO.a_w_xT(H2SO4_prs, tps, x_sulph, T) when T < T_max of the solution fit): the second
+ * input column is x, the weight fraction of H2SO4 [-], instead of a_w;  a_w = p_sol(x, T) / p_sat,liq(T), src/Common.jl:188-246. */
+int32_t cmx_ice_nucleation_rates_xT_f32(const cmx_thermo_f32 *tps, const cmx_abifm_dust_f32 *dust, const cmx_koop2000_f32 *koop,
+                                        const cmx_h2so4_solution_params_f32 *h2so4, uint32_t flags, int64_t n, const float *T, const float *x_sulph,
+                                        const float *r, float *delta_a_w, float *J_het, float *J_hom, float *rate_het, float *rate_hom,
+                                        int64_t *n_domain_errors, void *stream);
+int32_t cmx_ice_nucleation_rates_xT_f64(const cmx_thermo_f64 *tps, const cmx_abifm_dust_f64 *dust, const cmx_koop2000_f64 *koop,
+                                        const cmx_h2so4_solution_params_f64 *h2so4, uint32_t flags, int64_t n, const double *T, const double *x_sulph,
+                                        const double *r, double *delta_a_w, double *J_het, double *J_hom, double *rate_het, double *rate_hom,
+                                        int64_t *n_domain_errors, void *stream);
+
+/* CO.H2SO4_soln_saturation_vapor_pressure(prs, x, T) [Pa] and CO.a_w_xT(prs, tps, x, T) over columns — src/Common.jl:188-246
+ * (KA wrapper Common_H2SO4_kernel!, test/gpu_tests.jl:876-893).  Either output may be NULL. */
+int32_t cmx_h2so4_solution_f32(const cmx_h2so4_solution_params_f32 *prs, const cmx_thermo_f32 *tps, int64_t n, const float *x_sulph, const float *T,
+                               float *p_sol, float *a_w, void *stream);
+int32_t cmx_h2so4_solution_f64(const cmx_h2so4_solution_params_f64 *prs, const cmx_thermo_f64 *tps, int64_t n, const double *x_sulph, const double *T,
+                               double *p_sol, double *a_w, void *stream);
+
+/* Mohler et al. (2006) deposition nucleation on dust — src/IceNucleation.jl:44-79 (KA wrappers
+ * IceNucleation_dust_activated_number_fraction_kernel!, IceNucleation_MohlerDepositionRate_kernel!, test/gpu_tests.jl:930-966):
+ *   act_frac = CMI_het.dust_activated_number_fraction(dust, ip, S_i, T) = max(0, exp(a (S_i − S₀)) − 1)
+ *   dep_rate = CMI_het.MohlerDepositionRate(dust, ip, S_i, T, dSi_dt, N_aer) = max(0, N_aer a dSi_dt)        (a, S₀ by T ≷ T_thr)
+ * Columns S_i, T; dSi_dt and N_aer (both needed for dep_rate, NULL otherwise); either output may be NULL.  The reference asserts
+ * S_i < Sᵢ_max: such points get NaN and are counted in `n_domain_errors` (optional: ONE device int64, accumulating, zeroed by the caller). */
+int32_t cmx_mohler2006_deposition_f32(const cmx_mohler_dust_f32 *dust, const cmx_mohler2006_f32 *ip, int64_t n, const float *S_i, const float *T,
+                                      const float *dSi_dt, const float *N_aer, float *act_frac, float *dep_rate, int64_t *n_domain_errors,
+                                      void *stream);
+int32_t cmx_mohler2006_deposition_f64(const cmx_mohler_dust_f64 *dust, const cmx_mohler2006_f64 *ip, int64_t n, const double *S_i, const double *T,
+                                      const double *dSi_dt, const double *N_aer, double *act_frac, double *dep_rate, int64_t *n_domain_errors,
+                                      void *stream);
+
+/* CMI_het.deposition_J(dust, Δa_w) = 10^(m Δa_w + c + 4) [m⁻² s⁻¹] — src/IceNucleation.jl:81-102 (water-activity based deposition
+ * nucleation, China et al. 2017 / Alpert et al. 2022; KA wrapper IceNucleation_deposition_J_kernel!, test/gpu_tests.jl:968-984). */
+int32_t cmx_deposition_J_f32(const cmx_deposition_dust_f32 *dust, int64_t n, const float *delta_a_w, float *J, void *stream);
+int32_t cmx_deposition_J_f64(const cmx_deposition_dust_f64 *dust, int64_t n, const double *delta_a_w, double *J, void *stream);
+
+/* CMI_het.INP_concentration_frequency(params, INPC, T) — src/IceNucleation.jl:219-226 (Frostenberg et al. 2023: log-normal relative
+ * frequency of an INP concentration at temperature T; 0 at and above T_freeze; KA wrapper IceNucleation_INPC_frequency_kernel!,
+ * test/gpu_tests.jl:1041-1055). */
+int32_t cmx_inp_concentration_frequency_f32(const cmx_frostenberg2023_f32 *ip, int64_t n, const float *INPC, const float *T, float *freq, void *stream);
+int32_t cmx_inp_concentration_frequency_f64(const cmx_frostenberg2023_f64 *ip, int64_t n, const double *INPC, const double *T, double *freq, void *stream);
 
 /* CO.a_w_ice(tps, T) and CO.a_w_eT(tps, e, T) over columns — src/Common.jl:250-253,267-271
  * (KA wrappers Common_a_w_ice_kernel!, Common_a_w_eT_kernel!, test/gpu_tests.jl:340-362).
@@ -759,6 +817,17 @@ int32_t cmx_arg2000_activation_f64(
     const cmx_air_properties_f64 *aip, const cmx_thermo_f64 *tps, int64_t n,
     const double *T, const double *p, const double *w, const double *q_tot, const double *q_liq, const double *q_ice,
     const double *N_liq, const double *N_ice, double *const *N_act, double *const *M_act, double *S_max, void *stream);
+
+/* AA.total_N_activated(…) / AA.total_M_activated(…) — src/AerosolActivation.jl:355-433: the sums over the modes of N_activated_per_mode /
+ * M_activated_per_mode (left to right, as Julia sums the tuple), formed in the activation kernel.  Either output may be NULL, not both. */
+int32_t cmx_arg2000_total_activated_f32(const cmx_aerosol_activation_params_f32 *ap, const cmx_aerosol_distribution_f32 *ad,
+                                        const cmx_air_properties_f32 *aip, const cmx_thermo_f32 *tps, int64_t n, const float *T, const float *p,
+                                        const float *w, const float *q_tot, const float *q_liq, const float *q_ice, const float *N_liq,
+                                        const float *N_ice, float *N_total, float *M_total, void *stream);
+int32_t cmx_arg2000_total_activated_f64(const cmx_aerosol_activation_params_f64 *ap, const cmx_aerosol_distribution_f64 *ad,
+                                        const cmx_air_properties_f64 *aip, const cmx_thermo_f64 *tps, int64_t n, const double *T, const double *p,
+                                        const double *w, const double *q_tot, const double *q_liq, const double *q_ice, const double *N_liq,
+                                        const double *N_ice, double *N_total, double *M_total, void *stream);
 
 /* Same activation for aerosol that varies in space: every mode's (r_dry, stdev, N, hygroscopicity, molar_mass_mix) is a
  * device column (arrays of n_modes column pointers), as the reference's own KA kernel passes them per element

@@ -618,6 +618,9 @@ void FN(cmxo_sb2006_process_rates)(const TY(cmx_warm_rain_2m) * wr, const TY(cmx
         PUT(CMX_SB_NUMADJ_RAI, na_r);
         PUT(CMX_SB_NUMADJ_LCL, na_l);
         PUT(CMX_SB_CONDEVAP, ce);
+        /* ∂rain_evaporation_∂N_rai_∂q_rai — src/Microphysics2M.jl:844-855 */
+        PUT(CMX_SB_DEVAP_DN_RAI, N_rai[i] > th->eps_n ? evN / N_rai[i] : (FT)0);
+        PUT(CMX_SB_DEVAP_DQ_RAI, q_rai[i] > th->eps_m ? evq / q_rai[i] : (FT)0);
     }
 #undef PUT
 }
@@ -778,6 +781,7 @@ void FN(cmxo_bulk_2m_cloud_to_rain)(const TY(cmx_bulk_2m_schemes) * p, uint32_t 
 #include "cmx_oracle_sed_impl.h"
 #include "cmx_oracle_p3col_impl.h"
 #include "cmx_oracle_column_impl.h"
+#include "cmx_oracle_extra_impl.h"
 
 #undef CAT_
 #undef CAT

@@ -77,6 +77,8 @@ typedef struct TY(cmxo_p3col) {
     FT c_lo, c_hi;                    /* cloud bounds */
     FT N0r, Dr_mean, r_lo, r_hi;      /* rain PSD and bounds */
     FT T_C;                           /* T − T_freeze of compute_local_rime_density :281 */
+    FT mfr_amp;                       /* Σ|operands| / |result| of mfr_coef = K (T_frz − T) + L_v D ρ (q_sat,i(T_frz) − q_sat,i(T)): both differences cancel as T → T_frz */
+    FT dT_amp;                        /* (|T| + T_frz) / |T − T_frz| */
     FT mfr_coef, denom; int above_freezing;   /* compute_max_freeze_rate :167-201 */
     FT cbrt_Nsc, nu_air;
     FT rho_w;
@@ -158,6 +160,11 @@ static inline void FN(o_p3col_setup)(TY(cmxo_p3col) * k, const TY(cmx_p3_ice_par
     FT drho_v = rho_a * (FN(o_qsat_ice)(tps, T_frz, rho_a) - FN(o_qsat_ice)(tps, T, rho_a));
     k->denom = L_f - tps->cp_l * dT;
     k->mfr_coef = aps->K_therm * dT + L_v * aps->D_vapor * drho_v;
+    {   /* conditioning of the two T-differences (parity scale only: not part of the reference's arithmetic) */
+        FT operands = aps->K_therm * (T_frz + M_ABS(T)) + L_v * aps->D_vapor * rho_a * (FN(o_qsat_ice)(tps, T_frz, rho_a) + FN(o_qsat_ice)(tps, T, rho_a));
+        k->mfr_amp = k->mfr_coef != 0 ? operands / M_ABS(k->mfr_coef) : (FT)0;
+        k->dT_amp = T != T_frz ? (M_ABS(T) + T_frz) / M_ABS(T - T_frz) : (FT)0;
+    }
     k->above_freezing = T >= T_frz;
     k->cbrt_Nsc = M_CBRT(aps->nu_air / aps->D_vapor); k->nu_air = aps->nu_air;
     k->rho_w = ip->cloud_pdf.rho_w;
@@ -205,11 +212,14 @@ static inline void FN(o_closed_rain_inner_NM)(const TY(cmxo_p3col) * k, FT v_i, 
     *N = k->N0r * cross[0];
     *M = k->N0r * mfac * cross[1];
 }
+/* (cond[2], optional, parity scale only: ∫ n M_frz and ∫ n (B_c + B_r) f_frz over the nodes where the maximum freezing rate is the
+ * active limit — the part of the freeze / shed split that is proportional to mfr_coef) */
 /* ∫liquid_ice_collisions — :449-489 (outer integrand) + :527-562; rates[10] = (QCFRZ, QCSHD, NCCOL, QRFRZ, QRSHD, NRCOL, ∫M_col,
  * BCCOL, BRCOL, ∫𝟙_wet M_col) */
-static inline void FN(o_p3_collision_integrals)(const TY(cmxo_p3col) * k, const TY(cmx_quadrature) * quad, FT rates[10]) {
+static inline void FN(o_p3_collision_integrals)(const TY(cmxo_p3col) * k, const TY(cmx_quadrature) * quad, FT rates[10], FT cond[2]) {
     const TY(cmx_p3_params) *pr = &k->ip->scheme;
     for (int q = 0; q < 10; ++q) rates[q] = 0;
+    if (cond) cond[0] = cond[1] = 0;
     for (int sg = 0; sg < 4; ++sg) {
         FT a = k->ice_bnd[sg], b = k->ice_bnd[sg + 1];
         if (!(a < b)) continue;
@@ -236,6 +246,7 @@ static inline void FN(o_p3_collision_integrals)(const TY(cmxo_p3col) * k, const 
             r[3] += n * Mr * f_frz * w;       r[4] += n * Mr * (1 - f_frz) * w;   r[5] += n * Nr * w;
             r[6] += n * M_col * w;            r[7] += n * Bc * f_frz * w;         r[8] += n * Br * f_frz * w;
             r[9] += n * wet * M_col * w;
+            if (cond) { cond[0] += scale * n * wet * M_frz * w; cond[1] += scale * n * wet * (Bc + Br) * f_frz * w; }
         }
         for (int q = 0; q < 10; ++q) rates[q] += scale * r[q];
     }
@@ -275,7 +286,7 @@ void FN(cmxo_p3_liquid_ice_collisions)(const TY(cmx_p3_ice_params) * ip, const T
         if (!(s.rho_n_ice < s.eps || s.rho_q_ice < s.eps)) {
             TY(cmxo_p3col) k;
             FN(o_p3col_setup)(&k, ip, aps, tps, flags, th, &s, L_c[i], N_c[i], L_r[i], N_r[i], rho_a[i], T[i], loglam[i]);
-            FN(o_p3_collision_integrals)(&k, quad, r);
+            FN(o_p3_collision_integrals)(&k, quad, r, (FT *)0);
             FN(o_p3_collision_sources)(&k, r, rho_a[i], src);
         }
         if (rates) for (int q = 0; q < 10; ++q) rates[(int64_t)q * n + i] = r[q];
@@ -395,12 +406,24 @@ static inline void FN(o_bulk_tendencies_2m_p3)(const TY(cmx_warm_rain_2m) * wr, 
         TY(cmxo_p3col) k;
         FT r[10], src[7];
         FN(o_p3col_setup)(&k, ip, aps, tps, p3flags, th, &s, L_lcl, N_lcl, L_rai, N_rai, rho, T, loglam);
-        FN(o_p3_collision_integrals)(&k, &ip->quad, r);
+        FT cond[2];
+        FN(o_p3_collision_integrals)(&k, &ip->quad, r, cond);
         FN(o_p3_collision_sources)(&k, r, rho, src);
         dq_lcl += src[0]; dq_rai += src[1]; dn_lcl += src[2] / rho; dn_rai += src[3] / rho;
         dq_ice += src[5] / rho; dq_rim += src[4] / rho; db_rim += src[6] / rho;
         sc[0] += M_ABS(src[0]); sc[2] += (r[3] + r[1]) / rho; sc[1] += M_ABS(src[2] / rho); sc[3] += (r[5] + M_ABS(src[3] + r[5])) / rho;
         sc[4] += M_ABS(src[5] / rho); sc[6] += M_ABS(src[4] / rho); sc[7] += (M_ABS(r[7]) + M_ABS(r[8]) + M_ABS(src[6] - r[7] - r[8])) / rho;
+        {   /* The freeze / shed split of the collected liquid is limited by compute_max_freeze_rate (P3_processes.jl:167-201), which is
+             * proportional to mfr_coef = K (T_frz − T) + L_v D ρ (q_sat(T_frz) − q_sat(T)): two differences whose operands are mfr_amp
+             * times larger than the result near T_frz.  Wherever that limit is active the frozen mass (∂ₜq_ice, ∂ₜq_rim, −∂ₜq_rai through
+             * QRFRZ and QCSHD, ∂ₜn_rai through the shed drops) carries that conditioning; the rime volume also that of T − T_frz in the
+             * local rime density (compute_local_rime_density :281-299). */
+            const FT D_shd = (FT)1e-3;
+            const FT S_frz = k.mfr_amp * cond[0] / rho, S_B = (k.mfr_amp + k.dT_amp) * cond[1] / rho;
+            sc[2] += S_frz; sc[4] += S_frz; sc[6] += S_frz;
+            sc[3] += S_frz / (k.rho_w * (D_shd * D_shd * D_shd * (FT)M_PI / 6));
+            sc[7] += S_B;
+        }
         /* aggregation — BMT:976-977 */
         FT agg = FN(o_p3_ice_self_collection)(pr, &ip->vel_ice, &ip->quad, p3flags, &s, rho, loglam, gi_iters);
         dn_ice -= agg / rho; sc[5] += M_ABS(agg / rho);
@@ -412,8 +435,11 @@ static inline void FN(o_bulk_tendencies_2m_p3)(const TY(cmx_warm_rain_2m) * wr, 
         dq_rai += mq; dn_rai += mn; dq_ice -= mq; dn_ice -= mn;
         dq_rim -= mq * s.F_rim;
         db_rim -= s.rho_rim > 0 ? mq * s.F_rim / s.rho_rim : (FT)0;
-        sc[2] += M_ABS(mq); sc[3] += M_ABS(mn); sc[4] += M_ABS(mq); sc[5] += M_ABS(mn); sc[6] += M_ABS(mq * s.F_rim);
-        sc[7] += s.rho_rim > 0 ? M_ABS(mq * s.F_rim / s.rho_rim) : (FT)0;
+        {   /* ice_melt ∝ K (T − T_frz) (P3_processes.jl:64-94): operands (|T| + T_frz)/|T − T_frz| times the result */
+            const FT am = T > tps->T_freeze ? k.dT_amp : (FT)1;
+            sc[2] += am * M_ABS(mq); sc[3] += am * M_ABS(mn); sc[4] += am * M_ABS(mq); sc[5] += am * M_ABS(mn); sc[6] += am * M_ABS(mq * s.F_rim);
+            sc[7] += s.rho_rim > 0 ? am * M_ABS(mq * s.F_rim / s.rho_rim) : (FT)0;
+        }
     }
     /* ice nucleation (F23 + Bigg) — BMT:997-1034 */
     FT tau_act = ip->tau_act;

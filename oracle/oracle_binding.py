@@ -660,6 +660,37 @@ def p3_crossover_probe(fam, chen, rho_a, v_target, D_min, D_max, maxiters=10):
     return tuple(out)
 
 
+def h2so4_solution(fam, prs, tps, x, T):
+    """(H2SO4_soln_saturation_vapor_pressure, a_w_xT) over columns — src/Common.jl:188-246."""
+    xs, Ts = _col(fam, x), _col(fam, T)
+    n = xs[0].size
+    p, a = np.empty(n, dtype=NP[fam.sfx]), np.empty(n, dtype=NP[fam.sfx])
+    fn = getattr(lib(), f"cmxo_h2so4_solution_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(prs), C.byref(tps), C.c_int64(n), xs[1], Ts[1], p.ctypes.data_as(C.c_void_p), a.ctypes.data_as(C.c_void_p))
+    return p, a
+
+
+def mohler2006_deposition(fam, dust, ip, S_i, T, dSi_dt, N_aer):
+    """(dust_activated_number_fraction, MohlerDepositionRate) over columns — src/IceNucleation.jl:44-79 (NaN where the reference asserts)."""
+    cols = [_col(fam, a) for a in (S_i, T, dSi_dt, N_aer)]
+    n = cols[0][0].size
+    f, r = np.empty(n, dtype=NP[fam.sfx]), np.empty(n, dtype=NP[fam.sfx])
+    fn = getattr(lib(), f"cmxo_mohler2006_deposition_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(dust), C.byref(ip), C.c_int64(n), *[p for _, p in cols], f.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p))
+    return f, r
+
+
+def deposition_J(fam, dust, delta_a_w):
+    d = _col(fam, delta_a_w)
+    J = np.empty(d[0].size, dtype=NP[fam.sfx])
+    fn = getattr(lib(), f"cmxo_deposition_J_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(dust), C.c_int64(d[0].size), d[1], J.ctypes.data_as(C.c_void_p))
+    return J
+
+
 def mp0m_tendencies(fam, p0m, q_lcl, q_icl, q_vap_sat=None):
     """Oracle twin of cmx_mp0m_tendencies_*: (dq_tot_dt, ∂dq_tot_dt/∂q_tot)."""
     a, ap = _col(fam, q_lcl)

@@ -58,7 +58,7 @@ def test_size_contract_matches_the_ctypes_mirror():
     import re
     text = (REPO / "include" / "cmx.h").read_text()
     rows = re.findall(r"CMX_STATIC_ASSERT\(sizeof\((cmx_\w+)_##SFX\) == (?:(\d+) \+ )?(\d+) \* sizeof\(FT\)", text)
-    assert len(rows) == 50
+    assert len(rows) == 54
     checked = 0
     for name, hdr, nft in rows:
         for fam, w in ((_abi.F32, 4), (_abi.F64, 8)):
@@ -66,7 +66,7 @@ def test_size_contract_matches_the_ctypes_mirror():
             assert ct.__name__ == f"{name}_{fam.sfx}"
             assert C.sizeof(ct) == int(hdr or 0) + int(nft) * w, (name, fam.sfx)
             checked += 1
-    assert checked == 100
+    assert checked == 108
     assert C.sizeof(_abi.F32.thermo) == 52 and C.sizeof(_abi.F64.thermo) == 104               # 13 fields: cv_l is the 13th
 
 

@@ -1,0 +1,189 @@
+"""The remaining public functions of the subsystems this library replaces (VERDICT r02 row g): CO.H2SO4_soln_saturation_vapor_pressure /
+a_w_xT, CMI_het.dust_activated_number_fraction / MohlerDepositionRate / deposition_J / INP_concentration_frequency,
+∂rain_evaporation_∂N_rai_∂q_rai, AA.total_N_activated / total_M_activated.
+
+CPU: the oracle against the reference's KATs (tests/golden/ice_nucleation_kats.json ← test/gpu_tests.jl:876-1055).
+GPU (-m gpu): the device entries through the C ABI against the same KATs and against the oracle on random columns."""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import parity
+from cmx import _abi
+from cmx import parameters as P
+
+G = json.loads((Path(__file__).parent / "golden" / "ice_nucleation_kats.json").read_text())
+DT = {"f32": torch.float32, "f64": torch.float64}
+F64 = _abi.F64
+
+
+def _isapprox(x, y, rtol):
+    """Julia's isapprox(x, y; rtol): |x − y| ≤ rtol·max(|x|, |y|) (the form the reference's `≈ … rtol = 0.1` tests use)."""
+    return abs(x - y) <= rtol * max(abs(x), abs(y))
+
+
+def _a(*v):
+    return [np.atleast_1d(np.asarray(x, dtype=np.float64)) for x in v]
+
+
+# ---- CPU: oracle vs the reference's KATs ------------------------------------------------------------------------------------------------
+def test_oracle_h2so4_kats(oracle):
+    g = G["H2SO4_solution"]
+    p, a = oracle.h2so4_solution(F64, P.H2SO4SolutionParameters("f64"), P.ThermodynamicsParameters("f64"), *_a(g["x_sulph"], g["T"]))
+    assert p[0] == pytest.approx(g["p_sol"], rel=g["rtol"]) and a[0] == pytest.approx(g["a_w_xT"], rel=g["rtol"])
+
+
+def test_oracle_mohler_kats(oracle):
+    f, r = G["dust_activated_number_fraction"], G["MohlerDepositionRate"]
+    for name, ctor in (("DesertDust", P.DesertDust), ("ArizonaTestDust", P.ArizonaTestDust)):
+        frac, rate = oracle.mohler2006_deposition(F64, ctor("f64"), P.Mohler2006("f64"), *_a(f["S_i"], f["T"], r["dSi_dt"], r["N_aer"]))
+        assert frac[0] == pytest.approx(f[name], rel=1e-8) and rate[0] == pytest.approx(r[name], rel=1e-8), name   # printed to 9-11 digits
+    # the orderings of test/heterogeneous_ice_nucleation_tests.jl:39-90 (they constrain the unpinned cold branch)
+    ip = P.Mohler2006("f64")
+    for ctor in (P.DesertDust, P.ArizonaTestDust):
+        fr = lambda S, T: oracle.mohler2006_deposition(F64, ctor("f64"), ip, *_a(S, T, 0.05, 3000.0))  # noqa: E731
+        assert fr(1.34, 250.0)[0][0] > fr(1.2, 250.0)[0][0] and fr(1.2, 210.0)[0][0] > fr(1.2, 250.0)[0][0] and fr(1.2, 210.0)[1][0] > fr(1.2, 250.0)[1][0]
+        assert np.isnan(fr(1.5, 250.0)[0][0]) and np.isnan(fr(1.5, 210.0)[1][0])        # the reference asserts S_i < Sᵢ_max
+        assert oracle.mohler2006_deposition(F64, ctor("f64"), ip, *_a(1.01, 250.0, -0.3, 3000.0))[1][0] == 0
+
+
+def test_oracle_deposition_J_and_inp_frequency_kats(oracle):
+    for g in G["deposition_J"]:
+        J = oracle.deposition_J(F64, P.DepositionDust("f64", g["mineral"]), _a(g["delta_a_w"])[0])
+        assert J[0] == pytest.approx(g["expected"], rel=1e-9), g["mineral"]
+    g = G["INP_concentration_frequency"]
+    for c in g["cases"]:
+        assert _isapprox(oracle.INP_concentration_frequency(F64, P.Frostenberg2023("f64"), c["INPC"], c["T"]), c["expected"], g["rtol"]), c
+
+
+# ---- GPU ------------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_device_kats(dev, ft):
+    import cmx
+    col = lambda *v: torch.tensor(v, dtype=DT[ft], device=dev)  # noqa: E731
+    tol = 1.5e-8 if ft == "f64" else 2e-5
+    tps = P.ThermodynamicsParameters(ft)
+    g = G["H2SO4_solution"]
+    p, a = cmx.h2so4_solution(P.H2SO4SolutionParameters(ft), tps, col(g["x_sulph"], g["x_sulph"]), col(g["T"], g["T"]))
+    assert float(p[0]) == pytest.approx(g["p_sol"], rel=tol) and float(a[1]) == pytest.approx(g["a_w_xT"], rel=tol)
+    f, r = G["dust_activated_number_fraction"], G["MohlerDepositionRate"]
+    for name, ctor in (("DesertDust", P.DesertDust), ("ArizonaTestDust", P.ArizonaTestDust)):
+        m = cmx.mohler2006_deposition(ctor(ft), P.Mohler2006(ft), col(f["S_i"], 1.5), col(f["T"], f["T"]), col(r["dSi_dt"], 0.03), col(r["N_aer"], 10.0))
+        # Float32: exp(a ΔS) − 1 with a ΔS ≈ 0.013 cancels two digits
+        assert float(m.act_frac[0]) == pytest.approx(f[name], rel=1e-8 if ft == "f64" else 3e-4) and float(m.dep_rate[0]) == pytest.approx(r[name], rel=tol)
+        assert torch.isnan(m.act_frac[1]) and torch.isnan(m.dep_rate[1]) and int(m.n_domain_errors) == 1       # S_i ≥ Sᵢ_max: the reference asserts
+    for g in G["deposition_J"]:
+        J = cmx.deposition_J(P.DepositionDust(ft, g["mineral"]), col(g["delta_a_w"], 0.0))
+        assert float(J[0]) == pytest.approx(g["expected"], rel=1e-9 if ft == "f64" else 5e-5), g["mineral"]
+    g = G["INP_concentration_frequency"]
+    for c in g["cases"]:
+        fr = cmx.INP_concentration_frequency(P.Frostenberg2023(ft), col(c["INPC"], c["INPC"]), col(c["T"], 280.0))
+        assert _isapprox(float(fr[0]), c["expected"], g["rtol"]) and float(fr[1]) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_device_functions_match_oracle_on_random_columns(dev, oracle, ft):
+    import cmx
+    n = 200_003
+    rng = np.random.default_rng(17)
+    tol = parity.RTOL[ft] * 0.1
+    to = lambda a: torch.from_numpy(a).to(DT[ft]).to(dev)  # noqa: E731
+    back = lambda t: t.cpu().numpy().astype(np.float64)  # noqa: E731
+    rd = lambda a: np.asarray(a).astype({"f32": np.float32, "f64": np.float64}[ft]).astype(np.float64)  # noqa: E731  (the inputs the kernel sees)
+    tps64 = P.ThermodynamicsParameters("f64")
+    # H2SO4 solution: the validity range of the fit, 185 K < T < 235 K, x up to 40 %
+    x, T = rd(rng.uniform(0.0, 0.4, n)), rd(rng.uniform(185.0, 235.0, n))
+    p, a = cmx.h2so4_solution(P.H2SO4SolutionParameters(ft), P.ThermodynamicsParameters(ft), to(x), to(T))
+    pr, ar = oracle.h2so4_solution(F64, P.H2SO4SolutionParameters("f64"), tps64, x, T)
+    np.testing.assert_allclose(back(p), pr, rtol=tol * 3)           # exp of an argument of size 25: 3 digits of the argument's rounding
+    np.testing.assert_allclose(back(a), ar, rtol=tol * 3)
+    # Mohler deposition
+    S, T2, dS, Na = rd(rng.uniform(1.0, 1.45, n)), rd(rng.uniform(200.0, 260.0, n)), rd(rng.uniform(-0.1, 0.1, n)), rd(10 ** rng.uniform(1, 5, n))
+    m = cmx.mohler2006_deposition(P.DesertDust(ft), P.Mohler2006(ft), to(S), to(T2), to(dS), to(Na))
+    fr, rr = oracle.mohler2006_deposition(F64, P.DesertDust("f64"), P.Mohler2006("f64"), S, T2, dS, Na)
+    # exp(a ΔS) − 1: absolute accuracy eps·exp(a ΔS) — scale = 1 + |f|
+    assert np.all((np.abs(back(m.act_frac) - fr) <= tol * (1 + np.abs(fr))) | (np.isnan(fr) & np.isnan(back(m.act_frac))))
+    np.testing.assert_allclose(back(m.dep_rate), rr, rtol=tol, equal_nan=True)
+    assert int(m.n_domain_errors) == int(np.isnan(fr).sum()) > 0
+    # deposition_J, INP frequency
+    d = rd(rng.uniform(0.0, 0.32, n))
+    np.testing.assert_allclose(back(cmx.deposition_J(P.DepositionDust(ft, "Feldspar"), to(d))), oracle.deposition_J(F64, P.DepositionDust("f64", "Feldspar"), d), rtol=tol)
+    inpc, T3 = rd(10 ** rng.uniform(1, 7, n)), rd(rng.uniform(225.0, 275.0, n))
+    got = back(cmx.INP_concentration_frequency(P.Frostenberg2023(ft), to(inpc), to(T3)))
+    ref = np.array([oracle.INP_concentration_frequency(F64, P.Frostenberg2023("f64"), float(i), float(t)) for i, t in zip(inpc[:20000], T3[:20000])])
+    assert np.all(np.abs(got[:20000] - ref) <= tol * 10 * np.abs(ref) + 1e-30)      # exp(−Δ²/2σ²) with Δ up to 10: the argument's rounding × 50
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_ice_nucleation_from_solution_droplets(dev, oracle, ft):
+    """cmx_ice_nucleation_rates_xT_*: BASELINE config 4 as the parcel model drives it — a_w = a_w_xT(x, T) formed in the kernel."""
+    import cmx
+    n = 200_003
+    rng = np.random.default_rng(5)
+    T, x, r = rng.uniform(190.0, 234.0, n), rng.uniform(0.0, 0.35, n), 10 ** rng.uniform(-8, -5, n)
+    cols = [torch.from_numpy(c).to(DT[ft]) for c in (T, x, r)]
+    tps, dust, koop, hs = P.ThermodynamicsParameters(ft), P.Kaolinite(ft), P.Koop2000(ft), P.H2SO4SolutionParameters(ft)
+    want = ("delta_a_w", "J_het", "J_hom", "rate_het", "rate_hom")
+    got = cmx.ice_nucleation_rates(tps, dust, koop, *[c.to(dev) for c in cols], want=want, h2so4=hs)
+    c64 = [c.numpy().astype(np.float64) for c in cols]
+    _, aw = oracle.h2so4_solution(F64, P.H2SO4SolutionParameters("f64"), P.ThermodynamicsParameters("f64"), c64[1], c64[0])
+    ref = oracle.ice_nucleation_rates(F64, P.ThermodynamicsParameters("f64"), P.Kaolinite("f64"), P.Koop2000("f64"), 0, c64[0], aw, c64[2])
+    # the same two-step sequence on the device (a_w column from cmx.h2so4_solution) must agree to rounding with the fused input mode
+    aw_dev = cmx.h2so4_solution(hs, tps, cols[1].to(dev), cols[0].to(dev))[1]
+    two = cmx.ice_nucleation_rates(tps, dust, koop, cols[0].to(dev), aw_dev, cols[2].to(dev), want=want)
+    torch.cuda.synchronize()
+    d = got.delta_a_w.cpu().numpy().astype(np.float64)
+    assert np.abs(d - ref["delta_a_w"]).max() <= (2e-6 if ft == "f32" else 1e-12)
+    ok = np.isfinite(ref["J_hom"])
+    # J = 10^(m Δ + c): a relative error of Δ of eps·a_w/Δ is amplified by m·ln10·Δ ≈ 125·Δ (ABIFM) / 2e4·Δ² (Koop cubic)
+    tol_het, tol_hom = ({"f32": 2e-3, "f64": 1e-9}[ft], {"f32": 3e-2, "f64": 1e-8}[ft])
+    np.testing.assert_allclose(got.J_het.cpu().numpy(), ref["J_het"], rtol=tol_het)
+    np.testing.assert_allclose(got.J_hom.cpu().numpy()[ok], ref["J_hom"][ok], rtol=tol_hom)
+    np.testing.assert_allclose(got.rate_het.cpu().numpy(), two.rate_het.cpu().numpy(), rtol=tol_het)
+    assert cmx.domain_error_count(got) == int((~ok).sum()) == cmx.domain_error_count(two)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_rain_evaporation_derivatives_and_activation_totals(dev, oracle, ft):
+    import cmx
+    from cmx import synthetic
+    # ∂rain_evaporation_∂N_rai_∂q_rai — two more columns of the per-process entry
+    n = 100_003
+    st = synthetic.sb2006_state(n, dtype=DT[ft], seed=3)
+    rho = st.rho.to(dev)
+    mp, tps = P.Microphysics2MParams(ft), P.ThermodynamicsParameters(ft)
+    r = cmx.sb2006_process_rates(mp, tps, st.q_tot.to(dev), st.q_lcl.to(dev), st.q_rai.to(dev), (st.n_lcl * st.rho).to(dev), (st.n_rai * st.rho).to(dev), rho, st.T.to(dev))
+    N_rai = (st.n_rai * st.rho).to(dev)
+    eps = torch.finfo(DT[ft]).eps
+    exp_N = torch.where(N_rai > eps, r.evap_dN_rai_dt / N_rai, torch.zeros_like(N_rai))
+    exp_q = torch.where(st.q_rai.to(dev) > eps, r.evap_dq_rai_dt / st.q_rai.to(dev), torch.zeros_like(N_rai))
+    finite = torch.isfinite(exp_N) & torch.isfinite(exp_q)
+    assert torch.allclose(r.devap_dN_rai[finite], exp_N[finite], rtol=1e-5 if ft == "f32" else 1e-12, atol=0)
+    assert torch.allclose(r.devap_dq_rai[finite], exp_q[finite], rtol=1e-5 if ft == "f32" else 1e-12, atol=0)
+    assert float(r.devap_dq_rai.min()) < 0
+    # total_N_activated / total_M_activated = Σ over the per-mode columns, in mode order
+    a = synthetic.arg_state(50_001, dtype=DT[ft], device=dev, seed=9)
+    ap, aip = P.AerosolActivationParameters(ft), P.AirProperties(ft)
+    ad = synthetic.arg_config3_distribution()
+    per = cmx.aerosol_activation(ap, ad, aip, tps, *a, want=("N_act", "M_act"))
+    N_tot, M_tot = cmx.total_activated(ap, ad, aip, tps, *a)
+    n_sum, m_sum = per.N_act[0].clone(), per.M_act[0].clone()
+    for j in range(1, len(per.N_act)):
+        n_sum += per.N_act[j]
+        m_sum += per.M_act[j]
+    assert torch.equal(N_tot, n_sum) and torch.equal(M_tot, m_sum)
+    only_n = cmx.total_activated(ap, ad, aip, tps, *a, want=("N",))
+    assert only_n[1] is None and torch.equal(only_n[0], N_tot)

@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Generate the measured tables and sentences of DESIGN.md from the committed evidence under profiles/ — so that the document cannot
+quote a number the evidence does not hold ("DESIGN §5 misquotes its own evidence", "0.666-vs-0.707 discrepancies").
+
+    tools/gen_design_tables.py [--round rNN]            print the generated blocks
+    tools/gen_design_tables.py --write [--round rNN]    rewrite the blocks between the markers in DESIGN.md
+    tools/gen_design_tables.py --check [--round rNN]    exit 1 if DESIGN.md's blocks differ from what the evidence generates
+
+Markers in DESIGN.md:  <!-- BEGIN GENERATED <name> --> … <!-- END GENERATED <name> -->   with <name> ∈ {performance, parity}.
+Sources (round rNN = the newest round that has a bench directory unless --round is given):
+    profiles/bench_rNN/<workload>_<dtype>.json          bench.py lines (HIP-event mean of the timed launches, same session)
+    profiles/rNN_kernel_stats_<workload>_<dtype>.csv    rocprofv3 --kernel-trace --stats (mean / min over ≥ 40 profiled launches)
+    profiles/rNN_pmc_traffic[_<workload>]_<dtype>.json  FETCH_SIZE / WRITE_SIZE passes (HBM bytes over algorithmic bytes)
+    profiles/rNN_pmc_valu_<workload>_<dtype>.json       SQ_INSTS_VALU pass (instructions per point, VALU issue utilisation)
+    profiles/rNN_parity_report.json                     rows written by tests/parity.py during the -m gpu session
+"""
+import csv
+import json
+import re
+import sys
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+PROF = REPO / "profiles"
+HBM_PEAK = 8000.0
+ORDER = ["sb2006", "sb2006_chen", "sb2006_column", "sb2006_aos", "sb2006_fields", "mp0m", "icenuc", "mp1m", "mp1m_lin", "mp1m_column", "mp1m_column_lin", "arg2000",
+         "p3_fused", "p3", "p3_selfcol", "mp2m_p3"]
+
+
+def latest_round():
+    rounds = sorted(int(m.group(1)) for p in PROF.glob("bench_r*") if (m := re.fullmatch(r"bench_r(\d+)", p.name)))
+    return f"r{rounds[-1]:02d}" if rounds else None
+
+
+def bench_lines(rnd):
+    out = {}
+    for p in sorted((PROF / f"bench_{rnd}").glob("*.json")):
+        try:
+            lines = [l for l in p.read_text().splitlines() if l.strip().startswith("{")]
+            d = json.loads(lines[-1])
+        except (OSError, ValueError, IndexError):
+            continue
+        out[p.stem] = d
+    return out
+
+
+def kernel_stats(rnd, wl, dt):
+    """(sum of the mean durations of the cmx kernels of one step [ms], sum of the minima, calls of the main kernel) or None."""
+    p = PROF / f"{rnd}_kernel_stats_{wl}_{dt}.csv"
+    if not p.exists():
+        return None
+    rows = [r for r in list(csv.reader(open(p)))[1:] if r and "cmx::" in r[0] and "column_sums" not in r[0]]
+    if not rows:
+        return None
+    main = max(rows, key=lambda r: float(r[2]))
+    calls = int(float(main[1]))
+    same = [r for r in rows if int(float(r[1])) == calls]      # the kernels launched once per step
+    return sum(float(r[3]) for r in same) * 1e-6, sum(float(r[5]) for r in same) * 1e-6, calls
+
+
+def load(p):
+    try:
+        return json.loads(p.read_text())
+    except (OSError, ValueError):
+        return None
+
+
+def performance_block(rnd):
+    lines = bench_lines(rnd)
+    rows = []
+    for key, d in lines.items():
+        m = re.fullmatch(r"(.+)_(f32|f64)", key)
+        if not m:
+            continue
+        wl, dt = m.groups()
+        r = d["roofline"]
+        n = d["config"]["points_per_gpu"]
+        bpp = r.get("bytes_per_point") or r.get("hbm", {}).get("bytes_per_point")
+        ks = kernel_stats(rnd, wl, dt)
+        tr = load(PROF / f"{rnd}_pmc_traffic{'' if wl == 'sb2006' else '_' + wl}_{dt}.json")
+        pv = load(PROF / f"{rnd}_pmc_valu_{wl}_{dt}.json")
+        frac_b = n * bpp / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK
+        frac_p = n * bpp / (ks[0] * 1e-3) / 1e9 / HBM_PEAK if ks else None
+        ipp = util = None
+        if pv and pv.get("points") == n:
+            insts = [k.get("counters", {}).get("SQ_INSTS_VALU") for k in pv["kernels"].values()]
+            if insts and all(v is not None for v in insts):
+                ipp = sum(insts) * 64 / n
+            util = pv.get("valu_issue_utilisation")
+        rows.append((ORDER.index(wl) if wl in ORDER else 99, dt, wl, n, bpp, r["kernel_ms"], d.get("cold_ms_first5"), ks, frac_b, frac_p,
+                     tr.get("traffic_over_algorithmic") if tr and tr.get("points") == n else None, ipp, util, r.get("bound", "hbm")))
+    rows.sort()
+    fmt = lambda v, f: "—" if v is None else f % v  # noqa: E731
+    out = [f"Measured in ONE session on one box (round {rnd}; `profiles/bench_{rnd}/`, `profiles/{rnd}_kernel_stats_*.csv`, "
+           f"`profiles/{rnd}_pmc_*.json`).  bench = HIP-event mean of the timed launches of `bench.py`; rocprof = mean (min) over the "
+           "profiled launches of `rocprofv3 --kernel-trace --stats` in the same session — the two are printed side by side because they "
+           "differ by 1–5 % (profiler overhead, clock state).  frac = algorithmic bytes ÷ time ÷ 8 TB/s.  cold = mean of the first five "
+           "launches after the inputs are generated.", "",
+           "| workload | dtype | points | B/point | bench ms | cold ms | rocprof ms (min) | frac bench | frac rocprof | HBM traffic / algorithmic | "
+           "VALU instr / point | VALU issue utilisation | bound |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    for _, dt, wl, n, bpp, ms, cold, ks, fb, fp, tro, ipp, util, bound in rows:
+        out.append(f"| `{wl}` | {dt} | {n:.3g} | {bpp} | {ms:.3f} | {fmt(cold, '%.3f')} | " +
+                   (f"{ks[0]:.3f} ({ks[1]:.3f})" if ks else "—") + f" | {fb:.3f} | {fmt(fp, '%.3f')} | {fmt(tro, '%.4f')} | {fmt(ipp, '%.0f')} | "
+                   f"{fmt(util, '%.2f')} | {bound} |")
+    return "\n".join(out)
+
+
+def parity_block(rnd):
+    d = load(PROF / f"{rnd}_parity_report.json")
+    if not d:
+        return f"(no `profiles/{rnd}_parity_report.json`)"
+    out = [f"From `profiles/{rnd}_parity_report.json` (written by `tests/parity.py` during the `-m gpu` session of round {rnd}; "
+           "`tools/gen_design_tables.py` prints this paragraph, `tests/test_design_doc.py` checks it):", ""]
+    for ft, tol in (("f64", "1e-6"), ("f32", "1e-3")):
+        s = d["summary"].get(ft)
+        if not s:
+            continue
+        rows = [r for r in d["rows"] if r["ft"] == ft]
+        worst = max(rows, key=lambda r: r["worst_wellcond"])
+        low = min(rows, key=lambda r: r["frac_within"])
+        out.append(f"* **{'Float64' if ft == 'f64' else 'Float32'}** (plain bound {tol}): {s['rows']} output columns, {s['points']:,} compared points, "
+                   f"{s['outside_plain_bound']:,} outside the plain relative bound ({s['outside_plain_bound'] / max(s['points'], 1):.2e} of them), "
+                   f"{s['excluded_near_branch']:,} excluded next to a genuine discontinuity; smallest per-column fraction inside "
+                   f"{s['min_frac_within']:.4f} (`{low['what']}` `{low['output']}`); worst well-conditioned point "
+                   f"{s['worst_wellcond']:.2e} (`{worst['what']}` `{worst['output']}`).")
+    bad = [r for r in d["rows"] if r["worst_wellcond"] > r["rtol"]]
+    out.append("")
+    out.append(f"Rows whose worst well-conditioned point exceeds the tolerance: {len(bad)}" +
+               ("." if not bad else ": " + "; ".join(f"`{r['what']}` `{r['output']}` {r['worst_wellcond']:.2e}" for r in bad) + "."))
+    set_aside = [r for r in d["rows"] if r.get("frac_below_difference_quotient_floor", 0) > 0]
+    if set_aside:
+        w = max(set_aside, key=lambda r: r["frac_below_difference_quotient_floor"])
+        out.append(f"LinearizedAverage Float32 rows set points aside below the difference-quotient floor eps·q/Δt (tests/test_mp1m_linearized.py): "
+                   f"at most {w['frac_below_difference_quotient_floor']:.3f} of the states (`{w['what']}` `{w['output']}`).")
+    return "\n".join(out)
+
+
+BLOCKS = {"performance": performance_block, "parity": parity_block}
+
+
+def main():
+    args = sys.argv[1:]
+    rnd = args[args.index("--round") + 1] if "--round" in args else latest_round()
+    doc_path = REPO / "DESIGN.md"
+    gen = {name: fn(rnd) for name, fn in BLOCKS.items()}
+    if "--write" not in args and "--check" not in args:
+        for name, text in gen.items():
+            print(f"<!-- BEGIN GENERATED {name} -->\n{text}\n<!-- END GENERATED {name} -->\n")
+        return 0
+    doc = doc_path.read_text()
+    stale = []
+    for name, text in gen.items():
+        pat = re.compile(rf"(<!-- BEGIN GENERATED {name} -->\n)(.*?)(\n<!-- END GENERATED {name} -->)", re.S)
+        m = pat.search(doc)
+        if not m:
+            stale.append(f"{name}: markers missing")
+            continue
+        if m.group(2) != text:
+            stale.append(name)
+            doc = doc[:m.start(2)] + text + doc[m.end(2):]
+    if "--write" in args:
+        doc_path.write_text(doc)
+        print("rewrote: " + (", ".join(stale) if stale else "nothing (current)"))
+        return 0
+    if stale:
+        print("DESIGN.md generated blocks are stale: " + ", ".join(stale) + f"  (run tools/gen_design_tables.py --write --round {rnd})")
+        return 1
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
