@@ -52,6 +52,9 @@ def parse():
                          "a device — local_rank modulo the device count — so the N > 1 code path can be exercised on a 1-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the bounded baseline sample")
+    ap.add_argument("--dry-run-scaffolding", action="store_true",
+                    help="TEST MODE (tests/test_launcher.py, no GPU): run only the multi-rank scaffolding — sharding, barriers, max-over-ranks timing, "
+                         "reductions, rank-0 JSON — over gloo with a step that does nothing; the line carries \"dry_run\": true and no throughput")
     ap.add_argument("--diagnostics", action="store_true",
                     help="also reduce Σ of the output columns per step (block reduce + RCCL all-reduce of a few doubles)")
     return ap.parse_args()
@@ -635,9 +638,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(1, args.gpus):
         sys.exit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
-    dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
+    dry = args.dry_run_scaffolding
+    if dry:
+        args.backend, args.no_cpu_baseline, args.settle = "gloo", True, 0
+    n_dev = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if not dry and args.backend == "nccl" and n_dev < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+        # one process per GPU over RCCL: fewer devices than ranks cannot work — say so and leave non-zero before any rank blocks in a collective
+        sys.exit(f"bench.py: --gpus {world} with the nccl (RCCL) backend needs {world} visible GPUs, this node has {n_dev}")
+    if not dry and n_dev == 0:
+        sys.exit("bench.py: no GPU visible (the product has no CPU path)")
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, n_dev)
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
     # CMX_BENCH_FORCE_DIST=1 (tests/test_bench_gpu.py, under torchrun with one rank): take the process-group path at world size 1 too,
     # so that the RCCL initialisation, barrier and reductions of the N > 1 job run on a 1-GPU box
     use_dist = world > 1 or os.environ.get("CMX_BENCH_FORCE_DIST") == "1"
@@ -657,7 +672,12 @@ def main():
     # Either way: disjoint seeds, no exchange
     setup = {"sb2006": setup_sb2006, "sb2006_chen": setup_sb2006, "sb2006_column": setup_sb2006_column, "icenuc": setup_icenuc, "mp0m": setup_mp0m, "mp1m": setup_mp1m, "mp1m_lin": setup_mp1m_lin, "mp1m_column": setup_mp1m_column, "mp1m_column_lin": setup_mp1m_column, "arg2000": setup_arg2000,
              "p3": setup_p3, "p3_fused": setup_p3, "p3_selfcol": setup_p3_selfcol, "mp2m_p3": setup_mp2m_p3, "sb2006_aos": setup_sb2006_layout, "sb2006_fields": setup_sb2006_layout}[args.workload]
-    state, kernel_step, desc, cpu_run = setup(args, dev, dtype, rank)
+    if dry:
+        state, kernel_step, cpu_run = [], (lambda: None), None
+        desc = {"metric": "dry run of the multi-rank scaffolding (no kernel)", "bytes_per_point": 0, "kernel": "none", "workload": "none",
+                "columns_in": 0, "columns_out": 0, "diag_cols": []}
+    else:
+        state, kernel_step, desc, cpu_run = setup(args, dev, dtype, rank)
     n = args.points                                          # a layout workload may round the size to whole field runs
 
     def step():
@@ -668,9 +688,35 @@ def main():
     def fence():
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
     # the first five launches after the inputs are generated, timed one by one (clocks not settled: the cold figure next to settle_steps)
+    if dry:      # no GPU: the same control flow without HIP events
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed = max(time.perf_counter() - t0, 1e-9)
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        tot = torch.tensor([float(n)], dtype=torch.float64)
+        lo_hi = torch.zeros(2 * world, dtype=torch.float64)
+        if args.scaling == "strong":
+            lo_hi[2 * rank], lo_hi[2 * rank + 1] = sharding.shard_bounds(points_arg, rank, world)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            dist.all_reduce(lo_hi, op=dist.ReduceOp.SUM)
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": desc["metric"], "value": None, "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "scaling": args.scaling, "points_per_rank0": n, "points_total": int(tot.item()),
+                              "shard_bounds": [[int(lo_hi[2 * r]), int(lo_hi[2 * r + 1])] for r in range(world)] if args.scaling == "strong" else None}),
+                  flush=True)
+        return
     cold = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
     for a, b in cold:
         a.record()

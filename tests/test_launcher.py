@@ -128,3 +128,40 @@ def test_bench_becomes_a_launcher_before_importing_torch():
     import torch
     if not torch.cuda.is_available():
         assert r.returncode != 0 and r.stdout.strip() == ""
+
+
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_bench_scaffolding_at_world_size_8(scaling):
+    """The N = 8 job of bench.py itself — launcher → torch.distributed.run → 8 ranks → sharding, barriers, max-over-ranks timing,
+    reductions, ONE rank-0 JSON line — with the kernel step replaced by nothing (`--dry-run-scaffolding`, gloo, no GPU): what the
+    driver's 8-GPU run exercises around the kernel.  Shard sizes must tile the requested range (strong) or add up to 8 × it (weak)."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    n = 100_000_000
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--points", str(n),
+                        "--scaling", scaling, "--dry-run-scaffolding"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 8 and d["scaling"] == scaling and d["value"] is None
+    if scaling == "strong":
+        assert d["points_total"] == n
+        b = d["shard_bounds"]
+        assert b[0][0] == 0 and b[-1][1] == n and all(b[k][1] == b[k + 1][0] for k in range(7))
+        assert all(lo % 256 == 0 for lo, _ in b) and max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 512
+    else:
+        assert d["points_total"] == 8 * n and d["points_per_rank0"] == n
+
+
+def test_nccl_job_with_too_few_gpus_exits_nonzero_with_a_message():
+    """`--gpus 2` over RCCL on a node with fewer than 2 GPUs: every rank leaves with a clear message before any collective (here: 0 GPUs)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a node with fewer than 2 GPUs")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--points", "1024", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "needs 2 visible GPUs" in r.stderr

@@ -228,7 +228,7 @@ def test_process_rates_match_oracle(dev, oracle, ft, limited):
         got = getattr(r, k).cpu().numpy().astype(np.float64)
         keep = np.ones(n, bool)
         scale = None
-        if k in ("evap_dN_rai_dt", "evap_dq_rai_dt", "condevap"):
+        if k in ("evap_dN_rai_dt", "evap_dq_rai_dt", "condevap", "devap_dN_rai", "devap_dq_rai"):   # ∝ the supersaturation S
             keep &= far
         if k == "rain_breakup":
             keep &= ~near

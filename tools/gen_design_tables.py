@@ -120,7 +120,8 @@ def parity_block(rnd):
         low = min(rows, key=lambda r: r["frac_within"])
         out.append(f"* **{'Float64' if ft == 'f64' else 'Float32'}** (plain bound {tol}): {s['rows']} output columns, {s['points']:,} compared points, "
                    f"{s['outside_plain_bound']:,} outside the plain relative bound ({s['outside_plain_bound'] / max(s['points'], 1):.2e} of them), "
-                   f"{s['excluded_near_branch']:,} excluded next to a genuine discontinuity; smallest per-column fraction inside "
+                   f"{s['excluded_near_branch']:,} excluded (next to a genuine discontinuity of the scheme, or — LinearizedAverage Float32 rows — below the "
+                   f"difference-quotient floor); smallest per-column fraction inside "
                    f"{s['min_frac_within']:.4f} (`{low['what']}` `{low['output']}`); worst well-conditioned point "
                    f"{s['worst_wellcond']:.2e} (`{worst['what']}` `{worst['output']}`).")
     bad = [r for r in d["rows"] if r["worst_wellcond"] > r["rtol"]]
