@@ -41,6 +41,8 @@ def _declare(lib):
     lib.cmx_last_hip_error.argtypes = []
     lib.cmx_lean_eval_f64.restype = i32
     lib.cmx_lean_eval_f64.argtypes = [i32, i64, vp, vp, vp]
+    lib.cmx_lean_eval_literal_f64.restype = i32
+    lib.cmx_lean_eval_literal_f64.argtypes = [i32, i64, vp, vp, vp]
     for fam in (_abi.F32, _abi.F64):
         s = fam.sfx
         f = getattr(lib, f"cmx_sb2006_warm_rain_tendencies_{s}")

@@ -7,6 +7,7 @@
 
 #include "cmx_launch.hpp"
 #include "cmx_math.hpp"
+#include "cmx_lean_eval.hpp"
 
 namespace cmx {
 
@@ -74,46 +75,11 @@ static int32_t column_sums(int32_t ncols, const FT *const *cols, int64_t n, doub
     return CMX_OK;
 }
 
-// Diagnostic: the Float64 elementary functions of cmx_lean_f64.hpp evaluated on the device (tests/test_lean_math.py compares them with
-// libm in ulps; the host build of the same header is checked there too).
-__global__ __launch_bounds__(kBlock) void lean_eval_kernel(const int which, const int64_t n, const double *__restrict__ x, double *__restrict__ y) {
-    lean::erfc_tab_fill();
-    Math<double>::prepare();
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const double v = x[i];
-    double r = v;
-    switch (which) {
-        case 0: r = lean::exp2(v); break;
-        case 1: r = lean::log2(v); break;
-        case 2: r = lean::exp(v); break;
-        case 3: r = lean::log(v); break;
-        case 4: r = lean::rcp(v); break;
-        case 5: r = lean::sqrt(v); break;
-        case 6: r = lean::rsqrt(v); break;
-        case 7: r = lean::expm1(v); break;
-        case 8: r = lean::log1p(v); break;
-        case 9: r = lean::erfc(v); break;
-        case 10: r = lean::lgamma_pos(v); break;
-        default: break;
-    }
-    y[i] = r;
-}
-
 }  // namespace cmx
 
 extern "C" {
 
-int32_t cmx_lean_eval_f64(int32_t which, int64_t n, const double *x, double *y, void *stream) {
-    if (which < 0 || which > 10 || n < 0) return CMX_ERR_BAD_ARG;
-    if (n > cmx::kMaxPoints) return CMX_ERR_UNSUPPORTED;
-    if (n == 0) return CMX_OK;
-    if (!x || !y) return CMX_ERR_BAD_ARG;
-    hipLaunchKernelGGL(cmx::lean_eval_kernel, dim3((unsigned)((n + cmx::kBlock - 1) / cmx::kBlock)), dim3(cmx::kBlock), 0,
-                       reinterpret_cast<hipStream_t>(stream), which, n, x, y);
-    CMX_HIP_TRY(hipGetLastError());
-    return CMX_OK;
-}
+int32_t cmx_lean_eval_f64(int32_t which, int64_t n, const double *x, double *y, void *stream) { return cmx::lean_eval_entry<0>(which, n, x, y, stream); }
 
 int32_t cmx_version(void) { return (CMX_VERSION_MAJOR << 16) | CMX_VERSION_MINOR; }
 

@@ -22,6 +22,7 @@
 
 #include "cmx_launch.hpp"
 #include "cmx_math.hpp"
+#include "cmx_lean_eval.hpp"
 
 namespace cmx {
 
@@ -497,5 +498,8 @@ int32_t cmx_inp_concentration_frequency_f32(const cmx_frostenberg2023_f32 *ip, i
 int32_t cmx_inp_concentration_frequency_f64(const cmx_frostenberg2023_f64 *ip, int64_t n, const double *INPC, const double *T, double *freq, void *stream) {
     return cmx::inp_frequency_entry<double>(ip, n, INPC, T, freq, stream);
 }
+
+// the same diagnostic as cmx_lean_eval_f64, compiled in this literal-coefficient translation unit (cmx_lean_eval.hpp)
+int32_t cmx_lean_eval_literal_f64(int32_t which, int64_t n, const double *x, double *y, void *stream) { return cmx::lean_eval_entry<1>(which, n, x, y, stream); }
 
 }  // extern "C"

@@ -178,7 +178,7 @@ template <typename FT> __device__ __forceinline__ FT gamma_series_sum(FT a, FT x
 #if CMX_P3_SERIES_FWD_F32
     if constexpr (sizeof(FT) == 4) {
         // Float32: forwards, S_k = M_k/D_k with M_k = M_{k−1}(a+k) + x^k, D_k = D_{k−1}(a+k) — four instructions per term, but the
-        // terms fall monotonically (x < a + 1), so the wave can stop once x^k ≤ eps·M_k for all of its lanes in this loop
+        // terms fall monotonically (x < a + 1), so the wave can stop once the remaining tail is ≤ eps·S_k for all of its lanes in this loop
         FT M = FT(1), D = a, X = FT(1);
 #pragma unroll 1
         for (int k0 = 0; k0 < P::kGammaIters; k0 += R) {
@@ -189,7 +189,11 @@ template <typename FT> __device__ __forceinline__ FT gamma_series_sum(FT a, FT x
                 M = Math<FT>::fma(M, ak, X);
                 D *= ak;
             }
-            const bool done = X <= P::eps() * M;
+            // exit once the NEGLECTED TAIL is below eps of the sum, not merely the last term: the terms fall like
+            // ρ_k = x/(a+k+1), so the tail after term k is ≤ term·ρ/(1 − ρ) = (X/D)·x/(a+k+1 − x); close to x = a + 1 with large a the
+            // ratio is near 1 and the last term alone under-estimates the tail many times over
+            const FT a_next = a + FT(k0 + R + 1);
+            const bool done = X * x <= P::eps() * M * (a_next - x);
             const FT r = P::rcp(D);
             M *= r; X *= r; D = FT(1);
             if (__all(done)) break;

@@ -18,7 +18,7 @@
 // Lanes run along the flat index (coalesced 16-byte accesses as in the pointwise kernel); the flux of the cell above is the next
 // point: inside a lane's vector it is in registers, across lanes it goes through LDS (one 16-byte row per lane), and the point
 // after the workgroup's tile is evaluated by a flux-only function (rain PSD + fall speeds: the same inline code as the point
-// function, hence the same bits — results do not depend on where tile boundaries fall).
+// function, hence the same bits — results, NaN propagation included, do not depend on where tile boundaries fall).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -148,10 +148,11 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(sizeof(FT) =
                 A[k][0] = M::fma(-F[k].q_lcl, g[k], A[k][0]);
                 A[k][1] = M::fma(-F[k].n_lcl, g[k], A[k][1]);
             }
-            if (poisoned) {
-                A[k][0] = A[k][1] = A[k][2] = A[k][3] = M::nan();
-                F[k].q_rai = F[k].n_rai = F[k].q_lcl = F[k].n_lcl = M::nan();
-            }
+            // NaN rule (one rule for every path — ADVICE r02): a NaN in ANY input poisons the point's four tendencies; the FLUXES depend on
+            // (ρ, q_lcl, n_lcl, q_rai, n_rai) only — exactly the operands of sed_fluxes_of_point, which evaluates the point after the tile —
+            // so a NaN in T or q_tot does not reach the cell below, wherever the tile boundary falls
+            if (poisoned) A[k][0] = A[k][1] = A[k][2] = A[k][3] = M::nan();
+            if (any_nan(rho[k], q_lcl[k], n_lcl[k], q_rai[k], n_rai[k])) F[k].q_rai = F[k].n_rai = F[k].q_lcl = F[k].n_lcl = M::nan();
         }
         halo[threadIdx.x][0] = F[0].q_rai;
         halo[threadIdx.x][1] = F[0].n_rai;

@@ -395,6 +395,9 @@ const char *cmx_last_hip_error(void);
  * device.  which: 0 exp2, 1 log2, 2 exp, 3 log, 4 rcp, 5 sqrt, 6 rsqrt, 7 expm1, 8 log1p, 9 erfc (the table-driven form of the ARG kernel),
  * 10 lgamma for z > 0 (the P3 shape solver's). */
 int32_t cmx_lean_eval_f64(int32_t which, int64_t n, const double *x, double *y, void *stream);
+/* … and the same functions as compiled into the production Float64 kernels' translation units (polynomial coefficients as SGPR literals
+ * instead of LDS reads; csrc/Makefile LITCOEF). */
+int32_t cmx_lean_eval_literal_f64(int32_t which, int64_t n, const double *x, double *y, void *stream);
 
 /* ---------------------------------------------------------------------------
  * (1) North star — SB2006 two-moment warm-rain fused tendencies.

@@ -189,3 +189,33 @@ def test_full_size_1e8_f32_conservation_and_sample(dev, oracle):
     ref = _oracle(oracle, ft, True, "sb", False, inv_dz.cpu(), sample)
     g = {k: getattr(got, k)[idx].reshape(-1).cpu().numpy() for k in NAMES}
     parity.assert_parity(g, ref, parity.RTOL[ft], names=NAMES, what="column 1e8 f32 sample")
+
+
+@pytest.mark.parametrize("ft", ["f32", "f64"])
+def test_nan_rule_does_not_depend_on_tile_boundaries(dev, ft):
+    """a NaN in T or q_tot poisoned the flux of the point itself inside a tile (→ the cell below got NaN) but not when the
+    point was the one evaluated after a tile (halo).  One rule now: every input poisons the point's tendencies, only the flux operands
+    (ρ, q_lcl, n_lcl, q_rai, n_rai) poison its fluxes — identical at a tile boundary (flat index a multiple of 128·VEC) and inside."""
+    import cmx
+    n_col, n_lev = 6, 1024
+    vec = 4 if ft == "f32" else 1
+    boundary = 128 * vec * 3
+    base = _state(n_col, n_lev, ft, seed=5)
+    inv_dz = _inv_dz(n_lev, ft).to(dev)
+    mp, tps = P.Microphysics2MParams(ft), P.ThermodynamicsParameters(ft)
+    run = lambda cols: cmx.column_tendencies_sedimentation(mp, tps, inv_dz, *[c.to(dev) for c in cols], vel=cmx.SB2006VelType,  # noqa: E731
+                                                           cloud_vel=P.StokesRegimeVelType(ft))
+    clean = run(base)
+    for flat_idx in (boundary, boundary + 37 * vec + 1):
+        for col_i, name, flux_operand in ((1, "T", False), (2, "q_tot", False), (5, "q_rai", True), (0, "rho", True)):
+            cols = [c.clone() for c in base]
+            cols[col_i].reshape(-1)[flat_idx] = float("nan")
+            got = run(cols)
+            torch.cuda.synchronize()
+            for k in NAMES:
+                g, c0 = getattr(got, k).reshape(-1), getattr(clean, k).reshape(-1)
+                assert torch.isnan(g[flat_idx]), (name, k, flat_idx)
+                assert bool(torch.isnan(g[flat_idx - 1])) == flux_operand, (name, k, flat_idx)
+                mask = torch.ones_like(g, dtype=torch.bool)
+                mask[flat_idx - 1:flat_idx + 1] = False
+                assert torch.equal(g[mask], c0[mask]), (name, k, flat_idx)

@@ -131,18 +131,20 @@ def test_special_values(lean):
 
 
 # ---- the same functions ON THE DEVICE (cmx_lean_eval_f64: LDS tables, hardware rcp / rsq seeds, v_ldexp / v_frexp) -------------------
-@pytest.fixture(scope="module")
-def dev_lean():
+# both builds of the polynomial coefficients: LDS reads (cmx_common.hip) and SGPR literals (the production Float64 kernels' units)
+@pytest.fixture(scope="module", params=["cmx_lean_eval_f64", "cmx_lean_eval_literal_f64"])
+def dev_lean(request):
     import torch
 
     from cmx import _lib
     assert torch.cuda.is_available()
     lib = _lib.lib()
+    fn = getattr(lib, request.param)
 
     def ev(which, x):
         xd = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64)).cuda()
         yd = torch.empty_like(xd)
-        st = lib.cmx_lean_eval_f64(which, xd.numel(), C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), None)
+        st = fn(which, xd.numel(), C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), None)
         assert st == 0
         torch.cuda.synchronize()
         return yd.cpu().numpy()
