@@ -7,7 +7,7 @@ configuration BASELINE.json quotes the metric on).  Inputs are generated on the 
 region; nothing crosses PCIe inside it.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--points P] [--dtype f32|f64] [--scaling weak|strong]
-                    [--workload sb2006|sb2006_chen|sb2006_column|sb2006_aos|sb2006_fields|icenuc|mp0m|mp1m|mp1m_lin|mp1m_column|mp1m_column_lin|arg2000|p3|p3_fused|p3_selfcol|mp2m_p3]
+                    [--workload sb2006|sb2006_chen|sb2006_column|sb2006_aos|sb2006_fields|icenuc|mp0m|mp1m|mp1m_lin|mp1m_column|mp1m_column_lin|arg2000|p3|p3_split|p3_selfcol|mp2m_p3]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --points per GPU; strong: --points in total, sharded over the ranks (cmx.sharding.shard_bounds)")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--workload", choices=["sb2006", "sb2006_chen", "sb2006_column", "icenuc", "mp0m", "mp1m", "mp1m_lin", "mp1m_column", "mp1m_column_lin", "arg2000", "p3", "p3_fused", "p3_selfcol", "mp2m_p3", "sb2006_aos", "sb2006_fields"], default="sb2006")
+    ap.add_argument("--workload", choices=["sb2006", "sb2006_chen", "sb2006_column", "icenuc", "mp0m", "mp1m", "mp1m_lin", "mp1m_column", "mp1m_column_lin", "arg2000", "p3", "p3_split", "p3_selfcol", "mp2m_p3", "sb2006_aos", "sb2006_fields"], default="sb2006")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend for N > 1: nccl (= RCCL over xGMI; the measured configuration) or gloo (TEST MODE: ranks may share "
                          "a device — local_rank modulo the device count — so the N > 1 code path can be exercised on a 1-GPU box)")
@@ -452,7 +452,7 @@ def setup_p3(args, dev, dtype, rank):
     quad = P.ChebyshevGauss(args.dtype, 100)          # the reference's default rule (src/P3_terminal_velocity.jl:74)
     holder = {}
 
-    fused = args.workload == "p3_fused"       # the same pass as one launch (cmx_p3_shape_terminal_velocities_*)
+    fused = args.workload == "p3"             # config 5 as ONE launch (cmx_p3_shape_terminal_velocities_*); "p3_split" = the two entries back to back
 
     def step():   # (ρq_ice, ρn_ice, ρq_rim, ρb_rim, ρₐ) → (logλ, D_m, v_n, v_m)
         if fused:
@@ -671,7 +671,7 @@ def main():
     # weak scaling: fixed work per GPU; rank r owns shard r of the global [0, world·n) index space.
     # Either way: disjoint seeds, no exchange
     setup = {"sb2006": setup_sb2006, "sb2006_chen": setup_sb2006, "sb2006_column": setup_sb2006_column, "icenuc": setup_icenuc, "mp0m": setup_mp0m, "mp1m": setup_mp1m, "mp1m_lin": setup_mp1m_lin, "mp1m_column": setup_mp1m_column, "mp1m_column_lin": setup_mp1m_column, "arg2000": setup_arg2000,
-             "p3": setup_p3, "p3_fused": setup_p3, "p3_selfcol": setup_p3_selfcol, "mp2m_p3": setup_mp2m_p3, "sb2006_aos": setup_sb2006_layout, "sb2006_fields": setup_sb2006_layout}[args.workload]
+             "p3": setup_p3, "p3_split": setup_p3, "p3_selfcol": setup_p3_selfcol, "mp2m_p3": setup_mp2m_p3, "sb2006_aos": setup_sb2006_layout, "sb2006_fields": setup_sb2006_layout}[args.workload]
     if dry:
         state, kernel_step, cpu_run = [], (lambda: None), None
         desc = {"metric": "dry run of the multi-rank scaffolding (no kernel)", "bytes_per_point": 0, "kernel": "none", "workload": "none",
@@ -786,7 +786,7 @@ def main():
         if "note" in desc:
             line["roofline"]["note"] = desc["note"]
         if not args.no_cpu_baseline and world == 1:
-            m = min(n, {"sb2006": 20_000_000, "sb2006_chen": 20_000_000, "sb2006_column": 74 * 270_000, "mp1m_column": 74 * 54_000, "mp1m_column_lin": 74 * 27_000, "sb2006_aos": 20_000_000, "sb2006_fields": 20_000_000, "p3": 100_000, "p3_fused": 100_000, "p3_selfcol": 2_000, "mp2m_p3": 20_000}.get(args.workload, 4_000_000))
+            m = min(n, {"sb2006": 20_000_000, "sb2006_chen": 20_000_000, "sb2006_column": 74 * 270_000, "mp1m_column": 74 * 54_000, "mp1m_column_lin": 74 * 27_000, "sb2006_aos": 20_000_000, "sb2006_fields": 20_000_000, "p3": 100_000, "p3_split": 100_000, "p3_selfcol": 2_000, "mp2m_p3": 20_000}.get(args.workload, 4_000_000))
             cols_np = [np.ascontiguousarray(c[:m].cpu().numpy()) for c in state]
             line["cpu_baseline"] = cpu_baseline(args, cols_np, desc, cpu_run)
         print(json.dumps(line), flush=True)

@@ -160,24 +160,24 @@ __device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, cons
                                                     FT q_tot, FT q_liq, FT q_ice, FT N_liq, FT N_ice, bool want_N, bool want_M) {
     using M = Math<FT>;
     ArgOut<FT, NM> o;
-    const FT inv_T = M::rcp(T);
+    const FT inv_T = M::rcp_nz(T);                  // temperature, pressure, R_m, cp_m: positive and finite
     // TD.gas_constant_air, cp_m, latent heat, air density, vapour pressures — AA:152-160
     const FT R_m = c.R_d * (FT(1) + (c.Rv_over_Rd - FT(1)) * q_tot - c.Rv_over_Rd * (q_liq + q_ice));
     const FT cp_m = M::fma(c.cpm_qi, q_ice, M::fma(c.cpm_ql, q_liq, M::fma(c.cpm_qt, q_tot, c.cp_d)));
     const FT L_v = M::fma(c.dcp_l, T - c.T_0, c.LH_v0);
-    const FT inv_Rm = M::rcp(R_m), inv_cp = M::rcp(cp_m);
+    const FT inv_Rm = M::rcp_nz(R_m), inv_cp = M::rcp_nz(cp_m);
     const FT rho_air = p * inv_Rm * inv_T;
     const FT p_v = (q_tot - q_liq - q_ice) * rho_air * c.R_v * T;
     const FT l2_TT = M::log2(T * c.inv_T_tr), dinvT = c.inv_T_tr - inv_T;
     const FT l2_pvs = M::fma(c.psl_a, l2_TT, M::fma(c.psl_b, dinvT, c.ps_c0));
-    const FT inv_pvs = M::exp2(-l2_pvs);
+    const FT inv_pvs = M::exp2_fin(-l2_pvs);          // overflow → +Inf is still right (capped by inv_eps_1m below)
     const FT LoRT = L_v * c.inv_R_v * inv_T;
     // 1/G_liq = L/(K T)(L/(R_v T) − 1) + R_v T/(D max(p_vs, ϵ))  (Common.jl:47-63); 1/max(p_vs, ϵ) = min(1/p_vs, 1/ϵ).  Only the
     // reciprocal of G = G_liq/ρ_w enters S_max (αw/G), so G itself is formed only for the sink terms.
     const FT inv_G_liq = M::fma(L_v * c.inv_K * inv_T, LoRT - FT(1), c.Rv_over_D * T * M::min(inv_pvs, c.inv_eps_1m));
     const FT ratio = p_v * inv_pvs;
     const FT alpha = ratio * (LoRT * c.g * inv_cp * inv_T - c.g * inv_Rm * inv_T);                       // AA:164
-    const FT gamma = M::fma(ratio * R_m * L_v, LoRT * inv_cp * M::rcp(p), c.R_v * T * inv_pvs);          // AA:165
+    const FT gamma = M::fma(ratio * R_m * L_v, LoRT * inv_cp * M::rcp_nz(p), c.R_v * T * inv_pvs);       // AA:165
     const FT aw = alpha * w;
     const FT aw_over_G = aw * c.rho_w * inv_G_liq;
     // A = A_c/T (AA:35-40), ζ = ⅔ A √(αw/G) (AA:168) and X = (αw/G)^1.5/(2π ρw γ) (η_i = X/N_i) assembled in the log2 domain from
@@ -192,8 +192,8 @@ __device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, cons
     // Σ_i (1/Sm_i²)·[f_i (ζ/η_i)^p1 + g_i (Sm_i²/(η_i+3ζ))^p2] — AA:170-183.  Everything that depends only on the mode is
     // folded on the host (ArgModeConsts); per state three shared powers, per mode one log2 + one exp2.
     const FT Z1 = M::exp2(c.p1 * (l2_zeta - l2_X));            // (ζ/X)^p1
-    const FT A3p2 = M::exp2(FT(2) * c.p2 * l2_A15);            // A^(3 p2)
-    const FT Am15 = M::exp2(-l2_A15);                          // A^(−3/2)
+    const FT A3p2 = M::exp2_fin(FT(2) * c.p2 * l2_A15);            // A^(3 p2)
+    const FT Am15 = M::exp2_fin(-l2_A15);                         // A^(−3/2)
     // with the mode-only factors c1_i, c2_i the sum is  A⁻³·(Z1 Σ c1_i + A^(3p2) Σ c2_i (η_i + 3ζ)^(−p2)): per mode one
     // multiply, one FMA, one log2, one exp2 and one accumulating FMA
     FT sum1 = FT(0), sum2 = FT(0);

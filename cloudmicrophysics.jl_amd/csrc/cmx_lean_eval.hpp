@@ -30,6 +30,9 @@ __global__ __launch_bounds__(kBlock) void lean_eval_kernel(const int which, cons
         case 8: r = lean::log1p(v); break;
         case 9: r = lean::erfc(v); break;
         case 10: r = lean::lgamma_pos(v); break;
+            case 11: r = lean::exp2_fin(v); break;
+            case 12: r = lean::exp_fin(v); break;
+            case 13: r = lean::rcp_finite(v); break;
         default: break;
     }
     y[i] = r;

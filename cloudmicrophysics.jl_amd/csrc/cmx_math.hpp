@@ -55,6 +55,9 @@ template <> struct Math<float> {
     static __device__ __forceinline__ float exp2(float x) { return hw::exp2(x); }
     static __device__ __forceinline__ float log2(float x) { return hw::log2(x); }
     static __device__ __forceinline__ float rcp(float x) { return hw::rcp(x); }
+    // the finite-argument forms of the Float64 side (below): the hardware instructions handle every special value at no cost
+    static __device__ __forceinline__ float exp2_fin(float x) { return hw::exp2(x); }
+    static __device__ __forceinline__ float rcp_nz(float x) { return hw::rcp(x); }
     static __device__ __forceinline__ float sqrt(float x) { return hw::sqrt(x); }
     static __device__ __forceinline__ float rsqrt(float x) { return hw::rsq(x); }
     static __device__ __forceinline__ float div(float a, float b) { return a * rcp(b); }
@@ -87,6 +90,11 @@ template <> struct Math<double> {
     static __device__ __forceinline__ double exp2(double x) { return lean::exp2(x); }
     static __device__ __forceinline__ double log2(double x) { return lean::log2(x); }
     static __device__ __forceinline__ double rcp(double x) { return lean::rcp(x); }
+    // exp2_fin: the argument is finite or NaN (never ±Inf); rcp_nz: the argument is finite and non-zero, or NaN.  They drop the clamp /
+    // NaN select (5 instructions) and the 0 / Inf fix-up (3 instructions) of the full forms; NaN still propagates.  Every call site
+    // states why its argument qualifies; CMX_F64_FINITE_FORMS=0 (cmx_lean_f64.hpp) maps them back to the full forms for A/B runs.
+    static __device__ __forceinline__ double exp2_fin(double x) { return lean::exp2_fin(x); }
+    static __device__ __forceinline__ double rcp_nz(double x) { return CMX_F64_FINITE_FORMS ? lean::rcp_finite(x) : lean::rcp(x); }
     static __device__ __forceinline__ double sqrt(double x) { return lean::sqrt(x); }
     static __device__ __forceinline__ double rsqrt(double x) { return lean::rsqrt(x); }
     static __device__ __forceinline__ double div(double a, double b) { return a * lean::rcp(b); }

@@ -217,7 +217,7 @@ template <typename FT, bool REGULAR> __device__ __forceinline__ FT logistic_rate
     if constexpr (!REGULAR)
         if (qthr < eps) return x < eps ? FT(0) : x * inv_tau;
     const FT y2 = x * y2c;
-    const FT lg2 = M::log2(M::fma(emk, M::exp2(M::min(y2, FT(60.0 * 1.4426950408889634))), omemk));
+    const FT lg2 = M::log2(M::fma(emk, M::exp2_fin(M::min(y2, FT(60.0 * 1.4426950408889634))), omemk));   // y2 = x·y2c, x ≥ 0 finite
     return x < eps ? FT(0) : M::max(lg2, y2 - kl2e) * out;
 }
 
@@ -232,13 +232,13 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     // clamp_to_nonneg — BMT:147-152 (T is not clamped)
     rho = max0(rho); q_tot = max0(q_tot); q_lcl = max0(q_lcl);
     q_icl = max0(q_icl); q_rai = max0(q_rai); q_sno = max0(q_sno);
-    const FT inv_rho = M::rcp(rho), inv_T = M::rcp(T);
+    const FT inv_rho = M::rcp(rho), inv_T = M::rcp_nz(T);      // T: a temperature (positive, finite); ρ may arrive clamped to 0
     const bool has_lcl = q_lcl > eps, has_icl = q_icl > eps, has_rai = q_rai > eps, has_sno = q_sno > eps;
 
     // ---- thermodynamics, once -------------------------------------------------------------------------------
     const FT l2_TT = M::log2(T * c->inv_T_tr), dinvT = c->inv_T_tr - inv_T;
-    const FT psat_l = M::exp2(M::fma(c->psl_a, l2_TT, M::fma(c->psl_b, dinvT, c->ps_c0)));
-    const FT psat_i = M::exp2(M::fma(c->psi_a, l2_TT, M::fma(c->psi_b, dinvT, c->ps_c0)));
+    const FT psat_l = M::exp2_fin(M::fma(c->psl_a, l2_TT, M::fma(c->psl_b, dinvT, c->ps_c0)));
+    const FT psat_i = M::exp2_fin(M::fma(c->psi_a, l2_TT, M::fma(c->psi_b, dinvT, c->ps_c0)));
     const FT dT0 = T - c->T_0;
     const FT L_v = M::fma(c->dcp_l, dT0, c->LH_v0), L_s = M::fma(c->dcp_i, dT0, c->LH_s0), L_f = M::fma(c->dcp_f, dT0, c->LH_f0);
     const FT q_liq = q_lcl + q_rai, q_ice = q_icl + q_sno;
@@ -247,14 +247,14 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     const FT rho_RvT = rho * (c->R_v * T);
     const FT inv_rho_RvT = inv_rho * inv_RT;                                      // 1/(ρ R_v T) from the two reciprocals at hand
     const FT cp_air = M::fma(c->cpm_qi, q_ice, M::fma(c->cpm_ql, q_liq, M::fma(c->cpm_qt, q_tot, c->cp_d)));
-    const FT inv_cp = M::rcp(cp_air);
+    const FT inv_cp = M::rcp_nz(cp_air);
     const FT dTf = T - c->T_freeze;
     const bool above_freezing = T > c->T_freeze;
     o.qsat_l = psat_l * inv_rho_RvT; o.qsat_i = psat_i * inv_rho_RvT;
     // (L/(R_v T) − 1)/T: the factor of dq_sat/dT (NonEq dqcld_dT) and of the conduction term of the G functions (Common.jl:47-102)
     const FT u_v = M::fma(L_v, inv_RT, FT(-1)) * inv_T, u_s = M::fma(L_s, inv_RT, FT(-1)) * inv_T;
     if (fl & CMX_1M_CLOUD_LIQUID_FORMATION) {   // NonEq:117-140: S < 0 ? −min(−S, q)/(τΓ) : S/(τΓ)  =  max(S, −q)/(τΓ) for q ≥ 0
-        const FT inv_ts = M::rcp(c->tau_l * M::fma(L_v * inv_cp, o.qsat_l * u_v, FT(1)));
+        const FT inv_ts = M::rcp_nz(c->tau_l * M::fma(L_v * inv_cp, o.qsat_l * u_v, FT(1)));
         o.vap_lcl = M::max(q_vap - o.qsat_l, -q_lcl) * inv_ts;
     }
     if (fl & (CMX_1M_CLOUD_ICE_FORMATION_CONST | CMX_1M_CLOUD_ICE_FORMATION_TDEP)) {
@@ -262,7 +262,7 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
         const FT cap = above_freezing ? FT(0) : FT(__builtin_inf());
         const FT ex = q_vap - o.qsat_i;
         const FT lim = clamp_ordered(ex, -q_icl, cap);
-        const FT inv_G = M::rcp(M::fma(L_s * inv_cp, o.qsat_i * u_s, FT(1)));
+        const FT inv_G = M::rcp_nz(M::fma(L_s * inv_cp, o.qsat_i * u_s, FT(1)));
         if (fl & CMX_1M_CLOUD_ICE_FORMATION_CONST) {   // NonEq:168-193
             o.vap_icl = lim * (c->inv_tau_i * inv_G);
         } else {   // TemperatureDependent — NonEq:194-224 with τ_dep = τ_relax(…) :32-50 (Frostenberg 2023 INP number, spherical crystals)
@@ -282,8 +282,8 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     const FT S_i = M::fma(pv, inv_ps_i, FT(-1));                                  // …over_ice
     // 1/max(p_sat, ϵ) = min(1/p_sat, 1/ϵ): the reciprocal is shared with the supersaturation
     const FT RvDT = c->Rv_over_D * T;
-    const FT G_l = M::rcp(M::fma(L_v * c->inv_K, u_v, RvDT * M::min(inv_ps_l, c->inv_eps)));   // Common.jl:47-63
-    const FT G_i = M::rcp(M::fma(L_s * c->inv_K, u_s, RvDT * M::min(inv_ps_i, c->inv_eps)));   // :83-102
+    const FT G_l = M::rcp_nz(M::fma(L_v * c->inv_K, u_v, RvDT * M::min(inv_ps_l, c->inv_eps)));   // Common.jl:47-63
+    const FT G_i = M::rcp_nz(M::fma(L_s * c->inv_K, u_s, RvDT * M::min(inv_ps_i, c->inv_eps)));   // :83-102
     const FT SG_i = S_i * G_i;
 
     c = &consts_after(*c, SG_i);
@@ -292,17 +292,17 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     // snow: n0 = μ (ρ max(q, ϵ))^ν if q > ϵ else 0 (get_n0 :83-86); λ⁻¹ uses max(n0, ϵ).  For q ≤ ϵ every snow term is gated to 0 below
     // (through n0 = 0 or has_sno), so the slope parameter only has to stay finite there: no select on log2 n0
     const FT l2_n0_sno = M::fma(c->sno_nu, l2_rq_sno, c->sno_l2_mu);
-    const FT n0_sno = has_sno ? M::exp2(l2_n0_sno) : FT(0);
+    const FT n0_sno = has_sno ? M::exp2_fin(l2_n0_sno) : FT(0);      // finite where q_sno > ϵ; the other side of the select is discarded
     const FT l2_rqn_sno = l2_rq_sno - M::max(l2_n0_sno, c->l2_eps);
-    const FT li_icl = M::exp2(M::max(c->lam_floor_icl, M::fma(l2_rq_icl, c->lam_a_icl, c->lam_b_icl)));
+    const FT li_icl = M::exp2_fin(M::max(c->lam_floor_icl, M::fma(l2_rq_icl, c->lam_a_icl, c->lam_b_icl)));
     // powers of the two slope parameters (see kDefExpBit): rain r = λ⁻¹^¼, snow s = λ⁻¹^⅛
     FT l2_li_rai = FT(0), l2_li_sno = FT(0), li_rai, li_sno, li2_rai, li2_sno;
     FT pr_half = FT(0), pr_075 = FT(0), pr_3h = FT(0), pr_r12 = FT(0), pw_rs = FT(0), ps_q = FT(0), ps_58 = FT(0), pw_sr = FT(0), ps_3q = FT(0);
     if constexpr (DEFEXP) {
-        const FT r = M::exp2(M::max(c->lamp_floor_rai, M::fma(l2_rq_rai, c->lamp_a_rai, c->lamp_b_rai)));
+        const FT r = M::exp2_fin(M::max(c->lamp_floor_rai, M::fma(l2_rq_rai, c->lamp_a_rai, c->lamp_b_rai)));
         const FT r2 = r * r, r4 = r2 * r2, r8 = r4 * r4, r12 = r8 * r4;
         li_rai = r4; li2_rai = r8; pr_half = r2; pr_075 = r2 * r; pr_3h = r12 * r2; pr_r12 = r12;
-        const FT s = M::exp2(M::max(c->lamp_floor_sno, M::fma(l2_rqn_sno, c->lamp_a_sno, c->lamp_b_sno)));
+        const FT s = M::exp2_fin(M::max(c->lamp_floor_sno, M::fma(l2_rqn_sno, c->lamp_a_sno, c->lamp_b_sno)));
         const FT s2 = s * s, s4 = s2 * s2, s8 = s4 * s4, s16 = s8 * s8, s24 = s16 * s8;
         li_sno = s8; li2_sno = s16; ps_q = s2; ps_58 = s4 * s; ps_3q = s24 * s2;
         pw_rs = s8 * (r8 * r8);      // λ_sno⁻¹ λ_rai⁻⁴
@@ -310,7 +310,7 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     } else {
         l2_li_rai = M::max(c->lam_floor_rai, M::fma(l2_rq_rai, c->lam_a_rai, c->lam_b_rai));
         l2_li_sno = M::max(c->lam_floor_sno, M::fma(l2_rqn_sno, c->lam_a_sno, c->lam_b_sno));
-        li_rai = M::exp2(l2_li_rai); li_sno = M::exp2(l2_li_sno); li2_rai = li_rai * li_rai; li2_sno = li_sno * li_sno;
+        li_rai = M::exp2_fin(l2_li_rai); li_sno = M::exp2_fin(l2_li_sno); li2_rai = li_rai * li_rai; li2_sno = li_sno * li_sno;
     }
     // get_v0 :101-104: v0_rai = v0c · sq (v0c folded into the constants)
     const FT sq = M::sqrt(max0(M::fma(c->rho_w, inv_rho, FT(-1))));
@@ -324,8 +324,8 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     if (fl & CMX_1M_SNOW_ACNV_NO_SUPERSAT) {
         o.acnv_icl_sno = logistic_rate<FT, DEFEXP && sizeof(FT) == 4>(q_icl, c->ks_qthr, c->ks_y2, c->ks_emk, c->ks_omemk, c->ks_kl2e, c->ks_out, c->ks_inv_tau, eps);
     } else if (fl & CMX_1M_SNOW_ACNV_WITH_SUPERSAT) {
-        const FT x = c->r_is * M::rcp(li_icl);
-        const FT rate = c->four_pi_n0_icl * SG_i * inv_rho * M::exp2(x * FT(-1.4426950408889634)) *
+        const FT x = c->r_is * M::rcp_nz(li_icl);                 // ≥ 2^floor > 0
+        const FT rate = c->four_pi_n0_icl * SG_i * inv_rho * M::exp2_fin(x * FT(-1.4426950408889634)) *
                         M::fma(x + FT(1), li_icl * li_icl, c->r_is2_over_me);
         o.acnv_icl_sno = (has_icl && S_i > FT(0) && T < c->T_freeze) ? rate : FT(0);
     }
@@ -333,33 +333,33 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     c = &consts_after(*c, o.acnv_icl_sno);
     // ---- accretion — CM1:491-897, routed by temperature as in BMT:171-198 ----------------------------------------
     o.is_warm = T >= c->T_freeze;
-    const FT w_melt = M::rcp(L_f) * max0(dTf);            // (T − T_freeze)/L_f above freezing, 0 at and below
+    const FT w_melt = M::rcp_nz(L_f) * max0(dTf);            // (T − T_freeze)/L_f above freezing, 0 at and below
     o.alpha = c->cv_l * w_melt;                           // warm_accretion_melt_factor :458-465
-    const FT A_rai = sq * (DEFEXP ? pr_3h : M::exp2(c->acc_e_rai * l2_li_rai));
-    const FT A_sno = n0_sno * (DEFEXP ? ps_3q : M::exp2(c->acc_e_sno * l2_li_sno));
+    const FT A_rai = sq * (DEFEXP ? pr_3h : M::exp2_fin(c->acc_e_rai * l2_li_rai));
+    const FT A_sno = n0_sno * (DEFEXP ? ps_3q : M::exp2_fin(c->acc_e_sno * l2_li_sno));
     if (fl & CMX_1M_ACCR_LCL_RAI) o.accr_lcl_rai = (has_lcl && has_rai) ? (q_lcl * c->acc_k_lcl_rai) * A_rai : FT(0);
     if (fl & CMX_1M_ACCR_LCL_SNO) o.S_lcl_sno = (has_lcl && has_sno) ? (q_lcl * c->acc_k_lcl_sno) * A_sno : FT(0);
     if (fl & CMX_1M_ACCR_ICL_RAI) {
         const bool both = has_icl && has_rai;
         o.accr_icl_rai = both ? (q_icl * c->acc_k_icl_rai) * A_rai : FT(0);
         // λ_rai⁻^6½ = λ_rai⁻^3½ · λ_rai⁻³
-        const FT p = DEFEXP ? A_rai * pr_r12 : sq * M::exp2(c->sink_e * l2_li_rai);
+        const FT p = DEFEXP ? A_rai * pr_r12 : sq * M::exp2_fin(c->sink_e * l2_li_rai);
         o.freeze_icl_rai = both ? (c->sink_k * inv_rho) * (li_icl * p) : FT(0);
     }
     if (fl & CMX_1M_ACCR_ICL_SNO) o.accr_icl_sno = (has_icl && has_sno) ? (q_icl * c->acc_k_icl_sno) * A_sno : FT(0);
     c = &consts_after(*c, A_sno);
     const FT nir_sno = n0_sno * inv_rho;
     if (fl & CMX_1M_ACCR_RAI_SNO) {   // CM1:604-644, 815-867 (the fall speeds of absent species are not needed: the term is gated on both)
-        const FT v_rai = (c->vt_k_rai * sq) * (DEFEXP ? pr_half : M::exp2(c->vt_e_rai * l2_li_rai));
-        const FT v_sno = c->vt_k_sno * (DEFEXP ? ps_q : M::exp2(c->vt_e_sno * l2_li_sno));
+        const FT v_rai = (c->vt_k_rai * sq) * (DEFEXP ? pr_half : M::exp2_fin(c->vt_e_rai * l2_li_rai));
+        const FT v_sno = c->vt_k_sno * (DEFEXP ? ps_q : M::exp2_fin(c->vt_e_sno * l2_li_sno));
         const FT dv = v_sno - v_rai;
         const FT dv_eff = M::sqrt(M::fma(dv, dv, c->coeff_disp * M::fma(v_sno, v_sno, v_rai * v_rai)));
         const FT pre = nir_sno * dv_eff;
         const bool both = has_rai && has_sno;
         const FT X = li_sno * li_rai;
         if constexpr (!DEFEXP) {
-            pw_rs = M::exp2(M::fma(c->rs_dp1_rai, l2_li_rai, l2_li_sno));
-            pw_sr = M::exp2(M::fma(c->rs_dp1_sno, l2_li_sno, l2_li_rai));
+            pw_rs = M::exp2_fin(M::fma(c->rs_dp1_rai, l2_li_rai, l2_li_sno));
+            pw_sr = M::exp2_fin(M::fma(c->rs_dp1_sno, l2_li_sno, l2_li_rai));
         }
         // i = snow, j = rain (δ of rain);  i = rain, j = snow (δ of snow)
         const FT poly_rs = M::fma(c->rs_q2_rai, li2_rai, M::fma(c->rs_q1_rai, X, li2_sno));
@@ -371,10 +371,10 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     c = &consts_after(*c, o.S_sno_rai);
     // ---- ventilated vapour exchange and melting — CM1:917-1139 ---------------------------------------------------
     if (fl & CMX_1M_RAIN_EVAPORATION) {   // min(0, S G 4π n0/ρ λ⁻² F) with the factor of S ≥ 0: the min moves onto S
-        const FT F4 = M::fma(c->ven_b_rai * M::sqrt(sq), DEFEXP ? pr_075 : M::exp2(c->ven_e_rai * l2_li_rai), c->ven_a_rai);
+        const FT F4 = M::fma(c->ven_b_rai * M::sqrt(sq), DEFEXP ? pr_075 : M::exp2_fin(c->ven_e_rai * l2_li_rai), c->ven_a_rai);
         o.vap_rai = has_rai ? (inv_rho * li2_rai) * (F4 * (M::min(S_l, FT(0)) * G_l)) : FT(0);
     }
-    const FT F4_sno = M::fma(c->ven_b_sno, DEFEXP ? ps_58 : M::exp2(c->ven_e_sno * l2_li_sno), c->ven_a_sno);
+    const FT F4_sno = M::fma(c->ven_b_sno, DEFEXP ? ps_58 : M::exp2_fin(c->ven_e_sno * l2_li_sno), c->ven_a_sno);
     const FT mp_sno = (nir_sno * li2_sno) * F4_sno;                                // 4π n0/ρ λ⁻² F
     if (fl & (CMX_1M_SNOW_SUBLIMATION_ONLY | CMX_1M_SNOW_DEP_AND_SUBL)) {
         const FT rate = has_sno ? mp_sno * SG_i : FT(0);
@@ -471,15 +471,15 @@ __device__ __forceinline__ void mp1m_linearized_point(const C &c, AF args, int n
         // _linearized_implicit_step — BMT:381-465
         const FT q_sat_min = M::min(p.qsat_l, p.qsat_i);
         const FT q_v = (((q_tot - ql) - qi) - qr) - qs;
-        const FT alpha = M::min(FT(1), M::max(FT(0), q_v - q_sat_min) * a.inv_dt_sub * M::rcp(M::max((e1 + e2) + e4, M::eps())));
+        const FT alpha = M::min(FT(1), M::max(FT(0), q_v - q_sat_min) * a.inv_dt_sub * M::rcp_nz(M::max((e1 + e2) + e4, M::eps())));
         const FT a11 = a.inv_dt_sub - M11, a22 = a.inv_dt_sub - M22, a33 = a.inv_dt_sub - M33, a44 = a.inv_dt_sub - M44;
         const FT b1 = M::fma(alpha, e1, a.inv_dt_sub * ql), b2 = M::fma(alpha, e2, a.inv_dt_sub * qi), b3 = a.inv_dt_sub * qr,
                  b4 = M::fma(alpha, e4, a.inv_dt_sub * qs);
-        const FT inv_det12 = M::rcp(a11 * a22);
+        const FT inv_det12 = M::rcp_nz(a11 * a22);                          // a_kk ≥ 1/Δt_sub > 0
         const FT ql_new = M::fma(b1, a22, M12 * b2) * inv_det12, qi_new = a11 * b2 * inv_det12;
         const FT r3 = M::fma(M31, ql_new, b3);
         const FT r4 = M::fma(M41, ql_new, M::fma(M42, qi_new, b4));
-        const FT inv_det = M::rcp(M::fma(-M34, M43, a33 * a44));
+        const FT inv_det = M::rcp_nz(M::fma(-M34, M43, a33 * a44));          // a33 ≥ 1/Δt + M43, a44 ≥ 1/Δt + M34: positive
         const FT qr_new = M::fma(r3, a44, M34 * r4) * inv_det, qs_new = M::fma(a33, r4, r3 * M43) * inv_det;
         const FT dl = (ql_new - ql) * a.inv_dt_sub, di = (qi_new - qi) * a.inv_dt_sub, dr = (qr_new - qr) * a.inv_dt_sub,
                  ds = (qs_new - qs) * a.inv_dt_sub;

@@ -57,7 +57,9 @@ template <> struct PM<double> {
 #if CMX_P3_SCALAR_COEFS
     struct Coefs {};
     static __device__ __forceinline__ Coefs coefs() { return {}; }
-    static __device__ __forceinline__ double exp(double x, const Coefs &) { return lean::exp(x); }
+    // the two-argument forms are the quadrature-integrand forms: their exponents are finite combinations of ln D, D and per-state
+    // constants at interior nodes D > 0 — the finite-argument exponential (no clamp, no NaN select; NaN still propagates)
+    static __device__ __forceinline__ double exp(double x, const Coefs &) { return lean::exp_fin(x); }
     static __device__ __forceinline__ double log(double x, const Coefs &) { return lean::log(x); }
 #else
 #if CMX_P3_TABLE_MATH
@@ -67,7 +69,7 @@ template <> struct PM<double> {
     using Coefs = lean::PinnedCoefs;
     static __device__ __forceinline__ Coefs coefs() { return lean::pinned_coefs(); }
 #endif
-    static __device__ __forceinline__ double exp(double x, const Coefs &k) { return lean::exp(x, k); }
+    static __device__ __forceinline__ double exp(double x, const Coefs &k) { return lean::exp_fin(x, k); }   // integrand form: see above
     static __device__ __forceinline__ double log(double x, const Coefs &k) { return lean::log(x, k); }
 #endif
     static __device__ __forceinline__ void pin(double &x) { lean::pin(x); }

@@ -273,25 +273,25 @@ __device__ __forceinline__ void sb2006_rain_velocity(const C &c, FT rho, FT rs_r
     vt_n = FT(0);
     vt_m = FT(0);
     if constexpr (VEL == VEL_SB) {   // CM2:685-702, helper :720-739
-        const FT Dr_mean = M::exp2(-l2_lam);
+        const FT Dr_mean = M::exp2_fin(-l2_lam);          // l2_lam: finite combination of log2 of clamped positives
         FT pa0 = FT(1), pb0 = FT(1), pa1 = FT(1), pb1 = FT(1);
         if constexpr (!LIMITED) {
-            const FT lam = M::exp2(l2_lam);
+            const FT lam = M::exp2_fin(l2_lam);
             const FT ta = c.rc2 * lam, tb = c.rc2 * (lam + c.cR);
-            pa0 = M::exp2(ta * FT(-1.4426950408889634));
+            pa0 = M::exp2_fin(ta * FT(-1.4426950408889634));
             pb0 = pa0 * c.e_rc2cR;
             pa1 = (((ta + FT(3)) * ta + FT(6)) * ta + FT(6)) * pa0 * FT(1.0 / 6.0);
             pb1 = (((tb + FT(3)) * tb + FT(6)) * tb + FT(6)) * pb0 * FT(1.0 / 6.0);
         }
         const FT s = c.vel_s * rs_rho;
-        const FT inv_d1 = M::rcp(M::fma(c.cR, Dr_mean, FT(1)));
+        const FT inv_d1 = M::rcp_nz(M::fma(c.cR, Dr_mean, FT(1)));      // ≥ 1
         const FT inv_d2 = inv_d1 * inv_d1;
         const FT vt0 = M::max(FT(0), s * (c.aR * pa0 - c.bR * pb0 * inv_d1));
         const FT vt1 = M::max(FT(0), s * (c.aR * pa1 - c.bR * pb1 * (inv_d2 * inv_d2)));
         vt_n = no_N_rai ? FT(0) : vt0;
         vt_m = no_q_rai ? FT(0) : vt1;
     } else if constexpr (VEL == VEL_CHEN || VEL == VEL_CHEN_GEN) {   // CM2:703-719, Common.jl:290-302, 414-422
-        const FT lam = M::exp2(l2_lam);
+        const FT lam = M::exp2_fin(l2_lam);
         const FT rho_c = M::max(rho, FT(0));
         const FT l2_q = c.ch_rho0_l2e * rho_c;                  // log2 exp(ρ0 ρ)
         const FT l2_rho = M::log2(rho_c);
@@ -351,10 +351,10 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, F
 
     // ---- thermodynamics: one p_sat(T) shared by cond/evap, S and G -----------------------------
     const C &c = c0;
-    const FT inv_T = M::rcp(T);
+    const FT inv_T = M::rcp_nz(T);                                           // a temperature: positive, finite
     const FT L_v = M::fma(c.dcp, T - c.T_0, c.LH_v0);                       // TD.latent_heat_vapor
     const FT l2_ps = M::fma(c.ps_a, M::log2(T * c.inv_T_tr), M::fma(c.ps_b, c.inv_T_tr - inv_T, c.ps_c0));
-    const FT p_sat = M::exp2(l2_ps);                                         // TD.saturation_vapor_pressure
+    const FT p_sat = M::exp2_fin(l2_ps);                                       // TD.saturation_vapor_pressure
     const FT q_liq = q_lcl + q_rai;
     FT q_vap = M::max(FT(0), q_tot - q_liq);                                 // TDI.q_vap (q_ice = q_sno = 0)
     if constexpr (ICE) q_vap = M::max(FT(0), (q_tot - q_liq) - q_ice);
@@ -369,14 +369,14 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, F
         const FT dqsl_dT = q_sat * (LoRT * inv_T - inv_T);                   // dqcld_dT NonEq:74-76
         // gamma_helper NonEq:88-90: Γ = 1 + (L/cp)·dq/dT = (cp + L·dq/dT)/cp, so 1/(τΓ) needs one reciprocal, not two
         const FT excess = q_vap - q_sat;
-        const FT inv_ts = cp_air * M::rcp(c.tau_ce * M::fma(L_v, dqsl_dT, cp_air));
+        const FT inv_ts = cp_air * M::rcp_nz(c.tau_ce * M::fma(L_v, dqsl_dT, cp_air));
         const FT evap_lim = -M::min(-excess, M::max(FT(0), q_lcl));
         r.cond = (excess < FT(0) ? evap_lim : excess) * inv_ts;
     }
     const FT S = M::fma(q_vap * rho_RvT, inv_p_sat, FT(-1));                 // TDI.supersaturation_over_liquid
     // G_func_liquid  Common.jl:47-63
     const FT inv_p_safe = M::min(inv_p_sat, c.inv_eps_1m);                  // 1/max(p_sat, ϵ)
-    const FT G = M::rcp(M::fma(L_v * c.inv_K * inv_T, LoRT - FT(1), c.Rv_over_D * T * inv_p_safe));
+    const FT G = M::rcp_nz(M::fma(L_v * c.inv_K * inv_T, LoRT - FT(1), c.Rv_over_D * T * inv_p_safe));
 
     // ---- cloud side: autoconversion, cloud self-collection, accretion --------------------------
     const FT sq_lcl = M::max(q_lcl, eps);
@@ -385,26 +385,26 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, F
     const FT sN_rai = M::max(N_rai, eps);
     const FT L_lcl = rho * sq_lcl;
     const FT L_rai = rho * sq_rai;
-    const FT x_lcl_raw = L_lcl * M::rcp(sN_lcl);
+    const FT x_lcl_raw = L_lcl * M::rcp_nz(sN_lcl);                       // sN ≥ eps
     const bool no_q_lcl = q_lcl < eps, no_N_lcl = N_lcl < eps, no_q_rai = q_rai < eps;
     // τ = 1 − q_l/(q_l+q_r) (Eq. 5) in its cancellation-free form q_r/(q_l+q_r); 1−τ likewise.
     // With q_rai < eps the reference's two τ (max(0,q_r) in CM2:407 vs max(q_r,eps) in :450) differ,
     // but there ϕ_au ≡ 0 and accretion ≡ 0, so one τ serves both.
-    const FT inv_qsum = M::rcp(sq_lcl + sq_rai);
+    const FT inv_qsum = M::rcp_nz(sq_lcl + sq_rai);                       // ≥ 2 eps
     const FT tau = sq_rai * inv_qsum;
     const FT one_m_tau = sq_lcl * inv_qsum;
     const FT l2_tau = M::log2(tau);
     {   // autoconversion CM2:396-427
         const C &c = consts_after(c0, CMX_PHASE_DEP(G, inv_T));
         const FT x_lcl = M::min(c.x_star, x_lcl_raw);
-        const FT tau_a = M::exp2(c.acnv_a * l2_tau);
+        const FT tau_a = M::exp2_fin(c.acnv_a * l2_tau);                  // τ ∈ [eps², 1]: l2_tau finite
         FT pow_b;
         if constexpr (INTPOW) { const FT u = FT(1) - tau_a; pow_b = u * u * u; }
         else pow_b = M::exp2(c.acnv_b * M::log2(FT(1) - tau_a));
         const FT phi_raw = keep(c.acnv_A * tau_a * pow_b);
         const FT phi_au = no_q_rai ? FT(0) : phi_raw;
         const FT u = (L_lcl * x_lcl) * c.sqrt_kfac;   // √(kcc/20/x*·ν-terms)·L·x̄: keeps L²x̄² inside the f32 range
-        const FT inv_omt = M::rcp(one_m_tau);
+        const FT inv_omt = M::rcp_nz(one_m_tau);                          // 1 − τ = sq_lcl/(sq_lcl + sq_rai) > 0
         const FT dL_rai = (u * u) * M::fma(phi_au, inv_omt * inv_omt, FT(1)) * (c.acnv_rho0 * inv_rho);
         const FT dN_rai = dL_rai * c.inv_x_star;
         const bool gate = no_q_lcl || no_N_lcl;
@@ -424,8 +424,8 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, F
     {   // accretion CM2:445-470
         const C &c = consts_after(c0, CMX_PHASE_DEP(G, inv_T));
         FT pow_c;
-        if constexpr (INTPOW) { const FT t = tau * M::rcp(tau + c.tau_0), t2 = t * t; pow_c = t2 * t2; }
-        else pow_c = M::exp2(c.accr_c * (l2_tau - M::log2(tau + c.tau_0)));
+        if constexpr (INTPOW) { const FT t = tau * M::rcp_nz(tau + c.tau_0), t2 = t * t; pow_c = t2 * t2; }
+        else pow_c = M::exp2_fin(c.accr_c * (l2_tau - M::log2(tau + c.tau_0)));
         const FT phi_ac = keep(pow_c);
         const FT k_ac = c.kcr_s * rs_rho * L_rai * phi_ac;
         const FT dq = keep(k_ac * L_lcl * inv_rho);          // dL_rai/ρ with dL_rai = kcr √(ρ0/ρ) L_lcl L_rai ϕ_ac
@@ -441,34 +441,34 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, F
     const SbRainPsd<FT> psd = sb2006_rain_psd<FT, LIMITED>(c_psd, L_rai, sN_rai);
     const FT l2_xr = psd.l2_xr, l2_lam = psd.l2_lam;
     const FT l2_Dr = (l2_xr + c_psd.l2_Drc) * FT(1.0 / 3.0);
-    const FT Dr = M::exp2(l2_Dr);                       // ∛(6 x̄_r/(π ρw)): CM2:588 and :809
+    const FT Dr = M::exp2_fin(l2_Dr);                      // ∛(6 x̄_r/(π ρw)): CM2:588 and :809
     const bool no_N_rai = N_rai < eps;
     {   // rain_self_collection CM2:545-560 + rain_breakup CM2:579-601
         const C &c = consts_after(c0, CMX_PHASE_DEP(r.ac_dN_lcl, l2_tau));
         // 1/Br = ∛(x̄_r/6) = Dr·∛(π ρw/36): κ_rr/Br = kappa_rr_K·Dr
         FT pw;
-        if constexpr (INTPOW) { const FT r1 = M::rcp(M::fma(c.kappa_rr_K, Dr, FT(1))), r2 = r1 * r1; pw = r2 * r2 * r1; }
-        else pw = M::exp2(c.self_d * M::log2(M::fma(c.kappa_rr_K, Dr, FT(1))));
+        if constexpr (INTPOW) { const FT r1 = M::rcp_nz(M::fma(c.kappa_rr_K, Dr, FT(1))), r2 = r1 * r1; pw = r2 * r2 * r1; }
+        else pw = M::exp2_fin(c.self_d * M::log2(M::fma(c.kappa_rr_K, Dr, FT(1))));
         const FT sc = -c.krr_s * rs_rho * N_rai * L_rai * pw;
         const bool gate = no_q_rai || no_N_rai;
         r.rsc = gate ? FT(0) : sc;
         const FT dD = Dr - c.Deq;
-        const FT br_lin = keep(c.kbr * dD), br_exp = keep(M::exp2(c.kappa_br_l2e * dD) - FT(1));
+        const FT br_lin = keep(c.kbr * dD), br_exp = keep(M::exp2_fin(c.kappa_br_l2e * dD) - FT(1));
         const FT phi_br = (Dr < c.Dr_th) ? FT(-1) : ((Dr <= c.Deq) ? br_lin : br_exp);
         r.rbr = gate ? FT(0) : -(phi_br + FT(1)) * r.rsc;
     }
     {   // rain_evaporation CM2:780-828
         const C &c = consts_after(c0, CMX_PHASE_DEP(r.rbr, l2_xr));
         const FT l2_t = (c.l2_6xstar - l2_xr) * FT(1.0 / 3.0);            // t* = ∛(6 x*/x̄_r)
-        const FT t_star = M::exp2(l2_t);
+        const FT t_star = M::exp2_fin(l2_t);
         // e^{−t*}/x̄_r in one exponential: both factors enter the number tendency only (Γ_incl does not appear in the mass one);
         // the ventilation coefficients a_vent_0, b_vent_0·∛Sc are folded into the Γ_incl denominators on the host
-        const FT e_tx = M::exp2(M::fma(t_star, FT(-1.4426950408889634), -l2_xr));
-        const FT g_a = M::rcp(M::fma(c.ga_c1, M::exp2(c.ga_e1 * l2_t), c.ga_c2 * M::exp2(c.ga_e2 * l2_t)));   // a_vent_0·Γ_incl(−1, t*)·e^{t*}
-        const FT g_b = M::rcp(M::fma(c.gb_c1, M::exp2(c.gb_e1 * l2_t), c.gb_c2 * M::exp2(c.gb_e2 * l2_t)));   // b_vent_0 ∛Sc·Γ_incl(β, t*)·e^{t*}
+        const FT e_tx = M::exp2_fin(M::fma(t_star, FT(-1.4426950408889634), -l2_xr));   // t* ≤ 2^((l2_6x* + 1100)/3): finite
+        const FT g_a = M::rcp_nz(M::fma(c.ga_c1, M::exp2_fin(c.ga_e1 * l2_t), c.ga_c2 * M::exp2_fin(c.ga_e2 * l2_t)));   // both coefficients > 0;   // a_vent_0·Γ_incl(−1, t*)·e^{t*}
+        const FT g_b = M::rcp(M::fma(c.gb_c1, M::exp2_fin(c.gb_e1 * l2_t), c.gb_c2 * M::exp2_fin(c.gb_e2 * l2_t)));   // b_vent_0 ∛Sc·Γ_incl(β, t*)·e^{t*}
         // √N_Re = √(α/ν)·(ρ0/ρ)^¼·√(x̄^β·Dr)
         const FT sqrt_N_Re = c.sqrt_alpha_nu_rho0q * M::sqrt(rs_rho) *
-                             M::exp2(FT(0.5) * M::fma(c.beta, l2_xr, l2_Dr));
+                             M::exp2_fin(FT(0.5) * M::fma(c.beta, l2_xr, l2_Dr));
         const FT Fv0 = M::fma(g_b, sqrt_N_Re, g_a);
         const FT Fv1 = M::fma(c.bSc_vent_1, sqrt_N_Re, c.a_vent_1);
         const FT common = c.two_pi * G * S * N_rai * Dr;

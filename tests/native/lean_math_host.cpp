@@ -16,6 +16,9 @@ extern "C" void lean_eval(int which, int64_t n, const double *x, double *y) {
             case 8: y[i] = L::log1p(x[i]); break;
             case 9: y[i] = L::erfc(x[i]); break;
             case 10: y[i] = L::lgamma_pos(x[i]); break;
+            case 11: y[i] = L::exp2_fin(x[i]); break;
+            case 12: y[i] = L::exp_fin(x[i]); break;
+            case 13: y[i] = L::rcp_finite(x[i]); break;
         }
     }
 }

@@ -27,7 +27,7 @@ def lean(tmp_path_factory):
     return ev
 
 
-EXP2, LOG2, EXP, LOG, RCP, SQRT, RSQRT, EXPM1, LOG1P, ERFC, LGAMMA = range(11)
+EXP2, LOG2, EXP, LOG, RCP, SQRT, RSQRT, EXPM1, LOG1P, ERFC, LGAMMA, EXP2_FIN, EXP_FIN, RCP_NZ = range(14)
 
 
 @pytest.mark.parametrize("script", ["gen_lean_tables.py", "gen_erfc_table.py"])
@@ -164,6 +164,31 @@ def test_device_accuracy_in_ulps(dev_lean):
     assert ulps(dev_lean(LOG2, x), np.log2(x)) <= 2 and ulps(dev_lean(LOG, x), np.log(x)) <= 3
     x = 10.0 ** rng.uniform(-320, -300, 100_000)       # subnormal arguments take the rescue path
     assert ulps(dev_lean(LOG2, x), np.log2(x)) <= 2
+
+
+def test_finite_argument_forms(lean):
+    """exp2_fin / exp_fin / rcp_finite (Math<double>::exp2_fin, rcp_nz): the full forms minus the clamp, the NaN select and the 0 / Inf
+    fix-up.  Same accuracy; finite arguments of ANY size still give the right overflow / underflow result; NaN propagates.  (±Inf into
+    the exponentials and 0 / ±Inf into the reciprocal are outside their contract: the call sites exclude them.)"""
+    rng = np.random.default_rng(21)
+    x = rng.uniform(-1000, 1000, 400_000)
+    assert ulps(lean(EXP2_FIN, x), np.exp2(x)) <= 2
+    np.testing.assert_array_equal(lean(EXP2_FIN, x), lean(EXP2, x))
+    x = rng.uniform(-700, 700, 400_000)
+    np.testing.assert_array_equal(lean(EXP_FIN, x), lean(EXP, x))
+    x = np.concatenate([10.0 ** rng.uniform(-300, 300, 200_000), -10.0 ** rng.uniform(-300, 300, 200_000)])
+    np.testing.assert_array_equal(lean(RCP_NZ, x), lean(RCP, x))
+    with np.errstate(all="ignore"):
+        big = [1100.0, 2000.0, 1e6, 1e12, 1e300, -1100.0, -2000.0, -1e6, -1e12, -1e300, -1074.0, -1060.5]
+        np.testing.assert_array_equal(lean(EXP2_FIN, big), np.exp2(big))
+        eb = [800.0, 1e6, 1e12, -800.0, -1e6, -1e12]            # e^x: the Cody–Waite reduction needs |x|·128/ln2 to be an exact integer (|x| < 2e13)
+        np.testing.assert_array_equal(lean(EXP_FIN, eb), np.exp(eb))
+        assert np.isnan(lean(EXP2_FIN, [np.nan])[0]) and np.isnan(lean(EXP_FIN, [np.nan])[0]) and np.isnan(lean(RCP_NZ, [np.nan])[0])
+
+
+@pytest.mark.gpu
+def test_device_finite_argument_forms(dev_lean):
+    test_finite_argument_forms(dev_lean)
 
 
 @pytest.mark.gpu

@@ -24,7 +24,7 @@ REPO = Path(__file__).resolve().parent.parent
 PROF = REPO / "profiles"
 HBM_PEAK = 8000.0
 ORDER = ["sb2006", "sb2006_chen", "sb2006_column", "sb2006_aos", "sb2006_fields", "mp0m", "icenuc", "mp1m", "mp1m_lin", "mp1m_column", "mp1m_column_lin", "arg2000",
-         "p3_fused", "p3", "p3_selfcol", "mp2m_p3"]
+         "p3_split", "p3", "p3_selfcol", "mp2m_p3"]
 
 
 def latest_round():

@@ -55,7 +55,7 @@ for wl in sb2006 sb2006_column icenuc mp0m mp1m arg2000; do
 done
 bench sb2006_chen_f32 --workload sb2006_chen --dtype f32 --steps 20 --warmup 3
 for dt in f32 f64; do
-  bench p3_fused_${dt} --workload p3_fused --dtype $dt --points 10000000 --steps 5 --warmup 1
+  bench p3_split_${dt} --workload p3_split --dtype $dt --points 10000000 --steps 5 --warmup 1
   bench p3_${dt} --workload p3 --dtype $dt --points 10000000 --steps 5 --warmup 1
   bench p3_selfcol_${dt} --workload p3_selfcol --dtype $dt --points 1000000 --steps 3 --warmup 1
   bench mp1m_lin_${dt} --workload mp1m_lin --dtype $dt --steps 10 --warmup 2
