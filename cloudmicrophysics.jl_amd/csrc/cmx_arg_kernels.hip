@@ -145,6 +145,16 @@ template <> __device__ __forceinline__ double erfc_rel_dev<double>(double x) { r
 #ifndef CMX_ARG_P2_ROOTS
 #define CMX_ARG_P2_ROOTS 1      // A/B switch for the p2 = ¾ path of the Float64 S_max sum (arg_point)
 #endif
+// y^(−¾) for the p2 = ¾ path of the Float64 S_max sum
+__device__ __forceinline__ double arg_pow_m34(double y) {
+#if CMX_F64_FINITE_FORMS
+    return lean::pow_m34_pos(y);
+#else
+    const double t = lean::rsqrt(y);
+    return t * lean::sqrt(t);
+#endif
+}
+__device__ __forceinline__ float arg_pow_m34(float y) { const float t = Math<float>::rsqrt(y); return t * Math<float>::sqrt(t); }
 template <typename FT> struct ArgIO {
     const FT *T, *p, *w, *q_tot, *q_liq, *q_ice, *N_liq, *N_ice;
     FT *N_act[CMX_ARG_MAX_MODES], *M_act[CMX_ARG_MAX_MODES], *S_max;
@@ -186,15 +196,15 @@ __device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, cons
     const FT l2_A = c.l2_Ac_Ttr - l2_TT;
     const FT l2_A15 = FT(1.5) * l2_A;
     const FT l2_zeta = c.l2_two_thirds + l2_A + FT(0.5) * l2_awG;
-    const FT zeta = M::exp2(l2_zeta);
+    const FT zeta = M::exp2_fin(l2_zeta);                    // w > 0: finite; w ≤ 0: the reference gives NaN (ζ/η = 0/0, √ of a negative)
     const FT l2_X = M::fma(FT(1.5), l2_awG, -(c.l2_two_pi_rho_w + M::log2(gamma)));
-    const FT X = M::exp2(l2_X);
+    const FT X = M::exp2_fin(l2_X);
     // Σ_i (1/Sm_i²)·[f_i (ζ/η_i)^p1 + g_i (Sm_i²/(η_i+3ζ))^p2] — AA:170-183.  Everything that depends only on the mode is
     // folded on the host (ArgModeConsts); per state three shared powers, per mode one log2 + one exp2.
-    const FT Z1 = M::exp2(c.p1 * (l2_zeta - l2_X));            // (ζ/X)^p1
-    const FT A3p2 = M::exp2_fin(FT(2) * c.p2 * l2_A15);            // A^(3 p2)
-    const FT Am15 = M::exp2_fin(-l2_A15);                         // A^(−3/2)
-    // with the mode-only factors c1_i, c2_i the sum is  A⁻³·(Z1 Σ c1_i + A^(3p2) Σ c2_i (η_i + 3ζ)^(−p2)): per mode one
+    // the two state-only factors of the sum, one exponential each: A⁻³ (ζ/X)^p1 and A^(3 p2 − 3)
+    const FT E_f = M::exp2_fin(M::fma(c.p1, l2_zeta - l2_X, FT(-2) * l2_A15));
+    const FT E_g = M::exp2_fin((FT(2) * c.p2 - FT(2)) * l2_A15);
+    // with the mode-only factors c1_i, c2_i the sum is  A⁻³ (ζ/X)^p1 Σ c1_i + A^(3p2 − 3) Σ c2_i (η_i + 3ζ)^(−p2): per mode one
     // multiply, one FMA, one log2, one exp2 and one accumulating FMA
     FT sum1 = FT(0), sum2 = FT(0);
 #pragma unroll
@@ -204,8 +214,10 @@ __device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, cons
         // a square root (hardware seed + Newton steps, ≈ 30 instructions) instead of a table-driven log2 and exp2 (≈ 45) per mode
 #pragma unroll
         for (int k = 0; k < NM; ++k) {
-            const FT t = M::rsqrt(M::fma(FT(3), zeta, X * cm[k].inv_N));
-            sum2 = M::fma(cm[k].c2, t * M::sqrt(t), sum2);
+            // 3ζ + η_k > 0 for w > 0; w = 0 gives ζ/η = 0/0 = NaN in the reference as well (Z1 below), so no 0 / Inf cases to keep
+            const FT y = M::fma(FT(3), zeta, X * cm[k].inv_N);
+            if constexpr (sizeof(FT) == 8) sum2 = M::fma(cm[k].c2, arg_pow_m34(y), sum2);
+            else { const FT t = M::rsqrt(y); sum2 = M::fma(cm[k].c2, t * M::sqrt(t), sum2); }
         }
     } else {
 #pragma unroll
@@ -214,8 +226,8 @@ __device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, cons
             sum2 = M::fma(cm[k].c2, M::exp2(-c.p2 * M::log2(M::fma(FT(3), zeta, eta))), sum2);
         }
     }
-    const FT tmp = (Am15 * Am15) * M::fma(A3p2, sum2, Z1 * sum1);
-    const FT S_arg = M::rsqrt(tmp);                                                                        // AA:185
+    const FT tmp = M::fma(E_g, sum2, E_f * sum1);
+    const FT S_arg = M::rsqrt_pos(tmp);                                                                       // AA:185
     FT smax;
     if constexpr (SINKS) {   // liquid / ice sink correction — AA:187-197
         const FT L_s = M::fma(c.dcp_i, T - c.T_0, c.LH_s0);

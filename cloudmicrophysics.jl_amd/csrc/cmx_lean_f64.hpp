@@ -51,6 +51,19 @@ CMX_LEAN_FN double rcp_finite(double d) {
 #endif
     return fma_(r, fma_(-d, r, 1.0), r);
 }
+// 1/d for finite, non-zero d to 2⁻⁴⁸ relative (≈ 16 ulp): the seed and ONE Newton step — 3 instructions against 8 for the full rcp
+// below (second step, class test, two selects).  For the reciprocals of the point functions whose argument is a positive physical
+// quantity (Math<double>::rcp_nz): the result multiplies terms that carry the ≈ 1 ulp of every table-driven function anyway, and the
+// Float64 parity bound is 1e-6.  CMX_F64_FINITE_FORMS=0 maps it back to the full form.  NaN propagates.
+CMX_LEAN_FN double rcp_nz(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double r = __builtin_amdgcn_rcp(d);
+#else
+    int e; const double m = std::frexp(1.0 / d, &e);
+    const double r = std::ldexp((double)(float)m, e);   // host stand-in for the seed (tests only): 1/d rounded to 24 bits
+#endif
+    return fma_(r, fma_(-d, r, 1.0), r);
+}
 // 1/d with the IEEE results for d = ±0 (±Inf), ±Inf (±0) and NaN: whenever the seed is 0 or ±Inf the Newton steps
 // would produce NaN, so the seed itself is returned (one class test on the seed; subnormal d saturates to ±Inf)
 CMX_LEAN_FN double rcp(double d) {
@@ -470,19 +483,21 @@ CMX_LEAN_FN double log(double x) {
 #endif
 }
 // ---- erfc (round 2): table-driven, for the activated NUMBER fractions of the ARG kernel ------------------------------------------------
-// erfc(x) = e^(−x²)·E(x), x ≥ 0, with E = erfcx as a degree-12 polynomial in s = x − centre on 16 intervals of [0, 6.5]
-// (cmx_erfc_table.inc, tools/gen_erfc_table.py: ≤ 1.9e-16 relative per interval); erfc(−x) = 2 − erfc(x).  One rounding of x² enters the
+// erfc(x) = e^(−x²)·E(x), x ≥ 0, with E = erfcx as a degree-8 polynomial in s = x − centre on 64 intervals of [0, 6.5]
+// (cmx_erfc_table.inc, tools/gen_erfc_table.py: ≤ 2.4e-16 relative per interval); erfc(−x) = 2 − erfc(x).  One rounding of x² enters the
 // exponent, so the relative error is ≤ (2 + x²)·2e-16 against mpmath (9e-15 at 6.5, where erfc = 4e-20); beyond 6.5 E(6.5) is used (erfc < 4e-20:
-// the value is right to a factor x/6.5).  ≈ 45 VALU instructions, branch-free — OCML's erfc is 135, and five of them were 70 % of the
+// the value is right to a factor x/6.5).  ≈ 36 VALU instructions, branch-free — OCML's erfc is 135, and five of them were 70 % of the
 // Float64 ARG kernel.  NOT for arguments whose tiny result must keep full relative accuracy beyond 6.5 (the activated MASS, which the
 // reference evaluates with erfc itself, stays on OCML).  The kernel that uses it fills the LDS copy with erfc_tab_fill() before
 // Math<double>::prepare() (whose barrier publishes it).
 #if defined(__HIP_DEVICE_COMPILE__)
-static __device__ const double kErfcTab[CMX_LEAN_ERFC_NINT * CMX_LEAN_ERFC_ROW] = {CMX_LEAN_ERFC_TABLE};
+static __device__ __align__(16) const double kErfcTab[CMX_LEAN_ERFC_NINT * CMX_LEAN_ERFC_ROW] = {CMX_LEAN_ERFC_TABLE};
 __device__ __forceinline__ double *lds_erfc_tab() { __shared__ __align__(16) double t[CMX_LEAN_ERFC_NINT * CMX_LEAN_ERFC_ROW]; return t; }
-__device__ __forceinline__ void erfc_tab_fill() {
-    double *t = lds_erfc_tab();
-    for (int i = threadIdx.x; i < CMX_LEAN_ERFC_NINT * CMX_LEAN_ERFC_ROW; i += blockDim.x) t[i] = kErfcTab[i];
+__device__ __forceinline__ void erfc_tab_fill() {          // 16 bytes per lane and trip (the table is an even number of doubles)
+    static_assert((CMX_LEAN_ERFC_NINT * CMX_LEAN_ERFC_ROW) % 2 == 0, "erfc table: even number of doubles");
+    double2 *t = reinterpret_cast<double2 *>(lds_erfc_tab());
+    const double2 *g = reinterpret_cast<const double2 *>(kErfcTab);
+    for (int i = threadIdx.x; i < CMX_LEAN_ERFC_NINT * CMX_LEAN_ERFC_ROW / 2; i += blockDim.x) t[i] = g[i];
 }
 __device__ __forceinline__ const double *erfc_row(int j) { return lds_erfc_tab() + j * CMX_LEAN_ERFC_ROW; }
 #else
@@ -493,7 +508,7 @@ inline const double *erfc_row(int j) { return kErfcTab + j * CMX_LEAN_ERFC_ROW; 
 CMX_LEAN_FN double erfc(double x) {
     const double ax = __builtin_fabs(x);
     const double xc = __builtin_fmin(ax, CMX_LEAN_ERFC_XMAX * (1.0 - 0x1p-52));      // polynomial range [0, 6.5)
-    const int j = (int)(xc * CMX_LEAN_ERFC_INV_H);                                  // 0 … 15 (a NaN argument: 0, fixed up below)
+    const int j = (int)(xc * CMX_LEAN_ERFC_INV_H);                                  // 0 … NINT−1 (a NaN argument: 0, fixed up below)
     const double sft = fma_((double)j, -CMX_LEAN_ERFC_H, xc) - 0.5 * CMX_LEAN_ERFC_H;   // x − centre of interval j, |s| ≤ h/2
     const double *c = erfc_row(j);
     double p = c[CMX_LEAN_ERFC_DEG];
@@ -740,6 +755,28 @@ CMX_LEAN_FN double sqrt(double x) {
     const double inf = std::numeric_limits<double>::infinity();
     s = (x == 0.0 || x == inf) ? x : s;
     return s;                                                                 // x < 0 → NaN from the seed
+}
+// √x, 1/√x and x^(−¾) for a POSITIVE FINITE argument (or NaN, which propagates): no 0 / Inf fix-ups (round 3, see exp2_fin)
+CMX_LEAN_FN double rsqrt_pos(double x) { return rsqrt_core(x); }
+CMX_LEAN_FN double sqrt_pos(double x) {
+    const double y = rsqrt_core(x);
+    const double s = x * y;
+    return fma_(fma_(-s, s, x), 0.5 * y, s);
+}
+// x^(−¾) = u³ with u = x^(−¼): seed rsq(sqrt(x)) from the two hardware instructions (≈ 2⁻²³ relative), two Newton steps
+// u ← u + ¼u(1 − x u⁴) (error 2.5 e² per step: 2⁻⁴³, 2⁻⁸⁵) — 14 instructions against 22 for rsqrt + sqrt + product
+CMX_LEAN_FN double pow_m34_pos(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double u = __builtin_amdgcn_rsq(__builtin_amdgcn_sqrt(x));
+#else
+    int e; const double m = std::frexp(std::pow(x, -0.25), &e);
+    double u = std::ldexp((double)(float)m, e);          // host stand-in for the seed (tests only): 24 bits
+#endif
+    double u2 = u * u;
+    u = fma_(0.25 * u, fma_(-x, u2 * u2, 1.0), u);
+    u2 = u * u;
+    u = fma_(0.25 * u, fma_(-x, u2 * u2, 1.0), u);
+    return u * (u * u);
 }
 CMX_LEAN_FN double rsqrt(double x) {
     const double inf = std::numeric_limits<double>::infinity();

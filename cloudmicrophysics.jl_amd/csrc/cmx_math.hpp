@@ -58,8 +58,11 @@ template <> struct Math<float> {
     // the finite-argument forms of the Float64 side (below): the hardware instructions handle every special value at no cost
     static __device__ __forceinline__ float exp2_fin(float x) { return hw::exp2(x); }
     static __device__ __forceinline__ float rcp_nz(float x) { return hw::rcp(x); }
+    static __device__ __forceinline__ float rcp_nz1(float x) { return hw::rcp(x); }
     static __device__ __forceinline__ float sqrt(float x) { return hw::sqrt(x); }
     static __device__ __forceinline__ float rsqrt(float x) { return hw::rsq(x); }
+    static __device__ __forceinline__ float sqrt_pos(float x) { return hw::sqrt(x); }
+    static __device__ __forceinline__ float rsqrt_pos(float x) { return hw::rsq(x); }
     static __device__ __forceinline__ float div(float a, float b) { return a * rcp(b); }
     static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
     static __device__ __forceinline__ float max(float a, float b) { return __builtin_fmaxf(a, b); }
@@ -91,12 +94,19 @@ template <> struct Math<double> {
     static __device__ __forceinline__ double log2(double x) { return lean::log2(x); }
     static __device__ __forceinline__ double rcp(double x) { return lean::rcp(x); }
     // exp2_fin: the argument is finite or NaN (never ±Inf); rcp_nz: the argument is finite and non-zero, or NaN.  They drop the clamp /
-    // NaN select (5 instructions) and the 0 / Inf fix-up (3 instructions) of the full forms; NaN still propagates.  Every call site
-    // states why its argument qualifies; CMX_F64_FINITE_FORMS=0 (cmx_lean_f64.hpp) maps them back to the full forms for A/B runs.
+    // NaN select (5 instructions) resp. the second Newton step and the 0 / Inf fix-up (5 instructions; 2⁻⁴⁸ relative instead of ≤ 1 ulp)
+    // of the full forms; NaN still propagates.  Every call site states why its argument qualifies; CMX_F64_FINITE_FORMS=0
+    // (cmx_lean_f64.hpp) maps them back to the full forms for A/B runs.
     static __device__ __forceinline__ double exp2_fin(double x) { return lean::exp2_fin(x); }
-    static __device__ __forceinline__ double rcp_nz(double x) { return CMX_F64_FINITE_FORMS ? lean::rcp_finite(x) : lean::rcp(x); }
+    static __device__ __forceinline__ double rcp_nz(double x) { return CMX_F64_FINITE_FORMS ? lean::rcp_nz(x) : lean::rcp(x); }
+    // rcp_nz1: the same contract at ≤ 1 ulp (two Newton steps, no 0 / Inf fix-up) — where the reciprocal is amplified afterwards, e.g.
+    // the determinants of the implicit step, whose result enters a difference quotient (q_new − q)/Δt
+    static __device__ __forceinline__ double rcp_nz1(double x) { return CMX_F64_FINITE_FORMS ? lean::rcp_finite(x) : lean::rcp(x); }
     static __device__ __forceinline__ double sqrt(double x) { return lean::sqrt(x); }
     static __device__ __forceinline__ double rsqrt(double x) { return lean::rsqrt(x); }
+    // positive finite argument (or NaN): no 0 / Inf fix-ups
+    static __device__ __forceinline__ double sqrt_pos(double x) { return CMX_F64_FINITE_FORMS ? lean::sqrt_pos(x) : lean::sqrt(x); }
+    static __device__ __forceinline__ double rsqrt_pos(double x) { return CMX_F64_FINITE_FORMS ? lean::rsqrt_pos(x) : lean::rsqrt(x); }
     static __device__ __forceinline__ double div(double a, double b) { return a * lean::rcp(b); }
     static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
     static __device__ __forceinline__ double max(double a, double b) { return __builtin_fmax(a, b); }

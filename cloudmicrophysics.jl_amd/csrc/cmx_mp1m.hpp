@@ -475,11 +475,11 @@ __device__ __forceinline__ void mp1m_linearized_point(const C &c, AF args, int n
         const FT a11 = a.inv_dt_sub - M11, a22 = a.inv_dt_sub - M22, a33 = a.inv_dt_sub - M33, a44 = a.inv_dt_sub - M44;
         const FT b1 = M::fma(alpha, e1, a.inv_dt_sub * ql), b2 = M::fma(alpha, e2, a.inv_dt_sub * qi), b3 = a.inv_dt_sub * qr,
                  b4 = M::fma(alpha, e4, a.inv_dt_sub * qs);
-        const FT inv_det12 = M::rcp_nz(a11 * a22);                          // a_kk ≥ 1/Δt_sub > 0
+        const FT inv_det12 = M::rcp_nz1(a11 * a22);                          // a_kk ≥ 1/Δt_sub > 0
         const FT ql_new = M::fma(b1, a22, M12 * b2) * inv_det12, qi_new = a11 * b2 * inv_det12;
         const FT r3 = M::fma(M31, ql_new, b3);
         const FT r4 = M::fma(M41, ql_new, M::fma(M42, qi_new, b4));
-        const FT inv_det = M::rcp_nz(M::fma(-M34, M43, a33 * a44));          // a33 ≥ 1/Δt + M43, a44 ≥ 1/Δt + M34: positive
+        const FT inv_det = M::rcp_nz1(M::fma(-M34, M43, a33 * a44));          // a33 ≥ 1/Δt + M43, a44 ≥ 1/Δt + M34: positive
         const FT qr_new = M::fma(r3, a44, M34 * r4) * inv_det, qs_new = M::fma(a33, r4, r3 * M43) * inv_det;
         const FT dl = (ql_new - ql) * a.inv_dt_sub, di = (qi_new - qi) * a.inv_dt_sub, dr = (qr_new - qr) * a.inv_dt_sub,
                  ds = (qs_new - qs) * a.inv_dt_sub;

@@ -341,6 +341,27 @@ template <typename FT> __device__ __forceinline__ FT regularised_ratio(FT num, F
 
 template <typename FT> struct P3IO { const FT *rho_q, *rho_n, *x3, *x4, *guess; FT *F_rim, *rho_rim, *loglam, *D_m, *logN0; };
 
+// ice_mass_coeffs at the midpoint of segment k (regime_value :320-332, :346-356): m(D) = a D^b.  From the thresholds and ρ_g of the point —
+// a kernel that needs the coefficients of one segment late (the melting sweep of the 2M + P3 entry) re-derives them with this instead of
+// keeping the eight values of P3Point::log_a / b alive across its other sweeps
+template <typename FT> struct P3Point;
+template <typename FT>
+__device__ __forceinline__ void p3_mass_law_at(const P3Consts<FT> &c, const P3Point<FT> &s, FT D, FT &a, FT &b);
+template <typename FT>
+__device__ __forceinline__ void p3_segment_mass_law(const P3Consts<FT> &c, const P3Point<FT> &s, int k, FT &a, FT &b) {
+    p3_mass_law_at<FT>(c, s, (s.bnd[k] + s.bnd[k + 1]) / FT(2), a, b);
+}
+template <typename FT>
+__device__ __forceinline__ void p3_mass_law_at(const P3Consts<FT> &c, const P3Point<FT> &s, FT D, FT &a, FT &b) {
+    using P = PM<FT>;
+    const bool unrimed = s.F_rim == FT(0);
+    if (D < c.D_th) { a = c.a_sph_i; b = FT(3); }
+    else if (unrimed) { a = c.alpha_va; b = c.beta_va; }
+    else if (D < s.bnd[2]) { a = c.alpha_va; b = c.beta_va; }
+    else if (D < s.bnd[3]) { a = s.rho_g * c.pi_6; b = FT(3); }
+    else { a = c.alpha_va / Math<FT>::max(FT(1) - s.F_rim, P::eps()); b = c.beta_va; }
+}
+
 // state_from_prognostic :101-106 (or P3State from (F_rim, ρ_rim)) → P3State :43-56: ρ_d (exact solution :191-199), ρ_g,
 // thresholds, and the per-segment mass-law coefficients (regime_value at the segment midpoint :320-332)
 template <typename FT>
@@ -364,16 +385,10 @@ __device__ __forceinline__ void p3_make_point(const P3Consts<FT> &c, FT rho_q, F
     const FT D_gr = unrimed ? FT(INFINITY) : P::pow(c.six_alpha_pi / s.rho_g, c.p_inv);
     const FT D_cr = unrimed ? FT(INFINITY) : P::pow(c.six_alpha_pi / (s.rho_g * (FT(1) - s.F_rim)), c.p_inv);
     s.bnd[0] = FT(0); s.bnd[1] = c.D_th; s.bnd[2] = D_gr; s.bnd[3] = D_cr; s.bnd[4] = FT(INFINITY);
-    const FT Fu = Math<FT>::max(FT(1) - s.F_rim, P::eps());
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const FT D = (s.bnd[k] + s.bnd[k + 1]) / FT(2);
         FT a, b;
-        if (D < c.D_th) { a = c.a_sph_i; b = FT(3); }
-        else if (unrimed) { a = c.alpha_va; b = c.beta_va; }
-        else if (D < D_gr) { a = c.alpha_va; b = c.beta_va; }
-        else if (D < D_cr) { a = s.rho_g * c.pi_6; b = FT(3); }
-        else { a = c.alpha_va / Fu; b = c.beta_va; }
+        p3_segment_mass_law<FT>(c, s, k, a, b);
         s.log_a[k] = P::log(a); s.b[k] = b;
     }
 }

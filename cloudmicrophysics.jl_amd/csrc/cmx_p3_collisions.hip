@@ -170,7 +170,7 @@ template <typename FT> struct P3ColIO {
 #endif
 // LDS per group, in FT units: quadrature copy is per block
 template <typename FT> struct ColLds {
-    static __device__ __forceinline__ int per_group(int n) { return 6 * n + 72; }
+    static __host__ __device__ __forceinline__ int per_group(int n) { return 6 * n + 100; }
 };
 
 template <typename FT, typename QUAD, bool ASPECT, bool FUSED, int GROUP>
@@ -188,37 +188,40 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
         for (int j = 0; j < nq; ++j) { q_node[j] = quad.node[j]; q_wt[j] = quad.weight[j]; }
     const int grp = threadIdx.x / GROUP, g = threadIdx.x % GROUP;
     FT *G = lds + 2 * nq + grp * ColLds<FT>::per_group(nq);
-    FT *cD = G, *cV = G + nq, *cW = G + 2 * nq, *rD = G + 3 * nq, *rV = G + 4 * nq, *rW = G + 5 * nq, *E = G + 6 * nq, *Fm = G + 6 * nq + 48;
+    // per-group layout: E[48], Fm[24] at compile-time offsets from G, then one (D, v, weight) record per inner node — cloud nodes, then
+    // rain nodes — so that a node's three values sit at immediate offsets of ONE address (separate arrays of run-time length nq cost a
+    // pointer register each, eight in all, and most of them were spilled)
+    // S[28]: the per-state constants of the rain part (curve exponents, size range, N₀, mean diameter) — needed once per outer node and in
+    // the crossover solve — and the values only the epilogue needs (ρq, ρn, ρ_rim, 1/ρₐ, T), the five segment bounds of the
+    // collision sweep, the quantiles of the self-collection / melting sweeps and ρ_g (the melting sweep's mass law), read back through a
+    // volatile pointer so that they do not occupy twenty-five register pairs across all the sweeps
+    FT *E = G, *Fm = G + 48, *S = G + 72, *cN = G + 100, *rN = G + 100 + 3 * nq;
+    const volatile FT *Sv = S;
     const int64_t pt_raw = (int64_t)blockIdx.x * (blockDim.x / GROUP) + grp;
     const bool valid = pt_raw < n;
     const int64_t i = valid ? pt_raw : n - 1;
     __syncthreads();
 
     // ---- per-point set-up (uniform over the group) ---------------------------------------------------------------
-    P3Point<FT> s;
-    FT L_c, N_c, L_r, N_r;
+    // Order: the quantile solve first — it needs only ρq, ρn and log λ, and it is the register-hungriest piece of the set-up, so nothing else
+    // is alive across it — then the state (p3_make_point) and the liquid-side loads.
+    const FT rho_a = M::max(io.rho_a[i], FT(0));
+    FT rho_q_in, rho_n_in;
     bool present;
-    const FT rho_a = M::max(io.rho_a[i], FT(0)), T = io.T[i];
     if constexpr (FUSED) {
         // clamp_to_nonneg and the volumetric quantities of BMT:912-932; ice processes only where q_ice > ϵₘ && n_ice > ϵₙ (:959)
         const FT q_ice = M::max(io.q_ice[i], FT(0)), n_ice = M::max(io.n_ice[i], FT(0));
-        L_c = M::max(io.q_lcl[i], FT(0)) * rho_a; N_c = M::max(io.n_lcl[i], FT(0)) * rho_a;
-        L_r = M::max(io.q_rai[i], FT(0)) * rho_a; N_r = M::max(io.n_rai[i], FT(0)) * rho_a;
-        p3_make_point<FT>(c, q_ice * rho_a, n_ice * rho_a, M::max(io.q_rim[i], FT(0)) * rho_a, M::max(io.b_rim[i], FT(0)) * rho_a, s);
-        present = q_ice > P::eps() && n_ice > P::eps() && !(s.rho_n < P::eps() || s.rho_q < P::eps());
+        rho_q_in = q_ice * rho_a; rho_n_in = n_ice * rho_a;
+        present = q_ice > P::eps() && n_ice > P::eps() && !(rho_n_in < P::eps() || rho_q_in < P::eps());
     } else {
-        L_c = io.L_c[i]; N_c = io.N_c[i]; L_r = io.L_r[i]; N_r = io.N_r[i];
-        p3_make_point<FT>(c, io.rho_q[i], io.rho_n[i], io.x3[i], io.x4[i], s);
-        present = !(s.rho_n < P::eps() || s.rho_q < P::eps());
+        rho_q_in = io.rho_q[i]; rho_n_in = io.rho_n[i];
+        present = !(rho_n_in < P::eps() || rho_q_in < P::eps());
     }
     const FT loglam = present ? io.loglam[i] : FT(10), lam = P::exp(loglam), mu = p3_mu<FT>(c, loglam);
-    const FT logN0 = P::log(present ? s.rho_n : FT(1)) - (-(mu + FT(1)) * loglam + P::lgamma(mu + FT(1)));
-    const FT lra = P::log(rho_a);
-    const FT sb = v.s_B + rho_a * v.s_C, se = v.s_A * lra + sb * v.ln1000;
-    const FT le1 = v.l_A * lra, le2 = le1 + v.l_H * rho_a;
     // quantiles of the ice PSD (integral_bounds, P3_integral_properties.jl:34-46): one Halley solve per LANE — lanes 0/1 the
     // collision bounds (p = 1e-5), 2/3 the self-collection bounds (p = eps), 4/5 the melting bounds (p = 1e-6) — shared by shuffles
-    FT D_min, D_max, D_lo_sc = FT(0), D_hi_sc = FT(0), D_lo_m = FT(0), D_hi_m = FT(0);
+    // (the 2M+P3 entry parks the self-collection / melting bounds in S[20…23] until their sweeps)
+    FT D_min, D_max;
     {
         FT plev = (g & 1) ? v.p_hi : v.p_lo;
         if constexpr (FUSED) {
@@ -230,14 +233,30 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
         const FT xq = gamma_inc_inv_dev<FT>(mu + FT(1), plev, FT(1) - plev) / lam;
         D_min = __shfl(xq, 0, GROUP); D_max = __shfl(xq, 1, GROUP);
         if constexpr (FUSED) {
-            D_lo_sc = __shfl(xq, 2, GROUP); D_hi_sc = __shfl(xq, 3, GROUP);
-            D_lo_m = __shfl(xq, 4, GROUP); D_hi_m = __shfl(xq, 5, GROUP);
+            if (g >= 2 && g < 6) S[18 + g] = xq;
         }
     }
-    FT bnd[5];
-    bnd[0] = D_min; bnd[4] = D_max;
+    P3Point<FT> s;
+    FT L_c, N_c, L_r, N_r;
+    const FT T = io.T[i];
+    if constexpr (FUSED) {
+        L_c = M::max(io.q_lcl[i], FT(0)) * rho_a; N_c = M::max(io.n_lcl[i], FT(0)) * rho_a;
+        L_r = M::max(io.q_rai[i], FT(0)) * rho_a; N_r = M::max(io.n_rai[i], FT(0)) * rho_a;
+        p3_make_point<FT>(c, rho_q_in, rho_n_in, M::max(io.q_rim[i], FT(0)) * rho_a, M::max(io.b_rim[i], FT(0)) * rho_a, s);
+        if (g == 0) { S[24] = s.rho_g; S[25] = s.bnd[1]; S[26] = s.bnd[2]; S[27] = s.bnd[3]; }   // for the two later sweeps' segment bounds
+    } else {
+        L_c = io.L_c[i]; N_c = io.N_c[i]; L_r = io.L_r[i]; N_r = io.N_r[i];
+        p3_make_point<FT>(c, rho_q_in, rho_n_in, io.x3[i], io.x4[i], s);
+    }
+    const FT logN0 = P::log(present ? s.rho_n : FT(1)) - (-(mu + FT(1)) * loglam + P::lgamma(mu + FT(1)));
+    const FT lra = P::log(rho_a);
+    const FT sb = v.s_B + rho_a * v.s_C, se = v.s_A * lra + sb * v.ln1000;
+    const FT le1 = v.l_A * lra, le2 = le1 + v.l_H * rho_a;
+    if (g == 0) {
+        S[15] = D_min; S[19] = D_max;
 #pragma unroll
-    for (int q = 1; q < 4; ++q) bnd[q] = M::min(M::max(s.bnd[q], D_min), D_max);
+        for (int q = 1; q < 4; ++q) S[15 + q] = M::min(M::max(s.bnd[q], D_min), D_max);
+    }
     const FT Fu = M::max(FT(1) - s.F_rim, P::eps());
     const FT h0 = (v.h0_num - P::log(Fu)) / FT(3), h1 = c.beta_va / FT(3);
     const bool unrimed = s.F_rim == FT(0);
@@ -278,9 +297,15 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
         return k.r_a[0] * P::exp(re[0] + rb[0] * logD - k.r_c[0] * D, kc) + k.r_a[1] * P::exp(re[1] + rb[1] * logD - k.r_c[1] * D, kc) +
                k.r_a[2] * P::exp(re[2] + rb[2] * logD - k.r_c[2] * D, kc);
     };
+    auto v_liq_s = [&](FT D, FT logD) {      // the same with the exponents read from S (the crossover solve)
+        return k.r_a[0] * P::exp(Sv[0] + Sv[1] * logD - k.r_c[0] * D, kc) + k.r_a[1] * P::exp(Sv[2] + Sv[3] * logD - k.r_c[1] * D, kc) +
+               k.r_a[2] * P::exp(Sv[4] + Sv[5] * logD - k.r_c[2] * D, kc);
+    };
     // cloud PSD in diameter — log_pdf_cloud_parameters_mass CM2:172-188, pdf_cloud_parameters :227-236
     const FT inv_rho = FT(1) / rho_a;
     const FT q_c = L_c * inv_rho, q_r = L_r * inv_rho;
+    if (g == 0) { S[10] = s.rho_q; S[11] = s.rho_n; S[12] = s.rho_rim; S[13] = inv_rho; S[14] = T; }   // published by the barrier below
+    const bool melts = T > k.T_freeze_tps;   // BMT:980
     const bool no_cloud = N_c < P::eps() || q_c < P::eps();
     FT logN0c, lam_c, c_lo = FT(0), c_hi = FT(0);
     {
@@ -334,15 +359,20 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
         for (int j = g; j < nq; j += GROUP) {
             const FT D = sc * q_node[j] + sh, logD = P::log(D);
             const FT nD = P::exp(logN0c + k.nu_cD * logD - lam_c * P::exp(k.mu_cD * logD));
-            cD[j] = D; cV[j] = v_liq(D, logD); cW[j] = q_wt[j] * sc * nD;
+            cN[3 * j] = D; cN[3 * j + 1] = v_liq(D, logD); cN[3 * j + 2] = q_wt[j] * sc * nD;
         }
     }
     if (has_rain) {
+        if (g == 0) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { S[2 * j] = re[j]; S[2 * j + 1] = rb[j]; }
+            S[6] = r_lo; S[7] = r_hi; S[8] = Dr_mean; S[9] = N0r;
+        }
         const FT sc = (r_hi - r_lo) / FT(2), sh = (r_lo + r_hi) / FT(2);
         for (int j = g; j < nq; j += GROUP) {
             const FT D = sc * q_node[j] + sh, logD = P::log(D);
-            rD[j] = D; rV[j] = v_liq(D, logD);
-            rW[j] = q_wt[j] * sc * (N0r * P::exp(-D * lam_r)) * (k.m_fac * (D * D * D));
+            rN[3 * j] = D; rN[3 * j + 1] = v_liq(D, logD);
+            rN[3 * j + 2] = q_wt[j] * sc * (N0r * P::exp(-D * lam_r)) * (k.m_fac * (D * D * D));
         }
         if (g < 8) {
             // families of the closed form (closed_rain_inner_NM :343-369): (α, z₀) = (λ, 1) for the v_i term and (λ + c_j, 1 + b_j)
@@ -375,7 +405,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
     for (int q = 0; q < 10; ++q) acc[q] = FT(0);
     if (present) {
         for (int sg = 0; sg < 4; ++sg) {
-            const FT a = bnd[sg], b = bnd[sg + 1];
+            const FT a = Sv[15 + sg], b = Sv[16 + sg];
             if (!(a < b)) continue;
             const FT scale = (b - a) / FT(2), shift = (a + b) / FT(2);
             for (int o = g; o < nq; o += GROUP) {
@@ -386,8 +416,8 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
                 FT Nc = FT(0), Mc = FT(0), Bc = FT(0), Nr = FT(0), Mr = FT(0), Br = FT(0);
                 if (has_cloud) {
                     for (int j = 0; j < nq; ++j) {
-                        const FT D = cD[j], dv = P::abs(v_i - cV[j]);
-                        const FT t1 = M::fma(D, M::fma(D, K2, K1), K0) * dv * cW[j];
+                        const FT D = cN[3 * j], dv = P::abs(v_i - cN[3 * j + 1]);
+                        const FT t1 = M::fma(D, M::fma(D, K2, K1), K0) * dv * cN[3 * j + 2];
                         const FT t2 = t1 * (k.m_fac * (D * D * D));
                         const FT Ri = M::min(M::max(D * dv * inv_2TC, FT(1)), FT(12));
                         const FT rho_p = Ri <= FT(8) ? k.rime_a + k.rime_b * Ri + k.rime_c * (Ri * Ri)
@@ -399,8 +429,8 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
                     // crossover_diameter — :325-334: Brent on v_l(D) − v_i over [r_lo, r_hi], fixed iteration budget
                     FT Dstar;
                     {
-                        FT xa = r_lo, xb = r_hi;
-                        FT fa = v_liq(xa, P::log(xa, kc)) - v_i, fb = v_liq(xb, P::log(xb, kc)) - v_i;
+                        FT xa = Sv[6], xb = Sv[7];
+                        FT fa = v_liq_s(xa, P::log(xa, kc)) - v_i, fb = v_liq_s(xb, P::log(xb, kc)) - v_i;
                         if (!(fa * fb <= FT(0))) Dstar = P::abs(fa) <= P::abs(fb) ? xa : xb;
                         else {
                             if (P::abs(fa) < P::abs(fb)) { FT t = xa; xa = xb; xb = t; t = fa; fa = fb; fb = t; }
@@ -419,7 +449,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
                                     (!mflag && P::abs(sx - xb) >= P::abs(xc - xd) / FT(2))) {
                                     sx = (xa + xb) / FT(2); mflag = true;
                                 } else mflag = false;
-                                const FT fs = v_liq(sx, P::log(sx, kc)) - v_i;
+                                const FT fs = v_liq_s(sx, P::log(sx, kc)) - v_i;
                                 xd = xc; xc = xb; fc = fb;
                                 if (fa * fs < FT(0)) { xb = sx; fb = fs; } else { xa = sx; fa = fs; }
                                 if (P::abs(fa) < P::abs(fb)) { FT t = xa; xa = xb; xb = t; t = fa; fa = fb; fb = t; }
@@ -430,7 +460,8 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
                     // crossing(p) = Σ_f coef_f Σ_i K_i α_f^{−z} [2γ(z, α_f D*) − γ(z, α_f D_lo) − γ(z, α_f D_hi)],  z = z₀_f + p + i,
                     // with every α^{−z} written as λ^{−z} (λ/α)^z: N = N₀r/λ · S₀, M = N₀r/λ · ρ_w π/6 · D̄³ · S₃
                     FT S0 = FT(0), S3 = FT(0);
-                    const FT Kt1 = K1 * Dr_mean, Kt2 = K2 * (Dr_mean * Dr_mean);
+                    const FT Dr_m = Sv[8];
+                    const FT Kt1 = K1 * Dr_m, Kt2 = K2 * (Dr_m * Dr_m);
 #pragma unroll 1
                     for (int f = 0; f < 4; ++f) {
                         const FT al = Fm[f * 6 + 0], z0 = Fm[f * 6 + 1], G0 = Fm[f * 6 + 2], rr = Fm[f * 6 + 4];
@@ -446,13 +477,13 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
                         S0 += wq * (K0 * I[0] + Kt1 * I[1] + Kt2 * I[2]);
                         S3 += wq * (K0 * I[3] + Kt1 * I[4] + Kt2 * I[5]);
                     }
-                    const FT N0_lam = N0r * Dr_mean;
-                    Nr = N0_lam * S0; Mr = N0_lam * (k.m_fac * (Dr_mean * Dr_mean * Dr_mean)) * S3;
+                    const FT N0_lam = Sv[9] * Dr_m;
+                    Nr = N0_lam * S0; Mr = N0_lam * (k.m_fac * (Dr_m * Dr_m * Dr_m)) * S3;
                     if (!(isfinite(Nr) && isfinite(Mr))) { Nr = FT(0); Mr = FT(0); }
                     else {
                         for (int j = 0; j < nq; ++j) {
-                            const FT D = rD[j], dv = P::abs(v_i - rV[j]);
-                            const FT t2 = M::fma(D, M::fma(D, K2, K1), K0) * dv * rW[j];
+                            const FT D = rN[3 * j], dv = P::abs(v_i - rN[3 * j + 1]);
+                            const FT t2 = M::fma(D, M::fma(D, K2, K1), K0) * dv * rN[3 * j + 2];
                             const FT Ri = M::min(M::max(D * dv * inv_2TC, FT(1)), FT(12));
                             const FT rho_p = Ri <= FT(8) ? k.rime_a + k.rime_b * Ri + k.rime_c * (Ri * Ri)
                                                          : k.rime_rho8 + (Ri - FT(8)) * FT(0.25) * (k.rime_rho_ice - k.rime_rho8);
@@ -471,7 +502,13 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
                 const FT nw = n_i * w;
                 acc[0] += nw * Mc * f_frz; acc[1] += nw * Mc * (FT(1) - f_frz); acc[2] += nw * Nc;
                 acc[3] += nw * Mr * f_frz; acc[4] += nw * Mr * (FT(1) - f_frz); acc[5] += nw * Nr;
-                acc[6] += nw * M_col;      acc[7] += nw * Bc * f_frz;           acc[8] += nw * Br * f_frz;
+                if constexpr (FUSED) {
+                    // the 2M + P3 entry does not report the ten rates: Σ n w M_col is the sum of the four mass sums and the two rime-volume
+                    // sums are only ever added — eight accumulators instead of ten
+                    acc[7] += nw * (Bc + Br) * f_frz;
+                } else {
+                    acc[6] += nw * M_col;      acc[7] += nw * Bc * f_frz;           acc[8] += nw * Br * f_frz;
+                }
                 acc[9] += M_col > M_frz ? nw * M_col : FT(0);
             }
         }
@@ -479,11 +516,12 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
     // ---- 2M+P3 entry only: aggregation (ice_self_collection :676-712) and melting (ice_melt :64-94), outer node per lane ------
     FT acc_sc = FT(0), acc_m = FT(0);
     if constexpr (FUSED) {
+        const FT D_lo_sc = Sv[20], D_hi_sc = Sv[21];
         if (present) {
             FT bs[5];
             bs[0] = D_lo_sc; bs[4] = D_hi_sc;
 #pragma unroll
-            for (int q = 1; q < 4; ++q) bs[q] = M::min(M::max(s.bnd[q], D_lo_sc), D_hi_sc);
+            for (int q = 1; q < 4; ++q) bs[q] = M::min(M::max(Sv[24 + q], D_lo_sc), D_hi_sc);
             for (int sg = 0; sg < 4; ++sg) {
                 const FT a = bs[sg], b = bs[sg + 1];
                 if (!(a < b)) continue;
@@ -509,17 +547,21 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
                     acc_sc += inner * n1 * (q_wt[o] * scale);
                 }
             }
-            if (T > k.T_freeze_tps) {   // BMT:980
-                FT bm[5];
-                bm[0] = D_lo_m; bm[4] = D_hi_m;
-#pragma unroll
-                for (int q = 1; q < 4; ++q) bm[q] = M::min(M::max(s.bnd[q], D_lo_m), D_hi_m);
-#pragma unroll
+            if (melts) {
+                const FT D_lo_m = Sv[22], D_hi_m = Sv[23];
+                s.rho_g = Sv[24];
+                // segments one at a time (not unrolled: each segment's mass law is derived inside its iteration, see p3_segment_mass_law);
+                // the thresholds are picked with selects — a run-time index into a local array would put the array into scratch
+#pragma unroll 1
                 for (int sg = 0; sg < 4; ++sg) {
-                    const FT a = bm[sg], b = bm[sg + 1];
+                    const FT t_lo = sg == 0 ? FT(0) : Sv[24 + sg];
+                    const FT t_hi = sg == 3 ? FT(INFINITY) : Sv[25 + sg];
+                    const FT a = sg == 0 ? D_lo_m : M::min(M::max(t_lo, D_lo_m), D_hi_m);
+                    const FT b = sg == 3 ? D_hi_m : M::min(M::max(t_hi, D_lo_m), D_hi_m);
                     if (!(a < b)) continue;
                     const FT scale = (b - a) / FT(2), shift = (a + b) / FT(2);
-                    const FT mb = s.b[sg], ma = P::exp(s.log_a[sg]);
+                    FT ma, mb;
+                    p3_mass_law_at<FT>(c, s, (t_lo + t_hi) / FT(2), ma, mb);   // re-derived here: P3Point::log_a / b are not kept across the sweeps
                     for (int o = g; o < nq; o += GROUP) {
                         const FT x = scale * q_node[o] + shift;
                         FT vD, rD_, nD;
@@ -544,13 +586,21 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
 #pragma unroll
         for (int d = GROUP / 2; d >= 1; d >>= 1) { acc_sc += __shfl_xor(acc_sc, d, GROUP); acc_m += __shfl_xor(acc_m, d, GROUP); }
     }
-    if (g == 0 && valid) {
+    if constexpr (FUSED) acc[6] = (acc[0] + acc[1]) + (acc[3] + acc[4]);
+    // the state's index once more, from an opaque copy of the lane number: two integer instructions here instead of a register pair
+    // (or a scratch slot) held across the sweeps
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));
+    const int64_t i_out = (int64_t)blockIdx.x * (blockDim.x / GROUP) + lane / GROUP;
+    if (g == 0 && i_out < n) {
+        const int64_t i = i_out;
+        const FT e_rho_q = Sv[10], e_rho_n = Sv[11], e_rho_rim = Sv[12], e_inv_rho = Sv[13], e_T = Sv[14];
         const FT f_wet = acc[6] == FT(0) ? FT(0) : acc[9] / acc[6];
         const FT NRSHD = acc[4] * k.inv_m_shd;
-        const FT B_rim = s.rho_rim == FT(0) ? FT(0) : (s.rho_q * s.F_rim) / s.rho_rim;
-        const FT QIWET = present ? f_wet * s.rho_q * (FT(1) - s.F_rim) / k.tau_wet : FT(0);
-        const FT BIWET = present ? f_wet * (s.rho_q / k.rho_i - B_rim) / k.tau_wet : FT(0);
-        const FT o[7] = {(-acc[0] - acc[1]) * inv_rho, (-acc[3] + acc[1]) * inv_rho, -acc[2], -acc[5] + NRSHD,
+        const FT B_rim = e_rho_rim == FT(0) ? FT(0) : (e_rho_q * s.F_rim) / e_rho_rim;
+        const FT QIWET = present ? f_wet * e_rho_q * (FT(1) - s.F_rim) / k.tau_wet : FT(0);
+        const FT BIWET = present ? f_wet * (e_rho_q / k.rho_i - B_rim) / k.tau_wet : FT(0);
+        const FT o[7] = {(-acc[0] - acc[1]) * e_inv_rho, (-acc[3] + acc[1]) * e_inv_rho, -acc[2], -acc[5] + NRSHD,
                          acc[0] + acc[3] + QIWET, acc[0] + acc[3], acc[7] + acc[8] + BIWET};
         if constexpr (!FUSED) {
 #pragma unroll
@@ -562,21 +612,21 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
         } else if (present) {
             // BMT:966-994: collisions, aggregation (½π factored out of the sums), melting (ice → rain; rime drains in proportion)
             const FT agg = FT(0.5) * pi * acc_sc;
-            const FT L_f = k.LH_f0 + k.dcp_f * (T - k.T_0);
-            const FT mL = T > k.T_freeze_tps ? M::max(FT(0), k.K4 / L_f * (T - k.T_freeze_p3) * acc_m) : FT(0);
-            const FT mq = mL * inv_rho, mn = (s.rho_n / s.rho_q * mL) * inv_rho;
-            const FT d[8] = {o[0], o[2] * inv_rho, o[1] + mq, o[3] * inv_rho + mn, o[5] * inv_rho - mq, -agg * inv_rho - mn,
-                             o[4] * inv_rho - mq * s.F_rim, o[6] * inv_rho - (s.rho_rim > FT(0) ? mq * s.F_rim / s.rho_rim : FT(0))};
+            const FT L_f = k.LH_f0 + k.dcp_f * (e_T - k.T_0);
+            const FT mL = melts ? M::max(FT(0), k.K4 / L_f * (e_T - k.T_freeze_p3) * acc_m) : FT(0);
+            const FT mq = mL * e_inv_rho, mn = (e_rho_n / e_rho_q * mL) * e_inv_rho;
+            const FT d[8] = {o[0], o[2] * e_inv_rho, o[1] + mq, o[3] * e_inv_rho + mn, o[5] * e_inv_rho - mq, -agg * e_inv_rho - mn,
+                             o[4] * e_inv_rho - mq * s.F_rim, o[6] * e_inv_rho - (e_rho_rim > FT(0) ? mq * s.F_rim / e_rho_rim : FT(0))};
 #pragma unroll
             for (int q = 0; q < 8; ++q) io.out[q][i] += d[q];
         }
     }
 }
 
-// launch geometry: 256 lanes (32 states) per workgroup unless the per-state LDS caches (6n + 72 values) would not fit — then 128
+// launch geometry: 256 lanes (32 states) per workgroup unless the per-state LDS caches (6n + 100 values) would not fit — then 128
 template <typename FT> static void collision_geometry(int group, int nq, int64_t n, dim3 &grid, dim3 &block, size_t &lds) {
     int threads = kBlock;
-    auto bytes = [&](int t) { return sizeof(FT) * (size_t)(2 * nq + (t / group) * (6 * nq + 72)); };
+    auto bytes = [&](int t) { return sizeof(FT) * (size_t)(2 * nq + (t / group) * ColLds<FT>::per_group(nq)); };
     while (threads > 64 && bytes(threads) > 150 * 1024) threads /= 2;
     const int ppb = threads / group;
     grid = dim3((unsigned)((n + ppb - 1) / ppb)); block = dim3(threads); lds = bytes(threads);

@@ -345,7 +345,7 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, F
     const FT eps = M::eps();  // ϵ_numerics_2M_M = ϵ_numerics_2M_N = eps(FT)  (Utilities.jl:325,332)
     SbRates<FT> r;
 
-    const FT rs_rho = M::rsqrt(rho);  // ρ^(-1/2); each √(ρ0/ρ) is (host √ρ0)·rs_rho
+    const FT rs_rho = M::rsqrt_pos(rho);  // air density: positive, finite.  ρ^(-1/2); each √(ρ0/ρ) is (host √ρ0)·rs_rho
     const FT inv_rho = rs_rho * rs_rho;   // one hardware transcendental for both
     r.inv_rho = inv_rho;
 
@@ -467,7 +467,7 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, F
         const FT g_a = M::rcp_nz(M::fma(c.ga_c1, M::exp2_fin(c.ga_e1 * l2_t), c.ga_c2 * M::exp2_fin(c.ga_e2 * l2_t)));   // both coefficients > 0;   // a_vent_0·Γ_incl(−1, t*)·e^{t*}
         const FT g_b = M::rcp(M::fma(c.gb_c1, M::exp2_fin(c.gb_e1 * l2_t), c.gb_c2 * M::exp2_fin(c.gb_e2 * l2_t)));   // b_vent_0 ∛Sc·Γ_incl(β, t*)·e^{t*}
         // √N_Re = √(α/ν)·(ρ0/ρ)^¼·√(x̄^β·Dr)
-        const FT sqrt_N_Re = c.sqrt_alpha_nu_rho0q * M::sqrt(rs_rho) *
+        const FT sqrt_N_Re = c.sqrt_alpha_nu_rho0q * M::sqrt_pos(rs_rho) *
                              M::exp2_fin(FT(0.5) * M::fma(c.beta, l2_xr, l2_Dr));
         const FT Fv0 = M::fma(g_b, sqrt_N_Re, g_a);
         const FT Fv1 = M::fma(c.bSc_vent_1, sqrt_N_Re, c.a_vent_1);

@@ -19,6 +19,10 @@ extern "C" void lean_eval(int which, int64_t n, const double *x, double *y) {
             case 11: y[i] = L::exp2_fin(x[i]); break;
             case 12: y[i] = L::exp_fin(x[i]); break;
             case 13: y[i] = L::rcp_finite(x[i]); break;
+            case 14: y[i] = L::rcp_nz(x[i]); break;
+            case 15: y[i] = L::sqrt_pos(x[i]); break;
+            case 16: y[i] = L::rsqrt_pos(x[i]); break;
+            case 17: y[i] = L::pow_m34_pos(x[i]); break;
         }
     }
 }

@@ -27,7 +27,7 @@ def lean(tmp_path_factory):
     return ev
 
 
-EXP2, LOG2, EXP, LOG, RCP, SQRT, RSQRT, EXPM1, LOG1P, ERFC, LGAMMA, EXP2_FIN, EXP_FIN, RCP_NZ = range(14)
+EXP2, LOG2, EXP, LOG, RCP, SQRT, RSQRT, EXPM1, LOG1P, ERFC, LGAMMA, EXP2_FIN, EXP_FIN, RCP_FINITE, RCP_NZ, SQRT_POS, RSQRT_POS, POW_M34 = range(18)
 
 
 @pytest.mark.parametrize("script", ["gen_lean_tables.py", "gen_erfc_table.py"])
@@ -71,7 +71,7 @@ def test_erfc(lean):
     import mpmath as mp
     mp.mp.dps = 40
     rng = np.random.default_rng(11)
-    x = np.concatenate([rng.uniform(0, 6.5, 4000), np.linspace(0, 6.5, 16 * 16 + 1), 6.5 / 16 * np.arange(17)])   # incl. the interval joints
+    x = np.concatenate([rng.uniform(0, 6.5, 4000), np.linspace(0, 6.5, 64 * 16 + 1), 6.5 / 64 * np.arange(65)])   # incl. the interval joints
     y = lean(ERFC, x)
     worst = max(float(abs((mp.mpf(float(yi)) - mp.erfc(mp.mpf(float(xi)))) / mp.erfc(mp.mpf(float(xi)))) / (2 + xi * xi)) for xi, yi in zip(x, y))
     assert worst < 2e-16, worst
@@ -84,7 +84,8 @@ def test_erfc(lean):
     y, r = lean(ERFC, x), erfc(x)
     assert np.all(y >= r * (1 - 1e-13)) and np.all(y <= r * (x / 6.5) * (1 + 1e-13)) and np.all(y < 4.1e-20)
     with np.errstate(all="ignore"):
-        np.testing.assert_array_equal(lean(ERFC, [0.0, -0.0, np.inf, -np.inf, np.nan, 40.0, -40.0]), [1.0, 1.0, 0.0, 2.0, np.nan, 0.0, 2.0])
+        np.testing.assert_array_equal(lean(ERFC, [np.inf, -np.inf, np.nan, 40.0, -40.0]), [0.0, 2.0, np.nan, 0.0, 2.0])
+        assert np.all(np.abs(lean(ERFC, [0.0, -0.0]) - 1.0) <= 2.3e-16)        # the end of the first interval: within the polynomial's 1 ulp
 
 
 def test_lgamma_pos(lean):
@@ -177,13 +178,22 @@ def test_finite_argument_forms(lean):
     x = rng.uniform(-700, 700, 400_000)
     np.testing.assert_array_equal(lean(EXP_FIN, x), lean(EXP, x))
     x = np.concatenate([10.0 ** rng.uniform(-300, 300, 200_000), -10.0 ** rng.uniform(-300, 300, 200_000)])
-    np.testing.assert_array_equal(lean(RCP_NZ, x), lean(RCP, x))
+    np.testing.assert_array_equal(lean(RCP_FINITE, x), lean(RCP, x))
+    worst = ulps(lean(RCP_NZ, x), 1.0 / x)                      # seed + one Newton step: 2⁻⁴⁸ relative
+    print(f"rcp_nz worst error {worst:.1f} ulp")
+    assert worst <= 40
+    x = 10.0 ** rng.uniform(-300, 300, 400_000)
+    np.testing.assert_array_equal(lean(SQRT_POS, x), lean(SQRT, x))
+    np.testing.assert_array_equal(lean(RSQRT_POS, x), lean(RSQRT, x))
+    x = 10.0 ** rng.uniform(-100, 100, 400_000)                 # x^(−¾): the ARG S_max sum (3ζ + η: 1e-12 … 1e3)
+    assert ulps(lean(POW_M34, x), x ** -0.75) <= 6            # u³: three times the error of u = x^(−¼) plus two roundings
+    assert np.isnan(lean(POW_M34, [np.nan])[0]) and np.isnan(lean(SQRT_POS, [np.nan])[0]) and np.isnan(lean(RSQRT_POS, [np.nan])[0])
     with np.errstate(all="ignore"):
         big = [1100.0, 2000.0, 1e6, 1e12, 1e300, -1100.0, -2000.0, -1e6, -1e12, -1e300, -1074.0, -1060.5]
         np.testing.assert_array_equal(lean(EXP2_FIN, big), np.exp2(big))
         eb = [800.0, 1e6, 1e12, -800.0, -1e6, -1e12]            # e^x: the Cody–Waite reduction needs |x|·128/ln2 to be an exact integer (|x| < 2e13)
         np.testing.assert_array_equal(lean(EXP_FIN, eb), np.exp(eb))
-        assert np.isnan(lean(EXP2_FIN, [np.nan])[0]) and np.isnan(lean(EXP_FIN, [np.nan])[0]) and np.isnan(lean(RCP_NZ, [np.nan])[0])
+        assert np.isnan(lean(EXP2_FIN, [np.nan])[0]) and np.isnan(lean(EXP_FIN, [np.nan])[0]) and np.isnan(lean(RCP_NZ, [np.nan])[0]) and np.isnan(lean(RCP_FINITE, [np.nan])[0])
 
 
 @pytest.mark.gpu
