@@ -90,19 +90,32 @@ def pmc_traffic(workload: str, dtype: str, n: int):
     return None, None
 
 
+def source_digest() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, *.hpp, *.inc, Makefile, include/cmx.h): a PMC instruction count taken from another build of
+    the kernels is not a property of THIS code — pmc_valu() only accepts a committed profile whose digest matches."""
+    import hashlib
+    h = hashlib.sha256()
+    src = REPO / "cloudmicrophysics.jl_amd" / "csrc"
+    files = sorted(list(src.glob("*.hip")) + list(src.glob("*.hpp")) + list(src.glob("*.inc")) + [src / "Makefile", REPO / "include" / "cmx.h"])
+    for f in files:
+        h.update(f.name.encode()); h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
 VALU_PEAK_GINST = 1024 * 2.4e9 / 4 / 1e9     # wave64 VALU instructions per second the chip can issue: 256 CUs × 4 SIMDs, one per 4 cycles at 2.4 GHz
 
 
 def pmc_valu(workload: str, dtype: str, n: int):
     """Wave64 VALU instructions per launch (SQ_INSTS_VALU, summed over the kernels of one step) from the committed rocprofv3 PMC pass of
     this exact workload (tools/profile.sh … valu → profiles/rNN_pmc_valu_<workload>_<dtype>.json), newest round first; (None, None) if
-    no committed profile matches the size.  The count is a property of the code and the input distribution, not of the box."""
+    no committed profile matches the size AND the kernel sources (source_digest).  The count is a property of the code and the input
+    distribution, not of the box."""
     for p in sorted((REPO / "profiles").glob(f"r*_pmc_valu_{workload}_{dtype}.json"), reverse=True):
         try:
             d = json.loads(p.read_text())
         except (OSError, ValueError):
             continue
-        if d.get("points") != n:
+        if d.get("points") != n or d.get("source_digest") != source_digest():
             continue
         insts = [k.get("counters", {}).get("SQ_INSTS_VALU") for k in d.get("kernels", {}).values()]
         if insts and all(v is not None for v in insts):

@@ -297,8 +297,13 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
         return k.r_a[0] * P::exp(re[0] + rb[0] * logD - k.r_c[0] * D, kc) + k.r_a[1] * P::exp(re[1] + rb[1] * logD - k.r_c[1] * D, kc) +
                k.r_a[2] * P::exp(re[2] + rb[2] * logD - k.r_c[2] * D, kc);
     };
+    // Float64 reads the rain constants back from S inside the sweep (they would otherwise hold ten register pairs: scratch spills at three
+    // waves per SIMD); Float32 has the registers and keeps them there — the LDS round trip in the crossover solve's dependent chain cost
+    // 3 % of the 2M + P3 step (same-box A/B, round 3: 7.54 -> 7.76 ms per 1e6 states)
+    constexpr bool PARK_RAIN = sizeof(FT) == 8;
     auto v_liq_s = [&](FT D, FT logD) {      // the same with the exponents read from S (the crossover solve)
-        return k.r_a[0] * P::exp(Sv[0] + Sv[1] * logD - k.r_c[0] * D, kc) + k.r_a[1] * P::exp(Sv[2] + Sv[3] * logD - k.r_c[1] * D, kc) +
+        if constexpr (!PARK_RAIN) return v_liq(D, logD);
+        else return k.r_a[0] * P::exp(Sv[0] + Sv[1] * logD - k.r_c[0] * D, kc) + k.r_a[1] * P::exp(Sv[2] + Sv[3] * logD - k.r_c[1] * D, kc) +
                k.r_a[2] * P::exp(Sv[4] + Sv[5] * logD - k.r_c[2] * D, kc);
     };
     // cloud PSD in diameter — log_pdf_cloud_parameters_mass CM2:172-188, pdf_cloud_parameters :227-236
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
                     // crossover_diameter — :325-334: Brent on v_l(D) − v_i over [r_lo, r_hi], fixed iteration budget
                     FT Dstar;
                     {
-                        FT xa = Sv[6], xb = Sv[7];
+                        FT xa = PARK_RAIN ? Sv[6] : r_lo, xb = PARK_RAIN ? Sv[7] : r_hi;
                         FT fa = v_liq_s(xa, P::log(xa, kc)) - v_i, fb = v_liq_s(xb, P::log(xb, kc)) - v_i;
                         if (!(fa * fb <= FT(0))) Dstar = P::abs(fa) <= P::abs(fb) ? xa : xb;
                         else {
@@ -460,7 +465,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
                     // crossing(p) = Σ_f coef_f Σ_i K_i α_f^{−z} [2γ(z, α_f D*) − γ(z, α_f D_lo) − γ(z, α_f D_hi)],  z = z₀_f + p + i,
                     // with every α^{−z} written as λ^{−z} (λ/α)^z: N = N₀r/λ · S₀, M = N₀r/λ · ρ_w π/6 · D̄³ · S₃
                     FT S0 = FT(0), S3 = FT(0);
-                    const FT Dr_m = Sv[8];
+                    const FT Dr_m = PARK_RAIN ? Sv[8] : Dr_mean;
                     const FT Kt1 = K1 * Dr_m, Kt2 = K2 * (Dr_m * Dr_m);
 #pragma unroll 1
                     for (int f = 0; f < 4; ++f) {
@@ -477,7 +482,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
                         S0 += wq * (K0 * I[0] + Kt1 * I[1] + Kt2 * I[2]);
                         S3 += wq * (K0 * I[3] + Kt1 * I[4] + Kt2 * I[5]);
                     }
-                    const FT N0_lam = Sv[9] * Dr_m;
+                    const FT N0_lam = (PARK_RAIN ? Sv[9] : N0r) * Dr_m;
                     Nr = N0_lam * S0; Mr = N0_lam * (k.m_fac * (Dr_m * Dr_m * Dr_m)) * S3;
                     if (!(isfinite(Nr) && isfinite(Mr))) { Nr = FT(0); Mr = FT(0); }
                     else {

@@ -5,7 +5,7 @@
 #   usage: tools/gpu_round.sh <round-tag, e.g. r02> [notests]
 set -u
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 mkdir -p gpurun_out/bench
 FAILED=0
 
@@ -41,40 +41,57 @@ bench() {  # bench <name> <bench.py args…>
 }
 
 prof() {  # prof <workload> <dtype> <points> [valu]
-  tools/profile.sh "$1" "$2" "$3" "$TAG" "${4:-}" > gpurun_out/prof_${1}_${2}.log 2>&1
+  KT_STEPS=${KT_STEPS:-40} tools/profile.sh "$1" "$2" "$3" "$TAG" "${4:-}" > gpurun_out/prof_${1}_${2}.log 2>&1
   local rc=$?
   if [ $rc -ne 0 ]; then echo "profile $1 $2 FAILED rc=$rc"; FAILED=$((FAILED+1)); fi
 }
 
+# ---- profiles first: the bench lines of the compute-bound workloads take their VALU instruction count from the PMC pass of THIS build
+# (bench.py pmc_valu: same size, same source digest), so the summaries are copied into profiles/ of this box before any line is printed
+prof sb2006 f32 100000000 valu
+prof sb2006 f64 100000000 valu
+prof sb2006_column f32 100000000
+prof sb2006_column f64 100000000
+prof mp0m f32 100000000
+prof icenuc f32 100000000
+prof icenuc f64 100000000
+prof mp1m f32 100000000 valu
+prof mp1m f64 100000000 valu
+prof mp1m_lin f32 100000000 valu
+prof mp1m_lin f64 100000000 valu
+prof mp1m_column f32 100000000 valu
+prof mp1m_column f64 100000000 valu
+prof mp1m_column_lin f32 100000000 valu
+prof arg2000 f32 100000000 valu
+prof arg2000 f64 100000000 valu
+KT_STEPS=10 prof p3 f32 10000000 valu
+KT_STEPS=10 prof p3 f64 10000000 valu
+KT_STEPS=10 prof p3_split f64 10000000
+KT_STEPS=6 prof p3_selfcol f32 1000000 valu
+KT_STEPS=6 prof p3_selfcol f64 1000000 valu
+KT_STEPS=10 prof mp2m_p3 f32 1000000 valu
+KT_STEPS=10 prof mp2m_p3 f64 1000000 valu
+prof sb2006_aos f32 100000000
+mkdir -p profiles
+cp gpurun_out/profiles/${TAG}_pmc_*.json gpurun_out/profiles/${TAG}_kernel_stats_*.csv profiles/ 2>/dev/null
+
 bench default_driver --steps 20 --warmup 5
 bench default
-for wl in sb2006 sb2006_column icenuc mp0m mp1m arg2000; do
+for wl in sb2006 sb2006_column icenuc mp0m mp1m arg2000 mp1m_lin mp1m_column sb2006_aos sb2006_fields; do
   for dt in f32 f64; do
     bench ${wl}_${dt} --workload $wl --dtype $dt --steps 20 --warmup 3
   done
 done
 bench sb2006_chen_f32 --workload sb2006_chen --dtype f32 --steps 20 --warmup 3
+bench mp1m_column_lin_f32 --workload mp1m_column_lin --dtype f32 --steps 20 --warmup 3
 for dt in f32 f64; do
-  bench p3_split_${dt} --workload p3_split --dtype $dt --points 10000000 --steps 5 --warmup 1
   bench p3_${dt} --workload p3 --dtype $dt --points 10000000 --steps 5 --warmup 1
+  bench p3_split_${dt} --workload p3_split --dtype $dt --points 10000000 --steps 5 --warmup 1
   bench p3_selfcol_${dt} --workload p3_selfcol --dtype $dt --points 1000000 --steps 3 --warmup 1
-  bench mp1m_lin_${dt} --workload mp1m_lin --dtype $dt --steps 10 --warmup 2
   bench mp2m_p3_${dt} --workload mp2m_p3 --dtype $dt --points 1000000 --steps 3 --warmup 1
-  bench sb2006_aos_${dt} --workload sb2006_aos --dtype $dt --steps 20 --warmup 3
-  bench sb2006_fields_${dt} --workload sb2006_fields --dtype $dt --steps 20 --warmup 3
 done
-prof sb2006 f32 100000000 valu
-prof sb2006 f64 100000000 valu
-prof sb2006_column f32 100000000
-prof mp0m f32 100000000
-prof icenuc f32 100000000
-prof mp1m f32 100000000 valu
-prof mp1m f64 100000000 valu
-prof arg2000 f32 100000000 valu
-prof arg2000 f64 100000000
-prof p3 f64 10000000
-prof mp2m_p3 f64 1000000 valu
-prof sb2006_aos f32 100000000
+cp gpurun_out/parity_report.json gpurun_out/profiles/${TAG}_parity_report.json 2>/dev/null
+python tools/kernel_resources.py > gpurun_out/profiles/${TAG}_kernel_resources.txt 2>&1
 # instruction issue rates and dependent-issue latency (tools/valu_probe.hip), stream ceilings (tools/stream_probe.hip quick)
 [ -x tools/valu_probe ] && timeout 120 tools/valu_probe > gpurun_out/profiles/${TAG}_probe_valu.txt 2>&1
 [ -x tools/stream_probe ] && timeout 300 tools/stream_probe 100000000 20 slab pattern quick > gpurun_out/profiles/${TAG}_probe_streams.txt 2>&1

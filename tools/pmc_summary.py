@@ -14,6 +14,14 @@ BYTES_PER_POINT = {"sb2006": 13, "sb2006_column": 11, "icenuc": 5, "mp0m": 3, "m
                    "p3_split": 9, "p3_selfcol": 7, "sb2006_aos": 15, "sb2006_fields": 11, "mp2m_p3": 20}   # columns in + out
 
 
+def source_digest():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", Path(__file__).resolve().parent.parent / "bench.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.source_digest()
+
+
 def find(out, sub, suffix):
     hits = glob.glob(f"{out}/{sub}/**/*{suffix}", recursive=True)
     return hits[0] if hits else None
@@ -38,7 +46,7 @@ def valu_summary(wl, dt, n, out, rnd):
         for r in list(csv.reader(open(stats)))[1:]:
             if r and "cmx::" in r[0]:
                 avg_ns[r[0].split("(")[0]] = float(r[3])
-    res = {"round": rnd, "workload": wl, "dtype": dt, "points": n,
+    res = {"round": rnd, "workload": wl, "dtype": dt, "points": n, "source_digest": source_digest(),
            "valu_issue_utilisation_formula": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel_avg_ns x 2.4 GHz): the share of the chip's "
                                              "one-wave64-VALU-instruction-per-4-cycles issue slots the kernel fills (kernel_avg_ns from the "
                                              "kernel-trace pass of the same profile run; 2.4 GHz = the spec clock, so DVFS shows up as a lower "
@@ -72,7 +80,7 @@ def main():
         return valu_summary(wl, dt, n, out, rnd)
     dst = Path("gpurun_out/profiles")
     dst.mkdir(parents=True, exist_ok=True)
-    summary = {"round": rnd, "workload": wl, "dtype": dt, "points": n,
+    summary = {"round": rnd, "workload": wl, "dtype": dt, "points": n, "source_digest": source_digest(),
                "command": f"tools/profile.sh {wl} {dt} {n}  (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE in separate passes, "
                           f"--kernel-trace --stats in a third; PMC passes: bench.py --steps 5 --warmup 1; kernel-trace pass: --steps 40 --warmup 5)"}
     stats = find(out, "kt", "kernel_stats.csv")
