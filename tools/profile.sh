@@ -30,3 +30,6 @@ if [ "${5:-}" = "valu" ]; then
   cd "$ROOT"
   run valu-summary python3 tools/pmc_summary.py "$WL" "$DT" "$N" "$OUT" "$R" valu
 fi
+# the raw rocprofv3 output (per-dispatch CSVs, several MB per pass) stays on the box: gpurun merges at most 64 MiB back, and a session
+# profiles two dozen workloads; the summaries above and the pass logs are what is kept
+rm -rf "$OUT/kt" "$OUT/fetch" "$OUT/write" "$OUT/sq"
