@@ -16,7 +16,7 @@ script is a launcher — before anything touches torch or the GPU it starts the 
 (cmx/launcher.py), relays rank 0's JSON line and exits with the child's code.  `--scaling weak` (default) keeps
 `--points` per GPU; `--scaling strong` splits `--points` over the ranks with cmx.sharding.shard_bounds.
 
-Rank 0 prints ONE JSON line (contract: see the task statement; DESIGN.md §6 explains every field).
+Rank 0 prints ONE JSON line (contract: see the task statement; DESIGN.md §7 explains every field).
 `--workload` selects one of the other hot-path kernels for roofline measurements (same JSON shape); the default,
 and the line the driver records, is the north-star SB2006 sweep.
 """
@@ -102,7 +102,14 @@ def source_digest() -> str:
     return h.hexdigest()[:16]
 
 
-VALU_PEAK_GINST = 1024 * 2.4e9 / 4 / 1e9     # wave64 VALU instructions per second the chip can issue: 256 CUs × 4 SIMDs, one per 4 cycles at 2.4 GHz
+# The VALU ceiling, in wave64 instructions per second: 256 CUs × 4 SIMDs issuing one instruction per 2.4 cycles of the 2.4 GHz clock — the
+# FASTEST rate any VALU instruction was measured to issue at on this part (tools/valu_probe.hip → profiles/rNN_probe_valu.txt: v_fmamk_f32,
+# v_mul_f32 with a literal 2.37–2.40 cycles; v_add/v_mul 2.5–2.9; v_fma_f32 with three registers, any SGPR operand, compares and selects
+# 4.2–4.7; every Float64 instruction 4.2–4.8; transcendentals 8.2 (f32) / 16.3 (f64)).  Round 2's "one per 4 cycles" put Float32 kernels
+# above 1.  With this ceiling the fraction is ≤ 1 by construction; a Float64 kernel cannot exceed ≈ 0.55 of it (its instructions take ≥ 4.2
+# cycles each) — `issue_slots_4cycle` in the same object is the old figure.
+VALU_ISSUE_CYCLES_MIN = 2.4
+VALU_PEAK_GINST = 1024 * 2.4e9 / VALU_ISSUE_CYCLES_MIN / 1e9
 
 
 def pmc_valu(workload: str, dtype: str, n: int):
@@ -788,12 +795,15 @@ def main():
             valu = {"bound": "valu", "achieved": rate, "peak": VALU_PEAK_GINST, "unit": "G wave64-VALU-instructions/s", "frac": rate / VALU_PEAK_GINST,
                     "traffic": None, "insts_per_point": insts * 64 / n, "insts_source": insts_source + " (SQ_INSTS_VALU of a rocprofv3 PMC pass of this "
                     "command; a property of the code and the inputs, not of the box)", "kernel": desc["kernel"], "kernel_ms": kern_ms,
-                    "peak_formula": "256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction"}
+                    "issue_slots_4cycle": rate / (1024 * 2.4 / 4),
+                    "peak_formula": "256 CUs x 4 SIMDs x 2.4 GHz / 2.4 cycles: the fastest measured issue rate of a wave64 VALU instruction "
+                                    "(profiles/rNN_probe_valu.txt); Float64 instructions take >= 4.2 cycles, so a Float64 kernel tops out near 0.55; "
+                                    "issue_slots_4cycle = the same count against one instruction per 4 cycles (round 2's definition, > 1 for Float32)"}
         if desc.get("bound") == "valu" and valu is not None:
             # compute-bound line: the VALU-issue fraction is the roofline, the HBM fraction a secondary field
             line["roofline"] = dict(valu, hbm={k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "traffic", "traffic_source", "bytes_per_point")})
         else:
-            line["roofline"] = dict(hbm, valu=({k: valu[k] for k in ("achieved", "peak", "unit", "frac", "insts_per_point", "insts_source")} if valu else None))
+            line["roofline"] = dict(hbm, valu=({k: valu[k] for k in ("achieved", "peak", "unit", "frac", "issue_slots_4cycle", "insts_per_point", "insts_source")} if valu else None))
             if desc.get("bound") == "valu":
                 line["roofline"]["note"] = "compute-bound workload, but no committed PMC instruction count matches this size: HBM fraction shown"
         if "note" in desc:

@@ -275,7 +275,7 @@ CMX_LEAN_FN double exp2(double x) {
 // Finite x of any size is still right: the int conversion saturates, its low 7 bits pick a table entry in [1, 2) and v_ldexp_f64
 // turns the saturated exponent into +Inf / 0; r stays exact.  NaN propagates through r.  What is NOT handled is x = ±Inf (r = Inf − Inf
 // → NaN where 2^±Inf = Inf / 0 is meant): call sites are those whose argument is a finite combination of log2 of positive, clamped
-// quantities (each one is listed in DESIGN "Float64 finite-argument forms").  CMX_F64_FINITE_FORMS=0 maps them back to the full forms.
+// quantities (each site states why; the rule is DESIGN.md §4.3).  CMX_F64_FINITE_FORMS=0 maps them back to the full forms.
 #ifndef CMX_F64_FINITE_FORMS
 #define CMX_F64_FINITE_FORMS 1
 #endif

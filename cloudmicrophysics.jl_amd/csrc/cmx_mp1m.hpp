@@ -12,7 +12,7 @@
 // Microphysics1MOptions arrive as a flags word: a compile-time constant for the default option set (one straight-line basic
 // block), an SGPR otherwise (disabled processes skipped by wave-uniform branches).
 //
-// Round 3 restructuring of the point function (VALU instructions per Float32 point 318 → see DESIGN §4): the logistic integrals
+// Round 3 restructuring of the point function (VALU instructions per Float32 point 327 → 253): the logistic integrals
 // without their three selects (max of the two branches), the limited saturation excess as one max / med3, the rain–snow kernel
 // polynomial on host-folded coefficients and the already-formed squares of the slope parameters, the melt gates as max(T − T_freeze, 0),
 // ρ R_v T inverted as a product of the two reciprocals the point needs anyway.

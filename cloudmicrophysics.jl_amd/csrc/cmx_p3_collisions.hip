@@ -16,7 +16,7 @@
 //     evaluated once per point by 8 lanes of the group;
 //   * the ten outer sums are reduced over the group with log2(group) xor-shuffle steps.
 // The per-point set-up (P3 state, the two Halley solves for the integration bounds, PSD parameters) is evaluated
-// redundantly by the 8 lanes of a group — that is what bounds the group width from above; DESIGN.md §4.8 has the
+// redundantly by the 8 lanes of a group — that is what bounds the group width from above; DESIGN.md §4.6 has the
 // instruction budget and the measurement that led to 8 (the end-point incomplete gammas and the six
 // quantile solves each use up to 8 lanes of the group: 8 is also the smallest width that keeps them one pass).
 //

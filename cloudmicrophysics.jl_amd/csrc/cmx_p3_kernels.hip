@@ -8,7 +8,7 @@
 // get_μ :171-173, logmass_gamma_moment :193-200, logLdivN :211-216, get_logN₀ :233-237, get_distribution_logλ :284-320;
 // P3_integral_properties.jl D_m :56-61.
 //
-// COMPUTE-bound: ≈12 residual evaluations per point × 8 incomplete-gamma evaluations × 20/30 fixed
+// COMPUTE-bound (HISTORY.md §4.5): ≈12 residual evaluations per point × 8 incomplete-gamma evaluations × 20/30 fixed
 // iterations ≈ 1e5 flops per point against 32–72 B of HBM traffic — the roofline is the FP64 (FP32) vector rate,
 // not HBM.  What this kernel does about it:
 //   * the four mass-regime coefficients (a_k, b_k), log a_k and the segment boundaries are per-point invariants

@@ -37,12 +37,12 @@
  *    std::call_once).  Every entry is therefore re-entrant, capturable into a HIP graph, and safe to call
  *    concurrently from several host threads on several streams or devices;
  *  - no `cmx_*_host` entry points taking host pointers: a host-pointer variant could only be a copy-in / copy-out
- *    wrapper (PCIe 63 GB/s against 52 B/point: ≈ 90× below the HBM-resident rate, DESIGN.md §6) or a CPU
+ *    wrapper (PCIe 63 GB/s against 52 B/point: ≈ 90× below the HBM-resident rate, DESIGN.md §5) or a CPU
  *    implementation, and a CPU path inside the product is ruled out (the CPU restatement lives in oracle/ as
  *    test infrastructure only).  A caller with host data does hipMemcpyAsync on its own stream;
  *  - no `cmx_multi_*` device-list entry points: the multi-GPU model is one PROCESS per GPU (torch.distributed /
  *    RCCL, cmx/sharding.py); each rank calls the single-device entries on its contiguous shard of every column
- *    and there is no data-path collective to hide behind an API (DESIGN.md §7).
+ *    and there is no data-path collective to hide behind an API (DESIGN.md §8).
  */
 #ifndef CMX_H
 #define CMX_H

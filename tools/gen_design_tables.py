@@ -94,14 +94,17 @@ def performance_block(rnd):
     out = [f"Measured in ONE session on one box (round {rnd}; `profiles/bench_{rnd}/`, `profiles/{rnd}_kernel_stats_*.csv`, "
            f"`profiles/{rnd}_pmc_*.json`).  bench = HIP-event mean of the timed launches of `bench.py`; rocprof = mean (min) over the "
            "profiled launches of `rocprofv3 --kernel-trace --stats` in the same session — the two are printed side by side because they "
-           "differ by 1–5 % (profiler overhead, clock state).  frac = algorithmic bytes ÷ time ÷ 8 TB/s.  cold = mean of the first five "
-           "launches after the inputs are generated.", "",
-           "| workload | dtype | points | B/point | bench ms | cold ms | rocprof ms (min) | frac bench | frac rocprof | HBM traffic / algorithmic | "
-           "VALU instr / point | VALU issue utilisation | bound |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+           "differ by 1–5 % (profiler overhead, clock state).  HBM frac = algorithmic bytes ÷ time ÷ 8 TB/s.  cold = mean of the first five "
+           "launches after the inputs are generated.  VALU frac = SQ_INSTS_VALU x 2.4 cycles / (1024 SIMDs x rocprof mean x 2.4 GHz) — against the "
+           "fastest measured issue rate of a wave64 VALU instruction (`profiles/" + rnd + "_probe_valu.txt`), <= 1 by construction; 4-cycle slots = the "
+           "same count against one instruction per 4 cycles (round 2's figure; Float32 instructions issue faster than that).  `bound` is what "
+           "`bench.py` prices `roofline.frac` against.", "",
+           "| workload | dtype | points | B/point | bench ms | cold ms | rocprof ms (min) | HBM frac bench | HBM frac rocprof | HBM traffic / algorithmic | "
+           "VALU instr / point | VALU frac | 4-cycle slots | bound |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for _, dt, wl, n, bpp, ms, cold, ks, fb, fp, tro, ipp, util, bound in rows:
         out.append(f"| `{wl}` | {dt} | {n:.3g} | {bpp} | {ms:.3f} | {fmt(cold, '%.3f')} | " +
                    (f"{ks[0]:.3f} ({ks[1]:.3f})" if ks else "—") + f" | {fb:.3f} | {fmt(fp, '%.3f')} | {fmt(tro, '%.4f')} | {fmt(ipp, '%.0f')} | "
-                   f"{fmt(util, '%.2f')} | {bound} |")
+                   f"{fmt(util * 0.6 if util is not None else None, '%.2f')} | {fmt(util, '%.2f')} | {bound} |")
     return "\n".join(out)
 
 

@@ -1,4 +1,4 @@
-"""Which outputs of the 2M warm-rain entry are NaN when exactly one input column holds a NaN (documentation probe)."""
+"""Which outputs of the 2M warm-rain entry are NaN when exactly one input column holds a NaN (documentation probe, HISTORY.md §5, "NaN inputs")."""
 import sys
 from pathlib import Path
 
