@@ -31,7 +31,7 @@ def test_collision_kernels_do_not_spill(kernels):
     for k in col:
         assert k["vgpr_spill"] == 0, k
         assert k["vgpr"] <= 168, k             # three waves per SIMD (CMX_COL_WAVES)
-        assert k["private"] <= 8, k            # no scratch buffer beyond the 8-byte slot the OCML calls of the set-up reserve
+        assert k["private"] <= 32, k           # no spill area: only the 8–20-byte stack object the OCML calls of the set-up (lgamma) reserve
 
 
 def test_streaming_kernels_do_not_spill(kernels):
