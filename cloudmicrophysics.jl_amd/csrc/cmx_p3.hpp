@@ -364,16 +364,22 @@ __device__ __forceinline__ void p3_mass_law_at(const P3Consts<FT> &c, const P3Po
 
 // state_from_prognostic :101-106 (or P3State from (F_rim, ρ_rim)) → P3State :43-56: ρ_d (exact solution :191-199), ρ_g,
 // thresholds, and the per-segment mass-law coefficients (regime_value at the segment midpoint :320-332)
+// (F_rim, ρ_rim) of state_from_prognostic :101-106 alone — all the pointwise part of the 2M + P3 entry needs of the state
+template <typename FT>
+__device__ __forceinline__ void p3_rime_state(const P3Consts<FT> &c, FT rho_q, FT x3, FT x4, FT &F_rim, FT &rho_rim) {
+    using P = PM<FT>;
+    if (c.flags & CMX_P3_INPUT_IS_STATE) {
+        F_rim = x3; rho_rim = x4;
+    } else {
+        F_rim = Math<FT>::min(regularised_ratio<FT>(Math<FT>::min(x3, rho_q), rho_q), FT(1) - P::eps());
+        rho_rim = Math<FT>::min(regularised_ratio<FT>(x3, x4), c.rho_l_08);
+    }
+}
 template <typename FT>
 __device__ __forceinline__ void p3_make_point(const P3Consts<FT> &c, FT rho_q, FT rho_n, FT x3, FT x4, P3Point<FT> &s) {
     using P = PM<FT>;
     s.rho_q = rho_q; s.rho_n = rho_n;
-    if (c.flags & CMX_P3_INPUT_IS_STATE) {
-        s.F_rim = x3; s.rho_rim = x4;
-    } else {
-        s.F_rim = Math<FT>::min(regularised_ratio<FT>(Math<FT>::min(x3, s.rho_q), s.rho_q), FT(1) - P::eps());
-        s.rho_rim = Math<FT>::min(regularised_ratio<FT>(x3, x4), c.rho_l_08);
-    }
+    p3_rime_state<FT>(c, rho_q, x3, x4, s.F_rim, s.rho_rim);
     {
         const FT p = c.p_inv, logFu = P::log1p(-s.F_rim);
         const FT phi1 = exprel1<FT>(logFu), phi1mp = exprel1<FT>((FT(1) - p) * logFu);

@@ -163,6 +163,198 @@ template <typename FT> struct P3ColIO {
     FT *out[8];
 };
 
+// =====================================================================================================================
+// 2M + P3 fused entry — bulk_microphysics_tendencies(::Microphysics2Moment, mp{WR, P3IceParams}, …), BMT:898-1083.
+// Two launches on the caller's stream:
+//   1. mp2m_p3_pointwise_kernel (lane per point, HBM-bound): clamps, warm rain with the ice content in the vapour budget
+//      (sb2006_point<ICE>), F23 deposition nucleation, F23-capped Bigg freezing of cloud drops, ice sublimation/deposition,
+//      ice number adjustment, Bigg freezing of rain — writes the eight tendency columns;
+//   2. p3_collision_kernel<FUSED> (8 lanes per point, compute-bound): liquid–ice collisions, aggregation and melting where
+//      q_ice > ϵ and n_ice > ϵ — read-modify-writes the same columns.
+template <typename FT> struct PointwiseConsts {
+    FT f23_b10, f23_log_a, f23_T_freeze, inv_tau_act, m_nuc, T_dep, S_thresh;           // Frostenberg 2023 (IceNucleation.jl:250-511)
+    FT rf_a, rf_B, T_bigg;                                                             // RainFreezing, T_freeze − 4
+    FT ps_pow, ps_b, inv_T_tr, press_tr, R_v, LH_s0, dcp_s, T_0, cp_d, cpm_qt, cpm_ql, cpm_qi, T_freeze_tps;
+    FT tau_subdep;
+    FT mu_c, lg_z1, lg_z2, log_km_mu, G3, G6, k3, k6, V1, rho_w_V1sq;                   // cloud PSD moments (generalized gamma)
+    FT xr_min, xr_max, N0_min, N0_max, lam_min, lam_max, pi_rho_w;                      // rain PSD
+    FT inv_rho_i;
+};
+template <typename FT, typename WR, typename IP, typename TH>
+static PointwiseConsts<FT> make_pointwise_consts(const WR &wr, const IP &ip, const TH &tps) {
+    PointwiseConsts<FT> k{};
+    const double pi = 3.14159265358979323846;
+    const auto &fr = ip.ice_nucleation;
+    k.f23_b10 = (FT)(-(double)fr.b / 10.0); k.f23_log_a = fr.log_a; k.f23_T_freeze = fr.T_freeze;
+    k.inv_tau_act = (FT)(1.0 / (double)ip.tau_act);
+    k.m_nuc = (FT)((double)ip.scheme.rho_i * (1e-15 * pi / 6.0));                       // ρ_i · volume_sphere_D(10 µm) — BMT:999-1000
+    k.T_dep = (FT)((double)fr.T_freeze - 15.0); k.S_thresh = (FT)0.05;
+    k.rf_a = ip.rain_freezing.het_a; k.rf_B = ip.rain_freezing.het_B; k.T_bigg = (FT)((double)tps.T_freeze - 4.0);
+    const double dcp_i = (double)tps.cp_v - (double)tps.cp_i, Rv = tps.R_v;
+    k.ps_pow = (FT)(dcp_i / Rv); k.ps_b = (FT)(((double)tps.LH_s0 - dcp_i * (double)tps.T_0) / Rv); k.inv_T_tr = (FT)(1.0 / (double)tps.T_triple);
+    k.press_tr = tps.press_triple; k.R_v = tps.R_v; k.LH_s0 = tps.LH_s0; k.dcp_s = (FT)dcp_i; k.T_0 = tps.T_0;
+    k.cp_d = tps.cp_d; k.cpm_qt = (FT)((double)tps.cp_v - (double)tps.cp_d); k.cpm_ql = (FT)((double)tps.cp_l - (double)tps.cp_v);
+    k.cpm_qi = (FT)((double)tps.cp_i - (double)tps.cp_v); k.T_freeze_tps = tps.T_freeze;
+    k.tau_subdep = wr.subdep_tau_relax;
+    const auto &pc = ip.cloud_pdf;
+    const double nu = pc.nu_c, mu = pc.mu_c, km = (double)pc.rho_w * pi / 6.0, nuD = 3 * nu + 2, muD = 3 * mu;
+    k.mu_c = pc.mu_c; k.lg_z1 = pc.loggamma_z1; k.lg_z2 = pc.loggamma_z2; k.log_km_mu = (FT)(mu * std::log(km));
+    k.G3 = (FT)(std::tgamma((nuD + 4) / muD) / std::tgamma((nuD + 1) / muD));
+    k.G6 = (FT)(std::tgamma((nuD + 7) / muD) / std::tgamma((nuD + 1) / muD));
+    k.k3 = (FT)(-3.0 / muD); k.k6 = (FT)(-6.0 / muD);
+    k.V1 = (FT)(pi / 6.0); k.rho_w_V1sq = (FT)((double)pc.rho_w * (pi / 6.0) * (pi / 6.0));
+    const auto &pr = ip.rain_pdf;
+    k.xr_min = pr.xr_min; k.xr_max = pr.xr_max; k.N0_min = pr.N0_min; k.N0_max = pr.N0_max; k.lam_min = pr.lambda_min; k.lam_max = pr.lambda_max;
+    k.pi_rho_w = (FT)(pi * (double)pr.rho_w);
+    k.inv_rho_i = (FT)(1.0 / (double)ip.scheme.rho_i);
+    return k;
+}
+// liquid_freezing_rate(::RainFreezing, ::CloudParticlePDF_SB2006, …) — IceNucleation.jl:355-389: Bigg kinetics over the generalized-gamma
+// cloud PSD, M_D^k = n λc^(−k/μ) Γ((ν+1+k)/μ)/Γ((ν+1)/μ) with the Γ ratios folded on the host
+template <typename FT>
+__device__ __forceinline__ void bigg_cloud(const PointwiseConsts<FT> &k, FT J_bigg, FT rho, FT q_lcl, FT n_lcl, FT N_lcl, FT T, FT &bn, FT &bq) {
+    using P = PM<FT>;
+    const FT eps = P::eps();
+    bn = FT(0); bq = FT(0);
+    if (n_lcl > eps && q_lcl > eps && T < k.T_bigg && !(N_lcl < eps)) {
+        const FT log_lam_c = -k.mu_c * (P::log(rho * q_lcl / N_lcl) + k.lg_z1 - k.lg_z2) + k.log_km_mu;
+        bn = J_bigg * k.V1 * (n_lcl * P::exp(k.k3 * log_lam_c) * k.G3);
+        bq = J_bigg * k.rho_w_V1sq * (n_lcl * P::exp(k.k6 * log_lam_c) * k.G6);
+    }
+}
+// liquid_freezing_rate(::RainFreezing, pdf_r, …) — IceNucleation.jl:274-311: exponential rain PSD, M_D³ = 6 n D̄³, M_D⁶ = 720 n D̄⁶
+template <typename FT, bool LIMITED>
+__device__ __forceinline__ void bigg_rain(const PointwiseConsts<FT> &k, FT J_bigg, FT rho, FT q_rai, FT n_rai, FT N_rai, FT T, FT &rn, FT &rq) {
+    using P = PM<FT>;
+    using M = Math<FT>;
+    const FT eps = P::eps();
+    rn = FT(0); rq = FT(0);
+    if (n_rai > eps && q_rai > eps && T < k.T_bigg) {
+        const FT sq = q_rai, sN = M::max(N_rai, eps), L = rho * sq;
+        FT lam_r;
+        if constexpr (!LIMITED) lam_r = P::exp(P::log(k.pi_rho_w / (L / sN)) / FT(3));
+        else {
+            const FT xt = M::min(M::max(L / sN, k.xr_min), k.xr_max);
+            const FT N0 = M::min(M::max(sN * P::exp(P::log(k.pi_rho_w / xt) / FT(3)), k.N0_min), k.N0_max);
+            lam_r = M::min(M::max(M::sqrt(M::sqrt(k.pi_rho_w * N0 / L)), k.lam_min), k.lam_max);
+        }
+        FT Dr = FT(1) / lam_r;
+        if constexpr (!LIMITED) { if (N_rai < eps) Dr = FT(0); }                // gate of the not-limited PSD (CM2:83)
+        const FT D3 = Dr * Dr * Dr;
+        rn = J_bigg * k.V1 * (n_rai * FT(6) * D3);
+        rq = J_bigg * k.rho_w_V1sq * (n_rai * FT(720) * (D3 * D3));
+    }
+}
+
+#ifndef CMX_SB_INTPOW_P3
+#define CMX_SB_INTPOW_P3 1
+#endif
+template <typename FT> struct FusedIO {
+    const FT *rho, *T, *q_tot, *q_lcl, *n_lcl, *q_rai, *n_rai, *q_ice, *n_ice, *q_rim, *b_rim, *shift;
+    FT *out[8];
+};
+
+// The pointwise part of the 2M + P3 entry for ONE state: in[11] = (ρ, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice, n_ice, q_rim, b_rim) as stored
+// (unclamped), shift = the INPC log shift → d[8] = (dq_lcl, dn_lcl, dq_rai, dn_rai, dq_ice, dn_ice, dq_rim, db_rim), NaN-poisoned.
+// Called by the pointwise kernel (a lane per state) and by the epilogue of the collision kernel (the one-launch form).
+// FENCED (the collision kernel's epilogue, which has 168 registers): the finished sums of a section are pinned behind a compiler memory fence
+// before the next section starts — left alone the scheduler hoists the table reads of all the later exponentials above the warm-rain part and
+// spills eight register pairs to scratch.
+template <typename FT> __device__ __forceinline__ void section_fence(FT &a, FT &b, FT &c, FT &d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory"); }
+template <typename FT, bool LIMITED, bool INTPOW, bool FENCED = false>      // INTPOW: the integer-exponent warm-rain point function (cmx_sb2006.hpp), as the 2M entry
+__device__ __forceinline__ void mp2m_p3_point(const SbConsts<FT> &sc, const P3Consts<FT> &c, const PointwiseConsts<FT> &k, const FT (&in)[11], FT shift,
+                                              FT (&d)[8]) {
+    using P = PM<FT>;
+    using M = Math<FT>;
+    const FT eps = P::eps();
+    // NaN in → NaN out (cmx_math.hpp any_nan): formed first, so that the eleven raw inputs are not alive across the point function
+    const FT poison = any_nan(in[0], in[2], in[3], in[4], in[5], in[6], in[7], in[8], in[9], in[10], in[1]) ? M::nan() : FT(0);
+    // clamp_to_nonneg — BMT:912-921 (T is not clamped)
+    const FT rho = M::max(in[0], FT(0)), T = in[1], q_tot = M::max(in[2], FT(0));
+    const FT q_lcl = M::max(in[3], FT(0)), n_lcl = M::max(in[4], FT(0)), q_rai = M::max(in[5], FT(0)), n_rai = M::max(in[6], FT(0));
+    const FT q_ice = M::max(in[7], FT(0)), n_ice = M::max(in[8], FT(0)), q_rim = M::max(in[9], FT(0)), b_rim = M::max(in[10], FT(0));
+    const FT N_lcl = rho * n_lcl, N_rai = rho * n_rai, inv_rho = FT(1) / rho;
+    // warm rain — BMT:942 → warm_rain_tendencies_2m :707-782
+    const SbRates<FT> w = sb2006_point<FT, LIMITED, VEL_NONE, true, INTPOW>(sc, rho, T, q_tot, q_lcl, q_rai, N_lcl, N_rai, n_lcl, n_rai, q_ice, k.cpm_qi);
+    FT dq_lcl = (w.cond + w.au_dq_lcl) + w.ac_dq_lcl;
+    FT dn_lcl = M::fma(w.lsc_plus_au + w.ac_dN_lcl, w.inv_rho, w.na_lcl);
+    FT dq_rai = (w.evq + w.au_dq_rai) + w.ac_dq_rai;
+    FT dn_rai = M::fma(((w.evN + w.au_dN_rai) + w.rsc) + w.rbr, w.inv_rho, w.na_rai);
+    FT dq_ice = FT(0), dn_ice = FT(0), dq_rim = FT(0), db_rim = FT(0);
+    if constexpr (FENCED) section_fence(dq_lcl, dn_lcl, dq_rai, dn_rai);
+    // P3 state (F_rim, ρ_rim) — state_from_prognostic, P3_particle_properties.jl:101-106
+    P3Point<FT> s;
+    p3_rime_state<FT>(c, q_ice * rho, q_rim * rho, b_rim * rho, s.F_rim, s.rho_rim);
+    // ice saturation
+    const FT inv_T = FT(1) / T;
+    const FT ps_i = k.press_tr * P::exp(k.ps_pow * P::log(T * k.inv_T_tr) + k.ps_b * (k.inv_T_tr - inv_T));
+    const FT qsi = ps_i / (rho * k.R_v * T);
+    const FT q_vap = M::max(FT(0), (q_tot - (q_lcl + q_rai)) - q_ice);
+    // Frostenberg INPC per kg — INP_concentration_mean :250-253
+    const FT T_c = M::min(T - k.f23_T_freeze, FT(0));
+    const FT inpc_kg = P::exp(FT(9) * P::log(k.f23_b10 * T_c) - k.f23_log_a + shift) * inv_rho;
+    const FT n_active = n_ice;                                                    // NIceProxyDepletion :527
+    {   // deposition_rate :491-511
+        const bool cond = (T < k.T_dep) && (q_vap / qsi - FT(1) > k.S_thresh);
+        const FT rn = cond ? M::max(FT(0), inpc_kg - n_active) * k.inv_tau_act : FT(0);
+        const FT rq = M::min(k.m_nuc * rn, M::max(FT(0), q_vap - qsi) * (FT(0.5) * k.inv_tau_act));
+        dn_ice += rn; dq_ice += rq;
+    }
+    const FT J_bigg = k.rf_B * P::exp(k.rf_a * (k.T_freeze_tps - T));                // RainFreezing functor, parameters/IceNucleation.jl:146
+    {   // Bigg freezing of cloud drops (:355-389) capped by the F23 budget (immersion_limit_rate :425-435) — BMT:1013-1034
+        FT bn, bq;
+        bigg_cloud<FT>(k, J_bigg, rho, q_lcl, n_lcl, N_lcl, T, bn, bq);
+        const FT cap = T >= k.f23_T_freeze ? FT(0) : M::max(FT(0), inpc_kg - n_active) * k.inv_tau_act;
+        const FT imm_n = M::min(bn, cap);
+        const FT imm_q = bn > FT(0) ? bq * imm_n / bn : FT(0);
+        dq_lcl -= imm_q; dn_lcl -= imm_n; dq_ice += imm_q; dn_ice += imm_n; dq_rim += imm_q; db_rim += imm_q * k.inv_rho_i;
+    }
+    {   // sublimation / deposition — BMT:1037-1054, _conv_q_vap_to_q_icl_const NonEq:168-193
+        const FT L_s = k.LH_s0 + k.dcp_s * (T - k.T_0);
+        const FT cp_air = k.cp_d + k.cpm_qt * q_tot + k.cpm_ql * (q_lcl + q_rai) + k.cpm_qi * q_ice;
+        const FT dqsi_dT = qsi * (L_s / (k.R_v * (T * T)) - inv_T);
+        const FT ts = k.tau_subdep * (FT(1) + (L_s / cp_air) * dqsi_dT);
+        const FT excess = q_vap - qsi;
+        FT sd = excess < FT(0) ? -M::min(-excess, q_ice) / ts : excess / ts;
+        if (T > k.T_freeze_tps && sd > FT(0)) sd = FT(0);                         // INP limiter :56-58 and BMT:1045
+        const FT n_per_q = q_ice > eps ? n_ice / q_ice : FT(0);
+        dq_ice += sd;
+        dn_ice += sd < FT(0) ? n_per_q * sd : FT(0);
+        const FT sub = M::min(sd, FT(0));
+        dq_rim += sub * s.F_rim;
+        db_rim += s.rho_rim > FT(0) ? sub * s.F_rim / s.rho_rim : FT(0);
+    }
+    {   // ice number adjustment — BMT:1057-1064 (τ = 100 s, x ∈ [1e-12, 1e-5] kg), number_tendency_from_mass_limits CM2:882-891
+        const FT target = q_ice < eps ? FT(0) : clampv(n_ice, q_ice * FT(1e5), q_ice * FT(1e12));
+        dn_ice += (target - n_ice) * FT(0.01);
+    }
+    {   // Bigg freezing of rain — liquid_freezing_rate :274-311, BMT:1067-1075
+        FT rn, rq;
+        bigg_rain<FT, LIMITED>(k, J_bigg, rho, q_rai, n_rai, N_rai, T, rn, rq);
+        dq_rai -= rq; dn_rai -= rn; dq_ice += rq; dn_ice += rn; dq_rim += rq; db_rim += rq * k.inv_rho_i;
+    }
+    d[0] = dq_lcl + poison; d[1] = dn_lcl + poison; d[2] = dq_rai + poison; d[3] = dn_rai + poison;
+    d[4] = dq_ice + poison; d[5] = dn_ice + poison; d[6] = dq_rim + poison; d[7] = db_rim + poison;
+}
+template <typename FT> __device__ __forceinline__ void mp2m_p3_load(const FusedIO<FT> &io, int64_t i, FT (&in)[11], FT &shift) {
+    in[0] = io.rho[i]; in[1] = io.T[i]; in[2] = io.q_tot[i]; in[3] = io.q_lcl[i]; in[4] = io.n_lcl[i]; in[5] = io.q_rai[i]; in[6] = io.n_rai[i];
+    in[7] = io.q_ice[i]; in[8] = io.n_ice[i]; in[9] = io.q_rim[i]; in[10] = io.b_rim[i];
+    shift = io.shift ? io.shift[i] : FT(0);
+}
+
+template <typename FT, bool LIMITED, bool INTPOW = false>
+__global__ __launch_bounds__(kBlock) void mp2m_p3_pointwise_kernel(const SbConsts<FT> sc, const P3Consts<FT> c, const PointwiseConsts<FT> k,
+                                                                  const FusedIO<FT> io, const int64_t n) {
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    FT in[11], shift, d[8];
+    mp2m_p3_load<FT>(io, i, in, shift);
+    mp2m_p3_point<FT, LIMITED, INTPOW>(sc, c, k, in, shift, d);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) io.out[q][i] = d[q];
+}
+
 #ifndef CMX_COL_WAVES
 #define CMX_COL_WAVES 3      // min waves per SIMD the register allocator must leave room for: 168 VGPRs + 544 B scratch at 3 waves (what the
                              // 43 KB of LDS per workgroup admit) beat 256 VGPRs + 224 B at 2 (2M + P3, Float64: 29.9 → 28.0 ms per 1e6 states,
@@ -173,9 +365,22 @@ template <typename FT> struct ColLds {
     static __host__ __device__ __forceinline__ int per_group(int n) { return 6 * n + 100; }
 };
 
-template <typename FT, typename QUAD, bool ASPECT, bool FUSED, int GROUP>
+// EXTRA: NoExtra, or — the ONE-launch form of the 2M + P3 entry — PointwiseExtra<FT>: the constants and the two extra columns of the pointwise part,
+// which lane 0 of each group then evaluates in the epilogue (mp2m_p3_point) so that the eight tendency columns are written once instead of
+// written by one kernel and read-modify-written by the next (47 → 20 column passes).  The kernel-argument segment is 4 KiB: the form is
+// taken when the quadrature rule fits QuadSmall (order ≤ 32); larger rules run the two launches.
+struct NoExtra {};
+template <typename FT, bool LIMITED_, bool INTPOW_> struct PointwiseExtra {      // the warm-rain instantiation is part of the type: one variant per kernel
+    static constexpr bool LIMITED = LIMITED_, INTPOW = INTPOW_;
+    SbConsts<FT> sc;
+    PointwiseConsts<FT> pk;
+    const FT *q_tot, *shift;
+};
+template <typename FT> struct QuadSmall { int32_t n; FT node[32], weight[32]; };
+template <typename FT, typename QUAD, bool ASPECT, bool FUSED, int GROUP, typename EXTRA = NoExtra>
 __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(const P3Consts<FT> c, const P3VelConsts<FT> v, const P3ColConsts<FT> k,
-                                                             const QUAD quad, const P3ColIO<FT> io, const int64_t n) {
+                                                             const QUAD quad, const P3ColIO<FT> io, const int64_t n, const EXTRA ex) {
+    constexpr bool ONE_LAUNCH = !std::is_same_v<EXTRA, NoExtra>;
     Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using P = PM<FT>;
     using M = Math<FT>;
@@ -614,16 +819,30 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
 #pragma unroll
             for (int q = 0; q < 7; ++q)
                 if (io.src[q]) io.src[q][i] = o[q];
-        } else if (present) {
+        } else if (present || ONE_LAUNCH) {
             // BMT:966-994: collisions, aggregation (½π factored out of the sums), melting (ice → rain; rime drains in proportion)
             const FT agg = FT(0.5) * pi * acc_sc;
             const FT L_f = k.LH_f0 + k.dcp_f * (e_T - k.T_0);
             const FT mL = melts ? M::max(FT(0), k.K4 / L_f * (e_T - k.T_freeze_p3) * acc_m) : FT(0);
             const FT mq = mL * e_inv_rho, mn = (e_rho_n / e_rho_q * mL) * e_inv_rho;
-            const FT d[8] = {o[0], o[2] * e_inv_rho, o[1] + mq, o[3] * e_inv_rho + mn, o[5] * e_inv_rho - mq, -agg * e_inv_rho - mn,
-                             o[4] * e_inv_rho - mq * s.F_rim, o[6] * e_inv_rho - (e_rho_rim > FT(0) ? mq * s.F_rim / e_rho_rim : FT(0))};
+            FT d[8] = {o[0], o[2] * e_inv_rho, o[1] + mq, o[3] * e_inv_rho + mn, o[5] * e_inv_rho - mq, -agg * e_inv_rho - mn,
+                       o[4] * e_inv_rho - mq * s.F_rim, o[6] * e_inv_rho - (e_rho_rim > FT(0) ? mq * s.F_rim / e_rho_rim : FT(0))};
+            if constexpr (!ONE_LAUNCH) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) io.out[q][i] += d[q];
+                for (int q = 0; q < 8; ++q) io.out[q][i] += d[q];
+            } else {
+                // park the ice-process sums in the state's LDS block (the rain constants there are dead now), evaluate the pointwise part of the
+                // entry for this state, add, write each column once
+#pragma unroll
+                for (int q = 0; q < 8; ++q) S[q] = present ? d[q] : FT(0);
+                FT in[11], pw[8];
+                in[0] = io.rho_a[i]; in[1] = io.T[i]; in[2] = ex.q_tot[i]; in[3] = io.q_lcl[i]; in[4] = io.n_lcl[i]; in[5] = io.q_rai[i];
+                in[6] = io.n_rai[i]; in[7] = io.q_ice[i]; in[8] = io.n_ice[i]; in[9] = io.q_rim[i]; in[10] = io.b_rim[i];
+                const FT shift = ex.shift ? ex.shift[i] : FT(0);
+                mp2m_p3_point<FT, EXTRA::LIMITED, EXTRA::INTPOW, true>(ex.sc, c, ex.pk, in, shift, pw);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) io.out[q][i] = pw[q] + Sv[q];
+            }
         }
     }
 }
@@ -639,21 +858,22 @@ template <typename FT> static void collision_geometry(int group, int nq, int64_t
 
 // one launch site for both entries: picks the group width from the quadrature order, sizes the workgroup so the LDS caches fit,
 // raises the dynamic-LDS limit when needed
-template <typename FT, typename QUAD, bool FUSED>
+template <typename FT, typename QUAD, bool FUSED, typename EXTRA = NoExtra>
 static int32_t launch_collision_kernel(const P3Consts<FT> &c, const P3VelConsts<FT> &v, const P3ColConsts<FT> &k, const QUAD &quad,
-                                       const P3ColIO<FT> &io, int64_t n, bool aspect, hipStream_t st) {
+                                       const P3ColIO<FT> &io, int64_t n, bool aspect, hipStream_t st, const EXTRA &ex = EXTRA{}) {
     const int group = collision_group(quad.n);
     dim3 grid, block;
     size_t lds;
     collision_geometry<FT>(group, quad.n, n, grid, block, lds);
     auto go = [&](auto kern) -> int32_t {
         if (lds > 48 * 1024) CMX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, grid, block, lds, st, c, v, k, quad, io, n);
+        hipLaunchKernelGGL(kern, grid, block, lds, st, c, v, k, quad, io, n, ex);
         CMX_HIP_TRY(hipGetLastError());
         return CMX_OK;
     };
-    if (group == 8) return aspect ? go(&p3_collision_kernel<FT, QUAD, true, FUSED, 8>) : go(&p3_collision_kernel<FT, QUAD, false, FUSED, 8>);
-    return aspect ? go(&p3_collision_kernel<FT, QUAD, true, FUSED, 16>) : go(&p3_collision_kernel<FT, QUAD, false, FUSED, 16>);
+    if (group == 8)
+        return aspect ? go(&p3_collision_kernel<FT, QUAD, true, FUSED, 8, EXTRA>) : go(&p3_collision_kernel<FT, QUAD, false, FUSED, 8, EXTRA>);
+    return aspect ? go(&p3_collision_kernel<FT, QUAD, true, FUSED, 16, EXTRA>) : go(&p3_collision_kernel<FT, QUAD, false, FUSED, 16, EXTRA>);
 }
 
 template <typename FT, typename IP, typename AP, typename TH, typename QUAD>
@@ -678,177 +898,6 @@ static int32_t p3_collision_entry(const IP *ip, const AP *aps, const TH *tps, co
     for (int q = 0; q < 7; ++q) io.src[q] = sources ? sources[q] : nullptr;
     for (int q = 0; q < 10; ++q) io.rates[q] = rates ? rates[q] : nullptr;
     return launch_collision_kernel<FT, QUAD, false>(c, v, k, *quad, io, n, !(flags & CMX_P3_NO_ASPECT_RATIO), reinterpret_cast<hipStream_t>(stream));
-}
-
-// =====================================================================================================================
-// 2M + P3 fused entry — bulk_microphysics_tendencies(::Microphysics2Moment, mp{WR, P3IceParams}, …), BMT:898-1083.
-// Two launches on the caller's stream:
-//   1. mp2m_p3_pointwise_kernel (lane per point, HBM-bound): clamps, warm rain with the ice content in the vapour budget
-//      (sb2006_point<ICE>), F23 deposition nucleation, F23-capped Bigg freezing of cloud drops, ice sublimation/deposition,
-//      ice number adjustment, Bigg freezing of rain — writes the eight tendency columns;
-//   2. p3_collision_kernel<FUSED> (8 lanes per point, compute-bound): liquid–ice collisions, aggregation and melting where
-//      q_ice > ϵ and n_ice > ϵ — read-modify-writes the same columns.
-template <typename FT> struct PointwiseConsts {
-    FT f23_b10, f23_log_a, f23_T_freeze, inv_tau_act, m_nuc, T_dep, S_thresh;           // Frostenberg 2023 (IceNucleation.jl:250-511)
-    FT rf_a, rf_B, T_bigg;                                                             // RainFreezing, T_freeze − 4
-    FT ps_pow, ps_b, inv_T_tr, press_tr, R_v, LH_s0, dcp_s, T_0, cp_d, cpm_qt, cpm_ql, cpm_qi, T_freeze_tps;
-    FT tau_subdep;
-    FT mu_c, lg_z1, lg_z2, log_km_mu, G3, G6, k3, k6, V1, rho_w_V1sq;                   // cloud PSD moments (generalized gamma)
-    FT xr_min, xr_max, N0_min, N0_max, lam_min, lam_max, pi_rho_w;                      // rain PSD
-    FT inv_rho_i;
-};
-template <typename FT, typename WR, typename IP, typename TH>
-static PointwiseConsts<FT> make_pointwise_consts(const WR &wr, const IP &ip, const TH &tps) {
-    PointwiseConsts<FT> k{};
-    const double pi = 3.14159265358979323846;
-    const auto &fr = ip.ice_nucleation;
-    k.f23_b10 = (FT)(-(double)fr.b / 10.0); k.f23_log_a = fr.log_a; k.f23_T_freeze = fr.T_freeze;
-    k.inv_tau_act = (FT)(1.0 / (double)ip.tau_act);
-    k.m_nuc = (FT)((double)ip.scheme.rho_i * (1e-15 * pi / 6.0));                       // ρ_i · volume_sphere_D(10 µm) — BMT:999-1000
-    k.T_dep = (FT)((double)fr.T_freeze - 15.0); k.S_thresh = (FT)0.05;
-    k.rf_a = ip.rain_freezing.het_a; k.rf_B = ip.rain_freezing.het_B; k.T_bigg = (FT)((double)tps.T_freeze - 4.0);
-    const double dcp_i = (double)tps.cp_v - (double)tps.cp_i, Rv = tps.R_v;
-    k.ps_pow = (FT)(dcp_i / Rv); k.ps_b = (FT)(((double)tps.LH_s0 - dcp_i * (double)tps.T_0) / Rv); k.inv_T_tr = (FT)(1.0 / (double)tps.T_triple);
-    k.press_tr = tps.press_triple; k.R_v = tps.R_v; k.LH_s0 = tps.LH_s0; k.dcp_s = (FT)dcp_i; k.T_0 = tps.T_0;
-    k.cp_d = tps.cp_d; k.cpm_qt = (FT)((double)tps.cp_v - (double)tps.cp_d); k.cpm_ql = (FT)((double)tps.cp_l - (double)tps.cp_v);
-    k.cpm_qi = (FT)((double)tps.cp_i - (double)tps.cp_v); k.T_freeze_tps = tps.T_freeze;
-    k.tau_subdep = wr.subdep_tau_relax;
-    const auto &pc = ip.cloud_pdf;
-    const double nu = pc.nu_c, mu = pc.mu_c, km = (double)pc.rho_w * pi / 6.0, nuD = 3 * nu + 2, muD = 3 * mu;
-    k.mu_c = pc.mu_c; k.lg_z1 = pc.loggamma_z1; k.lg_z2 = pc.loggamma_z2; k.log_km_mu = (FT)(mu * std::log(km));
-    k.G3 = (FT)(std::tgamma((nuD + 4) / muD) / std::tgamma((nuD + 1) / muD));
-    k.G6 = (FT)(std::tgamma((nuD + 7) / muD) / std::tgamma((nuD + 1) / muD));
-    k.k3 = (FT)(-3.0 / muD); k.k6 = (FT)(-6.0 / muD);
-    k.V1 = (FT)(pi / 6.0); k.rho_w_V1sq = (FT)((double)pc.rho_w * (pi / 6.0) * (pi / 6.0));
-    const auto &pr = ip.rain_pdf;
-    k.xr_min = pr.xr_min; k.xr_max = pr.xr_max; k.N0_min = pr.N0_min; k.N0_max = pr.N0_max; k.lam_min = pr.lambda_min; k.lam_max = pr.lambda_max;
-    k.pi_rho_w = (FT)(pi * (double)pr.rho_w);
-    k.inv_rho_i = (FT)(1.0 / (double)ip.scheme.rho_i);
-    return k;
-}
-// liquid_freezing_rate(::RainFreezing, ::CloudParticlePDF_SB2006, …) — IceNucleation.jl:355-389: Bigg kinetics over the generalized-gamma
-// cloud PSD, M_D^k = n λc^(−k/μ) Γ((ν+1+k)/μ)/Γ((ν+1)/μ) with the Γ ratios folded on the host
-template <typename FT>
-__device__ __forceinline__ void bigg_cloud(const PointwiseConsts<FT> &k, FT J_bigg, FT rho, FT q_lcl, FT n_lcl, FT N_lcl, FT T, FT &bn, FT &bq) {
-    using P = PM<FT>;
-    const FT eps = P::eps();
-    bn = FT(0); bq = FT(0);
-    if (n_lcl > eps && q_lcl > eps && T < k.T_bigg && !(N_lcl < eps)) {
-        const FT log_lam_c = -k.mu_c * (P::log(rho * q_lcl / N_lcl) + k.lg_z1 - k.lg_z2) + k.log_km_mu;
-        bn = J_bigg * k.V1 * (n_lcl * P::exp(k.k3 * log_lam_c) * k.G3);
-        bq = J_bigg * k.rho_w_V1sq * (n_lcl * P::exp(k.k6 * log_lam_c) * k.G6);
-    }
-}
-// liquid_freezing_rate(::RainFreezing, pdf_r, …) — IceNucleation.jl:274-311: exponential rain PSD, M_D³ = 6 n D̄³, M_D⁶ = 720 n D̄⁶
-template <typename FT, bool LIMITED>
-__device__ __forceinline__ void bigg_rain(const PointwiseConsts<FT> &k, FT J_bigg, FT rho, FT q_rai, FT n_rai, FT N_rai, FT T, FT &rn, FT &rq) {
-    using P = PM<FT>;
-    using M = Math<FT>;
-    const FT eps = P::eps();
-    rn = FT(0); rq = FT(0);
-    if (n_rai > eps && q_rai > eps && T < k.T_bigg) {
-        const FT sq = q_rai, sN = M::max(N_rai, eps), L = rho * sq;
-        FT lam_r;
-        if constexpr (!LIMITED) lam_r = P::exp(P::log(k.pi_rho_w / (L / sN)) / FT(3));
-        else {
-            const FT xt = M::min(M::max(L / sN, k.xr_min), k.xr_max);
-            const FT N0 = M::min(M::max(sN * P::exp(P::log(k.pi_rho_w / xt) / FT(3)), k.N0_min), k.N0_max);
-            lam_r = M::min(M::max(M::sqrt(M::sqrt(k.pi_rho_w * N0 / L)), k.lam_min), k.lam_max);
-        }
-        FT Dr = FT(1) / lam_r;
-        if constexpr (!LIMITED) { if (N_rai < eps) Dr = FT(0); }                // gate of the not-limited PSD (CM2:83)
-        const FT D3 = Dr * Dr * Dr;
-        rn = J_bigg * k.V1 * (n_rai * FT(6) * D3);
-        rq = J_bigg * k.rho_w_V1sq * (n_rai * FT(720) * (D3 * D3));
-    }
-}
-
-#ifndef CMX_SB_INTPOW_P3
-#define CMX_SB_INTPOW_P3 1
-#endif
-template <typename FT> struct FusedIO {
-    const FT *rho, *T, *q_tot, *q_lcl, *n_lcl, *q_rai, *n_rai, *q_ice, *n_ice, *q_rim, *b_rim, *shift;
-    FT *out[8];
-};
-
-template <typename FT, bool LIMITED, bool INTPOW = false>      // INTPOW: the integer-exponent warm-rain point function (cmx_sb2006.hpp), as the 2M entry
-__global__ __launch_bounds__(kBlock) void mp2m_p3_pointwise_kernel(const SbConsts<FT> sc, const P3Consts<FT> c, const PointwiseConsts<FT> k,
-                                                                  const FusedIO<FT> io, const int64_t n) {
-    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
-    using P = PM<FT>;
-    using M = Math<FT>;
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const FT eps = P::eps();
-    // clamp_to_nonneg — BMT:912-921 (T is not clamped)
-    const FT rho = M::max(io.rho[i], FT(0)), T = io.T[i], q_tot = M::max(io.q_tot[i], FT(0));
-    const FT q_lcl = M::max(io.q_lcl[i], FT(0)), n_lcl = M::max(io.n_lcl[i], FT(0)), q_rai = M::max(io.q_rai[i], FT(0)), n_rai = M::max(io.n_rai[i], FT(0));
-    const FT q_ice = M::max(io.q_ice[i], FT(0)), n_ice = M::max(io.n_ice[i], FT(0)), q_rim = M::max(io.q_rim[i], FT(0)), b_rim = M::max(io.b_rim[i], FT(0));
-    const FT shift = io.shift ? io.shift[i] : FT(0);
-    const FT N_lcl = rho * n_lcl, N_rai = rho * n_rai, inv_rho = FT(1) / rho;
-    // warm rain — BMT:942 → warm_rain_tendencies_2m :707-782
-    const SbRates<FT> w = sb2006_point<FT, LIMITED, VEL_NONE, true, INTPOW>(sc, rho, T, q_tot, q_lcl, q_rai, N_lcl, N_rai, n_lcl, n_rai, q_ice, k.cpm_qi);
-    FT dq_lcl = (w.cond + w.au_dq_lcl) + w.ac_dq_lcl;
-    FT dn_lcl = M::fma(w.lsc_plus_au + w.ac_dN_lcl, w.inv_rho, w.na_lcl);
-    FT dq_rai = (w.evq + w.au_dq_rai) + w.ac_dq_rai;
-    FT dn_rai = M::fma(((w.evN + w.au_dN_rai) + w.rsc) + w.rbr, w.inv_rho, w.na_rai);
-    FT dq_ice = FT(0), dn_ice = FT(0), dq_rim = FT(0), db_rim = FT(0);
-    // P3 state (F_rim, ρ_rim) — state_from_prognostic, P3_particle_properties.jl:101-106
-    P3Point<FT> s;
-    p3_make_point<FT>(c, q_ice * rho, n_ice * rho, q_rim * rho, b_rim * rho, s);
-    // ice saturation
-    const FT inv_T = FT(1) / T;
-    const FT ps_i = k.press_tr * P::exp(k.ps_pow * P::log(T * k.inv_T_tr) + k.ps_b * (k.inv_T_tr - inv_T));
-    const FT qsi = ps_i / (rho * k.R_v * T);
-    const FT q_vap = M::max(FT(0), (q_tot - (q_lcl + q_rai)) - q_ice);
-    // Frostenberg INPC per kg — INP_concentration_mean :250-253
-    const FT T_c = M::min(T - k.f23_T_freeze, FT(0));
-    const FT inpc_kg = P::exp(FT(9) * P::log(k.f23_b10 * T_c) - k.f23_log_a + shift) * inv_rho;
-    const FT n_active = n_ice;                                                    // NIceProxyDepletion :527
-    {   // deposition_rate :491-511
-        const bool cond = (T < k.T_dep) && (q_vap / qsi - FT(1) > k.S_thresh);
-        const FT rn = cond ? M::max(FT(0), inpc_kg - n_active) * k.inv_tau_act : FT(0);
-        const FT rq = M::min(k.m_nuc * rn, M::max(FT(0), q_vap - qsi) * (FT(0.5) * k.inv_tau_act));
-        dn_ice += rn; dq_ice += rq;
-    }
-    const FT J_bigg = k.rf_B * P::exp(k.rf_a * (k.T_freeze_tps - T));                // RainFreezing functor, parameters/IceNucleation.jl:146
-    {   // Bigg freezing of cloud drops (:355-389) capped by the F23 budget (immersion_limit_rate :425-435) — BMT:1013-1034
-        FT bn, bq;
-        bigg_cloud<FT>(k, J_bigg, rho, q_lcl, n_lcl, N_lcl, T, bn, bq);
-        const FT cap = T >= k.f23_T_freeze ? FT(0) : M::max(FT(0), inpc_kg - n_active) * k.inv_tau_act;
-        const FT imm_n = M::min(bn, cap);
-        const FT imm_q = bn > FT(0) ? bq * imm_n / bn : FT(0);
-        dq_lcl -= imm_q; dn_lcl -= imm_n; dq_ice += imm_q; dn_ice += imm_n; dq_rim += imm_q; db_rim += imm_q * k.inv_rho_i;
-    }
-    {   // sublimation / deposition — BMT:1037-1054, _conv_q_vap_to_q_icl_const NonEq:168-193
-        const FT L_s = k.LH_s0 + k.dcp_s * (T - k.T_0);
-        const FT cp_air = k.cp_d + k.cpm_qt * q_tot + k.cpm_ql * (q_lcl + q_rai) + k.cpm_qi * q_ice;
-        const FT dqsi_dT = qsi * (L_s / (k.R_v * (T * T)) - inv_T);
-        const FT ts = k.tau_subdep * (FT(1) + (L_s / cp_air) * dqsi_dT);
-        const FT excess = q_vap - qsi;
-        FT sd = excess < FT(0) ? -M::min(-excess, q_ice) / ts : excess / ts;
-        if (T > k.T_freeze_tps && sd > FT(0)) sd = FT(0);                         // INP limiter :56-58 and BMT:1045
-        const FT n_per_q = q_ice > eps ? n_ice / q_ice : FT(0);
-        dq_ice += sd;
-        dn_ice += sd < FT(0) ? n_per_q * sd : FT(0);
-        const FT sub = M::min(sd, FT(0));
-        dq_rim += sub * s.F_rim;
-        db_rim += s.rho_rim > FT(0) ? sub * s.F_rim / s.rho_rim : FT(0);
-    }
-    {   // ice number adjustment — BMT:1057-1064 (τ = 100 s, x ∈ [1e-12, 1e-5] kg), number_tendency_from_mass_limits CM2:882-891
-        const FT target = q_ice < eps ? FT(0) : clampv(n_ice, q_ice * FT(1e5), q_ice * FT(1e12));
-        dn_ice += (target - n_ice) * FT(0.01);
-    }
-    {   // Bigg freezing of rain — liquid_freezing_rate :274-311, BMT:1067-1075
-        FT rn, rq;
-        bigg_rain<FT, LIMITED>(k, J_bigg, rho, q_rai, n_rai, N_rai, T, rn, rq);
-        dq_rai -= rq; dn_rai -= rn; dq_ice += rq; dn_ice += rn; dq_rim += rq; db_rim += rq * k.inv_rho_i;
-    }
-    // NaN in → NaN out (cmx_math.hpp any_nan); the collision kernel then adds to the poisoned columns
-    const FT poison = any_nan(io.rho[i], io.q_tot[i], io.q_lcl[i], io.n_lcl[i], io.q_rai[i], io.n_rai[i], io.q_ice[i], io.n_ice[i], io.q_rim[i],
-                              io.b_rim[i], T) ? M::nan() : FT(0);
-    io.out[0][i] = dq_lcl + poison; io.out[1][i] = dn_lcl + poison; io.out[2][i] = dq_rai + poison; io.out[3][i] = dn_rai + poison;
-    io.out[4][i] = dq_ice + poison; io.out[5][i] = dn_ice + poison; io.out[6][i] = dq_rim + poison; io.out[7][i] = db_rim + poison;
 }
 
 // stand-alone Bigg freezing rates (the KA kernel test_rain_freezing_kernel!, test/gpu_tests.jl:463-468): cloud = generalized-gamma PSD
@@ -904,19 +953,8 @@ static int32_t mp2m_p3_entry(const WR *wr, const IP *ip, const TH *tps, uint32_t
     P3Consts<FT> c = make_p3_consts<FT>(ip->scheme, flags & CMX_P3_SLOPE_CONSTANT);
     c.brent_iters = 0;
     const PointwiseConsts<FT> pk = make_pointwise_consts<FT>(*wr, *ip, *tps);
-    FusedIO<FT> fio{rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice, n_ice, q_rim, b_rim, shift, {}};
-    for (int q = 0; q < 8; ++q) fio.out[q] = out[q];
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const dim3 block(kBlock), grid1((unsigned)((n + kBlock - 1) / kBlock));
-    // the same warm-rain instantiation as cmx_sb2006_warm_rain_tendencies_* picks (without ice the two entries agree bit for bit)
-    if (sb_integer_exponents(*wr) && CMX_SB_INTPOW_P3) {
-        if (limited) hipLaunchKernelGGL((mp2m_p3_pointwise_kernel<FT, true, true>), grid1, block, 0, st, sc, c, pk, fio, n);
-        else hipLaunchKernelGGL((mp2m_p3_pointwise_kernel<FT, false, true>), grid1, block, 0, st, sc, c, pk, fio, n);
-    } else {
-        if (limited) hipLaunchKernelGGL((mp2m_p3_pointwise_kernel<FT, true>), grid1, block, 0, st, sc, c, pk, fio, n);
-        else hipLaunchKernelGGL((mp2m_p3_pointwise_kernel<FT, false>), grid1, block, 0, st, sc, c, pk, fio, n);
-    }
-    CMX_HIP_TRY(hipGetLastError());
+    const bool intpow = sb_integer_exponents(*wr) && CMX_SB_INTPOW_P3;   // the same warm-rain instantiation as cmx_sb2006_warm_rain_tendencies_* picks
     // ice processes
     P3VelConsts<FT> v = make_p3_vel_consts<FT>(ip->scheme, ip->vel_ice, 1e-5);
     v.p_lo = FT(0.00001); v.p_hi = FT(1) - v.p_lo;
@@ -926,6 +964,35 @@ static int32_t mp2m_p3_entry(const WR *wr, const IP *ip, const TH *tps, uint32_t
     io.q_lcl = q_lcl; io.n_lcl = n_lcl; io.q_rai = q_rai; io.n_rai = n_rai; io.q_ice = q_ice; io.n_ice = n_ice; io.q_rim = q_rim; io.b_rim = b_rim;
     for (int q = 0; q < 8; ++q) io.out[q] = out[q];
     using QUAD = std::remove_cv_t<std::remove_reference_t<decltype(ip->quad)>>;
+#ifndef CMX_MP2M_P3_ONE_LAUNCH
+#define CMX_MP2M_P3_ONE_LAUNCH 1      // 0: always the two launches (A/B switch)
+#endif
+    if (CMX_MP2M_P3_ONE_LAUNCH && ip->quad.n <= 32) {
+        // ONE launch: the collision kernel's epilogue evaluates the pointwise part too (PointwiseExtra) — each tendency column is written once
+        QuadSmall<FT> qs{};
+        qs.n = ip->quad.n;
+        for (int j = 0; j < qs.n; ++j) { qs.node[j] = ip->quad.node[j]; qs.weight[j] = ip->quad.weight[j]; }
+        const bool aspect = !(flags & CMX_P3_NO_ASPECT_RATIO);
+        auto go = [&](auto ex) -> int32_t {
+            ex.sc = sc; ex.pk = pk; ex.q_tot = q_tot; ex.shift = shift;
+            return launch_collision_kernel<FT, QuadSmall<FT>, true, decltype(ex)>(c, v, k, qs, io, n, aspect, st, ex);
+        };
+        if (limited) return intpow ? go(PointwiseExtra<FT, true, true>{}) : go(PointwiseExtra<FT, true, false>{});
+        return intpow ? go(PointwiseExtra<FT, false, true>{}) : go(PointwiseExtra<FT, false, false>{});
+    }
+    // TWO launches (quadrature rules above order 32 — the kernel-argument segment is 4 KiB): pointwise kernel, then the collision kernel
+    // read-modify-writes the eight columns
+    FusedIO<FT> fio{rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice, n_ice, q_rim, b_rim, shift, {}};
+    for (int q = 0; q < 8; ++q) fio.out[q] = out[q];
+    const dim3 block(kBlock), grid1((unsigned)((n + kBlock - 1) / kBlock));
+    if (intpow) {
+        if (limited) hipLaunchKernelGGL((mp2m_p3_pointwise_kernel<FT, true, true>), grid1, block, 0, st, sc, c, pk, fio, n);
+        else hipLaunchKernelGGL((mp2m_p3_pointwise_kernel<FT, false, true>), grid1, block, 0, st, sc, c, pk, fio, n);
+    } else {
+        if (limited) hipLaunchKernelGGL((mp2m_p3_pointwise_kernel<FT, true>), grid1, block, 0, st, sc, c, pk, fio, n);
+        else hipLaunchKernelGGL((mp2m_p3_pointwise_kernel<FT, false>), grid1, block, 0, st, sc, c, pk, fio, n);
+    }
+    CMX_HIP_TRY(hipGetLastError());
     return launch_collision_kernel<FT, QUAD, true>(c, v, k, ip->quad, io, n, !(flags & CMX_P3_NO_ASPECT_RATIO), st);
 }
 
