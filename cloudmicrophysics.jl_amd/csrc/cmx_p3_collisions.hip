@@ -831,18 +831,28 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
 #pragma unroll
                 for (int q = 0; q < 8; ++q) io.out[q][i] += d[q];
             } else {
-                // park the ice-process sums in the state's LDS block (the rain constants there are dead now), evaluate the pointwise part of the
-                // entry for this state, add, write each column once
+                // park the ice-process sums in the state's LDS block (the rain constants there are dead now) for the pointwise pass below
 #pragma unroll
                 for (int q = 0; q < 8; ++q) S[q] = present ? d[q] : FT(0);
-                FT in[11], pw[8];
-                in[0] = io.rho_a[i]; in[1] = io.T[i]; in[2] = ex.q_tot[i]; in[3] = io.q_lcl[i]; in[4] = io.n_lcl[i]; in[5] = io.q_rai[i];
-                in[6] = io.n_rai[i]; in[7] = io.q_ice[i]; in[8] = io.n_ice[i]; in[9] = io.q_rim[i]; in[10] = io.b_rim[i];
-                const FT shift = ex.shift ? ex.shift[i] : FT(0);
-                mp2m_p3_point<FT, EXTRA::LIMITED, EXTRA::INTPOW, true>(ex.sc, c, ex.pk, in, shift, pw);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) io.out[q][i] = pw[q] + Sv[q];
             }
+        }
+    }
+    if constexpr (ONE_LAUNCH) {
+        // The pointwise part of the entry for the workgroup's states, one state per LANE of the first wave(s) instead of one per group: lane 0
+        // of a group doing it would run the ≈ 1 500 instructions with 8 of 64 lanes active in every wave (+1.1 % Float64, +2.5 % Float32 on the
+        // 2M + P3 step, same-box A/B); here 32 states share one pass of them.  Each tendency column is written once.
+        __syncthreads();
+        const int nst = blockDim.x / GROUP;
+        const int64_t i2 = (int64_t)blockIdx.x * nst + threadIdx.x;
+        if ((int)threadIdx.x < nst && i2 < n) {
+            const volatile FT *S2 = lds + 2 * nq + threadIdx.x * ColLds<FT>::per_group(nq) + 72;
+            FT in[11], pw[8];
+            in[0] = io.rho_a[i2]; in[1] = io.T[i2]; in[2] = ex.q_tot[i2]; in[3] = io.q_lcl[i2]; in[4] = io.n_lcl[i2]; in[5] = io.q_rai[i2];
+            in[6] = io.n_rai[i2]; in[7] = io.q_ice[i2]; in[8] = io.n_ice[i2]; in[9] = io.q_rim[i2]; in[10] = io.b_rim[i2];
+            const FT shift = ex.shift ? ex.shift[i2] : FT(0);
+            mp2m_p3_point<FT, EXTRA::LIMITED, EXTRA::INTPOW, true>(ex.sc, c, ex.pk, in, shift, pw);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) io.out[q][i2] = pw[q] + S2[q];
         }
     }
 }
