@@ -580,8 +580,8 @@ def setup_mp2m_p3(args, dev, dtype, rank):
     step()
     desc = {
         "metric": "grid-points/sec 2M + P3 fused tendencies (warm rain + collisions + aggregation + melting + nucleation, GaussLegendre(16))",
-        "bytes_per_point": {"f32": 112, "f64": 224}[args.dtype],      # 12 in + 8 out (the second launch re-reads and re-writes the 8)
-        "kernel": "mp2m_p3_pointwise_kernel + p3_collision_kernel<FUSED>", "bound": "valu",
+        "bytes_per_point": {"f32": 80, "f64": 160}[args.dtype],      # 12 in + 8 out, each column once (one launch since round 3)
+        "kernel": "p3_collision_kernel<FUSED, PointwiseExtra> (one launch: ice processes, 8 lanes per state, + the pointwise part per lane)", "bound": "valu",
         "workload": "bulk_microphysics_tendencies(Microphysics2Moment(), mp{WarmRain, P3IceParams}, …) — BMT:898-1083, quadrature_order 16",
         "columns_in": 12, "columns_out": 8, "diag_cols": [],
     }

@@ -267,6 +267,18 @@ template <typename FT> __device__ FT gamma_inc_dev(FT a, FT x, FT lgam_a, bool w
     return (series == want_P) ? pq : FT(1) - pq;
 }
 
+// A kernel-argument constant used as one side of a per-lane select.  Without this the optimiser rewrites `c ? k.a : k.b` (two uniform scalar
+// loads) into a load of the SELECTED ADDRESS — a per-lane vector load from the kernel-argument segment inside the quadrature loops (round 3:
+// two such loads per inner node of the self-collection integral, with three waves per SIMD to hide them).  The empty asm makes the loaded
+// value opaque in an SGPR, so the select stays a select of registers.  Float32 only (self-collection 19.8 → 19.5 ms per 1e6 states, same-box
+// A/B): in the Float64 kernels the SGPR file is over-subscribed and the pinned constants are re-loaded with scalar loads + s_waitcnt inside the
+// loop (2M + P3 22.2 → 30.2 ms, self-collection 62.4 → 76.4 — measured, reverted); there the vector loads, whose latency the other waves hide,
+// are the better code.
+template <typename FT> __device__ __forceinline__ FT kpin(FT x) {
+    if constexpr (sizeof(FT) == 4) asm volatile("" : "+s"(x));
+    return x;
+}
+
 template <typename FT> struct P3Point {
     FT rho_q, rho_n, F_rim, rho_rim, rho_g;
     FT bnd[5];          // 0, D_th, D_gr, D_cr, ∞          segment_boundaries :280-291

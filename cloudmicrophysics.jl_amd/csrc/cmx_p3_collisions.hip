@@ -486,7 +486,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
         const bool small = x <= v.cutoff;
         const FT E1 = small ? se + sb * logD : le1 + v.l_b1 * logD;
         const FT dE = small ? -v.s_c2 * x : (le2 - le1) + (v.l_b2 - v.l_b1) * logD - v.l_c2 * x;
-        const FT A1 = small ? v.s_E : v.l_a1, A2 = small ? v.s_F : v.l_a2;
+        const FT A1 = small ? kpin(v.s_E) : kpin(v.l_a1), A2 = small ? kpin(v.s_F) : kpin(v.l_a2);
         vv = P::exp(eA + E1, kc) * (A1 + A2 * P::exp(dE, kc));
         nn = P::exp(logN0 + mu * logD - lam * x, kc);
     };

@@ -103,6 +103,35 @@ def test_fused_entry_parity(dev, oracle, ft, limited):
     assert (ref[5][ice] != 0).all() and (ref[4][~ice & (s["T"] < 250)] >= 0).all()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", [32, 40])
+def test_both_launch_forms_against_the_oracle(dev, oracle, order):
+    """Quadrature order 32 is the largest rule of the ONE-launch form (the collision kernel evaluates the pointwise part, QuadSmall), order 40
+    runs the two launches (pointwise kernel, then read-modify-write): both against the oracle at the same order, Float64."""
+    import cmx
+    ft, n = "f64", 1500
+    s = _states(n, seed=29)
+    cols = {k: torch.from_numpy(v).to(DT[ft]) for k, v in s.items()}
+    d = {k: v.to(dev) for k, v in cols.items()}
+    mp = P.Microphysics2MParams(ft, with_ice=True, is_limited=True, quadrature_order=order)
+    assert mp.ice.c.quad.n == order
+    tps = P.ThermodynamicsParameters(ft)
+    ll = cmx.p3_shape(P.ParametersP3(ft), d["q_ice"] * d["rho"], d["n_ice"] * d["rho"], d["q_rim"] * d["rho"], d["b_rim"] * d["rho"],
+                      want=("log_lambda",), brent_iters=40).log_lambda
+    ll = torch.where(torch.isfinite(ll), ll, torch.zeros_like(ll))
+    got = cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), mp, tps, *[d[k] for k in s], ll)
+    torch.cuda.synchronize()
+    c64 = [cols[k].numpy().astype(np.float64) for k in s]
+    ref, scale = oracle.microphysics_2m_p3_tendencies(_abi.F64, mp.warm_rain.c, mp.ice.c, tps, mp.ice.flags, *c64, _np64(ll), np.zeros(n),
+                                                      float32_gates=False, nthreads=8)
+    for q, k in enumerate(NAMES):
+        x = _np64(getattr(got, k))
+        tol = parity.RTOL[ft] * np.abs(ref[q]) + parity.CTOL[ft] * scale[q]
+        err = np.abs(x - ref[q]) / np.maximum(tol, 1e-300)
+        err[(x == 0) & (ref[q] == 0)] = 0
+        assert err.max() <= 1.0, (order, k, int(np.argmax(err)), err.max())
+
+
 def test_reduces_to_warm_rain_without_ice_and_validates(dev):
     import cmx
     ft = "f64"
