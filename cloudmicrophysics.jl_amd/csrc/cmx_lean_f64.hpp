@@ -214,9 +214,21 @@ __device__ __forceinline__ double sc(double c) { asm volatile("" : "+s"(c)); ret
 #else
 CMX_LEAN_FN double sc(double c) { return c; }
 #endif
+// vc(c): the SECOND coefficient of a polynomial in a VGPR pair that the whole kernel shares.  A VOP3 instruction takes one scalar operand, so
+// the first Horner step c0·r + c1 with both coefficients on the scalar side costs a v_mov_b64 per evaluation (19 per SB2006 point); the
+// non-volatile asm is a pure function of its operand, so all uses of one constant fold into ONE move per kernel.  Two registers per
+// polynomial: translation units whose kernels are at their register limit leave it off (CMX_LEAN_VGPR_C1, per file in the Makefile).
+#ifndef CMX_LEAN_VGPR_C1
+#define CMX_LEAN_VGPR_C1 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !CMX_LEAN_COEFS_IN_LDS && CMX_LEAN_VGPR_C1
+__device__ __forceinline__ double vc(double c) { asm("" : "+v"(c)); return c; }
+#else
+CMX_LEAN_FN double vc(double c) { return sc(c); }
+#endif
 CMX_LEAN_FN double exp2m1_small(double r, const LeanCoefs &K) {
     double p = sc(K.e2[0]);
-    p = fma_(p, r, sc(K.e2[1]));
+    p = fma_(p, r, vc(K.e2[1]));
     p = fma_(p, r, sc(K.e2[2]));
     p = fma_(p, r, sc(K.e2[3]));
     p = fma_(p, r, sc(K.e2[4]));
@@ -225,7 +237,7 @@ CMX_LEAN_FN double exp2m1_small(double r, const LeanCoefs &K) {
 // eʳ − 1 for |r| ≤ ln2/256
 CMX_LEAN_FN double expm1_small(double r, const LeanCoefs &K) {
     double p = sc(K.ee[0]);
-    p = fma_(p, r, sc(K.ee[1]));
+    p = fma_(p, r, vc(K.ee[1]));
     p = fma_(p, r, sc(K.ee[2]));
     p = fma_(p, r, sc(K.ee[3]));
     p = fma_(p, r, sc(K.ee[4]));
@@ -374,7 +386,7 @@ CMX_LEAN_FN Log2Parts log2_reduce(double x, const LeanCoefs &K) {
 // log2(1 + r)/r = B1 + r·(B2 + … r·B7), B_k = (−1)^(k+1) log2e / k, |r| ≤ 2⁻⁸ (truncation r⁷/8 relative ≤ 2e-18); ln likewise
 CMX_LEAN_FN double poly7s(double r, const double (&b)[7]) {                   // coefficients on the scalar side (sc above)
     double p = sc(b[0]);
-    p = fma_(p, r, sc(b[1]));
+    p = fma_(p, r, vc(b[1]));
     p = fma_(p, r, sc(b[2]));
     p = fma_(p, r, sc(b[3]));
     p = fma_(p, r, sc(b[4]));
