@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <cstdint>
 #include <cstdlib>
 
@@ -93,5 +95,18 @@ __device__ __forceinline__ void store_col(FT *__restrict__ p, int64_t i, const F
     if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<V *>(p) + i);
     else reinterpret_cast<V *>(p)[i] = v;
 }
+
+// Launch of a kernel whose Float64 instantiation reads its constants through front_consts() (cmx_math.hpp), i.e. straight from the start of the
+// kernel-argument segment: the constants struct MUST be the first kernel parameter.  The macro checks that at compile time — the first
+// parameter type of the kernel is the type of the first argument passed — so reordering or prepending a parameter no longer compiles
+// (nothing enforced the assumption).  K is the parenthesised kernel name, as for hipLaunchKernelGGL.
+template <typename K> struct first_kernel_param;
+template <typename A0, typename... A> struct first_kernel_param<void (*)(A0, A...)> { using type = std::remove_cv_t<A0>; };
+#define CMX_LAUNCH_FRONT(K, grid, block, lds, stream, c, ...)                                                                                     \
+    do {                                                                                                                                         \
+        static_assert(std::is_same_v<typename ::cmx::first_kernel_param<decltype(&K)>::type, std::remove_cv_t<std::remove_reference_t<decltype(c)>>>, \
+                      "front_consts() reads the constants struct as the FIRST kernel argument");                                                 \
+        hipLaunchKernelGGL(K, grid, block, lds, stream, c, __VA_ARGS__);                                                                         \
+    } while (0)
 
 }  // namespace cmx

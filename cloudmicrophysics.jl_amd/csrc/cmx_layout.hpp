@@ -141,11 +141,11 @@ static int32_t launch_layout(const typename POLICY::Consts &c, int64_t n_seg, in
         const dim3 grid((unsigned)((nvec + kLayoutBS - 1) / kLayoutBS)), block(kLayoutBS);
         const size_t lds = aos ? sizeof(FT) * (size_t)kLayoutBS * (V * NAOS + 16 / sizeof(FT)) : 0;
         if (seg) {
-            if (aos) hipLaunchKernelGGL((tendencies_layout_kernel<FT, POLICY, V, true, true>), grid, block, lds, s, c, io, nvec);
-            else hipLaunchKernelGGL((tendencies_layout_kernel<FT, POLICY, V, true, false>), grid, block, lds, s, c, io, nvec);
+            if (aos) CMX_LAUNCH_FRONT((tendencies_layout_kernel<FT, POLICY, V, true, true>), grid, block, lds, s, c, io, nvec);
+            else CMX_LAUNCH_FRONT((tendencies_layout_kernel<FT, POLICY, V, true, false>), grid, block, lds, s, c, io, nvec);
         } else {
-            if (aos) hipLaunchKernelGGL((tendencies_layout_kernel<FT, POLICY, V, false, true>), grid, block, lds, s, c, io, nvec);
-            else hipLaunchKernelGGL((tendencies_layout_kernel<FT, POLICY, V, false, false>), grid, block, lds, s, c, io, nvec);
+            if (aos) CMX_LAUNCH_FRONT((tendencies_layout_kernel<FT, POLICY, V, false, true>), grid, block, lds, s, c, io, nvec);
+            else CMX_LAUNCH_FRONT((tendencies_layout_kernel<FT, POLICY, V, false, false>), grid, block, lds, s, c, io, nvec);
         }
     };
     if (vec_ok) launch(std::integral_constant<int, VEC>{});

@@ -274,18 +274,10 @@ template <typename T> struct is_kernarg<const __attribute__((address_space(4))) 
 // (ALSO: a Float32 kernel whose constants overflow the SGPR file too — the 1-moment kernels with run-time option flags)
 #if defined(CMX_HOST_BUILD)
 template <typename FT, bool ALSO = false, typename CT> inline const CT &front_consts(const CT &c) { return c; }
-template <typename FT, size_t OFFSET, typename CT> inline const CT &kernarg_at(const CT &c) { return c; }
 template <typename C, typename FT> inline const C &consts_after(const C &c, FT) { return c; }
 #else
 template <typename FT, bool ALSO = false, typename CT> __device__ __forceinline__ decltype(auto) front_consts(const CT &c) {
     if constexpr ((sizeof(FT) == 8 || ALSO) && CMX_PHASE_CONSTS) return (*(KernArg<CT> *)__builtin_amdgcn_kernarg_segment_ptr());
-    else return (c);
-}
-// the same for a LATER by-value kernel argument: OFFSET = its byte offset in the kernel-argument segment (arguments are laid out in
-// order, each at its own alignment)
-template <typename FT, size_t OFFSET, typename CT> __device__ __forceinline__ decltype(auto) kernarg_at(const CT &c) {
-    if constexpr (sizeof(FT) == 8 && CMX_PHASE_CONSTS)
-        return (*(KernArg<CT> *)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + OFFSET));
     else return (c);
 }
 // (a plain reference passes through: laundering the address of a by-value kernel argument would force a private copy of the struct)

@@ -132,7 +132,7 @@ static void launch_column_1m(bool def, bool lin, bool general, const Mp1mColKern
     if (nvec <= 0) return;
     const dim3 grid((unsigned)((nvec + kColBS1m - 1) / kColBS1m)), block(kColBS1m);
     constexpr uint32_t DEF = CMX_1M_DEFAULT_OPTIONS | kDefExpBit;
-#define CMX_L(FL, LN, GG) hipLaunchKernelGGL((mp1m_column_kernel<FT, FL, LN, GG, VEC, kColBS1m>), grid, block, 0, s, a, io, first, nvec)
+#define CMX_L(FL, LN, GG) CMX_LAUNCH_FRONT((mp1m_column_kernel<FT, FL, LN, GG, VEC, kColBS1m>), grid, block, 0, s, a, io, first, nvec)
 #define CMX_G(FL, LN) do { if (general) CMX_L(FL, LN, true); else CMX_L(FL, LN, false); } while (0)
     if (def) { if (lin) CMX_G(DEF, true); else CMX_G(DEF, false); }
     else { if (lin) CMX_G(kRuntimeFlags, true); else CMX_G(kRuntimeFlags, false); }

@@ -159,9 +159,9 @@ static int32_t tendencies_1m_entry(const MP *mp, const TH *tps, uint32_t flags, 
         const int64_t nv = count / V;
         const dim3 grid((unsigned)((nv + kBlock1m - 1) / kBlock1m));
         if (flags == CMX_1M_DEFAULT_OPTIONS && mp1m_default_exponents(c))
-            hipLaunchKernelGGL((mp1m_tendencies_kernel<FT, V, CMX_1M_DEFAULT_OPTIONS | kDefExpBit>), grid, dim3(kBlock1m), 0, s, c, in, out, nv);
+            CMX_LAUNCH_FRONT((mp1m_tendencies_kernel<FT, V, CMX_1M_DEFAULT_OPTIONS | kDefExpBit>), grid, dim3(kBlock1m), 0, s, c, in, out, nv);
         else
-            hipLaunchKernelGGL((mp1m_tendencies_kernel<FT, V>), grid, dim3(kBlock1m), 0, s, c, in, out, nv);
+            CMX_LAUNCH_FRONT((mp1m_tendencies_kernel<FT, V>), grid, dim3(kBlock1m), 0, s, c, in, out, nv);
     };
     if (same_mis) {
         const int64_t head = std::min<int64_t>(n, mis0 ? (int64_t)((16 - mis0) / sizeof(FT)) : 0);
@@ -227,9 +227,9 @@ static int32_t linearized_1m_entry(const MP *mp, const TH *tps, uint32_t flags, 
     Mp1mLinIO<FT> io{{rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno}, {dq_lcl, dq_icl, dq_rai, dq_sno}};
     const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
     if (flags == CMX_1M_DEFAULT_OPTIONS && mp1m_default_exponents(k.c))
-        hipLaunchKernelGGL((mp1m_linearized_kernel<FT, CMX_1M_DEFAULT_OPTIONS | kDefExpBit>), grid, dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), k, io, n);
+        CMX_LAUNCH_FRONT((mp1m_linearized_kernel<FT, CMX_1M_DEFAULT_OPTIONS | kDefExpBit>), grid, dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), k, io, n);
     else
-        hipLaunchKernelGGL((mp1m_linearized_kernel<FT>), grid, dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), k, io, n);
+        CMX_LAUNCH_FRONT((mp1m_linearized_kernel<FT>), grid, dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), k, io, n);
     CMX_HIP_TRY(hipGetLastError());
     return CMX_OK;
 }
@@ -258,7 +258,7 @@ static int32_t sources_1m_entry(const MP *mp, const TH *tps, uint32_t flags, int
     Mp1mIn<FT> in{rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno};
     Mp1mSrcOut<FT> o;
     for (int k = 0; k < CMX_MP1M_NSRC; ++k) o.col[k] = out[k];
-    hipLaunchKernelGGL((mp1m_sources_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+    CMX_LAUNCH_FRONT((mp1m_sources_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                        reinterpret_cast<hipStream_t>(stream), c, in, o, n);
     CMX_HIP_TRY(hipGetLastError());
     return CMX_OK;

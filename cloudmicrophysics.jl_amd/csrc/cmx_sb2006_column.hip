@@ -199,8 +199,8 @@ static void launch_column(bool limited, int vel, bool cloud, bool intpow, const 
     // intpow: the integer-exponent instantiation of the point function (cmx_sb2006.hpp INTPOW)
 #define CMX_LAUNCH(L, V, C)                                                                                                                          \
     do {                                                                                                                                             \
-        if (intpow) hipLaunchKernelGGL((sb2006_column_kernel<FT, L, V, C, VEC, kColBS, true>), dim3((unsigned)grid), dim3(kColBS), 0, s, c, cv, io, first, nvec); \
-        else hipLaunchKernelGGL((sb2006_column_kernel<FT, L, V, C, VEC, kColBS>), dim3((unsigned)grid), dim3(kColBS), 0, s, c, cv, io, first, nvec);   \
+        if (intpow) CMX_LAUNCH_FRONT((sb2006_column_kernel<FT, L, V, C, VEC, kColBS, true>), dim3((unsigned)grid), dim3(kColBS), 0, s, c, cv, io, first, nvec); \
+        else CMX_LAUNCH_FRONT((sb2006_column_kernel<FT, L, V, C, VEC, kColBS>), dim3((unsigned)grid), dim3(kColBS), 0, s, c, cv, io, first, nvec);   \
     } while (0)
 #define CMX_PICK(L, V) do { if (cloud) CMX_LAUNCH(L, V, true); else CMX_LAUNCH(L, V, false); } while (0)
     if (limited) {

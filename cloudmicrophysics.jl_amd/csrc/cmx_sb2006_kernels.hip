@@ -35,10 +35,10 @@ static void launch_tendencies(bool limited, int vel, bool intpow, const SbConsts
 #define CMX_LAUNCH(L, V)                                                                                                                   \
     do {                                                                                                                                   \
         if (intpow && CMX_SB_INTPOW)                                                                                                       \
-            hipLaunchKernelGGL((sb2006_tendencies_kernel<FT, L, V, VEC, kTendBS, 1, true, true>), dim3((unsigned)grid), dim3(kTendBS), 0, s, c, in, \
+            CMX_LAUNCH_FRONT((sb2006_tendencies_kernel<FT, L, V, VEC, kTendBS, 1, true, true>), dim3((unsigned)grid), dim3(kTendBS), 0, s, c, in, \
                                out, nvec);                                                                                                 \
         else                                                                                                                               \
-            hipLaunchKernelGGL((sb2006_tendencies_kernel<FT, L, V, VEC, kTendBS>), dim3((unsigned)grid), dim3(kTendBS), 0, s, c, in, out,  \
+            CMX_LAUNCH_FRONT((sb2006_tendencies_kernel<FT, L, V, VEC, kTendBS>), dim3((unsigned)grid), dim3(kTendBS), 0, s, c, in, out,  \
                                nvec);                                                                                                      \
     } while (0)
     if (limited) {
@@ -146,7 +146,7 @@ static int32_t process_entry(const WR *wr, const TH *tps, const VL *vel, uint32_
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int grid = grid_for(n);
 #define CMX_LAUNCH(L, V)                                                                                        \
-    hipLaunchKernelGGL((sb2006_process_kernel<FT, L, V>), dim3(grid), dim3(kBlock), 0, s, c, q_tot, q_lcl, q_rai, \
+    CMX_LAUNCH_FRONT((sb2006_process_kernel<FT, L, V>), dim3(grid), dim3(kBlock), 0, s, c, q_tot, q_lcl, q_rai, \
                        N_lcl, N_rai, rho, T, o, n)
     if (limited) {
         if (velk == VEL_NONE) CMX_LAUNCH(true, VEL_NONE);

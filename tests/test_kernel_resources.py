@@ -42,3 +42,12 @@ def test_streaming_kernels_do_not_spill(kernels):
         assert ks, frag
         bad = [k for k in ks if k["vgpr_spill"]]
         assert not bad, bad[:3]
+
+
+def test_kernel_argument_segments_fit(kernels):
+    """The parameter structs travel by value in the kernel-argument segment (4 KiB): the one-launch 2M + P3 form exists because the rule of order
+    <= 32 leaves room for the pointwise constants (QuadSmall), and no instantiation may silently outgrow the segment."""
+    big = max(kernels, key=lambda k: k["kernarg"])
+    assert 0 < big["kernarg"] <= 4096, big
+    one_launch = [k for k in kernels if "p3_collision_kernel" in k["name"] and "PointwiseExtra" in k["name"]]
+    assert len(one_launch) == 32 and all(k["kernarg"] <= 4096 for k in one_launch)

@@ -47,7 +47,8 @@ def kernels(path):
             if "name" in d:
                 out.append({"name": d["name"], "vgpr": int(d.get("vgpr_count", 0)), "sgpr": int(d.get("sgpr_count", 0)),
                             "vgpr_spill": int(d.get("vgpr_spill_count", 0)), "sgpr_spill": int(d.get("sgpr_spill_count", 0)),
-                            "private": int(d.get("private_segment_fixed_size", 0)), "lds": int(d.get("group_segment_fixed_size", 0))})
+                            "private": int(d.get("private_segment_fixed_size", 0)), "lds": int(d.get("group_segment_fixed_size", 0)),
+                            "kernarg": int(d.get("kernarg_segment_size", 0))})
     return out
 
 
@@ -66,7 +67,7 @@ def main():
     if "--scratch" in sys.argv:
         ks = [k for k in ks if k["private"] or k["vgpr_spill"]]
     for k, name in zip(ks, demangle([k["name"] for k in ks])):
-        print(f"vgpr {k['vgpr']:3d} spill {k['vgpr_spill']:3d} | sgpr {k['sgpr']:3d} spill {k['sgpr_spill']:3d} | private {k['private']:4d} B | lds {k['lds']:6d} B | {name[:150]}")
+        print(f"vgpr {k['vgpr']:3d} spill {k['vgpr_spill']:3d} | sgpr {k['sgpr']:3d} spill {k['sgpr_spill']:3d} | private {k['private']:4d} B | lds {k['lds']:6d} B | kernarg {k['kernarg']:4d} B | {name[:150]}")
     print(f"{len(ks)} kernels")
 
 
