@@ -12,7 +12,7 @@ from . import _abi, parameters, sharding, synthetic  # noqa: F401
 from ._lib import CmxLibraryError, CmxStatusError  # noqa: F401
 from .bulk_tendencies import (Chen2022VelTypeRain, Microphysics2Moment, SB2006ProcessRates,  # noqa: F401
                               SB2006VelType, Tendencies2MP3, WarmRainTendencies2M, bulk_microphysics_tendencies,
-                              bulk_microphysics_tendencies_fields,
+                              bulk_microphysics_tendencies_fields, bulk_microphysics_tendencies_2m_p3_fields,
                               bulk_2m_cloud_to_rain, cloud_terminal_velocity, column_sums, sb2006_process_rates,
                               ColumnTendencies2M, column_tendencies_sedimentation)
 

@@ -163,6 +163,10 @@ def _declare(lib):
         f.restype = i32
         f.argtypes = [C.POINTER(fam.warm_rain_2m), C.POINTER(fam.p3_ice_params), C.POINTER(fam.thermo), u32, i64] + [vp] * 13 + \
                      [C.POINTER(vp), vp]
+        f = getattr(lib, f"cmx_microphysics_2m_p3_tendencies_fields_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.warm_rain_2m), C.POINTER(fam.p3_ice_params), C.POINTER(fam.thermo), u32, i64, i64, C.POINTER(vp), C.POINTER(i64),
+                      C.POINTER(vp), C.POINTER(i64), vp]
         f = getattr(lib, f"cmx_column_sums_{s}")
         f.restype = i32
         f.argtypes = [i32, C.POINTER(vp), i64, vp, vp]

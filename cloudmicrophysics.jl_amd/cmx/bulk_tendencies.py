@@ -223,6 +223,60 @@ def _fields_call(fn_name, params_c, tps, flags, cols, names, n_out, n_aos, out, 
     return aos_t if aos else out
 
 
+def bulk_microphysics_tendencies_2m_p3_fields(scheme, mp, tps, rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice, n_ice, q_rim, b_rim, log_lambda,
+                                              inpc_log_shift=None, *, aspect_ratio=True, out=None, stream=None):
+    """The 2M + P3 method of `bulk_microphysics_tendencies` (BMT:898-1083) on the host model's own storage — the layout adapter of
+    `cmx_microphysics_2m_p3_tendencies_fields_*`: every column is a contiguous 1-D tensor or a 2-D strided view (n_seg, seg_len) with
+    contiguous rows (a component of a ClimaCore `VIJFH` field in place; each column may have its own row stride, all share the shape); the
+    eight tendencies go into `out` (8 tensors of that shape, e.g. components of the tendency field; allocated contiguous if None).
+    Bit-identical to the SoA call on the same states.  Returns `Tendencies2MP3`."""
+    if not isinstance(scheme, Microphysics2Moment):
+        raise TypeError("only Microphysics2Moment() is on this path")
+    if not (isinstance(mp, Microphysics2MParams) and mp.ice is not None):
+        raise TypeError("mp must be Microphysics2MParams(FT, with_ice=True)")
+    names = ["rho", "T", "q_tot", "q_lcl", "n_lcl", "q_rai", "n_rai", "q_ice", "n_ice", "q_rim", "b_rim", "log_lambda"]
+    cols = [rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice, n_ice, q_rim, b_rim, log_lambda]
+    if inpc_log_shift is not None:
+        names.append("inpc_log_shift"); cols.append(inpc_log_shift)
+    ref = cols[0]
+    fam = _fam_of(ref)
+    if fam is not mp.fam or fam is not mp.ice.fam or not isinstance(tps, fam.thermo):
+        raise TypeError("parameter float type does not match the state columns")
+    if mp.ice.is_limited != mp.warm_rain.is_limited:
+        raise ValueError("warm_rain and ice must use the same rain PSD variant (is_limited)")
+    n_seg, seg_len, _ = _segments(ref, names[0])
+    strides = []
+    for c, nm in zip(cols, names):
+        if not c.is_cuda or c.device != ref.device or c.dtype != ref.dtype:
+            raise TypeError(f"{nm}: all columns must live on the same GPU with the same dtype")
+        ns, sl, st = _segments(c, nm)
+        if (ns, sl) != (n_seg, seg_len):
+            raise ValueError(f"{nm}: shape differs from rho")
+        strides.append(st)
+    ptrs = [c.data_ptr() for c in cols]
+    if inpc_log_shift is None:
+        ptrs.append(None); strides.append(seg_len)
+    if out is None:
+        out = [torch.empty(ref.shape, dtype=ref.dtype, device=ref.device) for _ in range(8)]
+    if len(out) != 8:
+        raise ValueError("out: eight tendency columns")
+    ostr = []
+    for o in out:
+        ns, sl, st = _segments(o, "out")
+        if (ns, sl) != (n_seg, seg_len) or o.dtype != ref.dtype or o.device != ref.device:
+            raise ValueError("out: shape / dtype / device differs from the inputs")
+        ostr.append(st)
+    in_p, in_s = (C.c_void_p * 13)(*ptrs), (C.c_int64 * 13)(*strides)
+    out_p, out_s = (C.c_void_p * 8)(*[o.data_ptr() for o in out]), (C.c_int64 * 8)(*ostr)
+    flags = mp.ice.flags | (0 if aspect_ratio else _abi.CMX_P3_NO_ASPECT_RATIO)
+    s = stream if stream is not None else torch.cuda.current_stream(ref.device)
+    fn = getattr(_lib.lib(), f"cmx_microphysics_2m_p3_tendencies_fields_{fam.sfx}")
+    with torch.cuda.device(ref.device):
+        st = fn(C.byref(mp.warm_rain.c), C.byref(mp.ice.c), C.byref(tps), flags, n_seg, seg_len, in_p, in_s, out_p, out_s, C.c_void_p(s.cuda_stream))
+    _lib.check(fn.__name__, st)
+    return Tendencies2MP3(*out, torch.zeros((), dtype=ref.dtype, device=ref.device).expand(ref.shape))
+
+
 def bulk_microphysics_tendencies_fields(scheme, mp, tps, rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, *, out=None, aos=False, stream=None):
     """The 2-moment warm-rain tendencies (BMT:820-854) on the host model's own storage — zero-copy layout adapters of
     `cmx_sb2006_warm_rain_tendencies_fields_*`:

@@ -153,6 +153,23 @@ template <typename FT> __device__ __forceinline__ void lower_gamma6(FT z0, FT x,
     }
 }
 
+// Segmented columns of the 2M + P3 `_fields_` entry (cmx_layout.hpp for the streaming kernels): the flat state index i = seg·seg_len
+// + off addresses column k at p[seg·stride_k + off].  seg_len = 0: plain contiguous columns (seg = 0, off = i — every stride is ignored).
+// Order of s_in: ρ, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice, n_ice, q_rim, b_rim, log λ, INPC shift.
+struct SegLayout {
+    int64_t seg_len;
+    int64_t s_in[13], s_out[8];
+};
+struct SegPos {
+    int64_t seg, off;
+    __device__ __forceinline__ SegPos(const SegLayout &l, int64_t i) {
+        seg = l.seg_len ? i / l.seg_len : 0;
+        off = i - seg * l.seg_len;
+    }
+    template <typename T> __device__ __forceinline__ T &at(T *p, int64_t stride) const { return p[seg * stride + off]; }
+};
+enum { SEG_RHO = 0, SEG_T, SEG_QTOT, SEG_QLCL, SEG_NLCL, SEG_QRAI, SEG_NRAI, SEG_QICE, SEG_NICE, SEG_QRIM, SEG_BRIM, SEG_LOGLAM, SEG_SHIFT };
+
 template <typename FT> struct P3ColIO {
     const FT *rho_q, *rho_n, *x3, *x4, *L_c, *N_c, *L_r, *N_r, *rho_a, *T, *loglam;
     FT *src[7];      // ∂ₜq_c, ∂ₜq_r, ∂ₜN_c, ∂ₜN_r, ∂ₜL_rim, ∂ₜL_ice, ∂ₜB_rim   (nullable)
@@ -161,6 +178,7 @@ template <typename FT> struct P3ColIO {
     // (dq_lcl, dn_lcl, dq_rai, dn_rai, dq_ice, dn_ice, dq_rim, db_rim) are read-modify-written
     const FT *q_lcl, *n_lcl, *q_rai, *n_rai, *q_ice, *n_ice, *q_rim, *b_rim;
     FT *out[8];
+    SegLayout lay;     // FUSED only (zero-initialised = contiguous)
 };
 
 // =====================================================================================================================
@@ -252,6 +270,7 @@ __device__ __forceinline__ void bigg_rain(const PointwiseConsts<FT> &k, FT J_big
 template <typename FT> struct FusedIO {
     const FT *rho, *T, *q_tot, *q_lcl, *n_lcl, *q_rai, *n_rai, *q_ice, *n_ice, *q_rim, *b_rim, *shift;
     FT *out[8];
+    SegLayout lay;
 };
 
 // The pointwise part of the 2M + P3 entry for ONE state: in[11] = (ρ, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice, n_ice, q_rim, b_rim) as stored
@@ -337,9 +356,11 @@ __device__ __forceinline__ void mp2m_p3_point(const SbConsts<FT> &sc, const P3Co
     d[4] = dq_ice + poison; d[5] = dn_ice + poison; d[6] = dq_rim + poison; d[7] = db_rim + poison;
 }
 template <typename FT> __device__ __forceinline__ void mp2m_p3_load(const FusedIO<FT> &io, int64_t i, FT (&in)[11], FT &shift) {
-    in[0] = io.rho[i]; in[1] = io.T[i]; in[2] = io.q_tot[i]; in[3] = io.q_lcl[i]; in[4] = io.n_lcl[i]; in[5] = io.q_rai[i]; in[6] = io.n_rai[i];
-    in[7] = io.q_ice[i]; in[8] = io.n_ice[i]; in[9] = io.q_rim[i]; in[10] = io.b_rim[i];
-    shift = io.shift ? io.shift[i] : FT(0);
+    const SegPos ps(io.lay, i);
+    const FT *const col[11] = {io.rho, io.T, io.q_tot, io.q_lcl, io.n_lcl, io.q_rai, io.n_rai, io.q_ice, io.n_ice, io.q_rim, io.b_rim};
+#pragma unroll
+    for (int k = 0; k < 11; ++k) in[k] = ps.at(col[k], io.lay.s_in[k]);
+    shift = io.shift ? ps.at(io.shift, io.lay.s_in[SEG_SHIFT]) : FT(0);
 }
 
 template <typename FT, bool LIMITED, bool INTPOW = false>
@@ -351,8 +372,9 @@ __global__ __launch_bounds__(kBlock) void mp2m_p3_pointwise_kernel(const SbConst
     FT in[11], shift, d[8];
     mp2m_p3_load<FT>(io, i, in, shift);
     mp2m_p3_point<FT, LIMITED, INTPOW>(sc, c, k, in, shift, d);
+    const SegPos ps(io.lay, i);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) io.out[q][i] = d[q];
+    for (int q = 0; q < 8; ++q) ps.at(io.out[q], io.lay.s_out[q]) = d[q];
 }
 
 #ifndef CMX_COL_WAVES
@@ -410,19 +432,20 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
     // ---- per-point set-up (uniform over the group) ---------------------------------------------------------------
     // Order: the quantile solve first — it needs only ρq, ρn and log λ, and it is the register-hungriest piece of the set-up, so nothing else
     // is alive across it — then the state (p3_make_point) and the liquid-side loads.
-    const FT rho_a = M::max(io.rho_a[i], FT(0));
+    const SegPos ps(io.lay, i);       // (the other entries leave io.lay zero: contiguous columns)
+    const FT rho_a = M::max(ps.at(io.rho_a, io.lay.s_in[SEG_RHO]), FT(0));
     FT rho_q_in, rho_n_in;
     bool present;
     if constexpr (FUSED) {
         // clamp_to_nonneg and the volumetric quantities of BMT:912-932; ice processes only where q_ice > ϵₘ && n_ice > ϵₙ (:959)
-        const FT q_ice = M::max(io.q_ice[i], FT(0)), n_ice = M::max(io.n_ice[i], FT(0));
+        const FT q_ice = M::max(ps.at(io.q_ice, io.lay.s_in[SEG_QICE]), FT(0)), n_ice = M::max(ps.at(io.n_ice, io.lay.s_in[SEG_NICE]), FT(0));
         rho_q_in = q_ice * rho_a; rho_n_in = n_ice * rho_a;
         present = q_ice > P::eps() && n_ice > P::eps() && !(rho_n_in < P::eps() || rho_q_in < P::eps());
     } else {
         rho_q_in = io.rho_q[i]; rho_n_in = io.rho_n[i];
         present = !(rho_n_in < P::eps() || rho_q_in < P::eps());
     }
-    const FT loglam = present ? io.loglam[i] : FT(10), lam = P::exp(loglam), mu = p3_mu<FT>(c, loglam);
+    const FT loglam = present ? ps.at(io.loglam, io.lay.s_in[SEG_LOGLAM]) : FT(10), lam = P::exp(loglam), mu = p3_mu<FT>(c, loglam);
     // quantiles of the ice PSD (integral_bounds, P3_integral_properties.jl:34-46): one Halley solve per LANE — lanes 0/1 the
     // collision bounds (p = 1e-5), 2/3 the self-collection bounds (p = eps), 4/5 the melting bounds (p = 1e-6) — shared by shuffles
     // (the 2M+P3 entry parks the self-collection / melting bounds in S[20…23] until their sweeps)
@@ -443,11 +466,12 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
     }
     P3Point<FT> s;
     FT L_c, N_c, L_r, N_r;
-    const FT T = io.T[i];
+    const FT T = ps.at(io.T, io.lay.s_in[SEG_T]);
     if constexpr (FUSED) {
-        L_c = M::max(io.q_lcl[i], FT(0)) * rho_a; N_c = M::max(io.n_lcl[i], FT(0)) * rho_a;
-        L_r = M::max(io.q_rai[i], FT(0)) * rho_a; N_r = M::max(io.n_rai[i], FT(0)) * rho_a;
-        p3_make_point<FT>(c, rho_q_in, rho_n_in, M::max(io.q_rim[i], FT(0)) * rho_a, M::max(io.b_rim[i], FT(0)) * rho_a, s);
+        L_c = M::max(ps.at(io.q_lcl, io.lay.s_in[SEG_QLCL]), FT(0)) * rho_a; N_c = M::max(ps.at(io.n_lcl, io.lay.s_in[SEG_NLCL]), FT(0)) * rho_a;
+        L_r = M::max(ps.at(io.q_rai, io.lay.s_in[SEG_QRAI]), FT(0)) * rho_a; N_r = M::max(ps.at(io.n_rai, io.lay.s_in[SEG_NRAI]), FT(0)) * rho_a;
+        p3_make_point<FT>(c, rho_q_in, rho_n_in, M::max(ps.at(io.q_rim, io.lay.s_in[SEG_QRIM]), FT(0)) * rho_a,
+                          M::max(ps.at(io.b_rim, io.lay.s_in[SEG_BRIM]), FT(0)) * rho_a, s);
         if (g == 0) { S[24] = s.rho_g; S[25] = s.bnd[1]; S[26] = s.bnd[2]; S[27] = s.bnd[3]; }   // for the two later sweeps' segment bounds
     } else {
         L_c = io.L_c[i]; N_c = io.N_c[i]; L_r = io.L_r[i]; N_r = io.N_r[i];
@@ -829,7 +853,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
                        o[4] * e_inv_rho - mq * s.F_rim, o[6] * e_inv_rho - (e_rho_rim > FT(0) ? mq * s.F_rim / e_rho_rim : FT(0))};
             if constexpr (!ONE_LAUNCH) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) io.out[q][i] += d[q];
+                for (int q = 0; q < 8; ++q) SegPos(io.lay, i).at(io.out[q], io.lay.s_out[q]) += d[q];
             } else {
                 // park the ice-process sums in the state's LDS block (the rain constants there are dead now) for the pointwise pass below
 #pragma unroll
@@ -847,12 +871,14 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
         if ((int)threadIdx.x < nst && i2 < n) {
             const volatile FT *S2 = lds + 2 * nq + threadIdx.x * ColLds<FT>::per_group(nq) + 72;
             FT in[11], pw[8];
-            in[0] = io.rho_a[i2]; in[1] = io.T[i2]; in[2] = ex.q_tot[i2]; in[3] = io.q_lcl[i2]; in[4] = io.n_lcl[i2]; in[5] = io.q_rai[i2];
-            in[6] = io.n_rai[i2]; in[7] = io.q_ice[i2]; in[8] = io.n_ice[i2]; in[9] = io.q_rim[i2]; in[10] = io.b_rim[i2];
-            const FT shift = ex.shift ? ex.shift[i2] : FT(0);
+            const SegPos p2(io.lay, i2);
+            const FT *const col[11] = {io.rho_a, io.T, ex.q_tot, io.q_lcl, io.n_lcl, io.q_rai, io.n_rai, io.q_ice, io.n_ice, io.q_rim, io.b_rim};
+#pragma unroll
+            for (int kk = 0; kk < 11; ++kk) in[kk] = p2.at(col[kk], io.lay.s_in[kk]);
+            const FT shift = ex.shift ? p2.at(ex.shift, io.lay.s_in[SEG_SHIFT]) : FT(0);
             mp2m_p3_point<FT, EXTRA::LIMITED, EXTRA::INTPOW, true>(ex.sc, c, ex.pk, in, shift, pw);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) io.out[q][i2] = pw[q] + S2[q];
+            for (int q = 0; q < 8; ++q) p2.at(io.out[q], io.lay.s_out[q]) = pw[q] + S2[q];
         }
     }
 }
@@ -949,7 +975,7 @@ static int32_t liquid_freezing_entry(const IP *ip, const TH *tps, uint32_t flags
 template <typename FT, typename WR, typename IP, typename TH>
 static int32_t mp2m_p3_entry(const WR *wr, const IP *ip, const TH *tps, uint32_t flags, int64_t n, const FT *rho, const FT *T, const FT *q_tot,
                              const FT *q_lcl, const FT *n_lcl, const FT *q_rai, const FT *n_rai, const FT *q_ice, const FT *n_ice, const FT *q_rim,
-                             const FT *b_rim, const FT *loglam, const FT *shift, FT *const *out, void *stream) {
+                             const FT *b_rim, const FT *loglam, const FT *shift, FT *const *out, void *stream, const SegLayout *lay = nullptr) {
     if (!wr || !ip || !tps || n < 0 || (flags & ~(CMX_P3_SLOPE_CONSTANT | CMX_P3_NO_ASPECT_RATIO | CMX_P3_RAIN_PDF_LIMITED))) return CMX_ERR_BAD_ARG;
     if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;      // one launch cannot express the grid (cmx_launch.hpp)
     if (ip->quad.n < 1 || ip->quad.n > CMX_QUAD_MAX) return CMX_ERR_BAD_ARG;
@@ -973,6 +999,7 @@ static int32_t mp2m_p3_entry(const WR *wr, const IP *ip, const TH *tps, uint32_t
     io.rho_a = rho; io.T = T; io.loglam = loglam;
     io.q_lcl = q_lcl; io.n_lcl = n_lcl; io.q_rai = q_rai; io.n_rai = n_rai; io.q_ice = q_ice; io.n_ice = n_ice; io.q_rim = q_rim; io.b_rim = b_rim;
     for (int q = 0; q < 8; ++q) io.out[q] = out[q];
+    if (lay) io.lay = *lay;
     using QUAD = std::remove_cv_t<std::remove_reference_t<decltype(ip->quad)>>;
 #ifndef CMX_MP2M_P3_ONE_LAUNCH
 #define CMX_MP2M_P3_ONE_LAUNCH 1      // 0: always the two launches (A/B switch)
@@ -994,6 +1021,7 @@ static int32_t mp2m_p3_entry(const WR *wr, const IP *ip, const TH *tps, uint32_t
     // read-modify-writes the eight columns
     FusedIO<FT> fio{rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice, n_ice, q_rim, b_rim, shift, {}};
     for (int q = 0; q < 8; ++q) fio.out[q] = out[q];
+    if (lay) fio.lay = *lay;
     const dim3 block(kBlock), grid1((unsigned)((n + kBlock - 1) / kBlock));
     if (intpow) {
         if (limited) hipLaunchKernelGGL((mp2m_p3_pointwise_kernel<FT, true, true>), grid1, block, 0, st, sc, c, pk, fio, n);
@@ -1006,9 +1034,42 @@ static int32_t mp2m_p3_entry(const WR *wr, const IP *ip, const TH *tps, uint32_t
     return launch_collision_kernel<FT, QUAD, true>(c, v, k, ip->quad, io, n, !(flags & CMX_P3_NO_ASPECT_RATIO), st);
 }
 
+// the same entry on segmented columns (the host model's fields in place): in[13] / in_seg_stride[13] in the order of SegLayout::s_in
+template <typename FT, typename WR, typename IP, typename TH>
+static int32_t mp2m_p3_fields_entry(const WR *wr, const IP *ip, const TH *tps, uint32_t flags, int64_t n_seg, int64_t seg_len, const FT *const *in,
+                                    const int64_t *in_seg_stride, FT *const *out, const int64_t *out_seg_stride, void *stream) {
+    if (!in || !in_seg_stride || !out || !out_seg_stride || n_seg < 0 || seg_len < 0) return CMX_ERR_BAD_ARG;
+    if (n_seg == 0 || seg_len == 0) return (wr && ip && tps) ? CMX_OK : CMX_ERR_BAD_ARG;
+    if (n_seg > kMaxPoints / seg_len) return CMX_ERR_UNSUPPORTED;
+    SegLayout lay{};
+    lay.seg_len = seg_len;
+    for (int k = 0; k < 13; ++k) {
+        if (k < 12 && !in[k]) return CMX_ERR_BAD_ARG;                      // the INPC shift (k = 12) is optional
+        if (in[k] && n_seg > 1 && in_seg_stride[k] < seg_len) return CMX_ERR_BAD_ARG;   // runs must not overlap
+        lay.s_in[k] = in_seg_stride[k];
+    }
+    for (int q = 0; q < 8; ++q) {
+        if (!out[q] || (n_seg > 1 && out_seg_stride[q] < seg_len)) return CMX_ERR_BAD_ARG;
+        lay.s_out[q] = out_seg_stride[q];
+    }
+    return mp2m_p3_entry<FT>(wr, ip, tps, flags, n_seg * seg_len, in[0], in[1], in[2], in[3], in[4], in[5], in[6], in[7], in[8], in[9], in[10], in[11],
+                             in[12], out, stream, &lay);
+}
+
 }  // namespace cmx
 
 extern "C" {
+
+int32_t cmx_microphysics_2m_p3_tendencies_fields_f32(const cmx_warm_rain_2m_f32 *warm_rain, const cmx_p3_ice_params_f32 *ice, const cmx_thermo_f32 *tps,
+                                                     uint32_t flags, int64_t n_seg, int64_t seg_len, const float *const *in,
+                                                     const int64_t *in_seg_stride, float *const *out, const int64_t *out_seg_stride, void *stream) {
+    return cmx::mp2m_p3_fields_entry<float>(warm_rain, ice, tps, flags, n_seg, seg_len, in, in_seg_stride, out, out_seg_stride, stream);
+}
+int32_t cmx_microphysics_2m_p3_tendencies_fields_f64(const cmx_warm_rain_2m_f64 *warm_rain, const cmx_p3_ice_params_f64 *ice, const cmx_thermo_f64 *tps,
+                                                     uint32_t flags, int64_t n_seg, int64_t seg_len, const double *const *in,
+                                                     const int64_t *in_seg_stride, double *const *out, const int64_t *out_seg_stride, void *stream) {
+    return cmx::mp2m_p3_fields_entry<double>(warm_rain, ice, tps, flags, n_seg, seg_len, in, in_seg_stride, out, out_seg_stride, stream);
+}
 
 int32_t cmx_p3_liquid_ice_collisions_f32(const cmx_p3_ice_params_f32 *ice, const cmx_air_properties_f32 *aps, const cmx_thermo_f32 *tps,
                                          const cmx_quadrature_f32 *quad, uint32_t flags, int64_t n, const float *rho_q_ice,

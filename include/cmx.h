@@ -1014,6 +1014,18 @@ int32_t cmx_microphysics_2m_p3_tendencies_f64(const cmx_warm_rain_2m_f64 *warm_r
                                               const double *q_rim, const double *b_rim, const double *log_lambda, const double *inpc_log_shift,
                                               double *const *tendencies, void *stream);
 
+/* … and on the host model's own storage, like cmx_sb2006_warm_rain_tendencies_fields_* and cmx_mp1m_*_fields_*: every column is n_seg
+ * runs of seg_len contiguous elements with its own run stride (a component of a ClimaCore VIJFH field in place: seg_len = Nv·Ni·Nj, stride =
+ * Nv·Ni·Nj·Nf).  in[13] = (rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, q_ice, n_ice, q_rim, b_rim, log_lambda, inpc_log_shift — the last may be
+ * NULL), in_seg_stride[13]; out[8] = the eight tendency columns in the order of cmx_microphysics_2m_p3_tendencies_*, out_seg_stride[8].  Strides
+ * are in elements and >= seg_len.  Bit-identical to the SoA entry on the same states.  (No array-of-rows output form.) */
+int32_t cmx_microphysics_2m_p3_tendencies_fields_f32(const cmx_warm_rain_2m_f32 *warm_rain, const cmx_p3_ice_params_f32 *ice, const cmx_thermo_f32 *tps,
+                                                     uint32_t flags, int64_t n_seg, int64_t seg_len, const float *const *in,
+                                                     const int64_t *in_seg_stride, float *const *out, const int64_t *out_seg_stride, void *stream);
+int32_t cmx_microphysics_2m_p3_tendencies_fields_f64(const cmx_warm_rain_2m_f64 *warm_rain, const cmx_p3_ice_params_f64 *ice, const cmx_thermo_f64 *tps,
+                                                     uint32_t flags, int64_t n_seg, int64_t seg_len, const double *const *in,
+                                                     const int64_t *in_seg_stride, double *const *out, const int64_t *out_seg_stride, void *stream);
+
 /* ---------------------------------------------------------------------------
  * (0) 0-moment entry of bulk_microphysics_tendencies (src/BulkMicrophysicsTendencies.jl:658-680; KA kernels
  * test_bulk_tendencies_0m_kernel!, test_bulk_tendencies_0m_S0_kernel!, test/gpu_tests.jl:364-383, and

@@ -108,7 +108,7 @@ def test_ragged_shapes_and_tile_invariance(dev, oracle, ft, shape):
     torch.cuda.synchronize()
     ref = _oracle(oracle, ft, True, "sb", True, inv_dz, cols)
     g = {k: getattr(got, k).reshape(-1).cpu().numpy() for k in NAMES}
-    parity.assert_parity(g, ref, parity.RTOL[ft], names=NAMES, what=f"column {ft} {shape}", min_frac=0.0)
+    parity.assert_parity(g, ref, parity.RTOL[ft], names=NAMES, what=f"column {ft} {shape}")
     # misaligned twins: (a) every column shifted by one element (scalar head + vector body + scalar tail),
     # (b) columns at different offsets modulo 16 B (one point per lane throughout)
     n = n_col * n_lev

@@ -132,6 +132,43 @@ def test_both_launch_forms_against_the_oracle(dev, oracle, order):
         assert err.max() <= 1.0, (order, k, int(np.argmax(err)), err.max())
 
 
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+@pytest.mark.parametrize("order", [16, 40])
+def test_fields_entry_bit_identical_to_soa(dev, ft, order):
+    """cmx_microphysics_2m_p3_tendencies_fields_* (round 3): the 2M + P3 method on VIJFH components in place — state, log λ and the INPC shift as
+    strided views of one field array, the eight tendencies into components of another — bit for bit the SoA entry, for the one-launch form
+    (order 16) and the two launches (order 40), with and without the optional shift column, including a single-run and a length-1-run shape."""
+    import cmx
+    for Nh, Nf, S in ((9, 15, 37 * 8), (1, 13, 513), (6, 14, 1)):
+        n = Nh * S
+        st = _states(n, seed=31 + S, f32_safe=(ft == "f32"))
+        mp = P.Microphysics2MParams(ft, with_ice=True, is_limited=True, quadrature_order=order)
+        tps = P.ThermodynamicsParameters(ft)
+        flat = {k: torch.from_numpy(v).to(DT[ft]).to(dev) for k, v in st.items()}
+        ll = cmx.p3_shape(P.ParametersP3(ft), flat["q_ice"] * flat["rho"], flat["n_ice"] * flat["rho"], flat["q_rim"] * flat["rho"],
+                          flat["b_rim"] * flat["rho"], want=("log_lambda",), brent_iters=40).log_lambda
+        ll = torch.where(torch.isfinite(ll), ll, torch.zeros_like(ll))
+        shift = torch.from_numpy(np.random.default_rng(S).uniform(-1, 1, n)).to(DT[ft]).to(dev)
+        Y = torch.full((Nh, Nf, S), float("nan"), dtype=DT[ft], device=dev)
+        for f, k in enumerate(st):
+            Y[:, f, :] = flat[k].reshape(Nh, S)
+        Y[:, 11, :] = ll.reshape(Nh, S)
+        Y[:, 12, :] = shift.reshape(Nh, S)
+        cols = [Y[:, f, :] for f in range(12)]
+        for sh_flat, sh_view in ((None, None), (shift, Y[:, 12, :])):
+            ref = cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), mp, tps, *[flat[k] for k in st], ll, sh_flat)
+            Yt = torch.full((Nh, 10, S), float("nan"), dtype=DT[ft], device=dev)
+            got = cmx.bulk_microphysics_tendencies_2m_p3_fields(cmx.Microphysics2Moment(), mp, tps, *cols, sh_view, out=[Yt[:, k + 1, :] for k in range(8)])
+            torch.cuda.synchronize()
+            for k, name in enumerate(NAMES):
+                a, b = Yt[:, k + 1, :].reshape(-1), getattr(ref, name)
+                assert torch.equal(a, b) or (torch.isnan(a) == torch.isnan(b)).all() and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)), (name, Nh, S)
+                assert getattr(got, name).data_ptr() == Yt[:, k + 1, :].data_ptr()
+            assert torch.isnan(Yt[:, 0, :]).all() and torch.isnan(Yt[:, 9, :]).all()          # nothing written outside the eight components
+    with pytest.raises(TypeError):
+        cmx.bulk_microphysics_tendencies_2m_p3_fields(cmx.Microphysics2Moment(), P.Microphysics2MParams(ft), tps, *cols)
+
+
 def test_reduces_to_warm_rain_without_ice_and_validates(dev):
     import cmx
     ft = "f64"
