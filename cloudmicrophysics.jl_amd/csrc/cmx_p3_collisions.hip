@@ -909,7 +909,10 @@ static int32_t launch_collision_kernel(const P3Consts<FT> &c, const P3VelConsts<
     };
     if (group == 8)
         return aspect ? go(&p3_collision_kernel<FT, QUAD, true, FUSED, 8, EXTRA>) : go(&p3_collision_kernel<FT, QUAD, false, FUSED, 8, EXTRA>);
-    return aspect ? go(&p3_collision_kernel<FT, QUAD, true, FUSED, 16, EXTRA>) : go(&p3_collision_kernel<FT, QUAD, false, FUSED, 16, EXTRA>);
+    // 16 lanes per state: rules of order >= 48 (collision_group) — never a QuadSmall rule (order <= 32), so the one-launch form has no such
+    // instantiation
+    if constexpr (std::is_same_v<QUAD, QuadSmall<FT>>) return CMX_ERR_BAD_ARG;
+    else return aspect ? go(&p3_collision_kernel<FT, QUAD, true, FUSED, 16, EXTRA>) : go(&p3_collision_kernel<FT, QUAD, false, FUSED, 16, EXTRA>);
 }
 
 template <typename FT, typename IP, typename AP, typename TH, typename QUAD>
