@@ -161,12 +161,20 @@ struct SegLayout {
     int64_t s_in[13], s_out[8];
 };
 struct SegPos {
-    int64_t seg, off;
+    int64_t seg, off;      // contiguous columns: seg = 0, off = i
+    bool segmented;        // wave-uniform (a kernel argument): the contiguous case skips the stride arithmetic — and the scalar loads of the strides
     __device__ __forceinline__ SegPos(const SegLayout &l, int64_t i) {
-        seg = l.seg_len ? i / l.seg_len : 0;
-        off = i - seg * l.seg_len;
+        segmented = l.seg_len != 0;
+        seg = 0; off = i;
+        if (segmented) { seg = i / l.seg_len; off = i - seg * l.seg_len; }
     }
-    template <typename T> __device__ __forceinline__ T &at(T *p, int64_t stride) const { return p[seg * stride + off]; }
+    template <typename T> __device__ __forceinline__ T &at(T *p, const int64_t &stride) const { return segmented ? p[seg * stride + off] : p[off]; }
+    // the same with the stride read from a table in LDS (the collision kernel: 21 strides held in SGPRs across its sweeps cost it 80–160 more
+    // SGPR spills and 1–2 % of the 2M + P3 step; the table is only read for segmented columns)
+    template <typename T> __device__ __forceinline__ T &at_tab(T *p, const int64_t *tab, int k) const {
+        if (segmented) return p[seg * tab[k] + off];
+        return p[off];
+    }
 };
 enum { SEG_RHO = 0, SEG_T, SEG_QTOT, SEG_QLCL, SEG_NLCL, SEG_QRAI, SEG_NRAI, SEG_QICE, SEG_NICE, SEG_QRIM, SEG_BRIM, SEG_LOGLAM, SEG_SHIFT };
 
@@ -411,8 +419,16 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
     const int nq = quad.n;
     // block-wide copy of the quadrature rule: per-lane node indices need a memory the lanes can index
     FT *q_node = lds, *q_wt = lds + nq;
-    if (threadIdx.x == 0)
+    __shared__ int64_t seg_tab[21];      // run strides of the segmented-column form (SegLayout): s_in[13], s_out[8]; unused for contiguous columns
+    if (threadIdx.x == 0) {
         for (int j = 0; j < nq; ++j) { q_node[j] = quad.node[j]; q_wt[j] = quad.weight[j]; }
+        if constexpr (FUSED) {
+            if (io.lay.seg_len != 0) {
+                for (int j = 0; j < 13; ++j) seg_tab[j] = io.lay.s_in[j];
+                for (int j = 0; j < 8; ++j) seg_tab[13 + j] = io.lay.s_out[j];
+            }
+        }
+    }
     const int grp = threadIdx.x / GROUP, g = threadIdx.x % GROUP;
     FT *G = lds + 2 * nq + grp * ColLds<FT>::per_group(nq);
     // per-group layout: E[48], Fm[24] at compile-time offsets from G, then one (D, v, weight) record per inner node — cloud nodes, then
@@ -433,19 +449,19 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
     // Order: the quantile solve first — it needs only ρq, ρn and log λ, and it is the register-hungriest piece of the set-up, so nothing else
     // is alive across it — then the state (p3_make_point) and the liquid-side loads.
     const SegPos ps(io.lay, i);       // (the other entries leave io.lay zero: contiguous columns)
-    const FT rho_a = M::max(ps.at(io.rho_a, io.lay.s_in[SEG_RHO]), FT(0));
+    const FT rho_a = M::max(ps.at_tab(io.rho_a, seg_tab, SEG_RHO), FT(0));
     FT rho_q_in, rho_n_in;
     bool present;
     if constexpr (FUSED) {
         // clamp_to_nonneg and the volumetric quantities of BMT:912-932; ice processes only where q_ice > ϵₘ && n_ice > ϵₙ (:959)
-        const FT q_ice = M::max(ps.at(io.q_ice, io.lay.s_in[SEG_QICE]), FT(0)), n_ice = M::max(ps.at(io.n_ice, io.lay.s_in[SEG_NICE]), FT(0));
+        const FT q_ice = M::max(ps.at_tab(io.q_ice, seg_tab, SEG_QICE), FT(0)), n_ice = M::max(ps.at_tab(io.n_ice, seg_tab, SEG_NICE), FT(0));
         rho_q_in = q_ice * rho_a; rho_n_in = n_ice * rho_a;
         present = q_ice > P::eps() && n_ice > P::eps() && !(rho_n_in < P::eps() || rho_q_in < P::eps());
     } else {
         rho_q_in = io.rho_q[i]; rho_n_in = io.rho_n[i];
         present = !(rho_n_in < P::eps() || rho_q_in < P::eps());
     }
-    const FT loglam = present ? ps.at(io.loglam, io.lay.s_in[SEG_LOGLAM]) : FT(10), lam = P::exp(loglam), mu = p3_mu<FT>(c, loglam);
+    const FT loglam = present ? ps.at_tab(io.loglam, seg_tab, SEG_LOGLAM) : FT(10), lam = P::exp(loglam), mu = p3_mu<FT>(c, loglam);
     // quantiles of the ice PSD (integral_bounds, P3_integral_properties.jl:34-46): one Halley solve per LANE — lanes 0/1 the
     // collision bounds (p = 1e-5), 2/3 the self-collection bounds (p = eps), 4/5 the melting bounds (p = 1e-6) — shared by shuffles
     // (the 2M+P3 entry parks the self-collection / melting bounds in S[20…23] until their sweeps)
@@ -466,12 +482,12 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
     }
     P3Point<FT> s;
     FT L_c, N_c, L_r, N_r;
-    const FT T = ps.at(io.T, io.lay.s_in[SEG_T]);
+    const FT T = ps.at_tab(io.T, seg_tab, SEG_T);
     if constexpr (FUSED) {
-        L_c = M::max(ps.at(io.q_lcl, io.lay.s_in[SEG_QLCL]), FT(0)) * rho_a; N_c = M::max(ps.at(io.n_lcl, io.lay.s_in[SEG_NLCL]), FT(0)) * rho_a;
-        L_r = M::max(ps.at(io.q_rai, io.lay.s_in[SEG_QRAI]), FT(0)) * rho_a; N_r = M::max(ps.at(io.n_rai, io.lay.s_in[SEG_NRAI]), FT(0)) * rho_a;
-        p3_make_point<FT>(c, rho_q_in, rho_n_in, M::max(ps.at(io.q_rim, io.lay.s_in[SEG_QRIM]), FT(0)) * rho_a,
-                          M::max(ps.at(io.b_rim, io.lay.s_in[SEG_BRIM]), FT(0)) * rho_a, s);
+        L_c = M::max(ps.at_tab(io.q_lcl, seg_tab, SEG_QLCL), FT(0)) * rho_a; N_c = M::max(ps.at_tab(io.n_lcl, seg_tab, SEG_NLCL), FT(0)) * rho_a;
+        L_r = M::max(ps.at_tab(io.q_rai, seg_tab, SEG_QRAI), FT(0)) * rho_a; N_r = M::max(ps.at_tab(io.n_rai, seg_tab, SEG_NRAI), FT(0)) * rho_a;
+        p3_make_point<FT>(c, rho_q_in, rho_n_in, M::max(ps.at_tab(io.q_rim, seg_tab, SEG_QRIM), FT(0)) * rho_a,
+                          M::max(ps.at_tab(io.b_rim, seg_tab, SEG_BRIM), FT(0)) * rho_a, s);
         if (g == 0) { S[24] = s.rho_g; S[25] = s.bnd[1]; S[26] = s.bnd[2]; S[27] = s.bnd[3]; }   // for the two later sweeps' segment bounds
     } else {
         L_c = io.L_c[i]; N_c = io.N_c[i]; L_r = io.L_r[i]; N_r = io.N_r[i];
@@ -853,7 +869,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
                        o[4] * e_inv_rho - mq * s.F_rim, o[6] * e_inv_rho - (e_rho_rim > FT(0) ? mq * s.F_rim / e_rho_rim : FT(0))};
             if constexpr (!ONE_LAUNCH) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) SegPos(io.lay, i).at(io.out[q], io.lay.s_out[q]) += d[q];
+                for (int q = 0; q < 8; ++q) SegPos(io.lay, i).at_tab(io.out[q], seg_tab, 13 + q) += d[q];
             } else {
                 // park the ice-process sums in the state's LDS block (the rain constants there are dead now) for the pointwise pass below
 #pragma unroll
@@ -874,11 +890,11 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
             const SegPos p2(io.lay, i2);
             const FT *const col[11] = {io.rho_a, io.T, ex.q_tot, io.q_lcl, io.n_lcl, io.q_rai, io.n_rai, io.q_ice, io.n_ice, io.q_rim, io.b_rim};
 #pragma unroll
-            for (int kk = 0; kk < 11; ++kk) in[kk] = p2.at(col[kk], io.lay.s_in[kk]);
-            const FT shift = ex.shift ? p2.at(ex.shift, io.lay.s_in[SEG_SHIFT]) : FT(0);
+            for (int kk = 0; kk < 11; ++kk) in[kk] = p2.at_tab(col[kk], seg_tab, kk);
+            const FT shift = ex.shift ? p2.at_tab(ex.shift, seg_tab, SEG_SHIFT) : FT(0);
             mp2m_p3_point<FT, EXTRA::LIMITED, EXTRA::INTPOW, true>(ex.sc, c, ex.pk, in, shift, pw);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) p2.at(io.out[q], io.lay.s_out[q]) = pw[q] + S2[q];
+            for (int q = 0; q < 8; ++q) p2.at_tab(io.out[q], seg_tab, 13 + q) = pw[q] + S2[q];
         }
     }
 }
