@@ -281,3 +281,40 @@ def test_small_activated_mass_fractions_keep_relative_accuracy_f32(dev, oracle):
         checked += int(sel.sum())
         small += int((exp[sel] < 1e-4 * total).sum())
     assert checked > n and small > 1000          # the test did reach weakly activated states
+
+
+@pytest.mark.parametrize("ft", ["f32", "f64"])
+def test_edge_states_updraft_and_cold(dev, oracle, ft):
+    """Vanishing, zero and negative updrafts, very cold and very warm states, nearly saturated liquid: where the reference's formula is 0/0 or the
+    root of a negative number (w <= 0, AA:168-183) the result is NaN in the oracle AND here (the kernel's exp2_fin / x^(-3/4) forms have no 0 / Inf
+    cases to fall back on); everywhere else finite and in parity."""
+    import cmx
+    rows = []
+    for w in (0.0, -0.5, 1e-6, 1e-3, 0.5, 10.0, 40.0):
+        for T, p in ((294.0, 1e5), (273.15, 8e4), (235.0, 4e4), (200.0, 2e4), (310.0, 1.02e5)):
+            for q_tot, q_liq in ((1e-2, 0.0), (1e-5, 0.0), (2e-2, 5e-3)):
+                rows.append((T, p, w, q_tot, q_liq, 0.0))
+    arr = np.array(rows, dtype=np.float64).T
+    cols = [torch.tensor(a, dtype=DT[ft]) for a in arr]
+    ad = synthetic_distribution()
+    ap, aip, tps = _params(ft)
+    r = cmx.aerosol_activation(ap, ad, aip, tps, *[c.to(dev) for c in cols], want=("N_act", "S_max"))
+    torch.cuda.synchronize()
+    a64, i64, t64 = _params("f64")
+    adc = ad.c_struct(a64, _abi.F64)
+    ref = oracle.arg2000_activation(_abi.F64, a64, adc, i64, t64, *[c.numpy().astype(np.float64) for c in cols], nthreads=4, float32_gates=(ft == "f32"))
+    smax, rs = r.S_max.cpu().numpy().astype(np.float64), ref["S_max"]
+    bad_w = arr[2] <= 0
+    assert np.all(np.isnan(rs[bad_w])) and np.all(np.isnan(smax[bad_w]))
+    ok = ~bad_w
+    assert np.all(np.isfinite(smax[ok])) and np.all(np.isfinite(rs[ok]))
+    assert np.all(np.abs(smax[ok] - rs[ok]) <= parity.RTOL[ft] * np.abs(rs[ok]) + 1e-300)
+    for k in range(adc.n_modes):
+        x = r.N_act[k].cpu().numpy().astype(np.float64)
+        assert np.all(np.isnan(x[bad_w])) and np.all(np.isfinite(x[ok]))
+        assert np.all(np.abs(x[ok] - ref["N_act"][k][ok]) <= parity.RTOL[ft] * np.abs(ref["N_act"][k][ok]) + parity.CTOL[ft] * adc.modes[k].N)
+
+
+def synthetic_distribution():
+    from cmx import synthetic
+    return synthetic.arg_config3_distribution()
