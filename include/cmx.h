@@ -53,8 +53,16 @@
 extern "C" {
 #endif
 
+/* cmx_version() = (MAJOR << 16) | MINOR.  The minor number moves whenever a parameter struct changes its layout or an entry point is added, so a
+ * binding compiled against another header can refuse to run:
+ *   0.1  rounds 1–2
+ *   0.3  round 3: cmx_process_params_1m gained the Frostenberg member (cmx_microphysics_1m: 85 → 90 fields); new structs cmx_mohler2006,
+ *        cmx_mohler_dust, cmx_deposition_dust, cmx_h2so4_solution_params; new entries cmx_mp1m_column_tendencies_sedimentation,
+ *        cmx_mp1m_linearized_average_fields, cmx_microphysics_2m_p3_tendencies_fields, cmx_ice_nucleation_rates_xT, cmx_h2so4_solution,
+ *        cmx_mohler2006_deposition, cmx_deposition_J, cmx_inp_concentration_frequency, cmx_arg2000_total_activated, cmx_lean_eval_literal;
+ *        process columns CMX_SB_DEVAP_DN_RAI / CMX_SB_DEVAP_DQ_RAI; CMX_1M_CLOUD_ICE_FORMATION_TDEP and every Chen-2022 table accepted */
 #define CMX_VERSION_MAJOR 0
-#define CMX_VERSION_MINOR 1
+#define CMX_VERSION_MINOR 3
 
 typedef enum cmx_status {
     CMX_OK = 0,
