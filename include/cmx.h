@@ -60,9 +60,12 @@ extern "C" {
  *        cmx_mohler_dust, cmx_deposition_dust, cmx_h2so4_solution_params; new entries cmx_mp1m_column_tendencies_sedimentation,
  *        cmx_mp1m_linearized_average_fields, cmx_microphysics_2m_p3_tendencies_fields, cmx_ice_nucleation_rates_xT, cmx_h2so4_solution,
  *        cmx_mohler2006_deposition, cmx_deposition_J, cmx_inp_concentration_frequency, cmx_arg2000_total_activated, cmx_lean_eval_literal;
- *        process columns CMX_SB_DEVAP_DN_RAI / CMX_SB_DEVAP_DQ_RAI; CMX_1M_CLOUD_ICE_FORMATION_TDEP and every Chen-2022 table accepted */
+ *        process columns CMX_SB_DEVAP_DN_RAI / CMX_SB_DEVAP_DQ_RAI; CMX_1M_CLOUD_ICE_FORMATION_TDEP and every Chen-2022 table accepted
+ *   0.4  round 4: no struct layout changed.  cmx_lean_eval_* gained `which` 11-13 (UT.gamma_inc P / Q, UT.gamma_inc_inv — they take the
+ *        second argument in a new column `a`); new entries cmx_psd_* (SB2006 / generalized-gamma size-distribution helpers);
+ *        cmx_column_sums_* became one deterministic launch.  julia/CMXExt.jl (the reference-side binding) checks this number. */
 #define CMX_VERSION_MAJOR 0
-#define CMX_VERSION_MINOR 3
+#define CMX_VERSION_MINOR 4
 
 typedef enum cmx_status {
     CMX_OK = 0,
