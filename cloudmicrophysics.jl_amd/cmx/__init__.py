@@ -4,6 +4,7 @@ Host-side mirror of the reference's module layout for the hot path:
   cmx.parameters        ↔ CloudMicrophysics.Parameters (CMP)
   cmx.microphysics0m    ↔ CloudMicrophysics.Microphysics0M (CM0) + the 0M methods of BMT
   cmx.bulk_tendencies   ↔ CloudMicrophysics.BulkMicrophysicsTendencies (BMT) + per-process CM2 rates
+  cmx.utilities         ↔ CloudMicrophysics.Utilities (UT): gamma_inc / gamma_inc_inv over columns
   cmx.synthetic         ↔ the state generator of test/gpu_performance.jl:80-136
   cmx.sharding          ↔ (no reference equivalent) one-process-per-GPU sharding + RCCL diagnostic sums
 All compute goes through libcmx.so (include/cmx.h); there is no CPU fallback.
@@ -33,5 +34,7 @@ from .aerosol import (ActivationResult, AerosolDistribution, ModeColumns, Mode_B
 
 from .p3 import (P3Melt, P3Shape, P3ShapeVelocities, P3Velocities, p3_shape_and_terminal_velocities, p3_het_ice_nucleation, p3_ice_melt, p3_ice_self_collection, p3_liquid_ice_collisions,  # noqa: F401
                  p3_shape, p3_terminal_velocities)
+
+from .utilities import GammaInc, gamma_inc, gamma_inc_inv  # noqa: F401
 
 __version__ = "0.1.0"

@@ -167,9 +167,15 @@ def _declare(lib):
         f.restype = i32
         f.argtypes = [C.POINTER(fam.warm_rain_2m), C.POINTER(fam.p3_ice_params), C.POINTER(fam.thermo), u32, i64, i64, C.POINTER(vp), C.POINTER(i64),
                       C.POINTER(vp), C.POINTER(i64), vp]
+        f = getattr(lib, f"cmx_gamma_inc_{s}")
+        f.restype = i32
+        f.argtypes = [i64, vp, vp, vp, vp, vp]
+        f = getattr(lib, f"cmx_gamma_inc_inv_{s}")
+        f.restype = i32
+        f.argtypes = [i64, vp, vp, vp, vp, vp]
         f = getattr(lib, f"cmx_column_sums_{s}")
         f.restype = i32
-        f.argtypes = [i32, C.POINTER(vp), i64, vp, vp]
+        f.argtypes = [i32, C.POINTER(vp), i64, vp, vp, vp]
 
 
 def lib():

@@ -328,17 +328,27 @@ def sb2006_process_rates(mp, tps, q_tot, q_lcl, q_rai, N_lcl, N_rai, rho, T, *, 
     return SB2006ProcessRates(*outs)
 
 
-def column_sums(cols, stream=None) -> torch.Tensor:
-    """Σ of each device column (double accumulation) → float64 tensor [len(cols)] on the device.
-    Building block of the optional diagnostic reduction; no communication here."""
-    ref = _check_cols(list(cols), [f"col{i}" for i in range(len(cols))])
+def column_sums(cols, stream=None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Σ of each device column (double accumulation) → float64 tensor [len(cols)] on the device (≤ 16 columns).
+    Building block of the optional diagnostic reduction; no communication here.  Deterministic: one launch over all
+    columns into `workspace` (len(cols) × 1024 doubles, allocated here unless given), then a fixed-tree finish — bit-identical from run
+    to run (include/cmx.h §3)."""
+    cols = list(cols)
+    if len(cols) > _abi.CMX_COLUMN_SUMS_MAX_COLS:
+        raise ValueError(f"at most {_abi.CMX_COLUMN_SUMS_MAX_COLS} columns per call")
+    ref = _check_cols(cols, [f"col{i}" for i in range(len(cols))])
     fam = _fam_of(ref)
     sums = torch.empty(len(cols), dtype=torch.float64, device=ref.device)
+    need = len(cols) * _abi.CMX_COLUMN_SUMS_PARTIALS
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.float64, device=ref.device)
+    elif workspace.dtype != torch.float64 or workspace.device != ref.device or workspace.numel() < need or not workspace.is_contiguous():
+        raise ValueError(f"workspace: a contiguous float64 device tensor of at least {need} elements")
     arr = (C.c_void_p * len(cols))(*[t.data_ptr() for t in cols])
     s = stream if stream is not None else torch.cuda.current_stream(ref.device)
     fn = getattr(_lib.lib(), f"cmx_column_sums_{fam.sfx}")
     with torch.cuda.device(ref.device):
-        st = fn(len(cols), arr, ref.numel(), _ptr(sums), C.c_void_p(s.cuda_stream))
+        st = fn(len(cols), arr, ref.numel(), _ptr(sums), _ptr(workspace), C.c_void_p(s.cuda_stream))
     _lib.check(fn.__name__, st)
     return sums
 

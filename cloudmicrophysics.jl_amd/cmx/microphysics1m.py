@@ -193,10 +193,21 @@ def column_tendencies_sedimentation_1m(mode, scheme, mp, tps, stokes, chen_rain,
     if not isinstance(scheme, Microphysics1Moment) or not isinstance(mode, (Instantaneous, LinearizedAverage)):
         raise TypeError("mode must be Instantaneous() or LinearizedAverage() and scheme Microphysics1Moment()")
     cols = (rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno)
+    names = ("rho", "T", "q_tot", "q_lcl", "q_icl", "q_rai", "q_sno")
     if rho.dim() != 2:
         raise ValueError("state tensors must have shape (n_col, n_lev)")
-    flat = [c.reshape(-1) for c in cols]
+    # validate the 2-D tensors THEMSELVES: the kernel reads and writes flat row-major (n_col, n_lev) storage, so a transposed
+    # view, a column of another shape with the same number of elements or any non-contiguous tensor must be refused, not silently copied
+    for c, nm in zip(cols, names):
+        if c.shape != rho.shape:
+            raise ValueError(f"column {nm}: shape {tuple(c.shape)} differs from rho's {tuple(rho.shape)}")
+        if not c.is_contiguous():
+            raise ValueError(f"column {nm} must be a contiguous (n_col, n_lev) tensor (levels contiguous within a column)")
+    flat = [c.view(-1) for c in cols]
     ref, fam = _prep(mp, tps, flat)
+    for obj, cls, nm in ((stokes, fam.stokes_vel, "stokes"), (chen_rain, fam.chen2022_rain_vel, "chen_rain"), (chen_ice, fam.chen2022_ice_vel, "chen_ice")):
+        if not isinstance(obj, cls):
+            raise TypeError(f"{nm}: expected the {cls.__name__} struct of the state's float type, got {type(obj).__name__}")
     n_col, n_lev = rho.shape
     if inv_dz.numel() != n_lev or inv_dz.dtype != ref.dtype or inv_dz.device != ref.device or not inv_dz.is_contiguous():
         raise ValueError("inv_dz: n_lev contiguous values of the state's dtype on the state's device")
@@ -209,7 +220,7 @@ def column_tendencies_sedimentation_1m(mode, scheme, mp, tps, stokes, chen_rain,
             q_min = DEFAULT_PARAMETERS["specific_humidity_minimum"]
     elif dt is not None:
         raise TypeError("Instantaneous() takes no dt")
-    out = [torch.empty_like(rho) for _ in range(4)]
+    out = [torch.empty(rho.shape, dtype=ref.dtype, device=ref.device) for _ in range(4)]      # contiguous row-major, whatever rho's strides
     pr = [torch.empty(n_col, dtype=ref.dtype, device=ref.device) if precip else None for _ in range(2)]
     in_p = (C.c_void_p * 7)(*[c.data_ptr() for c in flat])
     out_p = (C.c_void_p * 4)(*[o.data_ptr() for o in out])

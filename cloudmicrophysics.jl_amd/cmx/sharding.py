@@ -37,7 +37,7 @@ def allreduce_sums(local_sums: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def global_diagnostics(columns, group=None) -> torch.Tensor:
-    """Σ over ALL ranks of each device column: per-rank fused block reduction (cmx_column_sums_*),
-    then one all-reduce of len(columns) doubles."""
+    """Σ over ALL ranks of each device column: per-rank deterministic two-stage reduction (cmx_column_sums_*: one launch over all
+    columns + a fixed-tree finish, no atomics), then one all-reduce of len(columns) doubles."""
     from .bulk_tendencies import column_sums
     return allreduce_sums(column_sums(columns), group)

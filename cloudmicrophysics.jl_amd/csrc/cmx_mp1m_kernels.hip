@@ -95,12 +95,17 @@ __global__ __launch_bounds__(kBlock) void mp1m_sources_kernel(const Mp1mConsts<F
     Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    const Mp1mSrc<FT> p = mp1m_point<FT>(front_consts<FT>(c), in.rho[i], in.T[i], in.q_tot[i], in.q_lcl[i], in.q_icl[i], in.q_rai[i], in.q_sno[i]);
+    const FT rho = in.rho[i], T = in.T[i], q_tot = in.q_tot[i], q_lcl = in.q_lcl[i], q_icl = in.q_icl[i], q_rai = in.q_rai[i], q_sno = in.q_sno[i];
+    const Mp1mSrc<FT> p = mp1m_point<FT>(front_consts<FT>(c), rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno);
     FT s[CMX_MP1M_NSRC];
     mp1m_expand<FT>(p, s);
+    // NaN in → NaN out, as in the tendencies kernels (cmx_math.hpp any_nan): the clamps and the max0 gates of the point function return 0
+    // for a NaN operand (for the Float32 integer form: for a NaN with the sign bit set), which would turn a NaN input into a
+    // zero melt / accretion term here
+    const FT poison = any_nan(rho, q_tot, q_lcl, q_icl, q_rai, q_sno, T) ? Math<FT>::nan() : FT(0);
 #pragma unroll
     for (int k = 0; k < CMX_MP1M_NSRC; ++k)
-        if (out.col[k]) out.col[k][i] = s[k];
+        if (out.col[k]) out.col[k][i] = s[k] + poison;
 }
 
 // ---- terminal velocities over (ρ, q) columns — CM1:223-270 (point functions: cmx_mp1m_vel.hpp) ---------------------

@@ -448,9 +448,64 @@ static int32_t p3_self_collection_entry(const PR *params, const VR *vel, const Q
     return CMX_OK;
 }
 
+// ---- UT.gamma_inc / UT.gamma_inc_inv over columns (src/Utilities.jl:54-61,93-144,205-252; KA wrapper test_gamma_inc_kernel!,
+// test/gpu_tests.jl:456-461) — the very functions the shape solver, the quantile bounds and the collision kernels call
+template <typename FT>
+__global__ __launch_bounds__(kBlock) void gamma_inc_kernel(const int64_t n, const FT *__restrict__ a, const FT *__restrict__ x, FT *__restrict__ Pout,
+                                                           FT *__restrict__ Qout) {
+    Math<FT>::prepare();
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const FT ai = a[i], xi = x[i];
+    const FT lg = PM<FT>::lgamma(ai);
+    // one evaluation, as the reference returns (P, 1 − P) on the series branch and (1 − Q, Q) on the continued-fraction branch
+    const bool series = xi < ai + FT(1);
+    const FT g = gamma_inc_dev<FT>(ai, xi, lg, series);
+    if (Pout) Pout[i] = series ? g : FT(1) - g;
+    if (Qout) Qout[i] = series ? FT(1) - g : g;
+}
+template <typename FT>
+__global__ __launch_bounds__(kBlock) void gamma_inc_inv_kernel(const int64_t n, const FT *__restrict__ a, const FT *__restrict__ p, const FT *__restrict__ q,
+                                                               FT *__restrict__ xout) {
+    Math<FT>::prepare();
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    xout[i] = gamma_inc_inv_dev<FT>(a[i], p[i], q[i]);
+}
+
+template <typename FT> static int32_t gamma_inc_entry(int64_t n, const FT *a, const FT *x, FT *P, FT *Q, void *stream) {
+    if (n < 0) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;
+    if (n == 0) return CMX_OK;
+    if (!a || !x || (!P && !Q)) return CMX_ERR_BAD_ARG;
+    hipLaunchKernelGGL((gamma_inc_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), n, a, x, P, Q);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+template <typename FT> static int32_t gamma_inc_inv_entry(int64_t n, const FT *a, const FT *p, const FT *q, FT *x, void *stream) {
+    if (n < 0) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;
+    if (n == 0) return CMX_OK;
+    if (!a || !p || !q || !x) return CMX_ERR_BAD_ARG;
+    hipLaunchKernelGGL((gamma_inc_inv_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), n, a, p, q,
+                       x);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+
 }  // namespace cmx
 
 extern "C" {
+
+int32_t cmx_gamma_inc_f32(int64_t n, const float *a, const float *x, float *P, float *Q, void *stream) { return cmx::gamma_inc_entry<float>(n, a, x, P, Q, stream); }
+int32_t cmx_gamma_inc_f64(int64_t n, const double *a, const double *x, double *P, double *Q, void *stream) { return cmx::gamma_inc_entry<double>(n, a, x, P, Q, stream); }
+int32_t cmx_gamma_inc_inv_f32(int64_t n, const float *a, const float *p, const float *q, float *x, void *stream) {
+    return cmx::gamma_inc_inv_entry<float>(n, a, p, q, x, stream);
+}
+int32_t cmx_gamma_inc_inv_f64(int64_t n, const double *a, const double *p, const double *q, double *x, void *stream) {
+    return cmx::gamma_inc_inv_entry<double>(n, a, p, q, x, stream);
+}
+
 
 int32_t cmx_p3_shape_f32(const cmx_p3_params_f32 *params, uint32_t flags, int32_t brent_iters, int64_t n, const float *rho_q_ice, const float *rho_n_ice,
                          const float *x3, const float *x4, const float *log_lambda_guess, float *F_rim, float *rho_rim,

@@ -345,7 +345,8 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, F
     const FT eps = M::eps();  // ϵ_numerics_2M_M = ϵ_numerics_2M_N = eps(FT)  (Utilities.jl:325,332)
     SbRates<FT> r;
 
-    const FT rs_rho = M::rsqrt_pos(rho);  // air density: positive, finite.  ρ^(-1/2); each √(ρ0/ρ) is (host √ρ0)·rs_rho
+    const FT rs_rho = M::rsqrt(rho);      // ρ^(-1/2); each √(ρ0/ρ) is (host √ρ0)·rs_rho.  The FULL form: ρ arrives clamped with max0(), so 0 is possible (+Inf
+                                          // in both float types; the positive-argument form gave NaN in Float64 only — two instructions)
     const FT inv_rho = rs_rho * rs_rho;   // one hardware transcendental for both
     r.inv_rho = inv_rho;
 

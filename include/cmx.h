@@ -61,9 +61,10 @@ extern "C" {
  *        cmx_mp1m_linearized_average_fields, cmx_microphysics_2m_p3_tendencies_fields, cmx_ice_nucleation_rates_xT, cmx_h2so4_solution,
  *        cmx_mohler2006_deposition, cmx_deposition_J, cmx_inp_concentration_frequency, cmx_arg2000_total_activated, cmx_lean_eval_literal;
  *        process columns CMX_SB_DEVAP_DN_RAI / CMX_SB_DEVAP_DQ_RAI; CMX_1M_CLOUD_ICE_FORMATION_TDEP and every Chen-2022 table accepted
- *   0.4  round 4: no struct layout changed.  cmx_lean_eval_* gained `which` 11-13 (UT.gamma_inc P / Q, UT.gamma_inc_inv — they take the
- *        second argument in a new column `a`); new entries cmx_psd_* (SB2006 / generalized-gamma size-distribution helpers);
- *        cmx_column_sums_* became one deterministic launch.  julia/CMXExt.jl (the reference-side binding) checks this number. */
+ *   0.4  round 4: no struct layout changed.  New entries cmx_gamma_inc, cmx_gamma_inc_inv (UT.gamma_inc / gamma_inc_inv over columns), cmx_psd_*
+ *        (SB2006 / generalized-gamma size-distribution helpers); cmx_column_sums_* takes a caller-owned workspace and is deterministic (one launch
+ *        for all columns + a one-workgroup-per-column finish, no floating-point atomics).
+ *        julia/CMXExt.jl (the reference-side binding) checks this number. */
 #define CMX_VERSION_MAJOR 0
 #define CMX_VERSION_MINOR 4
 
@@ -1037,6 +1038,17 @@ int32_t cmx_microphysics_2m_p3_tendencies_fields_f64(const cmx_warm_rain_2m_f64 
                                                      uint32_t flags, int64_t n_seg, int64_t seg_len, const double *const *in,
                                                      const int64_t *in_seg_stride, double *const *out, const int64_t *out_seg_stride, void *stream);
 
+/* UT.gamma_inc(a, x) = (P, Q) and UT.gamma_inc_inv(a, p, q) over columns — src/Utilities.jl:54-61,93-144 and :205-252 (KA wrapper
+ * test_gamma_inc_kernel!, test/gpu_tests.jl:456-461; CPU test test/gamma_inc_tests.jl): the reference's fast regularised incomplete gamma
+ * functions — series for x < a + 1, Lentz continued fraction otherwise, 20 (Float32) / 30 (Float64) terms — and their Halley inverse,
+ * evaluated by the SAME device routines the P3 kernels call (shape solver moments, quantile bounds, closed-form rain collisions).  a > 0.
+ * Either of P, Q may be NULL (not both).  The device series / continued fraction may stop early once converged to eps(FT); the reference's
+ * fixed term count is an upper bound, so results agree with it to rounding wherever the reference's truncation has converged. */
+int32_t cmx_gamma_inc_f32(int64_t n, const float *a, const float *x, float *P, float *Q, void *stream);
+int32_t cmx_gamma_inc_f64(int64_t n, const double *a, const double *x, double *P, double *Q, void *stream);
+int32_t cmx_gamma_inc_inv_f32(int64_t n, const float *a, const float *p, const float *q, float *x, void *stream);
+int32_t cmx_gamma_inc_inv_f64(int64_t n, const double *a, const double *p, const double *q, double *x, void *stream);
+
 /* ---------------------------------------------------------------------------
  * (0) 0-moment entry of bulk_microphysics_tendencies (src/BulkMicrophysicsTendencies.jl:658-680; KA kernels
  * test_bulk_tendencies_0m_kernel!, test_bulk_tendencies_0m_S0_kernel!, test/gpu_tests.jl:364-383, and
@@ -1053,15 +1065,19 @@ int32_t cmx_mp0m_tendencies_f64(const cmx_parameters_0m_f64 *p, int64_t n, const
                                 const double *q_vap_sat, double *dq_tot_dt, double *ddq_dq_tot, void *stream);
 
 /* ---------------------------------------------------------------------------
- * (3) Optional diagnostic sums over one rank's shard: per-column
- * Σx (double accumulation) of `ncols` device columns of length n into
- * `sums[ncols]` (device, double).  The caller all-reduces the ≤16 doubles over
- * RCCL; the library itself performs no communication.
+ * (3) Optional diagnostic sums over one rank's shard: Σx of `ncols` (≤ CMX_COLUMN_SUMS_MAX_COLS) device columns of length
+ * n, accumulated in double, into `sums[ncols]` (device, double).  ONE launch reduces all columns to CMX_COLUMN_SUMS_PARTIALS partial
+ * sums each (`workspace`: ncols · CMX_COLUMN_SUMS_PARTIALS doubles of device memory owned by the caller — the library allocates nothing),
+ * a second, one-workgroup-per-column launch adds those in a fixed tree.  No floating-point atomics: the result is a pure function of
+ * the column contents and n — bit-identical from run to run and from device to device (the decomposition does not depend on the CU
+ * count).  It is NOT invariant under re-sharding: a rank count changes the order of additions, so the all-reduced total of 8 shards and
+ * the sum of the unsharded column agree to rounding (a few ulp of Σ|x|·2⁻⁵³·log₂ n), not bit for bit.  The caller all-reduces the ≤ 16
+ * doubles over RCCL / MPI; the library itself performs no communication.
  * ------------------------------------------------------------------------- */
-int32_t cmx_column_sums_f32(int32_t ncols, const float *const *cols, int64_t n,
-                            double *sums, void *stream);
-int32_t cmx_column_sums_f64(int32_t ncols, const double *const *cols, int64_t n,
-                            double *sums, void *stream);
+#define CMX_COLUMN_SUMS_MAX_COLS 16
+#define CMX_COLUMN_SUMS_PARTIALS 1024
+int32_t cmx_column_sums_f32(int32_t ncols, const float *const *cols, int64_t n, double *sums, double *workspace, void *stream);
+int32_t cmx_column_sums_f64(int32_t ncols, const double *const *cols, int64_t n, double *sums, double *workspace, void *stream);
 
 #ifdef __cplusplus
 }

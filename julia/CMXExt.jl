@@ -121,6 +121,8 @@ const CMX_SB2006_NPROC = 19
 const CMX_MP1M_NSRC = 18
 const CMX_ARG_MAX_MODES = 8
 const CMX_QUAD_MAX = 128
+const CMX_COLUMN_SUMS_MAX_COLS = 16
+const CMX_COLUMN_SUMS_PARTIALS = 1024
 
 # ----------------------------------------------------------------------------------------------------------------
 # Reference structs whose memory layout IS the C layout (immutable, all-FT, declaration order): passed with Ref(x).
@@ -1109,10 +1111,32 @@ function bulk_microphysics_tendencies!(dq_tot_dt, ::BMT.Microphysics0Moment, mp:
     return dq_tot_dt
 end
 
-"""Σ of up to 16 device columns into `sums` (device `Float64[ncols]`), deterministic; the caller all-reduces the doubles (MPI / RCCL)."""
-function column_sums!(sums, cols, ::Type{FT}, n::Integer; stream = C_NULL) where {FT}
-    st = ccall(_fn("cmx_column_sums", FT), Int32, (Int32, Ptr{Ptr{FT}}, Int64, Ptr{Float64}, Ptr{Cvoid}),
-        length(cols), _ptrs(FT, cols), n, _dp(Float64, sums), stream)
+"""`UT.gamma_inc.(a, x)` → (P, Q) (src/Utilities.jl:54-61,93-144; `test_gamma_inc_kernel!`, test/gpu_tests.jl:456-461); either output may be `nothing`."""
+function gamma_inc!(P, Q, a::AbstractArray{FT}, x; stream = C_NULL) where {FT}
+    st = ccall(_fn("cmx_gamma_inc", FT), Int32, (Int64, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{Cvoid}),
+        length(a), _dp(FT, a), _dp(FT, x), _dp(FT, P), _dp(FT, Q), stream)
+    _check(st, "cmx_gamma_inc")
+    return nothing
+end
+
+"""`UT.gamma_inc_inv.(a, p, q)` (src/Utilities.jl:162-165,205-252)."""
+function gamma_inc_inv!(x, a::AbstractArray{FT}, p, q; stream = C_NULL) where {FT}
+    st = ccall(_fn("cmx_gamma_inc_inv", FT), Int32, (Int64, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{Cvoid}),
+        length(a), _dp(FT, a), _dp(FT, p), _dp(FT, q), _dp(FT, x), stream)
+    _check(st, "cmx_gamma_inc_inv")
+    return x
+end
+
+"""
+    column_sums!(sums, workspace, cols, FT, n; stream)
+
+Σ of up to 16 device columns into `sums` (device `Float64[ncols]`); `workspace` = device `Float64[ncols · CMX_COLUMN_SUMS_PARTIALS]`.
+Deterministic (no atomics): bit-identical from run to run; the caller all-reduces the doubles (MPI / RCCL).
+"""
+function column_sums!(sums, workspace, cols, ::Type{FT}, n::Integer; stream = C_NULL) where {FT}
+    length(cols) <= CMX_COLUMN_SUMS_MAX_COLS || error("at most $(CMX_COLUMN_SUMS_MAX_COLS) columns per call")
+    st = ccall(_fn("cmx_column_sums", FT), Int32, (Int32, Ptr{Ptr{FT}}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+        length(cols), _ptrs(FT, cols), n, _dp(Float64, sums), _dp(Float64, workspace), stream)
     _check(st, "cmx_column_sums")
     return sums
 end

@@ -92,6 +92,36 @@ def plain_stats(x, ref, scale, rtol, floor, ceil, keep, wellcond=1e-3):
             "worst_wellcond": float(rel[wc].max()) if wc.any() else 0.0}
 
 
+def record(what, ft, got: dict, ref: dict, *, family, pinned_by, scale=None, keep=None, names=None, wellcond=None, assert_wellcond=False,
+           note=None):
+    """Report rows for a comparison that a test asserts with its OWN documented tolerance (a reference KAT tolerance, an iterate-for-
+    iterate solver comparison, a quadrature-limited integral …): the same plain-bound statistics as assert_parity, so that
+    profiles/rNN_parity_report.json and DESIGN §6 cover every kernel family, without changing what that test asserts.  `scale` (name →
+    array) is the operand scale of a cancelling output; `keep` a mask of the compared points; with `assert_wellcond` the worst plain
+    relative error among points with |ref| > wellcond·scale must be ≤ RTOL[ft] (e.g. ARG's N_act against |N_act| where N_act > 1e-3 N)."""
+    rtol = RTOL[ft]
+    out = {}
+    for k in (names or list(got)):
+        if got.get(k) is None:
+            continue
+        x, r = np.asarray(got[k], dtype=np.float64).ravel(), np.asarray(ref[k], dtype=np.float64).ravel()
+        sc = None if scale is None or scale.get(k) is None else np.broadcast_to(np.asarray(scale[k], dtype=np.float64), r.shape if r.ndim else (1,)).ravel()
+        kp = slice(None) if keep is None else np.asarray(keep).ravel()
+        ps = plain_stats(x, r, sc, rtol, FLOOR[ft], CEIL[ft], kp, WELLCOND[ft] if wellcond is None else wellcond)
+        e = np.nan_to_num(scaled_err(x, r, sc, FLOOR[ft], CEIL[ft], CTOL[ft] / RTOL[ft]), nan=np.inf)
+        worst = float(np.max(e[kp])) if e[kp].size else 0.0
+        row = {"what": what.strip(), "output": k, "ft": ft, "rtol": rtol, "worst_normalised": worst, **ps, "family": family,
+               "pinned_by": pinned_by, "asserted": "test-specific" + (" + well-conditioned plain bound" if assert_wellcond else "")}
+        if note:
+            row["note"] = note
+        REPORTS.append(row)
+        out[k] = ps
+        if assert_wellcond:
+            assert ps["worst_wellcond"] <= rtol, (
+                f"{what} {k}: well-conditioned point with plain relative error {ps['worst_wellcond']:.3e} > {rtol:g}")
+    return out
+
+
 def assert_parity(got: dict, ref: dict, rtol: float, names=OUT_NAMES, what="", floor=None, min_frac=None):
     """got/ref: name → array; ref carries 'scale' (name → array) and 'near_branch' (bool mask).  Returns the worst
     normalised error per output (must be ≤ rtol).  Also checks and records the plain relative bound (see above)."""

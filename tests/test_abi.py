@@ -118,10 +118,12 @@ def test_argument_validation_without_gpu():
     assert f(C.byref(wr.c), C.byref(tps), None, 1, huge, *null, None) == _abi.CMX_ERR_UNSUPPORTED
     assert h(C.byref(wr.c), C.byref(tps), 1, 1 << 31, 1 << 31, ins, st7, outs, st4, None, None) == _abi.CMX_ERR_UNSUPPORTED
     g = lib.cmx_column_sums_f64
-    assert g(-1, None, 0, None, None) == _abi.CMX_ERR_BAD_ARG
+    assert g(-1, None, 0, None, None, None) == _abi.CMX_ERR_BAD_ARG
     two = (C.c_void_p * 2)(4096, None)
-    assert g(2, two, 8, C.c_void_p(8192), None) == _abi.CMX_ERR_BAD_ARG          # a NULL column is caught before anything is enqueued
-    assert g(0, None, 0, None, None) == _abi.CMX_OK
+    assert g(2, two, 8, C.c_void_p(8192), C.c_void_p(16384), None) == _abi.CMX_ERR_BAD_ARG          # a NULL column is caught before anything is enqueued
+    assert g(2, (C.c_void_p * 2)(4096, 4096), 8, C.c_void_p(8192), None, None) == _abi.CMX_ERR_BAD_ARG   # … and so is a missing workspace
+    assert g(17, (C.c_void_p * 17)(*[4096] * 17), 8, C.c_void_p(8192), C.c_void_p(16384), None) == _abi.CMX_ERR_BAD_ARG     # more than CMX_COLUMN_SUMS_MAX_COLS
+    assert g(0, None, 0, None, None, None) == _abi.CMX_OK
 
 
 def test_product_never_imports_the_oracle():

@@ -46,6 +46,18 @@ def _compare(got, ref, adc, ft, what):
             rep[f"{name}[{k}]"] = float(np.nan_to_num(e, nan=np.inf).max())
     worst = max(rep.values())
     assert worst <= rtol, (what, rep)
+    # report rows: S_max plain; N_act / M_act against the mode total (operand scale) AND, where more than 1e-3 of the mode
+    # activates, against |ref| itself — the plain north-star bound on the activated number
+    pin = "oracle restatement of src/AerosolActivation.jl:35-433 (pinned to 5-10 % by the reference's Fig.-1 test and an mpmath restatement)"
+    parity.record("ARG2000 " + what, ft, {"S_max": got.S_max.cpu().numpy()}, {"S_max": ref["S_max"]}, family="ARG2000 (a3)", pinned_by=pin, assert_wellcond=True)
+    for name, grp, sc in (("N_act", got.N_act, lambda m: m.N), ("M_act", got.M_act, lambda m: m.molar_mass_mix)):
+        if grp is None:
+            continue
+        for k in range(adc.n_modes):
+            x = grp[k].cpu().numpy()
+            parity.record("ARG2000 " + what, ft, {f"{name}[{k}]": x}, {f"{name}[{k}]": ref[name][k]}, family="ARG2000 (a3)", pinned_by=pin,
+                          scale={f"{name}[{k}]": np.full(x.shape, sc(adc.modes[k]))}, wellcond=1e-3, assert_wellcond=True,
+                          note="well-conditioned = more than 1e-3 of the mode's total activates")
     return rep
 
 

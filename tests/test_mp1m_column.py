@@ -245,3 +245,47 @@ def test_full_size_conservation_1e8(dev):
         col_sum = (rho * dz * getattr(got, k).double()).sum(dim=1)
         scale = (rho * dz * getattr(got, k).double().abs()).sum(dim=1) + pr.double().abs()
         assert bool(((col_sum + pr.double()).abs() <= 1e-5 * scale + 1e-30).all()), k
+
+
+# ---- argument validation: the 2-D tensors themselves are checked, before anything touches the GPU ---------------------------
+def test_column_entry_refuses_transposed_and_misshapen_tensors():
+    import cmx
+    ft = "f32"
+    n_col, n_lev = 8, 64
+    cols = _state(n_col, n_lev, ft)
+    mp, tps = P.Microphysics1MParams(ft), P.ThermodynamicsParameters(ft)
+    call = lambda c: cmx.column_tendencies_sedimentation_1m(cmx.Instantaneous(), cmx.Microphysics1Moment(), mp, tps, *_vel_params(ft), _inv_dz(n_lev, ft), *c)  # noqa: E731
+    # a transposed view has the right shape after .T.T only; as (n_lev, n_col).T it is (n_col, n_lev) but NOT contiguous
+    tr = [c.clone() for c in cols]
+    tr[3] = cols[3].t().contiguous().t()
+    assert tr[3].shape == cols[3].shape and not tr[3].is_contiguous()
+    with pytest.raises(ValueError, match="q_lcl must be a contiguous"):
+        call(tr)
+    # same number of elements, other shape
+    bad = [c.clone() for c in cols]
+    bad[5] = cols[5].reshape(n_lev, n_col)
+    with pytest.raises(ValueError, match="q_rai: shape"):
+        call(bad)
+    # a non-row-major rho: the outputs would have inherited its strides (torch.empty_like) while the kernel writes row-major
+    rho_t = [cols[0].t().contiguous().t()] + [c.clone() for c in cols[1:]]
+    with pytest.raises(ValueError, match="rho must be a contiguous"):
+        call(rho_t)
+    with pytest.raises(ValueError, match="shape"):
+        call([c.reshape(-1) for c in cols])
+
+
+@pytest.mark.gpu
+def test_column_entry_refuses_parameter_structs_of_the_other_float_type():
+    import cmx
+    dev = torch.device("cuda:0")
+    ft, other = "f32", "f64"
+    n_col, n_lev = 4, 32
+    cols = [c.to(dev) for c in _state(n_col, n_lev, ft)]
+    mp, tps = P.Microphysics1MParams(ft), P.ThermodynamicsParameters(ft)
+    st, cr, ci = _vel_params(ft)
+    so, co, io = _vel_params(other)
+    for args in ((so, cr, ci), (st, co, ci), (st, cr, io)):
+        with pytest.raises(TypeError, match="struct of the state's float type"):
+            cmx.column_tendencies_sedimentation_1m(cmx.Instantaneous(), cmx.Microphysics1Moment(), mp, tps, *args, _inv_dz(n_lev, ft).to(dev), *cols)
+    ok = cmx.column_tendencies_sedimentation_1m(cmx.Instantaneous(), cmx.Microphysics1Moment(), mp, tps, st, cr, ci, _inv_dz(n_lev, ft).to(dev), *cols)
+    assert all(getattr(ok, k).is_contiguous() and getattr(ok, k).shape == (n_col, n_lev) for k in NAMES)

@@ -10,12 +10,15 @@ from pathlib import Path
 
 import numpy as np
 import pytest
+
+import parity
 import torch
 
 from cmx import _abi
 from cmx import parameters as P
 
 pytestmark = pytest.mark.gpu
+PIN = "oracle restatement of src/P3_processes.jl:527-655 + the ten reference collision KATs (test/p3_tests.jl:823-880)"
 DT = {"f32": torch.float32, "f64": torch.float64}
 G = json.loads((Path(__file__).parent / "golden" / "p3_kats.json").read_text())
 RTOL = {"f64": 1e-6, "f32": 1e-3}
@@ -107,6 +110,9 @@ def test_random_state_parity(dev, oracle, ft, order):
         err[(r == 0) & (x == 0)] = 0
         worst[k] = err.max()
         assert err.max() <= RTOL[ft], (k, int(err.argmax()), x[err.argmax()], r[err.argmax()])
+        parity.record(f"P3 liquid-ice collision integrals {ft} GL{order}", ft, {k: x}, {k: r}, family="P3 collisions (f2)", pinned_by=PIN,
+                      scale=None if k not in ("QCSHD", "QRSHD", "int_wet_M_col") else {k: tot}, wellcond=1e-3 if ft == "f64" else 0.1, assert_wellcond=True,
+                      note="shedding / wet-growth integrals are differences against the total collected mass (operand scale)")
     print(f"\n[P3 collisions] {ft} GL{order}: worst rel err " + " ".join(f"{k}={v:.1e}" for k, v in worst.items()))
     assert (tot > 0).mean() > 0.5 and (orates[9] > 0).any() and (orates[9] == 0).any()
     # bulk sources: compared against the scale of the integrals they are assembled from
@@ -116,6 +122,8 @@ def test_random_state_parity(dev, oracle, ft, order):
         err = np.abs(x - r) / np.maximum(sc[q], 1e-300)
         err[(r == 0) & (x == 0)] = 0
         assert err.max() <= RTOL[ft], (k, int(err.argmax()), x[err.argmax()], r[err.argmax()])
+        parity.record(f"P3 bulk collision sources {ft} GL{order}", ft, {k: x}, {k: r}, family="P3 collisions (f2)", pinned_by=PIN, scale={k: sc[q]},
+                      note="sums of integrals of both signs: operand scale = the integrals they are assembled from")
 
 
 def test_edge_cases_and_validation(dev):
@@ -208,6 +216,9 @@ def test_p3_het_ice_nucleation(dev, oracle, ft):
     for x, r_ in ((_np64(got.dNdt), dN), (_np64(got.dLdt), dL)):
         live = ok & (r_ > (1e-30 if ft == "f32" else 1e-290))
         assert np.all(np.abs(x[live] - r_[live]) <= rt * r_[live]) and np.all(x >= 0)
+    parity.record(f"P3 het_ice_nucleation {ft}", ft, {"dNdt": _np64(got.dNdt), "dLdt": _np64(got.dLdt)}, {"dNdt": dN, "dLdt": dL}, family="P3 processes (f2)",
+                  pinned_by="oracle restatement of src/P3_processes.jl:20-46 + the reference's KATs (test/p3_tests.jl:572-613)", keep=ok,
+                  note="J = 10^(m Δa_w + c): the Float32 rounding of RH − a_w_ice is amplified by m ln 10 ≈ 125")
 
 
 @pytest.mark.parametrize("ft", ["f64", "f32"])
@@ -234,6 +245,8 @@ def test_liquid_freezing_rate(dev, oracle, ft, psd):
         assert np.array_equal(x == 0, r == 0)
         live = (r > (1e-30 if ft == "f32" else 1e-290)) & (r < (1e30 if ft == "f32" else 1e290))
         assert np.all(np.abs(x[live] - r[live]) <= RTOL[ft] * r[live]) and live.mean() > 0.3
+    parity.record(f"liquid_freezing_rate {ft} {psd}", ft, {"dn_frz": _np64(got.dn_frz), "dq_frz": _np64(got.dq_frz)}, {"dn_frz": dn, "dq_frz": dq},
+                  family="P3 processes (f2)", pinned_by="oracle restatement of src/IceNucleation.jl:274-389 + test/gpu_tests.jl:1072-1091", assert_wellcond=True)
     warm = c64[3] >= tps.T_freeze - 4
     assert warm.any() and np.all(_np64(got.dn_frz)[warm] == 0)
 

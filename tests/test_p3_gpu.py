@@ -64,6 +64,11 @@ def _solver_parity(oracle, got, rho_q, rho_n, ft, slope_flags, budget, what):
         e = np.abs(x - r) / np.maximum(np.abs(r), 1.0 if k == "log_N0" else 1e-300)
         rep[k] = float(e.max(initial=0.0))
         assert rep[k] <= RTOL[ft] * 20, (what, k, rep)
+    import parity
+    parity.record("P3 shape " + what, ft, {k: _np64(getattr(got, k)) for k in ("log_lambda", "D_m", "log_N0")}, ref, family="P3 shape solve (a5)",
+                  pinned_by="oracle restatement of src/P3_size_distribution.jl:284-320 (KATs: D_m, thresholds, robustness sweep); iterate-for-iterate at the same Brent budget",
+                  keep=ok, scale={"log_N0": np.ones_like(rl)},
+                  note=f"{int(flipped.sum())} of {int(fin.sum())} states on another Brent path / root are set aside (multi-root band of the residual)")
     return rep, flipped, ref
 
 
@@ -254,6 +259,9 @@ def test_random_state_fall_speed_parity(dev, oracle, ft, rule, aspect):
         e = np.abs(x[nz] - r[nz]) / np.abs(r[nz])
         rep[name] = float(e.max())
         assert rep[name] <= RTOL[ft], (name, rep)
+    import parity
+    parity.record(f"P3 fall speeds {ft} {rule} aspect={aspect}", ft, {"v_n": _np64(v.v_n), "v_m": _np64(v.v_m)}, {"v_n": r_n, "v_m": r_m},
+                  family="P3 fall speeds (a5)", pinned_by="oracle restatement of src/P3_terminal_velocity.jl:72-178 + the reference's KATs to 1e-14", assert_wellcond=True)
     assert (r_n == 0).mean() > 0.005 and np.all(r_n >= 0) and np.all(r_m[r_n > 0] >= r_n[r_n > 0] * 0.5)
     print(f"\n[P3 fall speeds] {ft} {rule} aspect={aspect}: {rep}")
 
@@ -349,6 +357,11 @@ def test_ice_melt(dev, oracle, ft):
         nz = r_ != 0
         e = np.abs(x[nz] - r_[nz]) / np.abs(r_[nz]) / (amp[nz] if ft == "f32" else 1.0)
         assert e.max() <= RTOL[ft], float(e.max())
+    import parity
+    # operand scale of the melt rate: the rate at |T − T_freeze| = |T| (the Float32 rounding of T is the cancelling operand)
+    sc = {k: np.abs(r_) * 273.15 / np.maximum(dT, 1e-30) for k, r_ in (("dNdt", dN), ("dLdt", dL))}
+    parity.record(f"P3 ice melt {ft}", ft, {"dNdt": _np64(got.dNdt), "dLdt": _np64(got.dLdt)}, {"dNdt": dN, "dLdt": dL}, family="P3 processes (f2)",
+                  pinned_by="oracle restatement of src/P3_processes.jl:64-94 + the reference's melting KATs to 1e-9", scale=sc, assert_wellcond=True)
     assert (dL > 0).mean() > 0.3 and (dL == 0).mean() > 0.3
 
 
@@ -382,6 +395,9 @@ def test_ice_self_collection(dev, oracle, ft):
         e = np.abs(x[nz] - ref[nz]) / ref[nz]
         print(f"\n[P3 self-collection] {ft} aspect={aspect}: max rel err {e.max():.2e}")
         assert e.max() <= RTOL[ft] and np.all(x >= 0)
+        import parity
+        parity.record(f"P3 self-collection {ft} aspect={aspect}", ft, {"dNdt": x}, {"dNdt": ref}, family="P3 processes (f2)",
+                      pinned_by="oracle restatement of src/P3_processes.jl:676-712 (the reference tests sign and zero only)", assert_wellcond=True)
 
 
 @pytest.mark.parametrize("ft", ["f32", "f64"])

@@ -123,6 +123,18 @@ def test_device_functions_match_oracle_on_random_columns(dev, oracle, ft):
     got = back(cmx.INP_concentration_frequency(P.Frostenberg2023(ft), to(inpc), to(T3)))
     ref = np.array([oracle.INP_concentration_frequency(F64, P.Frostenberg2023("f64"), float(i), float(t)) for i, t in zip(inpc[:20000], T3[:20000])])
     assert np.all(np.abs(got[:20000] - ref) <= tol * 10 * np.abs(ref) + 1e-30)      # exp(−Δ²/2σ²) with Δ up to 10: the argument's rounding × 50
+    fam = "row g: H2SO4 solution, Mohler-2006, deposition_J, INP frequency"
+    parity.record(f"H2SO4 solution {ft}", ft, {"p_sol": back(p), "a_w_xT": back(a)}, {"p_sol": pr, "a_w_xT": ar}, family=fam,
+                  pinned_by="oracle restatement of src/Common.jl:188-246 + KATs test/gpu_tests.jl:876-893", assert_wellcond=True)
+    parity.record(f"Mohler-2006 deposition {ft}", ft, {"act_frac": back(m.act_frac), "dep_rate": back(m.dep_rate)}, {"act_frac": fr, "dep_rate": rr}, family=fam,
+                  pinned_by="oracle restatement of src/IceNucleation.jl:44-79; warm branch pinned by KATs, cold branch UNPINNED (DESIGN §6)",
+                  scale={"act_frac": 1 + np.abs(np.nan_to_num(fr))}, assert_wellcond=True, note="exp(a ΔS) − 1 cancels for small a ΔS: operand scale 1 + |f|")
+    parity.record(f"deposition_J Feldspar {ft}", ft, {"J": back(cmx.deposition_J(P.DepositionDust(ft, "Feldspar"), to(d)))},
+                  {"J": oracle.deposition_J(F64, P.DepositionDust("f64", "Feldspar"), d)}, family=fam,
+                  pinned_by="oracle restatement of src/IceNucleation.jl:81-102; one KAT per mineral (slope of feldspar / ferrihydrite UNPINNED, DESIGN §6)", assert_wellcond=True)
+    parity.record(f"INP_concentration_frequency {ft}", ft, {"freq": got[:20000]}, {"freq": ref}, family=fam,
+                  pinned_by="oracle restatement of src/IceNucleation.jl:219-226 + KATs test/gpu_tests.jl:1041-1055",
+                  note="exp(−Δ²/2σ²) with Δ up to 10 standard deviations: the Float32 rounding of log INPC is amplified ×50")
 
 
 @pytest.mark.gpu
@@ -154,6 +166,13 @@ def test_ice_nucleation_from_solution_droplets(dev, oracle, ft):
     np.testing.assert_allclose(got.J_hom.cpu().numpy()[ok], ref["J_hom"][ok], rtol=tol_hom)
     np.testing.assert_allclose(got.rate_het.cpu().numpy(), two.rate_het.cpu().numpy(), rtol=tol_het)
     assert cmx.domain_error_count(got) == int((~ok).sum()) == cmx.domain_error_count(two)
+    parity.record(f"ice nucleation from (x, T) {ft}", ft, {k: getattr(got, k).cpu().numpy() for k in ("delta_a_w", "J_het", "rate_het")},
+                  {k: ref[k] for k in ("delta_a_w", "J_het", "rate_het")}, family="ice nucleation (a4)",
+                  pinned_by="oracle restatement (a_w_xT then ABIFM / Koop) + KATs", scale={"delta_a_w": np.ones(n)},
+                  note="J = 10^(m Δa_w + c): a Float32 Δa_w error of 4e-6 is amplified by m ln 10 ≈ 125")
+    parity.record(f"ice nucleation from (x, T) {ft}", ft, {k: getattr(got, k).cpu().numpy() for k in ("J_hom", "rate_hom")},
+                  {k: ref[k] for k in ("J_hom", "rate_hom")}, family="ice nucleation (a4)", pinned_by="oracle restatement (a_w_xT then Koop cubic) + KATs", keep=ok,
+                  note="Koop cubic: the Δa_w error is amplified by ≈ 2e4 Δa_w² ≈ 2000 — outside the plain Float32 bound by construction, asserted at 3e-2")
 
 
 @pytest.mark.gpu

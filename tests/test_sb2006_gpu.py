@@ -336,6 +336,42 @@ def test_column_sums(dev):
         for k, c in enumerate(cols):
             exp = c.double().sum().item()
             assert math.isclose(s[k].item(), exp, rel_tol=1e-9, abs_tol=1e-6 * 10 ** k)
+    with pytest.raises(ValueError):
+        cmx.column_sums([cols[0]] * 17)
+    assert cmx.column_sums([cols[0][:0]]).tolist() == [0.0]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_column_sums_are_deterministic(dev, dt):
+    """cmx_column_sums_*: one launch over all columns + a fixed-tree finish, no floating-point atomics — bit-identical
+    over repeated runs, for the whole column and for each of the 8 shards of cmx.sharding; independent of the workspace's previous content
+    and of how many columns ride in the call; the 8-shard total agrees with the unsharded sum to rounding (the order of additions differs,
+    include/cmx.h §3 says so) and both are far closer to the exact sum than a serial Float64 accumulation."""
+    import cmx
+    from cmx import sharding
+    g = torch.Generator(device=dev).manual_seed(11)
+    n = 10_000_019
+    # wide dynamic range and both signs: an order-dependent reduction shows up in the last bits at once
+    cols = [(torch.randn(n, dtype=torch.float64, device=dev, generator=g) * torch.exp(8 * torch.randn(n, dtype=torch.float64, device=dev, generator=g))).to(dt)
+            for _ in range(16)]
+    ws = torch.full((16 * 1024,), float("nan"), dtype=torch.float64, device=dev)
+    first = cmx.column_sums(cols, workspace=ws)
+    for _ in range(10):
+        ws.random_(0, 1000)                                  # stale workspace content must not matter
+        again = cmx.column_sums(cols, workspace=ws)
+        assert torch.equal(first, again)
+    assert torch.equal(cmx.column_sums(cols[3:5]), first[3:5])           # a column's sum does not depend on its neighbours in the call
+    exact = torch.tensor([math.fsum(c.double().cpu().tolist()) for c in cols[:2]], dtype=torch.float64)
+    scale = torch.stack([c.double().abs().sum() for c in cols]).cpu()
+    assert torch.all((first[:2].cpu() - exact).abs() <= 64 * 2.0 ** -53 * scale[:2])
+    total = torch.zeros(16, dtype=torch.float64, device=dev)
+    for r in range(8):
+        lo, hi = sharding.shard_bounds(n, r, 8)
+        part = cmx.column_sums([c[lo:hi] for c in cols])
+        for _ in range(10):
+            assert torch.equal(part, cmx.column_sums([c[lo:hi] for c in cols]))
+        total += part
+    assert torch.all((total - first).abs().cpu() <= 64 * 2.0 ** -53 * scale)
 
 
 # ---- BASELINE.json full size: 1e8 Float32 points, size-independent properties -----------------------
