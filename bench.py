@@ -7,7 +7,8 @@ configuration BASELINE.json quotes the metric on).  Inputs are generated on the 
 region; nothing crosses PCIe inside it.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--points P] [--dtype f32|f64] [--scaling weak|strong]
-                    [--workload sb2006|sb2006_chen|sb2006_column|sb2006_aos|sb2006_fields|icenuc|mp0m|mp1m|mp1m_lin|mp1m_column|mp1m_column_lin|arg2000|p3|p3_split|p3_selfcol|mp2m_p3]
+                    [--rotate K] [--workload sb2006|sb2006_chen|sb2006_column|sb2006_aos|sb2006_fields|icenuc|mp0m|mp1m|mp1m_lin|mp1m_column|mp1m_column_lin|
+                                             arg2000|arg2000_columns|p3|p3_split|p3_selfcol|mp2m_p3]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -15,6 +16,10 @@ Both forms work for N > 1: called as a plain process with `--gpus N` (no WORLD_S
 script is a launcher — before anything touches torch or the GPU it starts the second form as a child process
 (cmx/launcher.py), relays rank 0's JSON line and exits with the child's code.  `--scaling weak` (default) keeps
 `--points` per GPU; `--scaling strong` splits `--points` over the ranks with cmx.sharding.shard_bounds.
+
+Two timed regions of exactly K steps each, both bracketed by barrier + synchronize: one re-sweeps ONE buffer set (`same_buffer_ms_per_step`),
+one visits `--rotate` disjoint buffer sets round-robin (`rotating_ms_per_step`).  `ms_per_step` / `value` are the same-buffer figures unless the
+rotating region is more than 5 % slower — then they are the rotating ones (`value_uses` says which).
 
 Rank 0 prints ONE JSON line (contract: see the task statement; DESIGN.md §7 explains every field).
 `--workload` selects one of the other hot-path kernels for roofline measurements (same JSON shape); the default,
@@ -46,7 +51,11 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --points per GPU; strong: --points in total, sharded over the ranks (cmx.sharding.shard_bounds)")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--workload", choices=["sb2006", "sb2006_chen", "sb2006_column", "icenuc", "mp0m", "mp1m", "mp1m_lin", "mp1m_column", "mp1m_column_lin", "arg2000", "p3", "p3_split", "p3_selfcol", "mp2m_p3", "sb2006_aos", "sb2006_fields"], default="sb2006")
+    ap.add_argument("--workload", choices=["sb2006", "sb2006_chen", "sb2006_column", "icenuc", "mp0m", "mp1m", "mp1m_lin", "mp1m_column", "mp1m_column_lin", "arg2000", "arg2000_columns", "p3", "p3_split", "p3_selfcol", "mp2m_p3", "sb2006_aos", "sb2006_fields"], default="sb2006")
+    ap.add_argument("--rotate", type=int, default=4,
+                    help="number of DISJOINT input/output buffer sets visited round-robin in the rotating timed region, so that no step re-touches the "
+                         "pages of the previous one (what a model time loop sees: other arrays are touched between two microphysics calls); 1 = off")
+    ap.add_argument("--no-cold-probes", action="store_true", help="skip the idle / fresh-buffer probes that separate clock ramp from TLB effects")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend for N > 1: nccl (= RCCL over xGMI; the measured configuration) or gloo (TEST MODE: ranks may share "
                          "a device — local_rank modulo the device count — so the N > 1 code path can be exercised on a 1-GPU box)")
@@ -110,6 +119,9 @@ def source_digest() -> str:
 # cycles each) — `issue_slots_4cycle` in the same object is the old figure.
 VALU_ISSUE_CYCLES_MIN = 2.4
 VALU_PEAK_GINST = 1024 * 2.4e9 / VALU_ISSUE_CYCLES_MIN / 1e9
+# … and the guide's own figure (MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on the SIMD-32): 1228.8 G/s.  Both fractions
+# are printed (`frac` against the measured 2.4 cycles, `frac_vs_guide` against 2 cycles = 0.83 × frac).
+VALU_PEAK_GINST_GUIDE = 1024 * 2.4e9 / 2.0 / 1e9
 
 
 def pmc_valu(workload: str, dtype: str, n: int):
@@ -461,6 +473,50 @@ def setup_arg2000(args, dev, dtype, rank):
     return list(state), step, desc, cpu_run
 
 
+def setup_arg2000_columns(args, dev, dtype, rank):
+    """ARG2000 with per-element modes — the form the reference's own GPU test runs (aerosol_activation_kernel!, test/gpu_tests.jl:45-79): every
+    mode's (r_dry, σ, N, hygroscopicity) is a device column.  5 modes: 4 state + 5 × 4 mode columns in, 5 N_act columns out."""
+    import torch
+
+    import cmx
+    from cmx import _abi
+    from cmx import parameters as P
+    from cmx import synthetic
+    from cmx.aerosol import ModeColumns
+    state = synthetic.arg_state(args.points, dtype=dtype, device=dev, seed=1234 + rank)
+    ap, aip, tps = P.AerosolActivationParameters(args.dtype), P.AirProperties(args.dtype), P.ThermodynamicsParameters(args.dtype)
+    ad = synthetic.arg_config3_distribution()
+    adc = ad.c_struct(ap, _abi.family(args.dtype))
+    g = torch.Generator(device=dev).manual_seed(99 + rank)
+    modes = []
+    for k in range(adc.n_modes):
+        m = adc.modes[k]
+        jitter = lambda v, rel: (v * (1 + rel * (2 * torch.rand(args.points, generator=g, device=dev, dtype=torch.float64) - 1))).to(dtype)  # noqa: E731
+        modes.append(ModeColumns(jitter(m.r_dry, 0.2), jitter(m.stdev, 0.05), jitter(m.N, 0.5), jitter(m.hygroscopicity, 0.2)))
+    n_act = tuple(torch.empty_like(state.T) for _ in range(adc.n_modes))
+    out = cmx.ActivationResult(n_act, None, None)
+
+    def step():
+        cmx.aerosol_activation_columns(ap, modes, aip, tps, *state, out=out)
+
+    def cpu_run(ob, cols, threads):
+        fam = _abi.family(args.dtype)
+        m = cols[0].size
+        mode_cols = [tuple(getattr(mc, f)[:m].cpu().numpy() for f in ("r_dry", "stdev", "N", "hygroscopicity")) for mc in modes]
+        return lambda: ob.arg2000_activation_columns(fam, ap, aip, tps, *cols, mode_cols, nthreads=threads)
+
+    nm = adc.n_modes
+    desc = {
+        "metric": "states/sec ARG2000 aerosol activation sweep, per-element modes (5 modes)",
+        "bytes_per_point": (4 + 4 * nm + nm) * {"f32": 4, "f64": 8}[args.dtype],      # 4 state + 5 x 4 mode columns in, 5 N_act out
+        "kernel": "arg_activation_columns_kernel",
+        "workload": "AerosolActivation ARG2000 N_activated_per_mode with per-state mode descriptors (r_dry, stdev, N, hygroscopicity per mode and "
+                    "state) — the reference's aerosol_activation_kernel!, test/gpu_tests.jl:45-79",
+        "columns_in": 4 + 4 * nm, "columns_out": nm, "diag_cols": list(n_act),
+    }
+    return list(state), step, desc, cpu_run
+
+
 def setup_p3(args, dev, dtype, rank):
     import cmx
     from cmx import _abi
@@ -616,19 +672,44 @@ def cpu_baseline(args, cols_np, desc, cpu_run):
     sys.path.insert(0, str(REPO / "oracle"))
     import oracle_binding as ob
     cores = desc.get("cpu_threads") or usable_cores()
-    run = cpu_run(ob, cols_np, cores)
-    run()                                          # first pass: page in, spin up the thread team
-    passes, t0 = 0, time.perf_counter()
-    while True:
-        run()
-        passes += 1
-        dt = time.perf_counter() - t0
-        if dt >= args.cpu_seconds or passes >= 1000:
-            break
+
+    def timed(threads, seconds):
+        run = cpu_run(ob, cols_np, threads)
+        run()                                          # first pass: page in, spin up the thread team
+        passes, t0 = 0, time.perf_counter()
+        while True:
+            run()
+            passes += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds or passes >= 1000:
+                return passes, dt
+    # the all-cores figure (the baseline proper) and, beside it, ONE thread on a quarter of the sample (SURVEY 8d / BASELINE.md:60-72)
+    passes, dt = timed(cores, args.cpu_seconds * (0.75 if cores > 1 else 1.0))
     m = cols_np[0].size
+    one = None
+    if cores > 1:
+        full = cols_np
+        cols_np = [c[:max(1, m // 4)] for c in full]
+        p1, dt1 = timed(1, args.cpu_seconds * 0.25)
+        one = {"value": p1 * cols_np[0].size / dt1, "sample": f"{p1} passes over {cols_np[0].size} points, {dt1:.1f} s"}
+        cols_np = full
+    import shutil
     return {"value": passes * m / dt, "unit": "grid-points/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model(), "single_thread": one,
+            # the reference itself (Julia) would be the "reference" kind; this image and the GPU boxes have no Julia runtime:
+            "julia": shutil.which("julia") or "absent",
             "sample": f"{passes} passes over {m} of the same synthetic points ({passes * m} point evaluations), "
                       f"{args.dtype} arithmetic, oracle C restatement ({flags}, {cores} OpenMP thread(s)), {dt:.1f} s"}
+
+
+def cpu_model() -> str:
+    """Model string of the host CPU (/proc/cpuinfo) and the number of logical CPUs the machine has."""
+    try:
+        txt = Path("/proc/cpuinfo").read_text()
+        names = [ln.split(":", 1)[1].strip() for ln in txt.splitlines() if ln.startswith("model name")]
+        return f"{names[0]} ({len(names)} logical CPUs on the machine)" if names else "unknown"
+    except OSError:
+        return "unknown"
 
 
 def load_launcher():
@@ -690,7 +771,7 @@ def main():
         args.points = hi - lo
     # weak scaling: fixed work per GPU; rank r owns shard r of the global [0, world·n) index space.
     # Either way: disjoint seeds, no exchange
-    setup = {"sb2006": setup_sb2006, "sb2006_chen": setup_sb2006, "sb2006_column": setup_sb2006_column, "icenuc": setup_icenuc, "mp0m": setup_mp0m, "mp1m": setup_mp1m, "mp1m_lin": setup_mp1m_lin, "mp1m_column": setup_mp1m_column, "mp1m_column_lin": setup_mp1m_column, "arg2000": setup_arg2000,
+    setup = {"sb2006": setup_sb2006, "sb2006_chen": setup_sb2006, "sb2006_column": setup_sb2006_column, "icenuc": setup_icenuc, "mp0m": setup_mp0m, "mp1m": setup_mp1m, "mp1m_lin": setup_mp1m_lin, "mp1m_column": setup_mp1m_column, "mp1m_column_lin": setup_mp1m_column, "arg2000": setup_arg2000, "arg2000_columns": setup_arg2000_columns,
              "p3": setup_p3, "p3_split": setup_p3, "p3_selfcol": setup_p3_selfcol, "mp2m_p3": setup_mp2m_p3, "sb2006_aos": setup_sb2006_layout, "sb2006_fields": setup_sb2006_layout}[args.workload]
     if dry:
         state, kernel_step, cpu_run = [], (lambda: None), None
@@ -699,11 +780,21 @@ def main():
     else:
         state, kernel_step, desc, cpu_run = setup(args, dev, dtype, rank)
     n = args.points                                          # a layout workload may round the size to whole field runs
+    # --rotate K: K − 1 further DISJOINT buffer sets (inputs from other seeds, their own outputs) for the rotating timed region
+    rotate = 1 if dry else max(1, args.rotate)
+    sets = [(kernel_step, desc)]
+    for k in range(1, rotate):
+        _, ks, dk, _ = setup(args, dev, dtype, rank + 1000 * k)
+        sets.append((ks, dk))
 
-    def step():
-        kernel_step()
-        if args.diagnostics:
-            sharding.global_diagnostics(desc["diag_cols"])
+    def make_step(ks, dk):
+        def f():
+            ks()
+            if args.diagnostics:
+                sharding.global_diagnostics(dk["diag_cols"])
+        return f
+    steps = [make_step(ks, dk) for ks, dk in sets]
+    step = steps[0]
 
     def fence():
         if use_dist:
@@ -737,32 +828,80 @@ def main():
                               "shard_bounds": [[int(lo_hi[2 * r]), int(lo_hi[2 * r + 1])] for r in range(world)] if args.scaling == "strong" else None}),
                   flush=True)
         return
-    cold = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
-    for a, b in cold:
-        a.record()
-        step()
-        b.record()
-    for _ in range(max(0, args.settle - 5) + args.warmup):
-        step()
-    fence()
-    cold_ms = sum(a.elapsed_time(b) for a, b in cold) / len(cold)
-    # per-launch kernel duration from HIP events recorded on the stream the kernel is launched on
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for a, b in ev:
-        a.record()
-        step()
-        b.record()
-    fence()
-    elapsed = time.perf_counter() - t0
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    def timed_each(fn_of_i, count):
+        """`count` launches timed one by one with HIP events on the launch stream; returns the list of ms."""
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(count)]
+        for i, (a, b) in enumerate(evs):
+            a.record()
+            fn_of_i(i)()
+            b.record()
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in evs]
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    def timed_region(fn_of_i):
+        """EXACTLY args.steps steps bracketed by barrier + synchronize on both sides: (wall seconds, mean HIP-event ms per step)."""
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        fence()
+        t0 = time.perf_counter()
+        for i, (a, b) in enumerate(evs):
+            a.record()
+            fn_of_i(i)()
+            b.record()
+        fence()
+        wall = time.perf_counter() - t0
+        return wall, sum(a.elapsed_time(b) for a, b in evs) / max(1, args.steps)
+
+    # the first five launches of the process on set 0, timed one by one (clocks not settled, code object and TLBs cold)
+    cold_first5 = timed_each(lambda i: step, 5)
+    cold_ms = sum(cold_first5) / len(cold_first5)
+    # first visit of every other buffer set, clocks still ramping
+    first_visit_ms = [timed_each(lambda i, k=k: steps[k], 1)[0] for k in range(1, rotate)]
+    for i in range(max(0, args.settle - 5) + args.warmup):
+        steps[i % rotate]()
+    fence()
+    # region A: the same buffer set re-swept (rounds 1-3's figure)
+    same_wall, same_kern_ms = timed_region(lambda i: step)
+    # region B: round-robin over the disjoint buffer sets — no step touches the pages of the previous one
+    if rotate > 1:
+        rot_wall, rot_kern_ms = timed_region(lambda i: steps[i % rotate])
+    else:
+        rot_wall, rot_kern_ms = same_wall, same_kern_ms
+
+    # cold probes (VERDICT r03 item 2): what makes the first launches slow — the clock ramp or the address translation of untouched pages?
+    probes = None
+    if not args.no_cold_probes and world == 1:
+        probes = {}
+        time.sleep(1.0)                                                 # (1) SAME buffers after one second of idle: clocks dropped, TLB reach unchanged
+        probes["after_1s_idle_same_buffers_ms"] = timed_each(lambda i: step, 5)
+        for _ in range(20):                                             # clocks back up
+            step()
+        torch.cuda.synchronize()
+        _, fresh_step, fresh_desc, _ = setup(args, dev, dtype, rank + 7777)     # (2) FRESH buffers right after a busy period (the generator kernels
+        probes["fresh_buffers_warm_clocks_ms"] = timed_each(lambda i: fresh_step, 5)   #     keep the clocks up); first touch of their output pages
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        probes["steady_same_buffers_ms"] = timed_each(lambda i: step, 5)       # (3) control: the same five-launch probe in the steady state
+        del fresh_step, fresh_desc
+        torch.cuda.empty_cache()
+
+    use_rot = rotate > 1 and rot_wall > 1.05 * same_wall
+    elapsed = rot_wall if use_rot else same_wall
+    kern_ms = rot_kern_ms if use_rot else same_kern_ms
+    # max over ranks of BOTH regions; the decision which one `value` uses is taken on the maxima, identically on every rank
+    t = torch.tensor([same_wall, rot_wall], dtype=torch.float64, device=red_dev)
     tot = torch.tensor([float(n)], dtype=torch.float64, device=red_dev)
+    per_rank = torch.zeros(2 * world, dtype=torch.float64, device=red_dev)     # every rank's kernel ms (same-buffer, rotating): a slow rank is visible
+    per_rank[2 * rank], per_rank[2 * rank + 1] = same_kern_ms, rot_kern_ms
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)     # the points all ranks processed per step (layout workloads round per rank)
-    elapsed = float(t.item())
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+    same_wall, rot_wall = float(t[0].item()), float(t[1].item())
+    use_rot = rotate > 1 and rot_wall > 1.05 * same_wall
+    elapsed = rot_wall if use_rot else same_wall
+    kern_ms = rot_kern_ms if use_rot else same_kern_ms
+    ranks_kernel_ms = [[float(per_rank[2 * r]), float(per_rank[2 * r + 1])] for r in range(world)]
 
     if rank == 0:
         total_points = int(tot.item())
@@ -784,6 +923,15 @@ def main():
             "roofline": None,
         }
         line["cold_ms_first5"] = cold_ms      # mean kernel time of the first five launches (HIP events), before the settle launches
+        line["rotate"] = rotate
+        line["same_buffer_ms_per_step"] = same_wall / args.steps * 1e3
+        line["rotating_ms_per_step"] = rot_wall / args.steps * 1e3 if rotate > 1 else None
+        line["value_uses"] = "rotating" if use_rot else "same_buffer"        # rotating iff it is more than 5 % slower than the same-buffer region
+        line["ranks_kernel_ms"] = {"same_buffer": [r[0] for r in ranks_kernel_ms], "rotating": [r[1] for r in ranks_kernel_ms] if rotate > 1 else None}
+        line["timed_region_ms"] = elapsed * 1e3
+        if elapsed < 20e-3:
+            line["short_timed_region"] = f"the timed region is {elapsed * 1e3:.2f} ms (< 20 ms): one barrier skew of 50-100 µs moves `value` by several per mille to per cent"
+        line["cold"] = {"first5_ms": cold_first5, "first_visit_other_sets_ms": first_visit_ms, "probes": probes}
         hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                "traffic_source": (traffic_source + " (rocprofv3 PMC pass of this command on an earlier run; not measured in this run)")
                                  if traffic_source else None,
@@ -793,23 +941,25 @@ def main():
         if insts is not None:
             rate = insts / (kern_ms * 1e-3) / 1e9
             valu = {"bound": "valu", "achieved": rate, "peak": VALU_PEAK_GINST, "unit": "G wave64-VALU-instructions/s", "frac": rate / VALU_PEAK_GINST,
+                    "frac_vs_guide": rate / VALU_PEAK_GINST_GUIDE, "peak_guide": VALU_PEAK_GINST_GUIDE,
                     "traffic": None, "insts_per_point": insts * 64 / n, "insts_source": insts_source + " (SQ_INSTS_VALU of a rocprofv3 PMC pass of this "
                     "command; a property of the code and the inputs, not of the box)", "kernel": desc["kernel"], "kernel_ms": kern_ms,
                     "issue_slots_4cycle": rate / (1024 * 2.4 / 4),
                     "peak_formula": "256 CUs x 4 SIMDs x 2.4 GHz / 2.4 cycles: the fastest measured issue rate of a wave64 VALU instruction "
-                                    "(profiles/rNN_probe_valu.txt); Float64 instructions take >= 4.2 cycles, so a Float64 kernel tops out near 0.55; "
+                                    "(profiles/rNN_probe_valu.txt); frac_vs_guide = the same count against the guide's 2-cycle issue of a wave64 instruction "
+                                    "on the SIMD-32 (MI355X_MICROARCH.md: 1228.8 G/s); Float64 instructions take >= 4.2 cycles, so a Float64 kernel tops out near 0.55; "
                                     "issue_slots_4cycle = the same count against one instruction per 4 cycles (round 2's definition, > 1 for Float32)"}
         if desc.get("bound") == "valu" and valu is not None:
             # compute-bound line: the VALU-issue fraction is the roofline, the HBM fraction a secondary field
             line["roofline"] = dict(valu, hbm={k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "traffic", "traffic_source", "bytes_per_point")})
         else:
-            line["roofline"] = dict(hbm, valu=({k: valu[k] for k in ("achieved", "peak", "unit", "frac", "issue_slots_4cycle", "insts_per_point", "insts_source")} if valu else None))
+            line["roofline"] = dict(hbm, valu=({k: valu[k] for k in ("achieved", "peak", "unit", "frac", "frac_vs_guide", "peak_guide", "issue_slots_4cycle", "insts_per_point", "insts_source")} if valu else None))
             if desc.get("bound") == "valu":
                 line["roofline"]["note"] = "compute-bound workload, but no committed PMC instruction count matches this size: HBM fraction shown"
         if "note" in desc:
             line["roofline"]["note"] = desc["note"]
         if not args.no_cpu_baseline and world == 1:
-            m = min(n, {"sb2006": 20_000_000, "sb2006_chen": 20_000_000, "sb2006_column": 74 * 270_000, "mp1m_column": 74 * 54_000, "mp1m_column_lin": 74 * 27_000, "sb2006_aos": 20_000_000, "sb2006_fields": 20_000_000, "p3": 100_000, "p3_split": 100_000, "p3_selfcol": 2_000, "mp2m_p3": 20_000}.get(args.workload, 4_000_000))
+            m = min(n, {"sb2006": 20_000_000, "arg2000_columns": 2_000_000, "sb2006_chen": 20_000_000, "sb2006_column": 74 * 270_000, "mp1m_column": 74 * 54_000, "mp1m_column_lin": 74 * 27_000, "sb2006_aos": 20_000_000, "sb2006_fields": 20_000_000, "p3": 100_000, "p3_split": 100_000, "p3_selfcol": 2_000, "mp2m_p3": 20_000}.get(args.workload, 4_000_000))
             cols_np = [np.ascontiguousarray(c[:m].cpu().numpy()) for c in state]
             line["cpu_baseline"] = cpu_baseline(args, cols_np, desc, cpu_run)
         print(json.dumps(line), flush=True)

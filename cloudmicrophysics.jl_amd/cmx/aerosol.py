@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 from collections import namedtuple
-from typing import Sequence
+from typing import Optional, Sequence
 
 import torch
 
@@ -143,7 +143,7 @@ tensors too) and, if M_act is wanted, molar_mass_mix = Σ w_j M_j."""
 
 
 def aerosol_activation_columns(ap, modes: Sequence[ModeColumns], aip, tps, T, p, w, q_tot, q_liq=None, q_ice=None, N_liq=None,
-                               N_ice=None, *, want=("N_act",), stream=None) -> ActivationResult:
+                               N_ice=None, *, want=("N_act",), out: Optional[ActivationResult] = None, stream=None) -> ActivationResult:
     """ARG2000 activation when the aerosol itself varies in space — the reference's own KA kernel builds one
     `AerosolDistribution` per element from columns (aerosol_activation_kernel!, test/gpu_tests.jl:45-79).  Same
     outputs as `aerosol_activation`."""
@@ -168,9 +168,18 @@ def aerosol_activation_columns(ap, modes: Sequence[ModeColumns], aip, tps, T, p,
     have_mm = all(m.molar_mass_mix is not None for m in modes)
     if "M_act" in want and not have_mm:
         raise ValueError("M_act needs molar_mass_mix for every mode")
-    n_act = tuple(torch.empty_like(ref) for _ in range(nm)) if "N_act" in want else None
-    m_act = tuple(torch.empty_like(ref) for _ in range(nm)) if "M_act" in want else None
-    s_max = torch.empty_like(ref) if "S_max" in want else None
+    if out is not None:          # caller-provided output columns (KA-kernel style): no allocation in a time loop
+        n_act, m_act, s_max = out.N_act, out.M_act, out.S_max
+        given = [c for grp in (n_act, m_act) if grp is not None for c in grp] + ([s_max] if s_max is not None else [])
+        if (n_act is not None and len(n_act) != nm) or (m_act is not None and len(m_act) != nm):
+            raise ValueError("out: one column per mode")
+        if m_act is not None and not have_mm:
+            raise ValueError("M_act needs molar_mass_mix for every mode")
+        _check_cols([ref] + given, ["T"] + ["out"] * len(given))
+    else:
+        n_act = tuple(torch.empty_like(ref) for _ in range(nm)) if "N_act" in want else None
+        m_act = tuple(torch.empty_like(ref) for _ in range(nm)) if "M_act" in want else None
+        s_max = torch.empty_like(ref) if "S_max" in want else None
     arr = lambda cols_: (C.c_void_p * nm)(*[c.data_ptr() for c in cols_]) if cols_ is not None else None  # noqa: E731
     s = stream if stream is not None else torch.cuda.current_stream(ref.device)
     fn = getattr(_lib.lib(), f"cmx_arg2000_activation_columns_{fam.sfx}")

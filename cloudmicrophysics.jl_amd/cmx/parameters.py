@@ -251,6 +251,35 @@ SB2006_LIMITERS_OVERRIDE = {
 }
 
 
+class UnpinnedParameterWarning(UserWarning):
+    """A default value that NO number held by the reference pins (its ClimaParams source is not in the reference tree): results computed
+    with it are "parity unpinned" (DESIGN.md §6).  Pass the value explicitly (`create_toml_dict(FT, override={…})`) to silence it."""
+
+
+# names → what is (not) known about them.  Every constructor that reads one of these from the DEFAULTS warns and tags the struct it returns
+# with `.unpinned` (ADVICE r03: unpinned values must not pass silently as reference defaults).
+UNPINNED_DEFAULTS = {
+    "Mohler2006_maximum_allowed_Si": "only 1.34 < S_i,max <= 1.5 follows from test/heterogeneous_ice_nucleation_tests.jl:39-90",
+    "Mohler2006_threshold_T": "only 210 K < T_thr < 250 K follows from the reference's tests",
+    "Mohler2006_S0_cold_DesertDust": "cold branch: no reference number", "Mohler2006_a_cold_DesertDust": "cold branch: no reference number",
+    "Mohler2006_S0_cold_ArizonaTestDust": "cold branch: no reference number", "Mohler2006_a_cold_ArizonaTestDust": "cold branch: no reference number",
+    "Alpert2022_J_deposition_m_Feldspar": "slope digitised from a figure script; one KAT pins the intercept given the slope",
+    "Alpert2022_J_deposition_c_Feldspar": "back-solved from one KAT with the digitised slope",
+    "Alpert2022_J_deposition_m_Ferrihydrite": "slope digitised from a figure script; one KAT pins the intercept given the slope",
+    "Alpert2022_J_deposition_c_Ferrihydrite": "back-solved from one KAT with the digitised slope",
+}
+
+
+def _tag_unpinned(struct, td, names):
+    """Warn about — and record on the returned struct — the unpinned defaults among `names` that the caller did not override."""
+    import warnings
+    used = tuple(n for n in names if n in UNPINNED_DEFAULTS and n not in td.overridden)
+    struct.unpinned = used
+    if used:
+        warnings.warn("parity-unpinned default(s) in use: " + "; ".join(f"{n} ({UNPINNED_DEFAULTS[n]})" for n in used), UnpinnedParameterWarning, stacklevel=3)
+    return struct
+
+
 class ParamDict(dict):
     """`CP.create_toml_dict(FT; override_file)` analogue: defaults + overrides, typed by FT."""
 
@@ -261,6 +290,7 @@ class ParamDict(dict):
             if unknown:
                 raise KeyError(f"unknown parameter name(s): {sorted(unknown)}")
             self.update(override)
+        self.overridden = frozenset(override or ())
         self.fam = _abi.family(FT)
         self.FT = self.fam.sfx
 
@@ -475,13 +505,15 @@ def Illite(FT):
 def Mohler2006(FT):
     """CMP.Mohler2006 — src/parameters/IceNucleation.jl:13-28 (values: see DEFAULT_PARAMETERS — parity unpinned)."""
     td = _td(FT)
-    return td.fam.mohler2006(S_i_max=td["Mohler2006_maximum_allowed_Si"], T_thr=td["Mohler2006_threshold_T"])
+    return _tag_unpinned(td.fam.mohler2006(S_i_max=td["Mohler2006_maximum_allowed_Si"], T_thr=td["Mohler2006_threshold_T"]), td,
+                         ("Mohler2006_maximum_allowed_Si", "Mohler2006_threshold_T"))
 
 
 def _mohler_dust(FT, name):
     td = _td(FT)
-    return td.fam.mohler_dust(S0_warm=td[f"Mohler2006_S0_warm_{name}"], S0_cold=td[f"Mohler2006_S0_cold_{name}"],
-                              a_warm=td[f"Mohler2006_a_warm_{name}"], a_cold=td[f"Mohler2006_a_cold_{name}"])
+    return _tag_unpinned(td.fam.mohler_dust(S0_warm=td[f"Mohler2006_S0_warm_{name}"], S0_cold=td[f"Mohler2006_S0_cold_{name}"],
+                                            a_warm=td[f"Mohler2006_a_warm_{name}"], a_cold=td[f"Mohler2006_a_cold_{name}"]), td,
+                         (f"Mohler2006_S0_cold_{name}", f"Mohler2006_a_cold_{name}"))
 
 
 def DesertDust(FT):
@@ -499,7 +531,8 @@ def DepositionDust(FT, mineral: str):
     AerosolFerrihydrite.jl) for CMI_het.deposition_J."""
     td = _td(FT)
     src = {"Kaolinite": "China2017", "Feldspar": "Alpert2022", "Ferrihydrite": "Alpert2022"}[mineral]
-    return td.fam.deposition_dust(deposition_m=td[f"{src}_J_deposition_m_{mineral}"], deposition_c=td[f"{src}_J_deposition_c_{mineral}"])
+    return _tag_unpinned(td.fam.deposition_dust(deposition_m=td[f"{src}_J_deposition_m_{mineral}"], deposition_c=td[f"{src}_J_deposition_c_{mineral}"]), td,
+                         (f"{src}_J_deposition_m_{mineral}", f"{src}_J_deposition_c_{mineral}"))
 
 
 def H2SO4SolutionParameters(FT):

@@ -75,6 +75,17 @@ typedef enum cmx_status {
     CMX_ERR_UNSUPPORTED = -3  /* valid request this build has no kernel for */
 } cmx_status;
 
+/* ---- domain of the Chen-2022 RAIN fall speeds (every entry that takes a cmx_chen2022_rain_vel_* table: cmx_sb2006_warm_rain_tendencies_*,
+ * cmx_sb2006_process_rates_*, cmx_sb2006_column_tendencies_sedimentation_* with CMX_VEL_CHEN2022; cmx_mp1m_terminal_velocity_*,
+ * cmx_sedimentation_velocities_*, cmx_mp1m_column_tendencies_sedimentation_*; the vel_rain member of cmx_p3_ice_params_*) ---------------
+ * The table's exponents depend on the state only through the air density, b_i(ρ) = b_i − b_ρ ρ (src/Common.jl:290-302), and the reference
+ * evaluates Γ(b_i(ρ) + 1) with SpecialFunctions at any ρ.  The library fits those Γ per parameter set on 0 ≤ ρ ≤ 2 kg/m³ (csrc/cmx_math.hpp
+ * make_chen_gamma; the fit is checked against tgamma on the host and a table it cannot represent takes a general-Γ instantiation, valid
+ * for every ρ).  With a fitted table, a point with ρ > 2 kg/m³ gets NaN rain fall speeds — and, in the column entries, NaN sedimentation
+ * tendencies of that cell and the cell below — rather than an extrapolated value.  ρ ≤ 2 kg/m³ covers every terrestrial state
+ * (ρ = 1.4 kg/m³ at 1050 hPa and 260 K); callers with denser gases must not use the Chen-2022 rain table.  The SB2006 fall speeds
+ * (CMX_VEL_SB2006) and the Chen-2022 ICE tables have no such restriction. */
+
 /* ---- flags for the SB2006 entry points ------------------------------------ */
 /* rain PSD with the SB2006 Eq. 94-97 limiters (RainParticlePDF_SB2006_limited,
  * src/parameters/Microphysics2M.jl:314-335) vs. without (…_notlimited, :362-375) */

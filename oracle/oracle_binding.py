@@ -326,8 +326,11 @@ def arg2000_activation_columns(fam, ap, aip, tps, T, p, w, q_tot, modes, *, want
     th = thresholds(fam, float32_gates)
     req = [_col(fam, a) for a in (T, p, w, q_tot)]
     n, nm = req[0][0].size, len(modes)
-    mc = [[_col(fam, m[j]) for m in modes] for j in range(5)]
-    arr = lambda cols: (C.c_void_p * nm)(*[c[0].ctypes.data for c in cols])  # noqa: E731
+    have_mm = all(len(m) > 4 and m[4] is not None for m in modes)
+    if want_M and not have_mm:
+        raise ValueError("M_act needs molar_mass_mix for every mode")
+    mc = [[_col(fam, m[j]) for m in modes] for j in range(5 if have_mm else 4)] + ([] if have_mm else [None])
+    arr = lambda cols: (C.c_void_p * nm)(*[c[0].ctypes.data for c in cols]) if cols is not None else None  # noqa: E731
     n_act = [np.empty(n, dtype=NP[fam.sfx]) for _ in range(nm)]
     m_act = [np.empty(n, dtype=NP[fam.sfx]) for _ in range(nm)] if want_M else None
     s_max = np.empty(n, dtype=NP[fam.sfx])

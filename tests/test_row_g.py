@@ -207,3 +207,21 @@ def test_rain_evaporation_derivatives_and_activation_totals(dev, oracle, ft):
     assert torch.equal(N_tot, n_sum) and torch.equal(M_tot, m_sum)
     only_n = cmx.total_activated(ap, ad, aip, tps, *a, want=("N",))
     assert only_n[1] is None and torch.equal(only_n[0], N_tot)
+
+
+def test_unpinned_defaults_do_not_pass_silently():
+    """the Mohler-2006 cold branch, T_thr, S_i,max and the feldspar / ferrihydrite deposition coefficients are pinned by no
+    reference number — the constructors warn, tag the struct, and stay quiet once the caller supplies the values."""
+    import warnings
+    with pytest.warns(P.UnpinnedParameterWarning, match="Mohler2006_S0_cold_DesertDust"):
+        d = P.DesertDust("f64")
+    assert d.unpinned == ("Mohler2006_S0_cold_DesertDust", "Mohler2006_a_cold_DesertDust")
+    with pytest.warns(P.UnpinnedParameterWarning, match="Mohler2006_threshold_T"):
+        P.Mohler2006("f32")
+    with pytest.warns(P.UnpinnedParameterWarning, match="digitised"):
+        P.DepositionDust("f64", "Feldspar")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert P.DepositionDust("f64", "Kaolinite").unpinned == ()          # pinned to all printed digits by the reference's KAT
+        td = P.create_toml_dict("f64", {"Mohler2006_S0_cold_DesertDust": 1.05, "Mohler2006_a_cold_DesertDust": 2.35})
+        assert P.DesertDust(td).unpinned == ()
