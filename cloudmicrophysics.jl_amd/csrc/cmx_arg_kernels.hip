@@ -164,12 +164,17 @@ template <typename FT> struct ArgIO {
 
 template <typename FT, int NM> struct ArgOut { FT smax; FT n[NM]; FT m[NM]; };
 
-// one thermodynamic state.  NM = compile-time mode count (1…8)
-template <typename FT, int NM, bool SINKS>
-__device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, const ArgModeConsts<FT> *__restrict__ cm, FT T, FT p, FT w,
-                                                    FT q_tot, FT q_liq, FT q_ice, FT N_liq, FT N_ice, bool want_N, bool want_M) {
+// ---- one thermodynamic state, in three stages shared by the two kernels: arg_pre (everything in front of the sum over the modes),
+// the mode sum (kernel-specific: host-folded mode constants, or mode descriptors streamed from columns), arg_smax (S_max from the sum).
+template <typename FT> struct ArgPre {
+    FT T, p, inv_T, R_m, L_v, inv_cp, rho_air, l2_TT, dinvT, l2_pvs, inv_pvs, inv_G_liq, ratio, gamma, aw;
+    FT l2_A15, zeta, X, E_f, E_g;
+};
+template <typename FT>
+__device__ __forceinline__ ArgPre<FT> arg_pre(const ArgConsts<FT> &c, FT T, FT p, FT w, FT q_tot, FT q_liq, FT q_ice) {
     using M = Math<FT>;
-    ArgOut<FT, NM> o;
+    ArgPre<FT> s;
+    s.T = T; s.p = p;
     const FT inv_T = M::rcp_nz(T);                  // temperature, pressure, R_m, cp_m: positive and finite
     // TD.gas_constant_air, cp_m, latent heat, air density, vapour pressures — AA:152-160
     const FT R_m = c.R_d * (FT(1) + (c.Rv_over_Rd - FT(1)) * q_tot - c.Rv_over_Rd * (q_liq + q_ice));
@@ -196,59 +201,74 @@ __device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, cons
     const FT l2_A = c.l2_Ac_Ttr - l2_TT;
     const FT l2_A15 = FT(1.5) * l2_A;
     const FT l2_zeta = c.l2_two_thirds + l2_A + FT(0.5) * l2_awG;
-    const FT zeta = M::exp2_fin(l2_zeta);                    // w > 0: finite; w ≤ 0: the reference gives NaN (ζ/η = 0/0, √ of a negative)
+    s.zeta = M::exp2_fin(l2_zeta);                    // w > 0: finite; w ≤ 0: the reference gives NaN (ζ/η = 0/0, √ of a negative)
     const FT l2_X = M::fma(FT(1.5), l2_awG, -(c.l2_two_pi_rho_w + M::log2(gamma)));
-    const FT X = M::exp2_fin(l2_X);
+    s.X = M::exp2_fin(l2_X);
     // Σ_i (1/Sm_i²)·[f_i (ζ/η_i)^p1 + g_i (Sm_i²/(η_i+3ζ))^p2] — AA:170-183.  Everything that depends only on the mode is
-    // folded on the host (ArgModeConsts); per state three shared powers, per mode one log2 + one exp2.
+    // folded on the host (ArgModeConsts) or per state from the mode columns; per state three shared powers.
     // the two state-only factors of the sum, one exponential each: A⁻³ (ζ/X)^p1 and A^(3 p2 − 3)
-    const FT E_f = M::exp2_fin(M::fma(c.p1, l2_zeta - l2_X, FT(-2) * l2_A15));
-    const FT E_g = M::exp2_fin((FT(2) * c.p2 - FT(2)) * l2_A15);
+    s.E_f = M::exp2_fin(M::fma(c.p1, l2_zeta - l2_X, FT(-2) * l2_A15));
+    s.E_g = M::exp2_fin((FT(2) * c.p2 - FT(2)) * l2_A15);
+    s.inv_T = inv_T; s.R_m = R_m; s.L_v = L_v; s.inv_cp = inv_cp; s.rho_air = rho_air; s.l2_TT = l2_TT; s.dinvT = dinvT; s.l2_pvs = l2_pvs;
+    s.inv_pvs = inv_pvs; s.inv_G_liq = inv_G_liq; s.ratio = ratio; s.gamma = gamma; s.aw = aw; s.l2_A15 = l2_A15;
+    return s;
+}
+// (η + 3ζ)^(−p2) of one mode
+template <typename FT> __device__ __forceinline__ FT arg_pow_p2(const ArgConsts<FT> &c, FT y, bool p2_is_34) {
+    using M = Math<FT>;
+    if constexpr (sizeof(FT) == 8) {
+        // Float64 with ARG2000's own exponent p2 = ¾ (a wave-uniform test): y^(−¾) = t·√t with t = 1/√y — a reciprocal square root and
+        // a square root (hardware seed + Newton steps, ≈ 30 instructions) instead of a table-driven log2 and exp2 (≈ 45) per mode.
+        // 3ζ + η_k > 0 for w > 0; w = 0 gives ζ/η = 0/0 = NaN in the reference as well, so no 0 / Inf cases to keep
+        if (p2_is_34) return arg_pow_m34(y);
+    }
+    return M::exp2(-c.p2 * M::log2(y));
+}
+template <typename FT, bool SINKS>
+__device__ __forceinline__ FT arg_smax(const ArgConsts<FT> &c, const ArgPre<FT> &s, FT sum1, FT sum2, FT q_liq, FT q_ice, FT N_liq, FT N_ice) {
+    using M = Math<FT>;
+    const FT T = s.T, p = s.p, inv_T = s.inv_T;
+    const FT tmp = M::fma(s.E_g, sum2, s.E_f * sum1);
+    const FT S_arg = M::rsqrt_pos(tmp);                                                                       // AA:185
+    FT smax;
+    if constexpr (SINKS) {   // liquid / ice sink correction — AA:187-197
+        const FT L_s = M::fma(c.dcp_i, T - c.T_0, c.LH_s0);
+        const FT l2_pvi = M::fma(c.psi_a, s.l2_TT, M::fma(c.psi_b, s.dinvT, c.ps_c0));
+        const FT p_vi = M::exp2(l2_pvi), p_vs = M::exp2(s.l2_pvs);
+        const FT G = M::rcp(s.inv_G_liq) * c.inv_rho_w;
+        const FT r_liq = N_liq < c.eps_ft ? FT(0) : M::exp2(M::log2(s.rho_air * q_liq * M::rcp(N_liq) * c.inv_43pi_rho_w) * FT(1.0 / 3.0));
+        const FT K_liq = c.four_pi * c.rho_w * N_liq * r_liq * G * s.gamma;
+        const FT gamma_i = M::fma(s.ratio * s.R_m * s.L_v, L_s * c.inv_R_v * s.inv_cp * inv_T * M::rcp(p), c.R_v * T * s.inv_pvs);
+        const FT r_ice = N_ice < c.eps_ft ? FT(0) : M::exp2(M::log2(s.rho_air * q_ice * M::rcp(N_ice) * c.inv_43pi_rho_i) * FT(1.0 / 3.0));
+        const FT LoRT_s = L_s * c.inv_R_v * inv_T;
+        const FT G_ice = M::rcp(M::fma(L_s * c.inv_K * inv_T, LoRT_s - FT(1), c.Rv_over_D * T * M::rcp(M::max(p_vi, c.eps_1m))));
+        const FT xi = p_vs * M::rcp(p_vi);
+        const FT K_ice = c.four_pi * N_ice * r_ice * G_ice * gamma_i;
+        smax = S_arg * (s.aw - K_ice * (xi - FT(1))) * M::rcp(M::fma(M::fma(K_ice, xi, K_liq), S_arg, s.aw));
+    } else {
+        smax = S_arg;   // N_liq = N_ice = 0: K_liq = K_ice = 0 ⇒ S_max = S_max_ARG·αw/αw
+    }
+    return smax < FT(0) ? FT(0) : smax;   // AA:199 max(0, S_max) with Julia's NaN rule: a NaN from any input reaches every output below
+}
+
+// one thermodynamic state of the shared-distribution kernel.  NM = compile-time mode count (1…8)
+template <typename FT, int NM, bool SINKS>
+__device__ __forceinline__ ArgOut<FT, NM> arg_point(const ArgConsts<FT> &c, const ArgModeConsts<FT> *__restrict__ cm, FT T, FT p, FT w,
+                                                    FT q_tot, FT q_liq, FT q_ice, FT N_liq, FT N_ice, bool want_N, bool want_M) {
+    using M = Math<FT>;
+    ArgOut<FT, NM> o;
+    const ArgPre<FT> s = arg_pre<FT>(c, T, p, w, q_tot, q_liq, q_ice);
     // with the mode-only factors c1_i, c2_i the sum is  A⁻³ (ζ/X)^p1 Σ c1_i + A^(3p2 − 3) Σ c2_i (η_i + 3ζ)^(−p2): per mode one
     // multiply, one FMA, one log2, one exp2 and one accumulating FMA
     FT sum1 = FT(0), sum2 = FT(0);
 #pragma unroll
     for (int k = 0; k < NM; ++k) sum1 += cm[k].c1;
-    if (sizeof(FT) == 8 && CMX_ARG_P2_ROOTS && c.p2 == FT(0.75)) {
-        // Float64 with ARG2000's own exponent p2 = ¾ (a wave-uniform test): y^(−¾) = t·√t with t = 1/√y — a reciprocal square root and
-        // a square root (hardware seed + Newton steps, ≈ 30 instructions) instead of a table-driven log2 and exp2 (≈ 45) per mode
+    const bool p2_34 = sizeof(FT) == 8 && CMX_ARG_P2_ROOTS && c.p2 == FT(0.75);
 #pragma unroll
-        for (int k = 0; k < NM; ++k) {
-            // 3ζ + η_k > 0 for w > 0; w = 0 gives ζ/η = 0/0 = NaN in the reference as well (Z1 below), so no 0 / Inf cases to keep
-            const FT y = M::fma(FT(3), zeta, X * cm[k].inv_N);
-            if constexpr (sizeof(FT) == 8) sum2 = M::fma(cm[k].c2, arg_pow_m34(y), sum2);
-            else { const FT t = M::rsqrt(y); sum2 = M::fma(cm[k].c2, t * M::sqrt(t), sum2); }
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < NM; ++k) {
-            const FT eta = X * cm[k].inv_N;
-            sum2 = M::fma(cm[k].c2, M::exp2(-c.p2 * M::log2(M::fma(FT(3), zeta, eta))), sum2);
-        }
-    }
-    const FT tmp = M::fma(E_g, sum2, E_f * sum1);
-    const FT S_arg = M::rsqrt_pos(tmp);                                                                       // AA:185
-    FT smax;
-    if constexpr (SINKS) {   // liquid / ice sink correction — AA:187-197
-        const FT L_s = M::fma(c.dcp_i, T - c.T_0, c.LH_s0);
-        const FT l2_pvi = M::fma(c.psi_a, l2_TT, M::fma(c.psi_b, dinvT, c.ps_c0));
-        const FT p_vi = M::exp2(l2_pvi), p_vs = M::exp2(l2_pvs);
-        const FT G = M::rcp(inv_G_liq) * c.inv_rho_w;
-        const FT r_liq = N_liq < c.eps_ft ? FT(0) : M::exp2(M::log2(rho_air * q_liq * M::rcp(N_liq) * c.inv_43pi_rho_w) * FT(1.0 / 3.0));
-        const FT K_liq = c.four_pi * c.rho_w * N_liq * r_liq * G * gamma;
-        const FT gamma_i = M::fma(ratio * R_m * L_v, L_s * c.inv_R_v * inv_cp * inv_T * M::rcp(p), c.R_v * T * inv_pvs);
-        const FT r_ice = N_ice < c.eps_ft ? FT(0) : M::exp2(M::log2(rho_air * q_ice * M::rcp(N_ice) * c.inv_43pi_rho_i) * FT(1.0 / 3.0));
-        const FT LoRT_s = L_s * c.inv_R_v * inv_T;
-        const FT G_ice = M::rcp(M::fma(L_s * c.inv_K * inv_T, LoRT_s - FT(1), c.Rv_over_D * T * M::rcp(M::max(p_vi, c.eps_1m))));
-        const FT xi = p_vs * M::rcp(p_vi);
-        const FT K_ice = c.four_pi * N_ice * r_ice * G_ice * gamma_i;
-        smax = S_arg * (aw - K_ice * (xi - FT(1))) * M::rcp(M::fma(M::fma(K_ice, xi, K_liq), S_arg, aw));
-    } else {
-        smax = S_arg;   // N_liq = N_ice = 0: K_liq = K_ice = 0 ⇒ S_max = S_max_ARG·αw/αw
-    }
-    smax = smax < FT(0) ? FT(0) : smax;   // AA:199 max(0, S_max) with Julia's NaN rule: a NaN from any input reaches every output below
+    for (int k = 0; k < NM; ++k) sum2 = M::fma(cm[k].c2, arg_pow_p2<FT>(c, M::fma(FT(3), s.zeta, s.X * cm[k].inv_N), p2_34), sum2);
+    const FT smax = arg_smax<FT, SINKS>(c, s, sum1, sum2, q_liq, q_ice, N_liq, N_ice);
     o.smax = smax;
-    const FT dl0 = l2_A15 - M::log2(smax);                       // log2(Sm_i / S_max) = l2_sm_c + dl0
+    const FT dl0 = s.l2_A15 - M::log2(smax);                       // log2(Sm_i / S_max) = l2_sm_c + dl0
 #pragma unroll
     for (int k = 0; k < NM; ++k) {
         const FT u = M::fma(cm[k].u_c, dl0, cm[k].uc_sm);       // AA:255   (= ln(sm/smax)/fac, AA:316)
@@ -396,58 +416,145 @@ static int32_t arg_entry(const AP *ap, const AD *ad, const AI *aip, const TH *tp
 }
 
 // ---- aerosol that varies in space: mode descriptors are columns (test/gpu_tests.jl:45-79) --------------------------------
+// The reference's own GPU test builds one AerosolDistribution per element.  Per state the kernel streams the modes TWICE through
+// registers instead of holding every mode's constants (round 3: 17 values per mode alive across the whole point function — 414
+// VGPRs and 322 spilled SGPRs for 8 Float64 modes, one wave per SIMD):
+//   pass 1  per mode: load (r_dry, σ, N, hygroscopicity), form the mode's two terms of the S_max sum (AA:170-183) in the log2 domain —
+//           c1 = Sm_c⁻² f N^p1 as ONE exponential, c2 = Sm_c⁻² g Sm_c^(2 p2) as one — and accumulate; keep (ln σ, log2 Sm_c, N [, ΣM w]);
+//   S_max   arg_smax (the same function as the shared-distribution kernel);
+//   pass 2  per mode: u, ½ N erfc(u) [, ½ M erfc(u − fac)] → store.
+// 3 (4) kept values per mode and point; a lane owns VEC consecutive points of every column (16-byte loads / stores in Float32).
 template <typename FT> struct ArgColIO {
     const FT *r_dry[CMX_ARG_MAX_MODES], *stdev[CMX_ARG_MAX_MODES], *N[CMX_ARG_MAX_MODES], *hyg[CMX_ARG_MAX_MODES], *mmix[CMX_ARG_MAX_MODES];
 };
-// device twin of the per-mode part of make_arg_consts (same definitions, evaluated per state)
-template <typename FT>
-__device__ __forceinline__ ArgModeConsts<FT> arg_mode_consts_dev(const ArgConsts<FT> &c, FT f1, FT f2, FT g1, FT g2, FT r_dry, FT stdev,
-                                                                 FT N, FT hyg, FT mmix) {
+template <typename FT> struct ArgColPar { FT l2_f1, f2_l2e, g1, g2; };   // log2 f1, f2·log2 e, g1, g2 of the ARG fit (f_i = f1 exp(f2 ln²σ), g_i = g1 + g2 ln σ)
+
+#ifndef CMX_ARGCOL_BS
+#define CMX_ARGCOL_BS 128
+#endif
+constexpr int kArgColBS = CMX_ARGCOL_BS;
+template <typename FT, int NM, bool SINKS, int VEC, bool N_ONLY>
+__global__ __launch_bounds__(kArgColBS) void arg_activation_columns_kernel(const ArgConsts<FT> c, const ArgColPar<FT> par, const ArgIO<FT> io,
+                                                                           const ArgColIO<FT> mc, const int64_t nvec) {
     using M = Math<FT>;
-    const FT ln2 = FT(0.6931471805599453), l2e = FT(1.4426950408889634);
-    ArgModeConsts<FT> o;
-    const FT l2s = M::log2(stdev), ls = l2s * ln2;
-    const FT l2_sm_c = FT(1) - FT(0.5) * M::log2(hyg) - FT(1.5) * M::log2(FT(3) * r_dry);   // log2(2/√B) − 1.5 log2(3 r)
-    const FT l2_N = M::log2(N);
-    o.l2_sm_c = l2_sm_c;
-    o.f = f1 * M::exp2(f2 * ls * ls * l2e);
-    o.g = M::fma(g2, ls, g1);
-    o.l2_N = l2_N; o.N = N; o.half_N = FT(0.5) * N;
-    o.u_c = FT(2) * ln2 * M::rcp(FT(4.242640687119285) * ls);   // 2 ln2 / (3√2 ln σ)
-    o.fac = FT(2.1213203435596424) * ls;                          // 3 ln σ √2 / 2
-    o.half_M = FT(0.5) * mmix;
-    o.inv_N = M::rcp(N);
-    o.fN = o.f * M::exp2(c.p1 * l2_N);
-    o.gS = o.g * M::exp2(FT(2) * c.p2 * l2_sm_c);
-    o.inv_sm_c = M::exp2(-l2_sm_c);
-    const FT inv_sm2 = o.inv_sm_c * o.inv_sm_c;
-    o.c1 = inv_sm2 * o.fN; o.c2 = inv_sm2 * o.gS;
-    o.uc_sm = o.u_c * l2_sm_c;
-    return o;
+    const int64_t i = (int64_t)blockIdx.x * kArgColBS + threadIdx.x;
+    FT T[VEC], p[VEC], w[VEC], qt[VEC], ql[VEC] = {}, qi[VEC] = {}, Nl[VEC] = {}, Ni[VEC] = {};
+    if (i < nvec) {
+        load_col<FT, VEC>(io.T, i, T); load_col<FT, VEC>(io.p, i, p); load_col<FT, VEC>(io.w, i, w); load_col<FT, VEC>(io.q_tot, i, qt);
+        if (io.q_liq) load_col<FT, VEC>(io.q_liq, i, ql);
+        if (io.q_ice) load_col<FT, VEC>(io.q_ice, i, qi);
+        if constexpr (SINKS) {
+            if (io.N_liq) load_col<FT, VEC>(io.N_liq, i, Nl);
+            if (io.N_ice) load_col<FT, VEC>(io.N_ice, i, Ni);
+        }
+    }
+    if constexpr (sizeof(FT) == 8 && CMX_ARG_LEAN_ERFC) lean::erfc_tab_fill();   // published by the barrier inside prepare()
+    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS while the loads fly; no-op for Float32
+    if (i >= nvec) return;
+    const FT ln2 = FT(0.6931471805599453);
+    const bool p2_34 = sizeof(FT) == 8 && CMX_ARG_P2_ROOTS && c.p2 == FT(0.75);
+    ArgPre<FT> pre[VEC];
+    FT sum1[VEC], sum2[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        pre[v] = arg_pre<FT>(c, T[v], p[v], w[v], qt[v], ql[v], qi[v]);
+        sum1[v] = FT(0); sum2[v] = FT(0);
+    }
+    FT k_ls[NM][VEC], k_l2sm[NM][VEC], k_N[NM][VEC], k_mm[N_ONLY ? 1 : NM][VEC];
+    // ---- pass 1: the S_max sum
+#pragma unroll
+    for (int k = 0; k < NM; ++k) {
+        FT r[VEC], sd[VEC], Nk[VEC], hy[VEC];
+        load_col<FT, VEC>(mc.r_dry[k], i, r); load_col<FT, VEC>(mc.stdev[k], i, sd); load_col<FT, VEC>(mc.N[k], i, Nk); load_col<FT, VEC>(mc.hyg[k], i, hy);
+        if constexpr (!N_ONLY) {
+            if (mc.mmix[k]) load_col<FT, VEC>(mc.mmix[k], i, k_mm[k]);
+            else {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) k_mm[k][v] = FT(0);
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const FT ls = M::log2(sd[v]) * ln2;                                           // ln σ
+            // log2 Sm_c = log2(2/√B) − 1.5 log2(3 r_dry) (Sm = Sm_c A^1.5, AA:107-118)
+            FT l2sm;
+            const FT t3 = FT(3) * r[v];
+            if constexpr (sizeof(FT) == 8) l2sm = FT(1) - FT(0.5) * M::log2(hy[v] * (t3 * t3 * t3));      // one table-driven log2; (3r)³ B ≥ 1e-40 is far inside the Float64 range
+            else l2sm = M::fma(FT(-1.5), M::log2(t3), M::fma(FT(-0.5), M::log2(hy[v]), FT(1)));          // Float32: (3r)³ would underflow for r < 1e-13
+            const FT l2N = M::log2(Nk[v]);
+            // c1 = Sm_c⁻² f1 exp(f2 ln²σ) N^p1,  c2 = Sm_c⁻² (g1 + g2 ln σ) Sm_c^(2 p2)
+            const FT c1 = M::exp2(M::fma(c.p1, l2N, M::fma(par.f2_l2e * ls, ls, M::fma(FT(-2), l2sm, par.l2_f1))));
+            const FT c2 = M::fma(par.g2, ls, par.g1) * M::exp2((FT(2) * c.p2 - FT(2)) * l2sm);
+            sum1[v] += c1;
+            const FT y = M::fma(pre[v].X, M::rcp(Nk[v]), FT(3) * pre[v].zeta);              // η_k + 3ζ
+            sum2[v] = M::fma(c2, arg_pow_p2<FT>(c, y, p2_34), sum2[v]);
+            k_ls[k][v] = ls; k_l2sm[k][v] = l2sm; k_N[k][v] = Nk[v];
+        }
+        // one mode at a time (Float64: keeps the next mode's table reads and loads behind this mode's arithmetic, like arg_point's erfc loop)
+        if constexpr (sizeof(FT) == 8) asm volatile("" : "+v"(sum2[0]) : : "memory");
+    }
+    // ---- S_max
+    FT dl0[VEC], sm[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        sm[v] = arg_smax<FT, SINKS>(c, pre[v], sum1[v], sum2[v], ql[v], qi[v], Nl[v], Ni[v]);
+        dl0[v] = pre[v].l2_A15 - M::log2(sm[v]);                                         // log2(Sm_k / S_max) = log2 Sm_c + dl0
+    }
+    if (io.S_max) store_col<FT, VEC>(io.S_max, i, sm);
+    // ---- pass 2: activated number (and mass) per mode
+#pragma unroll
+    for (int k = 0; k < NM; ++k) {
+        FT na[VEC], ma[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const FT ls = k_ls[k][v];
+            const FT u = FT(0.32677907347424754) * M::rcp(ls) * (k_l2sm[k][v] + dl0[v]);   // 2 ln2/(3√2 ln σ) · log2(Sm_k/S_max)   AA:255
+            na[v] = FT(0.5) * k_N[k][v] * erfc_dev<FT>(u);                                  // N ½ (1 − erf u)   AA:257
+            if constexpr (sizeof(FT) == 8 && CMX_ARG_LEAN_ERFC) asm volatile("" : "+v"(na[v]) : : "memory");
+            if constexpr (!N_ONLY) ma[v] = FT(0.5) * k_mm[k][v] * erfc_rel_dev<FT>(u - FT(2.1213203435596424) * ls);   // M/2 erfc(u − 3 ln σ √2/2)   AA:319
+        }
+        if (io.N_act[k]) store_col<FT, VEC>(io.N_act[k], i, na);
+        if constexpr (!N_ONLY) {
+            if (io.M_act[k]) store_col<FT, VEC>(io.M_act[k], i, ma);
+        }
+    }
 }
 
 template <typename FT, int NM, bool SINKS>
-__global__ __launch_bounds__(kBlock) void arg_activation_columns_kernel(const ArgConsts<FT> c, const FT f1, const FT f2, const FT g1,
-                                                                        const FT g2, const ArgIO<FT> io, const ArgColIO<FT> mc,
-                                                                        const int64_t n) {
-    if constexpr (sizeof(FT) == 8 && CMX_ARG_LEAN_ERFC) lean::erfc_tab_fill();   // published by the barrier inside prepare()
-    Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    ArgModeConsts<FT> cm[NM];
-#pragma unroll
-    for (int k = 0; k < NM; ++k)
-        cm[k] = arg_mode_consts_dev<FT>(c, f1, f2, g1, g2, mc.r_dry[k][i], mc.stdev[k][i], mc.N[k][i], mc.hyg[k][i],
-                                        mc.mmix[k] ? mc.mmix[k][i] : FT(0));
-    const FT ql = io.q_liq ? io.q_liq[i] : FT(0), qi = io.q_ice ? io.q_ice[i] : FT(0);
-    FT Nl = FT(0), Ni = FT(0);
-    if constexpr (SINKS) { Nl = io.N_liq ? io.N_liq[i] : FT(0); Ni = io.N_ice ? io.N_ice[i] : FT(0); }
-    const ArgOut<FT, NM> o = arg_point<FT, NM, SINKS>(c, cm, io.T[i], io.p[i], io.w[i], io.q_tot[i], ql, qi, Nl, Ni, io.want_N, io.want_M);
-    if (io.S_max) io.S_max[i] = o.smax;
-#pragma unroll
-    for (int j = 0; j < NM; ++j) {
-        if (io.want_N && io.N_act[j]) io.N_act[j][i] = o.n[j];
-        if (io.want_M && io.M_act[j]) io.M_act[j][i] = o.m[j];
+static void launch_arg_columns(const ArgConsts<FT> &c, const ArgColPar<FT> &par, const ArgIO<FT> &io0, const ArgColIO<FT> &mc0, int64_t n,
+                               const void *const *ptrs, int nptrs, hipStream_t s) {
+    // Float64 runs one point per lane: the kernel is VALU-bound there and the second point's kept values would cost a wave per SIMD
+    constexpr int VEC = sizeof(FT) == 4 ? Math<FT>::VEC : 1;
+    const uintptr_t mis0 = reinterpret_cast<uintptr_t>(io0.T) & 15u;
+    bool same_mis = (mis0 % sizeof(FT)) == 0;
+    for (int k = 0; k < nptrs; ++k)
+        if (ptrs[k]) same_mis = same_mis && ((reinterpret_cast<uintptr_t>(ptrs[k]) & 15u) == mis0);
+    auto off = [](auto *p, int64_t lo) { return p ? p + lo : p; };
+    auto launch_range = [&](auto vec_tag, int64_t lo, int64_t count) {
+        constexpr int V = decltype(vec_tag)::value;
+        if (count <= 0) return;
+        ArgIO<FT> io = io0;
+        ArgColIO<FT> mc = mc0;
+        io.T += lo; io.p += lo; io.w += lo; io.q_tot += lo;
+        io.q_liq = off(io.q_liq, lo); io.q_ice = off(io.q_ice, lo); io.N_liq = off(io.N_liq, lo); io.N_ice = off(io.N_ice, lo);
+        io.S_max = off(io.S_max, lo);
+        for (int j = 0; j < NM; ++j) {
+            io.N_act[j] = off(io.N_act[j], lo); io.M_act[j] = off(io.M_act[j], lo);
+            mc.r_dry[j] += lo; mc.stdev[j] += lo; mc.N[j] += lo; mc.hyg[j] += lo; mc.mmix[j] = off(mc.mmix[j], lo);
+        }
+        const int64_t nv = count / V;
+        const dim3 grid((unsigned)((nv + kArgColBS - 1) / kArgColBS));
+        if (!io.want_M) hipLaunchKernelGGL((arg_activation_columns_kernel<FT, NM, SINKS, V, true>), grid, dim3(kArgColBS), 0, s, c, par, io, mc, nv);
+        else hipLaunchKernelGGL((arg_activation_columns_kernel<FT, NM, SINKS, V, false>), grid, dim3(kArgColBS), 0, s, c, par, io, mc, nv);
+    };
+    if (same_mis && VEC > 1) {
+        const int64_t head = std::min<int64_t>(n, mis0 ? (int64_t)((16 - mis0) / sizeof(FT)) : 0);
+        const int64_t body = ((n - head) / VEC) * VEC;
+        launch_range(std::integral_constant<int, 1>{}, 0, head);
+        launch_range(std::integral_constant<int, VEC>{}, head, body);
+        launch_range(std::integral_constant<int, 1>{}, head + body, n - head - body);
+    } else {
+        launch_range(std::integral_constant<int, 1>{}, 0, n);
     }
 }
 
@@ -468,20 +575,24 @@ static int32_t arg_columns_entry(const AP *ap, const AI *aip, const TH *tps, int
     io.T = T; io.p = p; io.w = w; io.q_tot = q_tot; io.q_liq = q_liq; io.q_ice = q_ice; io.N_liq = N_liq; io.N_ice = N_ice;
     io.S_max = S_max; io.want_N = N_act != nullptr; io.want_M = M_act != nullptr;
     ArgColIO<FT> mc{};
+    const void *ptrs[9 + 7 * CMX_ARG_MAX_MODES] = {T, p, w, q_tot, q_liq, q_ice, N_liq, N_ice, S_max};
+    int np = 9;
     for (int j = 0; j < n_modes; ++j) {
         if (!r_dry[j] || !stdev[j] || !N_mode[j] || !hyg[j]) return CMX_ERR_BAD_ARG;
         mc.r_dry[j] = r_dry[j]; mc.stdev[j] = stdev[j]; mc.N[j] = N_mode[j]; mc.hyg[j] = hyg[j]; mc.mmix[j] = mmix ? mmix[j] : nullptr;
         io.N_act[j] = N_act ? N_act[j] : nullptr;
         io.M_act[j] = M_act ? M_act[j] : nullptr;
+        const void *q[7] = {mc.r_dry[j], mc.stdev[j], mc.N[j], mc.hyg[j], mc.mmix[j], io.N_act[j], io.M_act[j]};
+        for (const void *x : q) ptrs[np++] = x;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool sinks = N_liq || N_ice;
-    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
-    const FT f1 = (FT)ap->f1, f2 = (FT)ap->f2, g1 = (FT)ap->g1, g2 = (FT)ap->g2;
-#define CMX_ARGC_CASE(NM)                                                                                                       \
-    case NM:                                                                                                                    \
-        if (sinks) hipLaunchKernelGGL((arg_activation_columns_kernel<FT, NM, true>), grid, block, 0, s, c, f1, f2, g1, g2, io, mc, n);  \
-        else hipLaunchKernelGGL((arg_activation_columns_kernel<FT, NM, false>), grid, block, 0, s, c, f1, f2, g1, g2, io, mc, n);       \
+    const double l2e = 1.4426950408889634074;
+    const ArgColPar<FT> par{(FT)std::log2((double)ap->f1), (FT)((double)ap->f2 * l2e), (FT)ap->g1, (FT)ap->g2};
+#define CMX_ARGC_CASE(NM)                                                                     \
+    case NM:                                                                                  \
+        if (sinks) launch_arg_columns<FT, NM, true>(c, par, io, mc, n, ptrs, np, s);          \
+        else launch_arg_columns<FT, NM, false>(c, par, io, mc, n, ptrs, np, s);               \
         break;
     switch (n_modes) {
         CMX_ARGC_CASE(1) CMX_ARGC_CASE(2) CMX_ARGC_CASE(3) CMX_ARGC_CASE(4)

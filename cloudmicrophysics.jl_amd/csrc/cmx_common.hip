@@ -95,15 +95,15 @@ template <typename FT>
 static int32_t column_sums(int32_t ncols, const FT *const *cols, int64_t n, double *sums, double *workspace, void *stream) {
     if (ncols < 0 || ncols > CMX_COLUMN_SUMS_MAX_COLS || n < 0 || (ncols > 0 && (!cols || !sums))) return CMX_ERR_BAD_ARG;
     if (ncols == 0) return CMX_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (n == 0) {                                       // empty columns (their pointers may be NULL): the sums are 0
+        CMX_HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * (size_t)ncols, s));
+        return CMX_OK;
+    }
     ColumnSumArgs<FT> a{};
     for (int32_t k = 0; k < ncols; ++k) {
         if (!cols[k]) return CMX_ERR_BAD_ARG;          // validate everything before the first enqueue
         a.col[k] = cols[k];
-    }
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (n == 0) {
-        CMX_HIP_TRY(hipMemsetAsync(sums, 0, sizeof(double) * (size_t)ncols, s));
-        return CMX_OK;
     }
     if (!workspace) return CMX_ERR_BAD_ARG;
     int64_t chunk = (n + CMX_COLUMN_SUMS_PARTIALS - 1) / CMX_COLUMN_SUMS_PARTIALS;

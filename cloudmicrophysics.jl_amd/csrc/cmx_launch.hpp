@@ -96,6 +96,32 @@ __device__ __forceinline__ void store_col(FT *__restrict__ p, int64_t i, const F
     else reinterpret_cast<V *>(p)[i] = v;
 }
 
+// --- division of a 32-bit index by a run-time constant (Granlund & Montgomery 1994; Hacker's Delight §10-9) ---------------------
+// The layout and column kernels turn a flat element index into (run, offset) or (column, level).  As a 64-bit quotient through
+// doubles that is ≈ 40 VALU instructions per lane (conversions, a Float64 multiply, a 64-bit multiply-subtract, two fix-ups) — in the
+// Float32 kernels, which are VALU-bound, 3–8 % of the lane's work (round 4: PMC counts).  For indices below 2³² (every launch up
+// to 4.29e9 elements; the kernels keep the 64-bit path for larger ones) the quotient is exact with one v_mul_hi_u32:
+//     t = mulhi(n, magic);   q = (t + ((n − t) >> sh1)) >> sh2;      magic = ⌊2³²(2^s − d)/d⌋ + 1,  s = ⌈log2 d⌉, sh1 = min(s, 1), sh2 = max(s − 1, 0)
+struct FastDivU32 { uint32_t magic, sh1, sh2, d; };
+inline FastDivU32 make_fastdiv(uint32_t d) {          // d ≥ 1
+    uint32_t s = 0;
+    while (s < 32 && ((uint64_t)1 << s) < d) ++s;      // s = ⌈log2 d⌉
+    FastDivU32 f;
+    f.magic = (uint32_t)((((uint64_t)1 << 32) * ((((uint64_t)1) << s) - d)) / d + 1);
+    f.sh1 = s < 1 ? s : 1;
+    f.sh2 = s > 0 ? s - 1 : 0;
+    f.d = d;
+    return f;
+}
+__host__ __device__ __forceinline__ uint32_t fastdiv(uint32_t n, const FastDivU32 &f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t t = __umulhi(n, f.magic);
+#else
+    const uint32_t t = (uint32_t)(((uint64_t)n * f.magic) >> 32);
+#endif
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
 // Launch of a kernel whose Float64 instantiation reads its constants through front_consts() (cmx_math.hpp), i.e. straight from the start of the
 // kernel-argument segment: the constants struct MUST be the first kernel parameter.  The macro checks that at compile time — the first
 // parameter type of the kernel is the type of the first argument passed — so reordering or prepending a parameter no longer compiles

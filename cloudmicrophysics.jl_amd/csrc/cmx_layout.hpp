@@ -30,6 +30,8 @@ template <typename FT, int NIN, int NOUT> struct LayoutIO {
     FT *aos;                  // n × NAOS (AoS mode)
     int64_t seg_len;
     double inv_seg_len;
+    FastDivU32 seg_div;       // division by seg_len for element indices below 2³² (idx32)
+    bool idx32;               // every element index and every (run · stride + offset) product of this call fits the 32-bit forms
 };
 
 #ifndef CMX_LAYOUT_F64_VEC
@@ -49,17 +51,29 @@ __global__ __launch_bounds__(BS) void tendencies_layout_kernel(const typename PO
     const bool active = i < nvec;
     FT y[VEC][NOUT];
     int64_t seg = 0, off = i * VEC;                           // element index → (run, offset in run)
+    uint32_t seg32 = 0, off32 = 0;
     if constexpr (SEG) {
         const int64_t e = i * VEC;
-        seg = (int64_t)((double)e * io.inv_seg_len);
-        off = e - seg * io.seg_len;
-        if (off < 0) { --seg; off += io.seg_len; }
-        if (off >= io.seg_len) { ++seg; off -= io.seg_len; }
+        if (io.idx32) {                                        // wave-uniform: one v_mul_hi_u32 instead of the Float64 quotient (cmx_launch.hpp fastdiv)
+            seg32 = fastdiv((uint32_t)e, io.seg_div);
+            off32 = (uint32_t)e - seg32 * (uint32_t)io.seg_len;
+            seg = seg32; off = off32;
+        } else {
+            seg = (int64_t)((double)e * io.inv_seg_len);
+            off = e - seg * io.seg_len;
+            if (off < 0) { --seg; off += io.seg_len; }
+            if (off >= io.seg_len) { ++seg; off -= io.seg_len; }
+        }
     }
+    // element offset of the lane's first point in column k: run · stride + offset — with 32-bit operands one v_mad_u64_u32
+    auto col_off = [&](int64_t stride) -> int64_t {
+        if constexpr (!SEG) return off;
+        else return io.idx32 ? (int64_t)((uint64_t)seg32 * (uint32_t)stride + off32) : seg * stride + off;
+    };
     FT x[NIN][VEC];
     if (active) {
 #pragma unroll
-        for (int k = 0; k < NIN; ++k) load_col<FT, VEC, true>(io.in[k] + (SEG ? seg * io.in_stride[k] : 0), off / VEC, x[k]);
+        for (int k = 0; k < NIN; ++k) load_col<FT, VEC, true>(io.in[k] + (col_off(io.in_stride[k]) - off), off / VEC, x[k]);
     }
     Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS while the loads fly (every lane of the workgroup reaches the barrier inside); no-op for Float32
     if (active) {
@@ -78,7 +92,7 @@ __global__ __launch_bounds__(BS) void tendencies_layout_kernel(const typename PO
             FT col[VEC];
 #pragma unroll
             for (int k = 0; k < VEC; ++k) col[k] = y[k][q];
-            store_col<FT, VEC, true>(io.out[q] + (SEG ? seg * io.out_stride[q] : 0), off / VEC, col);
+            store_col<FT, VEC, true>(io.out[q] + (col_off(io.out_stride[q]) - off), off / VEC, col);
         }
     } else {
         extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -134,6 +148,11 @@ static int32_t launch_layout(const typename POLICY::Consts &c, int64_t n_seg, in
     }
     if (aos && !aligned16(aos)) return CMX_ERR_BAD_ARG;
     io.aos = aos; io.seg_len = seg_len; io.inv_seg_len = 1.0 / (double)seg_len;
+    // the 32-bit index forms: every element index < 2³², every stride < 2³² (then run · stride + offset fits 64 bits from 32-bit factors)
+    io.idx32 = n < ((int64_t)1 << 32) && seg_len < ((int64_t)1 << 32);
+    for (int k = 0; k < NIN; ++k) io.idx32 = io.idx32 && io.in_stride[k] < ((int64_t)1 << 32);
+    for (int k = 0; k < NOUT && out; ++k) io.idx32 = io.idx32 && io.out_stride[k] < ((int64_t)1 << 32);
+    io.seg_div = make_fastdiv((uint32_t)(io.idx32 ? seg_len : 1));
     const bool seg = n_seg > 1;
     auto launch = [&](auto vec_tag) {
         constexpr int V = decltype(vec_tag)::value;

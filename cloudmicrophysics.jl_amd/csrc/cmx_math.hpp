@@ -190,6 +190,74 @@ template <typename FT, typename CH> inline bool make_chen_gamma(const CH &ch, Ch
     }
     return ok;
 }
+// ---- round 4: the whole density-dependent coefficient of a Chen-2022 rain term, in the log2 domain --------------------------------------
+// Term i of the number- (k = 0) and mass-weighted (k = 3) rain fall speed is (Common.jl:290-302,414-422, CM2:703-719)
+//     a_i e^{ρ0 ρ} 1000^{b_i(ρ)} [ρ^{a3_pow}, i = 3] · Γ(b_i(ρ) + k + 1)/k! · λ^{k+1} (λ + 1000 c_i)^{−(b_i(ρ) + k + 1)},   b_i(ρ) = b_i − b_ρ ρ.
+// Everything in front of the λ powers depends on the state only through ρ, and its logarithm
+//     L_{k,i}(ρ) = log2|a_i| + ρ0 log2(e) ρ + b_i(ρ) log2 1000 + log2 Γ(b_i(ρ) + k + 1) − log2 k!
+// is linear in ρ plus log2 Γ of an argument that moves by 2 b_ρ ≈ 0.08 over 0 ≤ ρ ≤ 2 kg/m³ — a polynomial of degree 3 (Float32) / 7
+// (Float64) in ρ − 1 to rounding.  The kernel then forms each term as ONE exponential of  L_{k,i}(ρ) + (k+1) log2 λ − (b_i(ρ)+k+1) log2(λ + 1000 c_i)
+// instead of a Γ polynomial, a magnitude and an exponential each (≈ 17 instead of 26 instructions per term; PMC round 4: 334 → … per point).
+// make_chen_log() returns false where the fit misses its accuracy (a pole of Γ inside the range, a huge b_ρ): the GENERAL instantiation runs.
+template <typename FT> struct ChenLog {
+    static constexpr int D = sizeof(FT) == 4 ? 3 : 7;
+    FT c[2][3][D + 1];    // [k = 0 | 3][term][monomial in (ρ − 1)]
+    FT sgn[3];            // sign of a_i (0 for a_i = 0)
+    FT b1[3], b4[3];      // b_i + 1, b_i + 4
+};
+template <typename FT, typename CH> inline bool make_chen_log(const CH &ch, ChenLog<FT> &g) {
+    constexpr int D = ChenLog<FT>::D, N = D + 1;
+    const double pi = 3.14159265358979323846, half = 0.5 * kChenGammaRhoMax, l2e = 1.4426950408889634074, ln2 = 0.69314718055994530942;
+    bool ok = true;
+    for (int i = 0; i < 3; ++i) {
+        const double ai = (double)ch.a[i];
+        g.sgn[i] = (FT)(ai > 0 ? 1.0 : (ai < 0 ? -1.0 : 0.0));
+        g.b1[i] = (FT)((double)ch.b[i] + 1.0);
+        g.b4[i] = (FT)((double)ch.b[i] + 4.0);
+        if (!((double)ch.b[i] + 1.0 - (double)ch.b_rho * kChenGammaRhoMax > 0.05) || !((double)ch.b[i] + 4.0 < 30.0)) ok = false;
+        for (int kk = 0; kk < 2; ++kk) {
+            const int k = kk == 0 ? 0 : 3;
+            auto f = [&](double t) {
+                const double rho = half + half * t, b = (double)ch.b[i] - (double)ch.b_rho * rho;
+                return (ai != 0 ? std::log2(std::fabs(ai)) : -1000.0) + (double)ch.rho_0 * l2e * rho + b * std::log2(1000.0) +
+                       (std::lgamma(b + k + 1.0) - (k == 3 ? std::log(6.0) : 0.0)) / ln2;
+            };
+            double a[N], fx[N], mono[N] = {0}, Tkm1[N] = {0}, Tk[N] = {0};
+            for (int j = 0; j < N; ++j) fx[j] = f(std::cos(pi * (j + 0.5) / N));
+            for (int q = 0; q < N; ++q) {
+                double sum = 0;
+                for (int j = 0; j < N; ++j) sum += fx[j] * std::cos(pi * q * (j + 0.5) / N);
+                a[q] = (q == 0 ? 1.0 : 2.0) / N * sum;
+            }
+            Tkm1[0] = 1.0;
+            for (int m = 0; m < N; ++m) mono[m] += a[0] * Tkm1[m];
+            if (N > 1) {
+                Tk[1] = 1.0;
+                for (int m = 0; m < N; ++m) mono[m] += a[1] * Tk[m];
+                for (int q = 2; q < N; ++q) {
+                    double Tn[N] = {0};
+                    for (int m = 0; m < N; ++m) Tn[m] = (m > 0 ? 2.0 * Tk[m - 1] : 0.0) - Tkm1[m];
+                    for (int m = 0; m < N; ++m) { mono[m] += a[q] * Tn[m]; Tkm1[m] = Tk[m]; Tk[m] = Tn[m]; }
+                }
+            }
+            double scale = 1.0;
+            for (int m = 0; m < N; ++m) { g.c[kk][i][m] = (FT)(mono[m] * scale); scale /= half; }
+            for (double t : {-0.97, -0.41, 0.13, 0.58, 0.99}) {      // off-node probes: ABSOLUTE error of the logarithm = relative error of the coefficient
+                double p = 0;
+                for (int m = N - 1; m >= 0; --m) p = p * t + mono[m];
+                if (!(std::fabs(p - f(t)) <= (sizeof(FT) == 4 ? 2e-7 : 4e-15) / ln2)) ok = false;
+            }
+        }
+    }
+    return ok;
+}
+template <typename FT, typename G> __device__ __forceinline__ FT chen_log_eval(const G &g, int kk, int i, FT t) {
+    FT p = g.c[kk][i][ChenLog<FT>::D];
+#pragma unroll
+    for (int m = ChenLog<FT>::D - 1; m >= 0; --m) p = Math<FT>::fma(p, t, g.c[kk][i][m]);
+    return p;
+}
+
 // (G: ChenGamma<FT>, possibly in the constant address space — the Float64 kernels read their constants through the kernel-argument pointer)
 template <typename FT, typename G> __device__ __forceinline__ FT chen_gamma_eval(const G &g, int i, FT rho_c) {
     const FT t = rho_c - FT(0.5 * kChenGammaRhoMax);

@@ -36,6 +36,7 @@ template <typename FT> struct Mp1mColIO {
     int64_t n;             // n_col · n_lev
     int32_t n_lev;
     double inv_n_lev;
+    FastDivU32 lev_div;    // division by n_lev for flat indices below 2³² (cmx_launch.hpp fastdiv)
 };
 
 // All constants (≈ 170 values: tendencies, LinearizedAverage step, fall speeds) travel as ONE by-value kernel argument, the first, and BOTH
@@ -73,11 +74,17 @@ __global__ __launch_bounds__(BS) void mp1m_column_kernel(const Mp1mColKernArgs<F
     int64_t col = 0;
     int32_t lev = 0;
     if (active) {
-        col = (int64_t)((double)i0 * io.inv_n_lev);       // i0 = col·n_lev + k (one double multiply + fix-up per lane; exact below 2^53)
-        int64_t k64 = i0 - col * io.n_lev;
-        if (k64 < 0) { --col; k64 += io.n_lev; }
-        if (k64 >= io.n_lev) { ++col; k64 -= io.n_lev; }
-        lev = (int32_t)k64;
+        if (io.n < ((int64_t)1 << 32)) {                  // i0 = col·n_lev + k; wave-uniform: one v_mul_hi_u32 (cmx_launch.hpp fastdiv)
+            const uint32_t c32 = fastdiv((uint32_t)i0, io.lev_div);
+            col = c32;
+            lev = (int32_t)((uint32_t)i0 - c32 * (uint32_t)io.n_lev);
+        } else {                                          // one double multiply + fix-up per lane; exact below 2^53
+            col = (int64_t)((double)i0 * io.inv_n_lev);
+            int64_t k64 = i0 - col * io.n_lev;
+            if (k64 < 0) { --col; k64 += io.n_lev; }
+            if (k64 >= io.n_lev) { ++col; k64 -= io.n_lev; }
+            lev = (int32_t)k64;
+        }
         int32_t lv = lev;
         const auto &k = a.k;
         // two passes over the lane's points — tendencies, then fluxes — so that only one pass's constants are live at a time
@@ -163,7 +170,7 @@ static int32_t column_1m_entry(const MP *mp, const TH *tps, const ST *stokes, co
     const void *ptrs[11];
     for (int j = 0; j < 7; ++j) { if (!in[j]) return CMX_ERR_BAD_ARG; io.in[j] = in[j]; ptrs[j] = in[j]; }
     for (int j = 0; j < 4; ++j) { if (!out[j]) return CMX_ERR_BAD_ARG; io.out[j] = out[j]; ptrs[7 + j] = out[j]; }
-    io.inv_dz = inv_dz; io.precip_rai = precip_rai; io.precip_sno = precip_sno; io.n = n; io.n_lev = n_lev; io.inv_n_lev = 1.0 / (double)n_lev;
+    io.inv_dz = inv_dz; io.precip_rai = precip_rai; io.precip_sno = precip_sno; io.n = n; io.n_lev = n_lev; io.inv_n_lev = 1.0 / (double)n_lev; io.lev_div = make_fastdiv((uint32_t)n_lev);
     const bool def = flags == CMX_1M_DEFAULT_OPTIONS && mp1m_default_exponents(k.c);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     constexpr int VEC = sizeof(FT) == 8 ? 1 : Math<FT>::VEC;     // Float64: one point per lane, as in the pointwise kernel

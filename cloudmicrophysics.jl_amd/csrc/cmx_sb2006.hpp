@@ -22,8 +22,8 @@
 
 namespace cmx {
 
-// VEL_CHEN: Γ of the Chen-2022 exponents from the host-fitted polynomials in ρ (cmx_math.hpp ChenGamma); VEL_CHEN_GEN: run-time Γ for
-// parameter sets the fit cannot represent (make_chen_gamma false)
+// VEL_CHEN: the density-dependent coefficients of the Chen-2022 terms from host-fitted polynomials in ρ (cmx_math.hpp ChenLog); VEL_CHEN_GEN: run-time Γ for
+// parameter sets the fit cannot represent (make_chen_log false)
 enum : int { VEL_NONE = 0, VEL_SB = 1, VEL_CHEN = 2, VEL_CHEN_GEN = 3 };
 
 // ---------------------------------------------------------------------------------------------
@@ -61,7 +61,7 @@ template <typename FT> struct SbConsts {
     FT vel_s, aR, bR, cR, rc2, e_rc2cR; // √ρ0(vel), …, 2·r_c, exp(−2 r_c c_R)
     // Chen-2022 rain velocity (Common.jl:290-302, 414-422)
     FT ch_rho0_l2e, ch_a[3], ch_a3_pow, ch_b[3], ch_b_rho, ch_c1000[3], l2_1000;
-    ChenGamma<FT> chg, chg3;   // Γ(b_i(ρ) + 1) and Γ(b_i(ρ) + 4)/3! as polynomials in ρ (cmx_math.hpp)
+    ChenLog<FT> chl;           // log2 of the density-dependent coefficient of every term, k = 0 and k = 3, as polynomials in ρ (cmx_math.hpp)
 };
 
 // The limited rain PSD clamps with v_med3 (clamp_ordered): every (min, max) pair of the limiters must be ordered and positive.
@@ -191,8 +191,7 @@ inline SbConsts<FT> make_sb_consts(const WR &wr, const TH &tp, const VL *vel, do
         c.ch_a3_pow = (FT)ch.a3_pow;
         c.ch_b_rho = (FT)ch.b_rho;
         c.l2_1000 = (FT)std::log2(1000.0);
-        (void)make_chen_gamma<FT>(ch, c.chg, 0);   // the entry points test the fits themselves (chen_vel_kind)
-        (void)make_chen_gamma<FT>(ch, c.chg3, 3);
+        (void)make_chen_log<FT>(ch, c.chl);        // the entry points test the fit themselves (chen_vel_kind)
     }
     return c;
 }
@@ -290,7 +289,30 @@ __device__ __forceinline__ void sb2006_rain_velocity(const C &c, FT rho, FT rs_r
         const FT vt1 = M::max(FT(0), s * (c.aR * pa1 - c.bR * pb1 * (inv_d2 * inv_d2)));
         vt_n = no_N_rai ? FT(0) : vt0;
         vt_m = no_q_rai ? FT(0) : vt1;
-    } else if constexpr (VEL == VEL_CHEN || VEL == VEL_CHEN_GEN) {   // CM2:703-719, Common.jl:290-302, 414-422
+    } else if constexpr (VEL == VEL_CHEN) {   // CM2:703-719, Common.jl:290-302, 414-422 — fitted coefficients (cmx_math.hpp ChenLog)
+        const FT lam = M::exp2_fin(l2_lam);
+        const FT rho_c = M::max(rho, FT(0));
+        const FT t = rho_c - FT(0.5 * kChenGammaRhoMax);
+        const FT l2_lam4 = FT(4) * l2_lam;
+        FT vt0 = FT(0), vt3 = FT(0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            // (wave-uniform shortcuts for the published table's c_1 = 0, c_2 = c_3 were tried: if-converted they cost three selects per point
+            // and save nothing; as real scalar branches they split the four points' code into 24 blocks — 149 VGPRs instead of 124)
+            const FT l2_den = M::log2(lam + c.ch_c1000[i]);     // log2(λ + 1000 c_i)
+            FT L0 = chen_log_eval<FT>(c.chl, 0, i, t), L3 = chen_log_eval<FT>(c.chl, 1, i, t);
+            if (i == 2) { const FT ar = c.ch_a3_pow * M::log2(rho_c); L0 += ar; L3 += ar; }      // ρ^a3_pow of the third term (log-singular at 0: not in the fit)
+            const FT e0 = M::exp2(M::fma(-M::fma(-c.ch_b_rho, rho_c, c.chl.b1[i]), l2_den, L0 + l2_lam));
+            const FT e3 = M::exp2(M::fma(-M::fma(-c.ch_b_rho, rho_c, c.chl.b4[i]), l2_den, L3 + l2_lam4));
+            vt0 = M::fma(c.chl.sgn[i], e0, vt0);
+            vt3 = M::fma(c.chl.sgn[i], e3, vt3);
+        }
+        vt0 = M::max(FT(0), vt0);
+        vt3 = M::max(FT(0), vt3);
+        if (rho_c > FT(kChenGammaRhoMax)) vt0 = vt3 = M::nan();   // outside the range of the fit: no silent extrapolation
+        vt_n = no_N_rai ? FT(0) : vt0;
+        vt_m = no_q_rai ? FT(0) : vt3;
+    } else if constexpr (VEL == VEL_CHEN_GEN) {   // any table, any ρ: run-time Γ (OCML tgamma)
         const FT lam = M::exp2_fin(l2_lam);
         const FT rho_c = M::max(rho, FT(0));
         const FT l2_q = c.ch_rho0_l2e * rho_c;                  // log2 exp(ρ0 ρ)
@@ -303,17 +325,16 @@ __device__ __forceinline__ void sb2006_rain_velocity(const C &c, FT rho, FT rs_r
             // aiu = a_i·q·(ρ^a3_pow for i = 3)·1000^b_i ; sign kept outside the log
             FT l2_mag = l2_q + bi * c.l2_1000 + (i == 2 ? c.ch_a3_pow * l2_rho : FT(0));
             const FT l2_den = M::log2(lam + c.ch_c1000[i]);     // log2(1/λ_inv + c)
-            const FT g1 = VEL == VEL_CHEN_GEN ? tgamma_general<FT>(bi + FT(1)) : chen_gamma_eval<FT>(c.chg, i, rho_c);
+            const FT g1 = tgamma_general<FT>(bi + FT(1));
             // k = 0: δ = 1;  k = 3: δ = 4, Γ(b+4) = (b+3)(b+2)(b+1)Γ(b+1), /3!
             const FT e0 = M::exp2(l2_mag - l2_lam_inv - (bi + FT(1)) * l2_den);
             const FT e3 = M::exp2(l2_mag - FT(4) * l2_lam_inv - (bi + FT(4)) * l2_den);
             vt0 = M::fma(c.ch_a[i] * e0, g1, vt0);
-            const FT g4 = VEL == VEL_CHEN_GEN ? g1 * (bi + FT(3)) * (bi + FT(2)) * (bi + FT(1)) * FT(1.0 / 6.0) : chen_gamma_eval<FT>(c.chg3, i, rho_c);
+            const FT g4 = g1 * (bi + FT(3)) * (bi + FT(2)) * (bi + FT(1)) * FT(1.0 / 6.0);
             vt3 = M::fma(c.ch_a[i] * e3, g4, vt3);
         }
         vt0 = M::max(FT(0), vt0);
         vt3 = M::max(FT(0), vt3);
-        if (VEL == VEL_CHEN && rho_c > FT(kChenGammaRhoMax)) vt0 = vt3 = M::nan();   // outside the range of the fitted Γ: no silent extrapolation
         vt_n = no_N_rai ? FT(0) : vt0;
         vt_m = no_q_rai ? FT(0) : vt3;
     }
@@ -321,8 +342,8 @@ __device__ __forceinline__ void sb2006_rain_velocity(const C &c, FT rho, FT rs_r
 
 // which Chen-2022 instantiation a parameter set takes (host): the fitted-Γ one, or the general one when the fit is not accurate
 template <typename FT, typename CH> inline int chen_vel_kind(const CH &ch) {
-    ChenGamma<FT> g;
-    return make_chen_gamma<FT>(ch, g, 0) && make_chen_gamma<FT>(ch, g, 3) ? VEL_CHEN : VEL_CHEN_GEN;
+    ChenLog<FT> g;
+    return make_chen_log<FT>(ch, g) ? VEL_CHEN : VEL_CHEN_GEN;
 }
 
 // `n_lcl`, `n_rai` are per-kg numbers (BMT), `N_*` = ρ n_* per m³ (CM2).  No input clamping here:

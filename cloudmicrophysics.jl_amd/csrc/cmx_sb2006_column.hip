@@ -37,6 +37,7 @@ template <typename FT> struct SbColIO {
     int64_t n;             // n_col · n_lev
     int32_t n_lev;
     double inv_n_lev;
+    FastDivU32 lev_div;    // division by n_lev for flat indices below 2³² (cmx_launch.hpp fastdiv)
 };
 
 template <typename FT> struct SedFlux { FT q_rai, n_rai, q_lcl, n_lcl; };
@@ -122,12 +123,18 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(sizeof(FT) =
     int64_t col = 0;
     int32_t lev = 0;
     if (active) {
-        // level of the lane's first point: i0 = col·n_lev + k (one double multiply + fix-up per lane; exact below 2^53)
-        col = (int64_t)((double)i0 * io.inv_n_lev);
-        int64_t k64 = i0 - col * io.n_lev;
-        if (k64 < 0) { --col; k64 += io.n_lev; }
-        if (k64 >= io.n_lev) { ++col; k64 -= io.n_lev; }
-        lev = (int32_t)k64;
+        // level of the lane's first point: i0 = col·n_lev + k
+        if (io.n < ((int64_t)1 << 32)) {             // wave-uniform: one v_mul_hi_u32 (≈ 7 instructions against ≈ 40 of the Float64 quotient)
+            const uint32_t c32 = fastdiv((uint32_t)i0, io.lev_div);
+            col = c32;
+            lev = (int32_t)((uint32_t)i0 - c32 * (uint32_t)io.n_lev);
+        } else {                                     // one double multiply + fix-up per lane; exact below 2^53
+            col = (int64_t)((double)i0 * io.inv_n_lev);
+            int64_t k64 = i0 - col * io.n_lev;
+            if (k64 < 0) { --col; k64 += io.n_lev; }
+            if (k64 >= io.n_lev) { ++col; k64 -= io.n_lev; }
+            lev = (int32_t)k64;
+        }
         int32_t lv = lev;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
@@ -234,7 +241,7 @@ static int32_t column_entry(const WR *wr, const TH *tps, const VL *vel, const ST
     const bool intpow = sb_integer_exponents(*wr);
     CloudVelConsts<FT> cv{};
     if (cloud_vel) cv = make_cloud_vel_consts<FT>(wr->seifert_beheng.pdf_c, *cloud_vel);
-    const SbColIO<FT> io{rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, dq_lcl, dn_lcl, dq_rai, dn_rai, inv_dz, precip, n, n_lev, 1.0 / (double)n_lev};
+    const SbColIO<FT> io{rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai, dq_lcl, dn_lcl, dq_rai, dn_rai, inv_dz, precip, n, n_lev, 1.0 / (double)n_lev, make_fastdiv((uint32_t)n_lev)};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool limited = flags & CMX_SB2006_LIMITED;
     const int velk = sbv ? VEL_SB : chen_vel_kind<FT>(vel->chen2022);   // fitted Γ(b(ρ)+1) or the general instantiation (cmx_math.hpp ChenGamma)

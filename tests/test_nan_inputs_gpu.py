@@ -86,3 +86,45 @@ def test_nan_in_the_other_entries(dev):
     rho, T, q_tot, q_lcl, n_lcl, q_rai, n_rai = st2
     mp2 = P.Microphysics2MParams(sfx)
     _check(lambda c: tuple(cmx.sb2006_process_rates(mp2, tps, *c)), [q_tot, q_lcl, q_rai, n_lcl * rho, n_rai * rho, rho, T], 17)
+
+
+@pytest.mark.parametrize("sfx", ["f32", "f64"])
+def test_zero_and_negative_air_density(dev, sfx):
+    """ρ ≤ 0 (clamped to 0 like every negative input) is outside the entries' domain — include/cmx.h "Conventions" states ρ > 0 — but the
+    result must not look valid: Float32 reproduces the reference's own finite / NaN / ±Inf pattern output by output (its
+    hardware reciprocals and logarithms handle 0 and Inf like IEEE division); Float64 — whose finite-argument forms assume
+    ρ > 0 — returns a non-finite value wherever the reference does, and may return NaN where the reference still returns a finite number
+    or a signed infinity.  The SB2006 kernel takes ρ^(-1/2) with the full form in both float types (+Inf at ρ = 0, never NaN from the seed)."""
+    import numpy as np
+
+    import cmx
+    import oracle_binding as ob
+    from cmx import _abi
+    dt = torch.float32 if sfx == "f32" else torch.float64
+    rows2 = [(rho, T, qt, ql, nl, qr, nr) for rho in (0.0, -1.0) for (T, qt, ql, nl, qr, nr) in
+             ((290.0, 7e-3, 1e-3, 1e8, 5e-3, 1e4), (290.0, 7e-3, 0.0, 0.0, 0.0, 0.0), (250.0, 1e-4, 1e-3, 1e8, 0.0, 0.0), (300.0, 3e-2, 0.0, 0.0, 2e-3, 5e3))]
+    rows1 = [(rho, T, qt, ql, qi, qr, qs) for rho in (0.0, -1.0) for (T, qt, ql, qi, qr, qs) in
+             ((290.0, 1.5e-2, 1e-3, 0.0, 5e-3, 0.0), (260.0, 3e-3, 1e-4, 2e-4, 1e-4, 3e-3), (275.0, 4e-3, 0.0, 1e-4, 0.0, 1e-3), (240.0, 3e-4, 0.0, 0.0, 0.0, 0.0))]
+    arr2, arr1 = np.array(rows2).T, np.array(rows1).T
+
+    def cls(a):
+        a = np.asarray(a, dtype=np.float64)
+        return np.where(np.isnan(a), 3, np.where(np.isposinf(a), 2, np.where(np.isneginf(a), 1, 0)))
+
+    got2 = cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), P.Microphysics2MParams(sfx), P.ThermodynamicsParameters(sfx),
+                                            *[torch.tensor(a, dtype=dt, device=dev) for a in arr2], vel=cmx.SB2006VelType)
+    ref2 = ob.sb2006_warm_rain_tendencies(_abi.F64, P.WarmRainParams2M("f64").c, P.ThermodynamicsParameters("f64"), P.rain_vel_params("f64"),
+                                          _abi.CMX_SB2006_LIMITED | _abi.CMX_VEL_SB2006, *arr2, float32_gates=(sfx == "f32"), nthreads=1)
+    mp = P.Microphysics1MParams(sfx)
+    got1 = cmx.bulk_microphysics_tendencies_1m(cmx.Instantaneous(), cmx.Microphysics1Moment(), mp, P.ThermodynamicsParameters(sfx),
+                                               *[torch.tensor(a, dtype=dt, device=dev) for a in arr1])
+    mp64 = P.Microphysics1MParams("f64")
+    ref1 = ob.mp1m(_abi.F64, mp64.c, P.ThermodynamicsParameters("f64"), mp64.flags, *arr1, nthreads=1, float32_gates=(sfx == "f32"))
+    for got, ref in ((got2, ref2), (got1, ref1)):
+        for k, v in got._asdict().items():
+            g, r = cls(v.cpu().numpy()), cls(ref[k])
+            if sfx == "f32":
+                assert np.array_equal(g, r), (k, g, r)
+            else:
+                assert np.all((g != 0) | (r == 0)), (k, g, r)            # non-finite wherever the reference is non-finite
+                assert np.all((g == r) | (g == 3)), (k, g, r)            # and otherwise the reference's class, or NaN

@@ -83,7 +83,7 @@ def test_against_the_oracle_truncation(dev, oracle, ft):
     # … and the truncation IS visible in that band: the oracle (and the device with it) is off the true value by far more than `tol`
     band = slice(4000, 8000)
     trunc = np.abs(ref[band, 0] - sp.gammainc(a[band], x[band]))
-    assert np.max(trunc) > 100 * tol
+    assert np.max(trunc) > 30 * tol            # Float32, 20 terms: up to 8e-3; Float64, 30 terms: up to 1e-4
     parity.record(f"UT.gamma_inc vs the 20/30-term truncation {ft}", ft, {"P": P, "Q": Q}, {"P": ref[:, 0], "Q": ref[:, 1]}, family="utilities",
                   pinned_by="oracle restatement of src/Utilities.jl:93-144", scale={"P": np.ones_like(P), "Q": np.ones_like(Q)})
 

@@ -29,3 +29,5 @@ for k, d in tot.items():
     for c, v in sorted(d.items()):
         print(f'   {c:28s} {v / n[(k, c)]:16.1f} per launch')
 PY
+# the raw per-dispatch CSVs stay on the box (gpurun merges at most 64 MiB back)
+rm -rf "$OUT"/p1 "$OUT"/p2 "$OUT"/p3
