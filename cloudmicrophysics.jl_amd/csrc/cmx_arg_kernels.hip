@@ -508,10 +508,10 @@ __global__ __launch_bounds__(kArgColBS) void arg_activation_columns_kernel(const
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             const FT ls = k_ls[k][v];
-            const FT u = FT(0.32677907347424754) * M::rcp(ls) * (k_l2sm[k][v] + dl0[v]);   // 2 ln2/(3√2 ln σ) · log2(Sm_k/S_max)   AA:255
+            const FT u = FT(0.3267527144895157) * M::rcp(ls) * (k_l2sm[k][v] + dl0[v]);   // 2 ln2/(3√2 ln σ) · log2(Sm_k/S_max)   AA:255
             na[v] = FT(0.5) * k_N[k][v] * erfc_dev<FT>(u);                                  // N ½ (1 − erf u)   AA:257
             if constexpr (sizeof(FT) == 8 && CMX_ARG_LEAN_ERFC) asm volatile("" : "+v"(na[v]) : : "memory");
-            if constexpr (!N_ONLY) ma[v] = FT(0.5) * k_mm[k][v] * erfc_rel_dev<FT>(u - FT(2.1213203435596424) * ls);   // M/2 erfc(u − 3 ln σ √2/2)   AA:319
+            if constexpr (!N_ONLY) ma[v] = FT(0.5) * k_mm[k][v] * erfc_rel_dev<FT>(u - FT(2.121320343559643) * ls);   // M/2 erfc(u − 3 ln σ √2/2)   AA:319
         }
         if (io.N_act[k]) store_col<FT, VEC>(io.N_act[k], i, na);
         if constexpr (!N_ONLY) {

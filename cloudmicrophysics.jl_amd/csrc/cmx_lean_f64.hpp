@@ -4,9 +4,9 @@
 // 50–110 VALU instructions each (correctly rounded-ish, every special case, double-double range reduction), which
 // makes every Float64 kernel of this library VALU-issue-bound (one f64 instruction = 4 cycles per wave).  The
 // functions here are TABLE-DRIVEN (round 2): exp2 / exp reduce to |r| ≤ 1/256 with a 128-entry table of 2^(j/128) and a
-// degree-5 polynomial (14 Float64-rate instructions + 4 integer / LDS ones; the round-1 Cody–Waite + degree-13 version took 23),
+// degree-4 polynomial (13 Float64-rate instructions + 4 integer / LDS ones; the round-1 Cody–Waite + degree-13 version took 23),
 // log2 / log index a 128-entry table of (1/c, log2 c) by the top mantissa bits — integer operations on the high word, no
-// reciprocal, degree-7 polynomial in r = z/c − 1 (10 Float64-rate instructions + 7 integer / LDS; round 1: ≈30).  On the
+// reciprocal, degree-6 polynomial in r = z/c − 1 (9 Float64-rate instructions + 7 integer / LDS; round 1: ≈30).  On the
 // device the tables live in LDS (3 KiB per workgroup, filled by `tables_init()` — every kernel that evaluates Float64
 // functions calls Math<FT>::prepare() first); the host build reads them from static arrays.  ≤ 2 ulp (exp2, exp), ≤ 4 ulp
 // (log2, log; relative accuracy kept for arguments near 1: the table interval around 1 has c = 1 exactly) — three to four
@@ -131,21 +131,25 @@ CMX_LEAN_FN double exp_poly(double t) {
 struct Log2Entry { double invc, logc; };
 struct LeanCoefs {
     double x_lo, x_hi, k128, inv128;            // exp2: clamp, 128, −1/128
-    double e2[5];                               // ln2⁵/5!, ln2⁴/4!, ln2³/3!, ln2²/2!, ln2
+    double e2[4];                               // (2ʳ − 1)/r on |r| ≤ 1/256, degree 3, highest power first (round 4: Chebyshev fit, 1.5e-16 relative to 2ʳ)
     double ex_lo, ex_hi, k128_log2e, ln2_128_hi, ln2_128_lo;
-    double ee[5];                               // 1/120, 1/24, 1/6, 1/2, 1
-    double l2[7];                               // log2e/7, −log2e/6, …, log2e
-    double ln[7];                               // 1/7, −1/6, …, 1
+    double ee[4];                               // (eʳ − 1)/r on |r| ≤ ln2/256, degree 3
+    double l2[6];                               // log2(1 + r)/r on |r| ≤ 2⁻⁸, degree 5 (1.6e-17 relative; the constant term is log2 e exactly)
+    double ln[6];                               // ln(1 + r)/r likewise (constant term 1, linear term −½ exactly)
     double minus_one, ln2, two64, sixty4;
 };
+// Round 4: the polynomials are one term shorter than the Taylor forms of round 2 (exp: degree 3 instead of 4 for (2ʳ − 1)/r, log: degree 5
+// instead of 6 for log2(1 + r)/r) at the same accuracy — Chebyshev interpolants on the reduced interval (mpmath, 200 bits; the Taylor
+// truncations were 5e-19 / 2e-18, far below one ulp: a term each was spent on nothing).  One Float64 FMA less per call: ≈ 22 of the 621
+// instructions of an SB2006 point.
 #define CMX_LEAN_COEFS                                                                                                          \
     {-1100.0, 1100.0, 128.0, -0.0078125,                                                                                       \
-     {1.3333558146428443e-03, 9.6181291076284772e-03, 5.5504108664821580e-02, 2.4022650695910071e-01, 6.9314718055994531e-01}, \
+     {0.009618131458020956, 0.05550412901021981, 0.24022650695909623, 0.6931471805599065},                                     \
      -760.0, 760.0, 184.66496523378732, 0x1.62e42fefa0000p-8, 1.2864023111638345e-14,                                        \
-     {1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0},                                                                           \
-     {2.0609929155556620e-01, -2.4044917348149390e-01, 2.8853900817779268e-01, -3.6067376022224085e-01,                       \
-      4.8089834696298783e-01, -7.2134752044448170e-01, 1.4426950408889634e+00},                                               \
-     {1.0 / 7.0, -1.0 / 6.0, 0.2, -0.25, 1.0 / 3.0, -0.5, 1.0},                                                                \
+     {0.04166667684879449, 0.16666672775943595, 0.4999999999999907, 0.999999999999944},                                        \
+     {-0.24045330112179908, 0.2885437254791991, -0.36067376019862224, 0.4808983469359951, -0.7213475204444817,                 \
+      1.4426950408889634},                                                                                                     \
+     {-0.16666952772890656, 0.20000326978416968, -0.24999999998362882, 0.3333333333146234, -0.5, 1.0},                         \
      -1.0, 0.6931471805599453, 1.8446744073709552e19, 64.0}
 #if defined(__HIP_DEVICE_COMPILE__)
 static __device__ const double kExp2Tab[128] = {CMX_LEAN_EXP2_TABLE};
@@ -205,7 +209,7 @@ inline int32_t lo_word(double x) { uint64_t u; std::memcpy(&u, &x, 8); return (i
 inline double from_words(int32_t hi, int32_t lo) { const uint64_t u = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; double x; std::memcpy(&x, &u, 8); return x; }
 #endif
 
-// 2ʳ − 1 for |r| ≤ 1/256: r·(C1 + r·(C2 + … r·C5)), C_k = ln2ᵏ/k!  (truncation (r ln2)⁶/6! ≤ 6e-19)
+// 2ʳ − 1 for |r| ≤ 1/256: r·(C1 + r·(C2 + r·(C3 + r·C4))), a Chebyshev fit of (2ʳ − 1)/r (LeanCoefs::e2; error 1.5e-16 relative to 2ʳ)
 // sc(c): a polynomial coefficient as an SGPR pair.  With the coefficients written as literals (CMX_LEAN_COEFS_IN_LDS=0) the
 // compiler is free to build each one in a VGPR pair instead (two v_mov_b32 per coefficient in front of a v_fmac_f64 — VALU
 // instructions on the port that bounds these kernels); the empty asm pins it to the scalar side (two s_mov_b32, SALU port).
@@ -231,7 +235,6 @@ CMX_LEAN_FN double exp2m1_small(double r, const LeanCoefs &K) {
     p = fma_(p, r, vc(K.e2[1]));
     p = fma_(p, r, sc(K.e2[2]));
     p = fma_(p, r, sc(K.e2[3]));
-    p = fma_(p, r, sc(K.e2[4]));
     return p * r;
 }
 // eʳ − 1 for |r| ≤ ln2/256
@@ -240,7 +243,6 @@ CMX_LEAN_FN double expm1_small(double r, const LeanCoefs &K) {
     p = fma_(p, r, vc(K.ee[1]));
     p = fma_(p, r, sc(K.ee[2]));
     p = fma_(p, r, sc(K.ee[3]));
-    p = fma_(p, r, sc(K.ee[4]));
     return p * r;
 }
 // int conversion that saturates (the device's v_cvt_i32_f64 does; the host cast would be undefined out of range)
@@ -383,24 +385,22 @@ CMX_LEAN_FN Log2Parts log2_reduce(double x, const LeanCoefs &K) {
     const Log2Entry e = log2_tab((tmp >> 13) & 127);
     return {(double)k + e.logc, fma_(z, e.invc, K.minus_one)};
 }
-// log2(1 + r)/r = B1 + r·(B2 + … r·B7), B_k = (−1)^(k+1) log2e / k, |r| ≤ 2⁻⁸ (truncation r⁷/8 relative ≤ 2e-18); ln likewise
-CMX_LEAN_FN double poly7s(double r, const double (&b)[7]) {                   // coefficients on the scalar side (sc above)
+// log2(1 + r)/r = B1 + r·(B2 + … r·B6) on |r| ≤ 2⁻⁸, a Chebyshev fit (LeanCoefs::l2; error 1.6e-17 relative, B1 = log2 e exactly); ln likewise
+CMX_LEAN_FN double poly6s(double r, const double (&b)[6]) {                   // coefficients on the scalar side (sc above)
     double p = sc(b[0]);
     p = fma_(p, r, vc(b[1]));
     p = fma_(p, r, sc(b[2]));
     p = fma_(p, r, sc(b[3]));
     p = fma_(p, r, sc(b[4]));
-    p = fma_(p, r, sc(b[5]));
-    return fma_(p, r, sc(b[6]));
+    return fma_(p, r, sc(b[5]));
 }
-CMX_LEAN_FN double poly7(double r, const double (&b)[7]) {
+CMX_LEAN_FN double poly6(double r, const double (&b)[6]) {
     double p = b[0];
     p = fma_(p, r, b[1]);
     p = fma_(p, r, b[2]);
     p = fma_(p, r, b[3]);
     p = fma_(p, r, b[4]);
-    p = fma_(p, r, b[5]);
-    return fma_(p, r, b[6]);
+    return fma_(p, r, b[5]);
 }
 CMX_LEAN_FN bool log_needs_rescue(double x) {            // anything but a positive normal number
 #if defined(CMX_LEAN_NO_RESCUE)
@@ -451,10 +451,10 @@ CMX_LEAN_FN double log2(double x) {
     const LeanCoefs &K = coefs();
 #if CMX_LEAN_RESCUE_REPEAT
     const Log2Parts q = log2_reduce(x, K);
-    double y = fma_(q.r, poly7s(q.r, K.l2), q.hi);
+    double y = fma_(q.r, poly6s(q.r, K.l2), q.hi);
     if (log_needs_rescue(x)) {                                                // no lane takes this for ordinary arguments
         const Log2Parts s = log2_reduce(x * K.two64, K);                      // positive subnormal: ×2⁶⁴
-        y = fma_(s.r, poly7s(s.r, K.l2), s.hi - K.sixty4);
+        y = fma_(s.r, poly6s(s.r, K.l2), s.hi - K.sixty4);
         y = x != x ? x : log_special(x, y);
     }
     return y;
@@ -462,7 +462,7 @@ CMX_LEAN_FN double log2(double x) {
     const bool rare = log_needs_rescue(x);                                    // no lane takes the two blocks for ordinary arguments
     if (rare) x = log_prescale(x, K.two64);
     const Log2Parts q = log2_reduce(x, K);
-    double y = fma_(q.r, poly7s(q.r, K.l2), q.hi);
+    double y = fma_(q.r, poly6s(q.r, K.l2), q.hi);
     if (rare) y = log_postfix(x, y - K.sixty4);
     return y;
 #endif
@@ -477,10 +477,10 @@ CMX_LEAN_FN double log(double x) {
     const LeanCoefs &K = coefs();
 #if CMX_LEAN_RESCUE_REPEAT
     const Log2Parts q = log2_reduce(x, K);
-    double y = fma_(q.hi, K.ln2, q.r * poly7s(q.r, K.ln));
+    double y = fma_(q.hi, K.ln2, q.r * poly6s(q.r, K.ln));
     if (log_needs_rescue(x)) {
         const Log2Parts s = log2_reduce(x * K.two64, K);
-        y = fma_(s.hi - K.sixty4, K.ln2, s.r * poly7s(s.r, K.ln));
+        y = fma_(s.hi - K.sixty4, K.ln2, s.r * poly6s(s.r, K.ln));
         y = x != x ? x : log_special(x, y);
     }
     return y;
@@ -488,7 +488,7 @@ CMX_LEAN_FN double log(double x) {
     const bool rare = log_needs_rescue(x);
     if (rare) x = log_prescale(x, K.two64);
     const Log2Parts q = log2_reduce(x, K);
-    const double rp = q.r * poly7s(q.r, K.ln);
+    const double rp = q.r * poly6s(q.r, K.ln);
     double y = fma_(q.hi, K.ln2, rp);
     if (rare) y = log_postfix(x, fma_(q.hi - K.sixty4, K.ln2, rp));
     return y;
@@ -670,20 +670,20 @@ CMX_LEAN_FN double log(double x, const PinnedCoefs &k) {
 
 // ---- table-driven eˣ / ln x with the coefficients pinned in VGPRs (round 2) -------------------------------------------------------
 // The quadrature loops of the P3 kernels evaluate ≈ 1 log + 3–4 exp per node, hundreds of nodes per state: the coefficients must not
-// be rematerialised per call (PinnedCoefs above), and the table-driven forms need 8 fewer Float64 FMAs per exp (degree 5 instead of
-// 13) and 8 fewer per log (degree 7, no reciprocal) for one LDS lookup each.  20 pinned values (40 VGPRs; PinnedCoefs: 29).
+// be rematerialised per call (PinnedCoefs above), and the table-driven forms need 9 fewer Float64 FMAs per exp (degree 4 instead of
+// 13) and 9 fewer per log (degree 6, no reciprocal) for one LDS lookup each.  18 pinned values (36 VGPRs; PinnedCoefs: 29).
 struct TabCoefs {
-    double ee[5];                                // 1/120, 1/24, 1/6, 1/2, 1
+    double ee[4];                                // (eʳ − 1)/r, degree 3 (LeanCoefs::ee)
     double k128_log2e, ln2_128_hi, ln2_128_lo, ex_lo, ex_hi;
-    double ln[7];                                // 1/7, −1/6, 1/5, −1/4, 1/3, −1/2, 1
+    double ln[6];                                // ln(1 + r)/r, degree 5 (LeanCoefs::ln)
     double ln2, two64, sixty4;
 };
 CMX_LEAN_FN TabCoefs tab_coefs() {
     TabCoefs k;
-    const double ee[5] = {1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0};
-    const double ln[7] = {1.0 / 7.0, -1.0 / 6.0, 0.2, -0.25, 1.0 / 3.0, -0.5, 1.0};
-    for (int i = 0; i < 5; ++i) { k.ee[i] = ee[i]; pin(k.ee[i]); }
-    for (int i = 0; i < 7; ++i) { k.ln[i] = ln[i]; pin(k.ln[i]); }
+    const double ee[4] = {0.04166667684879449, 0.16666672775943595, 0.4999999999999907, 0.999999999999944};
+    const double ln[6] = {-0.16666952772890656, 0.20000326978416968, -0.24999999998362882, 0.3333333333146234, -0.5, 1.0};
+    for (int i = 0; i < 4; ++i) { k.ee[i] = ee[i]; pin(k.ee[i]); }
+    for (int i = 0; i < 6; ++i) { k.ln[i] = ln[i]; pin(k.ln[i]); }
     k.k128_log2e = 184.66496523378732; k.ln2_128_hi = 0x1.62e42fefa0000p-8; k.ln2_128_lo = 1.2864023111638345e-14;
     k.ex_lo = -760.0; k.ex_hi = 760.0; k.ln2 = 0.6931471805599453; k.two64 = 1.8446744073709552e19; k.sixty4 = 64.0;
     pin(k.k128_log2e); pin(k.ln2_128_hi); pin(k.ln2_128_lo); pin(k.ex_lo); pin(k.ex_hi); pin(k.ln2); pin(k.two64); pin(k.sixty4);
@@ -697,7 +697,7 @@ CMX_LEAN_FN double exp(double x, const TabCoefs &k) {
     const int ki = (int)kd;
     const double s = exp2_tab(ki & 127);
     double p = k.ee[0];
-    for (int i = 1; i < 5; ++i) p = fma_(p, r, k.ee[i]);
+    for (int i = 1; i < 4; ++i) p = fma_(p, r, k.ee[i]);
     const double y = ldexp_(fma_(s, p * r, s), ki >> 7);
     return x != x ? x : y;
 }
@@ -711,7 +711,7 @@ CMX_LEAN_FN double exp_fin(double x, const TabCoefs &k) {                     //
     const int ki = sat_int(kd);
     const double s = exp2_tab(ki & 127);
     double p = k.ee[0];
-    for (int i = 1; i < 5; ++i) p = fma_(p, r, k.ee[i]);
+    for (int i = 1; i < 4; ++i) p = fma_(p, r, k.ee[i]);
     return ldexp_(fma_(s, p * r, s), ki >> 7);
 #endif
 }
@@ -726,10 +726,10 @@ CMX_LEAN_FN Log2Parts log2_reduce_m1(double x) {          // log2_reduce with th
 CMX_LEAN_FN double log(double x, const TabCoefs &k) {
 #if CMX_LEAN_RESCUE_REPEAT
     const Log2Parts q = log2_reduce_m1(x);
-    double y = fma_(q.hi, k.ln2, q.r * poly7(q.r, k.ln));
+    double y = fma_(q.hi, k.ln2, q.r * poly6(q.r, k.ln));
     if (log_needs_rescue(x)) {
         const Log2Parts s = log2_reduce_m1(x * k.two64);
-        y = fma_(s.hi - k.sixty4, k.ln2, s.r * poly7(s.r, k.ln));
+        y = fma_(s.hi - k.sixty4, k.ln2, s.r * poly6(s.r, k.ln));
         y = x != x ? x : log_special(x, y);
     }
     return y;
@@ -737,7 +737,7 @@ CMX_LEAN_FN double log(double x, const TabCoefs &k) {
     const bool rare = log_needs_rescue(x);
     if (rare) x = log_prescale(x, k.two64);
     const Log2Parts q = log2_reduce_m1(x);
-    const double rp = q.r * poly7(q.r, k.ln);
+    const double rp = q.r * poly6(q.r, k.ln);
     double y = fma_(q.hi, k.ln2, rp);
     if (rare) y = log_postfix(x, fma_(q.hi - k.sixty4, k.ln2, rp));
     return y;

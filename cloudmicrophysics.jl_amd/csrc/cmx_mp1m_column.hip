@@ -49,10 +49,13 @@ __global__ __launch_bounds__(BS) void mp1m_column_kernel(const Mp1mColKernArgs<F
     using M = Math<FT>;
     const auto &a = front_consts<FT, true>(a0);
     __shared__ __align__(16) FT halo[BS + 1][4];   // fluxes of every lane's FIRST point, + slot BS for the point that follows the tile
-    const int64_t tile0 = (int64_t)blockIdx.x * BS;
+    // tiles overlap by one lane, as in sb2006_column_kernel (cmx_sb2006_column.hip): lane BS−1 evaluates the next tile's first vector and only
+    // supplies the flux its first point sends down; the flux-only evaluation of that point runs in the last workgroup of a launch only
+    const int64_t tile0 = (int64_t)blockIdx.x * (BS - 1);
     const int64_t v = tile0 + threadIdx.x;
     const bool active = v < nvec;
     const int64_t nvalid = nvec - tile0 < BS ? nvec - tile0 : BS;       // active lanes of this tile (≥ 1)
+    const bool owner = threadIdx.x < BS - 1;
     const int64_t i0 = first + v * VEC;                                 // flat index of the lane's first point
 
     FT x[7][VEC];
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(BS) void mp1m_column_kernel(const Mp1mColKernArgs<F
         for (int j = 0; j < 7; ++j) load_col<FT, VEC, true>(io.in[j] + first, v, x[j]);
     }
     Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS while the loads fly (every lane of the workgroup reaches the barrier inside); no-op for Float32
-    if (threadIdx.x == BS - 1) {   // the point after the tile, from the raw columns
+    if (nvalid < BS && threadIdx.x == BS - 1) {   // last workgroup of the launch: the point after its last vector, from the raw columns
         const int64_t e = first + (tile0 + nvalid) * VEC;
         SedFlux4<FT> f{{FT(0), FT(0), FT(0), FT(0)}};
         if (e < io.n) f = mp1m_sed_fluxes<FT, GENERAL_GAMMA>(a.vc, io.in[0][e], io.in[3][e], io.in[4][e], io.in[5][e], io.in[6][e]);
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(BS) void mp1m_column_kernel(const Mp1mColKernArgs<F
         for (int s = 0; s < 4; ++s) halo[threadIdx.x][s] = F[0].f[s];
     }
     __syncthreads();
-    if (!active) return;
+    if (!active || !owner) return;
     const int up = (threadIdx.x + 1 < nvalid) ? threadIdx.x + 1 : BS;
     FT o[4][VEC];
 #pragma unroll
@@ -137,7 +140,7 @@ template <typename FT, int VEC>
 static void launch_column_1m(bool def, bool lin, bool general, const Mp1mColKernArgs<FT> &a, const Mp1mColIO<FT> &io, int64_t first, int64_t nvec,
                              hipStream_t s) {
     if (nvec <= 0) return;
-    const dim3 grid((unsigned)((nvec + kColBS1m - 1) / kColBS1m)), block(kColBS1m);
+    const dim3 grid((unsigned)((nvec + (kColBS1m - 1) - 1) / (kColBS1m - 1))), block(kColBS1m);      // tiles overlap by one lane
     constexpr uint32_t DEF = CMX_1M_DEFAULT_OPTIONS | kDefExpBit;
 #define CMX_L(FL, LN, GG) CMX_LAUNCH_FRONT((mp1m_column_kernel<FT, FL, LN, GG, VEC, kColBS1m>), grid, block, 0, s, a, io, first, nvec)
 #define CMX_G(FL, LN) do { if (general) CMX_L(FL, LN, true); else CMX_L(FL, LN, false); } while (0)

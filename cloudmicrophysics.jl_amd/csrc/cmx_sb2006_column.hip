@@ -88,10 +88,16 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(sizeof(FT) =
     using M = Math<FT>;
     // fluxes of every lane's FIRST point, + slot BS for the point that follows the tile
     __shared__ __align__(16) FT halo[BS + 1][4];
-    const int64_t tile0 = (int64_t)blockIdx.x * BS;
+    // Tiles OVERLAP by one lane (round 4): workgroup b owns the vectors [b(BS−1), (b+1)(BS−1)); its lane BS−1 evaluates the first vector of the
+    // next tile like any other lane and only supplies the flux its first point sends down to lane BS−2.  The redundant work is 1/(BS−1) of the
+    // launch; evaluating that one point on its own (rounds 2–3) made the last wave of every workgroup issue the whole flux function once
+    // more with one lane active — 12 of the Float32 kernel's 302 instructions per point (PMC).  Only the LAST workgroup of a launch, whose
+    // last owned vector is followed by another launch's (or no) point, still takes that path.
+    const int64_t tile0 = (int64_t)blockIdx.x * (BS - 1);
     const int64_t v = tile0 + threadIdx.x;
     const bool active = v < nvec;
     const int64_t nvalid = nvec - tile0 < BS ? nvec - tile0 : BS;       // active lanes of this tile (≥ 1)
+    const bool owner = threadIdx.x < BS - 1;                            // lane BS−1 never stores: its vector belongs to the next workgroup
     const int64_t i0 = first + v * VEC;                                 // flat index of the lane's first point
 
     // all global loads first: the lane's seven 16-byte vectors, and (last lane only) the five scalars of the point after the tile
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(sizeof(FT) =
     Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS while the loads fly (every lane of the workgroup reaches the barrier inside); no-op for Float32
     // the point after the tile (another workgroup's, or another launch's, first point) is evaluated here from the raw columns —
     // before the lane's own points, while nothing else is live in registers
-    if (threadIdx.x == BS - 1) {
+    if (nvalid < BS && threadIdx.x == BS - 1) {        // last workgroup of the launch only (lane BS−1 has no vector there)
         const int64_t e = first + (tile0 + nvalid) * VEC;
         SedFlux<FT> f{FT(0), FT(0), FT(0), FT(0)};
         if (e < io.n) f = sed_fluxes_of_point<FT, LIMITED, VEL, CLOUD>(front_consts<FT>(c), cv, io.rho[e], io.q_lcl[e], io.n_lcl[e], io.q_rai[e], io.n_rai[e]);
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(sizeof(FT) =
         halo[threadIdx.x][3] = F[0].n_lcl;
     }
     __syncthreads();
-    if (!active) return;
+    if (!active || !owner) return;
     const int up = (threadIdx.x + 1 < nvalid) ? threadIdx.x + 1 : BS;
     const SedFlux<FT> above{halo[up][0], halo[up][1], halo[up][2], halo[up][3]};
     FT o[4][VEC];
@@ -202,7 +208,7 @@ template <typename FT, int VEC>
 static void launch_column(bool limited, int vel, bool cloud, bool intpow, const SbConsts<FT> &c, const CloudVelConsts<FT> &cv, const SbColIO<FT> &io,
                           int64_t first, int64_t nvec, hipStream_t s) {
     if (nvec <= 0) return;
-    const int64_t grid = (nvec + kColBS - 1) / kColBS;
+    const int64_t grid = (nvec + (kColBS - 1) - 1) / (kColBS - 1);      // tiles overlap by one lane (sb2006_column_kernel)
     // intpow: the integer-exponent instantiation of the point function (cmx_sb2006.hpp INTPOW)
 #define CMX_LAUNCH(L, V, C)                                                                                                                          \
     do {                                                                                                                                             \
