@@ -5,6 +5,7 @@ Host-side mirror of the reference's module layout for the hot path:
   cmx.microphysics0m    ↔ CloudMicrophysics.Microphysics0M (CM0) + the 0M methods of BMT
   cmx.bulk_tendencies   ↔ CloudMicrophysics.BulkMicrophysicsTendencies (BMT) + per-process CM2 rates
   cmx.utilities         ↔ CloudMicrophysics.Utilities (UT): gamma_inc / gamma_inc_inv over columns
+  cmx.distribution_tools ↔ CloudMicrophysics.DistributionTools (DT) + the SB2006 PSD accessors of CM2
   cmx.synthetic         ↔ the state generator of test/gpu_performance.jl:80-136
   cmx.sharding          ↔ (no reference equivalent) one-process-per-GPU sharding + RCCL diagnostic sums
 All compute goes through libcmx.so (include/cmx.h); there is no CPU fallback.
@@ -36,5 +37,6 @@ from .p3 import (P3Melt, P3Shape, P3ShapeVelocities, P3Velocities, p3_shape_and_
                  p3_shape, p3_terminal_velocities)
 
 from .utilities import GammaInc, gamma_inc, gamma_inc_inv  # noqa: F401
+from .distribution_tools import Distribution, SizeDistribution, exponential_distribution, generalized_gamma, size_distribution  # noqa: F401
 
 __version__ = "0.1.0"

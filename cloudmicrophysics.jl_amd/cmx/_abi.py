@@ -25,6 +25,7 @@ CMX_P3_NO_ASPECT_RATIO = 1 << 2
 CMX_P3_RAIN_PDF_LIMITED = 1 << 3
 CMX_FREEZE_CLOUD_PSD = 1 << 4
 CMX_QUAD_MAX = 128
+CMX_PSD_CLOUD = 1 << 5
 CMX_COLUMN_SUMS_MAX_COLS = 16
 CMX_COLUMN_SUMS_PARTIALS = 1024
 

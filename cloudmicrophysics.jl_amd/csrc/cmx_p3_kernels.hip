@@ -493,9 +493,196 @@ template <typename FT> static int32_t gamma_inc_inv_entry(int64_t n, const FT *a
     return CMX_OK;
 }
 
+// ---- size-distribution helpers over columns (src/DistributionTools.jl:44-151, src/Microphysics2M.jl:270-354) ----------------------------
+// Helper entries (diagnostics, integration bounds a host model asks for): plain one-point-per-lane kernels on the OCML functions; the
+// incomplete gamma functions are the device routines of cmx_p3.hpp (the reference's DT functions call UT.gamma_inc / UT.gamma_inc_inv).
+template <typename FT> struct DistMath;
+template <> struct DistMath<float> {
+    static __device__ __forceinline__ float log(float x) { return ::logf(x); }
+    static __device__ __forceinline__ float exp(float x) { return ::expf(x); }
+    static __device__ __forceinline__ float pow(float x, float y) { return ::powf(x, y); }
+    static __device__ __forceinline__ float cbrt(float x) { return ::cbrtf(x); }
+    static __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
+    static __device__ __forceinline__ float log1p(float x) { return ::log1pf(x); }
+    static __device__ __forceinline__ float expm1(float x) { return ::expm1f(x); }
+};
+template <> struct DistMath<double> {
+    static __device__ __forceinline__ double log(double x) { return ::log(x); }
+    static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
+    static __device__ __forceinline__ double pow(double x, double y) { return ::pow(x, y); }
+    static __device__ __forceinline__ double cbrt(double x) { return ::cbrt(x); }
+    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    static __device__ __forceinline__ double log1p(double x) { return ::log1p(x); }
+    static __device__ __forceinline__ double expm1(double x) { return ::expm1(x); }
+};
+// DT.generalized_gamma_quantile(ν, μ, B, Y) — :44-47
+template <typename FT> __device__ __forceinline__ FT gg_quantile_dev(FT nu, FT mu, FT B, FT Y) {
+    return DistMath<FT>::pow(gamma_inc_inv_dev<FT>((nu + FT(1)) / mu, Y, FT(1) - Y) / B, FT(1) / mu);
+}
+// DT.generalized_gamma_cdf(ν, μ, B, x) — :75-82 (its DomainErrors, μ ≤ 0 or B ≤ 0, give NaN)
+template <typename FT> __device__ __forceinline__ FT gg_cdf_dev(FT nu, FT mu, FT B, FT x) {
+    if (!(mu > FT(0)) || !(B > FT(0))) return Math<FT>::nan();
+    if (x <= FT(0)) return FT(0);
+    const FT a = (nu + FT(1)) / mu;
+    return gamma_inc_dev<FT>(a, B * DistMath<FT>::pow(x, mu), PM<FT>::lgamma(a), true);
+}
+// DT.exponential_cdf(D_mean, D) = exp(log1mexp(−D/D_mean)) — :124-129; DT.exponential_quantile(D_mean, Y) = exp(log D_mean + cloglog Y) — :146-151
+template <typename FT> __device__ __forceinline__ FT exp_cdf_dev(FT D_mean, FT D) {
+    using DM = DistMath<FT>;
+    if (!(D_mean > FT(0))) return Math<FT>::nan();
+    if (D < FT(0)) return FT(0);
+    const FT x = -D / D_mean;
+    return DM::exp(x > FT(-0.6931471805599453) ? DM::log(-DM::expm1(x)) : DM::log1p(-DM::exp(x)));      // LogExpFunctions.log1mexp
+}
+template <typename FT> __device__ __forceinline__ FT exp_quantile_dev(FT D_mean, FT Y) {
+    using DM = DistMath<FT>;
+    if (!(Y >= FT(0) && Y <= FT(1)) || !(D_mean > FT(0))) return Math<FT>::nan();
+    return DM::exp(DM::log(D_mean) + DM::log(-DM::log1p(-Y)));                                              // LogExpFunctions.cloglog
+}
+template <typename FT>
+__global__ __launch_bounds__(kBlock) void generalized_gamma_kernel(const FT nu, const FT mu, const int64_t n, const FT *__restrict__ B,
+                                                                  const FT *__restrict__ Y, const FT *__restrict__ x, FT *__restrict__ quantile,
+                                                                  FT *__restrict__ cdf) {
+    Math<FT>::prepare();
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    if (quantile) quantile[i] = gg_quantile_dev<FT>(nu, mu, B[i], Y[i]);
+    if (cdf) cdf[i] = gg_cdf_dev<FT>(nu, mu, B[i], x[i]);
+}
+template <typename FT>
+__global__ __launch_bounds__(kBlock) void exponential_distribution_kernel(const int64_t n, const FT *__restrict__ D_mean, const FT *__restrict__ Y,
+                                                                         const FT *__restrict__ D, FT *__restrict__ quantile, FT *__restrict__ cdf) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    if (quantile) quantile[i] = exp_quantile_dev<FT>(D_mean[i], Y[i]);
+    if (cdf) cdf[i] = exp_cdf_dev<FT>(D_mean[i], D[i]);
+}
+// pdf parameters of the two SB2006 size distributions, restated as the reference writes them (CM2:67-110, 176-191, 227-236): these are
+// diagnostics — the rate kernels carry their own log2-domain forms
+template <typename FT> struct PsdPar {
+    FT nu_c, mu_c, rho_w_c, lg_z1, lg_z2;                                   // CloudParticlePDF_SB2006
+    FT xr_min, xr_max, N0_min, N0_max, lam_min, lam_max, rho_w_r;            // RainParticlePDF_SB2006 (limited fields used iff LIMITED)
+    FT p;
+};
+template <typename FT, bool CLOUD, bool LIMITED>
+__global__ __launch_bounds__(kBlock) void sb2006_size_distribution_kernel(const PsdPar<FT> k, const int64_t n, const FT *__restrict__ q,
+                                                                         const FT *__restrict__ rho, const FT *__restrict__ N, const FT *__restrict__ D,
+                                                                         FT *__restrict__ n_D, FT *__restrict__ D_min, FT *__restrict__ D_max) {
+    Math<FT>::prepare();
+    using DM = DistMath<FT>;
+    using M = Math<FT>;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const FT eps = M::eps(), pi = FT(3.14159265358979323846);
+    const FT qi = q[i], ri = rho[i], Ni = N[i];
+    const FT sq = M::max(qi, eps), sN = M::max(Ni, eps), L = ri * sq;
+    if constexpr (CLOUD) {
+        // log_pdf_cloud_parameters_mass CM2:176-191, pdf_cloud_parameters :227-236
+        const FT z1 = (k.nu_c + FT(1)) / k.mu_c;
+        FT logB = -k.mu_c * (DM::log(L / sN) + k.lg_z1 - k.lg_z2);
+        FT logA = DM::log(k.mu_c) + DM::log(sN) + z1 * logB - k.lg_z1;
+        if (Ni < eps || qi < eps) { logA = -INFINITY; logB = INFINITY; }
+        const FT k_m = k.rho_w_c * pi / FT(6);
+        const FT logN0c = logA + DM::log(FT(3)) + (k.nu_c + FT(1)) * DM::log(k_m);
+        const FT lam_c = DM::exp(logB) * DM::pow(k_m, k.mu_c);
+        const FT nu_D = FT(3) * k.nu_c + FT(2), mu_D = FT(3) * k.mu_c;
+        if (n_D) n_D[i] = logN0c == -INFINITY ? FT(0) : DM::exp(logN0c + nu_D * DM::log(D[i]) - lam_c * DM::pow(D[i], mu_D));     // CM2:295-303
+        if (D_min) D_min[i] = gg_quantile_dev<FT>(nu_D, mu_D, lam_c, k.p);                                                        // CM2:346-354
+        if (D_max) D_max[i] = gg_quantile_dev<FT>(nu_D, mu_D, lam_c, FT(1) - k.p);
+    } else {
+        // pdf_rain_parameters CM2:67-110
+        FT N0r, Dr_mean;
+        bool cond;
+        if constexpr (!LIMITED) {
+            const FT lam = DM::cbrt(pi * k.rho_w_r / (L / sN));
+            N0r = lam * sN; Dr_mean = FT(1) / lam;
+            cond = Ni < eps || qi < eps;
+        } else {
+            const FT xt = clampv(L / sN, k.xr_min, k.xr_max);                                            // Eq. 94
+            N0r = clampv(sN * DM::cbrt(pi * k.rho_w_r / xt), k.N0_min, k.N0_max);                        // Eq. 95
+            const FT lam = clampv(DM::sqrt(DM::sqrt(pi * k.rho_w_r * N0r / L)), k.lam_min, k.lam_max);   // Eq. 96
+            Dr_mean = FT(1) / lam;
+            cond = Ni < eps && qi < eps;
+        }
+        if (cond) { N0r = FT(0); Dr_mean = FT(0); }
+        if (n_D) n_D[i] = N0r == FT(0) ? FT(0) : N0r * DM::exp(-D[i] / Dr_mean);                          // CM2:270-277
+        const bool none = Dr_mean == FT(0);                                                              // CM2:336-345
+        if (D_min) D_min[i] = none ? FT(0) : exp_quantile_dev<FT>(Dr_mean, k.p);
+        if (D_max) D_max[i] = none ? FT(0) : exp_quantile_dev<FT>(Dr_mean, FT(1) - k.p);
+    }
+}
+
+template <typename FT> static int32_t generalized_gamma_entry(FT nu, FT mu, int64_t n, const FT *B, const FT *Y, const FT *x, FT *quantile, FT *cdf, void *stream) {
+    if (n < 0) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;
+    if (n == 0) return CMX_OK;
+    if (!B || (!quantile && !cdf) || (quantile && !Y) || (cdf && !x)) return CMX_ERR_BAD_ARG;
+    hipLaunchKernelGGL((generalized_gamma_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), nu, mu, n,
+                       B, Y, x, quantile, cdf);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+template <typename FT> static int32_t exponential_distribution_entry(int64_t n, const FT *D_mean, const FT *Y, const FT *D, FT *quantile, FT *cdf, void *stream) {
+    if (n < 0) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;
+    if (n == 0) return CMX_OK;
+    if (!D_mean || (!quantile && !cdf) || (quantile && !Y) || (cdf && !D)) return CMX_ERR_BAD_ARG;
+    hipLaunchKernelGGL((exponential_distribution_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), n,
+                       D_mean, Y, D, quantile, cdf);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+template <typename FT, typename PC, typename PR>
+static int32_t sb2006_size_distribution_entry(const PC *pdf_c, const PR *pdf_r, uint32_t flags, FT p, int64_t n, const FT *q, const FT *rho, const FT *N,
+                                              const FT *D, FT *n_D, FT *D_min, FT *D_max, void *stream) {
+    const bool cloud = flags & CMX_PSD_CLOUD, limited = flags & CMX_SB2006_LIMITED;
+    if (n < 0 || (flags & ~(uint32_t)(CMX_PSD_CLOUD | CMX_SB2006_LIMITED)) || (cloud ? !pdf_c : !pdf_r)) return CMX_ERR_BAD_ARG;
+    if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;
+    if (n == 0) return CMX_OK;
+    if (!q || !rho || !N || (!n_D && !D_min && !D_max) || (n_D && !D)) return CMX_ERR_BAD_ARG;
+    PsdPar<FT> k{};
+    if (cloud) { k.nu_c = pdf_c->nu_c; k.mu_c = pdf_c->mu_c; k.rho_w_c = pdf_c->rho_w; k.lg_z1 = pdf_c->loggamma_z1; k.lg_z2 = pdf_c->loggamma_z2; }
+    else {
+        k.xr_min = pdf_r->xr_min; k.xr_max = pdf_r->xr_max; k.N0_min = pdf_r->N0_min; k.N0_max = pdf_r->N0_max; k.lam_min = pdf_r->lambda_min;
+        k.lam_max = pdf_r->lambda_max; k.rho_w_r = pdf_r->rho_w;
+    }
+    k.p = p;
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (cloud) hipLaunchKernelGGL((sb2006_size_distribution_kernel<FT, true, false>), grid, block, 0, st, k, n, q, rho, N, D, n_D, D_min, D_max);
+    else if (limited) hipLaunchKernelGGL((sb2006_size_distribution_kernel<FT, false, true>), grid, block, 0, st, k, n, q, rho, N, D, n_D, D_min, D_max);
+    else hipLaunchKernelGGL((sb2006_size_distribution_kernel<FT, false, false>), grid, block, 0, st, k, n, q, rho, N, D, n_D, D_min, D_max);
+    CMX_HIP_TRY(hipGetLastError());
+    return CMX_OK;
+}
+
 }  // namespace cmx
 
 extern "C" {
+
+int32_t cmx_generalized_gamma_f32(float nu, float mu, int64_t n, const float *B, const float *Y, const float *x, float *quantile, float *cdf, void *stream) {
+    return cmx::generalized_gamma_entry<float>(nu, mu, n, B, Y, x, quantile, cdf, stream);
+}
+int32_t cmx_generalized_gamma_f64(double nu, double mu, int64_t n, const double *B, const double *Y, const double *x, double *quantile, double *cdf, void *stream) {
+    return cmx::generalized_gamma_entry<double>(nu, mu, n, B, Y, x, quantile, cdf, stream);
+}
+int32_t cmx_exponential_distribution_f32(int64_t n, const float *D_mean, const float *Y, const float *D, float *quantile, float *cdf, void *stream) {
+    return cmx::exponential_distribution_entry<float>(n, D_mean, Y, D, quantile, cdf, stream);
+}
+int32_t cmx_exponential_distribution_f64(int64_t n, const double *D_mean, const double *Y, const double *D, double *quantile, double *cdf, void *stream) {
+    return cmx::exponential_distribution_entry<double>(n, D_mean, Y, D, quantile, cdf, stream);
+}
+int32_t cmx_sb2006_size_distribution_f32(const cmx_cloud_pdf_sb2006_f32 *pdf_c, const cmx_rain_pdf_sb2006_f32 *pdf_r, uint32_t flags, float p, int64_t n,
+                                         const float *q, const float *rho, const float *N, const float *D, float *n_D, float *D_min, float *D_max,
+                                         void *stream) {
+    return cmx::sb2006_size_distribution_entry<float>(pdf_c, pdf_r, flags, p, n, q, rho, N, D, n_D, D_min, D_max, stream);
+}
+int32_t cmx_sb2006_size_distribution_f64(const cmx_cloud_pdf_sb2006_f64 *pdf_c, const cmx_rain_pdf_sb2006_f64 *pdf_r, uint32_t flags, double p, int64_t n,
+                                         const double *q, const double *rho, const double *N, const double *D, double *n_D, double *D_min, double *D_max,
+                                         void *stream) {
+    return cmx::sb2006_size_distribution_entry<double>(pdf_c, pdf_r, flags, p, n, q, rho, N, D, n_D, D_min, D_max, stream);
+}
+
 
 int32_t cmx_gamma_inc_f32(int64_t n, const float *a, const float *x, float *P, float *Q, void *stream) { return cmx::gamma_inc_entry<float>(n, a, x, P, Q, stream); }
 int32_t cmx_gamma_inc_f64(int64_t n, const double *a, const double *x, double *P, double *Q, void *stream) { return cmx::gamma_inc_entry<double>(n, a, x, P, Q, stream); }

@@ -100,6 +100,7 @@ const CMX_P3_SLOPE_CONSTANT = UInt32(1) << 1
 const CMX_P3_NO_ASPECT_RATIO = UInt32(1) << 2
 const CMX_P3_RAIN_PDF_LIMITED = UInt32(1) << 3
 const CMX_FREEZE_CLOUD_PSD = UInt32(1) << 4
+const CMX_PSD_CLOUD = UInt32(1) << 5
 const CMX_1M_CLOUD_LIQUID_FORMATION = UInt32(1) << 0
 const CMX_1M_CLOUD_ICE_FORMATION_CONST = UInt32(1) << 1
 const CMX_1M_CLOUD_ICE_FORMATION_TDEP = UInt32(1) << 2
@@ -1125,6 +1126,44 @@ function gamma_inc_inv!(x, a::AbstractArray{FT}, p, q; stream = C_NULL) where {F
         length(a), _dp(FT, a), _dp(FT, p), _dp(FT, q), _dp(FT, x), stream)
     _check(st, "cmx_gamma_inc_inv")
     return x
+end
+
+"""`DT.generalized_gamma_quantile.(ν, μ, B, Y)` / `DT.generalized_gamma_cdf.(ν, μ, B, x)` (src/DistributionTools.jl:44-82); an output and its input may be `nothing`."""
+function generalized_gamma!(quantile, cdf, ν, μ, B::AbstractArray{FT}, Y, x; stream = C_NULL) where {FT}
+    st = ccall(_fn("cmx_generalized_gamma", FT), Int32, (FT, FT, Int64, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{Cvoid}),
+        FT(ν), FT(μ), length(B), _dp(FT, B), _dp(FT, Y), _dp(FT, x), _dp(FT, quantile), _dp(FT, cdf), stream)
+    _check(st, "cmx_generalized_gamma")
+    return nothing
+end
+
+"""`DT.exponential_quantile.(D_mean, Y)` / `DT.exponential_cdf.(D_mean, D)` (src/DistributionTools.jl:124-151)."""
+function exponential_distribution!(quantile, cdf, D_mean::AbstractArray{FT}, Y, D; stream = C_NULL) where {FT}
+    st = ccall(_fn("cmx_exponential_distribution", FT), Int32, (Int64, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{Cvoid}),
+        length(D_mean), _dp(FT, D_mean), _dp(FT, Y), _dp(FT, D), _dp(FT, quantile), _dp(FT, cdf), stream)
+    _check(st, "cmx_exponential_distribution")
+    return nothing
+end
+
+"""
+    size_distribution!(n_D, D_min, D_max, pdf, q, ρₐ, N, D; p = eps(FT), stream)
+
+`CM2.size_distribution_value.(Ref(pdf), q, ρₐ, N, D)` and `CM2.get_size_distribution_bounds.(Ref(pdf), q, ρₐ, N, p)` (src/Microphysics2M.jl:270-354)
+for `pdf` a `CMP.CloudParticlePDF_SB2006` or a `CMP.RainParticlePDF_SB2006_limited` / `_notlimited`; `D` is needed for `n_D` only.
+"""
+function size_distribution!(n_D, D_min, D_max, pdf::CMP.CloudParticlePDF_SB2006{FT}, q, ρₐ, N, D; p = eps(FT), stream = C_NULL) where {FT}
+    st = ccall(_fn("cmx_sb2006_size_distribution", FT), Int32,
+        (Ptr{Cvoid}, Ptr{Cvoid}, UInt32, FT, Int64, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{Cvoid}),
+        Ref(pdf), C_NULL, CMX_PSD_CLOUD, FT(p), length(q), _dp(FT, q), _dp(FT, ρₐ), _dp(FT, N), _dp(FT, D), _dp(FT, n_D), _dp(FT, D_min), _dp(FT, D_max), stream)
+    _check(st, "cmx_sb2006_size_distribution")
+    return nothing
+end
+function size_distribution!(n_D, D_min, D_max, pdf::CMP.RainParticlePDF_SB2006, q::AbstractArray{FT}, ρₐ, N, D; p = eps(FT), stream = C_NULL) where {FT}
+    flags = CMP.islimited(pdf) ? CMX_SB2006_LIMITED : UInt32(0)
+    st = ccall(_fn("cmx_sb2006_size_distribution", FT), Int32,
+        (Ptr{Cvoid}, Ptr{Cvoid}, UInt32, FT, Int64, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{Cvoid}),
+        C_NULL, Ref(pack(pdf)), flags, FT(p), length(q), _dp(FT, q), _dp(FT, ρₐ), _dp(FT, N), _dp(FT, D), _dp(FT, n_D), _dp(FT, D_min), _dp(FT, D_max), stream)
+    _check(st, "cmx_sb2006_size_distribution")
+    return nothing
 end
 
 """

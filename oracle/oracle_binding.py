@@ -705,3 +705,55 @@ def mp0m_tendencies(fam, p0m, q_lcl, q_icl, q_vap_sat=None):
     fn.restype = None
     fn(C.byref(p0m), C.c_int64(a.size), ap, bp, sp, out.ctypes.data_as(C.c_void_p), der.ctypes.data_as(C.c_void_p))
     return out, der
+
+
+# ---- size-distribution helpers (oracle/cmx_oracle_dist_impl.h) ---------------------------------------------------------------------------
+def generalized_gamma(fam, nu, mu, B, Y=None, x=None):
+    """Oracle twin of cmx_generalized_gamma_*: (quantile or None, cdf or None) — DT.generalized_gamma_quantile / _cdf."""
+    Bc = _col(fam, B)
+    n = Bc[0].size
+    Yc = _col(fam, Y) if Y is not None else (None, None)
+    xc = _col(fam, x) if x is not None else (None, None)
+    qt = np.empty(n, dtype=NP[fam.sfx]) if Y is not None else None
+    cdf = np.empty(n, dtype=NP[fam.sfx]) if x is not None else None
+    fn = getattr(lib(), f"cmxo_generalized_gamma_{fam.sfx}")
+    fn.restype = None
+    fn.argtypes = [fam.ft, fam.ft, C.c_int64] + [C.c_void_p] * 5
+    fn(nu, mu, n, Bc[1], Yc[1], xc[1], qt.ctypes.data if qt is not None else None, cdf.ctypes.data if cdf is not None else None)
+    return qt, cdf
+
+
+def exponential_distribution(fam, D_mean, Y=None, D=None):
+    """Oracle twin of cmx_exponential_distribution_*: (quantile or None, cdf or None) — DT.exponential_quantile / _cdf."""
+    Mc = _col(fam, D_mean)
+    n = Mc[0].size
+    Yc = _col(fam, Y) if Y is not None else (None, None)
+    Dc = _col(fam, D) if D is not None else (None, None)
+    qt = np.empty(n, dtype=NP[fam.sfx]) if Y is not None else None
+    cdf = np.empty(n, dtype=NP[fam.sfx]) if D is not None else None
+    fn = getattr(lib(), f"cmxo_exponential_distribution_{fam.sfx}")
+    fn.restype = None
+    fn.argtypes = [C.c_int64] + [C.c_void_p] * 5
+    fn(n, Mc[1], Yc[1], Dc[1], qt.ctypes.data if qt is not None else None, cdf.ctypes.data if cdf is not None else None)
+    return qt, cdf
+
+
+def sb2006_size_distribution(fam, pdf_c, pdf_r, q, rho, N, D=None, *, cloud=False, limited=True, p=None, bounds=True, float32_gates=None):
+    """Oracle twin of cmx_sb2006_size_distribution_*: dict(n_D, D_min, D_max) — CM2.size_distribution_value / get_size_distribution_bounds."""
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    if p is None:
+        p = float(np.finfo(np.float32 if float32_gates else np.float64).eps)
+    qc, rc, Nc = _col(fam, q), _col(fam, rho), _col(fam, N)
+    n = qc[0].size
+    Dc = _col(fam, D) if D is not None else (None, None)
+    mk = lambda on: np.empty(n, dtype=NP[fam.sfx]) if on else None  # noqa: E731
+    n_D, D_min, D_max = mk(D is not None), mk(bounds), mk(bounds)
+    ptr = lambda a: a.ctypes.data if a is not None else None  # noqa: E731
+    fn = getattr(lib(), f"cmxo_sb2006_size_distribution_{fam.sfx}")
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, fam.ft, C.c_void_p, C.c_int64] + [C.c_void_p] * 7
+    fn(C.addressof(pdf_c) if pdf_c is not None else None, C.addressof(pdf_r) if pdf_r is not None else None, int(cloud), int(limited), p, C.addressof(th), n,
+       qc[1], rc[1], Nc[1], Dc[1], ptr(n_D), ptr(D_min), ptr(D_max))
+    return dict(n_D=n_D, D_min=D_min, D_max=D_max)
