@@ -386,13 +386,15 @@ __global__ __launch_bounds__(kBlock) void mp2m_p3_pointwise_kernel(const SbConst
 }
 
 #ifndef CMX_COL_WAVES
-#define CMX_COL_WAVES 3      // min waves per SIMD the register allocator must leave room for: 168 VGPRs + 544 B scratch at 3 waves (what the
-                             // 43 KB of LDS per workgroup admit) beat 256 VGPRs + 224 B at 2 (2M + P3, Float64: 29.9 → 28.0 ms per 1e6 states,
+#define CMX_COL_WAVES 3      // min waves per SIMD the register allocator must leave room for: 168 VGPRs at 3 waves (what the 50 KB of LDS per
+                             // workgroup admit) beat 256 VGPRs at 2 (2M + P3, Float64: 29.9 → 28.0 ms per 1e6 states when measured in round 3,
                              // same-box A/B; Float32 unchanged; 1 wave: 46 ms)
 #endif
-// LDS per group, in FT units: quadrature copy is per block
+// LDS per group, in FT units: quadrature copy is per block.  At the default order 16 a 32-state Float64 workgroup holds 50 KB, so THREE workgroups
+// share a CU's 160 KB; twelve more values per state (tried in round 4: the raw inputs kept for the pointwise pass of the one-launch form instead
+// of re-read through L2) make it 53.5 KB and two workgroups — 21.4 → 26.0 ms per 1e6 states, with FETCH_SIZE unchanged (the re-reads hit L2).
 template <typename FT> struct ColLds {
-    static __host__ __device__ __forceinline__ int per_group(int n) { return 6 * n + 112; }     // E[48], Fm[24], S[28], R[12] (raw inputs of the state, one-launch form), nodes
+    static __host__ __device__ __forceinline__ int per_group(int n) { return 6 * n + 100; }
 };
 
 // EXTRA: NoExtra, or — the ONE-launch form of the 2M + P3 entry — PointwiseExtra<FT>: the constants and the two extra columns of the pointwise part,
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
     // the crossover solve — and the values only the epilogue needs (ρq, ρn, ρ_rim, 1/ρₐ, T), the five segment bounds of the
     // collision sweep, the quantiles of the self-collection / melting sweeps and ρ_g (the melting sweep's mass law), read back through a
     // volatile pointer so that they do not occupy twenty-five register pairs across all the sweeps
-    FT *E = G, *Fm = G + 48, *S = G + 72, *R = G + 100, *cN = G + 112, *rN = G + 112 + 3 * nq;
+    FT *E = G, *Fm = G + 48, *S = G + 72, *cN = G + 100, *rN = G + 100 + 3 * nq;
     const volatile FT *Sv = S;
     const int64_t pt_raw = (int64_t)blockIdx.x * (blockDim.x / GROUP) + grp;
     const bool valid = pt_raw < n;
@@ -449,19 +451,12 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
     // Order: the quantile solve first — it needs only ρq, ρn and log λ, and it is the register-hungriest piece of the set-up, so nothing else
     // is alive across it — then the state (p3_make_point) and the liquid-side loads.
     const SegPos ps(io.lay, i);       // (the other entries leave io.lay zero: contiguous columns)
-    // R[0…9]: the RAW inputs of the state, for the pointwise pass of the one-launch form — it re-read them from global memory in round 3 and
-    // 5 of 11 columns missed L2 by then (FETCH_SIZE 1.30 × the algorithmic bytes; profiles/r03_pmc_traffic_mp2m_p3_f64.json)
-    const FT rho_raw = ps.at_tab(io.rho_a, seg_tab, SEG_RHO);
-    const FT rho_a = M::max(rho_raw, FT(0));
+    const FT rho_a = M::max(ps.at_tab(io.rho_a, seg_tab, SEG_RHO), FT(0));
     FT rho_q_in, rho_n_in;
     bool present;
     if constexpr (FUSED) {
         // clamp_to_nonneg and the volumetric quantities of BMT:912-932; ice processes only where q_ice > ϵₘ && n_ice > ϵₙ (:959)
-        const FT q_ice_raw = ps.at_tab(io.q_ice, seg_tab, SEG_QICE), n_ice_raw = ps.at_tab(io.n_ice, seg_tab, SEG_NICE);
-        if constexpr (ONE_LAUNCH) {
-            if (g == 0) { R[0] = rho_raw; R[6] = q_ice_raw; R[7] = n_ice_raw; }
-        }
-        const FT q_ice = M::max(q_ice_raw, FT(0)), n_ice = M::max(n_ice_raw, FT(0));
+        const FT q_ice = M::max(ps.at_tab(io.q_ice, seg_tab, SEG_QICE), FT(0)), n_ice = M::max(ps.at_tab(io.n_ice, seg_tab, SEG_NICE), FT(0));
         rho_q_in = q_ice * rho_a; rho_n_in = n_ice * rho_a;
         present = q_ice > P::eps() && n_ice > P::eps() && !(rho_n_in < P::eps() || rho_q_in < P::eps());
     } else {
@@ -491,15 +486,10 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
     FT L_c, N_c, L_r, N_r;
     const FT T = ps.at_tab(io.T, seg_tab, SEG_T);
     if constexpr (FUSED) {
-        const FT q_lcl_raw = ps.at_tab(io.q_lcl, seg_tab, SEG_QLCL), n_lcl_raw = ps.at_tab(io.n_lcl, seg_tab, SEG_NLCL);
-        const FT q_rai_raw = ps.at_tab(io.q_rai, seg_tab, SEG_QRAI), n_rai_raw = ps.at_tab(io.n_rai, seg_tab, SEG_NRAI);
-        const FT q_rim_raw = ps.at_tab(io.q_rim, seg_tab, SEG_QRIM), b_rim_raw = ps.at_tab(io.b_rim, seg_tab, SEG_BRIM);
-        if constexpr (ONE_LAUNCH) {
-            if (g == 0) { R[1] = T; R[2] = q_lcl_raw; R[3] = n_lcl_raw; R[4] = q_rai_raw; R[5] = n_rai_raw; R[8] = q_rim_raw; R[9] = b_rim_raw; }
-        }
-        L_c = M::max(q_lcl_raw, FT(0)) * rho_a; N_c = M::max(n_lcl_raw, FT(0)) * rho_a;
-        L_r = M::max(q_rai_raw, FT(0)) * rho_a; N_r = M::max(n_rai_raw, FT(0)) * rho_a;
-        p3_make_point<FT>(c, rho_q_in, rho_n_in, M::max(q_rim_raw, FT(0)) * rho_a, M::max(b_rim_raw, FT(0)) * rho_a, s);
+        L_c = M::max(ps.at_tab(io.q_lcl, seg_tab, SEG_QLCL), FT(0)) * rho_a; N_c = M::max(ps.at_tab(io.n_lcl, seg_tab, SEG_NLCL), FT(0)) * rho_a;
+        L_r = M::max(ps.at_tab(io.q_rai, seg_tab, SEG_QRAI), FT(0)) * rho_a; N_r = M::max(ps.at_tab(io.n_rai, seg_tab, SEG_NRAI), FT(0)) * rho_a;
+        p3_make_point<FT>(c, rho_q_in, rho_n_in, M::max(ps.at_tab(io.q_rim, seg_tab, SEG_QRIM), FT(0)) * rho_a,
+                          M::max(ps.at_tab(io.b_rim, seg_tab, SEG_BRIM), FT(0)) * rho_a, s);
         if (g == 0) { S[24] = s.rho_g; S[25] = s.bnd[1]; S[26] = s.bnd[2]; S[27] = s.bnd[3]; }   // for the two later sweeps' segment bounds
     } else {
         L_c = io.L_c[i]; N_c = io.N_c[i]; L_r = io.L_r[i]; N_r = io.N_r[i];
@@ -900,11 +890,9 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
             const volatile FT *S2 = lds + 2 * nq + threadIdx.x * ColLds<FT>::per_group(nq) + 72;
             FT in[11], pw[8];
             const SegPos p2(io.lay, i2);
-            // the state's raw inputs from its LDS block (R, written by lane 0 of its group in the set-up); q_tot is read here for the first time
-            const volatile FT *R2 = S2 + 28;
-            in[0] = R2[0]; in[1] = R2[1]; in[2] = p2.at_tab(ex.q_tot, seg_tab, SEG_QTOT);
+            const FT *const col[11] = {io.rho_a, io.T, ex.q_tot, io.q_lcl, io.n_lcl, io.q_rai, io.n_rai, io.q_ice, io.n_ice, io.q_rim, io.b_rim};
 #pragma unroll
-            for (int kk = 3; kk < 11; ++kk) in[kk] = R2[kk - 1];
+            for (int kk = 0; kk < 11; ++kk) in[kk] = p2.at_tab(col[kk], seg_tab, kk);
             const FT shift = ex.shift ? p2.at_tab(ex.shift, seg_tab, SEG_SHIFT) : FT(0);
             mp2m_p3_point<FT, EXTRA::LIMITED, EXTRA::INTPOW, true>(ex.sc, c, ex.pk, in, shift, pw);
 #pragma unroll
@@ -913,7 +901,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
     }
 }
 
-// launch geometry: 256 lanes (32 states) per workgroup unless the per-state LDS caches (6n + 112 values) would not fit — then 128
+// launch geometry: 256 lanes (32 states) per workgroup unless the per-state LDS caches (6n + 100 values) would not fit — then 128
 template <typename FT> static void collision_geometry(int group, int nq, int64_t n, dim3 &grid, dim3 &block, size_t &lds) {
     int threads = kBlock;
     auto bytes = [&](int t) { return sizeof(FT) * (size_t)(2 * nq + (t / group) * ColLds<FT>::per_group(nq)); };

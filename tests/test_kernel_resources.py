@@ -51,3 +51,28 @@ def test_kernel_argument_segments_fit(kernels):
     assert 0 < big["kernarg"] <= 4096, big
     one_launch = [k for k in kernels if "p3_collision_kernel" in k["name"] and "PointwiseExtra" in k["name"]]
     assert len(one_launch) == 16 and all(k["kernarg"] <= 4096 for k in one_launch)      # {f32, f64} x aspect x limited x integer exponents
+
+
+def test_column_kernels_do_not_spill(kernels):
+    """the column kernels (flux divergence over levels, ARG2000 over mode columns) keep every vector register and use no
+    scratch; the Float64 SB2006 column kernel the bench line runs stays inside the 168 registers of three waves per SIMD, and the Float64 ARG
+    columns kernel — 414 registers at 8 modes in round 3 — inside 128 at the bench line's 5 modes and 168 at the 8-mode maximum when it returns the
+    number only (the two passes over the modes of round 4)."""
+    import re
+    kernels = [dict(k, name=n) for k, n in zip(kernels, _tool().demangle([k["name"] for k in kernels]))]      # template arguments spelled out
+    for frag in ("sb2006_column_kernel", "mp1m_column_kernel", "arg_activation_columns_kernel"):
+        ks = [k for k in kernels if frag in k["name"]]
+        assert len(ks) >= 8, frag
+        assert not [k for k in ks if k["vgpr_spill"]], frag
+    for frag in ("sb2006_column_kernel", "mp1m_column_kernel"):
+        assert not [k for k in kernels if frag in k["name"] and k["private"]], frag
+    bench_sb = [k for k in kernels if "sb2006_column_kernel<double, true, 1, false, 1, 128" in k["name"]]
+    assert len(bench_sb) == 2 and all(k["vgpr"] <= 168 for k in bench_sb), bench_sb
+    arg = {}
+    for k in kernels:
+        m = re.search(r"arg_activation_columns_kernel<double, (\d+), (true|false), 1, (true|false)>", k["name"])
+        if m:
+            arg[(int(m.group(1)), m.group(2) == "true", m.group(3) == "true")] = k["vgpr"]      # (modes, sinks, number only)
+    assert arg[(5, False, True)] <= 128 and arg[(5, False, False)] <= 128, arg
+    assert arg[(8, False, True)] <= 168, arg
+    assert max(arg.values()) <= 256, arg
