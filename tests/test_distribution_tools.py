@@ -143,7 +143,9 @@ def test_device_sb2006_size_distribution(dev, oracle, ft, which):
                                           float32_gates=(ft == "f32"))
     tol = parity.RTOL[ft]
     nD, rn = back(got.n_D), ref["n_D"]
-    assert np.array_equal(nD == 0, rn == 0)
+    tiny = 1e-36 if ft == "f32" else 0.0                      # below the Float32 range the Float64 oracle's value is the device's zero
+    assert np.array_equal(nD[(rn == 0) | (rn > tiny)] == 0, rn[(rn == 0) | (rn > tiny)] == 0)
+    assert np.all(nD[(rn > 0) & (rn <= tiny)] <= 2 * tiny)
     live = (rn > (1e-30 if ft == "f32" else 1e-290)) & (rn < (1e30 if ft == "f32" else 1e300))
     # n(D) = exp(log N₀ + ν log D − λ D^μ): the exponent (size up to 100) carries the Float32 rounding of its terms
     lam_term = np.abs(np.log(np.maximum(rn, 1e-300))) + 50

@@ -105,11 +105,22 @@ def main():
                 per_kernel.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
                 summary.setdefault("vgpr", r["VGPR_Count"]); summary.setdefault("sgpr", r["SGPR_Count"])
                 summary.setdefault("scratch", r["Scratch_Size"])
-        if per_kernel:   # one step = one launch of each kernel of the workload: mean per kernel, summed over kernels
-            summary[f"{key}_KiB_per_launch_mean"] = sum(sum(v) / len(v) for v in per_kernel.values())
-            summary[f"{key}_launches"] = sum(len(v) for v in per_kernel.values())
+        if per_kernel:   # one step = one launch of each kernel of the workload: mean per kernel, summed over the kernels of the STEP.
+            # A kernel launched fewer than half as often as the most frequent one belongs to the workload's set-up, not to its step (the 2M + P3
+            # line computes its cached log λ column once, with p3_shape_kernel): rounds 1-3 added it in, which is where that line's "1.30 x the
+            # algorithmic bytes" came from (profiles/r04_raw_requests_mp2m_p3_f64.txt).
+            most = max(len(v) for v in per_kernel.values())
+            setup = sorted(k for k, v in per_kernel.items() if 2 * len(v) < most)
+            step = {k: v for k, v in per_kernel.items() if k not in setup}
+            summary[f"{key}_KiB_per_launch_mean"] = sum(sum(v) / len(v) for v in step.values())
+            summary[f"{key}_launches"] = sum(len(v) for v in step.values())
+            if setup:
+                summary["setup_kernels_excluded"] = [k[:80] for k in setup]
     if "FETCH_SIZE_KiB_per_launch_mean" in summary and "WRITE_SIZE_KiB_per_launch_mean" in summary:
-        fetch = summary["FETCH_SIZE_KiB_per_launch_mean"] * 1024 * 2      # gfx950 correction
+        # gfx950 correction: every TCC→fabric read request is 128 B and FETCH_SIZE tallies it at 64 — checked on known byte counts in six access
+        # patterns of this library, 4/8/16 B per lane and the 8-lanes-per-state reads of the collision kernels (profiles/r04_traffic_calibration.txt);
+        # WRITE_SIZE is exact in all seven write patterns tried there
+        fetch = summary["FETCH_SIZE_KiB_per_launch_mean"] * 1024 * 2
         write = summary["WRITE_SIZE_KiB_per_launch_mean"] * 1024
         algo = n * BYTES_PER_POINT[wl] * (4 if dt == "f32" else 8)
         summary.update(fetch_bytes_corrected=fetch, write_bytes=write, hbm_bytes_per_launch=fetch + write,
