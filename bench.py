@@ -60,6 +60,8 @@ def parse():
                     help="process-group backend for N > 1: nccl (= RCCL over xGMI; the measured configuration) or gloo (TEST MODE: ranks may share "
                          "a device — local_rank modulo the device count — so the N > 1 code path can be exercised on a 1-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-telemetry", action="store_true",
+                    help="skip the engine-clock / package-power samples (rocm-smi in a child process while the kernel loops, outside every timed region)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the bounded baseline sample")
     ap.add_argument("--dry-run-scaffolding", action="store_true",
                     help="TEST MODE (tests/test_launcher.py, no GPU): run only the multi-rank scaffolding — sharding, barriers, max-over-ranks timing, "
@@ -702,6 +704,45 @@ def cpu_baseline(args, cols_np, desc, cpu_run):
                       f"{args.dtype} arithmetic, oracle C restatement ({flags}, {cores} OpenMP thread(s)), {dt:.1f} s"}
 
 
+def device_telemetry(step, kern_ms, index, seconds=1.8):
+    """Engine clock, memory clock and package power WHILE the workload's kernel loops: rocm-smi (a child process) is read three times during
+    about `seconds` of queued launches, after and outside every timed region.  The VALU ceilings of this file assume the 2.4 GHz spec clock;
+    under the streaming kernels the package sits at its power cap and the firmware lowers the engine clock (profiles/r04_clock_probe.txt:
+    1.87-2.13 GHz at 1400 W for the SB2006 / 1-moment / ARG sweeps, 2.39 GHz for the P3 kernels) — this field says which case a line is."""
+    import re
+    import shutil
+    import subprocess
+
+    import torch
+    if not shutil.which("rocm-smi"):
+        return None
+    per = max(4, min(20000, int(seconds / 3 * 1e3 / max(kern_ms, 1e-3))))
+    sclk, mclk, power = [], [], []
+    for _ in range(3):
+        for _ in range(per):
+            step()
+        try:
+            out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=30).stdout
+        except (OSError, subprocess.SubprocessError):
+            return None
+        mine = [l for l in out.splitlines() if l.startswith(f"GPU[{index}]")]
+        for l in mine:
+            if (m := re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", l)):
+                sclk.append(int(m.group(1)))
+            if (m := re.search(r"mclk clock level: \S+ \((\d+)Mhz\)", l)):
+                mclk.append(int(m.group(1)))
+            if (m := re.search(r"Power \(W\): ([\d.]+)", l)):
+                power.append(float(m.group(1)))
+        busy = not torch.cuda.current_stream().query()      # the queue must still have held work when the sample was taken
+        if not busy and sclk:
+            sclk.pop(); mclk and mclk.pop(); power and power.pop()
+    torch.cuda.synchronize()
+    if not sclk:
+        return None
+    return {"sclk_mhz": sclk, "mclk_mhz": mclk, "package_power_w": power,
+            "how": f"rocm-smi --showclocks --showpower, read while {3 * per} launches of the step were queued (after the timed regions)"}
+
+
 def cpu_model() -> str:
     """Model string of the host CPU (/proc/cpuinfo) and the number of logical CPUs the machine has."""
     try:
@@ -885,6 +926,10 @@ def main():
         del fresh_step, fresh_desc
         torch.cuda.empty_cache()
 
+    telemetry = None
+    if rank == 0 and not args.no_telemetry and dev.type == "cuda":
+        telemetry = device_telemetry(step, same_kern_ms, dev.index or 0)
+
     use_rot = rotate > 1 and rot_wall > 1.05 * same_wall
     elapsed = rot_wall if use_rot else same_wall
     kern_ms = rot_kern_ms if use_rot else same_kern_ms
@@ -932,6 +977,7 @@ def main():
         if elapsed < 20e-3:
             line["short_timed_region"] = f"the timed region is {elapsed * 1e3:.2f} ms (< 20 ms): one barrier skew of 50-100 µs moves `value` by several per mille to per cent"
         line["cold"] = {"first5_ms": cold_first5, "first_visit_other_sets_ms": first_visit_ms, "probes": probes}
+        line["telemetry"] = telemetry
         hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                "traffic_source": (traffic_source + " (rocprofv3 PMC pass of this command on an earlier run; not measured in this run)")
                                  if traffic_source else None,
@@ -945,6 +991,7 @@ def main():
                     "traffic": None, "insts_per_point": insts * 64 / n, "insts_source": insts_source + " (SQ_INSTS_VALU of a rocprofv3 PMC pass of this "
                     "command; a property of the code and the inputs, not of the box)", "kernel": desc["kernel"], "kernel_ms": kern_ms,
                     "issue_slots_4cycle": rate / (1024 * 2.4 / 4),
+                    "frac_at_measured_clock": (rate / (VALU_PEAK_GINST * (sum(telemetry["sclk_mhz"]) / len(telemetry["sclk_mhz"])) / 2400.0)) if telemetry else None,
                     "peak_formula": "256 CUs x 4 SIMDs x 2.4 GHz / 2.4 cycles: the fastest measured issue rate of a wave64 VALU instruction "
                                     "(profiles/rNN_probe_valu.txt); frac_vs_guide = the same count against the guide's 2-cycle issue of a wave64 instruction "
                                     "on the SIMD-32 (MI355X_MICROARCH.md: 1228.8 G/s); Float64 instructions take >= 4.2 cycles, so a Float64 kernel tops out near 0.55; "
@@ -953,7 +1000,7 @@ def main():
             # compute-bound line: the VALU-issue fraction is the roofline, the HBM fraction a secondary field
             line["roofline"] = dict(valu, hbm={k: hbm[k] for k in ("achieved", "peak", "unit", "frac", "traffic", "traffic_source", "bytes_per_point")})
         else:
-            line["roofline"] = dict(hbm, valu=({k: valu[k] for k in ("achieved", "peak", "unit", "frac", "frac_vs_guide", "peak_guide", "issue_slots_4cycle", "insts_per_point", "insts_source")} if valu else None))
+            line["roofline"] = dict(hbm, valu=({k: valu[k] for k in ("achieved", "peak", "unit", "frac", "frac_vs_guide", "peak_guide", "issue_slots_4cycle", "frac_at_measured_clock", "insts_per_point", "insts_source")} if valu else None))
             if desc.get("bound") == "valu":
                 line["roofline"]["note"] = "compute-bound workload, but no committed PMC instruction count matches this size: HBM fraction shown"
         if "note" in desc:

@@ -605,7 +605,9 @@ __global__ __launch_bounds__(kBlock) void sb2006_size_distribution_kernel(const 
             cond = Ni < eps && qi < eps;
         }
         if (cond) { N0r = FT(0); Dr_mean = FT(0); }
-        if (n_D) n_D[i] = N0r == FT(0) ? FT(0) : N0r * DM::exp(-D[i] / Dr_mean);                          // CM2:270-277
+        // CM2:270-277, N₀r·exp(−D/D̄) formed as exp(log N₀r − D/D̄): the hardware exponential flushes results below 2⁻¹²⁶ to zero, and N₀r (up to
+        // 1e13) times such a value is still a normal Float32 number in the reference's arithmetic
+        if (n_D) n_D[i] = N0r == FT(0) ? FT(0) : DM::exp(DM::log(N0r) - D[i] / Dr_mean);
         const bool none = Dr_mean == FT(0);                                                              // CM2:336-345
         if (D_min) D_min[i] = none ? FT(0) : exp_quantile_dev<FT>(Dr_mean, k.p);
         if (D_max) D_max[i] = none ? FT(0) : exp_quantile_dev<FT>(Dr_mean, FT(1) - k.p);

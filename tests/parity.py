@@ -122,6 +122,24 @@ def record(what, ft, got: dict, ref: dict, *, family, pinned_by, scale=None, kee
     return out
 
 
+# rows of assert_parity carry the SURVEY §8 row of the test module that produced them (record() states its family itself)
+FAMILY_OF_MODULE = {
+    "test_sb2006_gpu": "SB2006 2M warm rain (a1)", "test_graphs_gpu": "SB2006 2M warm rain (a1)", "test_bench_gpu": "SB2006 2M warm rain (a1)",
+    "test_abi_caller": "plain C caller through the ABI (b)",
+    "test_mp1m_gpu": "1-moment (a2)", "test_mp1m_linearized": "1-moment LinearizedAverage (a2 / f1)",
+    "test_mp1m_column": "column steps (f4)", "test_column_gpu": "column steps (f4)",
+    "test_layouts_gpu": "host-model layouts (f1)", "test_mp2m_p3_gpu": "2M + P3 fused entry (f2)", "test_mp0m": "row g: 0-moment",
+    "test_nan_inputs_gpu": "NaN / degenerate inputs", "test_row_g": "row g: remaining public functions",
+}
+
+
+def _family_of_current_test():
+    import os
+    cur = os.environ.get("PYTEST_CURRENT_TEST", "")            # "tests/test_x.py::test_y[param] (call)"
+    mod = cur.split("::")[0].rsplit("/", 1)[-1].removesuffix(".py")
+    return FAMILY_OF_MODULE.get(mod, mod or "unattributed")
+
+
 def assert_parity(got: dict, ref: dict, rtol: float, names=OUT_NAMES, what="", floor=None, min_frac=None):
     """got/ref: name → array; ref carries 'scale' (name → array) and 'near_branch' (bool mask).  Returns the worst
     normalised error per output (must be ≤ rtol).  Also checks and records the plain relative bound (see above)."""
@@ -147,7 +165,9 @@ def assert_parity(got: dict, ref: dict, rtol: float, names=OUT_NAMES, what="", f
                 f"{what} {k}: normalised error {worst:.3e} > {rtol:g} at i={i}: got {np.asarray(got[k])[i]!r} "
                 f"ref {ref[k][i]!r} scale {(sc[i] if sc is not None else None)!r}")
         ps = plain_stats(got[k], ref[k], sc, rtol, floor, CEIL[ft], keep, WELLCOND[ft])
-        REPORTS.append({"what": what.strip(), "output": k, "ft": ft, "rtol": rtol, "worst_normalised": worst, **ps})
+        REPORTS.append({"what": what.strip(), "output": k, "ft": ft, "rtol": rtol, "worst_normalised": worst, **ps,
+                        "family": _family_of_current_test(), "pinned_by": "oracle (pinned by the reference's KATs, tests/golden/)",
+                        "asserted": f"operand-scaled bound + fraction inside the plain bound >= {min_frac} + well-conditioned plain bound"})
         assert ps["frac_within"] >= min_frac, (
             f"{what} {k}: only {ps['frac_within']:.6f} of {ps['n']} points are within the plain relative bound {rtol:g} "
             f"(required {min_frac})")

@@ -1,11 +1,12 @@
 #!/bin/bash
 # One GPU-box session: full parity suite FIRST (a failing suite aborts the session: no numbers are produced from a build whose
-# parity is red), then every workload's bench line (f32 + f64), then profiles.  Each step's rc is checked; a failed bench or
-# profile is reported and skipped, never summarised.
-#   usage: tools/gpu_round.sh <round-tag, e.g. r02> [notests]
+# parity is red), then the rocprofv3 passes of every workload (kernel-trace over >= 200 launches, FETCH_SIZE, WRITE_SIZE, SQ counters — the
+# bench lines of the compute-bound workloads read their instruction counts from THESE passes), then every workload's bench line
+# (f32 + f64), then the probes.  Each step's rc is checked; a failed bench or profile is reported and skipped, never summarised.
+#   usage: tools/gpu_round.sh <round-tag, e.g. r04> [notests]
 set -u
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 mkdir -p gpurun_out/bench
 FAILED=0
 
@@ -41,7 +42,7 @@ bench() {  # bench <name> <bench.py args…>
 }
 
 prof() {  # prof <workload> <dtype> <points> [valu]
-  KT_STEPS=${KT_STEPS:-40} tools/profile.sh "$1" "$2" "$3" "$TAG" "${4:-}" > gpurun_out/prof_${1}_${2}.log 2>&1
+  KT_STEPS=${KT_STEPS:-200} tools/profile.sh "$1" "$2" "$3" "$TAG" "${4:-}" > gpurun_out/prof_${1}_${2}.log 2>&1
   local rc=$?
   if [ $rc -ne 0 ]; then echo "profile $1 $2 FAILED rc=$rc"; FAILED=$((FAILED+1)); fi
 }
@@ -50,8 +51,11 @@ prof() {  # prof <workload> <dtype> <points> [valu]
 # (bench.py pmc_valu: same size, same source digest), so the summaries are copied into profiles/ of this box before any line is printed
 prof sb2006 f32 100000000 valu
 prof sb2006 f64 100000000 valu
-prof sb2006_column f32 100000000
-prof sb2006_column f64 100000000
+prof sb2006_chen f32 100000000 valu
+prof sb2006_column f32 100000000 valu
+prof sb2006_column f64 100000000 valu
+prof sb2006_fields f32 100000000 valu
+prof sb2006_fields f64 100000000 valu
 prof mp0m f32 100000000
 prof icenuc f32 100000000
 prof icenuc f64 100000000
@@ -64,6 +68,8 @@ prof mp1m_column f64 100000000 valu
 prof mp1m_column_lin f32 100000000 valu
 prof arg2000 f32 100000000 valu
 prof arg2000 f64 100000000 valu
+prof arg2000_columns f32 100000000 valu
+prof arg2000_columns f64 100000000 valu
 KT_STEPS=10 prof p3 f32 10000000 valu
 KT_STEPS=10 prof p3 f64 10000000 valu
 KT_STEPS=10 prof p3_split f64 10000000
@@ -77,7 +83,7 @@ cp gpurun_out/profiles/${TAG}_pmc_*.json gpurun_out/profiles/${TAG}_kernel_stats
 
 bench default_driver --steps 20 --warmup 5
 bench default
-for wl in sb2006 sb2006_column icenuc mp0m mp1m arg2000 mp1m_lin mp1m_column sb2006_aos sb2006_fields; do
+for wl in sb2006 sb2006_column icenuc mp0m mp1m arg2000 arg2000_columns mp1m_lin mp1m_column sb2006_aos sb2006_fields; do
   for dt in f32 f64; do
     bench ${wl}_${dt} --workload $wl --dtype $dt --steps 20 --warmup 3
   done
@@ -93,6 +99,7 @@ done
 cp gpurun_out/parity_report.json gpurun_out/profiles/${TAG}_parity_report.json 2>/dev/null
 python tools/kernel_resources.py > gpurun_out/profiles/${TAG}_kernel_resources.txt 2>&1
 # instruction issue rates and dependent-issue latency (tools/valu_probe.hip), stream ceilings (tools/stream_probe.hip quick)
+[ -x tools/traffic_calib ] && tools/traffic_calib.sh ${TAG} > /dev/null 2>&1
 [ -x tools/valu_probe ] && timeout 120 tools/valu_probe > gpurun_out/profiles/${TAG}_probe_valu.txt 2>&1
 [ -x tools/stream_probe ] && timeout 300 tools/stream_probe 100000000 20 slab pattern quick > gpurun_out/profiles/${TAG}_probe_streams.txt 2>&1
 ls gpurun_out/profiles

@@ -85,7 +85,7 @@ def main():
     dst.mkdir(parents=True, exist_ok=True)
     summary = {"round": rnd, "workload": wl, "dtype": dt, "points": n, "source_digest": source_digest(),
                "command": f"tools/profile.sh {wl} {dt} {n}  (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE in separate passes, "
-                          f"--kernel-trace --stats in a third; PMC passes: bench.py --steps 5 --warmup 1; kernel-trace pass: --steps 40 --warmup 5)"}
+                          "--kernel-trace --stats in a third; PMC passes: bench.py --steps 5 --warmup 1; kernel-trace pass: --steps " + __import__("os").environ.get("KT_STEPS", "40") + " --warmup 5)"}
     stats = find(out, "kt", "kernel_stats.csv")
     if stats:
         rows = list(csv.reader(open(stats)))
