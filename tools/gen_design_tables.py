@@ -92,8 +92,10 @@ def performance_block(rnd):
                 ipp = sum(insts) * 64 / n
             util = pv.get("valu_issue_utilisation")
         cold = (d.get("cold") or {}).get("first5_ms")
+        tel = d.get("telemetry") or {}
+        clk = (sum(tel["sclk_mhz"]) / len(tel["sclk_mhz"]), (sum(tel["package_power_w"]) / len(tel["package_power_w"])) if tel.get("package_power_w") else None) if tel.get("sclk_mhz") else None
         rows.append((ORDER.index(wl) if wl in ORDER else 99, dt, wl, n, bpp, same, rot, d.get("value_uses"), cold[0] if cold else None, ks, frac_b, frac_p,
-                     tr.get("traffic_over_algorithmic") if tr and tr.get("points") == n else None, ipp, util, r.get("bound", "hbm")))
+                     tr.get("traffic_over_algorithmic") if tr and tr.get("points") == n else None, ipp, util, r.get("bound", "hbm"), clk))
     rows.sort()
     fmt = lambda v, f: "—" if v is None else f % v  # noqa: E731
     out = [f"Measured in ONE session on one box (round {rnd}; `profiles/bench_{rnd}/`, `profiles/{rnd}_kernel_stats_*.csv`, "
@@ -101,17 +103,30 @@ def performance_block(rnd):
            "buffer set, and launches cycling through 4 disjoint buffer sets (`--rotate 4`; the working set of the sub-millisecond lines then "
            "exceeds the 256-MiB Infinity Cache several times over, and every launch sweeps pages another launch touched last) — `value` uses the "
            "rotating time when it is more than 5 % slower.  first = the very first timed launch after the inputs are generated.  rocprof = mean (min) "
-           "over ≥ 200 profiled launches of `rocprofv3 --kernel-trace --stats` in the same session.  HBM frac = algorithmic bytes ÷ time ÷ 8 TB/s "
+           "over the profiled launches of `rocprofv3 --kernel-trace --stats` in the same session (200 for the sweep kernels, 6–10 for the P3 lines).  HBM frac = algorithmic bytes ÷ time ÷ 8 TB/s "
            "(bench: of the region `value` uses).  traffic = (2 × FETCH_SIZE + WRITE_SIZE) ÷ algorithmic bytes, per launch, kernels of the step only "
-           f"(calibration: `profiles/{rnd}_traffic_calibration.txt`).  VALU frac = SQ_INSTS_VALU × 2.4 cycles ÷ (1024 SIMDs × rocprof mean × 2.4 GHz) — against "
-           "the fastest measured issue rate of a wave64 VALU instruction (`profiles/r03_probe_valu.txt`), ≤ 1 by construction; vs guide = the same "
-           "count against the microarchitecture guide's one instruction per 4 cycles per SIMD.  `bound` is what `bench.py` prices `roofline.frac` against.", "",
+           "(calibration: `profiles/r04_traffic_calibration.txt`).  VALU frac = SQ_INSTS_VALU × 2.4 cycles ÷ (1024 SIMDs × rocprof mean × 2.4 GHz) — against "
+           "the fastest measured issue rate of a wave64 VALU instruction (`profiles/r03_probe_valu.txt`), ≤ 1 by construction; 4-cycle slots = the same "
+           "count against one instruction per 4 cycles per SIMD.  sclk / W = engine clock and package power sampled by rocm-smi while the kernel loops "
+           "(`telemetry` of the bench line; the spec clock is 2400 MHz, the package power cap 1400 W).  `bound` is what `bench.py` prices `roofline.frac` against.", "",
            "| workload | dtype | points | B/point | same ms | rotating ms | first ms | rocprof ms (min) | HBM frac bench | HBM frac rocprof | traffic / algorithmic | "
-           "VALU instr / point | VALU frac | vs guide | bound |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
-    for _, dt, wl, n, bpp, same, rot, uses, first, ks, fb, fp, tro, ipp, util, bound in rows:
+           "VALU instr / point | VALU frac | 4-cycle slots | sclk MHz / W | bound |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    for _, dt, wl, n, bpp, same, rot, uses, first, ks, fb, fp, tro, ipp, util, bound, clk in rows:
         out.append(f"| `{wl}` | {dt} | {n:.3g} | {bpp} | {same:.3f} | {fmt(rot, '%.3f')}{' ←' if uses == 'rotating' else ''} | {fmt(first, '%.2f')} | " +
                    (f"{ks[0]:.3f} ({ks[1]:.3f})" if ks else "—") + f" | {fb:.3f} | {fmt(fp, '%.3f')} | {fmt(tro, '%.3f')} | {fmt(ipp, '%.0f')} | "
-                   f"{fmt(util * 0.6 if util is not None else None, '%.2f')} | {fmt(util, '%.2f')} | {bound} |")
+                   f"{fmt(util * 0.6 if util is not None else None, '%.2f')} | {fmt(util, '%.2f')} | " +
+                   ("—" if not clk else f"{clk[0]:.0f}" + (f" / {clk[1]:.0f}" if clk[1] is not None else "")) + f" | {bound} |")
+    # the cold probes of the driver's default line: what separates the clock / power ramp from address translation
+    dflt = lines.get("default") or {}
+    pr = (dflt.get("cold") or {}).get("probes")
+    if pr:
+        f5 = lambda v: "[" + ", ".join(f"{x:.2f}" for x in v) + "]"  # noqa: E731
+        out += ["", f"Cold probes of the default line (`profiles/bench_{rnd}/default.json`, north star, Float32, kernel ms of five consecutive launches): the first five "
+                f"launches of the process {f5(dflt['cold']['first5_ms'])}; the first visit of each other buffer set {f5(dflt['cold']['first_visit_other_sets_ms'])}; "
+                f"the SAME buffers after one second of idle {f5(pr['after_1s_idle_same_buffers_ms'])}; FRESH buffers right after a busy period "
+                f"{f5(pr['fresh_buffers_warm_clocks_ms'])}; control (steady state) {f5(pr['steady_same_buffers_ms'])}.  Same-buffer region "
+                f"{dflt.get('same_buffer_ms_per_step', float('nan')):.4f} ms per step, rotating region {dflt.get('rotating_ms_per_step') or float('nan'):.4f} ms per step; `value` uses the "
+                f"{dflt.get('value_uses', '?').replace('_', '-')} region."]
     return "\n".join(out)
 
 

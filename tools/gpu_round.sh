@@ -78,6 +78,10 @@ KT_STEPS=6 prof p3_selfcol f64 1000000 valu
 KT_STEPS=10 prof mp2m_p3 f32 1000000 valu
 KT_STEPS=10 prof mp2m_p3 f64 1000000 valu
 prof sb2006_aos f32 100000000
+# the stall / occupancy counters of the Float32 kernels VERDICT r03 item 4 names (three more PMC passes each; tools/sq_pass.sh)
+for wl in sb2006_column sb2006_chen sb2006_fields arg2000 mp1m; do
+  tools/sq_pass.sh $wl f32 > gpurun_out/profiles/${TAG}_sq_${wl}_f32.txt 2>&1 || { echo "sq_pass $wl FAILED"; FAILED=$((FAILED+1)); }
+done
 mkdir -p profiles
 cp gpurun_out/profiles/${TAG}_pmc_*.json gpurun_out/profiles/${TAG}_kernel_stats_*.csv profiles/ 2>/dev/null
 

@@ -25,9 +25,21 @@ for f in glob.glob(out + '/p*/**/*counter_collection.csv', recursive=True):
         k = r['Kernel_Name'].split('(')[0][:70]
         tot[k][r['Counter_Name']] += float(r['Counter_Value']); n[(k, r['Counter_Name'])] += 1
 for k, d in tot.items():
+    if 'cmx::' not in k:
+        continue
     print(k)
-    for c, v in sorted(d.items()):
-        print(f'   {c:28s} {v / n[(k, c)]:16.1f} per launch')
+    m = {c: v / n[(k, c)] for c, v in d.items()}
+    for c, v in sorted(m.items()):
+        print(f'   {c:28s} {v:16.1f} per launch')
+    wc = m.get('SQ_WAVE_CYCLES')
+    if wc:      # MI355X_MICROARCH.md: ACTIVE_INST_ANY + WAIT_INST_ANY + WAIT_ANY ~ WAVE_CYCLES (disjoint states of a resident wave)
+        print('   -- share of resident-wave time: issuing %.2f, issue-stalled (pipe busy / dependency) %.2f, parked on s_waitcnt / barrier %.2f'
+              % (m.get('SQ_ACTIVE_INST_ANY', 0) / wc, m.get('SQ_WAIT_INST_ANY', 0) / wc, m.get('SQ_WAIT_ANY', 0) / wc))
+    if m.get('SQ_INSTS_VALU') and m.get('SQ_ACTIVE_INST_VALU'):
+        print('   -- VALU-active quad-cycles per VALU instruction %.2f (x 4 = clocks of issue per instruction: %.2f)'
+              % (m['SQ_ACTIVE_INST_VALU'] / m['SQ_INSTS_VALU'], 4 * m['SQ_ACTIVE_INST_VALU'] / m['SQ_INSTS_VALU']))
+    if m.get('SQ_BUSY_CYCLES') and wc:
+        print('   -- resident waves per SIMD while busy: %.1f  (SQ_WAVE_CYCLES / (SQ_BUSY_CYCLES / 32 x 1024 SIMDs / 4))' % (wc / (m['SQ_BUSY_CYCLES'] / 32 * 1024 / 4)))
 PY
 # the raw per-dispatch CSVs stay on the box (gpurun merges at most 64 MiB back)
 rm -rf "$OUT"/p1 "$OUT"/p2 "$OUT"/p3
