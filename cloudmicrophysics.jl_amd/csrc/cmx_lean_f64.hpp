@@ -467,6 +467,18 @@ CMX_LEAN_FN double log2(double x) {
     return y;
 #endif
 }
+CMX_LEAN_FN double log(double x);
+// ln x for a POSITIVE NORMAL finite x (a diameter or an area at an interior quadrature node): the main path of log() alone — no class test, no
+// rescue block, so the call does not end a basic block.  NaN propagates (the reduction keeps the payload); 0, negatives, subnormals and Inf are outside the contract.
+CMX_LEAN_FN double log_pos(double x) {
+#if !CMX_LEAN_TABLES || !CMX_F64_FINITE_FORMS
+    return log(x);
+#else
+    const LeanCoefs &K = coefs();
+    const Log2Parts q = log2_reduce(x, K);
+    return fma_(q.hi, K.ln2, q.r * poly6s(q.r, K.ln));
+#endif
+}
 CMX_LEAN_FN double log(double x) {
 #if !CMX_LEAN_TABLES
     {
@@ -667,6 +679,7 @@ CMX_LEAN_FN double log(double x, const PinnedCoefs &k) {
     const double ed = (double)e;
     return log_special(x, fma_(ed, k.ln2_hi, fma_(ed, k.ln2_lo, lm)));
 }
+CMX_LEAN_FN double log_pos(double x, const PinnedCoefs &k) { return log(x, k); }   // (no shorter form in the table-free variant)
 
 // ---- table-driven eˣ / ln x with the coefficients pinned in VGPRs (round 2) -------------------------------------------------------
 // The quadrature loops of the P3 kernels evaluate ≈ 1 log + 3–4 exp per node, hundreds of nodes per state: the coefficients must not
@@ -741,6 +754,14 @@ CMX_LEAN_FN double log(double x, const TabCoefs &k) {
     double y = fma_(q.hi, k.ln2, rp);
     if (rare) y = log_postfix(x, fma_(q.hi - k.sixty4, k.ln2, rp));
     return y;
+#endif
+}
+CMX_LEAN_FN double log_pos(double x, const TabCoefs &k) {                      // positive normal finite x (see log_pos above)
+#if !CMX_F64_FINITE_FORMS
+    return log(x, k);
+#else
+    const Log2Parts q = log2_reduce_m1(x);
+    return fma_(q.hi, k.ln2, q.r * poly6(q.r, k.ln));
 #endif
 }
 

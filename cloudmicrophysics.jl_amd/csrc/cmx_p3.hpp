@@ -61,6 +61,7 @@ template <> struct PM<double> {
     // constants at interior nodes D > 0 — the finite-argument exponential (no clamp, no NaN select; NaN still propagates)
     static __device__ __forceinline__ double exp(double x, const Coefs &) { return lean::exp_fin(x); }
     static __device__ __forceinline__ double log(double x, const Coefs &) { return lean::log(x); }
+    static __device__ __forceinline__ double log_pos(double x, const Coefs &) { return lean::log_pos(x); }   // positive normal finite x
 #else
 #if CMX_P3_TABLE_MATH
     using Coefs = lean::TabCoefs;
@@ -71,6 +72,7 @@ template <> struct PM<double> {
 #endif
     static __device__ __forceinline__ double exp(double x, const Coefs &k) { return lean::exp_fin(x, k); }   // integrand form: see above
     static __device__ __forceinline__ double log(double x, const Coefs &k) { return lean::log(x, k); }
+    static __device__ __forceinline__ double log_pos(double x, const Coefs &k) { return lean::log_pos(x, k); }
 #endif
     static __device__ __forceinline__ void pin(double &x) { lean::pin(x); }
     static __device__ __forceinline__ double exp_fast(double x) { return exp(x); }       // Float64: the one-argument forms above
@@ -119,6 +121,7 @@ template <> struct PM<float> {
     static __device__ __forceinline__ float exp(float x, const Coefs &) { return ::expf(x); }
     static __device__ __forceinline__ float log(float x, const Coefs &) { return ::logf(x); }
 #endif
+    static __device__ __forceinline__ float log_pos(float x, const Coefs &k) { return log(x, k); }      // Float32: the hardware form handles every class
     static __device__ __forceinline__ float rcp(float d) {
         const float r = __builtin_amdgcn_rcpf(d);
         return __builtin_fmaf(r, __builtin_fmaf(-d, r, 1.0f), r);

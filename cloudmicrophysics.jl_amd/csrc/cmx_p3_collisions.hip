@@ -511,7 +511,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
     // ice fall speed (incl. aspect factor), collision radius and number density at diameter x — as in p3_self_collection_kernel
     const typename P::Coefs kc = P::coefs();          // exp / log constants pinned in VGPRs for the node loops
     auto eval_ice = [&](FT x, FT &vv, FT &rr, FT &nn) {
-        const FT logD = P::log(x, kc);
+        const FT logD = P::log_pos(x, kc);          // an interior quadrature node: positive, normal, finite
         const int reg = x < s.bnd[1] ? 0 : (unrimed ? 1 : (x < s.bnd[2] ? 1 : (x < s.bnd[3] ? 2 : 3)));
         // collision radius r = √(area/π) and aspect factor: spherical regimes r = D/2 exactly; unrimed non-spherical area = γ D^σ:
         // r = √(γ/π)·D^(σ/2) (one exponential, no square root); only the partially rimed regime needs the mixed area and its root
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
         } else if (reg == 3) {
             const FT area = s.F_rim * (v.pi_4 * x * x) + (FT(1) - s.F_rim) * (v.gamma_area * P::exp(v.sigma_area * logD, kc));
             rr = M::sqrt(area * inv_pi);
-            if (ASPECT) eA = h0 + h1 * logD - FT(0.5) * P::log(area, kc);
+            if (ASPECT) eA = h0 + h1 * logD - FT(0.5) * P::log_pos(area, kc);
         }
         const bool small = x <= v.cutoff;
         const FT E1 = small ? se + sb * logD : le1 + v.l_b1 * logD;

@@ -207,12 +207,12 @@ __global__ __launch_bounds__(kBlock) void p3_velocity_kernel(const P3Consts<FT> 
             FT rn = FT(0), rm = FT(0);
             for (int j = 0; j < quad.n; ++j) {
                 const FT x = scale * quad.node[j] + shift, w = quad.weight[j];
-                const FT logD = P::log(x, kc);
+                const FT logD = P::log_pos(x, kc);          // an interior quadrature node: positive, normal, finite
                 const FT eN = logN0 + mu * logD - lam_ * x;                 // log n(D)
                 FT eA = q0 + q1 * logD;                                      // log of the aspect factor
                 if (mixed_area) {
                     const FT area = s.F_rim * k_pi4 * x * x + (FT(1) - s.F_rim) * k_ga * P::exp(k_sa * logD, kc);
-                    eA -= FT(0.5) * P::log(area, kc);
+                    eA -= FT(0.5) * P::log_pos(area, kc);
                 }
                 // Chen-2022 particle speed Σ aₖ D^bₖ e^{−cₖD}: the two terms have opposite signs and cancel to ≈1/200 of
                 // their size for small D, so the shared factor stays OUTSIDE the difference (as D^b does in the reference)
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(kBlock) void p3_self_collection_kernel(const P3Cons
         const typename P::Coefs kc = P::coefs();
         // fall speed (incl. aspect factor), collision radius and number density at diameter x
         auto eval = [&](FT x, FT &vv, FT &rr, FT &nn) {
-            const FT logD = P::log(x, kc);
+            const FT logD = P::log_pos(x, kc);          // an interior quadrature node: positive, normal, finite
             const int reg = x < s.bnd[1] ? 0 : (unrimed ? 1 : (x < s.bnd[2] ? 1 : (x < s.bnd[3] ? 2 : 3)));
             // collision radius r = √(area/π) and aspect factor: spherical regimes r = D/2 exactly; unrimed non-spherical area = γ D^σ:
             // r = √(γ/π)·D^(σ/2) (one exponential, no square root); only the partially rimed regime needs the mixed area and its root
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(kBlock) void p3_self_collection_kernel(const P3Cons
             } else if (reg == 3) {
                 const FT area = s.F_rim * (v.pi_4 * x * x) + (FT(1) - s.F_rim) * (v.gamma_area * P::exp(v.sigma_area * logD, kc));
                 rr = Math<FT>::sqrt(area * inv_pi);
-                if (ASPECT) eA = h0 + h1 * logD - FT(0.5) * P::log(area, kc);
+                if (ASPECT) eA = h0 + h1 * logD - FT(0.5) * P::log_pos(area, kc);
             }
             const bool small = x <= v.cutoff;
             const FT E1 = small ? se + sb * logD : le1 + v.l_b1 * logD;
@@ -605,9 +605,13 @@ __global__ __launch_bounds__(kBlock) void sb2006_size_distribution_kernel(const 
             cond = Ni < eps && qi < eps;
         }
         if (cond) { N0r = FT(0); Dr_mean = FT(0); }
-        // CM2:270-277, N₀r·exp(−D/D̄) formed as exp(log N₀r − D/D̄): the hardware exponential flushes results below 2⁻¹²⁶ to zero, and N₀r (up to
-        // 1e13) times such a value is still a normal Float32 number in the reference's arithmetic
-        if (n_D) n_D[i] = N0r == FT(0) ? FT(0) : DM::exp(DM::log(N0r) - D[i] / Dr_mean);
+        // CM2:270-277.  Float32 forms N₀r·exp(−D/D̄) as exp(log N₀r − D/D̄): the hardware exponential flushes results below 2⁻¹²⁶ to zero, and N₀r (up
+        // to 1e13) times such a value is still a normal Float32 number in the reference's arithmetic; Float64 keeps the reference's product (its
+        // exponential delivers subnormal results, and the product underflows exactly where the reference's does)
+        if (n_D) {
+            if constexpr (sizeof(FT) == 4) n_D[i] = N0r == FT(0) ? FT(0) : DM::exp(DM::log(N0r) - D[i] / Dr_mean);
+            else n_D[i] = N0r == FT(0) ? FT(0) : N0r * DM::exp(-D[i] / Dr_mean);
+        }
         const bool none = Dr_mean == FT(0);                                                              // CM2:336-345
         if (D_min) D_min[i] = none ? FT(0) : exp_quantile_dev<FT>(Dr_mean, k.p);
         if (D_max) D_max[i] = none ? FT(0) : exp_quantile_dev<FT>(Dr_mean, FT(1) - k.p);

@@ -16,13 +16,22 @@ def dev():
     return torch.device("cuda", 0)
 
 
-def _check(call, cols, n_out, lo=0):
+def _nan(t, negative):
+    """A quiet NaN of t's dtype, with the sign bit set if `negative`: the Float32 max0() is an integer max on the bits, which turns a
+    sign-bit NaN into +0 — the any_nan poison of the entries must catch it all the same."""
+    x = torch.full((1,), float("nan"), dtype=t.dtype, device=t.device)
+    return -x if negative else x                 # negation flips the sign bit of a NaN (IEEE 754 §5.5.1: a sign-bit operation)
+
+
+def _check(call, cols, n_out, lo=0, negative_nan=False):
     clean = call(cols)
     n = cols[0].numel()
     for k in range(len(cols)):
         bad = [c.clone() for c in cols]
         idx = torch.arange(k, n, 37, device=cols[0].device)
-        bad[k][idx] = float("nan")
+        bad[k][idx] = _nan(bad[k], negative_nan)
+        if negative_nan:
+            assert bool(torch.signbit(bad[k][idx]).all())
         out = call(bad)
         mask = torch.zeros(n, dtype=torch.bool, device=cols[0].device)
         mask[idx] = True
@@ -51,6 +60,28 @@ def test_nan_in_any_input_poisons_the_point(dev, sfx):
     _check(lambda c: cmx.bulk_microphysics_tendencies_1m_fields(cmx.Instantaneous(), s1, mp1, tps, *c), st1, 4)
     _check(lambda c: (cmx.bulk_microphysics_tendencies_0m(s0, mp0, tps, c[0], c[0], c[1]),), [st1[3], st1[4]], 1)
     _check(lambda c: (cmx.bulk_microphysics_tendencies_0m(s0, mp0, tps, c[0], c[0], c[1], c[2]),), [st1[3], st1[4], st1[2]], 1)
+
+
+@pytest.mark.parametrize("sfx", ["f32", "f64"])
+def test_sign_bit_nan_is_poison_too(dev, sfx):
+    """A NaN whose sign bit is set: the integer-max clamp of the Float32 kernels would turn it into +0; the entries' NaN rule looks at the raw
+    inputs (unordered compares), so the point is poisoned — in the tendencies entries AND in the 1-moment source-term entry, which had no
+    poison before round 4."""
+    import cmx
+    from cmx import synthetic
+    dt = torch.float32 if sfx == "f32" else torch.float64
+    n = 4099
+    tps = P.ThermodynamicsParameters(sfx)
+    mp2, mp1 = P.Microphysics2MParams(sfx), P.Microphysics1MParams(sfx)
+    st2 = [c.clone() for c in synthetic.sb2006_state(n, dtype=dt, device=dev, seed=51)]
+    st1 = [c.clone() for c in synthetic.mp1m_state(n, dtype=dt, device=dev, seed=52)]
+    s2, s1 = cmx.Microphysics2Moment(), cmx.Microphysics1Moment()
+    _check(lambda c: cmx.bulk_microphysics_tendencies(s2, mp2, tps, *c, vel=cmx.SB2006VelType), st2, 6, negative_nan=True)
+    _check(lambda c: cmx.bulk_microphysics_tendencies_1m(cmx.Instantaneous(), s1, mp1, tps, *c), st1, 4, negative_nan=True)
+    src = lambda c: tuple(v for v in cmx.microphysics_source_terms_1m(mp1, tps, *c) if v is not None)  # noqa: E731
+    n_src = len(src(st1))
+    _check(src, st1, n_src, negative_nan=True)
+    _check(src, st1, n_src)
 
 
 def test_nan_in_the_2m_p3_entry(dev):
