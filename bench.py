@@ -61,7 +61,7 @@ def parse():
                          "a device — local_rank modulo the device count — so the N > 1 code path can be exercised on a 1-GPU box)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-telemetry", action="store_true",
-                    help="skip the engine-clock / package-power samples (rocm-smi in a child process while the kernel loops, outside every timed region)")
+                    help="skip the engine-clock / package-power samples (amdgpu sysfs reads while the kernel loops, outside every timed region)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the bounded baseline sample")
     ap.add_argument("--dry-run-scaffolding", action="store_true",
                     help="TEST MODE (tests/test_launcher.py, no GPU): run only the multi-rank scaffolding — sharding, barriers, max-over-ranks timing, "
@@ -704,43 +704,92 @@ def cpu_baseline(args, cols_np, desc, cpu_run):
                       f"{args.dtype} arithmetic, oracle C restatement ({flags}, {cores} OpenMP thread(s)), {dt:.1f} s"}
 
 
+def _amdgpu_sysfs_dir(index):
+    """sysfs directory of the AMD GPU that HIP device `index` is: matched by PCI address when torch exposes it, else the index-th amdgpu card in
+    PCI order.  None if there is no such directory (not an amdgpu box)."""
+    import glob
+    import os
+
+    import torch
+    cards = []
+    for d in glob.glob("/sys/class/drm/card[0-9]*/device"):
+        try:
+            if open(os.path.join(d, "vendor")).read().strip() != "0x1002" or not os.path.exists(os.path.join(d, "pp_dpm_sclk")):
+                continue
+            cards.append((os.path.basename(os.path.realpath(d)), d))      # ("0000:05:00.0", path)
+        except OSError:
+            continue
+    cards.sort()
+    if not cards:
+        return None
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        for addr, d in cards:
+            if addr == want:
+                return d
+    except (AttributeError, RuntimeError):
+        pass
+    return cards[index][1] if index < len(cards) else None
+
+
+def _read_sysfs_telemetry(d):
+    """(sclk MHz, mclk MHz, package power W) from the amdgpu sysfs files rocm-smi itself reads: the starred level of pp_dpm_sclk / pp_dpm_mclk and
+    hwmon power1_average (or power1_input), in microwatts.  Plain file reads: no child process is started from this (GPU-initialised) process."""
+    import glob
+    import re
+
+    def starred(name):
+        try:
+            for line in open(f"{d}/{name}"):
+                if "*" in line and (m := re.search(r"(\d+)\s*Mhz", line, re.I)):
+                    return int(m.group(1))
+        except OSError:
+            pass
+        return None
+    power = None
+    for name in ("power1_average", "power1_input"):
+        for f in glob.glob(f"{d}/hwmon/hwmon*/{name}"):
+            try:
+                power = int(open(f).read().strip()) * 1e-6
+                break
+            except (OSError, ValueError):
+                continue
+        if power is not None:
+            break
+    return starred("pp_dpm_sclk"), starred("pp_dpm_mclk"), power
+
+
 def device_telemetry(step, kern_ms, index, seconds=1.8):
-    """Engine clock, memory clock and package power WHILE the workload's kernel loops: rocm-smi (a child process) is read three times during
+    """Engine clock, memory clock and package power WHILE the workload's kernel loops: the amdgpu sysfs files are read three times during
     about `seconds` of queued launches, after and outside every timed region.  The VALU ceilings of this file assume the 2.4 GHz spec clock;
     under the streaming kernels the package sits at its power cap and the firmware lowers the engine clock (profiles/r04_clock_probe.txt:
     1.87-2.13 GHz at 1400 W for the SB2006 / 1-moment / ARG sweeps, 2.39 GHz for the P3 kernels) — this field says which case a line is."""
-    import re
-    import shutil
-    import subprocess
-
     import torch
-    if not shutil.which("rocm-smi"):
+    d = _amdgpu_sysfs_dir(index)
+    if d is None:
         return None
     per = max(4, min(20000, int(seconds / 3 * 1e3 / max(kern_ms, 1e-3))))
-    sclk, mclk, power = [], [], []
+    sclk, mclk, power, sustained = [], [], [], []
     for _ in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
         for _ in range(per):
             step()
-        try:
-            out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=30).stdout
-        except (OSError, subprocess.SubprocessError):
-            return None
-        mine = [l for l in out.splitlines() if l.startswith(f"GPU[{index}]")]
-        for l in mine:
-            if (m := re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", l)):
-                sclk.append(int(m.group(1)))
-            if (m := re.search(r"mclk clock level: \S+ \((\d+)Mhz\)", l)):
-                mclk.append(int(m.group(1)))
-            if (m := re.search(r"Power \(W\): ([\d.]+)", l)):
-                power.append(float(m.group(1)))
-        busy = not torch.cuda.current_stream().query()      # the queue must still have held work when the sample was taken
-        if not busy and sclk:
-            sclk.pop(); mclk and mclk.pop(); power and power.pop()
-    torch.cuda.synchronize()
+        b.record()
+        time.sleep(min(0.3, 0.5 * per * kern_ms * 1e-3))      # sample in the middle of the queued work, not at its first launch
+        c, m, w = _read_sysfs_telemetry(d)
+        if not torch.cuda.current_stream().query() and c is not None:      # the queue still held work when the sample was taken
+            sclk.append(c); mclk.append(m); power.append(w)
+        torch.cuda.synchronize()
+        sustained.append(a.elapsed_time(b) / per)
     if not sclk:
         return None
     return {"sclk_mhz": sclk, "mclk_mhz": mclk, "package_power_w": power,
-            "how": f"rocm-smi --showclocks --showpower, read while {3 * per} launches of the step were queued (after the timed regions)"}
+            # back-to-back launches for ~0.6 s per batch: the package reaches its power cap and the clock settles lower than in a K-step burst
+            "sustained_ms_per_step": sustained, "launches_per_batch": per,
+            "how": f"amdgpu sysfs (pp_dpm_sclk, pp_dpm_mclk, hwmon power1_average), read while {per} launches of the step were queued, three times "
+                   "(after the timed regions; no child process); sustained_ms_per_step = wall time of each batch / launches (HIP events)"}
 
 
 def cpu_model() -> str:

@@ -37,6 +37,20 @@ def test_single_gpu_line(scaling):
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     assert d["value"] == pytest.approx(1000003 * 3 / (d["ms_per_step"] * 3e-3), rel=1e-9)
+    # round 4: the rotating region, the cold probes, per-rank kernel times, telemetry, the baseline's provenance
+    assert d["rotate"] == 4 and d["value_uses"] in ("same_buffer", "rotating")
+    assert d["same_buffer_ms_per_step"] > 0 and d["rotating_ms_per_step"] > 0
+    assert d["ms_per_step"] == pytest.approx(d["rotating_ms_per_step"] if d["value_uses"] == "rotating" else d["same_buffer_ms_per_step"], rel=1e-9)
+    assert (d["value_uses"] == "rotating") == (d["rotating_ms_per_step"] > 1.05 * d["same_buffer_ms_per_step"])
+    assert len(d["ranks_kernel_ms"]["same_buffer"]) == 1 and len(d["ranks_kernel_ms"]["rotating"]) == 1
+    assert d["timed_region_ms"] < 20 and "short_timed_region" in d                         # 3 steps of a 1e6-point sweep: flagged
+    cold = d["cold"]
+    assert len(cold["first5_ms"]) == 5 and len(cold["first_visit_other_sets_ms"]) == 3
+    assert set(cold["probes"]) == {"after_1s_idle_same_buffers_ms", "fresh_buffers_warm_clocks_ms", "steady_same_buffers_ms"}
+    tel = d["telemetry"]
+    assert tel is None or (len(tel["sclk_mhz"]) >= 1 and all(100 < v < 3000 for v in tel["sclk_mhz"]))
+    assert cb["cpu_model"] and (cb["cores"] == 1 or cb["single_thread"]["value"] > 0) and (cb["julia"] == "absent" or str(cb["julia"]).startswith("/"))
+    assert "frac_vs_guide" in (rf.get("valu") or {"frac_vs_guide": None})
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
@@ -57,6 +71,7 @@ def test_two_ranks_sharing_this_gpu_gloo_test_mode(scaling):
     assert d["config"]["points_total"] == (2 * 1000003 if scaling == "weak" else 1000003)
     per = d["config"]["points_per_gpu"]
     assert per == (1000003 if scaling == "weak" else 500224)        # shard_bounds(1000003, 0, 2): 256-point-aligned halves
+    assert len(d["ranks_kernel_ms"]["same_buffer"]) == 2 and all(v > 0 for v in d["ranks_kernel_ms"]["same_buffer"])      # every rank's kernel time reaches rank 0
     assert d["value"] == pytest.approx(d["config"]["points_total"] * 3 / (d["ms_per_step"] * 3e-3), rel=1e-9)
 
 

@@ -93,9 +93,12 @@ def performance_block(rnd):
             util = pv.get("valu_issue_utilisation")
         cold = (d.get("cold") or {}).get("first5_ms")
         tel = d.get("telemetry") or {}
-        clk = (sum(tel["sclk_mhz"]) / len(tel["sclk_mhz"]), (sum(tel["package_power_w"]) / len(tel["package_power_w"])) if tel.get("package_power_w") else None) if tel.get("sclk_mhz") else None
+        pw = [w for w in (tel.get("package_power_w") or []) if w is not None]
+        clk = (sum(tel["sclk_mhz"]) / len(tel["sclk_mhz"]), (sum(pw) / len(pw)) if pw else None) if tel.get("sclk_mhz") else None
+        sus = tel.get("sustained_ms_per_step")
+        sus = (sum(sus[1:]) / len(sus[1:])) if sus and len(sus) > 1 else None      # the first batch is the ramp
         rows.append((ORDER.index(wl) if wl in ORDER else 99, dt, wl, n, bpp, same, rot, d.get("value_uses"), cold[0] if cold else None, ks, frac_b, frac_p,
-                     tr.get("traffic_over_algorithmic") if tr and tr.get("points") == n else None, ipp, util, r.get("bound", "hbm"), clk))
+                     tr.get("traffic_over_algorithmic") if tr and tr.get("points") == n else None, ipp, util, r.get("bound", "hbm"), clk, sus))
     rows.sort()
     fmt = lambda v, f: "—" if v is None else f % v  # noqa: E731
     out = [f"Measured in ONE session on one box (round {rnd}; `profiles/bench_{rnd}/`, `profiles/{rnd}_kernel_stats_*.csv`, "
@@ -107,12 +110,12 @@ def performance_block(rnd):
            "(bench: of the region `value` uses).  traffic = (2 × FETCH_SIZE + WRITE_SIZE) ÷ algorithmic bytes, per launch, kernels of the step only "
            "(calibration: `profiles/r04_traffic_calibration.txt`).  VALU frac = SQ_INSTS_VALU × 2.4 cycles ÷ (1024 SIMDs × rocprof mean × 2.4 GHz) — against "
            "the fastest measured issue rate of a wave64 VALU instruction (`profiles/r03_probe_valu.txt`), ≤ 1 by construction; 4-cycle slots = the same "
-           "count against one instruction per 4 cycles per SIMD.  sclk / W = engine clock and package power sampled by rocm-smi while the kernel loops "
+           "count against one instruction per 4 cycles per SIMD.  sclk / W = engine clock and package power read from the amdgpu sysfs files while the kernel loops "
            "(`telemetry` of the bench line; the spec clock is 2400 MHz, the package power cap 1400 W).  `bound` is what `bench.py` prices `roofline.frac` against.", "",
-           "| workload | dtype | points | B/point | same ms | rotating ms | first ms | rocprof ms (min) | HBM frac bench | HBM frac rocprof | traffic / algorithmic | "
-           "VALU instr / point | VALU frac | 4-cycle slots | sclk MHz / W | bound |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
-    for _, dt, wl, n, bpp, same, rot, uses, first, ks, fb, fp, tro, ipp, util, bound, clk in rows:
-        out.append(f"| `{wl}` | {dt} | {n:.3g} | {bpp} | {same:.3f} | {fmt(rot, '%.3f')}{' ←' if uses == 'rotating' else ''} | {fmt(first, '%.2f')} | " +
+           "| workload | dtype | points | B/point | same ms | rotating ms | sustained ms | first ms | rocprof ms (min) | HBM frac bench | HBM frac rocprof | traffic / algorithmic | "
+           "VALU instr / point | VALU frac | 4-cycle slots | sclk MHz / W | bound |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    for _, dt, wl, n, bpp, same, rot, uses, first, ks, fb, fp, tro, ipp, util, bound, clk, sus in rows:
+        out.append(f"| `{wl}` | {dt} | {n:.3g} | {bpp} | {same:.3f} | {fmt(rot, '%.3f')}{' ←' if uses == 'rotating' else ''} | {fmt(sus, '%.3f')} | {fmt(first, '%.2f')} | " +
                    (f"{ks[0]:.3f} ({ks[1]:.3f})" if ks else "—") + f" | {fb:.3f} | {fmt(fp, '%.3f')} | {fmt(tro, '%.3f')} | {fmt(ipp, '%.0f')} | "
                    f"{fmt(util * 0.6 if util is not None else None, '%.2f')} | {fmt(util, '%.2f')} | " +
                    ("—" if not clk else f"{clk[0]:.0f}" + (f" / {clk[1]:.0f}" if clk[1] is not None else "")) + f" | {bound} |")

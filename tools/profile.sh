@@ -9,10 +9,10 @@ OUT=$ROOT/gpurun_out/prof_${WL}_${DT}
 mkdir -p "$OUT" "$ROOT/gpurun_out/profiles"
 export TMPDIR=/tmp
 # counter passes: one buffer set, no probes (a per-launch counter does not depend on which buffers the launch sweeps)
-ARGS="$ROOT/bench.py --workload $WL --dtype $DT --points $N --steps 5 --warmup 1 --no-cpu-baseline --rotate 1 --no-cold-probes"
+ARGS="$ROOT/bench.py --workload $WL --dtype $DT --points $N --steps 5 --warmup 1 --no-cpu-baseline --rotate 1 --no-cold-probes --no-telemetry"
 # the kernel-trace pass runs enough launches for its average to be the steady-state duration bench.py reports
 # KT_ROTATE (default 1): with K > 1 the traced launches include the rotating region of bench.py (K disjoint buffer sets)
-KTARGS="$ROOT/bench.py --workload $WL --dtype $DT --points $N --steps ${KT_STEPS:-40} --warmup 5 --no-cpu-baseline --rotate ${KT_ROTATE:-1} --no-cold-probes"
+KTARGS="$ROOT/bench.py --workload $WL --dtype $DT --points $N --steps ${KT_STEPS:-40} --warmup 5 --no-cpu-baseline --rotate ${KT_ROTATE:-1} --no-cold-probes --no-telemetry"
 run() {  # run <what> <cmd…>: a failed or timed-out profiler pass ends the script BEFORE any summary is written from partial data
   local what=$1; shift
   "$@"

@@ -5,7 +5,7 @@ WL=$1; DT=$2; LIB=${3:-}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/sq_${WL}_${DT}; mkdir -p "$OUT"
 export TMPDIR=/tmp
 [ -n "$LIB" ] && export CMX_LIB=$ROOT/$LIB
-ARGS="$ROOT/bench.py --workload $WL --dtype $DT --steps 3 --warmup 1 --no-cpu-baseline"
+ARGS="$ROOT/bench.py --workload $WL --dtype $DT --steps 3 --warmup 1 --no-cpu-baseline --no-telemetry --no-cold-probes --rotate 1"
 cd /tmp
 rocprofv3 --list-avail 2>/dev/null | grep -o "SQ_[A-Z0-9_]*" | sort -u > "$OUT/counters.txt"
 i=0
