@@ -469,7 +469,9 @@ CMX_LEAN_FN double log2(double x) {
 }
 CMX_LEAN_FN double log(double x);
 // ln x for a POSITIVE NORMAL finite x (a diameter or an area at an interior quadrature node): the main path of log() alone — no class test, no
-// rescue block, so the call does not end a basic block.  NaN propagates (the reduction keeps the payload); 0, negatives, subnormals and Inf are outside the contract.
+// rescue block, so the call does not end a basic block.  0, negatives, subnormals, Inf AND NaN are outside the contract: a NaN argument is reduced
+// like a number of exponent 1024 and comes out as ≈ 710.  The P3 integrands that call it also feed the same x linearly into every result (−λ x in
+// the number density that multiplies each integrand), so a NaN node still yields a NaN integral (tests/test_nan_inputs_gpu.py).
 CMX_LEAN_FN double log_pos(double x) {
 #if !CMX_LEAN_TABLES || !CMX_F64_FINITE_FORMS
     return log(x);

@@ -23,6 +23,7 @@ extern "C" void lean_eval(int which, int64_t n, const double *x, double *y) {
             case 15: y[i] = L::sqrt_pos(x[i]); break;
             case 16: y[i] = L::rsqrt_pos(x[i]); break;
             case 17: y[i] = L::pow_m34_pos(x[i]); break;
+            case 18: y[i] = L::log_pos(x[i]); break;
         }
     }
 }
@@ -30,5 +31,5 @@ extern "C" void lean_eval(int which, int64_t n, const double *x, double *y) {
 extern "C" void lean_eval_pinned(int which, int64_t n, const double *x, double *y) {
     namespace L = cmx::lean;
     const L::TabCoefs k = L::tab_coefs();
-    for (int64_t i = 0; i < n; ++i) y[i] = which == 2 ? L::exp(x[i], k) : L::log(x[i], k);
+    for (int64_t i = 0; i < n; ++i) y[i] = which == 2 ? L::exp(x[i], k) : (which == 18 ? L::log_pos(x[i], k) : L::log(x[i], k));
 }

@@ -27,7 +27,7 @@ def lean(tmp_path_factory):
     return ev
 
 
-EXP2, LOG2, EXP, LOG, RCP, SQRT, RSQRT, EXPM1, LOG1P, ERFC, LGAMMA, EXP2_FIN, EXP_FIN, RCP_FINITE, RCP_NZ, SQRT_POS, RSQRT_POS, POW_M34 = range(18)
+EXP2, LOG2, EXP, LOG, RCP, SQRT, RSQRT, EXPM1, LOG1P, ERFC, LGAMMA, EXP2_FIN, EXP_FIN, RCP_FINITE, RCP_NZ, SQRT_POS, RSQRT_POS, POW_M34, LOG_POS = range(19)
 
 
 @pytest.mark.parametrize("script", ["gen_lean_tables.py", "gen_erfc_table.py"])
@@ -194,6 +194,27 @@ def test_finite_argument_forms(lean):
         eb = [800.0, 1e6, 1e12, -800.0, -1e6, -1e12]            # e^x: the Cody–Waite reduction needs |x|·128/ln2 to be an exact integer (|x| < 2e13)
         np.testing.assert_array_equal(lean(EXP_FIN, eb), np.exp(eb))
         assert np.isnan(lean(EXP2_FIN, [np.nan])[0]) and np.isnan(lean(EXP_FIN, [np.nan])[0]) and np.isnan(lean(RCP_NZ, [np.nan])[0]) and np.isnan(lean(RCP_FINITE, [np.nan])[0])
+
+
+def test_log_pos(lean):
+    """log_pos (round 4): ln x for a positive NORMAL finite x — the main path of log() without the class test and the rescue block; the P3
+    quadrature integrands call it on diameters and areas at interior nodes.  Bit-identical to log() on its domain, in the literal-coefficient
+    form and in the pinned (TabCoefs) form.  NaN is OUTSIDE its contract (it comes out as a finite number): the integrands also feed x linearly
+    into every result, which is what carries a NaN node (tests/test_nan_inputs_gpu.py)."""
+    rng = np.random.default_rng(31)
+    x = np.concatenate([10.0 ** rng.uniform(-307, 308, 400_000), 1 + rng.uniform(-1e-3, 1e-3, 100_000), [2.2250738585072014e-308, 1.7976931348623157e308, 1.0]])
+    np.testing.assert_array_equal(lean(LOG_POS, x), lean(LOG, x))
+    np.testing.assert_array_equal(lean(LOG_POS, x, pinned=True), lean(LOG, x, pinned=True))
+    assert ulps(lean(LOG_POS, x), np.log(x)) <= 3
+    assert np.isfinite(lean(LOG_POS, [np.nan])[0])          # documented: not a NaN-propagating form
+
+
+@pytest.mark.gpu
+def test_device_log_pos(dev_lean):
+    rng = np.random.default_rng(32)
+    x = np.concatenate([10.0 ** rng.uniform(-307, 308, 400_000), 1 + rng.uniform(-1e-3, 1e-3, 100_000), [2.2250738585072014e-308, 1.7976931348623157e308, 1.0]])
+    np.testing.assert_array_equal(dev_lean(LOG_POS, x), dev_lean(LOG, x))
+    assert ulps(dev_lean(LOG_POS, x), np.log(x)) <= 3
 
 
 @pytest.mark.gpu

@@ -85,12 +85,15 @@ def performance_block(rnd):
         rot = (rk.get("rotating") or [None])[0]
         frac_b = n * bpp / (kms * 1e-3) / 1e9 / HBM_PEAK
         frac_p = n * bpp / (ks[0] * 1e-3) / 1e9 / HBM_PEAK if ks else None
-        ipp = util = None
+        ipp = util = active = None
         if pv and pv.get("points") == n:
             insts = [k.get("counters", {}).get("SQ_INSTS_VALU") for k in pv["kernels"].values()]
             if insts and all(v is not None for v in insts):
                 ipp = sum(insts) * 64 / n
             util = pv.get("valu_issue_utilisation")
+            act = [k.get("counters", {}).get("SQ_ACTIVE_INST_VALU") for k in pv["kernels"].values()]
+            if act and all(v is not None for v in act):
+                active = sum(act) * 4 / 1024          # clocks per SIMD in which the VALU was executing (the counter ticks once per 4 clocks)
         cold = (d.get("cold") or {}).get("first5_ms")
         tel = d.get("telemetry") or {}
         pw = [w for w in (tel.get("package_power_w") or []) if w is not None]
@@ -98,7 +101,8 @@ def performance_block(rnd):
         sus = tel.get("sustained_ms_per_step")
         sus = (sum(sus[1:]) / len(sus[1:])) if sus and len(sus) > 1 else None      # the first batch is the ramp
         rows.append((ORDER.index(wl) if wl in ORDER else 99, dt, wl, n, bpp, same, rot, d.get("value_uses"), cold[0] if cold else None, ks, frac_b, frac_p,
-                     tr.get("traffic_over_algorithmic") if tr and tr.get("points") == n else None, ipp, util, r.get("bound", "hbm"), clk, sus))
+                     tr.get("traffic_over_algorithmic") if tr and tr.get("points") == n else None, ipp, util, r.get("bound", "hbm"), clk, sus,
+                     (active / (clk[0] * 1e6 * ks[0] * 1e-3)) if active and clk and ks and dt == "f64" else None))
     rows.sort()
     fmt = lambda v, f: "—" if v is None else f % v  # noqa: E731
     out = [f"Measured in ONE session on one box (round {rnd}; `profiles/bench_{rnd}/`, `profiles/{rnd}_kernel_stats_*.csv`, "
@@ -111,14 +115,17 @@ def performance_block(rnd):
            "(calibration: `profiles/r04_traffic_calibration.txt`).  VALU frac = SQ_INSTS_VALU × 2.4 cycles ÷ (1024 SIMDs × rocprof mean × 2.4 GHz) — against "
            "the fastest measured issue rate of a wave64 VALU instruction (`profiles/r03_probe_valu.txt`), ≤ 1 by construction; 4-cycle slots = the same "
            "count against one instruction per 4 cycles per SIMD.  sclk / W = engine clock and package power read from the amdgpu sysfs files while the kernel loops "
-           "(`telemetry` of the bench line; the spec clock is 2400 MHz, the package power cap 1400 W).  `bound` is what `bench.py` prices `roofline.frac` against.", "",
+           "(`telemetry` of the bench line; the spec clock is 2400 MHz, the package power cap 1400 W).  VALU busy at sclk = SQ_ACTIVE_INST_VALU × 4 clocks ÷ "
+           "1024 SIMDs ÷ (sclk × rocprof mean): the share of the launch, at the clock the kernel actually ran at, in which the SIMDs' vector ALUs were executing "
+           "(Float64 rows only: the counter ticks once per 4 clocks, exact for Float64 instructions, which occupy the ALU for at least 4; a Float32 instruction "
+           "that issues in 2.4–2.9 clocks is charged a whole tick, so the same ratio runs up to 1.7 for the Float32 kernels and is not printed).  `bound` is what `bench.py` prices `roofline.frac` against.", "",
            "| workload | dtype | points | B/point | same ms | rotating ms | sustained ms | first ms | rocprof ms (min) | HBM frac bench | HBM frac rocprof | traffic / algorithmic | "
-           "VALU instr / point | VALU frac | 4-cycle slots | sclk MHz / W | bound |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
-    for _, dt, wl, n, bpp, same, rot, uses, first, ks, fb, fp, tro, ipp, util, bound, clk, sus in rows:
+           "VALU instr / point | VALU frac | 4-cycle slots | sclk MHz / W | VALU busy at sclk | bound |", "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    for _, dt, wl, n, bpp, same, rot, uses, first, ks, fb, fp, tro, ipp, util, bound, clk, sus, busy in rows:
         out.append(f"| `{wl}` | {dt} | {n:.3g} | {bpp} | {same:.3f} | {fmt(rot, '%.3f')}{' ←' if uses == 'rotating' else ''} | {fmt(sus, '%.3f')} | {fmt(first, '%.2f')} | " +
                    (f"{ks[0]:.3f} ({ks[1]:.3f})" if ks else "—") + f" | {fb:.3f} | {fmt(fp, '%.3f')} | {fmt(tro, '%.3f')} | {fmt(ipp, '%.0f')} | "
                    f"{fmt(util * 0.6 if util is not None else None, '%.2f')} | {fmt(util, '%.2f')} | " +
-                   ("—" if not clk else f"{clk[0]:.0f}" + (f" / {clk[1]:.0f}" if clk[1] is not None else "")) + f" | {bound} |")
+                   ("—" if not clk else f"{clk[0]:.0f}" + (f" / {clk[1]:.0f}" if clk[1] is not None else "")) + f" | {fmt(busy, '%.2f')} | {bound} |")
     # the cold probes of the driver's default line: what separates the clock / power ramp from address translation
     dflt = lines.get("default") or {}
     pr = (dflt.get("cold") or {}).get("probes")
