@@ -142,7 +142,7 @@ def check_linearized_parity(ft, got, ref, inst, c64, dt, what):
         ps = parity.plain_stats(x, r, scale, parity.RTOL[ft], parity.FLOOR[ft], parity.CEIL[ft], ~near & (attainable | f64), parity.WELLCOND[ft])
         ps2 = parity.plain_stats(x, r, scale, parity.RTOL[ft], parity.FLOOR[ft], parity.CEIL[ft], ~near & (attainable2 | f64), parity.WELLCOND[ft])
         ps["worst_wellcond"], ps["n_wellcond"] = ps2["worst_wellcond"], ps2["n_wellcond"]
-        parity.REPORTS.append({"what": what, "output": k, "ft": ft, "rtol": parity.RTOL[ft], "worst_normalised": worst[k] * parity.RTOL[ft],
+        parity.REPORTS.append({"what": what, "family": "1-moment LinearizedAverage (a2 / f1)", "output": k, "ft": ft, "rtol": parity.RTOL[ft], "worst_normalised": worst[k] * parity.RTOL[ft],
                                "frac_below_difference_quotient_floor": frac_set_aside, **ps})
         # measured (host build of the point function, 200 003 states): 16 % of the q_rai tendencies and 10 % of the q_sno ones sit below
         # their floor at the Δt = 0.01 s probe (the reference's "small Δt → Instantaneous" test), < 0.3 % at Δt = 20 s and 60 s

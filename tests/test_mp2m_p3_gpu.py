@@ -94,7 +94,7 @@ def test_fused_entry_parity(dev, oracle, ft, limited):
         j = int(np.argmax(np.where(ok, err, 0)))
         assert worst[k] <= 1.0, (k, j, x[j], ref[q][j], scale[q][j], {kk: s[kk][j] for kk in s})
         ps = parity.plain_stats(x, ref[q], scale[q], parity.RTOL[ft], parity.FLOOR[ft], parity.CEIL[ft], ok, parity.WELLCOND[ft])
-        parity.REPORTS.append({"what": f"2M+P3 fused {ft} limited={limited}", "output": k, "ft": ft, "rtol": parity.RTOL[ft],
+        parity.REPORTS.append({"what": f"2M+P3 fused {ft} limited={limited}", "family": "2M + P3 fused entry (f2)", "output": k, "ft": ft, "rtol": parity.RTOL[ft],
                                "worst_normalised": float(worst[k]) * parity.RTOL[ft], **ps})
         assert ps["frac_within"] >= parity.MIN_FRAC_WITHIN[ft] and ps["worst_wellcond"] <= parity.RTOL[ft], (k, ps)
     print(f"\n[2M+P3 fused] {ft} limited={limited}: worst err/tol " + " ".join(f"{k}={v:.2f}" for k, v in worst.items()) + f" (compared {ok.mean():.1%})")

@@ -153,6 +153,11 @@ def parity_block(rnd):
            "well-conditioned plain bound; T = test-specific tolerance only — the reason is in the row's `note`).", "",
            "| family | dtype | columns | points | outside plain bound | set aside | min fraction inside | worst well-conditioned | asserted |",
            "|---|---|---|---|---|---|---|---|---|"]
+    # two tests append their rows themselves (their metrics differ from assert_parity's): attribute them by what they say they are
+    for r in d["rows"]:
+        if not r.get("family"):
+            r["family"] = ("2M + P3 fused entry (f2)" if r["what"].startswith("2M+P3 fused") else
+                           "1-moment LinearizedAverage (a2 / f1)" if r["what"].startswith("1M LinearizedAverage") else None)
     fams = []
     for r in d["rows"]:
         f = r.get("family") or "unattributed"
