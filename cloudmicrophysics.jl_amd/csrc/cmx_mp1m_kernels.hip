@@ -29,14 +29,18 @@ namespace cmx {
 
 
 // bulk_microphysics_tendencies(Instantaneous(), Microphysics1Moment(), …) over columns — BMT:505-514
-#ifndef CMX_1M_BLOCK
-#define CMX_1M_BLOCK 256      // lanes per workgroup of the tendencies kernel (A/B switch)
+// Lanes per workgroup of the tendencies kernel, per float type (same-box A/Bs, round 4, ms per 1e8 points: Float32 256 lanes 0.804, 128 lanes
+// 0.758 — and on another box 128 lanes 0.723, 64 lanes 0.714; Float64 256 lanes 2.375, 128 lanes 2.396 — profiles/r04_ab_sessions.txt, sessions
+// 13-15): short-lived one-wave workgroups free their slots as soon as their own wave has stored.  -DCMX_1M_BLOCK=n forces one size for both.
+#ifdef CMX_1M_BLOCK
+template <typename FT> constexpr int kBlock1m = CMX_1M_BLOCK;
+#else
+template <typename FT> constexpr int kBlock1m = sizeof(FT) == 4 ? 64 : 256;
 #endif
-constexpr int kBlock1m = CMX_1M_BLOCK;
 template <typename FT, int VEC, uint32_t FLAGS = kRuntimeFlags>
-__global__ __launch_bounds__(kBlock1m) void mp1m_tendencies_kernel(const Mp1mConsts<FT> c, const Mp1mIn<FT> in,
-                                                                   const Mp1mOut<FT> out, const int64_t nvec) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock1m + threadIdx.x;
+__global__ __launch_bounds__(kBlock1m<FT>) void mp1m_tendencies_kernel(const Mp1mConsts<FT> c, const Mp1mIn<FT> in,
+                                                                       const Mp1mOut<FT> out, const int64_t nvec) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock1m<FT> + threadIdx.x;
     FT rho[VEC], T[VEC], q_tot[VEC], q_lcl[VEC], q_icl[VEC], q_rai[VEC], q_sno[VEC];
     if (i < nvec) {
         load_col<FT, VEC>(in.rho, i, rho); load_col<FT, VEC>(in.T, i, T); load_col<FT, VEC>(in.q_tot, i, q_tot);
@@ -80,10 +84,14 @@ __device__ __forceinline__ void mp1m_linearized_lane(const Mp1mLinKernArgs<FT> &
     at(io.out[0], 7) = dl; at(io.out[1], 8) = di; at(io.out[2], 9) = dr; at(io.out[3], 10) = ds;
 }
 
+#ifndef CMX_1M_LIN_BLOCK
+#define CMX_1M_LIN_BLOCK 256      // lanes per workgroup of the LinearizedAverage kernel (A/B switch)
+#endif
+constexpr int kBlockLin = CMX_1M_LIN_BLOCK;
 template <typename FT, uint32_t FLAGS = kRuntimeFlags>
-__global__ __launch_bounds__(kBlock) void mp1m_linearized_kernel(const Mp1mLinKernArgs<FT> k0, const Mp1mLinIO<FT> io, const int64_t n) {
+__global__ __launch_bounds__(kBlockLin) void mp1m_linearized_kernel(const Mp1mLinKernArgs<FT> k0, const Mp1mLinIO<FT> io, const int64_t n) {
     Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kBlockLin + threadIdx.x;
     if (i >= n) return;
     mp1m_linearized_lane<FT, FLAGS>(k0, io, [i](auto *p, int) -> decltype(auto) { return (p[i]); });
 }
@@ -162,11 +170,11 @@ static int32_t tendencies_1m_entry(const MP *mp, const TH *tps, uint32_t flags, 
         Mp1mIn<FT> in{rho + lo, T + lo, q_tot + lo, q_lcl + lo, q_icl + lo, q_rai + lo, q_sno + lo};
         Mp1mOut<FT> out{dq_lcl + lo, dq_icl + lo, dq_rai + lo, dq_sno + lo};
         const int64_t nv = count / V;
-        const dim3 grid((unsigned)((nv + kBlock1m - 1) / kBlock1m));
+        const dim3 grid((unsigned)((nv + kBlock1m<FT> - 1) / kBlock1m<FT>));
         if (flags == CMX_1M_DEFAULT_OPTIONS && mp1m_default_exponents(c))
-            CMX_LAUNCH_FRONT((mp1m_tendencies_kernel<FT, V, CMX_1M_DEFAULT_OPTIONS | kDefExpBit>), grid, dim3(kBlock1m), 0, s, c, in, out, nv);
+            CMX_LAUNCH_FRONT((mp1m_tendencies_kernel<FT, V, CMX_1M_DEFAULT_OPTIONS | kDefExpBit>), grid, dim3(kBlock1m<FT>), 0, s, c, in, out, nv);
         else
-            CMX_LAUNCH_FRONT((mp1m_tendencies_kernel<FT, V>), grid, dim3(kBlock1m), 0, s, c, in, out, nv);
+            CMX_LAUNCH_FRONT((mp1m_tendencies_kernel<FT, V>), grid, dim3(kBlock1m<FT>), 0, s, c, in, out, nv);
     };
     if (same_mis) {
         const int64_t head = std::min<int64_t>(n, mis0 ? (int64_t)((16 - mis0) / sizeof(FT)) : 0);
@@ -230,11 +238,11 @@ static int32_t linearized_1m_entry(const MP *mp, const TH *tps, uint32_t flags, 
     if (n == 0) return CMX_OK;
     if (!rho || !T || !q_tot || !q_lcl || !q_icl || !q_rai || !q_sno || !dq_lcl || !dq_icl || !dq_rai || !dq_sno) return CMX_ERR_BAD_ARG;
     Mp1mLinIO<FT> io{{rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno}, {dq_lcl, dq_icl, dq_rai, dq_sno}};
-    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+    const dim3 grid((unsigned)((n + kBlockLin - 1) / kBlockLin));
     if (flags == CMX_1M_DEFAULT_OPTIONS && mp1m_default_exponents(k.c))
-        CMX_LAUNCH_FRONT((mp1m_linearized_kernel<FT, CMX_1M_DEFAULT_OPTIONS | kDefExpBit>), grid, dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), k, io, n);
+        CMX_LAUNCH_FRONT((mp1m_linearized_kernel<FT, CMX_1M_DEFAULT_OPTIONS | kDefExpBit>), grid, dim3(kBlockLin), 0, reinterpret_cast<hipStream_t>(stream), k, io, n);
     else
-        CMX_LAUNCH_FRONT((mp1m_linearized_kernel<FT>), grid, dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), k, io, n);
+        CMX_LAUNCH_FRONT((mp1m_linearized_kernel<FT>), grid, dim3(kBlockLin), 0, reinterpret_cast<hipStream_t>(stream), k, io, n);
     CMX_HIP_TRY(hipGetLastError());
     return CMX_OK;
 }

@@ -227,6 +227,16 @@ int main(int argc, char **argv) {
         RUN_NP(128, P_NT, P_NT, 256, false, 7, 6, 52.0, "7r/6w") RUN_NP(128, P_NT, P_SC1NT, 256, false, 7, 6, 52.0, "7r/6w")
         return 0;
     }
+    const bool shapes = argc > 5 && std::string(argv[5]) == "shapes";          // the column counts of the other HBM-bound kernels (bare copies)
+    if (shapes) {
+        for (int rep = 0; rep < 2; ++rep) {
+            RUN_NP(128, P_NT, P_NT, 0, false, 3, 2, 20.0, "3r/2w  (ice nucleation)") RUN_NP(256, P_NT, P_NT, 0, false, 3, 2, 20.0, "3r/2w  (ice nucleation)")
+            RUN_NP(128, P_NT, P_NT, 0, false, 2, 1, 12.0, "2r/1w  (0-moment)") RUN_NP(128, P_NT, P_NT, 0, false, 7, 4, 44.0, "7r/4w  (1-moment, fields)")
+            RUN_NP(128, P_NT, P_NT, 0, false, 4, 5, 36.0, "4r/5w  (ARG2000, 5 modes)") RUN_NP(128, P_NT, P_NT, 0, false, 7, 6, 52.0, "7r/6w  (north star)")
+            RUN_NP(128, P_NT, P_NT, 64, false, 3, 2, 20.0, "3r/2w") RUN_NP(128, P_NT, P_NT, 174, false, 4, 5, 36.0, "4r/5w") RUN_NP(128, P_NT, P_NT, 253, false, 7, 4, 44.0, "7r/4w")
+        }
+        return 0;
+    }
     if (quick) {
         for (int rep = 0; rep < 3; ++rep) {
             RUN_NP(128, P_NT, P_NT, 0, false, 7, 6, 52.0, "") RUN_NP(128, P_NT, P_SC1NT, 0, false, 7, 6, 52.0, "") RUN_NP(128, P_NT, P_NT, 256, false, 7, 6, 52.0, "")
