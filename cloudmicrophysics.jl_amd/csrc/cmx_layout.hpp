@@ -37,7 +37,10 @@ template <typename FT, int NIN, int NOUT> struct LayoutIO {
 #ifndef CMX_LAYOUT_F64_VEC
 #define CMX_LAYOUT_F64_VEC 1     // A/B switch (2: 16-byte accesses for Float64 as well)
 #endif
-constexpr int kLayoutBS = 128;   // lanes per workgroup of the adapter kernel
+#ifndef CMX_LAYOUT_BS
+#define CMX_LAYOUT_BS 128
+#endif
+constexpr int kLayoutBS = CMX_LAYOUT_BS;   // lanes per workgroup of the adapter kernel (A/B switch)
 
 template <typename FT, typename POLICY, int VEC, bool SEG, bool AOS, int BS = kLayoutBS>
 __global__ __launch_bounds__(BS) void tendencies_layout_kernel(const typename POLICY::Consts c,
