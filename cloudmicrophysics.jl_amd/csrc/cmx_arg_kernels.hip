@@ -429,15 +429,18 @@ template <typename FT> struct ArgColIO {
 };
 template <typename FT> struct ArgColPar { FT l2_f1, f2_l2e, g1, g2; };   // log2 f1, f2·log2 e, g1, g2 of the ARG fit (f_i = f1 exp(f2 ln²σ), g_i = g1 + g2 ln σ)
 
-#ifndef CMX_ARGCOL_BS
-#define CMX_ARGCOL_BS 128
+// lanes per workgroup, per float type (same-box A/B, round 4, ms per 1e8 states of 5 modes: Float32 64 lanes 1.967, 128 lanes 2.11, 256 lanes 2.085;
+// Float64 5.715 / 5.43 / 5.36 — profiles/r04_ab_sessions.txt, session 17).  -DCMX_ARGCOL_BS=n forces one size for both (A/B switch).
+#ifdef CMX_ARGCOL_BS
+template <typename FT> constexpr int kArgColBS = CMX_ARGCOL_BS;
+#else
+template <typename FT> constexpr int kArgColBS = sizeof(FT) == 4 ? 64 : 256;
 #endif
-constexpr int kArgColBS = CMX_ARGCOL_BS;
 template <typename FT, int NM, bool SINKS, int VEC, bool N_ONLY>
-__global__ __launch_bounds__(kArgColBS) void arg_activation_columns_kernel(const ArgConsts<FT> c, const ArgColPar<FT> par, const ArgIO<FT> io,
+__global__ __launch_bounds__(kArgColBS<FT>) void arg_activation_columns_kernel(const ArgConsts<FT> c, const ArgColPar<FT> par, const ArgIO<FT> io,
                                                                            const ArgColIO<FT> mc, const int64_t nvec) {
     using M = Math<FT>;
-    const int64_t i = (int64_t)blockIdx.x * kArgColBS + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kArgColBS<FT> + threadIdx.x;
     FT T[VEC], p[VEC], w[VEC], qt[VEC], ql[VEC] = {}, qi[VEC] = {}, Nl[VEC] = {}, Ni[VEC] = {};
     if (i < nvec) {
         load_col<FT, VEC>(io.T, i, T); load_col<FT, VEC>(io.p, i, p); load_col<FT, VEC>(io.w, i, w); load_col<FT, VEC>(io.q_tot, i, qt);
@@ -543,9 +546,9 @@ static void launch_arg_columns(const ArgConsts<FT> &c, const ArgColPar<FT> &par,
             mc.r_dry[j] += lo; mc.stdev[j] += lo; mc.N[j] += lo; mc.hyg[j] += lo; mc.mmix[j] = off(mc.mmix[j], lo);
         }
         const int64_t nv = count / V;
-        const dim3 grid((unsigned)((nv + kArgColBS - 1) / kArgColBS));
-        if (!io.want_M) hipLaunchKernelGGL((arg_activation_columns_kernel<FT, NM, SINKS, V, true>), grid, dim3(kArgColBS), 0, s, c, par, io, mc, nv);
-        else hipLaunchKernelGGL((arg_activation_columns_kernel<FT, NM, SINKS, V, false>), grid, dim3(kArgColBS), 0, s, c, par, io, mc, nv);
+        const dim3 grid((unsigned)((nv + kArgColBS<FT> - 1) / kArgColBS<FT>));
+        if (!io.want_M) hipLaunchKernelGGL((arg_activation_columns_kernel<FT, NM, SINKS, V, true>), grid, dim3(kArgColBS<FT>), 0, s, c, par, io, mc, nv);
+        else hipLaunchKernelGGL((arg_activation_columns_kernel<FT, NM, SINKS, V, false>), grid, dim3(kArgColBS<FT>), 0, s, c, par, io, mc, nv);
     };
     if (same_mis && VEC > 1) {
         const int64_t head = std::min<int64_t>(n, mis0 ? (int64_t)((16 - mis0) / sizeof(FT)) : 0);

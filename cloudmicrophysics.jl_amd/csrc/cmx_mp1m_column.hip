@@ -134,7 +134,12 @@ __global__ __launch_bounds__(BS) void mp1m_column_kernel(const Mp1mColKernArgs<F
     for (int s = 0; s < 4; ++s) store_col<FT, VEC, true>(io.out[s] + first, v, o[s]);
 }
 
-constexpr int kColBS1m = 128;
+// lanes per workgroup: 256 (same-box A/B, round 4, ms per 1e8 points: Float32 64 lanes 1.156, 128 lanes 1.140, 256 lanes 1.120; Float64 4.74 / 4.63 / 4.55;
+// profiles/r04_ab_sessions.txt, session 18 — as for the SB2006 column kernel, a longer tile halves the share of the overlap lane)
+#ifndef CMX_COLUMN1M_BS
+#define CMX_COLUMN1M_BS 256
+#endif
+constexpr int kColBS1m = CMX_COLUMN1M_BS;
 
 template <typename FT, int VEC>
 static void launch_column_1m(bool def, bool lin, bool general, const Mp1mColKernArgs<FT> &a, const Mp1mColIO<FT> &io, int64_t first, int64_t nvec,

@@ -199,8 +199,10 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(sizeof(FT) =
     store_col<FT, VEC, true>(io.dn_rai + first, v, o[3]);
 }
 
+// lanes per workgroup: 256 (same-box A/B, round 4, ms per 1e8 points: Float32 64 lanes 0.884, 128 lanes 0.852, 256 lanes 0.834; Float64 2.97 / 2.72 / 2.65 —
+// a longer tile halves the share of the overlap lane and of the halo traffic; profiles/r04_ab_sessions.txt, session 17)
 #ifndef CMX_COLUMN_BS
-#define CMX_COLUMN_BS 128
+#define CMX_COLUMN_BS 256
 #endif
 constexpr int kColBS = CMX_COLUMN_BS;
 

@@ -20,7 +20,8 @@ def test_design_is_the_current_state_document():
         m = re.search(rf"<!-- BEGIN GENERATED {name} -->\n(.*?)\n<!-- END GENERATED {name} -->", doc, re.S)
         assert m and len(m.group(1)) > 200, f"generated block {name} is missing or empty"
     assert (REPO / "HISTORY.md").exists()
-    assert len(doc) < 60_000, "DESIGN.md is the current-state document; narrative belongs in HISTORY.md"
+    # (the two generated blocks are ≈ 17 KB of it since round 4: 33 bench lines × 18 columns and the per-family parity table)
+    assert len(doc) < 64_000, "DESIGN.md is the current-state document; narrative belongs in HISTORY.md"
     # the parity paragraph of the document is the report's own summary: its Float32 / Float64 worst well-conditioned errors meet the bounds
     blk = re.search(r"<!-- BEGIN GENERATED parity -->\n(.*?)\n<!-- END GENERATED parity -->", doc, re.S).group(1)
     assert "Rows whose worst well-conditioned point exceeds the tolerance: 0." in blk

@@ -66,7 +66,7 @@ def test_column_kernels_do_not_spill(kernels):
         assert not [k for k in ks if k["vgpr_spill"]], frag
     for frag in ("sb2006_column_kernel", "mp1m_column_kernel"):
         assert not [k for k in kernels if frag in k["name"] and k["private"]], frag
-    bench_sb = [k for k in kernels if "sb2006_column_kernel<double, true, 1, false, 1, 128" in k["name"]]
+    bench_sb = [k for k in kernels if "sb2006_column_kernel<double, true, 1, false, 1, 256" in k["name"]]
     assert len(bench_sb) == 2 and all(k["vgpr"] <= 168 for k in bench_sb), bench_sb
     arg = {}
     for k in kernels:
