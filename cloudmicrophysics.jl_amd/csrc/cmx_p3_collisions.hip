@@ -903,7 +903,14 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
 
 // launch geometry: 256 lanes (32 states) per workgroup unless the per-state LDS caches (6n + 100 values) would not fit — then 128
 template <typename FT> static void collision_geometry(int group, int nq, int64_t n, dim3 &grid, dim3 &block, size_t &lds) {
-    int threads = kBlock;
+    // lanes per workgroup to start from (the kernel reads blockDim.x): Float64 256 — 128 or 64 lanes cost 15–17 % (21.4 → 24.6 / 25.0 ms per 1e6 states
+    // of the 2M + P3 entry: the pointwise pass then runs with 16 or 8 of a wave's 64 lanes) — Float32 64: 7.14 → 6.86 ms (same-box A/B, round 4,
+    // profiles/r04_ab_sessions.txt, session 19).  -DCMX_COL_THREADS=n forces one size for both.
+#ifdef CMX_COL_THREADS
+    int threads = CMX_COL_THREADS;
+#else
+    int threads = sizeof(FT) == 4 ? 64 : kBlock;
+#endif
     auto bytes = [&](int t) { return sizeof(FT) * (size_t)(2 * nq + (t / group) * ColLds<FT>::per_group(nq)); };
     while (threads > 64 && bytes(threads) > 150 * 1024) threads /= 2;
     const int ppb = threads / group;

@@ -24,6 +24,11 @@
 
 namespace cmx {
 
+#ifndef CMX_P3_BS
+#define CMX_P3_BS 256
+#endif
+constexpr int kP3BS = CMX_P3_BS;      // lanes per workgroup of the kernels of this file, one state per lane (A/B switch)
+
 
 // get_distribution_logλ :284-320 for one state (shared by the shape kernel and the fused shape → fall-speed kernel).  `guess` may be
 // nullptr (no warm start).  All residual evaluations (the two bracket ends, the optional warm-start guess of _narrow_bracket :336-353,
@@ -100,10 +105,10 @@ __device__ __forceinline__ FT p3_solve_loglam(const P3Consts<FT> &c, const P3Poi
 }
 
 template <typename FT>
-__global__ __launch_bounds__(kBlock) void p3_shape_kernel(const P3Consts<FT> c, const P3IO<FT> io, const int64_t n) {
+__global__ __launch_bounds__(kP3BS) void p3_shape_kernel(const P3Consts<FT> c, const P3IO<FT> io, const int64_t n) {
     Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using P = PM<FT>;
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kP3BS + threadIdx.x;
     if (i >= n) return;
     P3Point<FT> s;
     p3_make_point<FT>(c, io.rho_q[i], io.rho_n[i], io.x3[i], io.x4[i], s);
@@ -131,7 +136,7 @@ static int32_t p3_entry(const PR *params, uint32_t flags, int32_t brent_iters, i
     P3Consts<FT> c = make_p3_consts<FT>(*params, flags);
     c.brent_iters = brent_iters > 0 ? brent_iters : PM<FT>::kBrent;
     P3IO<FT> io{rho_q, rho_n, x3, x4, guess, F_rim, rho_rim, loglam, D_m, logN0};
-    hipLaunchKernelGGL((p3_shape_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+    hipLaunchKernelGGL((p3_shape_kernel<FT>), dim3((unsigned)((n + kP3BS - 1) / kP3BS)), dim3(kP3BS), 0,
                        reinterpret_cast<hipStream_t>(stream), c, io, n);
     CMX_HIP_TRY(hipGetLastError());
     return CMX_OK;
@@ -147,11 +152,11 @@ template <typename FT, typename QUAD> struct P3VelIO {
 // SOLVE: the shape solve (get_distribution_logλ) runs in this launch instead of reading a log λ column — one launch for the whole
 // BASELINE config-5 pass: no second read of the state, no log λ round trip through HBM (cmx_p3_shape_terminal_velocities_*).
 template <typename FT, typename QUAD, bool ASPECT, bool MELT = false, bool SOLVE = false>
-__global__ __launch_bounds__(kBlock) void p3_velocity_kernel(const P3Consts<FT> c, const P3VelConsts<FT> v, const QUAD quad,
+__global__ __launch_bounds__(kP3BS) void p3_velocity_kernel(const P3Consts<FT> c, const P3VelConsts<FT> v, const QUAD quad,
                                                             const P3VelIO<FT, QUAD> io, const int64_t n) {
     Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using P = PM<FT>;
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kP3BS + threadIdx.x;
     if (i >= n) return;
     P3Point<FT> s;
     p3_make_point<FT>(c, io.rho_q[i], io.rho_n[i], io.x3[i], io.x4[i], s);
@@ -269,7 +274,7 @@ static int32_t p3_velocity_entry(const PR *params, const VR *vel, const QUAD *qu
     c.brent_iters = 0;
     const P3VelConsts<FT> v = make_p3_vel_consts<FT>(*params, *vel, (double)p);
     P3VelIO<FT, QUAD> io{rho_q, rho_n, x3, x4, rho_a, loglam, v_n, v_m, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+    const dim3 grid((unsigned)((n + kP3BS - 1) / kP3BS)), block(kP3BS);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (flags & CMX_P3_NO_ASPECT_RATIO)
         hipLaunchKernelGGL((p3_velocity_kernel<FT, QUAD, false>), grid, block, 0, st, c, v, *quad, io, n);
@@ -294,7 +299,7 @@ static int32_t p3_shape_velocity_entry(const PR *params, const VR *vel, const QU
     c.brent_iters = brent_iters > 0 ? brent_iters : PM<FT>::kBrent;
     const P3VelConsts<FT> v = make_p3_vel_consts<FT>(*params, *vel, (double)p);
     P3VelIO<FT, QUAD> io{rho_q, rho_n, x3, x4, rho_a, nullptr, v_n, v_m, nullptr, nullptr, nullptr, guess, loglam, D_m};
-    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+    const dim3 grid((unsigned)((n + kP3BS - 1) / kP3BS)), block(kP3BS);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (flags & CMX_P3_NO_ASPECT_RATIO)
         hipLaunchKernelGGL((p3_velocity_kernel<FT, QUAD, false, false, true>), grid, block, 0, st, c, v, *quad, io, n);
@@ -324,7 +329,7 @@ static int32_t p3_melt_entry(const PR *params, const VR *vel, const AP *aps, con
     v.LH_f0 = (FT)((double)tps->LH_s0 - (double)tps->LH_v0); v.dcp_f = (FT)((double)tps->cp_l - (double)tps->cp_i);
     v.T_0 = (FT)tps->T_0; v.T_freeze = (FT)params->T_freeze;
     P3VelIO<FT, QUAD> io{rho_q, rho_n, x3, x4, rho_a, loglam, nullptr, nullptr, T, dNdt, dLdt, nullptr, nullptr, nullptr};
-    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+    const dim3 grid((unsigned)((n + kP3BS - 1) / kP3BS)), block(kP3BS);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (flags & CMX_P3_NO_ASPECT_RATIO)
         hipLaunchKernelGGL((p3_velocity_kernel<FT, QUAD, false, true>), grid, block, 0, st, c, v, *quad, io, n);
@@ -342,11 +347,11 @@ static int32_t p3_melt_entry(const PR *params, const VR *vel, const AP *aps, con
 template <typename FT, typename QUAD> struct P3SelfIO { const FT *rho_q, *rho_n, *x3, *x4, *rho_a, *loglam; FT *dNdt; };
 
 template <typename FT, typename QUAD, bool ASPECT>
-__global__ __launch_bounds__(kBlock) void p3_self_collection_kernel(const P3Consts<FT> c, const P3VelConsts<FT> v, const QUAD quad,
+__global__ __launch_bounds__(kP3BS) void p3_self_collection_kernel(const P3Consts<FT> c, const P3VelConsts<FT> v, const QUAD quad,
                                                                    const P3SelfIO<FT, QUAD> io, const int64_t n) {
     Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using P = PM<FT>;
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kP3BS + threadIdx.x;
     if (i >= n) return;
     P3Point<FT> s;
     p3_make_point<FT>(c, io.rho_q[i], io.rho_n[i], io.x3[i], io.x4[i], s);
@@ -438,7 +443,7 @@ static int32_t p3_self_collection_entry(const PR *params, const VR *vel, const Q
     c.brent_iters = 0;
     const P3VelConsts<FT> v = make_p3_vel_consts<FT>(*params, *vel, 1e-6);
     P3SelfIO<FT, QUAD> io{rho_q, rho_n, x3, x4, rho_a, loglam, dNdt};
-    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+    const dim3 grid((unsigned)((n + kP3BS - 1) / kP3BS)), block(kP3BS);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (flags & CMX_P3_NO_ASPECT_RATIO)
         hipLaunchKernelGGL((p3_self_collection_kernel<FT, QUAD, false>), grid, block, 0, st, c, v, *quad, io, n);
@@ -451,10 +456,10 @@ static int32_t p3_self_collection_entry(const PR *params, const VR *vel, const Q
 // ---- UT.gamma_inc / UT.gamma_inc_inv over columns (src/Utilities.jl:54-61,93-144,205-252; KA wrapper test_gamma_inc_kernel!,
 // test/gpu_tests.jl:456-461) — the very functions the shape solver, the quantile bounds and the collision kernels call
 template <typename FT>
-__global__ __launch_bounds__(kBlock) void gamma_inc_kernel(const int64_t n, const FT *__restrict__ a, const FT *__restrict__ x, FT *__restrict__ Pout,
+__global__ __launch_bounds__(kP3BS) void gamma_inc_kernel(const int64_t n, const FT *__restrict__ a, const FT *__restrict__ x, FT *__restrict__ Pout,
                                                            FT *__restrict__ Qout) {
     Math<FT>::prepare();
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kP3BS + threadIdx.x;
     if (i >= n) return;
     const FT ai = a[i], xi = x[i];
     const FT lg = PM<FT>::lgamma(ai);
@@ -465,10 +470,10 @@ __global__ __launch_bounds__(kBlock) void gamma_inc_kernel(const int64_t n, cons
     if (Qout) Qout[i] = series ? FT(1) - g : g;
 }
 template <typename FT>
-__global__ __launch_bounds__(kBlock) void gamma_inc_inv_kernel(const int64_t n, const FT *__restrict__ a, const FT *__restrict__ p, const FT *__restrict__ q,
+__global__ __launch_bounds__(kP3BS) void gamma_inc_inv_kernel(const int64_t n, const FT *__restrict__ a, const FT *__restrict__ p, const FT *__restrict__ q,
                                                                FT *__restrict__ xout) {
     Math<FT>::prepare();
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kP3BS + threadIdx.x;
     if (i >= n) return;
     xout[i] = gamma_inc_inv_dev<FT>(a[i], p[i], q[i]);
 }
@@ -478,7 +483,7 @@ template <typename FT> static int32_t gamma_inc_entry(int64_t n, const FT *a, co
     if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;
     if (n == 0) return CMX_OK;
     if (!a || !x || (!P && !Q)) return CMX_ERR_BAD_ARG;
-    hipLaunchKernelGGL((gamma_inc_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), n, a, x, P, Q);
+    hipLaunchKernelGGL((gamma_inc_kernel<FT>), dim3((unsigned)((n + kP3BS - 1) / kP3BS)), dim3(kP3BS), 0, reinterpret_cast<hipStream_t>(stream), n, a, x, P, Q);
     CMX_HIP_TRY(hipGetLastError());
     return CMX_OK;
 }
@@ -487,7 +492,7 @@ template <typename FT> static int32_t gamma_inc_inv_entry(int64_t n, const FT *a
     if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;
     if (n == 0) return CMX_OK;
     if (!a || !p || !q || !x) return CMX_ERR_BAD_ARG;
-    hipLaunchKernelGGL((gamma_inc_inv_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), n, a, p, q,
+    hipLaunchKernelGGL((gamma_inc_inv_kernel<FT>), dim3((unsigned)((n + kP3BS - 1) / kP3BS)), dim3(kP3BS), 0, reinterpret_cast<hipStream_t>(stream), n, a, p, q,
                        x);
     CMX_HIP_TRY(hipGetLastError());
     return CMX_OK;
@@ -540,19 +545,19 @@ template <typename FT> __device__ __forceinline__ FT exp_quantile_dev(FT D_mean,
     return DM::exp(DM::log(D_mean) + DM::log(-DM::log1p(-Y)));                                              // LogExpFunctions.cloglog
 }
 template <typename FT>
-__global__ __launch_bounds__(kBlock) void generalized_gamma_kernel(const FT nu, const FT mu, const int64_t n, const FT *__restrict__ B,
+__global__ __launch_bounds__(kP3BS) void generalized_gamma_kernel(const FT nu, const FT mu, const int64_t n, const FT *__restrict__ B,
                                                                   const FT *__restrict__ Y, const FT *__restrict__ x, FT *__restrict__ quantile,
                                                                   FT *__restrict__ cdf) {
     Math<FT>::prepare();
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kP3BS + threadIdx.x;
     if (i >= n) return;
     if (quantile) quantile[i] = gg_quantile_dev<FT>(nu, mu, B[i], Y[i]);
     if (cdf) cdf[i] = gg_cdf_dev<FT>(nu, mu, B[i], x[i]);
 }
 template <typename FT>
-__global__ __launch_bounds__(kBlock) void exponential_distribution_kernel(const int64_t n, const FT *__restrict__ D_mean, const FT *__restrict__ Y,
+__global__ __launch_bounds__(kP3BS) void exponential_distribution_kernel(const int64_t n, const FT *__restrict__ D_mean, const FT *__restrict__ Y,
                                                                          const FT *__restrict__ D, FT *__restrict__ quantile, FT *__restrict__ cdf) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kP3BS + threadIdx.x;
     if (i >= n) return;
     if (quantile) quantile[i] = exp_quantile_dev<FT>(D_mean[i], Y[i]);
     if (cdf) cdf[i] = exp_cdf_dev<FT>(D_mean[i], D[i]);
@@ -565,13 +570,13 @@ template <typename FT> struct PsdPar {
     FT p;
 };
 template <typename FT, bool CLOUD, bool LIMITED>
-__global__ __launch_bounds__(kBlock) void sb2006_size_distribution_kernel(const PsdPar<FT> k, const int64_t n, const FT *__restrict__ q,
+__global__ __launch_bounds__(kP3BS) void sb2006_size_distribution_kernel(const PsdPar<FT> k, const int64_t n, const FT *__restrict__ q,
                                                                          const FT *__restrict__ rho, const FT *__restrict__ N, const FT *__restrict__ D,
                                                                          FT *__restrict__ n_D, FT *__restrict__ D_min, FT *__restrict__ D_max) {
     Math<FT>::prepare();
     using DM = DistMath<FT>;
     using M = Math<FT>;
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kP3BS + threadIdx.x;
     if (i >= n) return;
     const FT eps = M::eps(), pi = FT(3.14159265358979323846);
     const FT qi = q[i], ri = rho[i], Ni = N[i];
@@ -623,7 +628,7 @@ template <typename FT> static int32_t generalized_gamma_entry(FT nu, FT mu, int6
     if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;
     if (n == 0) return CMX_OK;
     if (!B || (!quantile && !cdf) || (quantile && !Y) || (cdf && !x)) return CMX_ERR_BAD_ARG;
-    hipLaunchKernelGGL((generalized_gamma_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), nu, mu, n,
+    hipLaunchKernelGGL((generalized_gamma_kernel<FT>), dim3((unsigned)((n + kP3BS - 1) / kP3BS)), dim3(kP3BS), 0, reinterpret_cast<hipStream_t>(stream), nu, mu, n,
                        B, Y, x, quantile, cdf);
     CMX_HIP_TRY(hipGetLastError());
     return CMX_OK;
@@ -633,7 +638,7 @@ template <typename FT> static int32_t exponential_distribution_entry(int64_t n, 
     if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;
     if (n == 0) return CMX_OK;
     if (!D_mean || (!quantile && !cdf) || (quantile && !Y) || (cdf && !D)) return CMX_ERR_BAD_ARG;
-    hipLaunchKernelGGL((exponential_distribution_kernel<FT>), dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(stream), n,
+    hipLaunchKernelGGL((exponential_distribution_kernel<FT>), dim3((unsigned)((n + kP3BS - 1) / kP3BS)), dim3(kP3BS), 0, reinterpret_cast<hipStream_t>(stream), n,
                        D_mean, Y, D, quantile, cdf);
     CMX_HIP_TRY(hipGetLastError());
     return CMX_OK;
@@ -653,7 +658,7 @@ static int32_t sb2006_size_distribution_entry(const PC *pdf_c, const PR *pdf_r, 
         k.lam_max = pdf_r->lambda_max; k.rho_w_r = pdf_r->rho_w;
     }
     k.p = p;
-    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+    const dim3 grid((unsigned)((n + kP3BS - 1) / kP3BS)), block(kP3BS);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (cloud) hipLaunchKernelGGL((sb2006_size_distribution_kernel<FT, true, false>), grid, block, 0, st, k, n, q, rho, N, D, n_D, D_min, D_max);
     else if (limited) hipLaunchKernelGGL((sb2006_size_distribution_kernel<FT, false, true>), grid, block, 0, st, k, n, q, rho, N, D, n_D, D_min, D_max);
