@@ -89,11 +89,11 @@ bench default_driver --steps 20 --warmup 5
 bench default
 for wl in sb2006 sb2006_column icenuc mp0m mp1m arg2000 arg2000_columns mp1m_lin mp1m_column sb2006_aos sb2006_fields; do
   for dt in f32 f64; do
-    bench ${wl}_${dt} --workload $wl --dtype $dt --steps 20 --warmup 3
+    bench ${wl}_${dt} --workload $wl --dtype $dt --steps 100 --warmup 20
   done
 done
-bench sb2006_chen_f32 --workload sb2006_chen --dtype f32 --steps 20 --warmup 3
-bench mp1m_column_lin_f32 --workload mp1m_column_lin --dtype f32 --steps 20 --warmup 3
+bench sb2006_chen_f32 --workload sb2006_chen --dtype f32 --steps 100 --warmup 20
+bench mp1m_column_lin_f32 --workload mp1m_column_lin --dtype f32 --steps 100 --warmup 20
 for dt in f32 f64; do
   bench p3_${dt} --workload p3 --dtype $dt --points 10000000 --steps 5 --warmup 1
   bench p3_split_${dt} --workload p3_split --dtype $dt --points 10000000 --steps 5 --warmup 1
