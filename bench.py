@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--settle", type=int, default=30,
                     help="untimed launches before the warm-up: after idle the first ≈15 launches run 5–20 %% slower while the clocks settle")
+    ap.add_argument("--settle-ms", type=float, default=250.0,
+                    help="… and keep launching (untimed) until this much time has passed since the first launch: the clock / power state settles on a "
+                         "time scale of ~0.1 s, not on a launch count (one box needed > 70 launches of the 0.85-ms sweep; profiles/r04_round.log)")
     ap.add_argument("--points", type=int, default=100_000_000, help="grid points per GPU (weak scaling) or in total (strong scaling)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --points per GPU; strong: --points in total, sharded over the ranks (cmx.sharding.shard_bounds)")
@@ -946,7 +949,18 @@ def main():
     cold_ms = sum(cold_first5) / len(cold_first5)
     # first visit of every other buffer set, clocks still ramping
     first_visit_ms = [timed_each(lambda i, k=k: steps[k], 1)[0] for k in range(1, rotate)]
-    for i in range(max(0, args.settle - 5) + args.warmup):
+    t_settle = time.perf_counter()
+    for i in range(max(0, args.settle - 5)):
+        steps[i % rotate]()
+    settle_extra = 0
+    if args.settle > 0:
+        torch.cuda.synchronize()
+        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms and settle_extra < 100000:      # time-based part of the settle phase
+            for _ in range(8):
+                steps[settle_extra % rotate]()
+                settle_extra += 1
+            torch.cuda.synchronize()
+    for i in range(args.warmup):                       # the W warm-up steps of the contract, immediately before the timed region
         steps[i % rotate]()
     fence()
     # region A: the same buffer set re-swept (rounds 1-3's figure)
@@ -1006,7 +1020,7 @@ def main():
             "metric": desc["metric"],
             "value": total_points * args.steps / elapsed,
             "unit": "grid-points/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": args.settle,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": args.settle + settle_extra,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",

@@ -401,6 +401,14 @@ template <typename FT> struct ColLds {
 // which lane 0 of each group then evaluates in the epilogue (mp2m_p3_point) so that the eight tendency columns are written once instead of
 // written by one kernel and read-modify-written by the next (47 → 20 column passes).  The kernel-argument segment is 4 KiB: the form is
 // taken when the quadrature rule fits QuadSmall (order ≤ 32); larger rules run the two launches.
+// XCD-aware tile order.  Workgroups are dispatched round-robin over the 8 XCDs (workgroup b runs on XCD b % 8) and every XCD has its own L2.  A tile
+// of this kernel is only 8–32 states, i.e. 32–256 B of each column: with tile = b, the four to one tiles that share a 128-byte line would be read
+// into four to one DIFFERENT L2s (the Float32 64-lane geometry measured 3.7 × the algorithmic HBM traffic that way).  Here XCD x gets the contiguous
+// range [x·per, (x+1)·per) of tiles, per = gridDim.x / 8 (the launch rounds the grid up to a multiple of 8; surplus workgroups exit at once).
+__device__ __forceinline__ int64_t xcd_tile(unsigned block, unsigned grid) {
+    const unsigned per = grid >> 3;
+    return (int64_t)(block & 7u) * per + (block >> 3);
+}
 struct NoExtra {};
 template <typename FT, bool LIMITED_, bool INTPOW_> struct PointwiseExtra {      // the warm-rain instantiation is part of the type: one variant per kernel
     static constexpr bool LIMITED = LIMITED_, INTPOW = INTPOW_;
@@ -413,6 +421,7 @@ template <typename FT, typename QUAD, bool ASPECT, bool FUSED, int GROUP, typena
 __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(const P3Consts<FT> c, const P3VelConsts<FT> v, const P3ColConsts<FT> k,
                                                              const QUAD quad, const P3ColIO<FT> io, const int64_t n, const EXTRA ex) {
     constexpr bool ONE_LAUNCH = !std::is_same_v<EXTRA, NoExtra>;
+    if (xcd_tile(blockIdx.x, gridDim.x) * (int64_t)(blockDim.x / GROUP) >= n) return;      // a surplus workgroup of the rounded-up grid (uniform: before any barrier)
     Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS (no-op for Float32)
     using P = PM<FT>;
     using M = Math<FT>;
@@ -442,7 +451,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
     // volatile pointer so that they do not occupy twenty-five register pairs across all the sweeps
     FT *E = G, *Fm = G + 48, *S = G + 72, *cN = G + 100, *rN = G + 100 + 3 * nq;
     const volatile FT *Sv = S;
-    const int64_t pt_raw = (int64_t)blockIdx.x * (blockDim.x / GROUP) + grp;
+    const int64_t pt_raw = xcd_tile(blockIdx.x, gridDim.x) * (blockDim.x / GROUP) + grp;
     const bool valid = pt_raw < n;
     const int64_t i = valid ? pt_raw : n - 1;
     __syncthreads();
@@ -843,7 +852,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
     // (or a scratch slot) held across the sweeps
     int lane = threadIdx.x;
     asm volatile("" : "+v"(lane));
-    const int64_t i_out = (int64_t)blockIdx.x * (blockDim.x / GROUP) + lane / GROUP;
+    const int64_t i_out = xcd_tile(blockIdx.x, gridDim.x) * (blockDim.x / GROUP) + lane / GROUP;
     if (g == 0 && i_out < n) {
         const int64_t i = i_out;
         const FT e_rho_q = Sv[10], e_rho_n = Sv[11], e_rho_rim = Sv[12], e_inv_rho = Sv[13], e_T = Sv[14];
@@ -885,7 +894,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
         // 2M + P3 step, same-box A/B); here 32 states share one pass of them.  Each tendency column is written once.
         __syncthreads();
         const int nst = blockDim.x / GROUP;
-        const int64_t i2 = (int64_t)blockIdx.x * nst + threadIdx.x;
+        const int64_t i2 = xcd_tile(blockIdx.x, gridDim.x) * nst + threadIdx.x;
         if ((int)threadIdx.x < nst && i2 < n) {
             const volatile FT *S2 = lds + 2 * nq + threadIdx.x * ColLds<FT>::per_group(nq) + 72;
             FT in[11], pw[8];
@@ -914,7 +923,8 @@ template <typename FT> static void collision_geometry(int group, int nq, int64_t
     auto bytes = [&](int t) { return sizeof(FT) * (size_t)(2 * nq + (t / group) * ColLds<FT>::per_group(nq)); };
     while (threads > 64 && bytes(threads) > 150 * 1024) threads /= 2;
     const int ppb = threads / group;
-    grid = dim3((unsigned)((n + ppb - 1) / ppb)); block = dim3(threads); lds = bytes(threads);
+    const int64_t tiles = (n + ppb - 1) / ppb;
+    grid = dim3((unsigned)((tiles + 7) / 8 * 8)); block = dim3(threads); lds = bytes(threads);      // a multiple of 8: xcd_tile
 }
 
 // one launch site for both entries: picks the group width from the quadrature order, sizes the workgroup so the LDS caches fit,

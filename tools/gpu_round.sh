@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: full parity suite FIRST (a failing suite aborts the session: no numbers are produced from a build whose
-# parity is red), then the rocprofv3 passes of every workload (kernel-trace over >= 200 launches, FETCH_SIZE, WRITE_SIZE, SQ counters — the
+# parity is red), then the rocprofv3 passes of every workload (kernel-trace over 1000 launches of the sweep kernels, FETCH_SIZE, WRITE_SIZE, SQ counters — the
 # bench lines of the compute-bound workloads read their instruction counts from THESE passes), then every workload's bench line
 # (f32 + f64), then the probes.  Each step's rc is checked; a failed bench or profile is reported and skipped, never summarised.
 #   usage: tools/gpu_round.sh <round-tag, e.g. r04> [notests]
@@ -42,7 +42,7 @@ bench() {  # bench <name> <bench.py args…>
 }
 
 prof() {  # prof <workload> <dtype> <points> [valu]
-  KT_STEPS=${KT_STEPS:-200} tools/profile.sh "$1" "$2" "$3" "$TAG" "${4:-}" > gpurun_out/prof_${1}_${2}.log 2>&1
+  KT_STEPS=${KT_STEPS:-1000} tools/profile.sh "$1" "$2" "$3" "$TAG" "${4:-}" > gpurun_out/prof_${1}_${2}.log 2>&1
   local rc=$?
   if [ $rc -ne 0 ]; then echo "profile $1 $2 FAILED rc=$rc"; FAILED=$((FAILED+1)); fi
 }
