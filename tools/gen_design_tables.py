@@ -110,7 +110,7 @@ def performance_block(rnd):
            "buffer set, and launches cycling through 4 disjoint buffer sets (`--rotate 4`; the working set of the sub-millisecond lines then "
            "exceeds the 256-MiB Infinity Cache several times over, and every launch sweeps pages another launch touched last) — `value` uses the "
            "rotating time when it is more than 5 % slower.  first = the very first timed launch after the inputs are generated.  rocprof = mean (min) "
-           "over the profiled launches of `rocprofv3 --kernel-trace --stats` in the same session (200 for the sweep kernels, 6–10 for the P3 lines).  HBM frac = algorithmic bytes ÷ time ÷ 8 TB/s "
+           "over the profiled launches of `rocprofv3 --kernel-trace --stats` in the same session (1000 timed launches of the sweep kernels plus bench.py's settle and warm-up launches, 6–10 for the P3 lines).  HBM frac = algorithmic bytes ÷ time ÷ 8 TB/s "
            "(bench: of the region `value` uses).  traffic = (2 × FETCH_SIZE + WRITE_SIZE) ÷ algorithmic bytes, per launch, kernels of the step only "
            "(calibration: `profiles/r04_traffic_calibration.txt`).  VALU frac = SQ_INSTS_VALU × 2.4 cycles ÷ (1024 SIMDs × rocprof mean × 2.4 GHz) — against "
            "the fastest measured issue rate of a wave64 VALU instruction (`profiles/r03_probe_valu.txt`), ≤ 1 by construction; 4-cycle slots = the same "
