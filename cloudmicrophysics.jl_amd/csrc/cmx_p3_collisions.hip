@@ -237,8 +237,8 @@ static PointwiseConsts<FT> make_pointwise_consts(const WR &wr, const IP &ip, con
 }
 // liquid_freezing_rate(::RainFreezing, ::CloudParticlePDF_SB2006, …) — IceNucleation.jl:355-389: Bigg kinetics over the generalized-gamma
 // cloud PSD, M_D^k = n λc^(−k/μ) Γ((ν+1+k)/μ)/Γ((ν+1)/μ) with the Γ ratios folded on the host
-template <typename FT>
-__device__ __forceinline__ void bigg_cloud(const PointwiseConsts<FT> &k, FT J_bigg, FT rho, FT q_lcl, FT n_lcl, FT N_lcl, FT T, FT &bn, FT &bq) {
+template <typename FT, typename KC = PointwiseConsts<FT>>
+__device__ __forceinline__ void bigg_cloud(const KC &k, FT J_bigg, FT rho, FT q_lcl, FT n_lcl, FT N_lcl, FT T, FT &bn, FT &bq) {
     using P = PM<FT>;
     const FT eps = P::eps();
     bn = FT(0); bq = FT(0);
@@ -249,8 +249,8 @@ __device__ __forceinline__ void bigg_cloud(const PointwiseConsts<FT> &k, FT J_bi
     }
 }
 // liquid_freezing_rate(::RainFreezing, pdf_r, …) — IceNucleation.jl:274-311: exponential rain PSD, M_D³ = 6 n D̄³, M_D⁶ = 720 n D̄⁶
-template <typename FT, bool LIMITED>
-__device__ __forceinline__ void bigg_rain(const PointwiseConsts<FT> &k, FT J_bigg, FT rho, FT q_rai, FT n_rai, FT N_rai, FT T, FT &rn, FT &rq) {
+template <typename FT, bool LIMITED, typename KC = PointwiseConsts<FT>>
+__device__ __forceinline__ void bigg_rain(const KC &k, FT J_bigg, FT rho, FT q_rai, FT n_rai, FT N_rai, FT T, FT &rn, FT &rq) {
     using P = PM<FT>;
     using M = Math<FT>;
     const FT eps = P::eps();
@@ -288,9 +288,9 @@ template <typename FT> struct FusedIO {
 // before the next section starts — left alone the scheduler hoists the table reads of all the later exponentials above the warm-rain part and
 // spills eight register pairs to scratch.
 template <typename FT> __device__ __forceinline__ void section_fence(FT &a, FT &b, FT &c, FT &d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory"); }
-template <typename FT, bool LIMITED, bool INTPOW, bool FENCED = false>      // INTPOW: the integer-exponent warm-rain point function (cmx_sb2006.hpp), as the 2M entry
-__device__ __forceinline__ void mp2m_p3_point(const SbConsts<FT> &sc, const P3Consts<FT> &c, const PointwiseConsts<FT> &k, const FT (&in)[11], FT shift,
-                                              FT (&d)[8]) {
+template <typename FT, bool LIMITED, bool INTPOW, bool FENCED = false, typename SC, typename KC>      // INTPOW: the integer-exponent warm-rain point function (cmx_sb2006.hpp), as the 2M entry
+__device__ __forceinline__ void mp2m_p3_point(const SC &sc, const P3Consts<FT> &c, const KC &k, const FT (&in)[11], FT shift,
+                                              FT (&d)[8]) {      // SC / KC: SbConsts<FT> / PointwiseConsts<FT>, by value or in the kernel-argument segment (KernArg)
     using P = PM<FT>;
     using M = Math<FT>;
     const FT eps = P::eps();
@@ -903,7 +903,16 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
 #pragma unroll
             for (int kk = 0; kk < 11; ++kk) in[kk] = p2.at_tab(col[kk], seg_tab, kk);
             const FT shift = ex.shift ? p2.at_tab(ex.shift, seg_tab, SEG_SHIFT) : FT(0);
-            mp2m_p3_point<FT, EXTRA::LIMITED, EXTRA::INTPOW, true>(ex.sc, c, ex.pk, in, shift, pw);
+            if constexpr (sizeof(FT) == 8 && CMX_PHASE_CONSTS) {
+                // Float64: the pointwise constants (≈ 150 doubles) are read THROUGH the kernel-argument segment and only now — taken from the by-value
+                // argument the compiler loads them in the entry block and parks them in VGPR lanes across all the sweeps (cmx_math.hpp consts_after)
+                struct KArgs { P3Consts<FT> c; P3VelConsts<FT> v; P3ColConsts<FT> k; QUAD quad; P3ColIO<FT> io; int64_t n; EXTRA ex; };
+                const auto *base = (const __attribute__((address_space(4))) unsigned char *)__builtin_amdgcn_kernarg_segment_ptr();
+                KernArg<EXTRA> &exk = *(KernArg<EXTRA> *)(base + offsetof(KArgs, ex));
+                const auto &exl = consts_after(exk, in[0]);
+                mp2m_p3_point<FT, EXTRA::LIMITED, EXTRA::INTPOW, true>(exl.sc, c, exl.pk, in, shift, pw);
+            } else
+                mp2m_p3_point<FT, EXTRA::LIMITED, EXTRA::INTPOW, true>(ex.sc, c, ex.pk, in, shift, pw);
 #pragma unroll
             for (int q = 0; q < 8; ++q) p2.at_tab(io.out[q], seg_tab, 13 + q) = pw[q] + S2[q];
         }

@@ -34,6 +34,18 @@ def test_collision_kernels_do_not_spill(kernels):
         assert k["private"] <= 32, k           # no spill area: only the 8–20-byte stack object the OCML calls of the set-up (lgamma) reserve
 
 
+def test_one_launch_form_adds_no_sgpr_spills(kernels):
+    """the one-launch 2M + P3 instantiations (PointwiseExtra) carried 95-125 spilled SGPRs, 20-30 more than the two-launch kernel —
+    the pointwise part's ≈ 150 constants, loaded in the entry block and parked in VGPR lanes across all the sweeps.  Round 4 reads them through the
+    kernel-argument segment at the point of use (Float64): what remains is the collision kernel's own constants, as in the two-launch form."""
+    named = [dict(k, name=n) for k, n in zip(kernels, _tool().demangle([k["name"] for k in kernels]))]
+    f64 = [k for k in named if "p3_collision_kernel<double" in k["name"] and ", true, 8," in k["name"].replace("true, true, 8", "X, true, 8").replace("false, true, 8", "X, true, 8")]
+    one = [k["sgpr_spill"] for k in f64 if "PointwiseExtra" in k["name"]]
+    two = [k["sgpr_spill"] for k in f64 if "NoExtra" in k["name"]]
+    assert len(one) == 8 and len(two) == 2, (len(one), len(two))
+    assert max(one) <= max(two) + 20, (one, two)
+
+
 def test_streaming_kernels_do_not_spill(kernels):
     """The pointwise kernels the bench lines run: no spilled vector registers in either float type."""
     for frag in ("sb2006_tendencies_kernel", "mp1m_tendencies_kernel", "mp1m_linearized_kernel", "mp1m_column_kernel", "mp0m_tendencies_kernel", "ice_nucleation_kernel",
