@@ -52,9 +52,14 @@ def exponential_distribution(D_mean: torch.Tensor, Y=None, D=None, *, stream=Non
     return out
 
 
-def size_distribution(pdf, q, rho, N, D=None, *, p=None, bounds=True, is_limited=True, stream=None) -> SizeDistribution:
+def size_distribution(pdf, q, rho, N, D=None, *, p=None, bounds=True, is_limited=None, stream=None) -> SizeDistribution:
     """`pdf` = a cmx_cloud_pdf_sb2006 (SB2006(FT).pdf_c) or cmx_rain_pdf_sb2006 (SB2006(FT, is_limited).pdf_r) struct.  n_D = the size
-    distribution at diameter D (if D is given), (D_min, D_max) = get_size_distribution_bounds at probability level p (default eps(FT))."""
+    distribution at diameter D (if D is given), (D_min, D_max) = get_size_distribution_bounds at probability level p (default eps(FT)).
+
+    The reference picks the rain PSD variant from the struct's TYPE (`RainParticlePDF_SB2006_limited` / `_notlimited`,
+    src/parameters/Microphysics2M.jl:314-375); the C layout is one struct for both, so here the variant is read from the struct's CONTENT:
+    the not-limited constructor leaves the N0 / λ limiters at zero.  `is_limited` may still be passed explicitly; asking for the limited
+    variant with a struct whose limiters are not positive and ordered is an error (the C entry returns CMX_ERR_BAD_ARG as well)."""
     cols = [c for c in (q, rho, N, D) if c is not None]
     ref = _check_cols(cols, ["q", "rho", "N", "D"][:len(cols)])
     fam = _fam_of(ref)
@@ -65,6 +70,13 @@ def size_distribution(pdf, q, rho, N, D=None, *, p=None, bounds=True, is_limited
         raise ValueError("nothing to compute: pass D and / or bounds=True")
     if p is None:
         p = float(torch.finfo(ref.dtype).eps)
+    if not cloud:
+        has_limiters = (0 < pdf.N0_min <= pdf.N0_max) and (0 < pdf.lambda_min <= pdf.lambda_max)
+        if is_limited is None:
+            is_limited = has_limiters
+        elif is_limited and not has_limiters:
+            raise ValueError("is_limited=True needs a rain PSD struct with positive, ordered N0 / lambda limiters "
+                             "(RainParticlePDF_SB2006(FT, is_limited=True)); this one is the not-limited variant")
     out = SizeDistribution(torch.empty_like(ref) if D is not None else None, torch.empty_like(ref) if bounds else None, torch.empty_like(ref) if bounds else None)
     flags = (_abi.CMX_PSD_CLOUD if cloud else 0) | (_abi.CMX_SB2006_LIMITED if (is_limited and not cloud) else 0)
     s = stream if stream is not None else torch.cuda.current_stream(ref.device)

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <tuple>
 #include <type_traits>
 
 #include <cstdint>
@@ -49,9 +50,10 @@ inline int64_t tile_grid(int64_t work_items, int64_t items_per_block) {
     return g > (int64_t)0x7fffffff ? -1 : (g < 1 ? 1 : g);
 }
 
-// Upper bound on the points / states of ONE call, checked by every entry point (CMX_ERR_UNSUPPORTED above it): the smallest
-// tile any kernel gives a workgroup is 16 states (p3_collision_kernel at 16 lanes per state), so n ≤ 16·(2^31 − 1) ≈ 3.4e10 keeps
-// every grid inside HIP's 2^31 − 1 workgroups; at ≥ 12 B per point that is beyond the 288 GB of HBM anyway.
+// Upper bound on the points / states of ONE call, checked by every entry point (CMX_ERR_UNSUPPORTED above it): the streaming kernels give a
+// workgroup at least 16 points, so n ≤ 16·(2^31 − 1) ≈ 3.4e10 keeps their grids inside HIP's 2^31 − 1 workgroups; at ≥ 12 B per point that is
+// beyond the 288 GB of HBM anyway.  The P3 collision kernels have SMALLER tiles (Float32: 64-lane workgroups = 8 states at 8 lanes per state, 4 at
+// 16) and check their own rounded-up tile count (collision_geometry, cmx_p3_collisions.hip): CMX_ERR_UNSUPPORTED above 8·(2^31 − 8) resp. 4·(…) states.
 constexpr int64_t kMaxPoints = 16ll * 0x7fffffffll;
 
 // The two heaviest Float64 kernels (SB2006, 1-moment) run one point per lane (8-byte loads) instead of two (16-byte): they are
@@ -134,5 +136,28 @@ template <typename A0, typename... A> struct first_kernel_param<void (*)(A0, A..
                       "front_consts() reads the constants struct as the FIRST kernel argument");                                                 \
         hipLaunchKernelGGL(K, grid, block, lds, stream, c, __VA_ARGS__);                                                                         \
     } while (0)
+
+// Byte offset of the LAST parameter of a kernel inside its kernel-argument segment, derived from the kernel's own signature (the
+// one-launch 2M + P3 kernel found its EXTRA argument with offsetof() on a hand-copied mirror struct that nothing tied to the parameter list).
+// The AMDGPU kernarg ABI lays explicit arguments out in declaration order, each at the next multiple of its ABI alignment — the same rule as a
+// C struct of those members — so the fold below follows a reordered, added or removed parameter by itself; `Last` must be the type the caller
+// expects there, or it does not compile.
+template <typename Last, typename F> struct kernarg_last;
+template <typename Last, typename... A> struct kernarg_last<Last, void (*)(A...)> {
+    static_assert(sizeof...(A) > 0, "a kernel without parameters has no last argument");
+    static_assert(std::is_same_v<std::remove_cv_t<std::tuple_element_t<sizeof...(A) - 1, std::tuple<A...>>>, std::remove_cv_t<Last>>,
+                  "the kernel's last parameter is not the type read through the kernel-argument segment");
+    static constexpr size_t offset() {
+        constexpr size_t sz[] = {sizeof(A)...}, al[] = {alignof(A)...};
+        size_t off = 0;
+        for (size_t i = 0; i < sizeof...(A); ++i) {
+            off = (off + al[i] - 1) / al[i] * al[i];
+            if (i + 1 < sizeof...(A)) off += sz[i];
+        }
+        return off;
+    }
+};
+// use: kernarg_offset_of_last<EXTRA, decltype(&kernel<...>)>() — the kernel is named in an unevaluated operand only
+template <typename Last, typename F> constexpr size_t kernarg_offset_of_last() { return kernarg_last<Last, F>::offset(); }
 
 }  // namespace cmx

@@ -134,13 +134,15 @@ struct LeanCoefs {
     double e2[4];                               // (2ʳ − 1)/r on |r| ≤ 1/256, degree 3, highest power first (round 4: Chebyshev fit, 1.5e-16 relative to 2ʳ)
     double ex_lo, ex_hi, k128_log2e, ln2_128_hi, ln2_128_lo;
     double ee[4];                               // (eʳ − 1)/r on |r| ≤ ln2/256, degree 3
-    double l2[6];                               // log2(1 + r)/r on |r| ≤ 2⁻⁸, degree 5 (1.6e-17 relative; the constant term is log2 e exactly)
+    double l2[6];                               // log2(1 + r)/r on |r| ≤ 2⁻⁸, degree 5 (4.6e-17 relative, ln: 3.2e-17; the constant term is log2 e exactly)
     double ln[6];                               // ln(1 + r)/r likewise (constant term 1, linear term −½ exactly)
     double minus_one, ln2, two64, sixty4;
 };
 // Round 4: the polynomials are one term shorter than the Taylor forms of round 2 (exp: degree 3 instead of 4 for (2ʳ − 1)/r, log: degree 5
-// instead of 6 for log2(1 + r)/r) at the same accuracy — Chebyshev interpolants on the reduced interval (mpmath, 200 bits; the Taylor
-// truncations were 5e-19 / 2e-18, far below one ulp: a term each was spent on nothing).  One Float64 FMA less per call: ≈ 22 of the 621
+// instead of 6 for log2(1 + r)/r) — Chebyshev interpolants on the reduced interval (mpmath, 200 bits).  What that costs in accuracy (ADVICE r04,
+// re-measured with mpmath): the degree-3 fits of (2ʳ − 1)/r and (eʳ − 1)/r carry 1.5e-16 relative to 2ʳ / eʳ where the Taylor truncation carried
+// 5e-19 — about 0.7 ulp more, exp2 / exp go from ≤ 1 to ≤ 2 ulp (tests/test_lean_math.py asserts 2); the degree-5 log fits carry 3.2e-17 (ln) and
+// 4.6e-17 (log2), still below one ulp, so log2 / log stay ≤ 4 ulp.  Five decimal orders below the Float64 parity bound of 1e-6 either way.  One Float64 FMA less per call: ≈ 22 of the 621
 // instructions of an SB2006 point.
 #define CMX_LEAN_COEFS                                                                                                          \
     {-1100.0, 1100.0, 128.0, -0.0078125,                                                                                       \

@@ -906,9 +906,10 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
             if constexpr (sizeof(FT) == 8 && CMX_PHASE_CONSTS) {
                 // Float64: the pointwise constants (≈ 150 doubles) are read THROUGH the kernel-argument segment and only now — taken from the by-value
                 // argument the compiler loads them in the entry block and parks them in VGPR lanes across all the sweeps (cmx_math.hpp consts_after)
-                struct KArgs { P3Consts<FT> c; P3VelConsts<FT> v; P3ColConsts<FT> k; QUAD quad; P3ColIO<FT> io; int64_t n; EXTRA ex; };
+                // (its offset comes from THIS kernel's parameter list — kernarg_offset_of_last, cmx_launch.hpp — not from a hand-kept mirror struct)
+                constexpr size_t ex_off = kernarg_offset_of_last<EXTRA, decltype(&p3_collision_kernel<FT, QUAD, ASPECT, FUSED, GROUP, EXTRA>)>();
                 const auto *base = (const __attribute__((address_space(4))) unsigned char *)__builtin_amdgcn_kernarg_segment_ptr();
-                KernArg<EXTRA> &exk = *(KernArg<EXTRA> *)(base + offsetof(KArgs, ex));
+                KernArg<EXTRA> &exk = *(KernArg<EXTRA> *)(base + ex_off);
                 const auto &exl = consts_after(exk, in[0]);
                 mp2m_p3_point<FT, EXTRA::LIMITED, EXTRA::INTPOW, true>(exl.sc, c, exl.pk, in, shift, pw);
             } else
@@ -920,7 +921,9 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
 }
 
 // launch geometry: 256 lanes (32 states) per workgroup unless the per-state LDS caches (6n + 100 values) would not fit — then 128
-template <typename FT> static void collision_geometry(int group, int nq, int64_t n, dim3 &grid, dim3 &block, size_t &lds) {
+// Returns false when the rounded-up tile count does not fit HIP's 2^31 − 1 workgroups: a Float32 tile is only 8 (group 8) or 4 (group 16) states,
+// so that can happen below kMaxPoints (the cast to unsigned truncated it silently); the callers return CMX_ERR_UNSUPPORTED.
+template <typename FT> static bool collision_geometry(int group, int nq, int64_t n, dim3 &grid, dim3 &block, size_t &lds) {
     // lanes per workgroup to start from (the kernel reads blockDim.x): Float64 256 — 128 or 64 lanes cost 15–17 % (21.4 → 24.6 / 25.0 ms per 1e6 states
     // of the 2M + P3 entry: the pointwise pass then runs with 16 or 8 of a wave's 64 lanes) — Float32 64: 7.14 → 6.86 ms (same-box A/B, round 4,
     // profiles/r04_ab_sessions.txt, session 19).  -DCMX_COL_THREADS=n forces one size for both.
@@ -932,8 +935,10 @@ template <typename FT> static void collision_geometry(int group, int nq, int64_t
     auto bytes = [&](int t) { return sizeof(FT) * (size_t)(2 * nq + (t / group) * ColLds<FT>::per_group(nq)); };
     while (threads > 64 && bytes(threads) > 150 * 1024) threads /= 2;
     const int ppb = threads / group;
-    const int64_t tiles = (n + ppb - 1) / ppb;
-    grid = dim3((unsigned)((tiles + 7) / 8 * 8)); block = dim3(threads); lds = bytes(threads);      // a multiple of 8: xcd_tile
+    const int64_t tiles = (n + ppb - 1) / ppb, rounded = (tiles + 7) / 8 * 8;                        // a multiple of 8: xcd_tile
+    if (rounded > (int64_t)0x7fffffff) return false;
+    grid = dim3((unsigned)rounded); block = dim3(threads); lds = bytes(threads);
+    return true;
 }
 
 // one launch site for both entries: picks the group width from the quadrature order, sizes the workgroup so the LDS caches fit,
@@ -944,7 +949,7 @@ static int32_t launch_collision_kernel(const P3Consts<FT> &c, const P3VelConsts<
     const int group = collision_group(quad.n);
     dim3 grid, block;
     size_t lds;
-    collision_geometry<FT>(group, quad.n, n, grid, block, lds);
+    if (!collision_geometry<FT>(group, quad.n, n, grid, block, lds)) return CMX_ERR_UNSUPPORTED;
     auto go = [&](auto kern) -> int32_t {
         if (lds > 48 * 1024) CMX_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, grid, block, lds, st, c, v, k, quad, io, n, ex);

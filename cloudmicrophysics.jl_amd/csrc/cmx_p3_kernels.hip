@@ -651,6 +651,12 @@ static int32_t sb2006_size_distribution_entry(const PC *pdf_c, const PR *pdf_r, 
     if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;
     if (n == 0) return CMX_OK;
     if (!q || !rho || !N || (!n_D && !D_min && !D_max) || (n_D && !D)) return CMX_ERR_BAD_ARG;
+    // the limited rain PSD clamps with its limiter pairs: a struct of the NOT-limited variant (limiters all zero, cmx.h) passed with the flag set
+    // would clamp N0 and λ to 0 and return Inf / NaN silently — the same rule as the rate and column entries (sb_limiters_ok)
+    if (!cloud && limited &&
+        !(pdf_r->xr_min > 0 && pdf_r->xr_min <= pdf_r->xr_max && pdf_r->N0_min > 0 && pdf_r->N0_min <= pdf_r->N0_max && pdf_r->lambda_min > 0 &&
+          pdf_r->lambda_min <= pdf_r->lambda_max))
+        return CMX_ERR_BAD_ARG;
     PsdPar<FT> k{};
     if (cloud) { k.nu_c = pdf_c->nu_c; k.mu_c = pdf_c->mu_c; k.rho_w_c = pdf_c->rho_w; k.lg_z1 = pdf_c->loggamma_z1; k.lg_z2 = pdf_c->loggamma_z2; }
     else {

@@ -1082,7 +1082,9 @@ int32_t cmx_exponential_distribution_f64(int64_t n, const double *D_mean, const 
 /*   CM2.size_distribution_value(pdf, q, ρₐ, N, D)            n(D) of the rain (N₀r e^(−D/D̄r)) or cloud (N₀c D^(3ν+2) e^(−λc D^(3μ))) PSD      src/Microphysics2M.jl:270-315
  *   CM2.get_size_distribution_bounds(pdf, q, ρₐ, N, p)        the p and 1 − p quantiles of that PSD (the reference's default p = eps(FT))     :336-354
  * flags: CMX_PSD_CLOUD selects pdf_c (CloudParticlePDF_SB2006; pdf_r may be NULL), otherwise pdf_r (CMX_SB2006_LIMITED: the limited rain PSD;
- * pdf_c may be NULL).  N per m³.  D is needed for n_D only; any output may be NULL (not all three). */
+ * pdf_c may be NULL).  N per m³.  D is needed for n_D only; any output may be NULL (not all three).  With CMX_SB2006_LIMITED the limiter
+ * pairs of pdf_r must be positive and ordered (xr_min ≤ xr_max, N0_min ≤ N0_max, lambda_min ≤ lambda_max) as for the rate entries: a struct of
+ * the not-limited variant (limiters zero) passed with the flag set returns CMX_ERR_BAD_ARG instead of clamping N₀ and λ to 0. */
 #define CMX_PSD_CLOUD (1u << 5)
 int32_t cmx_sb2006_size_distribution_f32(const cmx_cloud_pdf_sb2006_f32 *pdf_c, const cmx_rain_pdf_sb2006_f32 *pdf_r, uint32_t flags, float p, int64_t n,
                                          const float *q, const float *rho, const float *N, const float *D, float *n_D, float *D_min, float *D_max,

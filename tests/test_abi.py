@@ -117,6 +117,20 @@ def test_argument_validation_without_gpu():
     assert z(C.byref(p0), huge, None, None, None, None, None, None) == _abi.CMX_ERR_UNSUPPORTED
     assert f(C.byref(wr.c), C.byref(tps), None, 1, huge, *null, None) == _abi.CMX_ERR_UNSUPPORTED
     assert h(C.byref(wr.c), C.byref(tps), 1, 1 << 31, 1 << 31, ins, st7, outs, st4, None, None) == _abi.CMX_ERR_UNSUPPORTED
+    # SB2006 PSD accessors: the limited rain variant asked of a NOT-limited struct (its N0 / lambda limiters are zero) is refused
+    # before anything is launched; the same struct without the flag, and the limited struct with it, pass the parameter check (and then
+    # fail on the next one here: no output column)
+    sd = lib.cmx_sb2006_size_distribution_f32
+    fake = [C.c_void_p(4096)] * 3
+    pr_nl, pr_l = P.RainParticlePDF_SB2006("f32", is_limited=False), P.RainParticlePDF_SB2006("f32", is_limited=True)
+    out3 = [C.c_void_p(4096), None, None]
+    assert pr_nl.N0_max == 0 and pr_nl.lambda_max == 0
+    assert sd(None, C.byref(pr_nl), _abi.CMX_SB2006_LIMITED, 1e-6, 8, *fake, C.c_void_p(4096), *out3, None) == _abi.CMX_ERR_BAD_ARG
+    swapped = P.RainParticlePDF_SB2006("f32", is_limited=True)
+    swapped.N0_min, swapped.N0_max = swapped.N0_max, swapped.N0_min
+    assert sd(None, C.byref(swapped), _abi.CMX_SB2006_LIMITED, 1e-6, 8, *fake, C.c_void_p(4096), *out3, None) == _abi.CMX_ERR_BAD_ARG
+    assert sd(None, C.byref(pr_nl), _abi.CMX_SB2006_LIMITED, 1e-6, 0, *fake, None, None, None, None, None) == _abi.CMX_OK      # n = 0
+    assert sd(None, C.byref(pr_l), _abi.CMX_SB2006_LIMITED, 1e-6, 8, *fake, None, None, None, None, None) == _abi.CMX_ERR_BAD_ARG   # no output
     g = lib.cmx_column_sums_f64
     assert g(-1, None, 0, None, None, None) == _abi.CMX_ERR_BAD_ARG
     two = (C.c_void_p * 2)(4096, None)

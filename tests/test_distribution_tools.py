@@ -138,7 +138,14 @@ def test_device_sb2006_size_distribution(dev, oracle, ft, which):
     D = rd(10 ** (rng.uniform(-6, -4, n) if cloud else rng.uniform(-4.5, -2, n)))
     p = 1e-6
     pdf, pdf64 = (sb.pdf_c, sb64.pdf_c) if cloud else (sb.pdf_r, sb64.pdf_r)
-    got = cmx.size_distribution(pdf, to(q), to(rho), to(N), to(D), p=p, is_limited=limited)
+    # the rain PSD variant is read from the struct (the reference dispatches on its type): no is_limited argument
+    got = cmx.size_distribution(pdf, to(q), to(rho), to(N), to(D), p=p)
+    if not cloud:
+        again = cmx.size_distribution(pdf, to(q), to(rho), to(N), to(D), p=p, is_limited=limited)
+        assert all(torch.equal(a, b) for a, b in zip(got, again))
+        if not limited:
+            with pytest.raises(ValueError):
+                cmx.size_distribution(pdf, to(q), to(rho), to(N), to(D), p=p, is_limited=True)
     ref = oracle.sb2006_size_distribution(_abi.F64, pdf64 if cloud else None, None if cloud else pdf64, q, rho, N, D=D, cloud=cloud, limited=limited, p=p,
                                           float32_gates=(ft == "f32"))
     tol = parity.RTOL[ft]

@@ -6,7 +6,7 @@ for wd in $1; do
   IFS=: read wl dt pts <<< "$wd"
   pts=${pts:-100000000}
   steps=${STEPS:-4000}
-  python bench.py --workload $wl --dtype $dt --points $pts --steps $steps --warmup 5 --no-cpu-baseline --no-cold-probes --rotate 1 > /tmp/clock_probe_$wl_$dt.json 2>/dev/null &
+  python bench.py --workload $wl --dtype $dt --points $pts --steps $steps --warmup 5 --no-cpu-baseline --no-cold-probes --rotate 1 > /tmp/clock_probe_${wl}_${dt}.json 2>/dev/null &
   pid=$!
   sleep ${LEAD:-6}          # import torch, build inputs
   echo "== $wl $dt ($pts points)"
@@ -17,7 +17,7 @@ for wd in $1; do
     sleep 0.7
   done
   wait $pid
-  python - /tmp/clock_probe_$wl_$dt.json <<'PY'
+  python - /tmp/clock_probe_${wl}_${dt}.json <<'PY'
 import json, sys
 try:
     d = json.loads([l for l in open(sys.argv[1]) if l.startswith('{')][-1])

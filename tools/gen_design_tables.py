@@ -49,7 +49,7 @@ def kernel_stats(rnd, wl, dt):
     p = PROF / f"{rnd}_kernel_stats_{wl}_{dt}.csv"
     if not p.exists():
         return None
-    rows = [r for r in list(csv.reader(open(p)))[1:] if r and "cmx::" in r[0] and "column_sums" not in r[0]]
+    rows = [r for r in list(csv.reader(open(p)))[1:] if r and "cmx::" in r[0] and not any(k in r[0] for k in ("column_sums", "column_partials", "column_finish"))]
     if not rows:
         return None
     main = max(rows, key=lambda r: float(r[2]))

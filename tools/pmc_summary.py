@@ -101,7 +101,7 @@ def main():
             continue
         per_kernel = {}
         for r in csv.DictReader(open(path)):
-            if r["Counter_Name"] == key and "cmx::" in r["Kernel_Name"] and "column_sums" not in r["Kernel_Name"]:
+            if r["Counter_Name"] == key and "cmx::" in r["Kernel_Name"] and not any(k in r["Kernel_Name"] for k in ("column_sums", "column_partials", "column_finish")):
                 per_kernel.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
                 summary.setdefault("vgpr", r["VGPR_Count"]); summary.setdefault("sgpr", r["SGPR_Count"])
                 summary.setdefault("scratch", r["Scratch_Size"])
