@@ -34,6 +34,15 @@ template <typename FT, int NIN, int NOUT> struct LayoutIO {
     bool idx32;               // every element index and every (run · stride + offset) product of this call fits the 32-bit forms
 };
 
+// does POLICY::point accept the packed pair type?  (policies declare `static constexpr bool PACKABLE = true`)
+template <typename P, typename = void> struct layout_packable : std::false_type {};
+template <typename P> struct layout_packable<P, std::enable_if_t<P::PACKABLE>> : std::true_type {};
+#ifndef CMX_F32_PACKED_LAYOUT
+#define CMX_F32_PACKED_LAYOUT 1          // A/B switch: 0 = one point at a time
+#endif
+#ifndef CMX_F32_PACKED_LAYOUT_PHASE
+#define CMX_F32_PACKED_LAYOUT_PHASE 1    // the packed instantiations read their constants phase by phase (cmx_sb2006_kernels.hpp CMX_F32_PACKED_PHASE_CONSTS)
+#endif
 #ifndef CMX_LAYOUT_F64_VEC
 #define CMX_LAYOUT_F64_VEC 1     // A/B switch (2: 16-byte accesses for Float64 as well)
 #endif
@@ -80,12 +89,25 @@ __global__ __launch_bounds__(BS) void tendencies_layout_kernel(const typename PO
     }
     Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS while the loads fly (every lane of the workgroup reaches the barrier inside); no-op for Float32
     if (active) {
+        // Float32 with four points per lane and a policy whose point function takes the packed pair type: two PAIRS of points (cmx_math.hpp f32x2)
+        if constexpr (layout_packable<POLICY>::value && sizeof(FT) == 4 && VEC % 2 == 0 && CMX_F32_PACKED_LAYOUT) {
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            FT xi[NIN];
+            for (int k = 0; k < VEC; k += 2) {
+                f32x2 xi[NIN], yi[NOUT];
 #pragma unroll
-            for (int q = 0; q < NIN; ++q) xi[q] = x[q][k];
-            POLICY::point(front_consts<FT>(c), xi, y[k]);   // Float64: phase-local constants (cmx_math.hpp); c is the first argument
+                for (int q = 0; q < NIN; ++q) xi[q] = f32x2{x[q][k], x[q][k + 1]};
+                POLICY::point(front_consts<FT, (bool)CMX_F32_PACKED_LAYOUT_PHASE>(c), xi, yi);
+#pragma unroll
+                for (int q = 0; q < NOUT; ++q) { y[k][q] = yi[q].x; y[k + 1][q] = yi[q].y; }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                FT xi[NIN];
+#pragma unroll
+                for (int q = 0; q < NIN; ++q) xi[q] = x[q][k];
+                POLICY::point(front_consts<FT>(c), xi, y[k]);   // Float64: phase-local constants (cmx_math.hpp); c is the first argument
+            }
         }
     }
     if constexpr (!AOS) {

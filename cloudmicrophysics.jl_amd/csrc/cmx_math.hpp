@@ -48,6 +48,9 @@ __device__ __forceinline__ float med3(float a, float b, float c) { return __buil
 }  // namespace hw
 
 template <> struct Math<float> {
+    using Scalar = float;
+    using Mask = bool;                     // the type of a comparison of two values (a lane mask pair for the packed type below)
+    static constexpr bool IS_F64 = false;
     static constexpr int VEC = 4;
     static constexpr float eps() { return 1.1920928955078125e-07f; }          // eps(Float32)
     static constexpr float eps_1m() { return 2.2737367544323206e-13f; }       // cbrt(floatmin(Float32))
@@ -83,6 +86,9 @@ template <> struct Math<float> {
 };
 
 template <> struct Math<double> {
+    using Scalar = double;
+    using Mask = bool;
+    static constexpr bool IS_F64 = true;
     static constexpr int VEC = 2;
     static constexpr double eps() { return 2.220446049250313e-16; }            // eps(Float64)
     static constexpr double eps_1m() { return 2.8126442852362996e-103; }      // cbrt(floatmin(Float64))
@@ -115,6 +121,92 @@ template <> struct Math<double> {
     static __device__ __forceinline__ double log1p(double x) { return lean::log1p(x); }
     static __device__ __forceinline__ double expm1(double x) { return lean::expm1(x); }
 };
+
+// ---- two Float32 points per value: the PACKED value type (round 5) ------------------------------------------------------------------------
+// gfx950 issues v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 — two results — in 4.2–4.8 cycles whatever their operands are, where the one-result forms cost
+// 2.4–2.9 cycles only in their cheapest shape and 4.2–4.4 with a scalar (SGPR) operand or three distinct registers (tools/valu_probe, profiles/r05_probe_valu.txt:
+// v_pk_mul v,s 4.80 against v_mul s,v 4.41; v_pk_fma v,s,v 4.66 against v_fma s,v,v 4.41; v_pk_fma of three registers 5.48 against 4.17; v_pk_add 4.39 against
+// 2.58).  A third of the arithmetic of the Float32 rate kernels multiplies by a kernel constant, i.e. reads an SGPR.  Round 2 tried the compiler's SLP vectorizer
+// and lost (it has to MOVE values into adjacent registers first); here the pairing is in the data flow from the start: a lane's 16-byte column vector arrives as
+// two register pairs, the point functions are instantiated on the pair type, every multiply / add / fma of the source becomes one packed instruction (a scalar
+// constant is broadcast by op_sel, no move), and the transcendentals, compares, selects and min / max — which have no packed Float32 form — run per half in
+// place.  Same IEEE operations in the same order: results are bit-identical to the one-point instantiation (tests/test_sb2006_gpu.py, unaligned columns).
+#if defined(__clang__)        // ext_vector_type: hipcc and clang++ (the host test build prefers clang++; under g++ the packed type does not exist)
+#define CMX_HAVE_PACKED 1
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+#define CMX_LANEWISE1(fn) f32x2{fn(x.x), fn(x.y)}
+template <> struct Math<f32x2> {
+    using Scalar = float;
+    using Mask = i32x2;                    // lane-wise comparison results (−1 / 0); combine with | and &, select with ?:
+    static constexpr bool IS_F64 = false;
+    static constexpr float eps() { return Math<float>::eps(); }
+    static constexpr float eps_1m() { return Math<float>::eps_1m(); }
+    static __device__ __forceinline__ void prepare() {}
+    static __device__ __forceinline__ f32x2 exp2(f32x2 x) { return CMX_LANEWISE1(hw::exp2); }
+    static __device__ __forceinline__ f32x2 log2(f32x2 x) { return CMX_LANEWISE1(hw::log2); }
+    static __device__ __forceinline__ f32x2 rcp(f32x2 x) { return CMX_LANEWISE1(hw::rcp); }
+    static __device__ __forceinline__ f32x2 exp2_fin(f32x2 x) { return CMX_LANEWISE1(hw::exp2); }
+    static __device__ __forceinline__ f32x2 rcp_nz(f32x2 x) { return CMX_LANEWISE1(hw::rcp); }
+    static __device__ __forceinline__ f32x2 rcp_nz1(f32x2 x) { return CMX_LANEWISE1(hw::rcp); }
+    static __device__ __forceinline__ f32x2 sqrt(f32x2 x) { return CMX_LANEWISE1(hw::sqrt); }
+    static __device__ __forceinline__ f32x2 rsqrt(f32x2 x) { return CMX_LANEWISE1(hw::rsq); }
+    static __device__ __forceinline__ f32x2 sqrt_pos(f32x2 x) { return CMX_LANEWISE1(hw::sqrt); }
+    static __device__ __forceinline__ f32x2 rsqrt_pos(f32x2 x) { return CMX_LANEWISE1(hw::rsq); }
+    static __device__ __forceinline__ f32x2 log1p(f32x2 x) { return CMX_LANEWISE1(Math<float>::log1p); }
+    static __device__ __forceinline__ f32x2 expm1(f32x2 x) { return CMX_LANEWISE1(Math<float>::expm1); }
+    // any mix of pair and scalar arguments (a scalar is broadcast: (f32x2)s)
+    template <typename A, typename B> static __device__ __forceinline__ f32x2 div(A a, B b) { return (f32x2)a * rcp((f32x2)b); }
+    template <typename A, typename B, typename C> static __device__ __forceinline__ f32x2 fma(A a, B b, C c) {
+#if defined(CMX_HOST_BUILD)
+        const f32x2 u = (f32x2)a, v = (f32x2)b, w = (f32x2)c;
+        return f32x2{__builtin_fmaf(u.x, v.x, w.x), __builtin_fmaf(u.y, v.y, w.y)};
+#else
+        return __builtin_elementwise_fma((f32x2)a, (f32x2)b, (f32x2)c);
+#endif
+    }
+    template <typename A, typename B> static __device__ __forceinline__ f32x2 max(A a, B b) {
+        const f32x2 u = (f32x2)a, v = (f32x2)b;
+        return f32x2{__builtin_fmaxf(u.x, v.x), __builtin_fmaxf(u.y, v.y)};
+    }
+    template <typename A, typename B> static __device__ __forceinline__ f32x2 min(A a, B b) {
+        const f32x2 u = (f32x2)a, v = (f32x2)b;
+        return f32x2{__builtin_fminf(u.x, v.x), __builtin_fminf(u.y, v.y)};
+    }
+    static __device__ __forceinline__ f32x2 nan() { return (f32x2)__builtin_nanf(""); }
+};
+#undef CMX_LANEWISE1
+#else
+#define CMX_HAVE_PACKED 0
+#endif
+// m_or(a, b, …): "or" of comparison results of any value type — lane masks for the pair type; for bool the non-short-circuit form (both sides are plain
+// compares: no branch wanted)
+__device__ __forceinline__ bool m_or(bool a, bool b) { return (bool)((int)a | (int)b); }
+#if CMX_HAVE_PACKED
+__device__ __forceinline__ i32x2 m_or(i32x2 a, i32x2 b) { return a | b; }
+#endif
+template <typename B, typename... R> __device__ __forceinline__ B m_or(B a, B b, R... r) { return m_or(m_or(a, b), r...); }
+__device__ __forceinline__ bool m_and(bool a, bool b) { return a && b; }
+#if CMX_HAVE_PACKED
+__device__ __forceinline__ i32x2 m_and(i32x2 a, i32x2 b) { return a & b; }
+#endif
+template <typename B, typename... R> __device__ __forceinline__ B m_and(B a, B b, R... r) { return m_and(m_and(a, b), r...); }
+// CMX_F32_PACKED: the Float32 instantiations with four points per lane evaluate two PAIRS of points in packed arithmetic (cmx_math.hpp f32x2); 0 = one
+// point at a time as in rounds 1–4 (A/B switch)
+#ifndef CMX_F32_PACKED
+#define CMX_F32_PACKED 1
+#endif
+// CMX_F32_PACKED_PHASE_CONSTS: a packed instruction takes no literal, so the ≈ 30 literal constants of the point function occupy SGPRs next to the 95 kernel
+// constants — more than the file holds (84 v_writelane + 84 v_readlane per 4 points appeared).  The packed instantiations therefore read the constants
+// through the kernel-argument pointer, phase by phase, like the Float64 kernels do (cmx_math.hpp consts_after).
+#ifndef CMX_F32_PACKED_PHASE_CONSTS
+#define CMX_F32_PACKED_PHASE_CONSTS 1
+#endif
+// the scalar type and the points per value of a value type
+template <typename VT> struct lanes_of { static constexpr int value = 1; };
+#if CMX_HAVE_PACKED
+template <> struct lanes_of<f32x2> { static constexpr int value = 2; };
+#endif
 
 // Where the Float64 kernels' constants live (measured, round 2, one box, tools/ab_bench.sh): a Float64 kernel's 60–100 host-folded
 // parameters overflow the 102-SGPR file and the overflow is parked in VGPR lanes (v_writelane / v_readlane).  Staging the parameter
@@ -253,19 +345,21 @@ template <typename FT, typename CH> inline bool make_chen_log(const CH &ch, Chen
     }
     return ok;
 }
-template <typename FT, typename G> __device__ __forceinline__ FT chen_log_eval(const G &g, int kk, int i, FT t) {
-    FT p = g.c[kk][i][ChenLog<FT>::D];
+// (FT: the SCALAR type of the table; the argument may be the packed pair type)
+template <typename FT, typename G, typename VT> __device__ __forceinline__ VT chen_log_eval(const G &g, int kk, int i, VT t) {
+    VT p = VT(g.c[kk][i][ChenLog<FT>::D]);
 #pragma unroll
-    for (int m = ChenLog<FT>::D - 1; m >= 0; --m) p = Math<FT>::fma(p, t, g.c[kk][i][m]);
+    for (int m = ChenLog<FT>::D - 1; m >= 0; --m) p = Math<VT>::fma(p, t, g.c[kk][i][m]);
     return p;
 }
 
 // (G: ChenGamma<FT>, possibly in the constant address space — the Float64 kernels read their constants through the kernel-argument pointer)
-template <typename FT, typename G> __device__ __forceinline__ FT chen_gamma_eval(const G &g, int i, FT rho_c) {
-    const FT t = rho_c - FT(0.5 * kChenGammaRhoMax);
-    FT p = g.c[i][ChenGamma<FT>::D];
+// (FT: the SCALAR type of the table; the argument may be the packed pair type)
+template <typename FT, typename G, typename VT> __device__ __forceinline__ VT chen_gamma_eval(const G &g, int i, VT rho_c) {
+    const VT t = rho_c - VT(0.5 * kChenGammaRhoMax);
+    VT p = VT(g.c[i][ChenGamma<FT>::D]);
 #pragma unroll
-    for (int m = ChenGamma<FT>::D - 1; m >= 0; --m) p = Math<FT>::fma(p, t, g.c[i][m]);
+    for (int m = ChenGamma<FT>::D - 1; m >= 0; --m) p = Math<VT>::fma(p, t, g.c[i][m]);
     return p;
 }
 
@@ -279,6 +373,9 @@ template <typename FT> __device__ __forceinline__ FT tgamma_general(FT z) {
     else return ::tgammaf(z);
 #endif
 }
+#if CMX_HAVE_PACKED
+template <> __device__ __forceinline__ f32x2 tgamma_general<f32x2>(f32x2 z) { return f32x2{tgamma_general<float>(z.x), tgamma_general<float>(z.y)}; }
+#endif
 template <typename FT> __device__ __forceinline__ FT clampv(FT x, FT lo, FT hi) {
     // Base.clamp: x < lo ? lo : (x > hi ? hi : x)
     return Math<FT>::min(Math<FT>::max(x, lo), hi);
@@ -304,9 +401,16 @@ __device__ __forceinline__ float max0(float x) {
 #endif
 }
 __device__ __forceinline__ double max0(double x) { return Math<double>::max(0.0, x); }
+#if CMX_HAVE_PACKED
+__device__ __forceinline__ f32x2 max0(f32x2 x) { return f32x2{max0(x.x), max0(x.y)}; }
+#endif
 // the same for lo ≤ hi as ONE instruction (v_med3_f32: the median of three is the clamp); Float64 has no med3
 __device__ __forceinline__ float clamp_ordered(float x, float lo, float hi) { return hw::med3(x, lo, hi); }
 __device__ __forceinline__ double clamp_ordered(double x, double lo, double hi) { return clampv(x, lo, hi); }
+#if CMX_HAVE_PACKED
+__device__ __forceinline__ f32x2 clamp_ordered(f32x2 x, float lo, float hi) { return f32x2{hw::med3(x.x, lo, hi), hw::med3(x.y, lo, hi)}; }
+__device__ __forceinline__ f32x2 clamp_ordered(f32x2 x, f32x2 lo, f32x2 hi) { return f32x2{hw::med3(x.x, lo.x, hi.x), hw::med3(x.y, lo.y, hi.y)}; }
+#endif
 
 // ---- phase-local constants (Float64) --------------------------------------------------------------------------------------------
 // The constants struct of a Float64 kernel is large: SbConsts<double> is ≈ 95 doubles = 190 SGPRs; the register file has 102.
@@ -371,6 +475,20 @@ template <typename FT> __device__ __forceinline__ bool any_nan(FT a) { return CM
 template <typename FT> __device__ __forceinline__ bool any_nan(FT a, FT b) { return CMX_NAN_POISON && __builtin_isunordered(a, b); }
 template <typename FT, typename... R> __device__ __forceinline__ bool any_nan(FT a, FT b, R... r) {
     return (bool)((int)any_nan(a, b) | (int)any_nan(r...));   // bitwise on purpose: no branch
+}
+// pairs: a lane mask, formed per half with the same unordered compares
+#if CMX_HAVE_PACKED
+template <typename... R> __device__ __forceinline__ i32x2 any_nan_pair(f32x2 a, R... r) {
+    return i32x2{any_nan(a.x, r.x...) ? -1 : 0, any_nan(a.y, r.y...) ? -1 : 0};
+}
+#endif
+// nan_mask(inputs…): Math<VT>::Mask of "one of this point's inputs is a NaN" for any value type
+template <typename VT, typename... R> __device__ __forceinline__ typename Math<VT>::Mask nan_mask(VT a, R... r) {
+#if CMX_HAVE_PACKED
+    if constexpr (lanes_of<VT>::value == 2) return any_nan_pair(a, r...);
+    else
+#endif
+        return any_nan(a, r...);
 }
 
 }  // namespace cmx

@@ -195,7 +195,7 @@ template <typename FT> struct Mp1mSrc {
     FT vap_lcl, vap_icl, acnv_lcl_rai, acnv_icl_sno, accr_lcl_rai, accr_icl_rai, freeze_icl_rai, accr_icl_sno, vap_rai, vap_sno, melt_icl,
         melt_sno;
     FT S_lcl_sno, S_rai_sno, S_sno_rai, alpha;   // α = warm_accretion_melt_factor (0 at and below T_freeze)
-    bool is_warm;                                // T ≥ T_freeze
+    typename Math<FT>::Mask is_warm;             // T ≥ T_freeze (FT: the VALUE type — a point, or the packed pair f32x2 with a lane mask here; cmx_math.hpp)
     FT qsat_l, qsat_i;                           // q_sat over liquid / ice (LinearizedAverage)
 };
 
@@ -208,17 +208,17 @@ template <typename FT> struct Mp1mSrc {
 // eps(FT)·t·x0 (the oracle reports 2 t x0 as the operand scale of this term); the right side has absolute error eps(FT)·x0/k from the
 // rounding of its argument near 1, the same class.  x arrives clamped to ≥ 0; x0 < ϵ (a parameter-only case: the reference returns x)
 // takes a wave-uniform branch of the run-time-flags instantiations.
-template <typename FT, bool REGULAR> __device__ __forceinline__ FT logistic_rate(FT x, FT qthr, FT y2c, FT emk, FT omemk, FT kl2e, FT out, FT inv_tau, FT eps) {
-    using M = Math<FT>;
+template <typename FT, bool REGULAR, typename S> __device__ __forceinline__ FT logistic_rate(FT x, S qthr, S y2c, S emk, S omemk, S kl2e, S out, S inv_tau, S eps) {
+    using M = Math<FT>;      // FT: the value type, S: its scalar type (the constants)
     // REGULAR: the host has checked x0 ≥ ϵ (mp1m_default_exponents) — no branch in the default Float32 instantiation, whose four points
     // per lane then stay one basic block.  (The Float64 default instantiation keeps the never-taken scalar branch: without it the
     // scheduler hoists the autoconversion constants across the phase boundary and spills 38 SGPR pairs to VGPR lanes, 933 → 1000
     // instructions per point.)
     if constexpr (!REGULAR)
-        if (qthr < eps) return x < eps ? FT(0) : x * inv_tau;
+        if (qthr < eps) return x < eps ? FT(0) : FT(x * inv_tau);
     const FT y2 = x * y2c;
     const FT lg2 = M::log2(M::fma(emk, M::exp2_fin(M::min(y2, FT(60.0 * 1.4426950408889634))), omemk));   // y2 = x·y2c, x ≥ 0 finite
-    return x < eps ? FT(0) : M::max(lg2, y2 - kl2e) * out;
+    return x < eps ? FT(0) : FT(M::max(lg2, y2 - kl2e) * out);
 }
 
 template <typename FT, uint32_t FLAGS = kRuntimeFlags, typename C>
@@ -228,12 +228,13 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     Mp1mSrc<FT> o{};
     const uint32_t fl = FLAGS == kRuntimeFlags ? c->flags : FLAGS;
     constexpr bool DEFEXP = FLAGS != kRuntimeFlags && (FLAGS & kDefExpBit) != 0;
-    const FT eps = c->eps_1m;   // ϵ_numerics(FT) = cbrt(floatmin(FT))  Utilities.jl:318
+    using B = typename M::Mask;
+    const typename M::Scalar eps = c->eps_1m;   // ϵ_numerics(FT) = cbrt(floatmin(FT))  Utilities.jl:318
     // clamp_to_nonneg — BMT:147-152 (T is not clamped)
     rho = max0(rho); q_tot = max0(q_tot); q_lcl = max0(q_lcl);
     q_icl = max0(q_icl); q_rai = max0(q_rai); q_sno = max0(q_sno);
     const FT inv_rho = M::rcp(rho), inv_T = M::rcp_nz(T);      // T: a temperature (positive, finite); ρ may arrive clamped to 0
-    const bool has_lcl = q_lcl > eps, has_icl = q_icl > eps, has_rai = q_rai > eps, has_sno = q_sno > eps;
+    const B has_lcl = q_lcl > eps, has_icl = q_icl > eps, has_rai = q_rai > eps, has_sno = q_sno > eps;
 
     // ---- thermodynamics, once -------------------------------------------------------------------------------
     const FT l2_TT = M::log2(T * c->inv_T_tr), dinvT = c->inv_T_tr - inv_T;
@@ -249,7 +250,7 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     const FT cp_air = M::fma(c->cpm_qi, q_ice, M::fma(c->cpm_ql, q_liq, M::fma(c->cpm_qt, q_tot, c->cp_d)));
     const FT inv_cp = M::rcp_nz(cp_air);
     const FT dTf = T - c->T_freeze;
-    const bool above_freezing = T > c->T_freeze;
+    const B above_freezing = T > c->T_freeze;
     o.qsat_l = psat_l * inv_rho_RvT; o.qsat_i = psat_i * inv_rho_RvT;
     // (L/(R_v T) − 1)/T: the factor of dq_sat/dT (NonEq dqcld_dT) and of the conduction term of the G functions (Common.jl:47-102)
     const FT u_v = M::fma(L_v, inv_RT, FT(-1)) * inv_T, u_s = M::fma(L_s, inv_RT, FT(-1)) * inv_T;
@@ -269,9 +270,9 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
             const FT Tc = M::min(dTf, FT(0));
             const FT l2_N = M::fma(FT(9), M::log2(-(c->td_b10 * Tc)), -c->td_l2a);   // log2 of exp(INP_concentration_mean)
             const FT N = M::exp2(l2_N);
-            const FT r = N > eps ? M::exp2((M::log2(c->td_c3 * q_icl) - M::max(l2_N, c->l2_eps)) * FT(1.0 / 3.0)) : FT(0);
+            const FT r = N > eps ? FT(M::exp2((M::log2(c->td_c3 * q_icl) - M::max(l2_N, c->l2_eps)) * FT(1.0 / 3.0))) : FT(0);
             const FT inv_tau_dep = c->td_fourpiD * N * M::max(r, FT(1e-6));
-            o.vap_icl = lim * ((ex < FT(0) ? c->inv_tau_i : inv_tau_dep) * inv_G);
+            o.vap_icl = lim * ((ex < FT(0) ? FT(c->inv_tau_i) : inv_tau_dep) * inv_G);
         }
     }
     c = &consts_after(*c, o.vap_icl);
@@ -292,7 +293,7 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     // snow: n0 = μ (ρ max(q, ϵ))^ν if q > ϵ else 0 (get_n0 :83-86); λ⁻¹ uses max(n0, ϵ).  For q ≤ ϵ every snow term is gated to 0 below
     // (through n0 = 0 or has_sno), so the slope parameter only has to stay finite there: no select on log2 n0
     const FT l2_n0_sno = M::fma(c->sno_nu, l2_rq_sno, c->sno_l2_mu);
-    const FT n0_sno = has_sno ? M::exp2_fin(l2_n0_sno) : FT(0);      // finite where q_sno > ϵ; the other side of the select is discarded
+    const FT n0_sno = has_sno ? FT(M::exp2_fin(l2_n0_sno)) : FT(0);      // finite where q_sno > ϵ; the other side of the select is discarded
     const FT l2_rqn_sno = l2_rq_sno - M::max(l2_n0_sno, c->l2_eps);
     const FT li_icl = M::exp2_fin(M::max(c->lam_floor_icl, M::fma(l2_rq_icl, c->lam_a_icl, c->lam_b_icl)));
     // powers of the two slope parameters (see kDefExpBit): rain r = λ⁻¹^¼, snow s = λ⁻¹^⅛
@@ -318,16 +319,16 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     c = &consts_after(*c, sq);
     // ---- autoconversion — CM1:354-364, 414-446 ------------------------------------------------------------------
     if (fl & CMX_1M_RAIN_ACNV_KESSLER)
-        o.acnv_lcl_rai = logistic_rate<FT, DEFEXP && sizeof(FT) == 4>(q_lcl, c->ka_qthr, c->ka_y2, c->ka_emk, c->ka_omemk, c->ka_kl2e, c->ka_out, c->ka_inv_tau, eps);
+        o.acnv_lcl_rai = logistic_rate<FT, DEFEXP && !M::IS_F64>(q_lcl, c->ka_qthr, c->ka_y2, c->ka_emk, c->ka_omemk, c->ka_kl2e, c->ka_out, c->ka_inv_tau, eps);
     else if (fl & CMX_1M_RAIN_ACNV_PRESCRIBED_ND)
         o.acnv_lcl_rai = q_lcl * c->nd_coeff;
     if (fl & CMX_1M_SNOW_ACNV_NO_SUPERSAT) {
-        o.acnv_icl_sno = logistic_rate<FT, DEFEXP && sizeof(FT) == 4>(q_icl, c->ks_qthr, c->ks_y2, c->ks_emk, c->ks_omemk, c->ks_kl2e, c->ks_out, c->ks_inv_tau, eps);
+        o.acnv_icl_sno = logistic_rate<FT, DEFEXP && !M::IS_F64>(q_icl, c->ks_qthr, c->ks_y2, c->ks_emk, c->ks_omemk, c->ks_kl2e, c->ks_out, c->ks_inv_tau, eps);
     } else if (fl & CMX_1M_SNOW_ACNV_WITH_SUPERSAT) {
         const FT x = c->r_is * M::rcp_nz(li_icl);                 // ≥ 2^floor > 0
         const FT rate = c->four_pi_n0_icl * SG_i * inv_rho * M::exp2_fin(x * FT(-1.4426950408889634)) *
                         M::fma(x + FT(1), li_icl * li_icl, c->r_is2_over_me);
-        o.acnv_icl_sno = (has_icl && S_i > FT(0) && T < c->T_freeze) ? rate : FT(0);
+        o.acnv_icl_sno = m_and(has_icl, S_i > FT(0), T < c->T_freeze) ? rate : FT(0);
     }
 
     c = &consts_after(*c, o.acnv_icl_sno);
@@ -337,16 +338,16 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     o.alpha = c->cv_l * w_melt;                           // warm_accretion_melt_factor :458-465
     const FT A_rai = sq * (DEFEXP ? pr_3h : M::exp2_fin(c->acc_e_rai * l2_li_rai));
     const FT A_sno = n0_sno * (DEFEXP ? ps_3q : M::exp2_fin(c->acc_e_sno * l2_li_sno));
-    if (fl & CMX_1M_ACCR_LCL_RAI) o.accr_lcl_rai = (has_lcl && has_rai) ? (q_lcl * c->acc_k_lcl_rai) * A_rai : FT(0);
-    if (fl & CMX_1M_ACCR_LCL_SNO) o.S_lcl_sno = (has_lcl && has_sno) ? (q_lcl * c->acc_k_lcl_sno) * A_sno : FT(0);
+    if (fl & CMX_1M_ACCR_LCL_RAI) o.accr_lcl_rai = m_and(has_lcl, has_rai) ? FT((q_lcl * c->acc_k_lcl_rai) * A_rai) : FT(0);
+    if (fl & CMX_1M_ACCR_LCL_SNO) o.S_lcl_sno = m_and(has_lcl, has_sno) ? FT((q_lcl * c->acc_k_lcl_sno) * A_sno) : FT(0);
     if (fl & CMX_1M_ACCR_ICL_RAI) {
-        const bool both = has_icl && has_rai;
-        o.accr_icl_rai = both ? (q_icl * c->acc_k_icl_rai) * A_rai : FT(0);
+        const B both = m_and(has_icl, has_rai);
+        o.accr_icl_rai = both ? FT((q_icl * c->acc_k_icl_rai) * A_rai) : FT(0);
         // λ_rai⁻^6½ = λ_rai⁻^3½ · λ_rai⁻³
         const FT p = DEFEXP ? A_rai * pr_r12 : sq * M::exp2_fin(c->sink_e * l2_li_rai);
-        o.freeze_icl_rai = both ? (c->sink_k * inv_rho) * (li_icl * p) : FT(0);
+        o.freeze_icl_rai = both ? FT((c->sink_k * inv_rho) * (li_icl * p)) : FT(0);
     }
-    if (fl & CMX_1M_ACCR_ICL_SNO) o.accr_icl_sno = (has_icl && has_sno) ? (q_icl * c->acc_k_icl_sno) * A_sno : FT(0);
+    if (fl & CMX_1M_ACCR_ICL_SNO) o.accr_icl_sno = m_and(has_icl, has_sno) ? FT((q_icl * c->acc_k_icl_sno) * A_sno) : FT(0);
     c = &consts_after(*c, A_sno);
     const FT nir_sno = n0_sno * inv_rho;
     if (fl & CMX_1M_ACCR_RAI_SNO) {   // CM1:604-644, 815-867 (the fall speeds of absent species are not needed: the term is gated on both)
@@ -355,7 +356,7 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
         const FT dv = v_sno - v_rai;
         const FT dv_eff = M::sqrt(M::fma(dv, dv, c->coeff_disp * M::fma(v_sno, v_sno, v_rai * v_rai)));
         const FT pre = nir_sno * dv_eff;
-        const bool both = has_rai && has_sno;
+        const B both = m_and(has_rai, has_sno);
         const FT X = li_sno * li_rai;
         if constexpr (!DEFEXP) {
             pw_rs = M::exp2_fin(M::fma(c->rs_dp1_rai, l2_li_rai, l2_li_sno));
@@ -364,24 +365,24 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
         // i = snow, j = rain (δ of rain);  i = rain, j = snow (δ of snow)
         const FT poly_rs = M::fma(c->rs_q2_rai, li2_rai, M::fma(c->rs_q1_rai, X, li2_sno));
         const FT poly_sr = M::fma(c->rs_q2_sno, li2_sno, M::fma(c->rs_q1_sno, X, li2_rai));
-        o.S_rai_sno = both ? (pre * c->rs_k_rai) * (pw_rs * poly_rs) : FT(0);
-        o.S_sno_rai = both ? (pre * c->rs_k_sno) * (pw_sr * poly_sr) : FT(0);
+        o.S_rai_sno = both ? FT((pre * c->rs_k_rai) * (pw_rs * poly_rs)) : FT(0);
+        o.S_sno_rai = both ? FT((pre * c->rs_k_sno) * (pw_sr * poly_sr)) : FT(0);
     }
 
     c = &consts_after(*c, o.S_sno_rai);
     // ---- ventilated vapour exchange and melting — CM1:917-1139 ---------------------------------------------------
     if (fl & CMX_1M_RAIN_EVAPORATION) {   // min(0, S G 4π n0/ρ λ⁻² F) with the factor of S ≥ 0: the min moves onto S
         const FT F4 = M::fma(c->ven_b_rai * M::sqrt(sq), DEFEXP ? pr_075 : M::exp2_fin(c->ven_e_rai * l2_li_rai), c->ven_a_rai);
-        o.vap_rai = has_rai ? (inv_rho * li2_rai) * (F4 * (M::min(S_l, FT(0)) * G_l)) : FT(0);
+        o.vap_rai = has_rai ? FT((inv_rho * li2_rai) * (F4 * (M::min(S_l, FT(0)) * G_l))) : FT(0);
     }
     const FT F4_sno = M::fma(c->ven_b_sno, DEFEXP ? ps_58 : M::exp2_fin(c->ven_e_sno * l2_li_sno), c->ven_a_sno);
     const FT mp_sno = (nir_sno * li2_sno) * F4_sno;                                // 4π n0/ρ λ⁻² F
     if (fl & (CMX_1M_SNOW_SUBLIMATION_ONLY | CMX_1M_SNOW_DEP_AND_SUBL)) {
-        const FT rate = has_sno ? mp_sno * SG_i : FT(0);
+        const FT rate = has_sno ? FT(mp_sno * SG_i) : FT(0);
         o.vap_sno = (fl & CMX_1M_SNOW_DEP_AND_SUBL) ? rate : M::min(FT(0), rate);
     }
-    if (fl & CMX_1M_CLOUD_ICE_MELT) o.melt_icl = (has_icl && above_freezing) ? (c->mi_k * inv_rho) * (w_melt * (li_icl * li_icl)) : FT(0);
-    if (fl & CMX_1M_SNOW_MELT) o.melt_sno = (has_sno && above_freezing) ? mp_sno * (c->K_therm * w_melt) : FT(0);
+    if (fl & CMX_1M_CLOUD_ICE_MELT) o.melt_icl = m_and(has_icl, above_freezing) ? FT((c->mi_k * inv_rho) * (w_melt * (li_icl * li_icl))) : FT(0);
+    if (fl & CMX_1M_SNOW_MELT) o.melt_sno = m_and(has_sno, above_freezing) ? FT(mp_sno * (c->K_therm * w_melt)) : FT(0);
     return o;
 }
 
@@ -435,7 +436,12 @@ __device__ __forceinline__ void mp1m_tendencies_point(const C &c, FT rho, FT T, 
                                                       FT &dr, FT &ds) {
     const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(c, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno);
     mp1m_aggregate<FT>(p, dl, di, dr, ds);
-    if (any_nan(rho, q_tot, q_lcl, q_icl, q_rai, q_sno, T)) dl = di = dr = ds = Math<FT>::nan();
+    if constexpr (lanes_of<FT>::value == 1) {
+        if (any_nan(rho, q_tot, q_lcl, q_icl, q_rai, q_sno, T)) dl = di = dr = ds = Math<FT>::nan();
+    } else {
+        const typename Math<FT>::Mask poisoned = nan_mask(rho, q_tot, q_lcl, q_icl, q_rai, q_sno, T);
+        dl = poisoned ? Math<FT>::nan() : dl; di = poisoned ? Math<FT>::nan() : di; dr = poisoned ? Math<FT>::nan() : dr; ds = poisoned ? Math<FT>::nan() : ds;
+    }
 }
 
 // bulk_microphysics_tendencies(LinearizedAverage(), Microphysics1Moment(), …, Δt, nsub) of one point — BMT:572-632: nsub linearized
@@ -471,7 +477,7 @@ __device__ __forceinline__ void mp1m_linearized_point(const C &c, AF args, int n
         // _linearized_implicit_step — BMT:381-465
         const FT q_sat_min = M::min(p.qsat_l, p.qsat_i);
         const FT q_v = (((q_tot - ql) - qi) - qr) - qs;
-        const FT alpha = M::min(FT(1), M::max(FT(0), q_v - q_sat_min) * a.inv_dt_sub * M::rcp_nz(M::max((e1 + e2) + e4, M::eps())));
+        const FT alpha = M::min(FT(1), M::max(FT(0), q_v - q_sat_min) * a.inv_dt_sub * M::rcp_nz(M::max((e1 + e2) + e4, FT(M::eps()))));
         const FT a11 = a.inv_dt_sub - M11, a22 = a.inv_dt_sub - M22, a33 = a.inv_dt_sub - M33, a44 = a.inv_dt_sub - M44;
         const FT b1 = M::fma(alpha, e1, a.inv_dt_sub * ql), b2 = M::fma(alpha, e2, a.inv_dt_sub * qi), b3 = a.inv_dt_sub * qr,
                  b4 = M::fma(alpha, e4, a.inv_dt_sub * qs);
@@ -488,7 +494,7 @@ __device__ __forceinline__ void mp1m_linearized_point(const C &c, AF args, int n
         T += (a.Lv_over_cp * (dl + dr) + a.Ls_over_cp * (di + ds)) * a.dt_sub;
     }
     const auto &a = args(T);
-    const FT poison = any_nan(rho, q_tot, ql0, qi0, qr0, qs0, T0) ? M::nan() : FT(0);   // NaN in → NaN out (cmx_math.hpp any_nan)
+    const FT poison = nan_mask(rho, q_tot, ql0, qi0, qr0, qs0, T0) ? M::nan() : FT(0);   // NaN in → NaN out (cmx_math.hpp any_nan)
     dl_avg = (ql - ql0) * a.inv_dt + poison; di_avg = (qi - qi0) * a.inv_dt + poison;
     dr_avg = (qr - qr0) * a.inv_dt + poison; ds_avg = (qs - qs0) * a.inv_dt + poison;
 }

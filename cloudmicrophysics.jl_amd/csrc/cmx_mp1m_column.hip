@@ -44,6 +44,9 @@ template <typename FT> struct Mp1mColIO {
 // SGPR file and were parked in VGPR lanes — 34 v_readlane / v_writelane per Float32 point and 143 VGPRs in the first version.
 template <typename FT> struct Mp1mColKernArgs { Mp1mLinKernArgs<FT> k; Vel1mConsts<FT> vc; };
 
+#ifndef CMX_1M_COLUMN_PACKED
+#define CMX_1M_COLUMN_PACKED 1      // A/B switch: 0 = one point at a time (rounds 3–4)
+#endif
 template <typename FT, uint32_t FLAGS, bool LIN, bool GENERAL_GAMMA, int VEC, int BS>
 __global__ __launch_bounds__(BS) void mp1m_column_kernel(const Mp1mColKernArgs<FT> a0, const Mp1mColIO<FT> io, const int64_t first, const int64_t nvec) {
     using M = Math<FT>;
@@ -92,22 +95,75 @@ __global__ __launch_bounds__(BS) void mp1m_column_kernel(const Mp1mColKernArgs<F
         const auto &k = a.k;
         // two passes over the lane's points — tendencies, then fluxes — so that only one pass's constants are live at a time
         FT t[VEC][4];
+        // one value of the value type VT at a time: a point, or — Float32 with four points per lane — a PAIR of points in packed arithmetic (cmx_math.hpp f32x2;
+        // not the run-time-Γ instantiation: an OCML call per lane, nothing to pack)
+        constexpr int L = (sizeof(FT) == 4 && VEC % 2 == 0 && CMX_1M_COLUMN_PACKED && !GENERAL_GAMMA) ? 2 : 1;
+        using VT = std::conditional_t<L == 2, f32x2, FT>;
+        using MV = Math<VT>;
+        if constexpr (L == 1) {      // (kept verbatim from rounds 3–4: routing the one-point case through the generic form below doubled its registers)
 #pragma unroll
-        for (int p = 0; p < VEC; ++p) {
-            if constexpr (LIN)
-                mp1m_linearized_point<FT, FLAGS>(k.c, [&](FT dep) -> decltype(auto) { return (consts_after(k, dep).a); }, a0.k.a.nsub, x[0][p], x[1][p], x[2][p],
-                                                 x[3][p], x[4][p], x[5][p], x[6][p], t[p][0], t[p][1], t[p][2], t[p][3]);
-            else
-                mp1m_tendencies_point<FT, FLAGS>(k.c, x[0][p], x[1][p], x[2][p], x[3][p], x[4][p], x[5][p], x[6][p], t[p][0], t[p][1], t[p][2], t[p][3]);
-        }
-        const auto &vc = consts_after(a, t[VEC - 1][3]).vc;
+            for (int p = 0; p < VEC; ++p) {
+                if constexpr (LIN)
+                    mp1m_linearized_point<FT, FLAGS>(k.c, [&](FT dep) -> decltype(auto) { return (consts_after(k, dep).a); }, a0.k.a.nsub, x[0][p], x[1][p], x[2][p],
+                                                     x[3][p], x[4][p], x[5][p], x[6][p], t[p][0], t[p][1], t[p][2], t[p][3]);
+                else
+                    mp1m_tendencies_point<FT, FLAGS>(k.c, x[0][p], x[1][p], x[2][p], x[3][p], x[4][p], x[5][p], x[6][p], t[p][0], t[p][1], t[p][2], t[p][3]);
+            }
+            const auto &vc = consts_after(a, t[VEC - 1][3]).vc;
 #pragma unroll
-        for (int p = 0; p < VEC; ++p) {
-            F[p] = mp1m_sed_fluxes<FT, GENERAL_GAMMA>(vc, x[0][p], x[3][p], x[4][p], x[5][p], x[6][p]);
-            g[p] = io.inv_dz[lv] * M::rcp(max0(x[0][p]));                          // 1/(ρ_k Δz_k)
-            if (++lv == io.n_lev) lv = 0;
+            for (int p = 0; p < VEC; ++p) {
+                F[p] = mp1m_sed_fluxes<FT, GENERAL_GAMMA>(vc, x[0][p], x[3][p], x[4][p], x[5][p], x[6][p]);
+                g[p] = io.inv_dz[lv] * M::rcp(max0(x[0][p]));                          // 1/(ρ_k Δz_k)
+                if (++lv == io.n_lev) lv = 0;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) A[p][s] = M::fma(-F[p].f[s], g[p], t[p][s]);
+                for (int s = 0; s < 4; ++s) A[p][s] = M::fma(-F[p].f[s], g[p], t[p][s]);
+            }
+        } else {
+            auto val = [&x](int j, int p) -> VT {
+                if constexpr (L == 2) return VT{x[j][p], x[j][p + 1]};
+                else return x[j][p];
+            };
+#pragma unroll
+            for (int p = 0; p < VEC; p += L) {
+                VT tt[4];
+                if constexpr (LIN)
+                    mp1m_linearized_point<VT, FLAGS>(k.c, [&](VT dep) -> decltype(auto) { return (consts_after(k, dep).a); }, a0.k.a.nsub, val(0, p), val(1, p), val(2, p),
+                                                     val(3, p), val(4, p), val(5, p), val(6, p), tt[0], tt[1], tt[2], tt[3]);
+                else
+                    mp1m_tendencies_point<VT, FLAGS>(k.c, val(0, p), val(1, p), val(2, p), val(3, p), val(4, p), val(5, p), val(6, p), tt[0], tt[1], tt[2], tt[3]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if constexpr (L == 2) { t[p][s] = tt[s].x; t[p + 1][s] = tt[s].y; }
+                    else t[p][s] = tt[s];
+                }
+            }
+            const auto &vc = consts_after(a, t[VEC - 1][3]).vc;
+#pragma unroll
+            for (int p = 0; p < VEC; p += L) {
+                const SedFlux4<VT> Fp = mp1m_sed_fluxes<VT, GENERAL_GAMMA>(vc, val(0, p), val(3, p), val(4, p), val(5, p), val(6, p));
+                VT gp;                                                                 // 1/(ρ_k Δz_k)
+                if constexpr (L == 2) {
+                    const FT dz0 = io.inv_dz[lv];
+                    if (++lv == io.n_lev) lv = 0;
+                    const FT dz1 = io.inv_dz[lv];
+                    if (++lv == io.n_lev) lv = 0;
+                    gp = VT{dz0, dz1} * MV::rcp(max0(val(0, p)));
+                } else {
+                    gp = io.inv_dz[lv] * MV::rcp(max0(val(0, p)));
+                    if (++lv == io.n_lev) lv = 0;
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    VT tt;
+                    if constexpr (L == 2) tt = VT{t[p][s], t[p + 1][s]};
+                    else tt = t[p][s];
+                    const VT As = MV::fma(-Fp.f[s], gp, tt);
+                    if constexpr (L == 2) { A[p][s] = As.x; A[p + 1][s] = As.y; F[p].f[s] = Fp.f[s].x; F[p + 1].f[s] = Fp.f[s].y; }
+                    else { A[p][s] = As; F[p].f[s] = Fp.f[s]; }
+                }
+                if constexpr (L == 2) { g[p] = gp.x; g[p + 1] = gp.y; }
+                else g[p] = gp;
+            }
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s) halo[threadIdx.x][s] = F[0].f[s];

@@ -37,6 +37,9 @@ template <typename FT> constexpr int kBlock1m = CMX_1M_BLOCK;
 #else
 template <typename FT> constexpr int kBlock1m = sizeof(FT) == 4 ? 64 : 256;
 #endif
+#ifndef CMX_1M_PACKED
+#define CMX_1M_PACKED 1      // A/B switch: 0 = one point at a time (rounds 1–4)
+#endif
 template <typename FT, int VEC, uint32_t FLAGS = kRuntimeFlags>
 __global__ __launch_bounds__(kBlock1m<FT>) void mp1m_tendencies_kernel(const Mp1mConsts<FT> c, const Mp1mIn<FT> in,
                                                                        const Mp1mOut<FT> out, const int64_t nvec) {
@@ -50,7 +53,18 @@ __global__ __launch_bounds__(kBlock1m<FT>) void mp1m_tendencies_kernel(const Mp1
     Math<FT>::prepare();   // Float64: exp2 / log2 tables → LDS while the loads fly (every lane of the workgroup reaches the barrier inside); no-op for Float32
     if (i >= nvec) return;
     FT dl[VEC], di[VEC], dr[VEC], ds[VEC];
-    if constexpr (CMX_1M_HOIST && sizeof(FT) == 4 && VEC == 4 && FLAGS != kRuntimeFlags) {
+    if constexpr (CMX_1M_PACKED && sizeof(FT) == 4 && VEC == 4) {
+        // Float32, four points per lane: two PAIRS of points in packed arithmetic (cmx_math.hpp f32x2); the constants are read phase by phase through the
+        // kernel-argument pointer (a packed instruction takes no literal: the point function's literals occupy SGPRs next to the constants)
+#pragma unroll
+        for (int k = 0; k < VEC; k += 2) {
+            f32x2 l, ic, r, sn;
+            mp1m_tendencies_point<f32x2, FLAGS>(front_consts<FT, true>(c), f32x2{rho[k], rho[k + 1]}, f32x2{T[k], T[k + 1]}, f32x2{q_tot[k], q_tot[k + 1]},
+                                                f32x2{q_lcl[k], q_lcl[k + 1]}, f32x2{q_icl[k], q_icl[k + 1]}, f32x2{q_rai[k], q_rai[k + 1]},
+                                                f32x2{q_sno[k], q_sno[k + 1]}, l, ic, r, sn);
+            dl[k] = l.x; dl[k + 1] = l.y; di[k] = ic.x; di[k + 1] = ic.y; dr[k] = r.x; dr[k + 1] = r.y; ds[k] = sn.x; ds[k + 1] = sn.y;
+        }
+    } else if constexpr (CMX_1M_HOIST && sizeof(FT) == 4 && VEC == 4 && FLAGS != kRuntimeFlags) {
         Mp1mConsts<FT> ch = c;
         mp1m_hoist_consts<FT>(ch);
 #pragma unroll
@@ -94,6 +108,25 @@ __global__ __launch_bounds__(kBlockLin) void mp1m_linearized_kernel(const Mp1mLi
     const int64_t i = (int64_t)blockIdx.x * kBlockLin + threadIdx.x;
     if (i >= n) return;
     mp1m_linearized_lane<FT, FLAGS>(k0, io, [i](auto *p, int) -> decltype(auto) { return (p[i]); });
+}
+
+// Float32, round 5: TWO consecutive points per lane as one packed pair (cmx_math.hpp f32x2) — 8-byte loads and stores, the substep loop in packed
+// arithmetic.  Needs 8-byte-aligned columns; `npair` pairs.  (The host launches the one-point kernel for an odd last point or misaligned columns.)
+#ifndef CMX_1M_LIN_PACKED
+#define CMX_1M_LIN_PACKED 1      // A/B switch
+#endif
+template <uint32_t FLAGS = kRuntimeFlags>
+__global__ __launch_bounds__(kBlockLin) void mp1m_linearized_pair_kernel(const Mp1mLinKernArgs<float> k0, const Mp1mLinIO<float> io, const int64_t npair) {
+    const int64_t i = (int64_t)blockIdx.x * kBlockLin + threadIdx.x;
+    if (i >= npair) return;
+    const auto &k = front_consts<float, true>(k0);
+    f32x2 x[7], d[4];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) x[j] = reinterpret_cast<const f32x2 *>(io.in[j])[i];
+    mp1m_linearized_point<f32x2, FLAGS>(k.c, [&](f32x2 dep) -> decltype(auto) { return (consts_after(k, dep).a); }, k0.a.nsub, x[0], x[1], x[2], x[3], x[4], x[5], x[6],
+                                        d[0], d[1], d[2], d[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) reinterpret_cast<f32x2 *>(io.out[j])[i] = d[j];
 }
 
 // _microphysics_source_terms over columns (KAT / diagnostics harness): one point per lane
@@ -193,16 +226,18 @@ static int32_t tendencies_1m_entry(const MP *mp, const TH *tps, uint32_t flags, 
 template <typename FT, uint32_t FLAGS> struct Mp1mLayoutPolicy {
     static constexpr int NIN = 7, NOUT = 4, NAOS = 4;   // rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno → (dq_lcl_dt, dq_icl_dt, dq_rai_dt, dq_sno_dt)
     using Consts = Mp1mConsts<FT>;
-    template <typename C> static __device__ __forceinline__ void point(const C &c, const FT (&x)[NIN], FT (&y)[NOUT]) {
-        mp1m_tendencies_point<FT, FLAGS>(c, x[0], x[1], x[2], x[3], x[4], x[5], x[6], y[0], y[1], y[2], y[3]);
+    static constexpr bool PACKABLE = CMX_1M_PACKED;      // point() also takes the packed pair type (cmx_layout.hpp)
+    template <typename C, typename VT> static __device__ __forceinline__ void point(const C &c, const VT (&x)[NIN], VT (&y)[NOUT]) {
+        mp1m_tendencies_point<VT, FLAGS>(c, x[0], x[1], x[2], x[3], x[4], x[5], x[6], y[0], y[1], y[2], y[3]);
     }
 };
 // … and the LinearizedAverage tendencies (both constant structs as the one kernel argument)
 template <typename FT, uint32_t FLAGS> struct Mp1mLinLayoutPolicy {
     static constexpr int NIN = 7, NOUT = 4, NAOS = 4;
     using Consts = Mp1mLinKernArgs<FT>;
-    template <typename C> static __device__ __forceinline__ void point(const C &k, const FT (&x)[NIN], FT (&y)[NOUT]) {
-        mp1m_linearized_point<FT, FLAGS>(k.c, [&](FT dep) -> decltype(auto) { return (consts_after(k, dep).a); }, k.a.nsub, x[0], x[1], x[2], x[3], x[4], x[5],
+    static constexpr bool PACKABLE = CMX_1M_LIN_PACKED;
+    template <typename C, typename VT> static __device__ __forceinline__ void point(const C &k, const VT (&x)[NIN], VT (&y)[NOUT]) {
+        mp1m_linearized_point<VT, FLAGS>(k.c, [&](VT dep) -> decltype(auto) { return (consts_after(k, dep).a); }, k.a.nsub, x[0], x[1], x[2], x[3], x[4], x[5],
                                          x[6], y[0], y[1], y[2], y[3]);
     }
 };
@@ -237,12 +272,37 @@ static int32_t linearized_1m_entry(const MP *mp, const TH *tps, uint32_t flags, 
     if (const int32_t st = make_lin_kernargs<FT>(mp, tps, flags, q_min, dt, nsub, k)) return st;
     if (n == 0) return CMX_OK;
     if (!rho || !T || !q_tot || !q_lcl || !q_icl || !q_rai || !q_sno || !dq_lcl || !dq_icl || !dq_rai || !dq_sno) return CMX_ERR_BAD_ARG;
-    Mp1mLinIO<FT> io{{rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno}, {dq_lcl, dq_icl, dq_rai, dq_sno}};
-    const dim3 grid((unsigned)((n + kBlockLin - 1) / kBlockLin));
-    if (flags == CMX_1M_DEFAULT_OPTIONS && mp1m_default_exponents(k.c))
-        CMX_LAUNCH_FRONT((mp1m_linearized_kernel<FT, CMX_1M_DEFAULT_OPTIONS | kDefExpBit>), grid, dim3(kBlockLin), 0, reinterpret_cast<hipStream_t>(stream), k, io, n);
-    else
-        CMX_LAUNCH_FRONT((mp1m_linearized_kernel<FT>), grid, dim3(kBlockLin), 0, reinterpret_cast<hipStream_t>(stream), k, io, n);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool def = flags == CMX_1M_DEFAULT_OPTIONS && mp1m_default_exponents(k.c);
+    auto launch_points = [&](int64_t lo, int64_t count) {       // one point per lane
+        if (count <= 0) return;
+        Mp1mLinIO<FT> io{{rho + lo, T + lo, q_tot + lo, q_lcl + lo, q_icl + lo, q_rai + lo, q_sno + lo}, {dq_lcl + lo, dq_icl + lo, dq_rai + lo, dq_sno + lo}};
+        const dim3 grid((unsigned)((count + kBlockLin - 1) / kBlockLin));
+        if (def) CMX_LAUNCH_FRONT((mp1m_linearized_kernel<FT, CMX_1M_DEFAULT_OPTIONS | kDefExpBit>), grid, dim3(kBlockLin), 0, s, k, io, count);
+        else CMX_LAUNCH_FRONT((mp1m_linearized_kernel<FT>), grid, dim3(kBlockLin), 0, s, k, io, count);
+    };
+    if constexpr (sizeof(FT) == 4 && CMX_1M_LIN_PACKED) {
+        // Float32: pairs of points in packed arithmetic wherever all eleven columns share their offset modulo 8 bytes: an odd first point (and an
+        // odd last one) goes through the one-point kernel — the same per-point operations, so the result does not depend on the split
+        const void *ptrs[] = {rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno, dq_lcl, dq_icl, dq_rai, dq_sno};
+        const uintptr_t mis0 = reinterpret_cast<uintptr_t>(rho) & 7u;
+        bool same_mis = (mis0 % sizeof(FT)) == 0;
+        for (const void *p : ptrs) same_mis = same_mis && ((reinterpret_cast<uintptr_t>(p) & 7u) == mis0);
+        if (same_mis && n >= 2) {
+            const int64_t head = mis0 ? 1 : 0, npair = (n - head) / 2;
+            launch_points(0, head);
+            if (npair > 0) {
+                const int64_t lo = head;
+                Mp1mLinIO<float> io{{rho + lo, T + lo, q_tot + lo, q_lcl + lo, q_icl + lo, q_rai + lo, q_sno + lo}, {dq_lcl + lo, dq_icl + lo, dq_rai + lo, dq_sno + lo}};
+                const dim3 grid((unsigned)((npair + kBlockLin - 1) / kBlockLin));
+                if (def) CMX_LAUNCH_FRONT((mp1m_linearized_pair_kernel<CMX_1M_DEFAULT_OPTIONS | kDefExpBit>), grid, dim3(kBlockLin), 0, s, k, io, npair);
+                else CMX_LAUNCH_FRONT((mp1m_linearized_pair_kernel<kRuntimeFlags>), grid, dim3(kBlockLin), 0, s, k, io, npair);
+            }
+            launch_points(head + 2 * npair, n - head - 2 * npair);
+        } else
+            launch_points(0, n);
+    } else
+        launch_points(0, n);
     CMX_HIP_TRY(hipGetLastError());
     return CMX_OK;
 }

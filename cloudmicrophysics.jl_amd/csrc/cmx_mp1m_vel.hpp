@@ -32,18 +32,18 @@ template <typename FT, typename VC> __device__ __forceinline__ FT vel_l2_li_rain
 template <typename FT, typename VC> __device__ __forceinline__ FT vel_l2_li_snow(const VC &c, FT rp, FT q) {
     using M = Math<FT>;
     const FT l2_rq = M::log2(rp * M::max(FT(0), q));
-    const FT l2_n0 = q > c.eps_1m ? M::fma(c.sno_nu, l2_rq, c.sno_l2_mu) : c.l2_eps;
+    const FT l2_n0 = q > c.eps_1m ? FT(M::fma(c.sno_nu, l2_rq, c.sno_l2_mu)) : FT(c.l2_eps);
     return M::max(c.lam_floor_sno, M::fma(l2_rq - M::max(l2_n0, c.l2_eps), c.lam_a_sno, c.lam_b_sno));
 }
 // CM1.terminal_velocity(::Rain / ::Snow, ::Blk1MVelType, ρ, q) — CM1:223-249
 template <typename FT, typename VC> __device__ __forceinline__ FT vel_rain_blk1m(const VC &c, FT rho, FT l2_li, FT q) {
     using M = Math<FT>;
     const FT sq = M::sqrt(M::max(c.rho_w * M::rcp(rho) - FT(1), FT(0)));
-    return q > c.eps_1m ? (c.vt_k_rai * sq) * M::exp2(c.vt_e_rai * l2_li) : FT(0);
+    return q > c.eps_1m ? FT((c.vt_k_rai * sq) * M::exp2(c.vt_e_rai * l2_li)) : FT(0);
 }
 template <typename FT, typename VC> __device__ __forceinline__ FT vel_snow_blk1m(const VC &c, FT l2_li, FT q) {
     using M = Math<FT>;
-    return q > c.eps_1m ? c.vt_k_sno * M::exp2(c.vt_e_sno * l2_li) : FT(0);
+    return q > c.eps_1m ? FT(c.vt_k_sno * M::exp2(c.vt_e_sno * l2_li)) : FT(0);
 }
 // Chen 2022 rain, mass-weighted (k = 3), diameter slope = 2 λ⁻¹ — CM1:251-270, Common.jl:290-302,414-422.  Γ(b+1) from the host-fitted
 // polynomials in ρ (NaN fall speed beyond their range, ρ > 2 kg/m³); GENERAL: run-time Γ for parameter sets the fit cannot represent
@@ -61,18 +61,18 @@ template <typename FT, bool GENERAL = false, typename VC> __device__ __forceinli
         const FT l2_den = M::log2(lam + c.ch_c1000[k]);
         const FT e3 = M::exp2(l2_mag - FT(4) * l2_lam_inv - (bi + FT(4)) * l2_den);
         // Γ(b+4)/3!: the fitted polynomial in ρ, or (b+3)(b+2)(b+1)·Γ(b+1)/6 with the run-time Γ
-        const FT g = GENERAL ? tgamma_general<FT>(bi + FT(1)) * (bi + FT(3)) * (bi + FT(2)) * (bi + FT(1)) * FT(1.0 / 6.0) : chen_gamma_eval<FT>(c.chg, k, rp);
-        w = k == 0 ? (c.ch_a[k] * e3) * g : M::fma(c.ch_a[k] * e3, g, w);
+        const FT g = GENERAL ? FT(tgamma_general<FT>(bi + FT(1)) * (bi + FT(3)) * (bi + FT(2)) * (bi + FT(1)) * FT(1.0 / 6.0)) : chen_gamma_eval<typename M::Scalar>(c.chg, k, rp);
+        w = k == 0 ? FT((c.ch_a[k] * e3) * g) : M::fma(c.ch_a[k] * e3, g, w);
     }
     w = M::max(FT(0), w);
-    if (!GENERAL && rp > FT(kChenGammaRhoMax)) w = M::nan();       // outside the range of the fitted Γ: no silent extrapolation
+    if constexpr (!GENERAL) w = rp > FT(kChenGammaRhoMax) ? M::nan() : w;       // outside the range of the fitted Γ: no silent extrapolation
     return q > c.eps_1m ? w : FT(0);
 }
 // CMNonEq.terminal_velocity(::CloudLiquid, ::StokesRegimeVelType, ρ, q): Stokes at the mean-volume diameter — NonEq:250-265
 template <typename FT, typename VC> __device__ __forceinline__ FT vel_lcl_stokes(const VC &c, FT rho, FT q) {
     using M = Math<FT>;
     const FT D2 = M::exp2(FT(2.0 / 3.0) * M::log2(c.st_D3 * rho * M::max(FT(0), q)));
-    return q > c.eps_1m ? c.st_pref * (c.st_rho_w * M::rcp(rho) - FT(1)) * D2 : FT(0);
+    return q > c.eps_1m ? FT(c.st_pref * (c.st_rho_w * M::rcp(rho) - FT(1)) * D2) : FT(0);
 }
 // CMNonEq.terminal_velocity(::CloudIce, ::Chen2022VelTypeSmallIce, ρ, q): Σ aₖ D^bₖ e^{−cₖD} at that diameter — NonEq:267-281
 template <typename FT, typename VC> __device__ __forceinline__ FT vel_icl_chen(const VC &c, FT rho, FT rp, FT q) {
@@ -82,7 +82,7 @@ template <typename FT, typename VC> __device__ __forceinline__ FT vel_icl_chen(c
     const FT b = M::fma(rp, c.ci_C, c.ci_B);
     const FT common = M::exp2(c.ci_A * M::log2(rp) + b * (c.l2_1000 + l2_D));           // ρₐ^As · (1000 D)^b
     const FT w = common * M::fma(c.ci_F, M::exp2(-c.ci_c2 * D * FT(1.4426950408889634)), c.ci_E);
-    return q > c.eps_1m ? M::max(FT(0), w) : FT(0);
+    return q > c.eps_1m ? FT(M::max(FT(0), w)) : FT(0);
 }
 // CM1.terminal_velocity(::Snow, ::Chen2022VelTypeLargeIce, ρ, q): mass-weighted (k = 3), λ_D⁻¹ = 2 λ⁻¹ — CM1:272-297
 template <typename FT, typename VC> __device__ __forceinline__ FT vel_snow_chen(const VC &c, FT rp, FT l2_li, FT q) {
@@ -92,7 +92,7 @@ template <typename FT, typename VC> __device__ __forceinline__ FT vel_snow_chen(
     // aₖ e^{−4 ln λ_D⁻¹ − (bₖ+4) ln(λ_D + cₖ)}: term 1 has c = 0 → λ_D^{−b₁}·… collapses to one power
     const FT t1 = c.sn_a1 * M::exp2(l2_ra + c.sn_b1 * l2_ld);
     const FT t2 = c.sn_a2 * M::exp2(l2_ra + c.sn_H * rp * FT(1.4426950408889634) - FT(4) * l2_ld - (c.sn_b2 + FT(4)) * M::log2(lam + c.sn_c2));
-    return q > c.eps_1m ? M::max(FT(0), t1 + t2) : FT(0);
+    return q > c.eps_1m ? FT(M::max(FT(0), t1 + t2)) : FT(0);
 }
 
 // ---- sedimentation fluxes of the fused column step (cmx_mp1m_column.hip) ------------------------------------------------------------
@@ -114,8 +114,7 @@ __device__ __forceinline__ SedFlux4<FT> mp1m_sed_fluxes(const VC &vc, FT rho, FT
     F.f[3] = (r_ * qs) * vel_snow_chen<FT>(v3, r_, vel_l2_li_snow<FT>(v3, r_, qs), qs);
     const FT q[4] = {q_lcl, q_icl, q_rai, q_sno};
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-        if (any_nan(rho, q[s])) F.f[s] = M::nan();
+    for (int s = 0; s < 4; ++s) F.f[s] = nan_mask(rho, q[s]) ? M::nan() : F.f[s];
     return F;
 }
 

@@ -25,6 +25,9 @@ namespace cmx {
 // VEL_CHEN: the density-dependent coefficients of the Chen-2022 terms from host-fitted polynomials in ρ (cmx_math.hpp ChenLog); VEL_CHEN_GEN: run-time Γ for
 // parameter sets the fit cannot represent (make_chen_log false)
 enum : int { VEL_NONE = 0, VEL_SB = 1, VEL_CHEN = 2, VEL_CHEN_GEN = 3 };
+#ifndef CMX_SB_TSTAR_RCP
+#define CMX_SB_TSTAR_RCP 1        // A/B switch of the evaporation's t* (below)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Host-folded constants.  Plain FT members only (kernel argument → SGPRs).
@@ -48,6 +51,7 @@ template <typename FT> struct SbConsts {
     FT sqrt_alpha_nu, beta, ev_rho0_q;  // √(α/ν_air), β, ρ0^(1/4)
     FT sqrt_alpha_nu_rho0q;             // their product, folded on the host (a product of two kernel arguments is a VALU multiply per point)
     FT two_pi, l2_gate_N;               // log2(eps(FT)·x*) of the evaporation number gate
+    FT tstar_Dr;                        // t*·Dr = ∛(6 x*)·∛(6/(π ρw)) — parameter-only: t* = ∛(6 x*/x̄_r) and Dr = ∛(6 x̄_r/(π ρw)) share x̄_r (round 5)
     // autoconversion / cloud self-collection (CM2:396-427, 488-501)
     FT sqrt_kfac, x_star, inv_x_star, acnv_A, acnv_a, acnv_b, acnv_rho0, ksc;
     // accretion (CM2:445-470)
@@ -140,6 +144,7 @@ inline SbConsts<FT> make_sb_consts(const WR &wr, const TH &tp, const VL *vel, do
     c.sqrt_alpha_nu_rho0q = (FT)(std::sqrt((double)ev.alpha / (double)wr.air_properties.nu_air) * std::sqrt(std::sqrt((double)ev.rho_0)));
     c.two_pi = (FT)(2.0 * pi);
     c.l2_gate_N = (FT)std::log2((double)Math<FT>::eps() * x_star_ev);
+    c.tstar_Dr = (FT)(std::cbrt(6.0 * x_star_ev) * std::cbrt(6.0 / (pi * (double)pr.rho_w)));
     // autoconversion
     const auto &ac = sb.acnv;
     const double nu_c = (double)sb.pdf_c.nu_c;
@@ -229,17 +234,20 @@ inline CloudVelConsts<FT> make_cloud_vel_consts(const PDF &pdf, const VEL &vel) 
     c.K53 = (FT)std::exp(5.0 / 3.0 * dlg + std::lgamma(z1 + 5.0 / 3.0 / mu) - std::lgamma(z1));
     return c;
 }
-template <typename FT>
-__device__ __forceinline__ void sb2006_cloud_velocity(const CloudVelConsts<FT> &c, FT q, FT r, FT N, FT &vt_n, FT &vt_m) {
+template <typename FT, typename CV>      // FT: the value type; CV: CloudVelConsts of its scalar type
+__device__ __forceinline__ void sb2006_cloud_velocity(const CV &c, FT q, FT r, FT N, FT &vt_n, FT &vt_m) {
     using M = Math<FT>;
     const FT sq = M::max(q, M::eps()), sN = M::max(N, M::eps());
     const FT x23 = M::exp2(FT(2.0 / 3.0) * M::log2(r * sq * M::rcp(sN)));
     const FT pref = c.pre_c * (c.rho_w * M::rcp(r) - FT(1));
-    const bool none = N < M::eps() || q < M::eps();
+    const typename M::Mask none = m_or(N < M::eps(), q < M::eps());
     vt_n = none ? FT(0) : pref * c.K23 * x23;
     vt_m = none ? FT(0) : pref * c.K53 * x23;
 }
 
+// The point functions below are templates on the VALUE type `FT`: float, double, or the packed pair f32x2 (two Float32 points per value, cmx_math.hpp) — `FT(x)`
+// broadcasts a constant, comparisons give `typename Math<FT>::Mask` (bool, or a lane mask that is combined with | and selected with ?:), and the constants
+// struct C always holds SCALARS of Math<FT>::Scalar.
 // ---- rain PSD parameters (CM2:67-110) from the safe values, in the log2 domain ------------------------------
 // All four limiters (Eq. 94-97) are clamps of monotone power laws of L_rai and N_rai, so they are applied to the
 // log2 values: two log2 in, then every derived quantity is one exp2 (11 → 5-6 transcendentals).
@@ -266,9 +274,10 @@ __device__ __forceinline__ SbRainPsd<FT> sb2006_rain_psd(const C &c, FT L_rai, F
 
 // ---- rain terminal velocity (CM2:685-719) from log2 λ; gated like the reference -----------------------------------------------
 template <typename FT, bool LIMITED, int VEL, typename C>
-__device__ __forceinline__ void sb2006_rain_velocity(const C &c, FT rho, FT rs_rho, FT l2_lam, bool no_N_rai, bool no_q_rai,
-                                                     FT &vt_n, FT &vt_m) {
+__device__ __forceinline__ void sb2006_rain_velocity(const C &c, FT rho, FT rs_rho, FT l2_lam, typename Math<FT>::Mask no_N_rai,
+                                                     typename Math<FT>::Mask no_q_rai, FT &vt_n, FT &vt_m) {
     using M = Math<FT>;
+    using S = typename M::Scalar;
     vt_n = FT(0);
     vt_m = FT(0);
     if constexpr (VEL == VEL_SB) {   // CM2:685-702, helper :720-739
@@ -300,7 +309,7 @@ __device__ __forceinline__ void sb2006_rain_velocity(const C &c, FT rho, FT rs_r
             // (wave-uniform shortcuts for the published table's c_1 = 0, c_2 = c_3 were tried: if-converted they cost three selects per point
             // and save nothing; as real scalar branches they split the four points' code into 24 blocks — 149 VGPRs instead of 124)
             const FT l2_den = M::log2(lam + c.ch_c1000[i]);     // log2(λ + 1000 c_i)
-            FT L0 = chen_log_eval<FT>(c.chl, 0, i, t), L3 = chen_log_eval<FT>(c.chl, 1, i, t);
+            FT L0 = chen_log_eval<S>(c.chl, 0, i, t), L3 = chen_log_eval<S>(c.chl, 1, i, t);
             if (i == 2) { const FT ar = c.ch_a3_pow * M::log2(rho_c); L0 += ar; L3 += ar; }      // ρ^a3_pow of the third term (log-singular at 0: not in the fit)
             const FT e0 = M::exp2(M::fma(-M::fma(-c.ch_b_rho, rho_c, c.chl.b1[i]), l2_den, L0 + l2_lam));
             const FT e3 = M::exp2(M::fma(-M::fma(-c.ch_b_rho, rho_c, c.chl.b4[i]), l2_den, L3 + l2_lam4));
@@ -309,7 +318,11 @@ __device__ __forceinline__ void sb2006_rain_velocity(const C &c, FT rho, FT rs_r
         }
         vt0 = M::max(FT(0), vt0);
         vt3 = M::max(FT(0), vt3);
-        if (rho_c > FT(kChenGammaRhoMax)) vt0 = vt3 = M::nan();   // outside the range of the fit: no silent extrapolation
+        {   // outside the range of the fit: no silent extrapolation
+            const typename M::Mask beyond = rho_c > FT(kChenGammaRhoMax);
+            vt0 = beyond ? M::nan() : vt0;
+            vt3 = beyond ? M::nan() : vt3;
+        }
         vt_n = no_N_rai ? FT(0) : vt0;
         vt_m = no_q_rai ? FT(0) : vt3;
     } else if constexpr (VEL == VEL_CHEN_GEN) {   // any table, any ρ: run-time Γ (OCML tgamma)
@@ -363,7 +376,7 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, F
                                                     FT q_lcl, FT q_rai, FT N_lcl, FT N_rai,
                                                     FT n_lcl, FT n_rai, FT q_ice = FT(0), FT cpm_qi = FT(0)) {
     using M = Math<FT>;
-    const FT eps = M::eps();  // ϵ_numerics_2M_M = ϵ_numerics_2M_N = eps(FT)  (Utilities.jl:325,332)
+    const FT eps = FT(M::eps());  // ϵ_numerics_2M_M = ϵ_numerics_2M_N = eps(FT)  (Utilities.jl:325,332)
     SbRates<FT> r;
 
     const FT rs_rho = M::rsqrt(rho);      // ρ^(-1/2); each √(ρ0/ρ) is (host √ρ0)·rs_rho.  The FULL form: ρ arrives clamped with max0(), so 0 is possible (+Inf
@@ -408,7 +421,8 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, F
     const FT L_lcl = rho * sq_lcl;
     const FT L_rai = rho * sq_rai;
     const FT x_lcl_raw = L_lcl * M::rcp_nz(sN_lcl);                       // sN ≥ eps
-    const bool no_q_lcl = q_lcl < eps, no_N_lcl = N_lcl < eps, no_q_rai = q_rai < eps;
+    using B = typename M::Mask;
+    const B no_q_lcl = q_lcl < eps, no_N_lcl = N_lcl < eps, no_q_rai = q_rai < eps;
     // τ = 1 − q_l/(q_l+q_r) (Eq. 5) in its cancellation-free form q_r/(q_l+q_r); 1−τ likewise.
     // With q_rai < eps the reference's two τ (max(0,q_r) in CM2:407 vs max(q_r,eps) in :450) differ,
     // but there ϕ_au ≡ 0 and accretion ≡ 0, so one τ serves both.
@@ -429,7 +443,7 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, F
         const FT inv_omt = M::rcp_nz(one_m_tau);                          // 1 − τ = sq_lcl/(sq_lcl + sq_rai) > 0
         const FT dL_rai = (u * u) * M::fma(phi_au, inv_omt * inv_omt, FT(1)) * (c.acnv_rho0 * inv_rho);
         const FT dN_rai = dL_rai * c.inv_x_star;
-        const bool gate = no_q_lcl || no_N_lcl;
+        const B gate = m_or(no_q_lcl, no_N_lcl);
         r.au_dq_rai = gate ? FT(0) : dL_rai * inv_rho;
         r.au_dq_lcl = -r.au_dq_rai;
         r.au_dN_rai = gate ? FT(0) : dN_rai;
@@ -452,7 +466,7 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, F
         const FT k_ac = c.kcr_s * rs_rho * L_rai * phi_ac;
         const FT dq = keep(k_ac * L_lcl * inv_rho);          // dL_rai/ρ with dL_rai = kcr √(ρ0/ρ) L_lcl L_rai ϕ_ac
         const FT dN = keep(-k_ac * sN_lcl);                  // −dL_rai / x̄_c with x̄_c = L_lcl / N_lcl: the L_lcl of dL_rai cancels
-        const bool gate = no_q_lcl || no_q_rai || no_N_lcl;
+        const B gate = m_or(no_q_lcl, no_q_rai, no_N_lcl);
         r.ac_dq_rai = gate ? FT(0) : dq;
         r.ac_dq_lcl = -r.ac_dq_rai;
         r.ac_dN_lcl = gate ? FT(0) : dN;
@@ -464,7 +478,7 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, F
     const FT l2_xr = psd.l2_xr, l2_lam = psd.l2_lam;
     const FT l2_Dr = (l2_xr + c_psd.l2_Drc) * FT(1.0 / 3.0);
     const FT Dr = M::exp2_fin(l2_Dr);                      // ∛(6 x̄_r/(π ρw)): CM2:588 and :809
-    const bool no_N_rai = N_rai < eps;
+    const B no_N_rai = N_rai < eps;
     {   // rain_self_collection CM2:545-560 + rain_breakup CM2:579-601
         const C &c = consts_after(c0, CMX_PHASE_DEP(r.ac_dN_lcl, l2_tau));
         // 1/Br = ∛(x̄_r/6) = Dr·∛(π ρw/36): κ_rr/Br = kappa_rr_K·Dr
@@ -472,7 +486,7 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, F
         if constexpr (INTPOW) { const FT r1 = M::rcp_nz(M::fma(c.kappa_rr_K, Dr, FT(1))), r2 = r1 * r1; pw = r2 * r2 * r1; }
         else pw = M::exp2_fin(c.self_d * M::log2(M::fma(c.kappa_rr_K, Dr, FT(1))));
         const FT sc = -c.krr_s * rs_rho * N_rai * L_rai * pw;
-        const bool gate = no_q_rai || no_N_rai;
+        const B gate = m_or(no_q_rai, no_N_rai);
         r.rsc = gate ? FT(0) : sc;
         const FT dD = Dr - c.Deq;
         const FT br_lin = keep(c.kbr * dD), br_exp = keep(M::exp2_fin(c.kappa_br_l2e * dD) - FT(1));
@@ -482,7 +496,12 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, F
     {   // rain_evaporation CM2:780-828
         const C &c = consts_after(c0, CMX_PHASE_DEP(r.rbr, l2_xr));
         const FT l2_t = (c.l2_6xstar - l2_xr) * FT(1.0 / 3.0);            // t* = ∛(6 x*/x̄_r)
-        const FT t_star = M::exp2_fin(l2_t);
+        // Float64 (round 5): t*·Dr is a constant of the parameter set, so t* is one Newton reciprocal of the Dr already at hand (≈ 7 instruction
+        // slots) instead of a table-driven exponential (≈ 14); Float32 keeps the exponential (v_exp_f32 and v_rcp_f32 cost the same).  Dr > 0 and finite:
+        // the exponential of a finite log2.  2⁻⁴⁸ relative on t*, which enters e^{−t*} (absolute exponent error t*·2⁻⁴⁸) and nothing else.
+        FT t_star;
+        if constexpr (M::IS_F64 && CMX_SB_TSTAR_RCP) t_star = c.tstar_Dr * M::rcp_nz(Dr);
+        else t_star = M::exp2_fin(l2_t);
         // e^{−t*}/x̄_r in one exponential: both factors enter the number tendency only (Γ_incl does not appear in the mass one);
         // the ventilation coefficients a_vent_0, b_vent_0·∛Sc are folded into the Γ_incl denominators on the host
         const FT e_tx = M::exp2_fin(M::fma(t_star, FT(-1.4426950408889634), -l2_xr));   // t* ≤ 2^((l2_6x* + 1100)/3): finite
@@ -496,8 +515,8 @@ __device__ __forceinline__ SbRates<FT> sb2006_point(const C &c0, FT rho, FT T, F
         const FT common = c.two_pi * G * S * N_rai * Dr;
         const FT dN = M::min(FT(0), common * Fv0 * e_tx);
         const FT dq = M::min(FT(0), common * Fv1 * inv_rho);
-        const bool gate_q = no_q_rai || (N_rai <= eps) || (S >= FT(0));
-        const bool gate_N = gate_q || (l2_xr < c.l2_gate_N);             // x̄_r/x* < eps(FT) — CM2:824-825
+        const B gate_q = m_or(no_q_rai, N_rai <= eps, S >= FT(0));
+        const B gate_N = m_or(gate_q, l2_xr < c.l2_gate_N);                 // x̄_r/x* < eps(FT) — CM2:824-825
         r.evN = gate_N ? FT(0) : dN;
         r.evq = gate_q ? FT(0) : dq;
     }

@@ -43,8 +43,8 @@ template <typename FT> struct SbColIO {
 template <typename FT> struct SedFlux { FT q_rai, n_rai, q_lcl, n_lcl; };
 
 // fluxes of one (clamped) point from its fall speeds
-template <typename FT, bool CLOUD>
-__device__ __forceinline__ SedFlux<FT> sed_fluxes(const CloudVelConsts<FT> &cv, FT r_, FT ql, FT nl, FT qr, FT nr, FT vt_n, FT vt_m) {
+template <typename FT, bool CLOUD, typename CV>      // FT: the value type (a point or a packed pair); CV: CloudVelConsts of its scalar type
+__device__ __forceinline__ SedFlux<FT> sed_fluxes(const CV &cv, FT r_, FT ql, FT nl, FT qr, FT nr, FT vt_n, FT vt_m) {
     SedFlux<FT> f;
     f.q_rai = (r_ * qr) * vt_m;
     f.n_rai = (r_ * nr) * vt_n;
@@ -79,11 +79,19 @@ __device__ __forceinline__ SedFlux<FT> sed_fluxes_of_point(const C &c, const Clo
     return f;
 }
 
+#ifndef CMX_F32_PACKED_COLUMN
+#define CMX_F32_PACKED_COLUMN 1        // A/B switch: 0 = one point at a time (rounds 2–4)
+#endif
+// waves per SIMD the Float32 instantiation is compiled for: 5 (96 VGPRs) for the one-point form of rounds 2–4; the packed form holds two points' intermediates in
+// register pairs and spills at 96 (2–25 VGPRs to scratch in the SB2006 / Chen instantiations): 4 (128 VGPRs)
+#ifndef CMX_COL_F32_WAVES
+#define CMX_COL_F32_WAVES (CMX_F32_PACKED_COLUMN ? 4 : 5)
+#endif
 #ifndef CMX_COL_F64_WAVES
 #define CMX_COL_F64_WAVES 2      // A/B switch: waves per SIMD the Float64 instantiation is compiled for
 #endif
 template <typename FT, bool LIMITED, int VEL, bool CLOUD, int VEC, int BS, bool INTPOW = false>
-__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(sizeof(FT) == 4 ? 5 : CMX_COL_F64_WAVES))) void sb2006_column_kernel(const SbConsts<FT> c, const CloudVelConsts<FT> cv, const SbColIO<FT> io,
+__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(sizeof(FT) == 4 ? CMX_COL_F32_WAVES : CMX_COL_F64_WAVES))) void sb2006_column_kernel(const SbConsts<FT> c, const CloudVelConsts<FT> cv, const SbColIO<FT> io,
                                                            const int64_t first, const int64_t nvec) {
     using M = Math<FT>;
     // fluxes of every lane's FIRST point, + slot BS for the point that follows the tile
@@ -142,30 +150,92 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(sizeof(FT) =
             lev = (int32_t)k64;
         }
         int32_t lv = lev;
+        // one value of the value type VT at a time: a point, or — Float32 with four points per lane — a PAIR of points in packed arithmetic (cmx_math.hpp f32x2)
+        constexpr int L = (sizeof(FT) == 4 && VEC % 2 == 0 && CMX_F32_PACKED_COLUMN && VEL != VEL_CHEN_GEN) ? 2 : 1;    // (the run-time Γ of the general Chen instantiation is an OCML call per lane: nothing to pack, 100 spilled VGPRs)
+        if constexpr (L == 1) {      // one point at a time — rounds 2–4 verbatim (see sb2006_tendencies_kernel)
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) {
-            // clamp_to_nonneg — BMT:828-837 (T is not clamped)
-            const FT r_ = max0(rho[k]), qt = max0(q_tot[k]), ql = max0(q_lcl[k]);
-            const FT qr = max0(q_rai[k]), nl = max0(n_lcl[k]), nr = max0(n_rai[k]);
-            const bool poisoned = any_nan(rho[k], q_tot[k], q_lcl[k], n_lcl[k], q_rai[k], n_rai[k], T[k]);
-            const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL, false, INTPOW>(front_consts<FT>(c), r_, T[k], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
-            F[k] = sed_fluxes<FT, CLOUD>(cv, r_, ql, nl, qr, nr, p.vt_n, p.vt_m);
-            g[k] = io.inv_dz[lv] * p.inv_rho;                                  // 1/(ρ_k Δz_k)
-            if (++lv == io.n_lev) lv = 0;
-            // sums of warm_rain_tendencies_2m — BMT:738-779 (as in sb2006_tendencies_kernel), minus the outflow through the lower face
-            A[k][0] = (p.cond + p.au_dq_lcl) + p.ac_dq_lcl;
-            A[k][1] = M::fma(p.lsc_plus_au + p.ac_dN_lcl, p.inv_rho, p.na_lcl);
-            A[k][2] = M::fma(-F[k].q_rai, g[k], (p.evq + p.au_dq_rai) + p.ac_dq_rai);
-            A[k][3] = M::fma(-F[k].n_rai, g[k], M::fma(((p.evN + p.au_dN_rai) + p.rsc) + p.rbr, p.inv_rho, p.na_rai));
-            if constexpr (CLOUD) {
-                A[k][0] = M::fma(-F[k].q_lcl, g[k], A[k][0]);
-                A[k][1] = M::fma(-F[k].n_lcl, g[k], A[k][1]);
+            for (int k = 0; k < VEC; ++k) {
+                // clamp_to_nonneg — BMT:828-837 (T is not clamped)
+                const FT r_ = max0(rho[k]), qt = max0(q_tot[k]), ql = max0(q_lcl[k]);
+                const FT qr = max0(q_rai[k]), nl = max0(n_lcl[k]), nr = max0(n_rai[k]);
+                const bool poisoned = any_nan(rho[k], q_tot[k], q_lcl[k], n_lcl[k], q_rai[k], n_rai[k], T[k]);
+                const SbRates<FT> p = sb2006_point<FT, LIMITED, VEL, false, INTPOW>(front_consts<FT>(c), r_, T[k], qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
+                F[k] = sed_fluxes<FT, CLOUD>(cv, r_, ql, nl, qr, nr, p.vt_n, p.vt_m);
+                g[k] = io.inv_dz[lv] * p.inv_rho;                                  // 1/(ρ_k Δz_k)
+                if (++lv == io.n_lev) lv = 0;
+                // sums of warm_rain_tendencies_2m — BMT:738-779 (as in sb2006_tendencies_kernel), minus the outflow through the lower face
+                A[k][0] = (p.cond + p.au_dq_lcl) + p.ac_dq_lcl;
+                A[k][1] = M::fma(p.lsc_plus_au + p.ac_dN_lcl, p.inv_rho, p.na_lcl);
+                A[k][2] = M::fma(-F[k].q_rai, g[k], (p.evq + p.au_dq_rai) + p.ac_dq_rai);
+                A[k][3] = M::fma(-F[k].n_rai, g[k], M::fma(((p.evN + p.au_dN_rai) + p.rsc) + p.rbr, p.inv_rho, p.na_rai));
+                if constexpr (CLOUD) {
+                    A[k][0] = M::fma(-F[k].q_lcl, g[k], A[k][0]);
+                    A[k][1] = M::fma(-F[k].n_lcl, g[k], A[k][1]);
+                }
+                // NaN rule (one rule for every path — ADVICE r02): a NaN in ANY input poisons the point's four tendencies; the FLUXES depend on
+                // (ρ, q_lcl, n_lcl, q_rai, n_rai) only — exactly the operands of sed_fluxes_of_point, which evaluates the point after the tile —
+                // so a NaN in T or q_tot does not reach the cell below, wherever the tile boundary falls
+                if (poisoned) A[k][0] = A[k][1] = A[k][2] = A[k][3] = M::nan();
+                if (any_nan(rho[k], q_lcl[k], n_lcl[k], q_rai[k], n_rai[k])) F[k].q_rai = F[k].n_rai = F[k].q_lcl = F[k].n_lcl = M::nan();
             }
-            // NaN rule (one rule for every path — ADVICE r02): a NaN in ANY input poisons the point's four tendencies; the FLUXES depend on
-            // (ρ, q_lcl, n_lcl, q_rai, n_rai) only — exactly the operands of sed_fluxes_of_point, which evaluates the point after the tile —
-            // so a NaN in T or q_tot does not reach the cell below, wherever the tile boundary falls
-            if (poisoned) A[k][0] = A[k][1] = A[k][2] = A[k][3] = M::nan();
-            if (any_nan(rho[k], q_lcl[k], n_lcl[k], q_rai[k], n_rai[k])) F[k].q_rai = F[k].n_rai = F[k].q_lcl = F[k].n_lcl = M::nan();
+        } else {
+            using VT = std::conditional_t<L == 2, f32x2, FT>;
+            using MV = Math<VT>;
+#pragma unroll
+            for (int k = 0; k < VEC; k += L) {
+                auto val = [k](const FT (&a)[VEC]) -> VT {
+                    if constexpr (L == 2) return VT{a[k], a[k + 1]};
+                    else return a[k];
+                };
+                const VT rho_k = val(rho), T_k = val(T), qt_k = val(q_tot), ql_k = val(q_lcl), nl_k = val(n_lcl), qr_k = val(q_rai), nr_k = val(n_rai);
+                // clamp_to_nonneg — BMT:828-837 (T is not clamped)
+                const VT r_ = max0(rho_k), qt = max0(qt_k), ql = max0(ql_k);
+                const VT qr = max0(qr_k), nl = max0(nl_k), nr = max0(nr_k);
+                const typename MV::Mask poisoned = nan_mask(rho_k, qt_k, ql_k, nl_k, qr_k, nr_k, T_k);
+                const SbRates<VT> p = sb2006_point<VT, LIMITED, VEL, false, INTPOW>(front_consts<FT, (L == 2 && CMX_F32_PACKED_PHASE_CONSTS)>(c), r_, T_k, qt, ql, qr, r_ * nl, r_ * nr, nl, nr);
+                SedFlux<VT> Fk = sed_fluxes<VT, CLOUD>(cv, r_, ql, nl, qr, nr, p.vt_n, p.vt_m);
+                VT gk;                                                             // 1/(ρ_k Δz_k)
+                if constexpr (L == 2) {
+                    const FT dz0 = io.inv_dz[lv];
+                    if (++lv == io.n_lev) lv = 0;
+                    const FT dz1 = io.inv_dz[lv];
+                    if (++lv == io.n_lev) lv = 0;
+                    gk = VT{dz0, dz1} * p.inv_rho;
+                } else {
+                    gk = io.inv_dz[lv] * p.inv_rho;
+                    if (++lv == io.n_lev) lv = 0;
+                }
+                // sums of warm_rain_tendencies_2m — BMT:738-779 (as in sb2006_tendencies_kernel), minus the outflow through the lower face
+                VT Ak[4];
+                Ak[0] = (p.cond + p.au_dq_lcl) + p.ac_dq_lcl;
+                Ak[1] = MV::fma(p.lsc_plus_au + p.ac_dN_lcl, p.inv_rho, p.na_lcl);
+                Ak[2] = MV::fma(-Fk.q_rai, gk, (p.evq + p.au_dq_rai) + p.ac_dq_rai);
+                Ak[3] = MV::fma(-Fk.n_rai, gk, MV::fma(((p.evN + p.au_dN_rai) + p.rsc) + p.rbr, p.inv_rho, p.na_rai));
+                if constexpr (CLOUD) {
+                    Ak[0] = MV::fma(-Fk.q_lcl, gk, Ak[0]);
+                    Ak[1] = MV::fma(-Fk.n_lcl, gk, Ak[1]);
+                }
+                // NaN rule (one rule for every path — ADVICE r02): a NaN in ANY input poisons the point's four tendencies; the FLUXES depend on
+                // (ρ, q_lcl, n_lcl, q_rai, n_rai) only — exactly the operands of sed_fluxes_of_point, which evaluates the point after the tile —
+                // so a NaN in T or q_tot does not reach the cell below, wherever the tile boundary falls
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Ak[q] = poisoned ? MV::nan() : Ak[q];
+                const typename MV::Mask fpoison = nan_mask(rho_k, ql_k, nl_k, qr_k, nr_k);
+                Fk.q_rai = fpoison ? MV::nan() : Fk.q_rai; Fk.n_rai = fpoison ? MV::nan() : Fk.n_rai;
+                Fk.q_lcl = fpoison ? MV::nan() : Fk.q_lcl; Fk.n_lcl = fpoison ? MV::nan() : Fk.n_lcl;
+                if constexpr (L == 2) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { A[k][q] = Ak[q].x; A[k + 1][q] = Ak[q].y; }
+                    g[k] = gk.x; g[k + 1] = gk.y;
+                    F[k] = SedFlux<FT>{Fk.q_rai.x, Fk.n_rai.x, Fk.q_lcl.x, Fk.n_lcl.x};
+                    F[k + 1] = SedFlux<FT>{Fk.q_rai.y, Fk.n_rai.y, Fk.q_lcl.y, Fk.n_lcl.y};
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) A[k][q] = Ak[q];
+                    g[k] = gk;
+                    F[k] = Fk;
+                }
+            }
         }
         halo[threadIdx.x][0] = F[0].q_rai;
         halo[threadIdx.x][1] = F[0].n_rai;

@@ -783,6 +783,7 @@ void FN(cmxo_bulk_2m_cloud_to_rain)(const TY(cmx_bulk_2m_schemes) * p, uint32_t 
 #include "cmx_oracle_column_impl.h"
 #include "cmx_oracle_extra_impl.h"
 #include "cmx_oracle_dist_impl.h"
+#include "cmx_oracle_diag_impl.h"
 
 #undef CAT_
 #undef CAT

@@ -757,3 +757,21 @@ def sb2006_size_distribution(fam, pdf_c, pdf_r, q, rho, N, D=None, *, cloud=Fals
     fn(C.addressof(pdf_c) if pdf_c is not None else None, C.addressof(pdf_r) if pdf_r is not None else None, int(cloud), int(limited), p, C.addressof(th), n,
        qc[1], rc[1], Nc[1], Dc[1], ptr(n_D), ptr(D_min), ptr(D_max))
     return dict(n_D=n_D, D_min=D_min, D_max=D_max)
+
+
+# ---- cloud diagnostics (oracle/cmx_oracle_diag_impl.h) -----------------------------------------------------------------------------------
+def cloud_diagnostics(fam, rho, q_lcl, q_rai=None, N_lcl=None, N_rai=None, *, rain=None, pdf_c=None, pdf_r=None, rho_w=1000.0, limited=True,
+                      float32_gates=False, want=("Z_1m", "Z_2m", "reff_2m", "reff_lh97")):
+    """Oracle twin of cmx_cloud_diagnostics_*: dict of the requested columns — CMD.radar_reflectivity_1M / _2M, effective_radius_2M,
+    effective_radius_Liu_Hallet_97 (src/CloudDiagnostics.jl)."""
+    r, rp = _col(fam, rho)
+    cols = {k: (_col(fam, v) if v is not None else (None, None)) for k, v in (("q_lcl", q_lcl), ("q_rai", q_rai), ("N_lcl", N_lcl), ("N_rai", N_rai))}
+    out = {k: (np.empty(r.size, dtype=NP[fam.sfx]) if k in want else None) for k in ("Z_1m", "Z_2m", "reff_2m", "reff_lh97")}
+    th = thresholds(fam, float32_gates)
+    fn = getattr(lib(), f"cmxo_cloud_diagnostics_{fam.sfx}")
+    fn.restype = None
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None  # noqa: E731
+    fn(C.byref(rain) if rain is not None else None, C.byref(pdf_c) if pdf_c is not None else None, C.byref(pdf_r) if pdf_r is not None else None,
+       fam.ft(rho_w), C.c_int(int(limited)), C.byref(th), C.c_int64(r.size), rp, cols["q_lcl"][1], cols["q_rai"][1], cols["N_lcl"][1], cols["N_rai"][1],
+       ptr(out["Z_1m"]), ptr(out["Z_2m"]), ptr(out["reff_2m"]), ptr(out["reff_lh97"]))
+    return {k: v for k, v in out.items() if v is not None}

@@ -5,6 +5,7 @@ tools/valu_probe.hip (round 3, units: cycles of a 2.4 GHz clock per wave64 instr
     full-rate (v_mul/v_add/v_sub/v_mov v,v / v_fma with <= 2 distinct VGPR sources / literal forms) ~2.6
     v_fmac_f32 3.7;  v_fma_f32 with 3 distinct VGPRs 4.2;  any SGPR source operand 4.4;  v_max/v_min/v_med3/v_cmp/v_cndmask/v_ldexp 4.2-4.6
     transcendental (v_exp/v_log/v_rcp/v_rsq/v_sqrt f32) 8.3;  f64: add/mul/fma/max 4.3-5.2, rcp/rsq/sqrt 16.3
+    packed f32 (two results; round 5 probe): v_pk_mul/add/fma with an SGPR operand 4.7, v_pk_add 4.4, v_pk_mul v,v 5.1, v_pk_fma of three registers 5.5
 
     tools/isa_cost.py file.s <kernel-name substring>... [--per K]
 """
@@ -26,6 +27,14 @@ def cost(op, args):
         if has_s:
             return ("f64+sgpr", 5.3)
         return ("f64", 4.7)
+    if op.startswith("v_pk_"):      # round 5 probe (profiles/r05_probe_valu.txt): two results per instruction
+        if has_s:
+            return ("pk+sgpr", 4.7)
+        if op.startswith("v_pk_fma") and len(vs) >= 3:
+            return ("pk_fma3", 5.5)
+        if op.startswith("v_pk_mul"):
+            return ("pk_mul", 5.1)
+        return ("pk", 4.4)
     if op.startswith("v_cmp"):
         return ("cmp", 4.5)
     if op.startswith("v_cndmask"):

@@ -64,6 +64,17 @@ template <int MODE> __global__ __launch_bounds__(256) void probe(float *out, flo
             if constexpr (MODE == 50) asm volatile("v_mul_f32 %0, %0, %1\n\ts_mul_i32 s22, s22, s23" : "+v"(x[k]) : "v"(a) : "s22");
             if constexpr (MODE == 51) asm volatile("v_rsq_f32 %0, %0" : "+v"(x[k]));
             if constexpr (MODE == 52) asm volatile("v_fma_f32 %0, %0, %0, %1" : "+v"(x[k]) : "v"(b));
+            // round 5: packed Float32 with a scalar operand, legacy multiply, 64-bit move
+            if constexpr (MODE == 60) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(v[k]) : "s"(f32x2{a, a}));
+            if constexpr (MODE == 61) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(v[k]) : "s"(f32x2{a, b}));
+            if constexpr (MODE == 62) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(v[k]) : "s"(f32x2{a, a}), "v"(f32x2{b, b}));
+            if constexpr (MODE == 63) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(v[k]) : "v"(f32x2{b, b}));
+            if constexpr (MODE == 64) asm volatile("v_pk_fma_f32 %0, %0, %0, %1" : "+v"(v[k]) : "v"(f32x2{b, b}));
+            if constexpr (MODE == 65) asm volatile("v_mul_legacy_f32 %0, %0, %1" : "+v"(x[k]) : "v"(a));
+            if constexpr (MODE == 66) asm volatile("v_mov_b64 %0, %1" : "+v"(d[k]) : "v"((double)b));
+            if constexpr (MODE == 67) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(v[k]) : "s"(f32x2{b, b}));
+            if constexpr (MODE == 68) asm volatile("v_fma_f64 %0, %0, %1, 1.0" : "+v"(d[k]) : "s"((double)a));
+            if constexpr (MODE == 69) asm volatile("v_pk_fma_f32 %0, %1, %0, %2" : "+v"(v[k]) : "s"(f32x2{a, a}), "s"(f32x2{a, a}));   // same SGPR pair twice
             if constexpr (MODE == 53) { float t = v[k].x; asm volatile("v_mul_f32 %0, %0, %2\n\tv_mul_f32 %0, %0, %2\n\tv_mul_f32 %0, %0, %2\n\tv_exp_f32 %1, %1" : "+v"(x[k]), "+v"(t) : "v"(a)); v[k].x = t; }
         }
     }
@@ -129,6 +140,9 @@ int main() {
     run<38>("v_cmp e32", 1, out); run<39>("v_cmp e64", 1, out); run<40>("v_med3_f32", 1, out); run<41>("v_max_f32", 1, out);
     run<42>("v_mov_b32 v,v", 1, out); run<43>("v_max_i32", 1, out); run<49>("v_ldexp_f32", 1, out); run<51>("v_rsq_f32", 1, out);
     run<47>("v_mul_f64 s,v", 1, out); run<48>("v_fma_f64 s,v,v", 1, out); run<50>("v_mul+s_mul", 1, out);
+    run<60>("v_pk_mul_f32 v,s", 1, out); run<61>("v_pk_mul op_sel s", 1, out); run<62>("v_pk_fma_f32 v,s,v", 1, out); run<63>("v_pk_add_f32", 1, out);
+    run<64>("v_pk_fma x,x,b", 1, out); run<65>("v_mul_legacy_f32", 1, out); run<66>("v_mov_b64", 1, out); run<67>("v_pk_add_f32 v,s", 1, out);
+    run<68>("v_fma_f64 s,..1.0", 1, out); run<69>("v_pk_fma s,v,s", 1, out);
     run<53>("3 v_mul + v_exp", 4, out);   // does a transcendental overlap with ordinary VALU issue?
     for (int w : {1, 2, 3, 4, 8}) { run_chain<1, true>(w, out); run_chain<2, true>(w, out); run_chain<4, true>(w, out); }
     for (int w : {1, 2, 4}) { run_chain<1, false>(w, out); run_chain<2, false>(w, out); }
