@@ -37,6 +37,7 @@ from .p3 import (P3Melt, P3Shape, P3ShapeVelocities, P3Velocities, p3_shape_and_
                  p3_shape, p3_terminal_velocities)
 
 from .utilities import GammaInc, gamma_inc, gamma_inc_inv  # noqa: F401
+from . import cloud_diagnostics  # noqa: F401
 from .distribution_tools import Distribution, SizeDistribution, exponential_distribution, generalized_gamma, size_distribution  # noqa: F401
 
 __version__ = "0.1.0"

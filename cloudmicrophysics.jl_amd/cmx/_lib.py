@@ -182,6 +182,9 @@ def _declare(lib):
         f = getattr(lib, f"cmx_sb2006_size_distribution_{s}")
         f.restype = i32
         f.argtypes = [C.POINTER(fam.cloud_pdf_sb2006), C.POINTER(fam.rain_pdf_sb2006), u32, fam.ft, i64] + [vp] * 7 + [vp]
+        f = getattr(lib, f"cmx_cloud_diagnostics_{s}")
+        f.restype = i32
+        f.argtypes = [C.POINTER(fam.rain), C.POINTER(fam.cloud_pdf_sb2006), C.POINTER(fam.rain_pdf_sb2006), fam.ft, u32, i64] + [vp] * 9 + [vp]
         f = getattr(lib, f"cmx_column_sums_{s}")
         f.restype = i32
         f.argtypes = [i32, C.POINTER(vp), i64, vp, vp, vp]

@@ -69,9 +69,11 @@ extern "C" {
  *   0.4  round 4: no struct layout changed.  New entries cmx_gamma_inc, cmx_gamma_inc_inv (UT.gamma_inc / gamma_inc_inv over columns),
  *        cmx_generalized_gamma, cmx_exponential_distribution, cmx_sb2006_size_distribution (DistributionTools and the SB2006 PSD accessors); cmx_column_sums_* takes a caller-owned workspace and is deterministic (one launch
  *        for all columns + a one-workgroup-per-column finish, no floating-point atomics).
+ *   0.5  round 5: no struct layout changed.  New entry cmx_cloud_diagnostics (CloudDiagnostics over columns); cmx_sb2006_size_distribution refuses the
+ *        limited variant of a struct without limiters (CMX_ERR_BAD_ARG instead of silently clamping to 0).
  *        julia/CMXExt.jl (the reference-side binding) checks this number. */
 #define CMX_VERSION_MAJOR 0
-#define CMX_VERSION_MINOR 4
+#define CMX_VERSION_MINOR 5
 
 typedef enum cmx_status {
     CMX_OK = 0,
@@ -1107,6 +1109,26 @@ int32_t cmx_mp0m_tendencies_f32(const cmx_parameters_0m_f32 *p, int64_t n, const
                                 const float *q_vap_sat, float *dq_tot_dt, float *ddq_dq_tot, void *stream);
 int32_t cmx_mp0m_tendencies_f64(const cmx_parameters_0m_f64 *p, int64_t n, const double *q_lcl, const double *q_icl,
                                 const double *q_vap_sat, double *dq_tot_dt, double *ddq_dq_tot, void *stream);
+
+/* ---------------------------------------------------------------------------
+ * (10) Cloud diagnostics over columns — src/CloudDiagnostics.jl (round 5; what a host model's radiation / radar diagnostics broadcast over the SAME state
+ * columns the tendency entries read):
+ *   Z_1m      = CMD.radar_reflectivity_1M(rain, q_rai, ρ)                                    :31-46    [dBZ, clipped at −150]
+ *   Z_2m      = CMD.radar_reflectivity_2M(SB2006, q_lcl, q_rai, N_lcl, N_rai, ρ)             :64-84    [dBZ, clipped at −150]
+ *   reff_2m   = CMD.effective_radius_2M(SB2006, q_lcl, q_rai, N_lcl, N_rai, ρ)               :100-125  [m]
+ *   reff_lh97 = CMD.effective_radius_Liu_Hallet_97(wtr, ρ, q_lcl, N_lcl, q_rai, N_rai)       :143-163  [m]
+ * (CMD.effective_radius_const is the r_eff field of cmx_cloud_liquid / cmx_cloud_ice.)  N per m³ as in the reference.  Any output may be NULL (not all
+ * four); the parameter structs and columns only a NULL output needs may be NULL: `rain` and q_rai for Z_1m; pdf_c, pdf_r (flags: CMX_SB2006_LIMITED as
+ * for the rate entries, same limiter-pair rule) and all four of q_lcl, q_rai, N_lcl, N_rai for Z_2m / reff_2m; rho_w (WaterProperties.ρw) and q_lcl for
+ * reff_lh97 — whose three-argument method (N_lcl = 100, no rain: :165-180) is selected by passing N_lcl, q_rai and N_rai all NULL.  The reference's
+ * gates are kept (absent species, notvalid(B) = B is 0 or not finite in the float type, M² ≤ ϵ); a NaN input gives NaN.
+ * ------------------------------------------------------------------------- */
+int32_t cmx_cloud_diagnostics_f32(const cmx_rain_f32 *rain, const cmx_cloud_pdf_sb2006_f32 *pdf_c, const cmx_rain_pdf_sb2006_f32 *pdf_r, float rho_w,
+                                  uint32_t flags, int64_t n, const float *rho, const float *q_lcl, const float *q_rai, const float *N_lcl,
+                                  const float *N_rai, float *Z_1m, float *Z_2m, float *reff_2m, float *reff_lh97, void *stream);
+int32_t cmx_cloud_diagnostics_f64(const cmx_rain_f64 *rain, const cmx_cloud_pdf_sb2006_f64 *pdf_c, const cmx_rain_pdf_sb2006_f64 *pdf_r, double rho_w,
+                                  uint32_t flags, int64_t n, const double *rho, const double *q_lcl, const double *q_rai, const double *N_lcl,
+                                  const double *N_rai, double *Z_1m, double *Z_2m, double *reff_2m, double *reff_lh97, void *stream);
 
 /* ---------------------------------------------------------------------------
  * (3) Optional diagnostic sums over one rank's shard: Σx of `ncols` (≤ CMX_COLUMN_SUMS_MAX_COLS) device columns of length

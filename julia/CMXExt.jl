@@ -42,7 +42,7 @@ const TDP = TD.Parameters
 # library handle, version check, status
 # ----------------------------------------------------------------------------------------------------------------
 const CMX_VERSION_MAJOR = 0
-const CMX_VERSION_MINOR = 4        # == include/cmx.h; the minor number moves with every layout change / new entry
+const CMX_VERSION_MINOR = 5        # == include/cmx.h; the minor number moves with every layout change / new entry
 
 const _handle = Ref{Ptr{Cvoid}}(C_NULL)
 libpath() = get(ENV, "CMX_LIB", "libcmx.so")
@@ -1163,6 +1163,28 @@ function size_distribution!(n_D, D_min, D_max, pdf::CMP.RainParticlePDF_SB2006, 
         (Ptr{Cvoid}, Ptr{Cvoid}, UInt32, FT, Int64, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{Cvoid}),
         C_NULL, Ref(pack(pdf)), flags, FT(p), length(q), _dp(FT, q), _dp(FT, ρₐ), _dp(FT, N), _dp(FT, D), _dp(FT, n_D), _dp(FT, D_min), _dp(FT, D_max), stream)
     _check(st, "cmx_sb2006_size_distribution")
+    return nothing
+end
+
+"""
+    cloud_diagnostics!(Z_1m, Z_2m, reff_2m, reff_lh97, rain, sb, wtr, ρ, q_lcl, q_rai, N_lcl, N_rai; stream)
+
+`CMD.radar_reflectivity_1M.(Ref(rain), q_rai, ρ)`, `CMD.radar_reflectivity_2M.(Ref(sb), q_lcl, q_rai, N_lcl, N_rai, ρ)`,
+`CMD.effective_radius_2M.(…)` and `CMD.effective_radius_Liu_Hallet_97.(Ref(wtr), ρ, q_lcl, N_lcl, q_rai, N_rai)` (src/CloudDiagnostics.jl:31-163) in one pass
+over the state columns.  An output may be `nothing`, and so may the parameter struct only it needs (`rain::CMP.Rain`, `sb::CMP.SB2006`,
+`wtr::Union{CMP.WaterProperties, CMP.CloudLiquid}`); the three-argument Liu–Hallett method when `N_lcl`, `q_rai`, `N_rai` are all `nothing`.
+"""
+function cloud_diagnostics!(Z_1m, Z_2m, reff_2m, reff_lh97, rain, sb, wtr, ρ::AbstractArray{FT}, q_lcl, q_rai, N_lcl, N_rai; stream = C_NULL) where {FT}
+    flags = (sb !== nothing && is_limited(sb)) ? CMX_SB2006_LIMITED : UInt32(0)
+    p_rain = rain === nothing ? C_NULL : Ref(rain)          # CMP.Rain is layout-compatible (DIRECT_LAYOUT)
+    p_c = sb === nothing ? C_NULL : Ref(sb.pdf_c)
+    p_r = sb === nothing ? C_NULL : Ref(pack(sb.pdf_r))
+    ρw = wtr === nothing ? FT(0) : FT(wtr.ρw)
+    st = ccall(_fn("cmx_cloud_diagnostics", FT), Int32,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, FT, UInt32, Int64, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{FT}, Ptr{Cvoid}),
+        p_rain, p_c, p_r, ρw, flags, length(ρ), _dp(FT, ρ), _dp(FT, q_lcl), _dp(FT, q_rai), _dp(FT, N_lcl), _dp(FT, N_rai), _dp(FT, Z_1m), _dp(FT, Z_2m),
+        _dp(FT, reff_2m), _dp(FT, reff_lh97), stream)
+    _check(st, "cmx_cloud_diagnostics")
     return nothing
 end
 

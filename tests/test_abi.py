@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()
     for s in declared_symbols():
         assert hasattr(lib, s), f"libcmx.so does not export {s}"
-    assert lib.cmx_version() == (0 << 16) | 4          # include/cmx.h: the minor number moves with every layout change / new entry
+    assert lib.cmx_version() == (0 << 16) | 5          # include/cmx.h: the minor number moves with every layout change / new entry
     assert lib.cmx_last_hip_error() == b""
 
 

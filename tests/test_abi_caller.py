@@ -162,4 +162,4 @@ def test_fused_entries_match_oracle_and_ctypes_path(result, oracle):
 @pytest.mark.gpu
 def test_status_codes_seen_by_a_c_caller(result):
     assert result["status"] == {"null_params": _abi.CMX_ERR_BAD_ARG, "negative_n": _abi.CMX_ERR_BAD_ARG, "empty": 0}
-    assert result["cmx_version"] == (0 << 16) | 4
+    assert result["cmx_version"] == (0 << 16) | 5

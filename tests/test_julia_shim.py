@@ -54,7 +54,7 @@ MUTATIONS_HEADER_ONLY = [
     # an unclosed block
     ("    _check(st, \"cmx_deposition_J\")\n    return J\nend", "    _check(st, \"cmx_deposition_J\")\n    return J\n", "lint"),
     # another ABI version
-    ("const CMX_VERSION_MINOR = 4", "const CMX_VERSION_MINOR = 3", "CMX_VERSION_MINOR"),
+    ("const CMX_VERSION_MINOR = 5", "const CMX_VERSION_MINOR = 3", "CMX_VERSION_MINOR"),
 ]
 
 MUTATIONS_REFERENCE = [
