@@ -103,6 +103,24 @@ void FN(cmxo_arg2000_activation)(const TY(cmx_aerosol_activation_params) * ap, c
     }
 }
 
+/* The argument u_i of the error function in N_activated_per_mode (:254) per mode and state — for the parity tests: the reference forms the activated
+ * number as N ½ (1 − erf u), which cancels to an ABSOLUTE accuracy of eps(FT)·N/2 in the tail (u ≳ 4 in Float32, ≳ 6 in Float64); the tests compare the
+ * device also with N ½ erfc(u) of THIS u, the same quantity without the cancellation. */
+void FN(cmxo_arg2000_erf_argument)(const TY(cmx_aerosol_activation_params) * ap, const TY(cmx_aerosol_distribution) * ad,
+                                  const TY(cmx_air_properties) * aip, const TY(cmx_thermo) * tps, const TY(cmxo_thresholds) * th, int64_t n,
+                                  const FT *T, const FT *p, const FT *w, const FT *q_tot, const FT *q_liq, const FT *q_ice, const FT *N_liq,
+                                  const FT *N_ice, FT *const *u_out) {
+    for (int64_t i = 0; i < n; ++i) {
+        FT cond = 1;
+        FT smax = FN(o_max_supersaturation)(ap, ad, aip, tps, th, T[i], p[i], w[i], q_tot[i], q_liq ? q_liq[i] : (FT)0, q_ice ? q_ice[i] : (FT)0,
+                                            N_liq ? N_liq[i] : (FT)0, N_ice ? N_ice[i] : (FT)0, &cond);
+        for (int k = 0; k < ad->n_modes; ++k) {
+            FT sm = FN(o_critical_supersaturation)(ap, &ad->modes[k], T[i]);
+            u_out[k][i] = 2 * M_LOG(sm / smax) / 3 / M_SQRT((FT)2) / M_LOG(ad->modes[k].stdev);
+        }
+    }
+}
+
 /* oracle twin of cmx_arg2000_activation_columns_*: the aerosol modes vary in space — (r_dry, stdev, N, hygroscopicity,
  * molar_mass_mix) are columns per mode, as the reference's own GPU test passes them (test/gpu_tests.jl:45-79) */
 void FN(cmxo_arg2000_activation_columns)(const TY(cmx_aerosol_activation_params) * ap, const TY(cmx_air_properties) * aip,

@@ -318,6 +318,22 @@ def arg2000_activation(fam, ap, ad, aip, tps, T, p, w, q_tot, q_liq=None, q_ice=
     return dict(N_act=n_act, M_act=m_act, S_max=s_max, S_cond=s_cond)
 
 
+def arg2000_erf_argument(fam, ap, ad, aip, tps, T, p, w, q_tot, q_liq=None, q_ice=None, N_liq=None, N_ice=None, *, float32_gates=None):
+    """u_i of N_activated_per_mode (src/AerosolActivation.jl:254) per mode: list of arrays."""
+    if float32_gates is None:
+        float32_gates = fam.sfx == "f32"
+    th = thresholds(fam, float32_gates)
+    req = [_col(fam, a) for a in (T, p, w, q_tot)]
+    opt = [(_col(fam, a) if a is not None else (None, None)) for a in (q_liq, q_ice, N_liq, N_ice)]
+    n, nm = req[0][0].size, ad.n_modes
+    u = [np.empty(n, dtype=NP[fam.sfx]) for _ in range(nm)]
+    fn = getattr(lib(), f"cmxo_arg2000_erf_argument_{fam.sfx}")
+    fn.restype = None
+    fn(C.byref(ap), C.byref(ad), C.byref(aip), C.byref(tps), C.byref(th), C.c_int64(n), *[pp for _, pp in req], *[pp for _, pp in opt],
+       (C.c_void_p * nm)(*[c.ctypes.data for c in u]))
+    return u
+
+
 def arg2000_activation_columns(fam, ap, aip, tps, T, p, w, q_tot, modes, *, want_M=False, float32_gates=None, nthreads=1):
     """Oracle twin of cmx_arg2000_activation_columns_*; `modes` = sequence of (r_dry, stdev, N, hygroscopicity, molar_mass_mix)
     numpy columns.  Returns dict(N_act=[…], M_act=[…] or None, S_max)."""
