@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --points per GPU; strong: --points in total, sharded over the ranks (cmx.sharding.shard_bounds)")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--workload", choices=["sb2006", "sb2006_chen", "sb2006_column", "icenuc", "mp0m", "mp1m", "mp1m_lin", "mp1m_column", "mp1m_column_lin", "arg2000", "arg2000_columns", "p3", "p3_split", "p3_selfcol", "mp2m_p3", "sb2006_aos", "sb2006_fields"], default="sb2006")
+    ap.add_argument("--workload", choices=["sb2006", "sb2006_chen", "sb2006_column", "icenuc", "mp0m", "mp1m", "mp1m_lin", "mp1m_column", "mp1m_column_lin", "arg2000", "arg2000_columns", "p3", "p3_split", "p3_selfcol", "mp2m_p3", "sb2006_aos", "sb2006_fields", "cloud_diag"], default="sb2006")
     ap.add_argument("--rotate", type=int, default=4,
                     help="number of DISJOINT input/output buffer sets visited round-robin in the rotating timed region, so that no step re-touches the "
                          "pages of the previous one (what a model time loop sees: other arrays are touched between two microphysics calls); 1 = off")
@@ -308,6 +308,39 @@ def setup_icenuc(args, dev, dtype, rank):
     return list(state), step, desc, cpu_run
 
 
+def setup_cloud_diag(args, dev, dtype, rank):
+    """CloudDiagnostics (src/CloudDiagnostics.jl) over the SB2006 synthetic state: 1M and 2M radar reflectivity, 2M and Liu–Hallett effective radius in ONE pass."""
+    import torch
+
+    from cmx import _abi
+    from cmx import cloud_diagnostics as CD
+    from cmx import parameters as P
+    from cmx import synthetic
+    st = synthetic.sb2006_state(args.points, dtype=dtype, device=dev, seed=1234 + rank)
+    rho, q_lcl, q_rai = st.rho, st.q_lcl, st.q_rai
+    N_lcl, N_rai = (st.rho * st.n_lcl).contiguous(), (st.rho * st.n_rai).contiguous()      # per m³, as the reference's diagnostics take them
+    sb, rain = P.SB2006(args.dtype), P.Microphysics1MParams(args.dtype).c.rain
+    out = CD.Diagnostics(*[torch.empty_like(rho) for _ in range(4)])
+
+    def step():
+        CD.cloud_diagnostics(rain, sb, 1000.0, rho, q_lcl, q_rai, N_lcl, N_rai, out=out)
+
+    def cpu_run(ob, cols, threads):
+        fam = _abi.family(args.dtype)
+        return lambda: ob.cloud_diagnostics(fam, cols[0], cols[1], cols[2], cols[3], cols[4], rain=rain, pdf_c=sb.pdf_c, pdf_r=sb.pdf_r, rho_w=1000.0, limited=True,
+                                            float32_gates=(args.dtype == "f32"))   # scalar port: 1 thread
+
+    desc = {
+        "metric": "grid-points/sec cloud-diagnostics sweep (radar reflectivity 1M / 2M, effective radius 2M / Liu-Hallett)",
+        "bytes_per_point": {"f32": 36, "f64": 72}[args.dtype],      # 5 in + 4 out
+        "kernel": "cloud_diagnostics_kernel",
+        "workload": "CloudDiagnostics radar_reflectivity_1M + radar_reflectivity_2M + effective_radius_2M + effective_radius_Liu_Hallet_97 over (rho, q_lcl, q_rai, N_lcl, N_rai), limited rain PSD",
+        "columns_in": 5, "columns_out": 4, "diag_cols": [out.reff_2m],
+        "cpu_threads": 1,
+    }
+    return [rho, q_lcl, q_rai, N_lcl, N_rai], step, desc, cpu_run
+
+
 def setup_mp0m(args, dev, dtype, rank):
     import torch
 
@@ -392,7 +425,7 @@ def setup_mp1m_lin(args, dev, dtype, rank):
     desc = {
         "metric": "grid-points/sec 1-moment LinearizedAverage tendency sweep (dt = 30 s, nsub = 2)",
         "bytes_per_point": {"f32": 44, "f64": 88}[args.dtype],      # 7 in + 4 out
-        "kernel": "mp1m_linearized_kernel", "bound": "valu",
+        "kernel": "mp1m_linearized_pair_kernel (Float32: two points per lane in packed arithmetic)" if args.dtype == "f32" else "mp1m_linearized_kernel", "bound": "valu",
         "workload": "Microphysics1M LinearizedAverage bulk tendencies: 2 linearized implicit substeps (13 processes, 4x4 sparse solve, "
                     "T update) per point",
         "columns_in": 7, "columns_out": 4, "diag_cols": list(out),
@@ -864,7 +897,7 @@ def main():
         args.points = hi - lo
     # weak scaling: fixed work per GPU; rank r owns shard r of the global [0, world·n) index space.
     # Either way: disjoint seeds, no exchange
-    setup = {"sb2006": setup_sb2006, "sb2006_chen": setup_sb2006, "sb2006_column": setup_sb2006_column, "icenuc": setup_icenuc, "mp0m": setup_mp0m, "mp1m": setup_mp1m, "mp1m_lin": setup_mp1m_lin, "mp1m_column": setup_mp1m_column, "mp1m_column_lin": setup_mp1m_column, "arg2000": setup_arg2000, "arg2000_columns": setup_arg2000_columns,
+    setup = {"sb2006": setup_sb2006, "sb2006_chen": setup_sb2006, "sb2006_column": setup_sb2006_column, "icenuc": setup_icenuc, "mp0m": setup_mp0m, "cloud_diag": setup_cloud_diag, "mp1m": setup_mp1m, "mp1m_lin": setup_mp1m_lin, "mp1m_column": setup_mp1m_column, "mp1m_column_lin": setup_mp1m_column, "arg2000": setup_arg2000, "arg2000_columns": setup_arg2000_columns,
              "p3": setup_p3, "p3_split": setup_p3, "p3_selfcol": setup_p3_selfcol, "mp2m_p3": setup_mp2m_p3, "sb2006_aos": setup_sb2006_layout, "sb2006_fields": setup_sb2006_layout}[args.workload]
     if dry:
         state, kernel_step, cpu_run = [], (lambda: None), None

@@ -12,6 +12,7 @@ N per m³, as in the reference.  The rain PSD variant of the two-moment function
 from __future__ import annotations
 
 import ctypes as C
+from collections import namedtuple
 
 import torch
 
@@ -19,9 +20,13 @@ from . import _abi, _lib
 from .bulk_tendencies import _check_cols, _fam_of, _ptr
 
 
-def _call(ref, *, rain=None, sb=None, rho_w=0.0, rho, q_lcl=None, q_rai=None, N_lcl=None, N_rai=None, want, stream=None):
+def _call(ref, *, rain=None, sb=None, rho_w=0.0, rho, q_lcl=None, q_rai=None, N_lcl=None, N_rai=None, want, stream=None, out=None):
     fam = _fam_of(ref)
     outs = {k: (torch.empty_like(ref) if k in want else None) for k in ("Z_1m", "Z_2m", "reff_2m", "reff_lh97")}
+    if out is not None:      # caller-provided output columns (no allocation in a time loop)
+        for k in want:
+            _check_cols([ref, getattr(out, k)], ["rho", k])
+            outs[k] = getattr(out, k)
     flags = 0
     pdf_c = pdf_r = None
     if sb is not None:
@@ -42,6 +47,18 @@ def _call(ref, *, rain=None, sb=None, rho_w=0.0, rho, q_lcl=None, q_rai=None, N_
                 _ptr(outs["reff_2m"]), _ptr(outs["reff_lh97"]), C.c_void_p(s.cuda_stream))
     _lib.check(fn.__name__, st)
     return outs
+
+
+Diagnostics = namedtuple("Diagnostics", ["Z_1m", "Z_2m", "reff_2m", "reff_lh97"])
+
+
+def cloud_diagnostics(rain, sb, wtr, rho, q_lcl, q_rai, N_lcl, N_rai, *, want=("Z_1m", "Z_2m", "reff_2m", "reff_lh97"), out=None, stream=None) -> Diagnostics:
+    """All (or some) of the four diagnostics in ONE pass over the five state columns — what a host model's diagnostics step needs per cell.
+    `rain` (Z_1m), `sb` (Z_2m, reff_2m) and `wtr` (reff_lh97) may be None when their outputs are not wanted; `out` = a Diagnostics of output columns."""
+    ref = _check_cols([rho, q_lcl, q_rai, N_lcl, N_rai], ["rho", "q_lcl", "q_rai", "N_lcl", "N_rai"])
+    rho_w = float(getattr(wtr, "rho_w", wtr)) if wtr is not None else 0.0
+    o = _call(ref, rain=rain, sb=sb, rho_w=rho_w, rho=rho, q_lcl=q_lcl, q_rai=q_rai, N_lcl=N_lcl, N_rai=N_rai, want=tuple(want), stream=stream, out=out)
+    return Diagnostics(o["Z_1m"], o["Z_2m"], o["reff_2m"], o["reff_lh97"])
 
 
 def radar_reflectivity_1M(rain, q_rai: torch.Tensor, rho: torch.Tensor, *, stream=None) -> torch.Tensor:

@@ -131,6 +131,12 @@ def test_device_against_the_oracle_on_random_states(dev, oracle, ft, limited):
     Z2, r2 = CD.radar_reflectivity_and_effective_radius_2M(sb, to(q_lcl), to(q_rai), to(N_lcl), to(N_rai), to(rho))
     got = {"Z_1m": back(CD.radar_reflectivity_1M(rain, to(q_rai), to(rho))), "Z_2m": back(Z2), "reff_2m": back(r2),
            "reff_lh97": back(CD.effective_radius_Liu_Hallet_97(1000.0, to(rho), to(q_lcl), to(N_lcl), to(q_rai), to(N_rai)))}
+    # all four in ONE launch into caller-provided columns: the same bits as the per-function calls
+    outc = CD.Diagnostics(*[torch.empty(n, dtype=DT[ft], device=dev) for _ in range(4)])
+    fused = CD.cloud_diagnostics(rain, sb, 1000.0, to(rho), to(q_lcl), to(q_rai), to(N_lcl), to(N_rai), out=outc)
+    assert fused.Z_2m.data_ptr() == outc.Z_2m.data_ptr()
+    for k in ("Z_1m", "Z_2m", "reff_2m", "reff_lh97"):
+        assert np.array_equal(back(getattr(fused, k)), got[k], equal_nan=True), k
     tol = parity.RTOL[ft]
     # reflectivities are 10·log10 of a power law: an ABSOLUTE tolerance in dB — the relative tolerance of the linear quantity, 10 log10(1 + tol) ≈ 4.34 tol, plus the
     # rounding of the (≈ 300 dB) offsets that cancel inside the logarithm's affine form in Float32

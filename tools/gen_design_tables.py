@@ -23,7 +23,7 @@ from pathlib import Path
 REPO = Path(__file__).resolve().parent.parent
 PROF = REPO / "profiles"
 HBM_PEAK = 8000.0
-ORDER = ["sb2006", "sb2006_chen", "sb2006_column", "sb2006_aos", "sb2006_fields", "mp0m", "icenuc", "mp1m", "mp1m_lin", "mp1m_column", "mp1m_column_lin", "arg2000", "arg2000_columns",
+ORDER = ["sb2006", "sb2006_chen", "sb2006_column", "sb2006_aos", "sb2006_fields", "mp0m", "cloud_diag", "icenuc", "mp1m", "mp1m_lin", "mp1m_column", "mp1m_column_lin", "arg2000", "arg2000_columns",
          "p3_split", "p3", "p3_selfcol", "mp2m_p3"]
 
 

@@ -6,7 +6,7 @@
 #   usage: tools/gpu_round.sh <round-tag, e.g. r04> [notests]
 set -u
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 mkdir -p gpurun_out/bench
 FAILED=0
 
@@ -57,6 +57,8 @@ prof sb2006_column f64 100000000 valu
 prof sb2006_fields f32 100000000 valu
 prof sb2006_fields f64 100000000 valu
 prof mp0m f32 100000000
+prof cloud_diag f32 100000000
+prof cloud_diag f64 100000000
 prof icenuc f32 100000000
 prof icenuc f64 100000000
 prof mp1m f32 100000000 valu
@@ -79,7 +81,7 @@ KT_STEPS=10 prof mp2m_p3 f32 1000000 valu
 KT_STEPS=10 prof mp2m_p3 f64 1000000 valu
 prof sb2006_aos f32 100000000
 # the stall / occupancy counters of the Float32 kernels VERDICT r03 item 4 names (three more PMC passes each; tools/sq_pass.sh)
-for wl in sb2006_column sb2006_chen sb2006_fields arg2000 mp1m; do
+for wl in sb2006_column sb2006_chen sb2006_fields arg2000 mp1m mp1m_lin; do
   tools/sq_pass.sh $wl f32 > gpurun_out/profiles/${TAG}_sq_${wl}_f32.txt 2>&1 || { echo "sq_pass $wl FAILED"; FAILED=$((FAILED+1)); }
 done
 mkdir -p profiles
@@ -87,7 +89,7 @@ cp gpurun_out/profiles/${TAG}_pmc_*.json gpurun_out/profiles/${TAG}_kernel_stats
 
 bench default_driver --steps 20 --warmup 5
 bench default
-for wl in sb2006 sb2006_column icenuc mp0m mp1m arg2000 arg2000_columns mp1m_lin mp1m_column sb2006_aos sb2006_fields; do
+for wl in sb2006 sb2006_column icenuc mp0m cloud_diag mp1m arg2000 arg2000_columns mp1m_lin mp1m_column sb2006_aos sb2006_fields; do
   for dt in f32 f64; do
     bench ${wl}_${dt} --workload $wl --dtype $dt --steps 100 --warmup 20
   done
