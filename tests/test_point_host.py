@@ -158,3 +158,103 @@ def test_sedimentation_velocities(host, oracle, ft, general, variant):
         sc = scale[k] if k in ("w_icl", "w_sno") else np.abs(rr)
         tol = parity.RTOL[ft] * 0.1 * np.abs(rr) + parity.CTOL[ft] * sc
         assert np.all(np.abs(got.astype(np.float64) - rr) <= tol + 1e-300), (k, float(np.max(np.abs(got - rr) / (tol + 1e-300))))
+
+
+# ---- round 5: the packed pair instantiations are the one-point arithmetic, bit for bit -----------------------------------------------------------
+CLANG = Path("/opt/rocm/lib/llvm/bin/clang++")
+
+
+@pytest.fixture(scope="module")
+def host_clang():
+    """The same file built by clang++, which has ext_vector_type: the f32x2 value type of csrc/cmx_math.hpp exists in this build."""
+    if not CLANG.exists():
+        pytest.skip("no clang++ in this image (the packed value type needs ext_vector_type)")
+    out = REPO / "tests" / "native" / "_build"
+    out.mkdir(exist_ok=True)
+    so = out / "libpoint_host_clang.so"
+    subprocess.run([str(CLANG), "-std=c++17", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-o", str(so), str(REPO / "tests" / "native" / "point_host.cpp")], check=True)
+    lib = C.CDLL(str(so))
+    assert lib.host_have_packed() == 1
+    return lib
+
+
+@pytest.mark.parametrize("optset", list(OPTION_SETS))
+def test_packed_pairs_are_bit_identical_to_single_points(host_clang, optset):
+    """mp1m_tendencies_point / mp1m_linearized_point / mp1m_sed_fluxes instantiated on the pair type f32x2 (what the Float32 kernels with four points per lane
+    run since round 5) against the one-point instantiation of the SAME build, on random states plus NaN, zero and negative entries: identical bits —
+    the generic value-type code (lane masks, m_or / m_and, nan_mask, the scalar-broadcast overloads of Math<f32x2>) changes no operation and no order."""
+    ft, opts = "f32", OPTION_SETS[optset]
+    n = 40_000
+    st = [c.numpy().copy() for c in synthetic.mp1m_state(n, dtype=torch.float32, seed=77)]
+    rng = np.random.default_rng(5)
+    for c in st[2:]:
+        k = rng.integers(0, n, 200)
+        c[k[:70]] = 0.0; c[k[70:140]] = -1e-9; c[k[140:]] = np.nan
+    st[1][rng.integers(0, n, 50)] = np.float32(T_FREEZE)              # exactly at the warm / cold routing
+    mp, tps = P.Microphysics1MParams(ft, **opts), P.ThermodynamicsParameters(ft)
+    head = (C.byref(mp.c), C.byref(tps), C.c_uint32(mp.flags))
+    def same(a, b):
+        """identical bits; ±0 are taken as equal HERE (x86 maxss / minss return their second operand for (+0, −0), and the compiler is free to commute the
+        operands of fmaxf differently in the two instantiations — the device's v_max_f32 orders −0 < +0 and has no such freedom: the GPU suite compares bits)"""
+        ua, ub = a.view(np.uint32), b.view(np.uint32)
+        return bool(np.all((ua == ub) | ((a == 0) & (b == 0))))
+    rc1, one = _call(host_clang, "host_mp1m_tendencies", ft, head, st, 4)
+    rc2, two = _call(host_clang, "host_mp1m_tendencies_pairs", ft, head, st, 4)
+    assert rc1 == rc2
+    for a, b, name in zip(one, two, NAMES):
+        assert same(a, b), (name, int(np.sum(a.view(np.uint32) != b.view(np.uint32))))
+    lin = (*head, C.c_float(Q_MIN), C.c_float(30.0), C.c_int32(2))
+    _, one = _call(host_clang, "host_mp1m_linearized", ft, lin, st, 4)
+    _, two = _call(host_clang, "host_mp1m_linearized_pairs", ft, lin, st, 4)
+    for a, b, name in zip(one, two, NAMES):
+        assert same(a, b), ("linearized", name)
+    if optset == "default":
+        stokes, cr, ci = P.StokesRegimeVelType(ft), P.Chen2022VelTypeRain(ft), P.Chen2022VelTypeIce(ft)
+        cols = [st[0], st[3], st[4], st[5], st[6]]
+        hd = lambda pairs: (C.byref(mp.c), C.byref(stokes), C.byref(cr), C.byref(ci), C.c_int(pairs))  # noqa: E731
+        rc, one = _call(host_clang, "host_sed_fluxes", ft, hd(0), cols, 4)
+        assert rc == 0
+        _, two = _call(host_clang, "host_sed_fluxes", ft, hd(1), cols, 4)
+        for a, b in zip(one, two):
+            assert same(a, b)
+
+
+SB_NAMES = ["dq_lcl_dt", "dn_lcl_dt", "dq_rai_dt", "dn_rai_dt", "vt_rai_n", "vt_rai_m"]
+
+
+@pytest.mark.parametrize("ft", ["f32", "f64"])
+@pytest.mark.parametrize("limited", [True, False])
+@pytest.mark.parametrize("vel", ["sb2006", "chen2022"])
+def test_sb2006_point_function_on_the_host(host, oracle, ft, limited, vel):
+    """The north-star point function (csrc/cmx_sb2006.hpp sb2006_point + the fused sums of the tendencies kernel) compiled for the host against the oracle:
+    the log2-domain algebra, the host-folded constants (incl. round 5's t*·D_r) and the gates, without a GPU."""
+    n = 60_000
+    st = [c.numpy() for c in synthetic.sb2006_state(n, dtype=getattr(torch, {"f32": "float32", "f64": "float64"}[ft]), seed=321)]
+    wr, tps, velp = P.WarmRainParams2M(ft, limited), P.ThermodynamicsParameters(ft), P.rain_vel_params(ft)
+    flags = (_abi.CMX_SB2006_LIMITED if limited else 0) | (_abi.CMX_VEL_CHEN2022 if vel == "chen2022" else _abi.CMX_VEL_SB2006)
+    rc, got = _call(host, "host_sb2006", ft, (C.byref(wr.c), C.byref(tps), C.byref(velp), C.c_uint32(flags), C.c_int(0)), st, 6)
+    assert rc == 1                                   # the default parameter set takes the integer-exponent instantiation
+    ref = oracle.sb2006_warm_rain_tendencies(_abi.F64, P.WarmRainParams2M("f64", limited).c, P.ThermodynamicsParameters("f64"), P.rain_vel_params("f64"), flags,
+                                             *[np.asarray(c, dtype=np.float64) for c in st], float32_gates=(ft == "f32"), nthreads=8)
+    parity.assert_parity(dict(zip(SB_NAMES, got)), ref, parity.RTOL[ft], names=SB_NAMES, what=f"host-build SB2006 {ft} {'limited' if limited else 'not limited'} {vel}")
+
+
+@pytest.mark.parametrize("limited", [True, False])
+@pytest.mark.parametrize("vel", ["sb2006", "chen2022"])
+def test_sb2006_packed_pairs_are_bit_identical(host_clang, limited, vel):
+    ft, n = "f32", 40_000
+    st = [c.numpy().copy() for c in synthetic.sb2006_state(n, dtype=torch.float32, seed=99)]
+    rng = np.random.default_rng(6)
+    for c in (st[0], *st[2:]):
+        k = rng.integers(0, n, 150)
+        c[k[:50]] = 0.0; c[k[50:100]] = -1e-9; c[k[100:]] = np.nan
+    wr, tps, velp = P.WarmRainParams2M(ft, limited), P.ThermodynamicsParameters(ft), P.rain_vel_params(ft)
+    flags = (_abi.CMX_SB2006_LIMITED if limited else 0) | (_abi.CMX_VEL_CHEN2022 if vel == "chen2022" else _abi.CMX_VEL_SB2006)
+    hd = lambda pairs: (C.byref(wr.c), C.byref(tps), C.byref(velp), C.c_uint32(flags), C.c_int(pairs))  # noqa: E731
+    _, one = _call(host_clang, "host_sb2006", ft, hd(0), st, 6)
+    _, two = _call(host_clang, "host_sb2006", ft, hd(1), st, 6)
+    for a, b, name in zip(one, two, SB_NAMES):
+        ua, ub = a.view(np.uint32), b.view(np.uint32)
+        same = (ua == ub) | ((a == 0) & (b == 0)) | (np.isnan(a) & np.isnan(b))       # ±0: see test_packed_pairs_are_bit_identical_to_single_points
+        assert bool(np.all(same)), (name, int(np.sum(~same)))
+
