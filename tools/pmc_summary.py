@@ -10,7 +10,7 @@ import json
 import sys
 from pathlib import Path
 
-BYTES_PER_POINT = {"sb2006": 13, "sb2006_chen": 13, "arg2000_columns": 29, "sb2006_column": 11, "icenuc": 5, "mp0m": 3, "mp1m": 11, "mp1m_lin": 11, "mp1m_column": 11, "mp1m_column_lin": 11, "arg2000": 9, "p3": 9,
+BYTES_PER_POINT = {"sb2006": 13, "sb2006_chen": 13, "cloud_diag": 9, "arg2000_columns": 29, "sb2006_column": 11, "icenuc": 5, "mp0m": 3, "mp1m": 11, "mp1m_lin": 11, "mp1m_column": 11, "mp1m_column_lin": 11, "arg2000": 9, "p3": 9,
                    "p3_split": 9, "p3_selfcol": 7, "sb2006_aos": 15, "sb2006_fields": 11, "mp2m_p3": 20}   # columns in + out
 
 
