@@ -48,8 +48,9 @@ def test_one_launch_form_adds_no_sgpr_spills(kernels):
 
 def test_streaming_kernels_do_not_spill(kernels):
     """The pointwise kernels the bench lines run: no spilled vector registers in either float type."""
-    for frag in ("sb2006_tendencies_kernel", "mp1m_tendencies_kernel", "mp1m_linearized_kernel", "mp1m_column_kernel", "mp0m_tendencies_kernel", "ice_nucleation_kernel",
-                 "arg_activation_kernel", "p3_shape_kernel", "p3_velocity_kernel", "p3_self_collection_kernel", "mp2m_p3_pointwise_kernel"):
+    for frag in ("sb2006_tendencies_kernel", "mp1m_tendencies_kernel", "mp1m_linearized_kernel", "mp1m_linearized_pair_kernel", "mp1m_column_kernel", "mp0m_tendencies_kernel",
+                 "ice_nucleation_kernel", "arg_activation_kernel", "p3_shape_kernel", "p3_velocity_kernel", "p3_self_collection_kernel", "mp2m_p3_pointwise_kernel",
+                 "tendencies_layout_kernel", "cloud_diagnostics_kernel"):       # (round 5: the packed instantiations, the pair kernel, the layout adapters, the diagnostics)
         ks = [k for k in kernels if frag in k["name"]]
         assert ks, frag
         bad = [k for k in ks if k["vgpr_spill"]]
@@ -88,3 +89,24 @@ def test_column_kernels_do_not_spill(kernels):
     assert arg[(5, False, True)] <= 128 and arg[(5, False, False)] <= 128, arg
     assert arg[(8, False, True)] <= 168, arg
     assert max(arg.values()) <= 256, arg
+
+
+def test_packed_instantiations_keep_their_register_budget(kernels):
+    """Round 5: the Float32 kernels that evaluate PAIRS of points (f32x2) hold two points' intermediates in register pairs.  The budgets they were measured at
+    (DESIGN §4.8): the 1-moment sweep inside 128 VGPRs (four waves per SIMD), the SB2006 column step inside 128 (compiled for four waves), the LinearizedAverage
+    pair kernel inside 128; the north-star instantiation (one point at a time) where round 4 left it."""
+    named = [dict(k, name=n) for k, n in zip(kernels, _tool().demangle([k["name"] for k in kernels]))]
+
+    def one(pred):
+        ks = [k for k in named if pred(k["name"])]
+        assert ks, pred
+        return ks
+    for k in one(lambda n: "mp1m_tendencies_kernel<float, 4, 1073872219u>" in n):
+        assert k["vgpr"] <= 128 and k["sgpr_spill"] == 0, k
+    for k in one(lambda n: "mp1m_linearized_pair_kernel<1073872219u>" in n):
+        assert k["vgpr"] <= 128 and k["sgpr_spill"] == 0, k
+    for k in one(lambda n: "sb2006_column_kernel<float, true, 1, false, 4, 256, true>" in n or "sb2006_column_kernel<float, true, 2, false, 4, 256, true>" in n):
+        assert k["vgpr"] <= 128, k
+    for k in one(lambda n: "sb2006_tendencies_kernel<float, true, 1, 4, 128, 1, true, true>" in n):
+        assert k["vgpr"] <= 128 and k["sgpr_spill"] == 0, k      # the north star: one point at a time, four waves per SIMD
+

@@ -258,3 +258,31 @@ def test_sb2006_packed_pairs_are_bit_identical(host_clang, limited, vel):
         same = (ua == ub) | ((a == 0) & (b == 0)) | (np.isnan(a) & np.isnan(b))       # ±0: see test_packed_pairs_are_bit_identical_to_single_points
         assert bool(np.all(same)), (name, int(np.sum(~same)))
 
+
+
+@pytest.mark.parametrize("ft", ["f32", "f64"])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_sb2006_point_function_with_perturbed_parameter_sets(host, oracle, ft, seed):
+    """Every SB2006 / air / relaxation parameter scaled by a random factor in [0.8, 1.25] (limiters kept ordered; the three "integer" exponents become
+    general ones → the exp2(e·log2 x) instantiation): the host-folded constants of make_sb_consts and the log2-domain algebra follow ANY parameter set, not
+    just the ClimaParams defaults — host build against the oracle evaluated with the same perturbed structs."""
+    rng = np.random.default_rng(seed)
+    names = [k for k in P.DEFAULT_PARAMETERS if k.startswith("SB2006_") and "distribution_coeff_nu" not in k and "distribution_coeff_mu" not in k]
+    names += ["condensation_evaporation_timescale", "thermal_conductivity_of_air", "diffusivity_of_water_vapor", "kinematic_viscosity_of_air"]
+    names = [k for k in names if k in P.DEFAULT_PARAMETERS and isinstance(P.DEFAULT_PARAMETERS[k], float)]
+    ov = {k: P.DEFAULT_PARAMETERS[k] * rng.uniform(0.8, 1.25) for k in names}
+    for lo, hi in (("SB2006_raindrops_min_mass", "SB2006_raindrops_max_mass"), ("SB2006_raindrops_size_distribution_coeff_N0_min", "SB2006_raindrops_size_distribution_coeff_N0_max"),
+                   ("SB2006_raindrops_size_distribution_coeff_lambda_min", "SB2006_raindrops_size_distribution_coeff_lambda_max"),
+                   ("SB2006_raindrops_breakup_mean_diameter_threshold", "SB2006_raindrops_equilibrium_mean_diameter")):
+        assert ov[lo] < ov[hi]
+    n = 40_000
+    st = [c.numpy() for c in synthetic.sb2006_state(n, dtype=getattr(torch, {"f32": "float32", "f64": "float64"}[ft]), seed=100 + seed)]
+    for limited in (True, False):
+        wr, wr64 = P.WarmRainParams2M(P.create_toml_dict(ft, ov), limited), P.WarmRainParams2M(P.create_toml_dict("f64", ov), limited)
+        tps, velp = P.ThermodynamicsParameters(ft), P.rain_vel_params(ft)
+        flags = (_abi.CMX_SB2006_LIMITED if limited else 0) | _abi.CMX_VEL_SB2006
+        rc, got = _call(host, "host_sb2006", ft, (C.byref(wr.c), C.byref(tps), C.byref(velp), C.c_uint32(flags), C.c_int(0)), st, 6)
+        assert rc == 0                               # perturbed exponents: the general-exponent instantiation
+        ref = oracle.sb2006_warm_rain_tendencies(_abi.F64, wr64.c, P.ThermodynamicsParameters("f64"), P.rain_vel_params("f64"), flags,
+                                                 *[np.asarray(c, dtype=np.float64) for c in st], float32_gates=(ft == "f32"), nthreads=8)
+        parity.assert_parity(dict(zip(SB_NAMES, got)), ref, parity.RTOL[ft], names=SB_NAMES, what=f"host-build SB2006 perturbed parameters {ft} seed {seed} {'limited' if limited else 'not limited'}")
