@@ -483,6 +483,45 @@ CMX_LEAN_FN double log_pos(double x) {
     return fma_(q.hi, K.ln2, q.r * poly6s(q.r, K.ln));
 #endif
 }
+// exp_fin / log_pos with the polynomial's SECOND coefficient handed in by the caller (round 5).  A VOP3 instruction reads one scalar operand, so the
+// first Horner step c0·r + c1 with both coefficients on the scalar side costs a v_mov_b64 per evaluation; vc() above removes it with a VGPR pair that
+// lives through the whole kernel.  A kernel at its register limit in ONE phase and with slack in another (the 2M + P3 step: 163–168 VGPRs in the
+// collision sweep, ≈ 107 in the self-collection / melting sweeps) pins the pair for the slack phase only (cmx_p3.hpp PM<double>::coefs_local) and passes it
+// in — the same arithmetic, the same coefficient value.
+CMX_LEAN_FN double exp_fin_c1(double x, double c1) {
+#if !CMX_F64_FINITE_FORMS || !CMX_LEAN_TABLES
+    (void)c1;
+    return exp(x);
+#else
+    const LeanCoefs &K = coefs();
+    const double kd = __builtin_rint(x * K.k128_log2e);
+    double r = fma_(-kd, K.ln2_128_hi, x);
+    r = fma_(-kd, K.ln2_128_lo, r);
+    const int ki = sat_int(kd);
+    const double s = exp2_tab(ki & 127);
+    double p = sc(K.ee[0]);
+    p = fma_(p, r, c1);
+    p = fma_(p, r, sc(K.ee[2]));
+    p = fma_(p, r, sc(K.ee[3]));
+    return ldexp_(fma_(s, p * r, s), ki >> 7);
+#endif
+}
+CMX_LEAN_FN double log_pos_c1(double x, double c1) {
+#if !CMX_LEAN_TABLES || !CMX_F64_FINITE_FORMS
+    (void)c1;
+    return log(x);
+#else
+    const LeanCoefs &K = coefs();
+    const Log2Parts q = log2_reduce(x, K);
+    double p = sc(K.ln[0]);
+    p = fma_(p, q.r, c1);
+    p = fma_(p, q.r, sc(K.ln[2]));
+    p = fma_(p, q.r, sc(K.ln[3]));
+    p = fma_(p, q.r, sc(K.ln[4]));
+    p = fma_(p, q.r, sc(K.ln[5]));
+    return fma_(q.hi, K.ln2, q.r * p);
+#endif
+}
 CMX_LEAN_FN double log(double x) {
 #if !CMX_LEAN_TABLES
     {

@@ -10,7 +10,26 @@
 #include "cmx_launch.hpp"
 #include "cmx_math.hpp"
 
+// Floating-point contraction in the P3 code (round 5).  The library is built with -ffp-contract=off: a fused multiply-add is written where it is meant
+// (Math<FT>::fma), so every kernel that shares a point function rounds alike and the host builds of the point functions (tests/native) round like the
+// device.  The P3 quadrature integrands, incomplete-gamma recurrences and Brent arithmetic are the exception: long sums of products written term by term,
+// shared with no host build, in kernels bound by VALU issue — contraction takes 10–17 % of the instructions out of their node loops (same-box A/B, ms per
+// 1e6 / 1e7 states: 2M + P3 Float64 20.7 → 19.1, shape + fall speeds 26.8 → 24.5, self-collection 50.7 → 46.1; Float32 6.7 → 6.2, 8.0 → 7.1, 16.1 → 14.7).
+// The pragma brackets exactly that code: this header's device functions and the P3 kernels of cmx_p3_kernels.hip / cmx_p3_collisions.hip.  The pointwise
+// part of the 2M + P3 entry (mp2m_p3_point → sb2006_point) stays outside — it is bit-identical to the warm-rain entry, and tested so.
+// -DCMX_P3_FP_CONTRACT=0: no contraction anywhere (A/B switch).
+#ifndef CMX_P3_FP_CONTRACT
+#define CMX_P3_FP_CONTRACT 1
+#endif
+#if CMX_P3_FP_CONTRACT
+#define CMX_P3_CONTRACT_BEGIN _Pragma("clang fp contract(fast)")
+#else
+#define CMX_P3_CONTRACT_BEGIN
+#endif
+#define CMX_P3_CONTRACT_END _Pragma("clang fp contract(off)")
+
 namespace cmx {
+CMX_P3_CONTRACT_BEGIN
 
 // elementary functions for the solver (the residual is a log-sum-exp of incomplete-gamma moments): lean exp/log
 // (cmx_lean_f64.hpp) in Float64, OCML for the rest and for Float32
@@ -74,6 +93,32 @@ template <> struct PM<double> {
     static __device__ __forceinline__ double log(double x, const Coefs &k) { return lean::log(x, k); }
     static __device__ __forceinline__ double log_pos(double x, const Coefs &k) { return lean::log_pos(x, k); }
 #endif
+    // Coefficients pinned for ONE phase of a kernel (cmx_lean_f64.hpp exp_fin_c1 / log_pos_c1; round 5): the first Horner step of the integrand
+    // exponentials and logarithms reads its second coefficient from a VGPR pair instead of a v_mov_b64 per evaluation.  `dep` is a value born in
+    // that phase: the asm depends on it, so the two pairs are not live before it — the phase with register slack pays, the phase at the kernel's
+    // register limit (the collision sweep) keeps the scalar forms.  -DCMX_P3_LOCAL_COEFS=0: the scalar forms everywhere (A/B switch).
+#ifndef CMX_P3_LOCAL_COEFS
+#define CMX_P3_LOCAL_COEFS 2
+#endif
+#if CMX_P3_SCALAR_COEFS && CMX_P3_LOCAL_COEFS == 2
+    // every constant of the table-driven exp / log in registers for the phase (18 pairs, the TabCoefs of the translation units that are not at a register limit)
+    using LocalCoefs = lean::TabCoefs;
+    static __device__ __forceinline__ LocalCoefs coefs_local(double) { return lean::tab_coefs(); }
+    static __device__ __forceinline__ double exp(double x, const LocalCoefs &k) { return lean::exp_fin(x, k); }
+    static __device__ __forceinline__ double log_pos(double x, const LocalCoefs &k) { return lean::log_pos(x, k); }
+#elif CMX_P3_SCALAR_COEFS && CMX_P3_LOCAL_COEFS
+    struct LocalCoefs { double e1, l1; };
+    static __device__ __forceinline__ LocalCoefs coefs_local(double dep) {
+        LocalCoefs k{lean::coefs().ee[1], lean::coefs().ln[1]};
+        asm volatile("" : "+v"(k.e1), "+v"(k.l1) : "v"(dep));
+        return k;
+    }
+    static __device__ __forceinline__ double exp(double x, const LocalCoefs &k) { return lean::exp_fin_c1(x, k.e1); }
+    static __device__ __forceinline__ double log_pos(double x, const LocalCoefs &k) { return lean::log_pos_c1(x, k.l1); }
+#else
+    using LocalCoefs = Coefs;
+    static __device__ __forceinline__ LocalCoefs coefs_local(double) { return coefs(); }
+#endif
     static __device__ __forceinline__ void pin(double &x) { lean::pin(x); }
     static __device__ __forceinline__ double exp_fast(double x) { return exp(x); }       // Float64: the one-argument forms above
     static __device__ __forceinline__ double log_fast(double x) { return log(x); }
@@ -94,6 +139,8 @@ template <> struct PM<float> {
     static __device__ __forceinline__ float abs(float x) { return __builtin_fabsf(x); }
     struct Coefs {};
     static __device__ __forceinline__ Coefs coefs() { return {}; }
+    using LocalCoefs = Coefs;
+    static __device__ __forceinline__ LocalCoefs coefs_local(float) { return {}; }
     static __device__ __forceinline__ void pin(float &) {}
     // the incomplete-gamma prefactor e^(a ln x − x − ln Γ(a)) — eight per residual evaluation of the shape solver: CMX_P3_F32_FAST_PREFACTOR=1
     // takes the hardware forms there too (A/B switch)
@@ -235,12 +282,26 @@ template <typename FT> __device__ __forceinline__ FT gamma_cf_value(FT a, FT x) 
 #if CMX_P3_CF_EARLY_EXIT
     FT A_prev = FT(0);
 #endif
+    // Float64 (round 5): the coefficients by differences — a_{k+1} − a_k = a − (2k + 1), b_{k+1} − b_k = 2 — three additions per term instead of an
+    // integer conversion, a subtraction, a multiply and an addition; the accumulated rounding of a_k is ≤ k ulp of a number of size k² (1e-14 relative at
+    // the 30th term, against the 1e-6 of the parity bound and the 1e-11 the shape solve reaches).  -DCMX_P3_CF_INCREMENT=0: the closed forms (A/B switch).
+#ifndef CMX_P3_CF_INCREMENT
+#define CMX_P3_CF_INCREMENT 0
+#endif
+    constexpr bool INCR = sizeof(FT) == 8 && CMX_P3_CF_INCREMENT;
+    FT ak_i = a - FT(1), dk_i = a - FT(3), bk_i = b0 + FT(2);      // a_1 = −1·(1 − a), a_2 − a_1, b_1
 #pragma unroll 1
     for (int k0 = 0; k0 < P::kGammaIters; k0 += P::kRescale) {
 #pragma unroll
         for (int j = 1; j <= P::kRescale; ++j) {
-            const FT kk = FT(k0 + j);
-            const FT ak = -kk * (kk - a), bk = b0 + FT(2) * kk;
+            FT ak, bk;
+            if constexpr (INCR) {
+                ak = ak_i; bk = bk_i;
+                ak_i += dk_i; dk_i -= FT(2); bk_i += FT(2);
+            } else {
+                const FT kk = FT(k0 + j);
+                ak = -kk * (kk - a); bk = b0 + FT(2) * kk;
+            }
             const FT An = bk * A + ak * Am, Bn = bk * B + ak * Bm;
             Am = A; Bm = B; A = An; B = Bn;
         }
@@ -500,4 +561,5 @@ template <typename FT> __device__ FT gamma_inc_inv_dev(FT a, FT p, FT q) {
     return x;
 }
 
+CMX_P3_CONTRACT_END
 }  // namespace cmx

@@ -417,6 +417,7 @@ template <typename FT, bool LIMITED_, bool INTPOW_> struct PointwiseExtra {     
     const FT *q_tot, *shift;
 };
 template <typename FT> struct QuadSmall { int32_t n; FT node[32], weight[32]; };
+CMX_P3_CONTRACT_BEGIN      // the quadrature sweeps (cmx_p3.hpp); the pointwise part it calls in its epilogue (mp2m_p3_point, above) is defined outside and stays exact-as-written
 template <typename FT, typename QUAD, bool ASPECT, bool FUSED, int GROUP, typename EXTRA = NoExtra>
 __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(const P3Consts<FT> c, const P3VelConsts<FT> v, const P3ColConsts<FT> k,
                                                              const QUAD quad, const P3ColIO<FT> io, const int64_t n, const EXTRA ex) {
@@ -519,27 +520,44 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
     const FT pi = FT(3.14159265358979323846), inv_pi = FT(0.3183098861837907);
     // ice fall speed (incl. aspect factor), collision radius and number density at diameter x — as in p3_self_collection_kernel
     const typename P::Coefs kc = P::coefs();          // exp / log constants pinned in VGPRs for the node loops
-    auto eval_ice = [&](FT x, FT &vv, FT &rr, FT &nn) {
-        const FT logD = P::log_pos(x, kc);          // an interior quadrature node: positive, normal, finite
+    // `kk`: the coefficient set of the caller's phase (P::Coefs in the collision sweep, P::LocalCoefs in the self-collection / melting sweeps)
+    // SHARED: D^(σ/2) serves BOTH non-spherical laws (the mixed area's γ D^σ is its square) — a wave whose lanes sit in both regimes, i.e. most waves of
+    // the inner self-collection loop, evaluates one exponential instead of one per regime (round 5).  The collision sweep calls the form with one
+    // exponential per regime: one evaluation per OUTER node there, and the shared value would be two more live registers at the kernel's register peak.
+    auto eval_ice = [&](FT x, FT &vv, FT &rr, FT &nn, const auto &kk, auto shared) {
+        constexpr bool SHARED = decltype(shared)::value;
+        const FT logD = P::log_pos(x, kk);          // an interior quadrature node: positive, normal, finite
         const int reg = x < s.bnd[1] ? 0 : (unrimed ? 1 : (x < s.bnd[2] ? 1 : (x < s.bnd[3] ? 2 : 3)));
         // collision radius r = √(area/π) and aspect factor: spherical regimes r = D/2 exactly; unrimed non-spherical area = γ D^σ:
         // r = √(γ/π)·D^(σ/2) (one exponential, no square root); only the partially rimed regime needs the mixed area and its root
         FT eA = FT(0);
         rr = FT(0.5) * x;
-        if (reg == 1) {
-            rr = v.sqrt_gamma_pi * P::exp(v.half_sigma * logD, kc);
+        if constexpr (SHARED) {
+            if (reg == 1 || reg == 3) {
+                const FT dh = P::exp(v.half_sigma * logD, kk);
+                if (reg == 1) {
+                    rr = v.sqrt_gamma_pi * dh;
+                    if (ASPECT) eA = v.g0 + v.g1 * logD;
+                } else {
+                    const FT area = s.F_rim * (v.pi_4 * x * x) + (FT(1) - s.F_rim) * (v.gamma_area * (dh * dh));
+                    rr = M::sqrt(area * inv_pi);
+                    if (ASPECT) eA = h0 + h1 * logD - FT(0.5) * P::log_pos(area, kk);
+                }
+            }
+        } else if (reg == 1) {
+            rr = v.sqrt_gamma_pi * P::exp(v.half_sigma * logD, kk);
             if (ASPECT) eA = v.g0 + v.g1 * logD;
         } else if (reg == 3) {
-            const FT area = s.F_rim * (v.pi_4 * x * x) + (FT(1) - s.F_rim) * (v.gamma_area * P::exp(v.sigma_area * logD, kc));
+            const FT area = s.F_rim * (v.pi_4 * x * x) + (FT(1) - s.F_rim) * (v.gamma_area * P::exp(v.sigma_area * logD, kk));
             rr = M::sqrt(area * inv_pi);
-            if (ASPECT) eA = h0 + h1 * logD - FT(0.5) * P::log_pos(area, kc);
+            if (ASPECT) eA = h0 + h1 * logD - FT(0.5) * P::log_pos(area, kk);
         }
         const bool small = x <= v.cutoff;
         const FT E1 = small ? se + sb * logD : le1 + v.l_b1 * logD;
         const FT dE = small ? -v.s_c2 * x : (le2 - le1) + (v.l_b2 - v.l_b1) * logD - v.l_c2 * x;
         const FT A1 = small ? kpin(v.s_E) : kpin(v.l_a1), A2 = small ? kpin(v.s_F) : kpin(v.l_a2);
-        vv = P::exp(eA + E1, kc) * (A1 + A2 * P::exp(dE, kc));
-        nn = P::exp(logN0 + mu * logD - lam * x, kc);
+        vv = P::exp(ASPECT ? eA + E1 : E1, kk) * (A1 + A2 * P::exp(dE, kk));     // (without the aspect factor eA is the literal 0: no 0 + E1)
+        nn = P::exp(logN0 + mu * logD - lam * x, kk);
     };
     // rain Chen-2022 curve at ρₐ
     FT re[3], rb[3];
@@ -672,7 +690,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
             for (int o = g; o < nq; o += GROUP) {
                 const FT Di = scale * q_node[o] + shift, w = q_wt[o] * scale;
                 FT v_i, r_i, n_i;
-                eval_ice(Di, v_i, r_i, n_i);
+                eval_ice(Di, v_i, r_i, n_i, kc, std::false_type{});
                 const FT K0 = pi * (r_i * r_i), K1 = pi * r_i, K2 = FT(0.7853981633974483);
                 FT Nc = FT(0), Mc = FT(0), Bc = FT(0), Nr = FT(0), Mr = FT(0), Br = FT(0);
                 if (has_cloud) {
@@ -778,6 +796,9 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
     FT acc_sc = FT(0), acc_m = FT(0);
     if constexpr (FUSED) {
         const FT D_lo_sc = Sv[20], D_hi_sc = Sv[21];
+        // these two sweeps run far below the kernel's register count (≈ 107 of 163–168 VGPRs): their integrands read the second polynomial coefficient
+        // of exp / log from register pairs pinned HERE (cmx_p3.hpp coefs_local) — 5 v_mov_b64 fewer per inner node of the self-collection integral
+        const typename P::LocalCoefs kl = P::coefs_local(D_lo_sc);
         if (present) {
             FT bs[5];
             bs[0] = D_lo_sc; bs[4] = D_hi_sc;
@@ -790,7 +811,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
                 for (int o = g; o < nq; o += GROUP) {
                     const FT D1 = scale * q_node[o] + shift;
                     FT v1, r1, n1;
-                    eval_ice(D1, v1, r1, n1);
+                    eval_ice(D1, v1, r1, n1, kl, std::true_type{});
                     FT inner = FT(0);
                     for (int h = 0; h < 2; ++h) {   // inner integral split at the |v₁ − v₂| cusp D₂ = D₁
                         const FT ia = h == 0 ? D_lo_sc : D1, ib = h == 0 ? D1 : D_hi_sc;
@@ -799,7 +820,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
                         FT r_in = FT(0);
                         for (int j = 0; j < nq; ++j) {
                             FT v2, r2, n2;
-                            eval_ice(sc2 * q_node[j] + sh2, v2, r2, n2);
+                            eval_ice(sc2 * q_node[j] + sh2, v2, r2, n2, kl, std::true_type{});
                             const FT rs = r1 + r2;
                             r_in += rs * rs * P::abs(v1 - v2) * n2 * q_wt[j];
                         }
@@ -826,7 +847,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
                     for (int o = g; o < nq; o += GROUP) {
                         const FT x = scale * q_node[o] + shift;
                         FT vD, rD_, nD;
-                        eval_ice(x, vD, rD_, nD);
+                        eval_ice(x, vD, rD_, nD, kl, std::true_type{});
                         const FT Fv = k.vent_a + k.vent_bc * M::sqrt(M::max(x * vD, FT(0)));
                         const FT dm_over_D = mb == FT(3) ? ma * mb * x : ma * mb * P::exp((mb - FT(2)) * P::log(x));   // ∂m/∂D / D
                         acc_m += dm_over_D * Fv * nD * (q_wt[o] * scale);
@@ -919,6 +940,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
         }
     }
 }
+CMX_P3_CONTRACT_END
 
 // launch geometry: 256 lanes (32 states) per workgroup unless the per-state LDS caches (6n + 100 values) would not fit — then 128
 // Returns false when the rounded-up tile count does not fit HIP's 2^31 − 1 workgroups: a Float32 tile is only 8 (group 8) or 4 (group 16) states,

@@ -23,6 +23,7 @@
 #include "cmx_p3.hpp"
 
 namespace cmx {
+CMX_P3_CONTRACT_BEGIN      // the whole translation unit is P3 quadrature / solver code (cmx_p3.hpp)
 
 #ifndef CMX_P3_BS
 #define CMX_P3_BS 256
@@ -378,22 +379,26 @@ __global__ __launch_bounds__(kP3BS) void p3_self_collection_kernel(const P3Const
             const FT logD = P::log_pos(x, kc);          // an interior quadrature node: positive, normal, finite
             const int reg = x < s.bnd[1] ? 0 : (unrimed ? 1 : (x < s.bnd[2] ? 1 : (x < s.bnd[3] ? 2 : 3)));
             // collision radius r = √(area/π) and aspect factor: spherical regimes r = D/2 exactly; unrimed non-spherical area = γ D^σ:
-            // r = √(γ/π)·D^(σ/2) (one exponential, no square root); only the partially rimed regime needs the mixed area and its root
+            // r = √(γ/π)·D^(σ/2) (one exponential, no square root); only the partially rimed regime needs the mixed area and its root.  D^(σ/2) serves
+            // both non-spherical laws (γ D^σ is its square): lanes of one wave sit in both regimes, so the wave evaluates one exponential, not two
             FT eA = FT(0);
             rr = FT(0.5) * x;
-            if (reg == 1) {
-                rr = v.sqrt_gamma_pi * P::exp(v.half_sigma * logD, kc);
-                if (ASPECT) eA = v.g0 + v.g1 * logD;
-            } else if (reg == 3) {
-                const FT area = s.F_rim * (v.pi_4 * x * x) + (FT(1) - s.F_rim) * (v.gamma_area * P::exp(v.sigma_area * logD, kc));
-                rr = Math<FT>::sqrt(area * inv_pi);
-                if (ASPECT) eA = h0 + h1 * logD - FT(0.5) * P::log_pos(area, kc);
+            if (reg == 1 || reg == 3) {
+                const FT dh = P::exp(v.half_sigma * logD, kc);
+                if (reg == 1) {
+                    rr = v.sqrt_gamma_pi * dh;
+                    if (ASPECT) eA = v.g0 + v.g1 * logD;
+                } else {
+                    const FT area = s.F_rim * (v.pi_4 * x * x) + (FT(1) - s.F_rim) * (v.gamma_area * (dh * dh));
+                    rr = Math<FT>::sqrt(area * inv_pi);
+                    if (ASPECT) eA = h0 + h1 * logD - FT(0.5) * P::log_pos(area, kc);
+                }
             }
             const bool small = x <= v.cutoff;
             const FT E1 = small ? se + sb * logD : le1 + v.l_b1 * logD;
             const FT dE = small ? -v.s_c2 * x : (le2 - le1) + (v.l_b2 - v.l_b1) * logD - v.l_c2 * x;
             const FT A1 = small ? kpin(v.s_E) : kpin(v.l_a1), A2 = small ? kpin(v.s_F) : kpin(v.l_a2);
-            vv = P::exp(eA + E1, kc) * (A1 + A2 * P::exp(dE, kc));
+            vv = P::exp(ASPECT ? eA + E1 : E1, kc) * (A1 + A2 * P::exp(dE, kc));
             nn = P::exp(logN0 + mu * logD - lam * x, kc);
         };
         FT total = FT(0);
@@ -673,6 +678,7 @@ static int32_t sb2006_size_distribution_entry(const PC *pdf_c, const PR *pdf_r, 
     return CMX_OK;
 }
 
+CMX_P3_CONTRACT_END
 }  // namespace cmx
 
 extern "C" {
