@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 #include "cmx_launch.hpp"
 #include "cmx_math.hpp"
@@ -216,6 +217,9 @@ template <typename FT, typename PR> static P3Consts<FT> make_p3_consts(const PR 
 #ifndef CMX_P3_SERIES_FWD_F32
 #define CMX_P3_SERIES_FWD_F32 1      // A/B switch
 #endif
+#ifndef CMX_P3_CF_INCREMENT
+#define CMX_P3_CF_INCREMENT 2      // Float64: continued fraction from the tail inwards (2) / forwards (1) with its coefficients by differences, series denominators by decrement (gamma_cf_value; A/B switch)
+#endif
 #ifndef CMX_P3_SERIES_NODIV
 #define CMX_P3_SERIES_NODIV 1      // 0: term-by-term with one reciprocal per term (round 1; A/B switch)
 #endif
@@ -254,11 +258,14 @@ template <typename FT> __device__ __forceinline__ FT gamma_series_sum(FT a, FT x
     }
 #endif
     FT p = FT(1), q = FT(1);
+    FT ak = a + FT(P::kGammaIters);      // a + k carried downwards: one subtraction per term instead of an integer conversion and an addition (CMX_P3_CF_INCREMENT)
 #pragma unroll 1
     for (int k0 = P::kGammaIters; k0 > 0; k0 -= R) {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            const FT qa = q * (a + FT(k0 - j));
+            FT qa;
+            if constexpr (sizeof(FT) == 8 && CMX_P3_CF_INCREMENT) { qa = q * ak; ak -= FT(1); }
+            else qa = q * (a + FT(k0 - j));
             p = Math<FT>::fma(x, p, qa);
             q = qa;
         }
@@ -278,6 +285,30 @@ template <typename FT> __device__ __forceinline__ FT gamma_cf_value(FT a, FT x) 
     static_assert(P::kGammaIters % P::kRescale == 0, "rescale period must divide the term count");
     // h₀ = 1/b₀:  A₀ = 1, B₀ = b₀;  A₋₁ = 0, B₋₁ = 1
     const FT b0 = x + FT(1) - a;
+    if constexpr (sizeof(FT) == 8 && CMX_P3_CF_INCREMENT >= 2) {
+        // Float64 (round 5): the SAME convergent h_N, evaluated from the tail inwards.  t_N = b_N, t_{k−1} = b_{k−1} + a_k/t_k, h_N = 1/t_0, with t carried as a
+        // fraction p/q:  p ← b_{k−1} p + a_k q,  q ← p  — one multiply and one fused multiply-add per term where the forward (Wallis) recurrence above runs
+        // two of each (A and B), and no convergent is formed on the way: Float64 never took the early exit (it reaches eps only near the full count).  The
+        // coefficients by differences (a_{k−1} − a_k = 2k − 1 − a, b_{k−1} − b_k = −2: three additions per term); rescaled every kRescale terms by 1/p.
+        // 8.5 → 6 instructions per term; -DCMX_P3_CF_INCREMENT=1: the forward recurrence with difference coefficients, =0: with closed-form coefficients.
+        constexpr int N = P::kGammaIters;
+        FT bk = b0 + FT(2 * N);                      // b_N
+        FT ak = -FT(N) * (FT(N) - a);                // a_N
+        FT dk = FT(2 * N - 1) - a;                   // a_{N−1} − a_N
+        FT p = bk, q = FT(1);
+#pragma unroll 1
+        for (int k0 = N; k0 > 0; k0 -= P::kRescale) {
+#pragma unroll
+            for (int j = 0; j < P::kRescale; ++j) {
+                bk -= FT(2);
+                const FT pn = Math<FT>::fma(bk, p, ak * q);
+                q = p; p = pn;
+                ak += dk; dk -= FT(2);
+            }
+            q *= P::rcp(p); p = FT(1);
+        }
+        return q;
+    }
     FT Am = FT(0), Bm = FT(1), A = FT(1), B = b0;
 #if CMX_P3_CF_EARLY_EXIT
     FT A_prev = FT(0);
@@ -285,10 +316,7 @@ template <typename FT> __device__ __forceinline__ FT gamma_cf_value(FT a, FT x) 
     // Float64 (round 5): the coefficients by differences — a_{k+1} − a_k = a − (2k + 1), b_{k+1} − b_k = 2 — three additions per term instead of an
     // integer conversion, a subtraction, a multiply and an addition; the accumulated rounding of a_k is ≤ k ulp of a number of size k² (1e-14 relative at
     // the 30th term, against the 1e-6 of the parity bound and the 1e-11 the shape solve reaches).  -DCMX_P3_CF_INCREMENT=0: the closed forms (A/B switch).
-#ifndef CMX_P3_CF_INCREMENT
-#define CMX_P3_CF_INCREMENT 0
-#endif
-    constexpr bool INCR = sizeof(FT) == 8 && CMX_P3_CF_INCREMENT;
+    constexpr bool INCR = sizeof(FT) == 8 && CMX_P3_CF_INCREMENT == 1;
     FT ak_i = a - FT(1), dk_i = a - FT(3), bk_i = b0 + FT(2);      // a_1 = −1·(1 − a), a_2 − a_1, b_1
 #pragma unroll 1
     for (int k0 = 0; k0 < P::kGammaIters; k0 += P::kRescale) {
@@ -320,11 +348,13 @@ template <typename FT> __device__ __forceinline__ FT gamma_cf_value(FT a, FT x) 
     }
     return A;
 }
-template <typename FT> __device__ FT gamma_inc_dev(FT a, FT x, FT lgam_a, bool want_P) {
+// `logx`: ln x where the caller has it already (the shape solve: x = λ·D_threshold, ln x = ln λ + ln D_threshold with the second term fixed per state — one
+// logarithm fewer per incomplete gamma, 96 of them per solve); NaN = not given
+template <typename FT> __device__ FT gamma_inc_dev(FT a, FT x, FT lgam_a, bool want_P, FT logx = Math<FT>::nan()) {
     using P = PM<FT>;
     if (x <= FT(0)) return want_P ? FT(0) : FT(1);
     if (isinf(x)) return want_P ? FT(1) : FT(0);
-    const FT factor = P::exp_fast(a * P::log_fast(x) - x - lgam_a);
+    const FT factor = P::exp_fast(a * (logx == logx ? logx : P::log_fast(x)) - x - lgam_a);
     const bool series = x < a + FT(1);
     const FT body = series ? gamma_series_sum<FT>(a, x) : gamma_cf_value<FT>(a, x);
     const FT pq = Math<FT>::min(Math<FT>::max(factor * body, FT(0)), FT(1));   // P on the series branch, Q on the other
@@ -356,7 +386,10 @@ template <typename FT> __device__ __forceinline__ FT p3_mu(const P3Consts<FT> &c
 }
 
 // logmass_gamma_moment(state, μ, logλ; n) — :193-200 with loggamma_inc_moment :97-109 and unrolled_logsumexp
-template <typename FT> __device__ FT p3_logmass_moment(const P3Consts<FT> &c, const P3Point<FT> &s, FT mu, FT loglam, FT n) {
+// LogBnd: ln of the three finite thresholds s.bnd[1..3] (the shape solve computes them once per state: P3LogBnd), or NoLogBnd
+struct NoLogBnd {};
+template <typename FT> struct P3LogBnd { FT l1, l2, l3; };
+template <typename FT, typename LB = NoLogBnd> __device__ FT p3_logmass_moment(const P3Consts<FT> &c, const P3Point<FT> &s, FT mu, FT loglam, FT n, const LB lb = LB{}) {
     using P = PM<FT>;
     const FT lam = P::exp(loglam);
     // lgamma for the two distinct z: b = 3 (spherical regimes) and b = β_va (power-law regimes)
@@ -373,7 +406,15 @@ template <typename FT> __device__ FT p3_logmass_moment(const P3Consts<FT> &c, co
             const FT z = sph ? z_sph : z_pow, lg = sph ? lg_sph : lg_pow;
             const FT x1 = D1 * lam, x2 = D2 * lam;
             const bool use_P = x2 < z + FT(1);
-            const FT g1 = gamma_inc_dev<FT>(z, x1, lg, use_P), g2 = gamma_inc_dev<FT>(z, x2, lg, use_P);
+            FT g1, g2;
+            if constexpr (!std::is_same<LB, NoLogBnd>::value) {
+                // ln x = ln λ + ln D; i = 0: x1 = 0, i = 3: x2 = ∞ — both return before the logarithm is read
+                const FT lo = i == 1 ? lb.l1 : (i == 2 ? lb.l2 : lb.l3), hi = i == 0 ? lb.l1 : (i == 1 ? lb.l2 : lb.l3);
+                g1 = gamma_inc_dev<FT>(z, x1, lg, use_P, lo + loglam);
+                g2 = gamma_inc_dev<FT>(z, x2, lg, use_P, hi + loglam);
+            } else {
+                g1 = gamma_inc_dev<FT>(z, x1, lg, use_P); g2 = gamma_inc_dev<FT>(z, x2, lg, use_P);
+            }
             FT dq = use_P ? g2 - g1 : g1 - g2;
             dq = Math<FT>::max(dq, P::eps());
             val = -z * loglam + lg + P::log(dq) + s.log_a[i];
@@ -388,9 +429,9 @@ template <typename FT> __device__ FT p3_logmass_moment(const P3Consts<FT> &c, co
     return xmax + P::log(sum);
 }
 
-template <typename FT> __device__ __forceinline__ FT p3_logLdivN(const P3Consts<FT> &c, const P3Point<FT> &s, FT loglam) {   // :211-216
+template <typename FT, typename LB = NoLogBnd> __device__ __forceinline__ FT p3_logLdivN(const P3Consts<FT> &c, const P3Point<FT> &s, FT loglam, const LB lb = LB{}) {   // :211-216
     const FT mu = p3_mu<FT>(c, loglam);
-    return p3_logmass_moment<FT>(c, s, mu, loglam, FT(0)) - (-(mu + FT(1)) * loglam + PM<FT>::lgamma(mu + FT(1)));
+    return p3_logmass_moment<FT, LB>(c, s, mu, loglam, FT(0), lb) - (-(mu + FT(1)) * loglam + PM<FT>::lgamma(mu + FT(1)));
 }
 
 template <typename FT> __device__ __forceinline__ FT exprel1(FT x) { return PM<FT>::expm1(x) / x; }
