@@ -6,7 +6,6 @@
 
 #include <algorithm>
 #include <cmath>
-#include <type_traits>
 
 #include "cmx_launch.hpp"
 #include "cmx_math.hpp"
@@ -348,13 +347,11 @@ template <typename FT> __device__ __forceinline__ FT gamma_cf_value(FT a, FT x) 
     }
     return A;
 }
-// `logx`: ln x where the caller has it already (the shape solve: x = λ·D_threshold, ln x = ln λ + ln D_threshold with the second term fixed per state — one
-// logarithm fewer per incomplete gamma, 96 of them per solve); NaN = not given
-template <typename FT> __device__ FT gamma_inc_dev(FT a, FT x, FT lgam_a, bool want_P, FT logx = Math<FT>::nan()) {
+template <typename FT> __device__ FT gamma_inc_dev(FT a, FT x, FT lgam_a, bool want_P) {
     using P = PM<FT>;
     if (x <= FT(0)) return want_P ? FT(0) : FT(1);
     if (isinf(x)) return want_P ? FT(1) : FT(0);
-    const FT factor = P::exp_fast(a * (logx == logx ? logx : P::log_fast(x)) - x - lgam_a);
+    const FT factor = P::exp_fast(a * P::log_fast(x) - x - lgam_a);
     const bool series = x < a + FT(1);
     const FT body = series ? gamma_series_sum<FT>(a, x) : gamma_cf_value<FT>(a, x);
     const FT pq = Math<FT>::min(Math<FT>::max(factor * body, FT(0)), FT(1));   // P on the series branch, Q on the other
@@ -386,10 +383,7 @@ template <typename FT> __device__ __forceinline__ FT p3_mu(const P3Consts<FT> &c
 }
 
 // logmass_gamma_moment(state, μ, logλ; n) — :193-200 with loggamma_inc_moment :97-109 and unrolled_logsumexp
-// LogBnd: ln of the three finite thresholds s.bnd[1..3] (the shape solve computes them once per state: P3LogBnd), or NoLogBnd
-struct NoLogBnd {};
-template <typename FT> struct P3LogBnd { FT l1, l2, l3; };
-template <typename FT, typename LB = NoLogBnd> __device__ FT p3_logmass_moment(const P3Consts<FT> &c, const P3Point<FT> &s, FT mu, FT loglam, FT n, const LB lb = LB{}) {
+template <typename FT> __device__ FT p3_logmass_moment(const P3Consts<FT> &c, const P3Point<FT> &s, FT mu, FT loglam, FT n) {
     using P = PM<FT>;
     const FT lam = P::exp(loglam);
     // lgamma for the two distinct z: b = 3 (spherical regimes) and b = β_va (power-law regimes)
@@ -406,15 +400,7 @@ template <typename FT, typename LB = NoLogBnd> __device__ FT p3_logmass_moment(c
             const FT z = sph ? z_sph : z_pow, lg = sph ? lg_sph : lg_pow;
             const FT x1 = D1 * lam, x2 = D2 * lam;
             const bool use_P = x2 < z + FT(1);
-            FT g1, g2;
-            if constexpr (!std::is_same<LB, NoLogBnd>::value) {
-                // ln x = ln λ + ln D; i = 0: x1 = 0, i = 3: x2 = ∞ — both return before the logarithm is read
-                const FT lo = i == 1 ? lb.l1 : (i == 2 ? lb.l2 : lb.l3), hi = i == 0 ? lb.l1 : (i == 1 ? lb.l2 : lb.l3);
-                g1 = gamma_inc_dev<FT>(z, x1, lg, use_P, lo + loglam);
-                g2 = gamma_inc_dev<FT>(z, x2, lg, use_P, hi + loglam);
-            } else {
-                g1 = gamma_inc_dev<FT>(z, x1, lg, use_P); g2 = gamma_inc_dev<FT>(z, x2, lg, use_P);
-            }
+            const FT g1 = gamma_inc_dev<FT>(z, x1, lg, use_P), g2 = gamma_inc_dev<FT>(z, x2, lg, use_P);
             FT dq = use_P ? g2 - g1 : g1 - g2;
             dq = Math<FT>::max(dq, P::eps());
             val = -z * loglam + lg + P::log(dq) + s.log_a[i];
@@ -429,9 +415,9 @@ template <typename FT, typename LB = NoLogBnd> __device__ FT p3_logmass_moment(c
     return xmax + P::log(sum);
 }
 
-template <typename FT, typename LB = NoLogBnd> __device__ __forceinline__ FT p3_logLdivN(const P3Consts<FT> &c, const P3Point<FT> &s, FT loglam, const LB lb = LB{}) {   // :211-216
+template <typename FT> __device__ __forceinline__ FT p3_logLdivN(const P3Consts<FT> &c, const P3Point<FT> &s, FT loglam) {   // :211-216
     const FT mu = p3_mu<FT>(c, loglam);
-    return p3_logmass_moment<FT, LB>(c, s, mu, loglam, FT(0), lb) - (-(mu + FT(1)) * loglam + PM<FT>::lgamma(mu + FT(1)));
+    return p3_logmass_moment<FT>(c, s, mu, loglam, FT(0)) - (-(mu + FT(1)) * loglam + PM<FT>::lgamma(mu + FT(1)));
 }
 
 template <typename FT> __device__ __forceinline__ FT exprel1(FT x) { return PM<FT>::expm1(x) / x; }

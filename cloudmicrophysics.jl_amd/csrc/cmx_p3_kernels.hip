@@ -43,14 +43,6 @@ __device__ __forceinline__ FT p3_solve_loglam(const P3Consts<FT> &c, const P3Poi
         loglam = -INFINITY;
     } else {
         const FT target = P::log(s.rho_q) - P::log(s.rho_n);
-        // ln of the regime thresholds, once per state: every incomplete gamma of the residual is evaluated at x = λ·D_threshold (cmx_p3.hpp gamma_inc_dev).
-        // Float64 only — CMX_P3_SOLVE_LOGX=0: each incomplete gamma takes its own logarithm (A/B switch)
-#ifndef CMX_P3_SOLVE_LOGX
-#define CMX_P3_SOLVE_LOGX 1
-#endif
-        constexpr bool LOGX = sizeof(FT) == 8 && CMX_P3_SOLVE_LOGX;
-        P3LogBnd<FT> lb{FT(0), FT(0), FT(0)};
-        if constexpr (LOGX) { lb.l1 = P::log(s.bnd[1]); lb.l2 = P::log(s.bnd[2]); lb.l3 = P::log(s.bnd[3]); }
         FT a = FT(2), b = FT(17), fa = FT(0), fb = FT(0), cc = FT(0), fc = FT(0), d = FT(0);
         bool mflag = true, active = true, guess_valid = false;
         const int first = guess ? -3 : -2;          // wave-uniform
@@ -79,9 +71,7 @@ __device__ __forceinline__ FT p3_solve_loglam(const P3Consts<FT> &c, const P3Poi
                     mflag = false;
                 }
             }
-            FT fs;
-            if constexpr (LOGX) fs = p3_logLdivN<FT, P3LogBnd<FT>>(c, s, sx, lb) - target;
-            else fs = p3_logLdivN<FT>(c, s, sx) - target;
+            const FT fs = p3_logLdivN<FT>(c, s, sx) - target;
             // what the step does with the value
             if (step == -3) {
                 fa = fs;
