@@ -6,8 +6,8 @@
 
 The library holds one clang offload bundle per translation unit (magic __CLANG_OFFLOAD_BUNDLE__); each bundle's gfx950 entry is an ELF
 code object whose NT_AMDGPU_METADATA note lists, per kernel, .vgpr_count / .sgpr_count / .vgpr_spill_count / .sgpr_spill_count /
-.private_segment_fixed_size / .group_segment_fixed_size.  tests/test_build.py asserts that the two collision kernels stay at zero spilled
-VGPRs."""
+.private_segment_fixed_size / .group_segment_fixed_size.  tests/test_kernel_resources.py asserts that the collision kernels keep spill traffic
+out of their loops (`--loops` below) and that the streaming kernels spill nothing."""
 import re
 import struct
 import subprocess
