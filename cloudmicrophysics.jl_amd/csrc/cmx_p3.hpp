@@ -93,10 +93,11 @@ template <> struct PM<double> {
     static __device__ __forceinline__ double log(double x, const Coefs &k) { return lean::log(x, k); }
     static __device__ __forceinline__ double log_pos(double x, const Coefs &k) { return lean::log_pos(x, k); }
 #endif
-    // Coefficients pinned for ONE phase of a kernel (cmx_lean_f64.hpp exp_fin_c1 / log_pos_c1; round 5): the first Horner step of the integrand
-    // exponentials and logarithms reads its second coefficient from a VGPR pair instead of a v_mov_b64 per evaluation.  `dep` is a value born in
-    // that phase: the asm depends on it, so the two pairs are not live before it — the phase with register slack pays, the phase at the kernel's
-    // register limit (the collision sweep) keeps the scalar forms.  -DCMX_P3_LOCAL_COEFS=0: the scalar forms everywhere (A/B switch).
+    // Constants pinned in registers for ONE phase of a kernel built with the scalar forms (round 5): the phase with register slack pays for them, the phase
+    // at the kernel's register limit (the collision sweep) keeps the scalar forms.  CMX_P3_LOCAL_COEFS = 2 (default): all eighteen constants of the
+    // table-driven exp / log (lean::tab_coefs — volatile pins, so they are born where coefs_local() is called and not before); = 1: only the second
+    // polynomial coefficient of each (exp_fin_c1 / log_pos_c1: no v_mov_b64 in front of the first Horner step; the asm depends on `dep`, a value born
+    // in that phase); = 0: the scalar forms everywhere (A/B switch; profiles/r05_ab_sessions.txt session 9: 21.2 / 21.0 / 20.7 ms for 0 / 1 / 2).
 #ifndef CMX_P3_LOCAL_COEFS
 #define CMX_P3_LOCAL_COEFS 2
 #endif

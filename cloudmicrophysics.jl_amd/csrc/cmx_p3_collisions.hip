@@ -515,7 +515,8 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
         for (int q = 1; q < 4; ++q) S[15 + q] = M::min(M::max(s.bnd[q], D_min), D_max);
     }
     const FT Fu = M::max(FT(1) - s.F_rim, P::eps());
-    const FT h0 = (v.h0_num - P::log(Fu)) / FT(3), h1 = c.beta_va / FT(3);
+    // (h0 carries the −½ ln π of the partially rimed regime's area^(−½) = y/√π, y = 1/√(area/π): eval_ice below)
+    const FT h0 = (v.h0_num - P::log(Fu)) / FT(3) - FT(0.5723649429247001), h1 = c.beta_va / FT(3);
     const bool unrimed = s.F_rim == FT(0);
     const FT pi = FT(3.14159265358979323846), inv_pi = FT(0.3183098861837907);
     // ice fall speed (incl. aspect factor), collision radius and number density at diameter x — as in p3_self_collection_kernel
@@ -524,39 +525,49 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
     // SHARED: D^(σ/2) serves BOTH non-spherical laws (the mixed area's γ D^σ is its square) — a wave whose lanes sit in both regimes, i.e. most waves of
     // the inner self-collection loop, evaluates one exponential instead of one per regime (round 5).  The collision sweep calls the form with one
     // exponential per regime: one evaluation per OUTER node there, and the shared value would be two more live registers at the kernel's register peak.
-    auto eval_ice = [&](FT x, FT &vv, FT &rr, FT &nn, const auto &kk, auto shared) {
+    // `ik`: the area-law / aspect constants the regimes read — kernel arguments (SGPR pairs) in the collision sweep, register copies pinned for the fused sweeps
+    // (IceK below: six fewer scalar pairs in the inner self-collection loop, whose scalar file is over-subscribed — spilled SGPRs are re-read with v_readlane)
+    struct IceK { FT half_sigma, sqrt_gamma_pi, pi_4, gamma_area, g0, g1, bnd1; };      // bnd1 = s.bnd[1] = D_th, the one regime threshold that is a kernel constant
+    const IceK ik0{v.half_sigma, v.sqrt_gamma_pi, v.pi_4, v.gamma_area, v.g0, v.g1, s.bnd[1]};
+    auto eval_ice = [&](FT x, FT &vv, FT &rr, FT &nn, const auto &kk, auto shared, const IceK &ik) {
         constexpr bool SHARED = decltype(shared)::value;
         const FT logD = P::log_pos(x, kk);          // an interior quadrature node: positive, normal, finite
-        const int reg = x < s.bnd[1] ? 0 : (unrimed ? 1 : (x < s.bnd[2] ? 1 : (x < s.bnd[3] ? 2 : 3)));
+        const int reg = x < ik.bnd1 ? 0 : (unrimed ? 1 : (x < s.bnd[2] ? 1 : (x < s.bnd[3] ? 2 : 3)));
         // collision radius r = √(area/π) and aspect factor: spherical regimes r = D/2 exactly; unrimed non-spherical area = γ D^σ:
         // r = √(γ/π)·D^(σ/2) (one exponential, no square root); only the partially rimed regime needs the mixed area and its root
-        FT eA = FT(0);
+        // aspect factor = exp(eA)·mA.  Partially rimed regime: the factor carries area^(−½), and √(area/π) is formed for the collision radius anyway — its
+        // reciprocal root y is the Newton iterate that square root is made of, so area^(−½) = y/√π (the 1/√π folded into h0) is free where eA −= ½ ln(area) cost a
+        // logarithm (≈ 20 Float64 instructions per node of every wave with a lane in that regime; round 5)
+        FT eA = FT(0), mA = FT(1);
         rr = FT(0.5) * x;
         if constexpr (SHARED) {
             if (reg == 1 || reg == 3) {
-                const FT dh = P::exp(v.half_sigma * logD, kk);
+                const FT dh = P::exp(ik.half_sigma * logD, kk);
                 if (reg == 1) {
-                    rr = v.sqrt_gamma_pi * dh;
-                    if (ASPECT) eA = v.g0 + v.g1 * logD;
+                    rr = ik.sqrt_gamma_pi * dh;
+                    if (ASPECT) eA = ik.g0 + ik.g1 * logD;
                 } else {
-                    const FT area = s.F_rim * (v.pi_4 * x * x) + (FT(1) - s.F_rim) * (v.gamma_area * (dh * dh));
-                    rr = M::sqrt(area * inv_pi);
-                    if (ASPECT) eA = h0 + h1 * logD - FT(0.5) * P::log_pos(area, kk);
+                    const FT area = s.F_rim * (ik.pi_4 * x * x) + (FT(1) - s.F_rim) * (ik.gamma_area * (dh * dh));
+                    const FT ap = area * inv_pi;
+                    if (ASPECT) { const FT y = M::rsqrt_pos(ap); rr = ap * y; mA = y; eA = h0 + h1 * logD; }
+                    else rr = M::sqrt(ap);
                 }
             }
         } else if (reg == 1) {
-            rr = v.sqrt_gamma_pi * P::exp(v.half_sigma * logD, kk);
-            if (ASPECT) eA = v.g0 + v.g1 * logD;
+            rr = ik.sqrt_gamma_pi * P::exp(ik.half_sigma * logD, kk);
+            if (ASPECT) eA = ik.g0 + ik.g1 * logD;
         } else if (reg == 3) {
-            const FT area = s.F_rim * (v.pi_4 * x * x) + (FT(1) - s.F_rim) * (v.gamma_area * P::exp(v.sigma_area * logD, kk));
-            rr = M::sqrt(area * inv_pi);
-            if (ASPECT) eA = h0 + h1 * logD - FT(0.5) * P::log_pos(area, kk);
+            const FT area = s.F_rim * (ik.pi_4 * x * x) + (FT(1) - s.F_rim) * (ik.gamma_area * P::exp(v.sigma_area * logD, kk));
+            const FT ap = area * inv_pi;
+            if (ASPECT) { const FT y = M::rsqrt_pos(ap); rr = ap * y; mA = y; eA = h0 + h1 * logD; }
+            else rr = M::sqrt(ap);
         }
         const bool small = x <= v.cutoff;
         const FT E1 = small ? se + sb * logD : le1 + v.l_b1 * logD;
         const FT dE = small ? -v.s_c2 * x : (le2 - le1) + (v.l_b2 - v.l_b1) * logD - v.l_c2 * x;
         const FT A1 = small ? kpin(v.s_E) : kpin(v.l_a1), A2 = small ? kpin(v.s_F) : kpin(v.l_a2);
-        vv = P::exp(ASPECT ? eA + E1 : E1, kk) * (A1 + A2 * P::exp(dE, kk));     // (without the aspect factor eA is the literal 0: no 0 + E1)
+        const FT S = A1 + A2 * P::exp(dE, kk);
+        vv = ASPECT ? P::exp(eA + E1, kk) * (mA * S) : P::exp(E1, kk) * S;      // (without the aspect factor: no 0 + E1, no 1·S)
         nn = P::exp(logN0 + mu * logD - lam * x, kk);
     };
     // rain Chen-2022 curve at ρₐ
@@ -690,7 +701,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
             for (int o = g; o < nq; o += GROUP) {
                 const FT Di = scale * q_node[o] + shift, w = q_wt[o] * scale;
                 FT v_i, r_i, n_i;
-                eval_ice(Di, v_i, r_i, n_i, kc, std::false_type{});
+                eval_ice(Di, v_i, r_i, n_i, kc, std::false_type{}, ik0);
                 const FT K0 = pi * (r_i * r_i), K1 = pi * r_i, K2 = FT(0.7853981633974483);
                 FT Nc = FT(0), Mc = FT(0), Bc = FT(0), Nr = FT(0), Mr = FT(0), Br = FT(0);
                 if (has_cloud) {
@@ -799,6 +810,8 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
         // these two sweeps run far below the kernel's register count (≈ 107 of 163–168 VGPRs): their integrands read the second polynomial coefficient
         // of exp / log from register pairs pinned HERE (cmx_p3.hpp coefs_local) — 5 v_mov_b64 fewer per inner node of the self-collection integral
         const typename P::LocalCoefs kl = P::coefs_local(D_lo_sc);
+        IceK ikp = ik0;
+        if constexpr (CMX_P3_LOCAL_COEFS) { P::pin(ikp.half_sigma); P::pin(ikp.sqrt_gamma_pi); P::pin(ikp.pi_4); P::pin(ikp.gamma_area); P::pin(ikp.g0); P::pin(ikp.g1); P::pin(ikp.bnd1); }
         if (present) {
             FT bs[5];
             bs[0] = D_lo_sc; bs[4] = D_hi_sc;
@@ -811,7 +824,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
                 for (int o = g; o < nq; o += GROUP) {
                     const FT D1 = scale * q_node[o] + shift;
                     FT v1, r1, n1;
-                    eval_ice(D1, v1, r1, n1, kl, std::true_type{});
+                    eval_ice(D1, v1, r1, n1, kl, std::true_type{}, ikp);
                     FT inner = FT(0);
                     for (int h = 0; h < 2; ++h) {   // inner integral split at the |v₁ − v₂| cusp D₂ = D₁
                         const FT ia = h == 0 ? D_lo_sc : D1, ib = h == 0 ? D1 : D_hi_sc;
@@ -820,7 +833,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
                         FT r_in = FT(0);
                         for (int j = 0; j < nq; ++j) {
                             FT v2, r2, n2;
-                            eval_ice(sc2 * q_node[j] + sh2, v2, r2, n2, kl, std::true_type{});
+                            eval_ice(sc2 * q_node[j] + sh2, v2, r2, n2, kl, std::true_type{}, ikp);
                             const FT rs = r1 + r2;
                             r_in += rs * rs * P::abs(v1 - v2) * n2 * q_wt[j];
                         }
@@ -847,7 +860,7 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
                     for (int o = g; o < nq; o += GROUP) {
                         const FT x = scale * q_node[o] + shift;
                         FT vD, rD_, nD;
-                        eval_ice(x, vD, rD_, nD, kl, std::true_type{});
+                        eval_ice(x, vD, rD_, nD, kl, std::true_type{}, ikp);
                         const FT Fv = k.vent_a + k.vent_bc * M::sqrt(M::max(x * vD, FT(0)));
                         const FT dm_over_D = mb == FT(3) ? ma * mb * x : ma * mb * P::exp((mb - FT(2)) * P::log(x));   // ∂m/∂D / D
                         acc_m += dm_over_D * Fv * nD * (q_wt[o] * scale);

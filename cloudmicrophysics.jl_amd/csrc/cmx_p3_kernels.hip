@@ -215,10 +215,11 @@ __global__ __launch_bounds__(kP3BS) void p3_velocity_kernel(const P3Consts<FT> c
                 const FT x = scale * quad.node[j] + shift, w = quad.weight[j];
                 const FT logD = P::log_pos(x, kc);          // an interior quadrature node: positive, normal, finite
                 const FT eN = logN0 + mu * logD - lam_ * x;                 // log n(D)
-                FT eA = q0 + q1 * logD;                                      // log of the aspect factor
+                const FT eA = q0 + q1 * logD;                                // log of the aspect factor — but for the area^(−½) of the partially rimed segment:
+                FT mA = FT(1);                                               // a reciprocal square root (≈ 9 Float64 instructions) where eA −= ½ ln(area) cost a logarithm (≈ 20)
                 if (mixed_area) {
                     const FT area = s.F_rim * k_pi4 * x * x + (FT(1) - s.F_rim) * k_ga * P::exp(k_sa * logD, kc);
-                    eA -= FT(0.5) * P::log_pos(area, kc);
+                    mA = Math<FT>::rsqrt_pos(area);
                 }
                 // Chen-2022 particle speed Σ aₖ D^bₖ e^{−cₖD}: the two terms have opposite signs and cancel to ≈1/200 of
                 // their size for small D, so the shared factor stays OUTSIDE the difference (as D^b does in the reference)
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(kP3BS) void p3_velocity_kernel(const P3Consts<FT> c
                 const FT E1 = small ? se + sb * logD : le1 + k_lb1 * logD;
                 const FT dE = small ? -k_sc2 * x : (le2 - le1) + k_db * logD - k_lc2 * x;   // E2 − E1
                 const FT A1 = small ? k_sE : k_la1, A2 = small ? k_sF : k_la2;
-                const FT S = A1 + A2 * P::exp(dE, kc);
+                const FT S = mixed_area ? mA * (A1 + A2 * P::exp(dE, kc)) : A1 + A2 * P::exp(dE, kc);
                 if constexpr (!MELT) {
                     const FT nv = P::exp(eN + eA + E1, kc) * S;
                     // m(D) = a D^b: b = 3 on the spherical segments (no transcendental), β_va otherwise
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(kP3BS) void p3_self_collection_kernel(const P3Const
 #pragma unroll
         for (int k = 1; k < 4; ++k) bnd[k] = Math<FT>::min(Math<FT>::max(s.bnd[k], D_lo), D_hi);
         const FT Fu = Math<FT>::max(FT(1) - s.F_rim, P::eps());
-        const FT h0 = (v.h0_num - P::log(Fu)) / FT(3), h1 = c.beta_va / FT(3);
+        const FT h0 = (v.h0_num - P::log(Fu)) / FT(3) - FT(0.5723649429247001), h1 = c.beta_va / FT(3);      // incl. the −½ ln π of area^(−½) = y/√π (eval below)
         const bool unrimed = s.F_rim == FT(0);
         const FT inv_pi = FT(0.3183098861837907);
         const typename P::Coefs kc = P::coefs();
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(kP3BS) void p3_self_collection_kernel(const P3Const
             // collision radius r = √(area/π) and aspect factor: spherical regimes r = D/2 exactly; unrimed non-spherical area = γ D^σ:
             // r = √(γ/π)·D^(σ/2) (one exponential, no square root); only the partially rimed regime needs the mixed area and its root.  D^(σ/2) serves
             // both non-spherical laws (γ D^σ is its square): lanes of one wave sit in both regimes, so the wave evaluates one exponential, not two
-            FT eA = FT(0);
+            FT eA = FT(0), mA = FT(1);      // aspect factor = exp(eA)·mA: the partially rimed regime's area^(−½) is the reciprocal root of its √(area/π) (cmx_p3_collisions.hip eval_ice)
             rr = FT(0.5) * x;
             if (reg == 1 || reg == 3) {
                 const FT dh = P::exp(v.half_sigma * logD, kc);
@@ -390,15 +391,17 @@ __global__ __launch_bounds__(kP3BS) void p3_self_collection_kernel(const P3Const
                     if (ASPECT) eA = v.g0 + v.g1 * logD;
                 } else {
                     const FT area = s.F_rim * (v.pi_4 * x * x) + (FT(1) - s.F_rim) * (v.gamma_area * (dh * dh));
-                    rr = Math<FT>::sqrt(area * inv_pi);
-                    if (ASPECT) eA = h0 + h1 * logD - FT(0.5) * P::log_pos(area, kc);
+                    const FT ap = area * inv_pi;
+                    if (ASPECT) { const FT y = Math<FT>::rsqrt_pos(ap); rr = ap * y; mA = y; eA = h0 + h1 * logD; }
+                    else rr = Math<FT>::sqrt(ap);
                 }
             }
             const bool small = x <= v.cutoff;
             const FT E1 = small ? se + sb * logD : le1 + v.l_b1 * logD;
             const FT dE = small ? -v.s_c2 * x : (le2 - le1) + (v.l_b2 - v.l_b1) * logD - v.l_c2 * x;
             const FT A1 = small ? kpin(v.s_E) : kpin(v.l_a1), A2 = small ? kpin(v.s_F) : kpin(v.l_a2);
-            vv = P::exp(ASPECT ? eA + E1 : E1, kc) * (A1 + A2 * P::exp(dE, kc));
+            const FT S = A1 + A2 * P::exp(dE, kc);
+            vv = ASPECT ? P::exp(eA + E1, kc) * (mA * S) : P::exp(E1, kc) * S;
             nn = P::exp(logN0 + mu * logD - lam * x, kc);
         };
         FT total = FT(0);
