@@ -148,6 +148,30 @@ def test_product_never_imports_the_oracle():
             assert "oracle_binding" not in txt and "libcmx_oracle" not in txt and "cmxo_" not in txt, p
 
 
+def test_contraction_is_bracketed_around_the_p3_code_only():
+    """The library is built with -ffp-contract=off (Makefile) so that every kernel sharing a point function rounds alike; the P3 quadrature / incomplete-gamma code is
+    the one bracketed exception (cmx_p3.hpp CMX_P3_CONTRACT_BEGIN / END).  The pointwise part of the 2M + P3 entry must stay OUTSIDE the bracket: it is bit-identical to
+    the warm-rain entry (tests/test_mp2m_p3_gpu.py::test_reduces_to_warm_rain_without_ice_and_validates) only as long as it is compiled like that entry."""
+    csrc = REPO / "cloudmicrophysics.jl_amd" / "csrc"
+    assert "-ffp-contract=off" in (csrc / "Makefile").read_text()
+    users = {p.name: p.read_text() for p in csrc.iterdir() if p.suffix in (".hip", ".hpp") and "CMX_P3_CONTRACT_BEGIN" in p.read_text()}
+    assert sorted(users) == ["cmx_p3.hpp", "cmx_p3_collisions.hip", "cmx_p3_kernels.hip"]
+    for name, txt in users.items():
+        code = "\n".join(l for l in txt.splitlines() if not l.lstrip().startswith(("//", "#define", "#if", "#else", "#endif")))
+        assert code.count("CMX_P3_CONTRACT_BEGIN") == code.count("CMX_P3_CONTRACT_END") == 1, name      # one bracket per file, closed
+        assert code.index("CMX_P3_CONTRACT_BEGIN") < code.index("CMX_P3_CONTRACT_END"), name
+    col = users["cmx_p3_collisions.hip"]
+    begin, end = col.index("\nCMX_P3_CONTRACT_BEGIN"), col.index("\nCMX_P3_CONTRACT_END")
+    for outside in ("void mp2m_p3_point(", "void mp2m_p3_pointwise_kernel(", "void liquid_freezing_kernel(", '#include "cmx_sb2006.hpp"'):
+        at = col.index(outside)
+        assert at < begin or at > end, outside
+    assert begin < col.index("void p3_collision_kernel(") < end
+    # no other file switches contraction on
+    for p in csrc.iterdir():
+        if p.suffix in (".hip", ".hpp", ".inc") and p.name != "cmx_p3.hpp":
+            assert "fp contract" not in p.read_text() and "ffp-contract=fast" not in p.read_text(), p.name
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "nope.so")
