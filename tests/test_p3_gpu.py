@@ -400,6 +400,35 @@ def test_ice_self_collection(dev, oracle, ft):
                       pinned_by="oracle restatement of src/P3_processes.jl:676-712 (the reference tests sign and zero only)", assert_wellcond=True)
 
 
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+@pytest.mark.parametrize("f_rim", [0.5, 0.9, 0.99])
+def test_ice_self_collection_of_heavily_rimed_ice(dev, oracle, ft, f_rim):
+    """States in which the partially rimed regime (D > D_cr, mixed area law) carries the integral: the device forms that regime's area^(−½) from the reciprocal
+    root of its collision radius (round 5, cmx_p3_kernels.hip / cmx_p3_collisions.hip), the oracle takes exp(−½ ln area) as the reference writes it
+    (src/P3_particle_properties.jl ϕᵢ with the mixed area).  Both aspect settings; the same bound as the random-state test."""
+    import cmx
+    from cmx import synthetic
+    m = 1_500
+    rng = np.random.default_rng(int(f_rim * 100))
+    L = np.exp(rng.uniform(np.log(1e-6), np.log(1e-3), m)); N = np.exp(rng.uniform(np.log(1e2), np.log(1e6), m))
+    st = [torch.tensor(v, dtype=DT[ft]) for v in (L, N, np.full(m, f_rim), rng.uniform(200.0, 800.0, m))]
+    p, vel = P.ParametersP3(ft), P.Chen2022VelTypeIce(ft)
+    rho_a = synthetic.p3_air_density(m, dtype=DT[ft])
+    dcols = [c.to(dev) for c in st]
+    ll = cmx.p3_shape(p, *dcols, from_state=True, want=("log_lambda",), brent_iters=40).log_lambda
+    c64 = [c.numpy().astype(np.float64) for c in st]
+    for aspect in (True, False):
+        got = _np64(cmx.p3_ice_self_collection(p, vel, rho_a.to(dev), *dcols, ll, from_state=True, aspect_ratio=aspect, quad=P.GaussLegendre(ft, 12)))
+        ref = oracle.p3_ice_self_collection(_abi.F64, P.ParametersP3("f64").c, P.Chen2022VelTypeIce("f64"), P.GaussLegendre("f64", 12),
+                                            STATE | (0 if aspect else _abi.CMX_P3_NO_ASPECT_RATIO), *c64, rho_a.numpy().astype(np.float64), _np64(ll),
+                                            float32_gates=(ft == "f32"), nthreads=8)
+        nz = ref != 0
+        assert nz.mean() > 0.9 and np.array_equal(got == 0, ref == 0)
+        e = np.abs(got[nz] - ref[nz]) / ref[nz]
+        print(f"\n[P3 self-collection, F_rim = {f_rim}] {ft} aspect={aspect}: max rel err {e.max():.2e}")
+        assert e.max() <= RTOL[ft]
+
+
 @pytest.mark.parametrize("ft", ["f32", "f64"])
 def test_fused_shape_and_velocities_is_the_two_calls(dev, ft):
     """cmx_p3_shape_terminal_velocities_* (BASELINE config 5 as one launch) against cmx_p3_shape_* followed by
