@@ -98,6 +98,32 @@ __device__ __forceinline__ void store_col(FT *__restrict__ p, int64_t i, const F
     else reinterpret_cast<V *>(p)[i] = v;
 }
 
+// Workgroup-base addressing (round 6): `wg` = the column's address at the workgroup's first vector — a UNIFORM pointer the compiler keeps in an SGPR pair —
+// plus the lane's own vector index as a 32-bit offset: one `global_load … v_off, s[base:base+1]` per access with ONE offset VGPR shared by every column,
+// where `p + i` with a 64-bit per-lane index costs an address pair per column (the per-element ARG kernel streams 4 + 5·NM columns: 16 VGPRs per mode).
+template <typename FT, int VEC, bool NT = true>
+__device__ __forceinline__ void load_col_wg(const FT *__restrict__ wg, uint32_t lane, FT (&x)[VEC]) {
+    using V = typename VecT<FT, VEC>::type;
+    const char *a = reinterpret_cast<const char *>(wg) + (uint32_t)(lane * (uint32_t)sizeof(V));
+    V v;
+    if constexpr (NT) v = __builtin_nontemporal_load(reinterpret_cast<const V *>(a));
+    else v = *reinterpret_cast<const V *>(a);
+    const FT *e = reinterpret_cast<const FT *>(&v);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) x[k] = e[k];
+}
+template <typename FT, int VEC, bool NT = true>
+__device__ __forceinline__ void store_col_wg(FT *__restrict__ wg, uint32_t lane, const FT (&x)[VEC]) {
+    using V = typename VecT<FT, VEC>::type;
+    char *a = reinterpret_cast<char *>(wg) + (uint32_t)(lane * (uint32_t)sizeof(V));
+    V v;
+    FT *e = reinterpret_cast<FT *>(&v);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) e[k] = x[k];
+    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<V *>(a));
+    else *reinterpret_cast<V *>(a) = v;
+}
+
 // --- division of a 32-bit index by a run-time constant (Granlund & Montgomery 1994; Hacker's Delight §10-9) ---------------------
 // The layout and column kernels turn a flat element index into (run, offset) or (column, level).  As a 64-bit quotient through
 // doubles that is ≈ 40 VALU instructions per lane (conversions, a Float64 multiply, a 64-bit multiply-subtract, two fix-ups) — in the

@@ -140,9 +140,10 @@ def _family_of_current_test():
     return FAMILY_OF_MODULE.get(mod, mod or "unattributed")
 
 
-def assert_parity(got: dict, ref: dict, rtol: float, names=OUT_NAMES, what="", floor=None, min_frac=None):
+def assert_parity(got: dict, ref: dict, rtol: float, names=OUT_NAMES, what="", floor=None, min_frac=None, family=None, pinned_by=None, note=None):
     """got/ref: name → array; ref carries 'scale' (name → array) and 'near_branch' (bool mask).  Returns the worst
-    normalised error per output (must be ≤ rtol).  Also checks and records the plain relative bound (see above)."""
+    normalised error per output (must be ≤ rtol).  Also checks and records the plain relative bound (see above).
+    `family` / `pinned_by` / `note` override the report row's attribution (default: the test module's SURVEY §8 row, the KAT-pinned oracle)."""
     ft = _ft_of(rtol)
     near = ref.get("near_branch")
     keep = ~near if near is not None else slice(None)
@@ -166,8 +167,10 @@ def assert_parity(got: dict, ref: dict, rtol: float, names=OUT_NAMES, what="", f
                 f"ref {ref[k][i]!r} scale {(sc[i] if sc is not None else None)!r}")
         ps = plain_stats(got[k], ref[k], sc, rtol, floor, CEIL[ft], keep, WELLCOND[ft])
         REPORTS.append({"what": what.strip(), "output": k, "ft": ft, "rtol": rtol, "worst_normalised": worst, **ps,
-                        "family": _family_of_current_test(), "pinned_by": "oracle (pinned by the reference's KATs, tests/golden/)",
-                        "asserted": f"operand-scaled bound + fraction inside the plain bound >= {min_frac} + well-conditioned plain bound"})
+                        "family": family or _family_of_current_test(),
+                        "pinned_by": pinned_by or "oracle (pinned by the reference's KATs, tests/golden/)",
+                        "asserted": f"operand-scaled bound + fraction inside the plain bound >= {min_frac} + well-conditioned plain bound",
+                        **({"note": note} if note else {})})
         assert ps["frac_within"] >= min_frac, (
             f"{what} {k}: only {ps['frac_within']:.6f} of {ps['n']} points are within the plain relative bound {rtol:g} "
             f"(required {min_frac})")
