@@ -12,11 +12,90 @@
  *                           get_distribution_logλ :284-320
  *   src/P3_integral_properties.jl  D_m :56-61
  * of the reference.  SpecialFunctions.loggamma → libm lgamma; LogExpFunctions.xexpy(x, y) = x·eʸ.
- * RootSolvers.jl (compat "0.3, 0.4, 1"; un-vendored) BrentsMethod is restated from Brent's published algorithm
- * (inverse quadratic interpolation / secant with bisection safeguards); the reference runs it for a FIXED number
- * of iterations (8 Float32 / 10 Float64, P3_size_distribution.jl:311) — here `maxiters` is an input, and parity is
- * asserted on the converged root, not on the iterates.
+ * RootSolvers.jl (compat "0.3, 0.4, 1"; un-vendored, source ABSENT) BrentsMethod: the reference runs it for a FIXED number of
+ * iterations (8 Float32 / 10 Float64, P3_size_distribution.jl:311).  Its iterates cannot be restated from source; what pins the
+ * restatement is the reference's own warm-start suite (test/p3_shape_solver_warmstart_tests.jl:22-91, tests/golden/
+ * reference_suites.json): the cold start and nine narrowed brackets of 72 states must agree to 1e-4 (Float64, 10 iterations) /
+ * 1e-3 (Float32, 8).  o_brent_fixed below holds two candidates:
+ *   variant 0 (default since round 6)  Brent's zeroin (Brent 1973, Algorithms for Minimization without Derivatives, ch. 4; the
+ *              algorithm of netlib zeroin.f / Numerical Recipes zbrent) — passes that suite (worst 5e-7 at 10, 7e-4 at 8 iterations);
+ *   variant 1 (rounds 1-5)             the pseudo-code of the Wikipedia article "Brent's method" (c := b every iteration: after a
+ *              step that replaces `a` every proposal is refused until `b` moves) — FAILS it (1e-3 at 10, 3e-3 at 8 iterations),
+ *              kept for the exposure measurement of tests/test_reference_suites.py.
  */
+/* Quadrature rules beyond the ABI's struct (cmx_quadrature carries ≤ CMX_QUAD_MAX = 128 nodes; the reference's quadrature-order sweep compares
+ * against order 200, test/bulk_tendencies_quadrature_tests.jl:232): a rule set here replaces the `quad` argument of every P3 integral of this
+ * float type until it is cleared with n = 0.  Test infrastructure like the rest of the oracle; not thread-safe against concurrent setters. */
+#define CMXO_QUAD_OVERRIDE_MAX 1024
+static int FN(g_quad_n) = 0;
+static FT FN(g_quad_node)[CMXO_QUAD_OVERRIDE_MAX], FN(g_quad_weight)[CMXO_QUAD_OVERRIDE_MAX];
+int32_t FN(cmxo_set_quadrature_override)(int32_t n, const FT *node, const FT *weight) {
+    if (n < 0 || n > CMXO_QUAD_OVERRIDE_MAX) return -1;
+    for (int i = 0; i < n; ++i) { FN(g_quad_node)[i] = node[i]; FN(g_quad_weight)[i] = weight[i]; }
+    FN(g_quad_n) = n;
+    return 0;
+}
+#ifndef Q_N
+#define Q_N(q) (FN(g_quad_n) > 0 ? FN(g_quad_n) : (q)->n)
+#define Q_NODE(q, i) (FN(g_quad_n) > 0 ? FN(g_quad_node)[i] : (q)->node[i])
+#define Q_WEIGHT(q, i) (FN(g_quad_n) > 0 ? FN(g_quad_weight)[i] : (q)->weight[i])
+#endif
+static int FN(g_brent_variant) = 0;
+void FN(cmxo_set_brent_variant)(int32_t v) { FN(g_brent_variant) = v; }
+typedef FT (*TY(cmxo_fn1))(FT x, const void *ctx);
+/* the root of f on the bracket (a, b) with f(a) f(b) ≤ 0 after exactly `maxiters` further function evaluations (fewer once converged) */
+static inline FT FN(o_brent_fixed)(TY(cmxo_fn1) f, const void *ctx, FT a, FT b, FT fa, FT fb, int maxiters) {
+    if (FN(g_brent_variant) == 1) {
+        if (M_ABS(fa) < M_ABS(fb)) { FT t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
+        FT c = a, fc = fa, d = 0;
+        int mflag = 1;
+        for (int it = 0; it < maxiters; ++it) {
+            if (fb == 0 || a == b) break;
+            FT sx;
+            if (fa != fc && fb != fc)
+                sx = a * fb * fc / ((fa - fb) * (fa - fc)) + b * fa * fc / ((fb - fa) * (fb - fc)) + c * fa * fb / ((fc - fa) * (fc - fb));
+            else
+                sx = b - fb * (b - a) / (fb - fa);
+            FT lo3 = (3 * a + b) / 4;
+            int out_of_range = !((sx > FN(o_min)(lo3, b)) && (sx < FN(o_max)(lo3, b)));
+            if (out_of_range || (mflag && M_ABS(sx - b) >= M_ABS(b - c) / 2) || (!mflag && M_ABS(sx - b) >= M_ABS(c - d) / 2)) {
+                sx = (a + b) / 2;
+                mflag = 1;
+            } else {
+                mflag = 0;
+            }
+            FT fs = f(sx, ctx);
+            d = c; c = b; fc = fb;
+            if (fa * fs < 0) { b = sx; fb = fs; } else { a = sx; fa = fs; }
+            if (M_ABS(fa) < M_ABS(fb)) { FT t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
+        }
+        return b;
+    }
+    /* Brent's zeroin with t = 0: b the current iterate, a the previous one, c the end with the other sign; d the step, e the one before */
+    FT c = a, fc = fa, d = b - a, e = d;
+    for (int it = 0;; ++it) {
+        if ((fb > 0 && fc > 0) || (fb < 0 && fc < 0)) { c = a; fc = fa; d = b - a; e = d; }
+        if (M_ABS(fc) < M_ABS(fb)) { a = b; b = c; c = a; fa = fb; fb = fc; fc = fa; }
+        FT tol1 = 2 * M_EPS * M_ABS(b), xm = (c - b) / 2;
+        if (it >= maxiters || M_ABS(xm) <= tol1 || fb == 0) return b;       /* (the best end is returned: the ordering above ran after the last evaluation) */
+        if (M_ABS(e) >= tol1 && M_ABS(fa) > M_ABS(fb)) {
+            FT sq = fb / fa, pp, q;
+            if (a == c) { pp = 2 * xm * sq; q = 1 - sq; }                   /* secant */
+            else {                                                          /* inverse quadratic interpolation */
+                FT qa = fa / fc, r = fb / fc;
+                pp = sq * (2 * xm * qa * (qa - r) - (b - a) * (r - 1));
+                q = (qa - 1) * (r - 1) * (sq - 1);
+            }
+            if (pp > 0) q = -q;
+            pp = M_ABS(pp);
+            if (2 * pp < FN(o_min)(3 * xm * q - M_ABS(tol1 * q), M_ABS(e * q))) { e = d; d = pp / q; }
+            else { d = xm; e = d; }
+        } else { d = xm; e = d; }
+        a = b; fa = fb;
+        b += M_ABS(d) > tol1 ? d : (xm > 0 ? tol1 : -tol1);
+        fb = f(b, ctx);
+    }
+}
 
 typedef struct TY(cmxo_p3_state) {
     FT rho_q_ice, rho_n_ice, F_rim, rho_rim, rho_g, D_th, D_gr, D_cr;
@@ -132,22 +211,30 @@ static inline FT FN(o_loggamma_inc_moment)(FT D1, FT D2, FT mu, FT loglam, FT k,
     dq = FN(o_max)(dq, eps);
     return -z * loglam + M_LGAMMA(z) + M_LOG(dq) + M_LOG(scale);
 }
-/* logmass_gamma_moment — :193-200 (4 segments + unrolled_logsumexp, Utilities.jl:399-412) */
+/* UT.unrolled_logsumexp — src/Utilities.jl:399-412: the maximum with Julia's NaN rule (any NaN element makes it NaN), returned as it is when
+ * not finite (+Inf, −Inf, NaN: no Inf − Inf below), else max + log Σ exp(x_i − max) */
+static inline FT FN(o_unrolled_logsumexp)(const FT *x, int n) {
+    FT xmax = -(FT)INFINITY;
+    for (int i = 0; i < n; ++i) {
+        if (isnan(x[i])) xmax = x[i];
+        else if (!isnan(xmax) && x[i] > xmax) xmax = x[i];
+    }
+    if (!isfinite(xmax)) return xmax;
+    FT sum = 0;
+    for (int i = 0; i < n; ++i) sum += M_EXP(x[i] - xmax);
+    return xmax + M_LOG(sum);
+}
+/* logmass_gamma_moment — :193-200 (4 segments + unrolled_logsumexp) */
 static inline FT FN(o_logmass_gamma_moment)(const TY(cmx_p3_params) * pr, const TY(cmxo_p3_state) * s, FT mu, FT loglam,
                                            FT n, int gi_iters) {
     FT bnd[5] = {0, s->D_th, s->D_gr, s->D_cr, (FT)INFINITY};
-    FT m[4], xmax = -(FT)INFINITY;
+    FT m[4];
     for (int i = 0; i < 4; ++i) {
         FT a, b;
         FN(o_p3_mass_coeffs)(pr, s, (bnd[i] + bnd[i + 1]) / 2, &a, &b);
         m[i] = FN(o_loggamma_inc_moment)(bnd[i], bnd[i + 1], mu, loglam, b + n, a, gi_iters, s->eps);
-        if (isnan(m[i])) xmax = m[i];
-        else if (!isnan(xmax) && m[i] > xmax) xmax = m[i];
     }
-    if (!isfinite(xmax)) return xmax;
-    FT sum = 0;
-    for (int i = 0; i < 4; ++i) sum += M_EXP(m[i] - xmax);
-    return xmax + M_LOG(sum);
+    return FN(o_unrolled_logsumexp)(m, 4);
 }
 static inline FT FN(o_loggamma_moment)(FT mu, FT loglam, FT k) {   /* :151-157, scale = 1 */
     FT z = k + mu + 1;
@@ -158,12 +245,17 @@ static inline FT FN(o_logLdivN)(const TY(cmx_p3_params) * pr, uint32_t flags, co
     FT mu = FN(o_p3_mu)(pr, flags, loglam);
     return FN(o_logmass_gamma_moment)(pr, s, mu, loglam, (FT)0, gi_iters) - FN(o_loggamma_moment)(mu, loglam, (FT)0);
 }
-/* get_distribution_logλ — :284-320 (no warm-start guess), Brent's method on [2, 17] */
+/* get_distribution_logλ — :284-320 with the warm-start bracket of _narrow_bracket :336-353; Brent's method on [2, 17] */
+typedef struct TY(cmxo_shape_ctx) { const TY(cmx_p3_params) * pr; uint32_t flags; const TY(cmxo_p3_state) * s; FT target; int gi_iters; } TY(cmxo_shape_ctx);
+static FT FN(o_shape_problem)(FT loglam, const void *ctx) {
+    const TY(cmxo_shape_ctx) *k = (const TY(cmxo_shape_ctx) *)ctx;
+    return FN(o_logLdivN)(k->pr, k->flags, k->s, loglam, k->gi_iters) - k->target;
+}
 static inline FT FN(o_p3_loglambda)(const TY(cmx_p3_params) * pr, uint32_t flags, const TY(cmxo_p3_state) * s,
                                    const TY(cmxo_thresholds) * th, int maxiters, int gi_iters, const FT *guess) {
     if (s->rho_n_ice < th->eps_n || s->rho_q_ice < th->eps_m) return -(FT)INFINITY;
-    FT target = M_LOG(s->rho_q_ice) - M_LOG(s->rho_n_ice);
-#define SHAPE(x) (FN(o_logLdivN)(pr, flags, s, (x), gi_iters) - target)
+    TY(cmxo_shape_ctx) k = {pr, flags, s, M_LOG(s->rho_q_ice) - M_LOG(s->rho_n_ice), gi_iters};
+#define SHAPE(x) FN(o_shape_problem)((x), &k)
     FT a = 2, b = 17, fa = SHAPE(a), fb = SHAPE(b);
     if (!isfinite(fa) || !isfinite(fb) || fa * fb > 0) return M_ABS(fa) <= M_ABS(fb) ? a : b;
     if (guess) {   /* _narrow_bracket — :336-353 (a = lo, b = hi at this point) */
@@ -177,31 +269,8 @@ static inline FT FN(o_p3_loglambda)(const TY(cmx_p3_params) * pr, uint32_t flags
         if (left) { b = pc; fb = fp; }
         if (right) { a = pc; fa = fp; }
     }
-    if (M_ABS(fa) < M_ABS(fb)) { FT t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
-    FT c = a, fc = fa, d = 0;
-    int mflag = 1;
-    for (int it = 0; it < maxiters; ++it) {
-        if (fb == 0 || a == b) break;
-        FT sx;
-        if (fa != fc && fb != fc)
-            sx = a * fb * fc / ((fa - fb) * (fa - fc)) + b * fa * fc / ((fb - fa) * (fb - fc)) + c * fa * fb / ((fc - fa) * (fc - fb));
-        else
-            sx = b - fb * (b - a) / (fb - fa);
-        FT lo3 = (3 * a + b) / 4;
-        int out_of_range = !((sx > FN(o_min)(lo3, b)) && (sx < FN(o_max)(lo3, b)));
-        if (out_of_range || (mflag && M_ABS(sx - b) >= M_ABS(b - c) / 2) || (!mflag && M_ABS(sx - b) >= M_ABS(c - d) / 2)) {
-            sx = (a + b) / 2;
-            mflag = 1;
-        } else {
-            mflag = 0;
-        }
-        FT fs = SHAPE(sx);
-        d = c; c = b; fc = fb;
-        if (fa * fs < 0) { b = sx; fb = fs; } else { a = sx; fa = fs; }
-        if (M_ABS(fa) < M_ABS(fb)) { FT t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
-    }
 #undef SHAPE
-    return b;
+    return FN(o_brent_fixed)(FN(o_shape_problem), &k, a, b, fa, fb, maxiters);
 }
 /* D_m — src/P3_integral_properties.jl:56-61 */
 static inline FT FN(o_p3_D_m)(const TY(cmx_p3_params) * pr, uint32_t flags, const TY(cmxo_p3_state) * s, FT loglam, int gi_iters) {
@@ -342,8 +411,8 @@ static inline void FN(o_p3_velocities)(const TY(cmx_p3_params) * pr, const TY(cm
         FT a = bnd[k], b = bnd[k + 1];
         if (!(a < b)) continue;
         FT scale = (b - a) / 2, shift = (a + b) / 2, rn = 0, rm = 0;
-        for (int i = 0; i < quad->n; ++i) {
-            FT x = scale * quad->node[i] + shift, w = quad->weight[i];
+        for (int i = 0; i < Q_N(quad); ++i) {
+            FT x = scale * Q_NODE(quad, i) + shift, w = Q_WEIGHT(quad, i);
             FT nD = M_EXP(logN0 + mu * M_LOG(x) - lam * x);
             FT nv = nD * FN(o_p3_particle_velocity)(pr, s, &vt, x);
             rn += nv * w;
@@ -365,6 +434,10 @@ void FN(cmxo_p3_terminal_velocities)(const TY(cmx_p3_params) * pr, const TY(cmx_
                                                               : FN(o_p3_state_from_prognostic)(pr, rho_q_ice[i], rho_n_ice[i], x3[i], x4[i], th->eps_ft);
         FN(o_p3_velocities)(pr, vel, quad, flags, &s, rho_a[i], loglam[i], p, gi_iters, &v_n[i], &v_m[i]);
     }
+}
+/* CO.ventilation_factor — src/Common.jl:506-514: F_v(D) = a_v + b_v ∛N_Sc √N_Re(D), N_Sc = ν/D_v, N_Re = D v_term(D)/ν */
+static inline FT FN(o_ventilation_factor)(const TY(cmx_ventilation) * vent, const TY(cmx_air_properties) * aps, FT cbrt_Nsc, FT D, FT v_term) {
+    return vent->a + vent->b * cbrt_Nsc * M_SQRT(D * v_term / aps->nu_air);
 }
 /* ice_melt — src/P3_processes.jl:64-94 (QIMLT of Morrison & Milbrandt 2015): dL/dt = 4 K/L_f (T − T_freeze) ∫ ∂m/∂D F_v(D) N′(D)/D dD
  * with the ventilation factor CO.ventilation_factor (src/Common.jl:506-514); dN/dt = N/L · dL/dt. */
@@ -395,13 +468,13 @@ static inline void FN(o_p3_ice_melt)(const TY(cmx_p3_params) * pr, const TY(cmx_
         FT a = bnd[k], b = bnd[k + 1];
         if (!(a < b)) continue;
         FT scale = (b - a) / 2, shift = (a + b) / 2, r = 0;
-        for (int i = 0; i < quad->n; ++i) {
-            FT x = scale * quad->node[i] + shift, w = quad->weight[i];
+        for (int i = 0; i < Q_N(quad); ++i) {
+            FT x = scale * Q_NODE(quad, i) + shift, w = Q_WEIGHT(quad, i);
             FT nD = M_EXP(logN0 + mu * M_LOG(x) - lam * x);
             FT ma, mb;
             FN(o_p3_mass_coeffs)(pr, s, x, &ma, &mb);
             FT dm = ma * mb * M_POW(x, mb - 1);                                       /* ∂ice_mass_∂D :394-397 */
-            FT Fv = vent->a + vent->b * cbrt_Nsc * M_SQRT(x * FN(o_p3_particle_velocity)(pr, s, &vt, x) / aps->nu_air);
+            FT Fv = FN(o_ventilation_factor)(vent, aps, cbrt_Nsc, x, FN(o_p3_particle_velocity)(pr, s, &vt, x));
             r += dm * Fv * nD / x * w;
         }
         total += scale * r;
@@ -446,8 +519,8 @@ static inline FT FN(o_p3_ice_self_collection)(const TY(cmx_p3_params) * pr, cons
         FT a = bnd[k], b = bnd[k + 1];
         if (!(a < b)) continue;
         FT scale = (b - a) / 2, shift = (a + b) / 2, r_out = 0;
-        for (int i = 0; i < quad->n; ++i) {
-            FT D1 = scale * quad->node[i] + shift;
+        for (int i = 0; i < Q_N(quad); ++i) {
+            FT D1 = scale * Q_NODE(quad, i) + shift;
             FT v1 = FN(o_p3_particle_velocity)(pr, s, &vt, D1);
             FT r1 = M_SQRT(FN(o_p3_ice_area)(pr, s, D1) / pi);
             FT inner = 0;
@@ -455,16 +528,16 @@ static inline FT FN(o_p3_ice_self_collection)(const TY(cmx_p3_params) * pr, cons
                 FT ia = h == 0 ? D_lo : D1, ib = h == 0 ? D1 : D_hi;
                 if (!(ia < ib)) continue;
                 FT sc2 = (ib - ia) / 2, sh2 = (ia + ib) / 2, r_in = 0;
-                for (int j = 0; j < quad->n; ++j) {
-                    FT D2 = sc2 * quad->node[j] + sh2;
+                for (int j = 0; j < Q_N(quad); ++j) {
+                    FT D2 = sc2 * Q_NODE(quad, j) + sh2;
                     FT v2 = FN(o_p3_particle_velocity)(pr, s, &vt, D2);
                     FT r2 = M_SQRT(FN(o_p3_ice_area)(pr, s, D2) / pi);
                     FT K = pi * (r1 + r2) * (r1 + r2);
-                    r_in += K * M_ABS(v1 - v2) * M_EXP(logN0 + mu * M_LOG(D2) - lam * D2) * quad->weight[j];
+                    r_in += K * M_ABS(v1 - v2) * M_EXP(logN0 + mu * M_LOG(D2) - lam * D2) * Q_WEIGHT(quad, j);
                 }
                 inner += sc2 * r_in;
             }
-            r_out += inner * M_EXP(logN0 + mu * M_LOG(D1) - lam * D1) * quad->weight[i];
+            r_out += inner * M_EXP(logN0 + mu * M_LOG(D1) - lam * D1) * Q_WEIGHT(quad, i);
         }
         total += scale * r_out;
     }
@@ -491,6 +564,17 @@ FT FN(cmxo_p3_particle_velocity)(const TY(cmx_p3_params) * pr, const TY(cmx_chen
     FN(o_chen_large_ice)(&vel->large_ice, rho_a, (FT)916.7, vt.al, vt.bl, vt.cl);
     vt.cutoff = vel->small_ice.cutoff; vt.aspect = !(flags & CMX_P3_NO_ASPECT_RATIO);
     return FN(o_p3_particle_velocity)(pr, &s, &vt, D);
+}
+/* the ventilation factor of an ice particle of the state (F_rim, ρ_rim) at diameter D — test/ventilation_tests.jl:8-30 */
+FT FN(cmxo_p3_ventilation_factor)(const TY(cmx_p3_params) * pr, const TY(cmx_chen2022_ice_vel) * vel, const TY(cmx_air_properties) * aps,
+                                 const TY(cmx_ventilation) * vent, uint32_t flags, FT F_rim, FT rho_rim, FT rho_a, FT D) {
+    return FN(o_ventilation_factor)(vent, aps, M_CBRT(aps->nu_air / aps->D_vapor), D, FN(cmxo_p3_particle_velocity)(pr, vel, flags, F_rim, rho_rim, rho_a, D));
+}
+FT FN(cmxo_unrolled_logsumexp)(int32_t n, const FT *x) { return FN(o_unrolled_logsumexp)(x, n); }
+/* get_ρ_g(F_rim, ρ_rim, ρ_d) — src/P3_particle_properties.jl:219 with weighted_average :293-295 */
+FT FN(cmxo_p3_rho_g)(const TY(cmx_p3_params) * pr, FT F_rim, FT rho_rim) {
+    TY(cmxo_p3_state) s = FN(o_p3_state)(pr, (FT)0, (FT)0, F_rim, rho_rim, M_EPS);
+    return s.rho_g;
 }
 FT FN(cmxo_gamma_inc_inv)(FT a, FT p, FT q) { return FN(o_gamma_inc_inv)(a, p, q, sizeof(FT) == 4 ? 20 : 30, M_EPS); }
 FT FN(cmxo_p3_rho_d)(const TY(cmx_p3_params) * pr, FT F_rim, FT rho_rim) { return FN(o_p3_rho_d)(pr, F_rim, rho_rim); }

@@ -6,7 +6,7 @@
  * 246-275).
  *
  * RootSolvers.jl (compat "0.3, 0.4, 1", un-vendored): crossover_diameter's Brent solve uses the same restated Brent
- * iteration as the shape solver (cmx_oracle_p3_impl.h); without a sign change the end point with the smaller |f| is
+ * iteration as the shape solver (o_brent_fixed, cmx_oracle_p3_impl.h); without a sign change the end point with the smaller |f| is
  * returned, which is what the reference's own test demands (test/p3_tests.jl:1057-1058: D_min for a target below the
  * curve, D_max above it). */
 
@@ -34,35 +34,16 @@ static inline FT FN(o_gamma_inc_moment)(FT D1, FT D2, FT p, FT alpha, int gi_ite
     return M_TGAMMA(z) * dq / M_POW(alpha, z);
 }
 /* crossover_diameter — src/P3_processes.jl:325-334: root of v_l(D) − v_target on [D_min, D_max], Brent, fixed 8 / 10 iterations */
+typedef struct TY(cmxo_cross_ctx) { const FT *ra, *rb, *rc; FT v_target; } TY(cmxo_cross_ctx);
+static FT FN(o_cross_problem)(FT D, const void *ctx) {
+    const TY(cmxo_cross_ctx) *k = (const TY(cmxo_cross_ctx) *)ctx;
+    return FN(o_chen_rain_particle_velocity)(k->ra, k->rb, k->rc, D) - k->v_target;
+}
 static inline FT FN(o_crossover_diameter)(FT v_target, const FT ra[3], const FT rb[3], const FT rc[3], FT D_min, FT D_max, int maxiters) {
-#define XF(x) (FN(o_chen_rain_particle_velocity)(ra, rb, rc, (x)) - v_target)
-    FT a = D_min, b = D_max, fa = XF(a), fb = XF(b);
+    TY(cmxo_cross_ctx) k = {ra, rb, rc, v_target};
+    FT a = D_min, b = D_max, fa = FN(o_cross_problem)(a, &k), fb = FN(o_cross_problem)(b, &k);
     if (!isfinite(fa) || !isfinite(fb) || fa * fb > 0) return M_ABS(fa) <= M_ABS(fb) ? a : b;
-    if (M_ABS(fa) < M_ABS(fb)) { FT t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
-    FT c = a, fc = fa, d = 0;
-    int mflag = 1;
-    for (int it = 0; it < maxiters; ++it) {
-        if (fb == 0 || a == b) break;
-        FT sx;
-        if (fa != fc && fb != fc)
-            sx = a * fb * fc / ((fa - fb) * (fa - fc)) + b * fa * fc / ((fb - fa) * (fb - fc)) + c * fa * fb / ((fc - fa) * (fc - fb));
-        else
-            sx = b - fb * (b - a) / (fb - fa);
-        FT lo3 = (3 * a + b) / 4;
-        int out_of_range = !((sx > FN(o_min)(lo3, b)) && (sx < FN(o_max)(lo3, b)));
-        if (out_of_range || (mflag && M_ABS(sx - b) >= M_ABS(b - c) / 2) || (!mflag && M_ABS(sx - b) >= M_ABS(c - d) / 2)) {
-            sx = (a + b) / 2;
-            mflag = 1;
-        } else {
-            mflag = 0;
-        }
-        FT fs = XF(sx);
-        d = c; c = b; fc = fb;
-        if (fa * fs < 0) { b = sx; fb = fs; } else { a = sx; fa = fs; }
-        if (M_ABS(fa) < M_ABS(fb)) { FT t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
-    }
-#undef XF
-    return b;
+    return FN(o_brent_fixed)(FN(o_cross_problem), &k, a, b, fa, fb, maxiters);
 }
 
 /* everything ∫liquid_ice_collisions (src/P3_processes.jl:527-562) sets up once per point */
@@ -177,8 +158,8 @@ static inline void FN(o_liquid_integrals)(const TY(cmxo_p3col) * k, const TY(cmx
     *N = 0; *M = 0; *B = 0;
     if (!(a < b)) return;
     FT scale = (b - a) / 2, shift = (a + b) / 2, r1 = 0, r2 = 0, r3 = 0;
-    for (int j = 0; j < quad->n; ++j) {
-        FT D = scale * quad->node[j] + shift, w = quad->weight[j];
+    for (int j = 0; j < Q_N(quad); ++j) {
+        FT D = scale * Q_NODE(quad, j) + shift, w = Q_WEIGHT(quad, j);
         FT dv = M_ABS(v_i - FN(o_chen_rain_particle_velocity)(k->ra, k->rb, k->rc, D));
         FT Kc = M_FMA(D, M_FMA(D, K[2], K[1]), K[0]);                                  /* evalpoly :123-124 */
         FT V = (FT)1 * Kc * dv;                                                       /* E = 1 :142-144 */
@@ -224,8 +205,8 @@ static inline void FN(o_p3_collision_integrals)(const TY(cmxo_p3col) * k, const 
         FT a = k->ice_bnd[sg], b = k->ice_bnd[sg + 1];
         if (!(a < b)) continue;
         FT scale = (b - a) / 2, shift = (a + b) / 2, r[10] = {0};
-        for (int i = 0; i < quad->n; ++i) {
-            FT Di = scale * quad->node[i] + shift, w = quad->weight[i];
+        for (int i = 0; i < Q_N(quad); ++i) {
+            FT Di = scale * Q_NODE(quad, i) + shift, w = Q_WEIGHT(quad, i);
             FT v_i = FN(o_p3_particle_velocity)(pr, &k->s, &k->vt, Di);
             FT ri = M_SQRT(FN(o_p3_ice_area)(pr, &k->s, Di) / (FT)M_PI);
             FT K[3] = {(FT)M_PI * (ri * ri), (FT)M_PI * ri, (FT)(M_PI / 4)};

@@ -447,6 +447,53 @@ def p3_rho_d(fam, params, F_rim, rho_rim):
     return fn(C.addressof(params), F_rim, rho_rim)
 
 
+def set_quadrature_override(fam, nodes=None, weights=None):
+    """A quadrature rule of any order (≤ 1024) for every P3 integral of this float type, replacing the `quad` argument until cleared (no arguments).
+    The ABI's cmx_quadrature carries ≤ 128 nodes; the reference's order sweep compares against order 200."""
+    fn = getattr(lib(), f"cmxo_set_quadrature_override_{fam.sfx}")
+    fn.restype = C.c_int32
+    fn.argtypes = [C.c_int32, C.c_void_p, C.c_void_p]
+    if nodes is None:
+        assert fn(0, None, None) == 0
+        return
+    x = np.ascontiguousarray(nodes, dtype=NP[fam.sfx])
+    w = np.ascontiguousarray(weights, dtype=NP[fam.sfx])
+    assert x.size == w.size and fn(x.size, x.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p)) == 0
+
+
+def set_brent_variant(v: int):
+    """0: Brent's zeroin (default); 1: the Wikipedia pseudo-code variant of rounds 1-5 (cmx_oracle_p3_impl.h o_brent_fixed).  Both float types."""
+    for sfx in ("f32", "f64"):
+        fn = getattr(lib(), f"cmxo_set_brent_variant_{sfx}")
+        fn.restype = None
+        fn.argtypes = [C.c_int32]
+        fn(v)
+
+
+def p3_rho_g(fam, params, F_rim, rho_rim):
+    fn = getattr(lib(), f"cmxo_p3_rho_g_{fam.sfx}")
+    fn.restype = fam.ft
+    fn.argtypes = [C.c_void_p, fam.ft, fam.ft]
+    return fn(C.addressof(params), F_rim, rho_rim)
+
+
+def p3_ventilation_factor(fam, params, vel, aps, vent, flags, F_rim, rho_rim, rho_a, D):
+    """CO.ventilation_factor(vent, aps, P3.ice_particle_terminal_velocity(vel, ρₐ, state))(D) — src/Common.jl:506-514."""
+    fn = getattr(lib(), f"cmxo_p3_ventilation_factor_{fam.sfx}")
+    fn.restype = fam.ft
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, fam.ft, fam.ft, fam.ft, fam.ft]
+    return fn(C.addressof(params), C.addressof(vel), C.addressof(aps), C.addressof(vent), flags, F_rim, rho_rim, rho_a, D)
+
+
+def unrolled_logsumexp(fam, x):
+    """UT.unrolled_logsumexp — src/Utilities.jl:399-412."""
+    a = np.ascontiguousarray(x, dtype=NP[fam.sfx])
+    fn = getattr(lib(), f"cmxo_unrolled_logsumexp_{fam.sfx}")
+    fn.restype = fam.ft
+    fn.argtypes = [C.c_int32, C.c_void_p]
+    return fn(a.size, a.ctypes.data_as(C.c_void_p))
+
+
 def p3_logLdivN(fam, params, flags, F_rim, rho_rim, loglam):
     fn = getattr(lib(), f"cmxo_p3_logLdivN_{fam.sfx}")
     fn.restype = fam.ft

