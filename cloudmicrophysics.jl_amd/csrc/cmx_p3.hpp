@@ -179,6 +179,51 @@ template <> struct PM<float> {
     static constexpr float eps() { return 1.1920928955078125e-07f; }
 };
 
+// ---- Brent's method with a fixed number of function evaluations ----------------------------------------------------------------------------------
+// RootSolvers.BrentsMethod under the reference's FixedIterations tolerance (src/P3_size_distribution.jl:250-251,311-319; src/P3_processes.jl:325-334).
+// RootSolvers' source is not vendored: the algorithm is Brent's zeroin (Brent 1973, ch. 4; netlib zeroin.f, Numerical Recipes zbrent) with t = 0 — the
+// restatement that satisfies the reference's own warm-start suite (test/p3_shape_solver_warmstart_tests.jl, tests/test_reference_suites*.py), which the
+// Wikipedia pseudo-code variant of rounds 1–5 fails (oracle/cmx_oracle_p3_impl.h o_brent_fixed holds both).  Same operations in the same order as the
+// oracle's.  Usage: start(); then per evaluation: if (!order()) stop; x = propose(); accept(f(x)); after the last evaluation order() once more: b is
+// the better end.
+template <typename FT> struct Zeroin {
+    FT a, b, c, fa, fb, fc, d, e;      // b: current iterate, a: the previous one, c: the end with the other sign; d: the step, e: the one before
+    __device__ __forceinline__ void start(FT lo, FT hi, FT f_lo, FT f_hi) {
+        a = lo; b = hi; fa = f_lo; fb = f_hi; c = a; fc = fa; d = b - a; e = d;
+    }
+    __device__ __forceinline__ FT tol1() const { return FT(2) * PM<FT>::eps() * PM<FT>::abs(b); }
+    // orders the ends; false once the bracket has collapsed to 2 eps |b| or f(b) = 0
+    __device__ __forceinline__ bool order() {
+        using P = PM<FT>;
+        if ((fb > FT(0) && fc > FT(0)) || (fb < FT(0) && fc < FT(0))) { c = a; fc = fa; d = b - a; e = d; }
+        if (P::abs(fc) < P::abs(fb)) { a = b; b = c; c = a; fa = fb; fb = fc; fc = fa; }
+        return !(P::abs((c - b) / FT(2)) <= tol1() || fb == FT(0));
+    }
+    // the next abscissa: inverse quadratic interpolation / secant where it stays inside and shrinks fast enough, else bisection
+    __device__ __forceinline__ FT propose() {
+        using P = PM<FT>;
+        const FT t1 = tol1(), xm = (c - b) / FT(2);
+        if (P::abs(e) >= t1 && P::abs(fa) > P::abs(fb)) {
+            const FT sq = fb / fa;
+            FT pp, q;
+            if (a == c) { pp = FT(2) * xm * sq; q = FT(1) - sq; }
+            else {
+                const FT qa = fa / fc, r = fb / fc;
+                pp = sq * (FT(2) * xm * qa * (qa - r) - (b - a) * (r - FT(1)));
+                q = (qa - FT(1)) * (r - FT(1)) * (sq - FT(1));
+            }
+            if (pp > FT(0)) q = -q;
+            pp = P::abs(pp);
+            if (FT(2) * pp < Math<FT>::min(FT(3) * xm * q - P::abs(t1 * q), P::abs(e * q))) { e = d; d = pp / q; }
+            else { d = xm; e = d; }
+        } else { d = xm; e = d; }
+        a = b; fa = fb;
+        b += P::abs(d) > t1 ? d : (xm > FT(0) ? t1 : -t1);
+        return b;
+    }
+    __device__ __forceinline__ void accept(FT f_b) { fb = f_b; }
+};
+
 template <typename FT> struct P3Consts {
     uint32_t flags;
     int32_t brent_iters;   // fixed Brent iteration budget (P3_size_distribution.jl:311: 8 Float32 / 10 Float64)

@@ -723,28 +723,16 @@ __global__ __launch_bounds__(kBlock, CMX_COL_WAVES) void p3_collision_kernel(con
                         FT fa = v_liq_s(xa, P::log(xa, kc)) - v_i, fb = v_liq_s(xb, P::log(xb, kc)) - v_i;
                         if (!(fa * fb <= FT(0))) Dstar = P::abs(fa) <= P::abs(fb) ? xa : xb;
                         else {
-                            if (P::abs(fa) < P::abs(fb)) { FT t = xa; xa = xb; xb = t; t = fa; fa = fb; fb = t; }
-                            FT xc = xa, fc = fa, xd = FT(0);
-                            bool mflag = true;
+                            Zeroin<FT> z;                       // cmx_p3.hpp: Brent's zeroin under the fixed evaluation budget
+                            z.start(xa, xb, fa, fb);
+                            bool live = true;
                             for (int it = 0; it < k.brent_iters; ++it) {
-                                if (fb == FT(0) || xa == xb) break;
-                                FT sx;
-                                if (fa != fc && fb != fc)
-                                    sx = xa * fb * fc / ((fa - fb) * (fa - fc)) + xb * fa * fc / ((fb - fa) * (fb - fc)) + xc * fa * fb / ((fc - fa) * (fc - fb));
-                                else
-                                    sx = xb - fb * (xb - xa) / (fb - fa);
-                                const FT lo3 = (FT(3) * xa + xb) / FT(4);
-                                const bool out_of_range = !((sx > M::min(lo3, xb)) && (sx < M::max(lo3, xb)));
-                                if (out_of_range || (mflag && P::abs(sx - xb) >= P::abs(xb - xc) / FT(2)) ||
-                                    (!mflag && P::abs(sx - xb) >= P::abs(xc - xd) / FT(2))) {
-                                    sx = (xa + xb) / FT(2); mflag = true;
-                                } else mflag = false;
-                                const FT fs = v_liq_s(sx, P::log(sx, kc)) - v_i;
-                                xd = xc; xc = xb; fc = fb;
-                                if (fa * fs < FT(0)) { xb = sx; fb = fs; } else { xa = sx; fa = fs; }
-                                if (P::abs(fa) < P::abs(fb)) { FT t = xa; xa = xb; xb = t; t = fa; fa = fb; fb = t; }
+                                if (!z.order()) { live = false; break; }
+                                const FT sx = z.propose();
+                                z.accept(v_liq_s(sx, P::log(sx, kc)) - v_i);
                             }
-                            Dstar = xb;
+                            if (live) z.order();
+                            Dstar = z.b;
                         }
                     }
                     // crossing(p) = Σ_f coef_f Σ_i K_i α_f^{−z} [2γ(z, α_f D*) − γ(z, α_f D_lo) − γ(z, α_f D_hi)],  z = z₀_f + p + i,

@@ -16,8 +16,8 @@
 //     μ+1 instead of the reference's five calls; e^{logλ} is formed once per evaluation;
 //   * only the half (P or Q) of each incomplete-gamma pair that the segment difference needs is formed;
 //   * the Brent iteration count is fixed (as in the reference: no data-dependent exit → no divergence from it).
-// The solver is the same algorithm as the oracle's (Brent: inverse quadratic interpolation / secant with bisection
-// safeguards), so both land on the same root where the SlopePowerLaw makes the residual multi-rooted.
+// The solver is the same algorithm as the oracle's (cmx_p3.hpp Zeroin: Brent's zeroin under a fixed evaluation budget), so both land on the same
+// root where the SlopePowerLaw makes the residual multi-rooted.
 #include <hip/hip_runtime.h>
 
 #include "cmx_p3.hpp"
@@ -43,8 +43,9 @@ __device__ __forceinline__ FT p3_solve_loglam(const P3Consts<FT> &c, const P3Poi
         loglam = -INFINITY;
     } else {
         const FT target = P::log(s.rho_q) - P::log(s.rho_n);
-        FT a = FT(2), b = FT(17), fa = FT(0), fb = FT(0), cc = FT(0), fc = FT(0), d = FT(0);
-        bool mflag = true, active = true, guess_valid = false;
+        FT a = FT(2), b = FT(17), fa = FT(0), fb = FT(0);
+        Zeroin<FT> z;
+        bool active = true, guess_valid = false;
         const int first = guess ? -3 : -2;          // wave-uniform
         for (int it = first; it < c.brent_iters; ++it) {
             // which abscissa this step evaluates
@@ -57,19 +58,8 @@ __device__ __forceinline__ FT p3_solve_loglam(const P3Consts<FT> &c, const P3Poi
                 guess_valid = isfinite(pg) && (a < pg && pg < b);
                 sx = guess_valid ? pg : a;
             } else {
-                if (!active || fb == FT(0) || a == b) { active = false; continue; }
-                if (fa != fc && fb != fc)
-                    sx = a * fb * fc / ((fa - fb) * (fa - fc)) + b * fa * fc / ((fb - fa) * (fb - fc)) + cc * fa * fb / ((fc - fa) * (fc - fb));
-                else
-                    sx = b - fb * (b - a) / (fb - fa);
-                const FT lo3 = (FT(3) * a + b) / FT(4);
-                const bool out_of_range = !((sx > Math<FT>::min(lo3, b)) && (sx < Math<FT>::max(lo3, b)));
-                if (out_of_range || (mflag && P::abs(sx - b) >= P::abs(b - cc) / FT(2)) || (!mflag && P::abs(sx - b) >= P::abs(cc - d) / FT(2))) {
-                    sx = (a + b) / FT(2);
-                    mflag = true;
-                } else {
-                    mflag = false;
-                }
+                if (!active || !z.order()) { active = false; continue; }
+                sx = z.propose();
             }
             const FT fs = p3_logLdivN<FT>(c, s, sx) - target;
             // what the step does with the value
@@ -90,17 +80,15 @@ __device__ __forceinline__ FT p3_solve_loglam(const P3Consts<FT> &c, const P3Poi
                     if (right) { a = sx; fa = fs; }
                 }
             } else {
-                d = cc; cc = b; fc = fb;
-                if (fa * fs < FT(0)) { b = sx; fb = fs; } else { a = sx; fa = fs; }
-                if (P::abs(fa) < P::abs(fb)) { FT t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
+                z.accept(fs);
             }
-            // entering the Brent phase: order the bracket so that b is the better end, c = a
-            if (step < 0 && (guess ? step == -1 : step == -2) && active) {
-                if (P::abs(fa) < P::abs(fb)) { FT t = a; a = b; b = t; t = fa; fa = fb; fb = t; }
-                cc = a; fc = fa; d = FT(0); mflag = true;
+            // entering the Brent phase with the (possibly narrowed) bracket
+            if (step < 0 && (guess ? step == -1 : step == -2)) {
+                z.start(a, b, fa, fb);       // (without a sign change z.b = b is already the answer and `active` is off)
             }
         }
-        loglam = b;
+        if (active) z.order();               // after the last evaluation: b is the better end
+        loglam = z.b;
     }
     return loglam;
 }

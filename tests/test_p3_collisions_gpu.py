@@ -146,7 +146,7 @@ def test_edge_cases_and_validation(dev):
     S = np.stack([_np64(v) for v in src.values()])
     assert np.all(R[:, 0] == 0) and np.all(S[:, 0] == 0)                                 # no liquid
     assert np.all(R[3:6, 1] == 0) and R[8, 1] == 0 and R[0, 1] > 0                       # no rain
-    assert R[0, 2] == 0 and R[3, 2] == 0 and R[1, 2] > 0 and R[4, 2] > 0 and R[9, 2] == R[6, 2]   # above freezing: all shed, all wet
+    assert R[0, 2] == 0 and R[3, 2] == 0 and R[1, 2] > 0 and R[4, 2] > 0 and abs(R[9, 2] - R[6, 2]) <= 1e-14 * R[6, 2]   # above freezing: all shed, all wet (two accumulations of the same terms)
     assert R[1, 3] == 0 and R[4, 3] == 0 and R[9, 3] == 0 and R[0, 3] > 0                # very cold: f_frz = 1
     assert np.all(R[:, 4] == 0) and np.all(S[:, 4] == 0)                                 # absent ice
     with pytest.raises(TypeError):

@@ -57,7 +57,7 @@ OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 
 def scratch_in_loops(path, substring=""):
-    """{kernel name: (scratch instructions, those that lie inside a loop, those that lie inside an INNERMOST loop)} for the kernels whose mangled name contains `substring`,
+    """{kernel name: (scratch instructions, those that lie inside a loop, those that lie inside an INNERMOST loop, loops found)} for the kernels whose mangled name contains `substring`,
     from the disassembly of the built code objects.  A loop is the address range between a backward branch and its target; a spilled value that is
     stored / reloaded once between two phases of a kernel is outside every loop and costs nothing measurable, spill traffic inside a loop does."""
     out = {}
@@ -71,7 +71,7 @@ def scratch_in_loops(path, substring=""):
             if name is not None and substring in name:
                 inner = [(lo, hi) for lo, hi in loops if not any((l2, h2) != (lo, hi) and lo <= l2 and h2 <= hi for l2, h2 in loops)]
                 out[name] = (len(scr), sum(1 for a in scr if any(lo <= a <= hi for lo, hi in loops)),
-                             sum(1 for a in scr if any(lo <= a <= hi for lo, hi in inner)))
+                             sum(1 for a in scr if any(lo <= a <= hi for lo, hi in inner)), len(loops))
 
         for line in dis.splitlines():
             m = re.match(r"^([0-9a-f]{8,16}) <(\S+)>:$", line)
@@ -108,15 +108,19 @@ def main():
     lib = args[0] if args else str(Path(__file__).resolve().parent.parent / "cloudmicrophysics.jl_amd" / "csrc" / "libcmx.so")
     if "--loops" in sys.argv:      # scratch instructions of every kernel that has some: total and inside loops
         d = scratch_in_loops(lib)
-        for (name, (n, inside, innermost)), dem in zip(d.items(), demangle(list(d))):
+        for (name, (n, inside, innermost, _)), dem in zip(d.items(), demangle(list(d))):
             if n:
                 print(f"scratch instructions {n:3d}, inside loops {inside:3d}, inside innermost loops {innermost:3d} | {dem[:170]}")
         return
     ks = kernels(lib)
     if "--scratch" in sys.argv:
         ks = [k for k in ks if k["private"] or k["vgpr_spill"]]
+    # `scratch instr`: scratch_load / scratch_store instructions in the code.  A private segment WITHOUT any is the frame the compiler reserved for SGPR spills
+    # that then went to VGPR lanes (v_writelane): nothing touches memory.
+    scr = scratch_in_loops(lib)
     for k, name in zip(ks, demangle([k["name"] for k in ks])):
-        print(f"vgpr {k['vgpr']:3d} spill {k['vgpr_spill']:3d} | sgpr {k['sgpr']:3d} spill {k['sgpr_spill']:3d} | private {k['private']:4d} B | lds {k['lds']:6d} B | kernarg {k['kernarg']:4d} B | {name[:150]}")
+        print(f"vgpr {k['vgpr']:3d} spill {k['vgpr_spill']:3d} | sgpr {k['sgpr']:3d} spill {k['sgpr_spill']:3d} | private {k['private']:4d} B | scratch instr {scr.get(k['name'], (0,))[0]:2d} | "
+              f"lds {k['lds']:6d} B | kernarg {k['kernarg']:4d} B | {name[:150]}")
     print(f"{len(ks)} kernels")
 
 
