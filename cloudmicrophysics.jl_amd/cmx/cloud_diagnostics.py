@@ -24,6 +24,9 @@ def _call(ref, *, rain=None, sb=None, rho_w=0.0, rho, q_lcl=None, q_rai=None, N_
     fam = _fam_of(ref)
     outs = {k: (torch.empty_like(ref) if k in want else None) for k in ("Z_1m", "Z_2m", "reff_2m", "reff_lh97")}
     if out is not None:      # caller-provided output columns (no allocation in a time loop)
+        missing = [k for k in want if getattr(out, k, None) is None]
+        if missing:
+            raise ValueError(f"`out` holds no column for the requested output(s) {missing}: pass want=(…) for the columns it does hold")
         for k in want:
             _check_cols([ref, getattr(out, k)], ["rho", k])
             outs[k] = getattr(out, k)
@@ -35,7 +38,8 @@ def _call(ref, *, rain=None, sb=None, rho_w=0.0, rho, q_lcl=None, q_rai=None, N_
         pdf_c, pdf_r = sb.pdf_c, sb.pdf_r
         limited = getattr(sb, "is_limited", None)
         if limited is None:     # a bare C struct: the not-limited constructor leaves the N0 / lambda limiters at zero
-            limited = (0 < pdf_r.N0_min <= pdf_r.N0_max) and (0 < pdf_r.lambda_min <= pdf_r.lambda_max)
+            # (all three limiter pairs, like the entry's own check sb_limiters_ok: a struct with N0 / lambda limiters but a zero x_r pair is not a limited PSD)
+            limited = ((0 < pdf_r.N0_min <= pdf_r.N0_max) and (0 < pdf_r.lambda_min <= pdf_r.lambda_max) and (0 < pdf_r.xr_min <= pdf_r.xr_max))
         flags = _abi.CMX_SB2006_LIMITED if limited else 0
     if rain is not None and not isinstance(rain, fam.rain):
         raise TypeError("rain parameter float type does not match the state columns")

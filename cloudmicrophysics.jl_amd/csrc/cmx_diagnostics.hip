@@ -56,7 +56,9 @@ __device__ __forceinline__ void diag_point(const C &c, bool w1, bool w2, bool wr
         const FT sq_r = M::max(q_rai, eps), sN_r = M::max(N_rai, eps);
         const SbRainPsd<FT> psd = sb2006_rain_psd<FT, LIMITED>(c, rho * sq_r, sN_r);
         const bool no_rain = LIMITED ? (N_rai < eps && q_rai < eps) : (N_rai < eps || q_rai < eps);
-        const FT l2_Nr = M::log2(N_rai), dxr = psd.l2_xr - c.l2_6;
+        // the moments are N·B^(−n/μ): a NEGATIVE rain number (left by advection; the limited PSD only gates on N < ϵ AND q < ϵ) gives a finite negative
+        // moment in the reference — log2 of the magnitude, the sign folded back below (log2 of the raw column was a NaN there)
+        const FT l2_Nr = M::log2(N_rai < FT(0) ? -N_rai : N_rai), sgn_r = N_rai < FT(0) ? FT(-1) : FT(1), dxr = psd.l2_xr - c.l2_6;
         // cloud: log x̄_c and logB = −μc (log x̄ + lgΓ(z1) − lgΓ(z2)) (CM2:176-192); notvalid(Bc) where exp(logB) leaves the float type's range
         const FT sq_c = M::max(q_lcl, eps), sN_c = M::max(N_lcl, eps);
         const FT l2_xc = M::log2(rho * sq_c * M::rcp(sN_c));
@@ -66,13 +68,13 @@ __device__ __forceinline__ void diag_point(const C &c, bool w1, bool w2, bool wr
         const bool poisoned = any_nan(rho, q_lcl, q_rai, N_lcl, N_rai);
         if (w2) {   // CMD :64-84
             const FT Zc = no_cloud ? FT(0) : M::exp2(l2_Nc + M::fma(c.pc2, dxc, c.kc2));
-            const FT Zr = no_rain ? FT(0) : M::exp2(l2_Nr + M::fma(c.pr2, dxr, c.kr2));
+            const FT Zr = no_rain ? FT(0) : sgn_r * M::exp2(l2_Nr + M::fma(c.pr2, dxr, c.kr2));
             const FT z = M::max(FT(-150), FT(10) * M::fma(M::log2(M::max(FT(0), Zc + Zr)), log10_2, FT(18)));
             Z_2m = poisoned ? M::nan() : z;
         }
         if (wr) {   // CMD :100-125
-            const FT M3c = no_cloud ? FT(0) : M::exp2(l2_Nc + M::fma(c.pc1, dxc, c.kc1)), M3r = no_rain ? FT(0) : M::exp2(l2_Nr + M::fma(c.pr1, dxr, c.kr1));
-            const FT M2c = no_cloud ? FT(0) : M::exp2(l2_Nc + M::fma(c.pc23, dxc, c.kc23)), M2r = no_rain ? FT(0) : M::exp2(l2_Nr + M::fma(c.pr23, dxr, c.kr23));
+            const FT M3c = no_cloud ? FT(0) : M::exp2(l2_Nc + M::fma(c.pc1, dxc, c.kc1)), M3r = no_rain ? FT(0) : sgn_r * M::exp2(l2_Nr + M::fma(c.pr1, dxr, c.kr1));
+            const FT M2c = no_cloud ? FT(0) : M::exp2(l2_Nc + M::fma(c.pc23, dxc, c.kc23)), M2r = no_rain ? FT(0) : sgn_r * M::exp2(l2_Nr + M::fma(c.pr23, dxr, c.kr23));
             const FT M2 = M2c + M2r;
             const FT r = M2 <= c.eps_1m ? FT(0) : (M3c + M3r) * M::rcp(M2);
             reff_2m = poisoned ? M::nan() : r;

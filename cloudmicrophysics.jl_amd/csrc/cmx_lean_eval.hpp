@@ -38,13 +38,14 @@ __global__ __launch_bounds__(kBlock) void lean_eval_kernel(const int which, cons
             case 16: r = lean::rsqrt_pos(v); break;
             case 17: r = lean::pow_m34_pos(v); break;
             case 18: r = lean::log_pos(v); break;
+            case 19: break;      // identity: the kernel's own instructions (tools/f64_floor.py subtracts them)
         default: break;
     }
     y[i] = r;
 }
 
 template <int TAG> static int32_t lean_eval_entry(int32_t which, int64_t n, const double *x, double *y, void *stream) {
-    if (which < 0 || which > 18 || n < 0) return CMX_ERR_BAD_ARG;
+    if (which < 0 || which > 19 || n < 0) return CMX_ERR_BAD_ARG;
     if (n > kMaxPoints) return CMX_ERR_UNSUPPORTED;
     if (n == 0) return CMX_OK;
     if (!x || !y) return CMX_ERR_BAD_ARG;

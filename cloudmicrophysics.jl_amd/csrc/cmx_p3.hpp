@@ -21,12 +21,16 @@
 #ifndef CMX_P3_FP_CONTRACT
 #define CMX_P3_FP_CONTRACT 1
 #endif
-#if CMX_P3_FP_CONTRACT
+// The bracket acts in the DEVICE pass only: the host pass of the same sources holds the entry functions that fold the kernel constants
+// (make_p3_consts, the collision entry), which the Python and oracle mirrors reproduce operation by operation — an FMA-capable host build must not contract
+// them.  With CMX_P3_FP_CONTRACT=0 both macros are empty, so the translation unit's own default stays in force.
+#if CMX_P3_FP_CONTRACT && defined(__HIP_DEVICE_COMPILE__)
 #define CMX_P3_CONTRACT_BEGIN _Pragma("clang fp contract(fast)")
+#define CMX_P3_CONTRACT_END _Pragma("clang fp contract(off)")
 #else
 #define CMX_P3_CONTRACT_BEGIN
+#define CMX_P3_CONTRACT_END
 #endif
-#define CMX_P3_CONTRACT_END _Pragma("clang fp contract(off)")
 
 namespace cmx {
 CMX_P3_CONTRACT_BEGIN

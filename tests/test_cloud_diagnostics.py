@@ -174,6 +174,17 @@ def test_device_nan_and_argument_rules(dev):
     Z, r = CD.radar_reflectivity_and_effective_radius_2M(sb, t(1e-4, nan, 1e-4), t(1e-4, 1e-4, 1e-4), t(1e8, 1e8, 1e8), t(1e4, 1e4, nan), t(1.0, 1.0, 1.0))
     assert torch.isfinite(Z[0]) and torch.isnan(Z[1]) and torch.isnan(Z[2]) and torch.isnan(r[1]) and torch.isnan(r[2])
     assert torch.isnan(CD.radar_reflectivity_1M(P.Microphysics1MParams(ft).c.rain, t(nan), t(1.0)))[0]
+    # a negative rain number next to rain mass (left by advection; the limited PSD gates only on N < eps AND q < eps): the reference's N·B^(−n/μ) is a finite
+    # negative moment, not a NaN — against the oracle; a negative q_rai with a positive number likewise
+    import oracle_binding as ob
+    cols = [np.array(v, dtype=np.float64) for v in ([1e-4, 1e-4, 0.0], [1e-4, -1e-6, 1e-4], [1e8, 1e8, 0.0], [-1e3, 1e4, -1e3], [1.0, 1.0, 1.0])]
+    Z, r = CD.radar_reflectivity_and_effective_radius_2M(sb, *[torch.tensor(c, dtype=torch.float32, device=dev) for c in cols])
+    sb64 = _sb("f64", True)
+    ref = ob.cloud_diagnostics(_abi.F64, cols[4], cols[0], cols[1], cols[2], cols[3], pdf_c=sb64.pdf_c, pdf_r=sb64.pdf_r, limited=True, float32_gates=True,
+                               want=("Z_2m", "reff_2m"))
+    assert bool(torch.isfinite(Z).all()) and bool(torch.isfinite(r).all())
+    np.testing.assert_allclose(Z.cpu().numpy(), ref["Z_2m"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(r.cpu().numpy(), ref["reff_2m"], rtol=1e-3, atol=1e-12)
     # limited flag with a not-limited struct, and a missing parameter struct: refused
     lib = _lib.lib()
     fn = lib.cmx_cloud_diagnostics_f32
