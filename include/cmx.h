@@ -894,9 +894,14 @@ int32_t cmx_arg2000_activation_columns_f64(
  * test/gpu_performance.jl:59-67).  Compute-bound: ≈12 evaluations of the shape residual per point, each 8 incomplete-
  * gamma evaluations of 20/30 fixed iterations (src/Utilities.jl:93-144).  The root is bracketed on logλ ∈ [2, 17] with
  * Brent's method like the reference (same end-point fallbacks, :295-297); logλ = −Inf when ρn_ice or ρq_ice < eps(FT).
- * brent_iters ≤ 0 selects the reference's fixed budget (8 Float32 / 10 Float64 iterations, :311); a larger value runs
- * that many (the residual is non-monotonic where μ(λ) ramps, logλ ∈ [8.7, 10.4]: ≈5 % of typical states are not yet
- * converged at the reference budget, 30 iterations converge all of them to 1e-7).
+ * The solver is Brent's zeroin under a fixed evaluation budget: RootSolvers.jl is not vendored, and zeroin is the restatement
+ * that satisfies the reference's own warm-start suite (test/p3_shape_solver_warmstart_tests.jl).
+ * brent_iters ≤ 0 selects the reference's fixed budget (8 Float32 / 10 Float64 iterations, :311); a larger value runs that many.
+ * THE BUDGET DOES NOT ALWAYS CONVERGE: over 1e6 random states (L_ice 1e-6…1e-3 kg/m³, N_ice 1e2…1e6 m⁻³) the Float64 budget leaves
+ * logλ more than 1e-6 from the root for 6.8 % of them and D_m more than 1 % off for 3.5 % — every one of them in 8 ≤ logλ < 11, where
+ * the SlopePowerLaw's μ(λ) ramps (21 % of the states of that band).  brent_iters = 12 / 14 / 16 / 20 leave 2.2 % / 0.27 % / 0.02 % /
+ * 0.001 % (profiles/r06_brent_exposure.json).  Whether the reference is equally unconverged there depends on RootSolvers' iterates;
+ * on the reference's own state sweeps (warm-start, robustness, round trip) its budget converges, here too.
  * log_lambda_guess (nullable): the reference's optional warm start — the guess, when finite, strictly inside the
  * bracket and with a finite residual, replaces the bracket end on its side of the root (_narrow_bracket, :336-353).
  * Output columns may be NULL.

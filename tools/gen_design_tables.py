@@ -17,6 +17,7 @@ Sources (round rNN = the newest round that has a bench directory unless --round 
 import csv
 import json
 import re
+import subprocess
 import sys
 from pathlib import Path
 
@@ -214,7 +215,15 @@ def parity_block(rnd):
     return "\n".join(out)
 
 
-BLOCKS = {"performance": performance_block, "parity": parity_block}
+def floor_block(rnd):
+    """§4.2: the Float64 instruction floor (tools/f64_floor.py --markdown: census on the counting type, dynamic function costs, measured instructions)."""
+    r = subprocess.run([sys.executable, str(REPO / "tools" / "f64_floor.py"), "--round", rnd, "--markdown"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr)
+    return r.stdout.strip()
+
+
+BLOCKS = {"performance": performance_block, "parity": parity_block, "floor": floor_block}
 
 
 def main():
