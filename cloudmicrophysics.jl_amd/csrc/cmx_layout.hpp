@@ -37,6 +37,10 @@ template <typename FT, int NIN, int NOUT> struct LayoutIO {
 // does POLICY::point accept the packed pair type?  (policies declare `static constexpr bool PACKABLE = true`)
 template <typename P, typename = void> struct layout_packable : std::false_type {};
 template <typename P> struct layout_packable<P, std::enable_if_t<P::PACKABLE>> : std::true_type {};
+// a policy whose Float32 constants overflow the SGPR file (the 1-moment kernels with run-time option flags: P::PHASE_CONSTS) reads them through the
+// kernel-argument pointer like the Float64 kernels do (cmx_math.hpp front_consts ALSO) — as by-value arguments 32 of them were spilled to VGPR lanes
+template <typename P, typename = void> struct layout_phase_consts : std::false_type {};
+template <typename P> struct layout_phase_consts<P, std::enable_if_t<P::PHASE_CONSTS>> : std::true_type {};
 #ifndef CMX_F32_PACKED_LAYOUT
 #define CMX_F32_PACKED_LAYOUT 1          // A/B switch: 0 = one point at a time
 #endif
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(BS) void tendencies_layout_kernel(const typename PO
                 FT xi[NIN];
 #pragma unroll
                 for (int q = 0; q < NIN; ++q) xi[q] = x[q][k];
-                POLICY::point(front_consts<FT>(c), xi, y[k]);   // Float64: phase-local constants (cmx_math.hpp); c is the first argument
+                POLICY::point(front_consts<FT, layout_phase_consts<POLICY>::value>(c), xi, y[k]);   // Float64 (and P::PHASE_CONSTS): phase-local constants (cmx_math.hpp); c is the first argument
             }
         }
     }

@@ -236,6 +236,7 @@ template <typename FT, uint32_t FLAGS> struct Mp1mLinLayoutPolicy {
     static constexpr int NIN = 7, NOUT = 4, NAOS = 4;
     using Consts = Mp1mLinKernArgs<FT>;
     static constexpr bool PACKABLE = CMX_1M_LIN_PACKED;
+    static constexpr bool PHASE_CONSTS = FLAGS == kRuntimeFlags;
     template <typename C, typename VT> static __device__ __forceinline__ void point(const C &k, const VT (&x)[NIN], VT (&y)[NOUT]) {
         mp1m_linearized_point<VT, FLAGS>(k.c, [&](VT dep) -> decltype(auto) { return (consts_after(k, dep).a); }, k.a.nsub, x[0], x[1], x[2], x[3], x[4], x[5],
                                          x[6], y[0], y[1], y[2], y[3]);

@@ -183,6 +183,16 @@ template <> struct PM<float> {
     static constexpr float eps() { return 1.1920928955078125e-07f; }
 };
 
+#if CMX_HAVE_PACKED
+// Two quadrature nodes per value (round 6): the node loops of the Float32 fall-speed / melting integrals evaluate PAIRS of nodes in packed arithmetic
+// (cmx_math.hpp f32x2) — the transcendentals, compares and selects run per half, the ≈ 30 multiplies / adds / fmas of a node as v_pk_* instructions.
+template <> struct PM<f32x2> {
+    using Coefs = PM<float>::Coefs;
+    static __device__ __forceinline__ f32x2 exp(f32x2 x, const Coefs &k) { return f32x2{PM<float>::exp(x.x, k), PM<float>::exp(x.y, k)}; }
+    static __device__ __forceinline__ f32x2 log_pos(f32x2 x, const Coefs &k) { return f32x2{PM<float>::log_pos(x.x, k), PM<float>::log_pos(x.y, k)}; }
+    static __device__ __forceinline__ f32x2 abs(f32x2 x) { return __builtin_elementwise_abs(x); }
+};
+#endif
 // ---- Brent's method with a fixed number of function evaluations ----------------------------------------------------------------------------------
 // RootSolvers.BrentsMethod under the reference's FixedIterations tolerance (src/P3_size_distribution.jl:250-251,311-319; src/P3_processes.jl:325-334).
 // RootSolvers' source is not vendored: the algorithm is Brent's zeroin (Brent 1973, ch. 4; netlib zeroin.f, Numerical Recipes zbrent) with t = 0 — the

@@ -28,6 +28,9 @@ CMX_P3_CONTRACT_BEGIN      // the whole translation unit is P3 quadrature / solv
 #ifndef CMX_P3_BS
 #define CMX_P3_BS 256
 #endif
+#ifndef CMX_P3_F32_PACKED_NODES
+#define CMX_P3_F32_PACKED_NODES 1      // Float32 fall-speed / melting node loops two nodes at a time in packed arithmetic (0: one node at a time, A/B switch)
+#endif
 constexpr int kP3BS = CMX_P3_BS;      // lanes per workgroup of the kernels of this file, one state per lane (A/B switch)
 
 
@@ -199,37 +202,52 @@ __global__ __launch_bounds__(kP3BS) void p3_velocity_kernel(const P3Consts<FT> c
             const bool sph_mass = mb == FT(3);
             const FT ma = P::exp(mla);
             FT rn = FT(0), rm = FT(0);
-            for (int j = 0; j < quad.n; ++j) {
-                const FT x = scale * quad.node[j] + shift, w = quad.weight[j];
-                const FT logD = P::log_pos(x, kc);          // an interior quadrature node: positive, normal, finite
-                const FT eN = logN0 + mu * logD - lam_ * x;                 // log n(D)
-                const FT eA = q0 + q1 * logD;                                // log of the aspect factor — but for the area^(−½) of the partially rimed segment:
-                FT mA = FT(1);                                               // a reciprocal square root (≈ 9 Float64 instructions) where eA −= ½ ln(area) cost a logarithm (≈ 20)
+            // one node — or, Float32, a PAIR of nodes (VT = f32x2: packed arithmetic, cmx_p3.hpp PM<f32x2>) — of the segment's integrand
+            auto node = [&](auto x, auto w, auto &an, auto &am) {
+                using VT = decltype(x);
+                using PV = PM<VT>;
+                using MVT = Math<VT>;
+                const VT logD = PV::log_pos(x, kc);          // an interior quadrature node: positive, normal, finite
+                const VT eN = logN0 + mu * logD - lam_ * x;                 // log n(D)
+                const VT eA = q0 + q1 * logD;                                // log of the aspect factor — but for the area^(−½) of the partially rimed segment:
+                VT mA = VT(1);                                               // a reciprocal square root (≈ 9 Float64 instructions) where eA −= ½ ln(area) cost a logarithm (≈ 20)
                 if (mixed_area) {
-                    const FT area = s.F_rim * k_pi4 * x * x + (FT(1) - s.F_rim) * k_ga * P::exp(k_sa * logD, kc);
-                    mA = Math<FT>::rsqrt_pos(area);
+                    const VT area = s.F_rim * k_pi4 * x * x + (FT(1) - s.F_rim) * k_ga * PV::exp(k_sa * logD, kc);
+                    mA = MVT::rsqrt_pos(area);
                 }
                 // Chen-2022 particle speed Σ aₖ D^bₖ e^{−cₖD}: the two terms have opposite signs and cancel to ≈1/200 of
                 // their size for small D, so the shared factor stays OUTSIDE the difference (as D^b does in the reference)
-                const bool small = x <= k_cut;
-                const FT E1 = small ? se + sb * logD : le1 + k_lb1 * logD;
-                const FT dE = small ? -k_sc2 * x : (le2 - le1) + k_db * logD - k_lc2 * x;   // E2 − E1
-                const FT A1 = small ? k_sE : k_la1, A2 = small ? k_sF : k_la2;
-                const FT S = mixed_area ? mA * (A1 + A2 * P::exp(dE, kc)) : A1 + A2 * P::exp(dE, kc);
+                const typename MVT::Mask small = x <= VT(k_cut);
+                const VT E1 = small ? se + sb * logD : le1 + k_lb1 * logD;
+                const VT dE = small ? -k_sc2 * x : (le2 - le1) + k_db * logD - k_lc2 * x;   // E2 − E1
+                const VT A1 = small ? VT(k_sE) : VT(k_la1), A2 = small ? VT(k_sF) : VT(k_la2);
+                const VT S = mixed_area ? mA * (A1 + A2 * PV::exp(dE, kc)) : A1 + A2 * PV::exp(dE, kc);
                 if constexpr (!MELT) {
-                    const FT nv = P::exp(eN + eA + E1, kc) * S;
+                    const VT nv = PV::exp(eN + eA + E1, kc) * S;
                     // m(D) = a D^b: b = 3 on the spherical segments (no transcendental), β_va otherwise
-                    const FT mD = sph_mass ? ma * (x * x * x) : P::exp(mla + mb * logD, kc);
-                    rn += nv * w;
-                    rm += nv * mD * w;
+                    const VT mD = sph_mass ? ma * (x * x * x) : PV::exp(mla + mb * logD, kc);
+                    an += nv * w;
+                    am += nv * mD * w;
                 } else {
                     // ∂m/∂D · F_v(D) · N′(D) / D,  ∂m/∂D = a b D^(b−1)
-                    const FT vD = P::exp(eA + E1, kc) * S;                                     // fall speed incl. aspect factor
-                    const FT Fv = v.vent_a + v.vent_bc * Math<FT>::sqrt(Math<FT>::max(x * vD, FT(0)));
-                    const FT dm_over_D = sph_mass ? ma * mb * x : ma * mb * P::exp((mb - FT(2)) * logD, kc);
-                    rn += dm_over_D * Fv * P::exp(eN, kc) * w;
+                    const VT vD = PV::exp(eA + E1, kc) * S;                                     // fall speed incl. aspect factor
+                    const VT Fv = v.vent_a + v.vent_bc * MVT::sqrt(MVT::max(x * vD, VT(0)));
+                    const VT dm_over_D = sph_mass ? ma * mb * x : ma * mb * PV::exp((mb - FT(2)) * logD, kc);
+                    an += dm_over_D * Fv * PV::exp(eN, kc) * w;
                 }
+            };
+            int j = 0;
+#if CMX_HAVE_PACKED
+            if constexpr (sizeof(FT) == 4 && CMX_P3_F32_PACKED_NODES) {
+                f32x2 rn2 = f32x2(0.0f), rm2 = f32x2(0.0f);
+                for (; j + 1 < quad.n; j += 2) {
+                    const f32x2 xn = f32x2{quad.node[j], quad.node[j + 1]}, wn = f32x2{quad.weight[j], quad.weight[j + 1]};
+                    node(scale * xn + shift, wn, rn2, rm2);
+                }
+                rn = rn2.x + rn2.y; rm = rm2.x + rm2.y;
             }
+#endif
+            for (; j < quad.n; ++j) node(FT(scale * quad.node[j] + shift), FT(quad.weight[j]), rn, rm);
             sum_n += scale * rn; sum_m += scale * rm;
         }
         if constexpr (!MELT) {

@@ -424,7 +424,8 @@ const char *cmx_last_hip_error(void);
  * no Float64 transcendental unit) evaluated over a device column, so that a test can measure them against libm in ulps ON the
  * device.  which: 0 exp2, 1 log2, 2 exp, 3 log, 4 rcp, 5 sqrt, 6 rsqrt, 7 expm1, 8 log1p, 9 erfc (the table-driven form of the ARG kernel),
  * 10 lgamma for z > 0 (the P3 shape solver's); 11-17 the finite-argument forms exp2_fin, exp_fin, rcp_finite, rcp_nz, sqrt_pos, rsqrt_pos,
- * pow_m34_pos and 18 log_pos (positive normal finite arguments only: DESIGN.md section 4.3). */
+ * pow_m34_pos and 18 log_pos (positive normal finite arguments only: DESIGN.md section 4.3); 19 the identity (the kernel's own instructions:
+ * tools/f64_floor.py subtracts them from the per-dispatch instruction counters of the others). */
 int32_t cmx_lean_eval_f64(int32_t which, int64_t n, const double *x, double *y, void *stream);
 /* … and the same functions as compiled into the production Float64 kernels' translation units (polynomial coefficients as SGPR literals
  * instead of LDS reads; csrc/Makefile LITCOEF). */

@@ -67,6 +67,17 @@ def scaled_err(x, ref, scale=None, floor=0.0, ceil=np.inf, kappa=None):
 # gpurun_out/parity_report.json at the end of a session (committed under profiles/ per round).
 WELLCOND = {"f64": 1e-3, "f32": 0.1}
 MIN_FRAC_WITHIN = {"f64": 0.999, "f32": 0.99}
+# Round 6: the two knobs above are the DEFAULT.  The families whose kernels stream one point function over random states meet much
+# tighter ones, and are held to them — (minimum fraction inside the plain bound, largest well-conditioned plain error) per float type, set from
+# profiles/r06_parity_report.json with a margin: observed fractions 0.9961–0.9985 (Float32; the minimum is one point of a 257-point ragged case) and 1.0
+# (Float64), observed worst well-conditioned errors 1.8e-5–4.5e-5 and 1.7e-11–2.3e-11.  A regression inside the north-star tolerance but outside these fails.
+FAMILY_KNOBS = {
+    "SB2006 2M warm rain (a1)": {"f32": (0.997, 2e-4), "f64": (0.9999, 1e-9)},
+    "1-moment (a2)": {"f32": (0.995, 2e-4), "f64": (0.9999, 1e-9)},
+    "column steps (f4)": {"f32": (0.996, 2e-4), "f64": (0.9999, 1e-9)},
+    "host-model layouts (f1)": {"f32": (0.997, 2e-4), "f64": (0.9999, 1e-9)},
+    "ARG2000 (a3)": {"f32": (0.9995, 2e-4), "f64": (0.9999, 1e-9)},
+}
 REPORTS = []
 
 
@@ -150,8 +161,12 @@ def assert_parity(got: dict, ref: dict, rtol: float, names=OUT_NAMES, what="", f
     report = {}
     if floor is None:
         floor = FLOOR[ft]
+    fam_name = family or _family_of_current_test()
+    wc_max = rtol
     if min_frac is None:
         min_frac = MIN_FRAC_WITHIN[ft]
+        if fam_name in FAMILY_KNOBS and "degenerate" not in what:
+            min_frac, wc_max = FAMILY_KNOBS[fam_name][ft]
     for k in names:
         if got.get(k) is None:
             continue
@@ -167,15 +182,16 @@ def assert_parity(got: dict, ref: dict, rtol: float, names=OUT_NAMES, what="", f
                 f"ref {ref[k][i]!r} scale {(sc[i] if sc is not None else None)!r}")
         ps = plain_stats(got[k], ref[k], sc, rtol, floor, CEIL[ft], keep, WELLCOND[ft])
         REPORTS.append({"what": what.strip(), "output": k, "ft": ft, "rtol": rtol, "worst_normalised": worst, **ps,
-                        "family": family or _family_of_current_test(),
+                        "family": fam_name,
                         "pinned_by": pinned_by or "oracle (pinned by the reference's KATs, tests/golden/)",
-                        "asserted": f"operand-scaled bound + fraction inside the plain bound >= {min_frac} + well-conditioned plain bound",
+                        "asserted": f"operand-scaled bound + fraction inside the plain bound >= {min_frac} + well-conditioned plain bound" + (
+                            f" (family knob: worst well-conditioned error <= {wc_max:g})" if wc_max != rtol else ""),
                         **({"note": note} if note else {})})
         assert ps["frac_within"] >= min_frac, (
             f"{what} {k}: only {ps['frac_within']:.6f} of {ps['n']} points are within the plain relative bound {rtol:g} "
             f"(required {min_frac})")
-        assert ps["worst_wellcond"] <= rtol, (
-            f"{what} {k}: well-conditioned point (|ref| > {WELLCOND[ft]:g}·scale) with plain relative error {ps['worst_wellcond']:.3e} > {rtol:g}")
+        assert ps["worst_wellcond"] <= wc_max, (
+            f"{what} {k}: well-conditioned point (|ref| > {WELLCOND[ft]:g}·scale) with plain relative error {ps['worst_wellcond']:.3e} > {wc_max:g}")
     if near is not None and near.size:
         assert near.mean() < 1e-4 or near.sum() <= 2, f"{what}: implausibly many near-branch points ({near.sum()})"
     return report

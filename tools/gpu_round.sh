@@ -6,7 +6,7 @@
 #   usage: tools/gpu_round.sh <round-tag, e.g. r04> [notests]
 set -u
 set -o pipefail
-TAG=${1:-r05}
+TAG=${1:-r06}
 mkdir -p gpurun_out/bench
 FAILED=0
 
