@@ -281,7 +281,9 @@ __device__ __forceinline__ ArgOut<VT, NM> arg_point(const C &c, VT T, VT p, VT w
     VT sum2 = VT(0);
     const bool p2_34 = sizeof(S) == 8 && CMX_ARG_P2_ROOTS && c.p2 == S(0.75);
 #pragma unroll
-    for (int k = 0; k < NM; ++k) sum2 = M::fma(c.m[k].c2, arg_pow_p2<VT>(c, M::fma(s.Q, c.m[k].inv_N, VT(1)), p2_34), sum2);
+    // (a multiply and an add per mode, not an fma: the reference sums separately rounded terms, so its totals do not depend on the ORDER of two modes —
+    // test/aerosol_activation_tests.jl:222-234 asserts that with `==` — and a + b = b + a holds for rounded products, not for fma(c, p, a))
+    for (int k = 0; k < NM; ++k) sum2 = sum2 + c.m[k].c2 * arg_pow_p2<VT>(c, M::fma(s.Q, c.m[k].inv_N, VT(1)), p2_34);
     const VT l2_smax = arg_smax<VT, SINKS>(s, VT(c.sum_c1), sum2, want_smax, o.smax);
     const VT dl0 = s.l2_A15 - l2_smax;                             // log2(Sm_i / S_max) = l2_sm_c + dl0
     // phase boundary (cmx_math.hpp consts_after; a no-op unless the kernel reads its constants through the kernel-argument pointer): the erfc loop's

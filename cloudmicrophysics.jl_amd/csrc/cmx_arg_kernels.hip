@@ -261,7 +261,7 @@ __global__ __launch_bounds__(kArgColBS<FT>) void arg_activation_columns_kernel(c
             const FT c2 = M::fma(par.g2, ls, par.g1) * M::exp2((FT(2) * c.p2 - FT(2)) * l2sm);
             sum1[v] += c1;
             const FT y = M::fma(pre[v].Q, M::rcp(Nk[v]), FT(1));                            // (η_k + 3ζ)/(3ζ) = 1 + Q/N_k (arg_pre)
-            sum2[v] = M::fma(c2, arg_pow_p2<FT>(c, y, p2_34), sum2[v]);
+            sum2[v] = sum2[v] + c2 * arg_pow_p2<FT>(c, y, p2_34);                           // (mul + add: independent of the order of two modes, cmx_arg.hpp arg_point)
             k_ls[k][v] = ls; k_l2sm[k][v] = l2sm; k_N[k][v] = Nk[v];
         }
         // one mode at a time (Float64: keeps the next mode's table reads and loads behind this mode's arithmetic, like arg_point's erfc loop).  BOTH sums are

@@ -155,6 +155,49 @@ def test_reference_test_data_through_the_abi(dev, ft):
         assert rB.N_act[0][0].item() > 0
 
 
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_reference_property_tests_through_the_abi(dev, ft):
+    """test/aerosol_activation_tests.jl:134-234 on the device, both parameter sets (default, PySDM-calibrated), B- and κ-type modes, the reference's
+    conditions (T = 294 K, p = 1e5 Pa, w = 0.5 m/s, saturated, N_liq = N_ice = 1000): "callable and positive" (> 0 without sinks, ≥ 0 with), "same mean
+    hygroscopicity for the same aerosol" (==), "B and kappa hygroscopicities are equivalent" (rtol 0.1) and "order of modes does not matter" — which the
+    reference asserts with `==` on total_N_activated and total_M_activated: the kernel sums separately rounded terms for that reason (cmx_arg.hpp)."""
+    import cmx
+    t64 = P.ThermodynamicsParameters("f64")
+    aip, tps = P.AirProperties(ft), P.ThermodynamicsParameters(ft)
+    T, p, w = 294.0, 1e5, 0.5
+    dcl = t64.cp_v - t64.cp_l
+    p_vs = t64.press_triple * (T / t64.T_triple) ** (dcl / t64.R_v) * math.exp((t64.LH_v0 - dcl * t64.T_0) / t64.R_v * (1 / t64.T_triple - 1 / T))
+    q_vs = 1 / (1 - (t64.R_v / t64.R_d) * (p_vs - p) / p_vs)
+    col = lambda v: torch.full((5,), v, dtype=DT[ft], device=dev)  # noqa: E731
+    ss = P.Seasalt(ft)
+    mB = lambda r, sd, N: Mode_B(r, sd, N, (1.0,), (ss.eps,), (ss.phi,), (ss.M,), (ss.nu,), (ss.rho,))  # noqa: E731
+    mK = lambda r, sd, N: Mode_kappa(r, sd, N, (1.0,), (1.0,), (ss.M,), (ss.kappa,))  # noqa: E731
+    accum, coarse = (0.243e-6, 1.4, 100e6), (1.5e-6, 2.1, 1e6)
+    state = (col(T), col(p), col(w), col(q_vs), col(0.0), col(0.0))
+    sinks = (col(1000.0), col(1000.0))
+    for override in (None, P.ARG2000_CALIBRATED_OVERRIDE):
+        ap = P.AerosolActivationParameters(P.create_toml_dict(ft, override))
+        for mk in (mB, mK):
+            am1, am2, am3 = (AerosolDistribution(m) for m in ([mk(*accum)], [mk(*coarse), mk(*accum)], [mk(*accum), mk(*coarse)]))
+            assert all(m.hygroscopicity(ap) > 0 for m in am3.modes)
+            assert am3.modes[0].hygroscopicity(ap) == am1.modes[0].hygroscopicity(ap)                      # same aerosol → same mean hygroscopicity
+            r = cmx.aerosol_activation(ap, am3, aip, tps, *state, want=("N_act", "M_act", "S_max"))
+            rs = cmx.aerosol_activation(ap, am3, aip, tps, *state, *sinks, want=("N_act", "M_act", "S_max"))
+            assert bool((r.S_max > 0).all()) and bool((rs.S_max >= 0).all())
+            for k in range(2):
+                assert bool((r.N_act[k] > 0).all()) and bool((r.M_act[k] > 0).all())
+                assert bool((rs.N_act[k] >= 0).all()) and bool((rs.M_act[k] >= 0).all())
+            # totals, and their independence of the order of the modes — bit for bit, like the reference's `==`
+            t3 = cmx.total_activated(ap, am3, aip, tps, *state)
+            t2 = cmx.total_activated(ap, am2, aip, tps, *state)
+            assert bool((t3[0] > 0).all()) and bool((t3[1] > 0).all())
+            assert torch.equal(t3[0], t2[0]) and torch.equal(t3[1], t2[1])
+            ts = cmx.total_activated(ap, am3, aip, tps, *state, *sinks)
+            assert bool((ts[0] >= 0).all()) and bool((ts[1] >= 0).all())
+        kap, B = mK(*coarse).hygroscopicity(ap), mB(*coarse).hygroscopicity(ap)
+        assert abs(kap - B) <= 0.1 * max(abs(kap), abs(B))
+
+
 @pytest.mark.parametrize("ft", ["f32", "f64"])
 @pytest.mark.parametrize("nmodes", [5, 1, 2, 8])
 def test_random_state_parity(dev, oracle, ft, nmodes):
