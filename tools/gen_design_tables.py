@@ -223,6 +223,20 @@ def floor_block(rnd):
     return r.stdout.strip()
 
 
+def wrap_prose(text, width=150):
+    """Prose lines of a generated block wrapped at `width`; table rows (|…|) and list continuations stay whole lines / get a two-space hanging indent."""
+    import textwrap
+    out = []
+    for line in text.split("\n"):
+        if line.startswith("|") or len(line) <= width:
+            out.append(line)
+        elif line.startswith("* "):
+            out += textwrap.wrap(line, width, subsequent_indent="  ", break_long_words=False, break_on_hyphens=False)
+        else:
+            out += textwrap.wrap(line, width, break_long_words=False, break_on_hyphens=False)
+    return "\n".join(out)
+
+
 BLOCKS = {"performance": performance_block, "parity": parity_block, "floor": floor_block}
 
 
@@ -230,7 +244,7 @@ def main():
     args = sys.argv[1:]
     rnd = args[args.index("--round") + 1] if "--round" in args else latest_round()
     doc_path = REPO / "DESIGN.md"
-    gen = {name: fn(rnd) for name, fn in BLOCKS.items()}
+    gen = {name: wrap_prose(fn(rnd)) for name, fn in BLOCKS.items()}
     if "--write" not in args and "--check" not in args:
         for name, text in gen.items():
             print(f"<!-- BEGIN GENERATED {name} -->\n{text}\n<!-- END GENERATED {name} -->\n")
