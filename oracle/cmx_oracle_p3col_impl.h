@@ -33,6 +33,10 @@ static inline FT FN(o_gamma_inc_moment)(FT D1, FT D2, FT p, FT alpha, int gi_ite
     dq = FN(o_max)(dq, (FT)0);
     return M_TGAMMA(z) * dq / M_POW(alpha, z);
 }
+/* test switch: the crossover solve's iteration count (0 = the reference's 8 / 10) — how far the budget-limited crossover diameter is from the root, and what
+ * that does to the collision rates (tests/test_p3_collisions_oracle.py) */
+static int FN(g_crossover_iters) = 0;
+void FN(cmxo_set_crossover_iters)(int32_t n) { FN(g_crossover_iters) = n; }
 /* crossover_diameter — src/P3_processes.jl:325-334: root of v_l(D) − v_target on [D_min, D_max], Brent, fixed 8 / 10 iterations */
 typedef struct TY(cmxo_cross_ctx) { const FT *ra, *rb, *rc; FT v_target; } TY(cmxo_cross_ctx);
 static FT FN(o_cross_problem)(FT D, const void *ctx) {
@@ -103,7 +107,7 @@ static inline void FN(o_p3col_setup)(TY(cmxo_p3col) * k, const TY(cmx_p3_ice_par
     const TY(cmx_p3_params) *pr = &ip->scheme;
     k->ip = ip; k->s = *s;
     k->gi_iters = sizeof(FT) == 4 ? 20 : 30;
-    k->brent_iters = s->eps > (FT)1e-10 ? 8 : 10;
+    k->brent_iters = FN(g_crossover_iters) > 0 ? FN(g_crossover_iters) : (s->eps > (FT)1e-10 ? 8 : 10);
     FN(o_chen_small_ice)(&ip->vel_ice.small_ice, rho_a, (FT)916.7, k->vt.as, k->vt.bs, k->vt.cs);
     FN(o_chen_large_ice)(&ip->vel_ice.large_ice, rho_a, (FT)916.7, k->vt.al, k->vt.bl, k->vt.cl);
     k->vt.cutoff = ip->vel_ice.small_ice.cutoff;

@@ -461,6 +461,15 @@ def set_quadrature_override(fam, nodes=None, weights=None):
     assert x.size == w.size and fn(x.size, x.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p)) == 0
 
 
+def set_crossover_iters(n: int):
+    """Iteration count of the collision integrals' crossover solve (0 = the reference's 8 / 10).  Both float types."""
+    for sfx in ("f32", "f64"):
+        fn = getattr(lib(), f"cmxo_set_crossover_iters_{sfx}")
+        fn.restype = None
+        fn.argtypes = [C.c_int32]
+        fn(n)
+
+
 def set_brent_variant(v: int):
     """0: Brent's zeroin (default); 1: the Wikipedia pseudo-code variant of rounds 1-5 (cmx_oracle_p3_impl.h o_brent_fixed).  Both float types."""
     for sfx in ("f32", "f64"):
