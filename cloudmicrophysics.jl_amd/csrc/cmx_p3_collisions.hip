@@ -125,11 +125,7 @@ static P3ColConsts<FT> make_p3col_consts(const IP &ip, const AP &aps, const TH &
     k.m_fac = (FT)((double)pc.rho_w * pi / 6.0);
     k.tau_wet = ip.scheme.tau_wet; k.rho_i = ip.scheme.rho_i;
     k.inv_m_shd = (FT)(1.0 / ((double)pc.rho_w * 1e-9 * pi / 6.0));      // 1/m_liq(D_shd = 1 mm)
-#ifdef CMX_P3_CROSSOVER_ITERS
-    k.brent_iters = CMX_P3_CROSSOVER_ITERS;          // A/B switch: how much of the step the crossover solve is (tools/session_r06_7.sh)
-#else
     k.brent_iters = sizeof(FT) == 4 ? 8 : 10;
-#endif
     k.p_lo_m = (FT)1e-6; k.p_hi_m = (FT)(1.0 - 1e-6); k.K4 = (FT)(4.0 * (double)aps.K_therm);
     return k;
 }
