@@ -570,6 +570,12 @@ FT FN(cmxo_p3_ventilation_factor)(const TY(cmx_p3_params) * pr, const TY(cmx_che
                                  const TY(cmx_ventilation) * vent, uint32_t flags, FT F_rim, FT rho_rim, FT rho_a, FT D) {
     return FN(o_ventilation_factor)(vent, aps, M_CBRT(aps->nu_air / aps->D_vapor), D, FN(cmxo_p3_particle_velocity)(pr, vel, flags, F_rim, rho_rim, rho_a, D));
 }
+/* ice_mass, ice_area, ϕᵢ of the state (F_rim, ρ_rim) at diameter D, and its thresholds — test/p3_tests.jl:111-166 */
+void FN(cmxo_p3_particle_properties)(const TY(cmx_p3_params) * pr, FT F_rim, FT rho_rim, FT D, FT out[7]) {
+    TY(cmxo_p3_state) s = FN(o_p3_state)(pr, (FT)0, (FT)0, F_rim, rho_rim, M_EPS);
+    out[0] = FN(o_p3_ice_mass)(pr, &s, D); out[1] = FN(o_p3_ice_area)(pr, &s, D); out[2] = FN(o_p3_phi)(pr, &s, D);
+    out[3] = s.D_th; out[4] = s.D_gr; out[5] = s.D_cr; out[6] = s.rho_g;
+}
 FT FN(cmxo_unrolled_logsumexp)(int32_t n, const FT *x) { return FN(o_unrolled_logsumexp)(x, n); }
 /* get_ρ_g(F_rim, ρ_rim, ρ_d) — src/P3_particle_properties.jl:219 with weighted_average :293-295 */
 FT FN(cmxo_p3_rho_g)(const TY(cmx_p3_params) * pr, FT F_rim, FT rho_rim) {

@@ -486,6 +486,16 @@ def p3_rho_g(fam, params, F_rim, rho_rim):
     return fn(C.addressof(params), F_rim, rho_rim)
 
 
+def p3_particle_properties(fam, params, F_rim, rho_rim, D):
+    """dict(mass, area, phi, D_th, D_gr, D_cr, rho_g) of an ice particle of diameter D in the state (F_rim, ρ_rim) — P3.ice_mass / ice_area / ϕᵢ and the thresholds."""
+    out = (fam.ft * 7)()
+    fn = getattr(lib(), f"cmxo_p3_particle_properties_{fam.sfx}")
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, fam.ft, fam.ft, fam.ft, C.c_void_p]
+    fn(C.addressof(params), F_rim, rho_rim, D, out)
+    return dict(zip(("mass", "area", "phi", "D_th", "D_gr", "D_cr", "rho_g"), list(out)))
+
+
 def p3_ventilation_factor(fam, params, vel, aps, vent, flags, F_rim, rho_rim, rho_a, D):
     """CO.ventilation_factor(vent, aps, P3.ice_particle_terminal_velocity(vel, ρₐ, state))(D) — src/Common.jl:506-514."""
     fn = getattr(lib(), f"cmxo_p3_ventilation_factor_{fam.sfx}")

@@ -230,3 +230,165 @@ def test_quadrature_order_sweep_of_the_fused_2m_p3_tendencies(oracle):
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
     worst = check_quadrature_sweep(lambda order, cols, ll: oracle_tendencies_at_order(oracle, order, cols, ll), (cols, ll))
     print("\n[quadrature sweep, oracle] worst relative difference to n = 200: " + ", ".join(f"n={k}: {v:.2e}" for k, v in worst.items()))
+
+
+# ---- test/bulk_tendencies_tests.jl:120-642 — the 1-moment entry's qualitative and conservation tests ------------------------------------------------
+def bmt_1m_case_columns(oracle, case, ft):
+    """(rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno) of one case as length-1 arrays of the float type; q_tot from the oracle's saturation contents where
+    the reference builds it from them"""
+    g = G["bmt_1m_cases"]
+    npt = {"f32": np.float32, "f64": np.float64}[ft]
+    t64 = P.ThermodynamicsParameters("f64")
+    T = case["T"] if "T" in case else g["T_freeze"] + case["dT"]
+    T, rho = float(npt(T)), float(npt(case["rho"]))
+    q = {k: float(npt(case[k])) for k in ("q_lcl", "q_icl", "q_rai", "q_sno")}
+    qt = case["q_tot"]
+    if isinstance(qt, dict):
+        psat = oracle.psat_liquid(_abi.F64, t64, T) if qt["sat"] == "liquid" else oracle.psat_ice(_abi.F64, t64, T)
+        q_tot = qt["factor"] * psat / (rho * t64.R_v * T) + (sum(q.values()) if qt.get("plus_condensate") else 0.0)
+    else:
+        q_tot = qt
+    return [np.array([v], dtype=npt) for v in (rho, T, q_tot, q["q_lcl"], q["q_icl"], q["q_rai"], q["q_sno"])]
+
+
+def bmt_1m_options(case):
+    return {k: getattr(P, v)() for k, v in case.get("options", {}).items()}
+
+
+def check_bmt_1m_case(case, ft, tend, src):
+    """the reference's assertions of one case: `tend` = {dq_*_dt: float}, `src` = {S_*: float} (the 18 source terms)"""
+    eps = float(np.finfo({"f32": np.float32, "f64": np.float64}[ft]).eps)
+    for chk in case["checks"]:
+        kind = chk[0]
+        if kind == "gt":
+            assert tend[chk[1]] > 0, (case["name"], chk, tend)
+        elif kind == "lt":
+            assert tend[chk[1]] < 0, (case["name"], chk, tend)
+        elif kind == "le":
+            assert tend[chk[1]] <= 0, (case["name"], chk, tend)
+        elif kind == "finite":
+            assert math.isfinite(tend[chk[1]]), (case["name"], chk, tend)
+        elif kind == "finite_all":
+            assert all(math.isfinite(v) for v in tend.values()), (case["name"], tend)
+        elif kind == "notnan":
+            assert not math.isnan(tend[chk[1]]), (case["name"], chk, tend)
+        elif kind == "eq0":
+            assert tend[chk[1]] == 0, (case["name"], chk, tend)
+        elif kind == "abs_lt":
+            assert abs(tend[chk[1]]) < chk[2], (case["name"], chk, tend)
+        elif kind == "sum_approx0":
+            atol = math.sqrt(eps) if chk[2] == "sqrt_eps" else chk[2]
+            assert abs(tend[chk[1][0]] + tend[chk[1][1]]) <= atol, (case["name"], chk, tend)
+        elif kind == "rel_to_source":
+            assert abs(tend[chk[1]] - src[chk[2]]) / src[chk[2]] < chk[3], (case["name"], chk, tend, src[chk[2]])
+        elif kind == "src_gt":
+            assert src[chk[1]] > 0, (case["name"], chk, src[chk[1]])
+        elif kind == "alpha_formula":
+            want = -src["S_accr_melt_lcl_sno"] - src["S_melt_sno_rai"] + src["S_phase_change_vap_sno"]
+            assert abs(tend["dq_sno_dt"] - want) <= chk[1] * eps, (case["name"], tend["dq_sno_dt"], want)
+            alpha = src["S_accr_melt_lcl_sno"] / src["S_accr_lcl_sno_warm"]
+            assert 0 < alpha < 0.1, (case["name"], alpha)
+        else:
+            raise AssertionError(f"unknown check {kind}")
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_bulk_tendencies_1m_reference_cases(oracle, ft):
+    g = G["bmt_1m_cases"]
+    assert len(g["cases"]) == 19
+    names = ("dq_lcl_dt", "dq_icl_dt", "dq_rai_dt", "dq_sno_dt")
+    for case in g["cases"]:
+        mp = P.Microphysics1MParams(ft, **bmt_1m_options(case))
+        cols = bmt_1m_case_columns(oracle, case, ft)
+        r = oracle.mp1m(FAM[ft], mp.c, P.ThermodynamicsParameters(ft), mp.flags, *cols, want_sources=True)
+        check_bmt_1m_case(case, ft, {k: float(r[k][0]) for k in names}, {k: float(v[0]) for k, v in r["sources"].items()})
+
+
+# ---- test/bulk_tendencies_tests.jl:1154-1213 — the 2-moment warm-rain entry (the north star's own reference test) ----------------------------------------
+def bmt_2m_case_columns(oracle, case, ft):
+    g = G["bmt_2m_cases"]
+    npt = {"f32": np.float32, "f64": np.float64}[ft]
+    t64 = P.ThermodynamicsParameters("f64")
+    T, rho = float(npt(g["T_freeze"] + case["dT"])), float(npt(case["rho"]))
+    q_lcl, q_rai = float(npt(case["q_lcl"])), float(npt(case["q_rai"]))
+    qt = case["q_tot"]
+    q_sat = oracle.psat_liquid(_abi.F64, t64, T) / (rho * t64.R_v * T)
+    extra = {True: q_lcl + q_rai, False: 0.0, "q_lcl": q_lcl}[qt["plus_condensate"]]
+    vals = (rho, T, qt["factor"] * q_sat + extra, q_lcl, case["n_lcl"], q_rai, case["n_rai"])
+    return [np.array([v], dtype=npt) for v in vals]
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_bulk_tendencies_2m_reference_cases(oracle, ft):
+    names = ("dq_lcl_dt", "dn_lcl_dt", "dq_rai_dt", "dn_rai_dt")
+    for case in G["bmt_2m_cases"]["cases"]:
+        cols = [c.astype(np.float64) for c in bmt_2m_case_columns(oracle, case, ft)]
+        r = oracle.sb2006_warm_rain_tendencies(_abi.F64, P.WarmRainParams2M("f64").c, P.ThermodynamicsParameters("f64"), P.rain_vel_params("f64"),
+                                               _abi.CMX_SB2006_LIMITED | _abi.CMX_VEL_SB2006, *cols, float32_gates=(ft == "f32"))
+        check_bmt_1m_case(case, ft, {k: float(r[k][0]) for k in names}, {})
+
+
+# ---- test/p3_tests.jl:111-166 — mass, area, density and aspect ratio per regime ----------------------------------------------------------------------
+def test_p3_particle_properties_per_regime(oracle):
+    g = G["particle_properties"]
+    p = P.ParametersP3("f64")
+    F, rr = g["F_rim"], g["rho_rim"]
+    th = oracle.p3_particle_properties(_abi.F64, p.c, F, rr, 1e-4)
+    D_th, D_gr, D_cr, rho_g = th["D_th"], th["D_gr"], th["D_cr"], th["rho_g"]
+    assert D_th < D_gr < D_cr
+    D_1, D_2, D_3 = D_th / 2, (D_th + D_gr) / 2, (D_gr + D_cr) / 2
+    prop = lambda D, F_=F: oracle.p3_particle_properties(_abi.F64, p.c, F_, rr, D)  # noqa: E731
+    sph_area = lambda D: D ** 2 * math.pi / 4  # noqa: E731
+    non_area = lambda D: p.c.gamma * D ** p.c.sigma  # noqa: E731
+    sph_mass = lambda rho, D: rho * math.pi / 6 * D ** 3  # noqa: E731
+    non_mass = lambda D: p.c.alpha_va * D ** p.c.beta_va  # noqa: E731
+    close = lambda a, b, rt=1e-14: math.isclose(a, b, rel_tol=rt)  # noqa: E731 — the reference's == on Julia's expressions; libm pow against Julia's ^ is not bit-exact
+    assert close(prop(D_1)["area"], sph_area(D_1)) and close(prop(D_2)["area"], non_area(D_2)) and close(prop(D_3)["area"], sph_area(D_3))
+    assert close(prop(D_cr)["area"], F * sph_area(D_cr) + (1 - F) * non_area(D_cr))
+    assert close(prop(D_1)["mass"], sph_mass(p.c.rho_i, D_1)) and close(prop(D_2)["mass"], non_mass(D_2)) and close(prop(D_3)["mass"], sph_mass(rho_g, D_3))
+    assert close(prop(D_cr)["mass"], non_mass(D_cr) / (1 - F))
+    dens = lambda D: prop(D)["mass"] / (math.pi / 6 * D ** 3)  # noqa: E731
+    rt = math.sqrt(np.finfo(np.float64).eps)
+    assert close(dens(D_1), p.c.rho_i, rt) and close(dens(D_2), g["ice_density"]["D_2"], rt) and close(dens(D_3), rho_g, rt)
+    assert close(dens(D_cr), g["ice_density"]["D_cr"], rt)
+    phi_closed = lambda rho, D: 3 * math.sqrt(math.pi) * prop(D)["mass"] / (4 * rho * prop(D)["area"] ** 1.5)  # noqa: E731
+    assert close(prop(D_1)["phi"], 1.0, rt) and close(prop(D_3)["phi"], 1.0, rt)
+    assert close(prop(D_2)["phi"], phi_closed(p.c.rho_i, D_2), rt) and prop(D_2)["phi"] < 1
+    assert close(prop(D_cr)["phi"], phi_closed(p.c.rho_i, D_cr), rt) and prop(D_cr)["phi"] < 1
+    b = g["phi_band_above_D_th"]
+    assert b["lo"] < prop(D_th * b["factor"])["phi"] < b["hi"]
+    assert close(prop(D_2, 0.0)["area"], non_area(D_2)) and close(prop(D_2, 0.0)["mass"], non_mass(D_2))          # F_rim = 0 and D > D_th
+
+
+# ---- test/p3_tests.jl:513-555 — the weighted fall speeds against the same integrals with another rule --------------------------------------------------
+def numerical_integral_states(ft):
+    g = G["numerical_integrals"]
+    npt = {"f32": np.float32, "f64": np.float64}[ft]
+    L = np.linspace(g["L_ice"]["start"], g["L_ice"]["stop"], g["L_ice"]["length"])
+    grid = np.array(list(itertools.product(g["F_rim"], L)), dtype=np.float64)
+    n = grid.shape[0]
+    return [grid[:, 1].astype(npt), np.full(n, g["N_ice"], dtype=npt), grid[:, 0].astype(npt), np.full(n, g["rho_rim"], dtype=npt), np.full(n, g["rho_a"], dtype=npt)]
+
+
+def check_numerical_integrals(velocities):
+    """`velocities(p, quad_name, order) -> (v_n, v_m)` arrays over numerical_integral_states"""
+    g = G["numerical_integrals"]
+    for p_ in g["p"]:
+        a_n, a_m = velocities(p_, "GaussLegendre", 12)
+        b_n, b_m = velocities(p_, "ChebyshevGauss", 10)
+        assert np.all(a_n > 0) and np.all(a_m > 0)
+        assert np.all(np.abs(a_n - b_n) <= g["rtol_v_n"] * np.maximum(np.abs(a_n), np.abs(b_n))), (p_, a_n, b_n)
+        assert np.all(np.abs(a_m - b_m) <= g["rtol_v_m"] * np.maximum(np.abs(a_m), np.abs(b_m))), (p_, a_m, b_m)
+
+
+def test_weighted_fall_speeds_do_not_depend_on_the_rule(oracle):
+    p = P.ParametersP3("f64")
+    vel = P.Chen2022VelTypeIce("f64")
+    L, N, F, rr, rho_a = numerical_integral_states("f64")
+    flags = STATE | p.flags | _abi.CMX_P3_NO_ASPECT_RATIO
+    ll = oracle.p3_shape(_abi.F64, p.c, STATE | p.flags, L, N, F, rr)["log_lambda"]
+
+    def velocities(p_, rule, order):
+        quad = getattr(P, rule)("f64", order)
+        return oracle.p3_terminal_velocities(_abi.F64, p.c, vel, quad, flags, L, N, F, rr, rho_a, ll, p=p_)
+    check_numerical_integrals(velocities)

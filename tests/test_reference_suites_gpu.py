@@ -141,3 +141,47 @@ def test_brent_budget_exposure_in_output_terms(dev):
     for k, v in report["outputs"].items():
         assert v["share_above_1e-6"] <= 0.08, (k, v)
         assert v["share_above_1e-2"] <= 0.04, (k, v)
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_bulk_tendencies_1m_reference_cases_on_device(dev, oracle, ft):
+    """test/bulk_tendencies_tests.jl:120-642 (test_bulk_microphysics_1m_tendencies): the nineteen cases — signs of the tendencies in each regime, the
+    autoconversion share (Kessler and PrescribedNd), riming / shedding, rain-snow collisions on either side of freezing, deposition, the two conservation
+    identities at saturation, the warm-shedding α identity to 10 eps, nothing from nothing — through cmx_mp1m_tendencies_* and cmx_mp1m_source_terms_*."""
+    import cmx
+    names = ("dq_lcl_dt", "dq_icl_dt", "dq_rai_dt", "dq_sno_dt")
+    for case in rs.G["bmt_1m_cases"]["cases"]:
+        mp = P.Microphysics1MParams(ft, **rs.bmt_1m_options(case))
+        tps = P.ThermodynamicsParameters(ft)
+        cols = [torch.from_numpy(c).to(dev) for c in rs.bmt_1m_case_columns(oracle, case, ft)]
+        t = cmx.bulk_microphysics_tendencies_1m(cmx.Instantaneous(), cmx.Microphysics1Moment(), mp, tps, *cols)
+        src = cmx.microphysics_source_terms_1m(mp, tps, *cols)
+        rs.check_bmt_1m_case(case, ft, {k: float(getattr(t, k)[0]) for k in names}, {k: float(v[0]) for k, v in src._asdict().items()})
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_bulk_tendencies_2m_reference_cases_on_device(dev, oracle, ft):
+    """test/bulk_tendencies_tests.jl:1154-1213 (test_bulk_microphysics_2m_tendencies) — the north-star entry's own reference test: autoconversion at
+    saturation moves cloud to rain, 5 % supersaturation condenses, 20 % subsaturation evaporates cloud."""
+    import cmx
+    names = ("dq_lcl_dt", "dn_lcl_dt", "dq_rai_dt", "dn_rai_dt")
+    mp, tps = P.Microphysics2MParams(ft), P.ThermodynamicsParameters(ft)
+    for case in rs.G["bmt_2m_cases"]["cases"]:
+        cols = [torch.from_numpy(c).to(dev) for c in rs.bmt_2m_case_columns(oracle, case, ft)]
+        t = cmx.bulk_microphysics_tendencies(cmx.Microphysics2Moment(), mp, tps, *cols)
+        rs.check_bmt_1m_case(case, ft, {k: float(getattr(t, k)[0]) for k in names}, {})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_weighted_fall_speeds_do_not_depend_on_the_rule_on_device(dev, ft):
+    """test/p3_tests.jl:513-555 through the ABI: GaussLegendre(12) against ChebyshevGauss(10), p = 1e-3 and 1e-6, NoAspectRatio."""
+    import cmx
+    p, vel = P.ParametersP3(ft), P.Chen2022VelTypeIce(ft)
+    L, N, F, rr, rho_a = [torch.from_numpy(c).to(dev) for c in rs.numerical_integral_states(ft)]
+    ll = cmx.p3_shape(p, L, N, F, rr, from_state=True, want=("log_lambda",)).log_lambda
+
+    def velocities(p_, rule, order):
+        v = cmx.p3_terminal_velocities(p, vel, rho_a, L, N, F, rr, ll, from_state=True, aspect_ratio=False, p=p_, quad=getattr(P, rule)(ft, order))
+        return v.v_n.double().cpu().numpy(), v.v_m.double().cpu().numpy()
+    rs.check_numerical_integrals(velocities)
