@@ -45,8 +45,8 @@ __device__ __forceinline__ void diag_point(const C &c, bool w1, bool w2, bool wr
                                            FT &Z_2m, FT &reff_2m, FT &reff_lh97) {
     using M = Math<FT>;
     const FT log10_2 = FT(0.30102999566398119521);
-    if (w1) {   // CMD :31-46 with CM1.lambda_inverse :126-152 (q, ρ clamped to ≥ 0 there; the floor r0·1e-5 keeps log2(0) = −Inf harmless)
-        const FT l2_li = M::max(c.lam_floor, M::fma(M::log2(max0(rho) * max0(q_rai)), c.lam_a, c.lam_b));
+    if (w1) {   // CMD :31-46 with CM1.lambda_inverse :126-152 (q, ρ clamped to ≥ 0 there; the floor r0·1e-5 makes the floored log2 of an absent species harmless: cmx_math.hpp log2_floored)
+        const FT l2_li = M::max(c.lam_floor, M::fma(log2_floored(max0(rho) * max0(q_rai)), c.lam_a, c.lam_b));
         const FT z = M::max(FT(-150), M::fma(c.z1_c1, l2_li, c.z1_c0));
         Z_1m = any_nan(rho, q_rai) ? M::nan() : z;
     }
@@ -58,18 +58,18 @@ __device__ __forceinline__ void diag_point(const C &c, bool w1, bool w2, bool wr
         const bool no_rain = LIMITED ? (N_rai < eps && q_rai < eps) : (N_rai < eps || q_rai < eps);
         // the moments are N·B^(−n/μ): a NEGATIVE rain number (left by advection; the limited PSD only gates on N < ϵ AND q < ϵ) gives a finite negative
         // moment in the reference — log2 of the magnitude, the sign folded back below (log2 of the raw column was a NaN there)
-        const FT l2_Nr = M::log2(N_rai < FT(0) ? -N_rai : N_rai), sgn_r = N_rai < FT(0) ? FT(-1) : FT(1), dxr = psd.l2_xr - c.l2_6;
+        const FT l2_Nr = log2_floored(N_rai < FT(0) ? -N_rai : N_rai), sgn_r = N_rai < FT(0) ? FT(-1) : FT(1), dxr = psd.l2_xr - c.l2_6;
         // cloud: log x̄_c and logB = −μc (log x̄ + lgΓ(z1) − lgΓ(z2)) (CM2:176-192); notvalid(Bc) where exp(logB) leaves the float type's range
         const FT sq_c = M::max(q_lcl, eps), sN_c = M::max(N_lcl, eps);
         const FT l2_xc = M::log2(rho * sq_c * M::rcp(sN_c));
         const FT lnB = -c.mu_c * (l2_xc * FT(0.69314718055994530942) + c.dlg);
         const bool no_cloud = (N_lcl < eps || q_lcl < eps) || !(lnB < c.lnB_hi) || !(lnB > c.lnB_lo);
-        const FT l2_Nc = M::log2(N_lcl), dxc = M::fma(c.dlg, FT(1.4426950408889634074), l2_xc);
+        const FT l2_Nc = log2_floored(N_lcl), dxc = M::fma(c.dlg, FT(1.4426950408889634074), l2_xc);
         const bool poisoned = any_nan(rho, q_lcl, q_rai, N_lcl, N_rai);
         if (w2) {   // CMD :64-84
             const FT Zc = no_cloud ? FT(0) : M::exp2(l2_Nc + M::fma(c.pc2, dxc, c.kc2));
             const FT Zr = no_rain ? FT(0) : sgn_r * M::exp2(l2_Nr + M::fma(c.pr2, dxr, c.kr2));
-            const FT z = M::max(FT(-150), FT(10) * M::fma(M::log2(M::max(FT(0), Zc + Zr)), log10_2, FT(18)));
+            const FT z = M::max(FT(-150), FT(10) * M::fma(log2_floored(M::max(FT(0), Zc + Zr)), log10_2, FT(18)));
             Z_2m = poisoned ? M::nan() : z;
         }
         if (wr) {   // CMD :100-125

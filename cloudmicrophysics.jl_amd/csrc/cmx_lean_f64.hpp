@@ -469,6 +469,19 @@ CMX_LEAN_FN double log2(double x) {
     return y;
 #endif
 }
+// log2 x for a POSITIVE NORMAL finite x: the main path of log2() alone — no class test and no rescue block.  For arguments that are ordinarily
+// zero (ρ·q of an absent species: half the points of a real field, so nearly every wave would run log2()'s "rare" block — 55 instructions per
+// logarithm for the whole wave), floored at the smallest normal number by the caller (cmx_math.hpp log2_floored).  0, negatives, subnormals, Inf
+// and NaN are outside the contract (NaN comes out as ≈ 1024).
+CMX_LEAN_FN double log2_pos(double x) {
+#if !CMX_LEAN_TABLES || !CMX_F64_FINITE_FORMS
+    return log2(x);
+#else
+    const LeanCoefs &K = coefs();
+    const Log2Parts q = log2_reduce(x, K);
+    return fma_(q.r, poly6s(q.r, K.l2), q.hi);
+#endif
+}
 CMX_LEAN_FN double log(double x);
 // ln x for a POSITIVE NORMAL finite x (a diameter or an area at an interior quadrature node): the main path of log() alone — no class test, no
 // rescue block, so the call does not end a basic block.  0, negatives, subnormals, Inf AND NaN are outside the contract: a NaN argument is reduced

@@ -21,6 +21,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <type_traits>
 
 #include "cmx_lean_f64.hpp"
 
@@ -57,6 +58,7 @@ template <> struct Math<float> {
     static __device__ __forceinline__ void prepare() {}                       // Float32 runs on the hardware transcendental unit: nothing to set up
     static __device__ __forceinline__ float exp2(float x) { return hw::exp2(x); }
     static __device__ __forceinline__ float log2(float x) { return hw::log2(x); }
+    static __device__ __forceinline__ float log2_pn(float x) { return hw::log2(x); }
     static __device__ __forceinline__ float rcp(float x) { return hw::rcp(x); }
     // the finite-argument forms of the Float64 side (below): the hardware instructions handle every special value at no cost
     static __device__ __forceinline__ float exp2_fin(float x) { return hw::exp2(x); }
@@ -98,6 +100,7 @@ template <> struct Math<double> {
     static __device__ __forceinline__ void prepare() { lean::tables_init(); }
     static __device__ __forceinline__ double exp2(double x) { return lean::exp2(x); }
     static __device__ __forceinline__ double log2(double x) { return lean::log2(x); }
+    static __device__ __forceinline__ double log2_pn(double x) { return lean::log2_pos(x); }   // positive NORMAL finite argument (cmx_lean_f64.hpp)
     static __device__ __forceinline__ double rcp(double x) { return lean::rcp(x); }
     // exp2_fin: the argument is finite or NaN (never ±Inf); rcp_nz: the argument is finite and non-zero, or NaN.  They drop the clamp /
     // NaN select (5 instructions) resp. the second Newton step and the 0 / Inf fix-up (5 instructions; 2⁻⁴⁸ relative instead of ≤ 1 ulp)
@@ -145,6 +148,7 @@ template <> struct Math<f32x2> {
     static __device__ __forceinline__ void prepare() {}
     static __device__ __forceinline__ f32x2 exp2(f32x2 x) { return CMX_LANEWISE1(hw::exp2); }
     static __device__ __forceinline__ f32x2 log2(f32x2 x) { return CMX_LANEWISE1(hw::log2); }
+    static __device__ __forceinline__ f32x2 log2_pn(f32x2 x) { return CMX_LANEWISE1(hw::log2); }
     static __device__ __forceinline__ f32x2 rcp(f32x2 x) { return CMX_LANEWISE1(hw::rcp); }
     static __device__ __forceinline__ f32x2 exp2_fin(f32x2 x) { return CMX_LANEWISE1(hw::exp2); }
     static __device__ __forceinline__ f32x2 rcp_nz(f32x2 x) { return CMX_LANEWISE1(hw::rcp); }
@@ -404,6 +408,15 @@ __device__ __forceinline__ double max0(double x) { return Math<double>::max(0.0,
 #if CMX_HAVE_PACKED
 __device__ __forceinline__ f32x2 max0(f32x2 x) { return f32x2{max0(x.x), max0(x.y)}; }
 #endif
+// log2 of a non-negative quantity that is ORDINARILY zero — ρ·q of an absent species.  Float64: floored at the smallest normal number (−1022
+// instead of −Inf: every caller floors the slope parameter it derives far above that, or gates the result on q > ϵ) and evaluated by the
+// main path of the logarithm alone; the full form would send nearly every wave of a real field through its rescue block.  A NaN argument does
+// not survive the max: the kernels apply their NaN rule to the inputs.  Float32: the hardware logarithm takes 0 as it is.
+template <typename FT> __device__ __forceinline__ FT log2_floored(FT x) {
+    using M = Math<FT>;
+    if constexpr (M::IS_F64) return M::log2_pn(M::max(x, FT(2.2250738585072014e-308)));
+    else return M::log2(x);
+}
 // the same for lo ≤ hi as ONE instruction (v_med3_f32: the median of three is the clamp); Float64 has no med3
 __device__ __forceinline__ float clamp_ordered(float x, float lo, float hi) { return hw::med3(x, lo, hi); }
 __device__ __forceinline__ double clamp_ordered(double x, double lo, double hi) { return clampv(x, lo, hi); }
@@ -475,6 +488,13 @@ template <typename FT> __device__ __forceinline__ bool any_nan(FT a) { return CM
 template <typename FT> __device__ __forceinline__ bool any_nan(FT a, FT b) { return CMX_NAN_POISON && __builtin_isunordered(a, b); }
 template <typename FT, typename... R> __device__ __forceinline__ bool any_nan(FT a, FT b, R... r) {
     return (bool)((int)any_nan(a, b) | (int)any_nan(r...));   // bitwise on purpose: no branch
+}
+// The Float64 1-moment entries poison ρ ≤ 0 as well: the air density must be positive (include/cmx.h), their finite-argument forms assume it, and a
+// point outside the domain gets NaN in EVERY output rather than a pattern of NaN, ±Inf and valid-looking numbers.  (Float32 reproduces the
+// reference's own pattern there: its hardware functions take 0 and Inf as IEEE division does.)
+template <typename FT> __device__ __forceinline__ bool bad_density(FT rho) {
+    if constexpr (std::is_same<FT, double>::value) return !(rho > 0.0);
+    else return false;
 }
 // pairs: a lane mask, formed per half with the same unordered compares
 #if CMX_HAVE_PACKED

@@ -217,7 +217,7 @@ template <typename FT, bool REGULAR, typename S> __device__ __forceinline__ FT l
     if constexpr (!REGULAR)
         if (qthr < eps) return x < eps ? FT(0) : FT(x * inv_tau);
     const FT y2 = x * y2c;
-    const FT lg2 = M::log2(M::fma(emk, M::exp2_fin(M::min(y2, FT(60.0 * 1.4426950408889634))), omemk));   // y2 = x·y2c, x ≥ 0 finite
+    const FT lg2 = M::log2_pn(M::fma(emk, M::exp2_fin(M::min(y2, FT(60.0 * 1.4426950408889634))), omemk));   // y2 = x·y2c, x ≥ 0 finite; the argument lies in [1 − e^{−k}, 1 + e^{60−k}]
     return x < eps ? FT(0) : FT(M::max(lg2, y2 - kl2e) * out);
 }
 
@@ -233,7 +233,9 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     // clamp_to_nonneg — BMT:147-152 (T is not clamped)
     rho = max0(rho); q_tot = max0(q_tot); q_lcl = max0(q_lcl);
     q_icl = max0(q_icl); q_rai = max0(q_rai); q_sno = max0(q_sno);
-    const FT inv_rho = M::rcp(rho), inv_T = M::rcp_nz(T);      // T: a temperature (positive, finite); ρ may arrive clamped to 0
+    // T: a temperature (positive, finite).  ρ > 0 (include/cmx.h): Float32 — the hardware reciprocal — takes a ρ clamped to 0 like the reference; the
+    // Float64 entries poison every output of a point with ρ ≤ 0 (cmx_math.hpp bad_density), so the finite-argument form serves
+    const FT inv_rho = M::rcp_nz(rho), inv_T = M::rcp_nz(T);
     const B has_lcl = q_lcl > eps, has_icl = q_icl > eps, has_rai = q_rai > eps, has_sno = q_sno > eps;
 
     // ---- thermodynamics, once -------------------------------------------------------------------------------
@@ -277,7 +279,7 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     }
     c = &consts_after(*c, o.vap_icl);
     // ---- supersaturations and G functions ---------------------------------------------------------------------
-    const FT inv_ps_l = M::rcp(psat_l), inv_ps_i = M::rcp(psat_i);
+    const FT inv_ps_l = M::rcp_nz(psat_l), inv_ps_i = M::rcp_nz(psat_i);      // 2^finite of a temperature: positive normal numbers above T ≈ 10 K
     const FT pv = q_vap * rho_RvT;
     const FT S_l = M::fma(pv, inv_ps_l, FT(-1));                                  // TDI.supersaturation_over_liquid
     const FT S_i = M::fma(pv, inv_ps_i, FT(-1));                                  // …over_ice
@@ -289,7 +291,7 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
 
     c = &consts_after(*c, SG_i);
     // ---- size_distr_parameters — CM1:375-388 ------------------------------------------------------------------
-    const FT l2_rq_rai = M::log2(rho * q_rai), l2_rq_sno = M::log2(rho * q_sno), l2_rq_icl = M::log2(rho * q_icl);
+    const FT l2_rq_rai = log2_floored(rho * q_rai), l2_rq_sno = log2_floored(rho * q_sno), l2_rq_icl = log2_floored(rho * q_icl);   // q = 0: ordinary
     // snow: n0 = μ (ρ max(q, ϵ))^ν if q > ϵ else 0 (get_n0 :83-86); λ⁻¹ uses max(n0, ϵ).  For q ≤ ϵ every snow term is gated to 0 below
     // (through n0 = 0 or has_sno), so the slope parameter only has to stay finite there: no select on log2 n0
     const FT l2_n0_sno = M::fma(c->sno_nu, l2_rq_sno, c->sno_l2_mu);
@@ -314,7 +316,11 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
         li_rai = M::exp2_fin(l2_li_rai); li_sno = M::exp2_fin(l2_li_sno); li2_rai = li_rai * li_rai; li2_sno = li_sno * li_sno;
     }
     // get_v0 :101-104: v0_rai = v0c · sq (v0c folded into the constants)
-    const FT sq = M::sqrt(max0(M::fma(c->rho_w, inv_rho, FT(-1))));
+    // (Float64: floored at the smallest normal number instead of 0 — air denser than water gets √ = 1.5e-154 — so that this root, its root
+    // below and the one of the snow–rain kernel are the positive-argument forms)
+    FT sq_arg = M::fma(c->rho_w, inv_rho, FT(-1));
+    if constexpr (M::IS_F64) sq_arg = M::max(sq_arg, FT(2.2250738585072014e-308)); else sq_arg = max0(sq_arg);
+    const FT sq = M::sqrt_pos(sq_arg);
 
     c = &consts_after(*c, sq);
     // ---- autoconversion — CM1:354-364, 414-446 ------------------------------------------------------------------
@@ -354,7 +360,7 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
         const FT v_rai = (c->vt_k_rai * sq) * (DEFEXP ? pr_half : M::exp2_fin(c->vt_e_rai * l2_li_rai));
         const FT v_sno = c->vt_k_sno * (DEFEXP ? ps_q : M::exp2_fin(c->vt_e_sno * l2_li_sno));
         const FT dv = v_sno - v_rai;
-        const FT dv_eff = M::sqrt(M::fma(dv, dv, c->coeff_disp * M::fma(v_sno, v_sno, v_rai * v_rai)));
+        const FT dv_eff = M::sqrt_pos(M::fma(dv, dv, c->coeff_disp * M::fma(v_sno, v_sno, v_rai * v_rai)));   // v_sno > 0: the slope parameter is floored
         const FT pre = nir_sno * dv_eff;
         const B both = m_and(has_rai, has_sno);
         const FT X = li_sno * li_rai;
@@ -372,7 +378,7 @@ __device__ __forceinline__ Mp1mSrc<FT> mp1m_point(const C &c0, FT rho, FT T, FT 
     c = &consts_after(*c, o.S_sno_rai);
     // ---- ventilated vapour exchange and melting — CM1:917-1139 ---------------------------------------------------
     if (fl & CMX_1M_RAIN_EVAPORATION) {   // min(0, S G 4π n0/ρ λ⁻² F) with the factor of S ≥ 0: the min moves onto S
-        const FT F4 = M::fma(c->ven_b_rai * M::sqrt(sq), DEFEXP ? pr_075 : M::exp2_fin(c->ven_e_rai * l2_li_rai), c->ven_a_rai);
+        const FT F4 = M::fma(c->ven_b_rai * M::sqrt_pos(sq), DEFEXP ? pr_075 : M::exp2_fin(c->ven_e_rai * l2_li_rai), c->ven_a_rai);
         o.vap_rai = has_rai ? FT((inv_rho * li2_rai) * (F4 * (M::min(S_l, FT(0)) * G_l))) : FT(0);
     }
     const FT F4_sno = M::fma(c->ven_b_sno, DEFEXP ? ps_58 : M::exp2_fin(c->ven_e_sno * l2_li_sno), c->ven_a_sno);
@@ -437,7 +443,7 @@ __device__ __forceinline__ void mp1m_tendencies_point(const C &c, FT rho, FT T, 
     const Mp1mSrc<FT> p = mp1m_point<FT, FLAGS>(c, rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno);
     mp1m_aggregate<FT>(p, dl, di, dr, ds);
     if constexpr (lanes_of<FT>::value == 1) {
-        if (any_nan(rho, q_tot, q_lcl, q_icl, q_rai, q_sno, T)) dl = di = dr = ds = Math<FT>::nan();
+        if ((int)any_nan(rho, q_tot, q_lcl, q_icl, q_rai, q_sno, T) | (int)bad_density(rho)) dl = di = dr = ds = Math<FT>::nan();
     } else {
         const typename Math<FT>::Mask poisoned = nan_mask(rho, q_tot, q_lcl, q_icl, q_rai, q_sno, T);
         dl = poisoned ? Math<FT>::nan() : dl; di = poisoned ? Math<FT>::nan() : di; dr = poisoned ? Math<FT>::nan() : dr; ds = poisoned ? Math<FT>::nan() : ds;
@@ -494,7 +500,9 @@ __device__ __forceinline__ void mp1m_linearized_point(const C &c, AF args, int n
         T += (a.Lv_over_cp * (dl + dr) + a.Ls_over_cp * (di + ds)) * a.dt_sub;
     }
     const auto &a = args(T);
-    const FT poison = nan_mask(rho, q_tot, ql0, qi0, qr0, qs0, T0) ? M::nan() : FT(0);   // NaN in → NaN out (cmx_math.hpp any_nan)
+    typename M::Mask bad = nan_mask(rho, q_tot, ql0, qi0, qr0, qs0, T0);                 // NaN in → NaN out (cmx_math.hpp any_nan)
+    if constexpr (M::IS_F64) bad = (bool)((int)bad | (int)bad_density(rho));
+    const FT poison = bad ? M::nan() : FT(0);
     dl_avg = (ql - ql0) * a.inv_dt + poison; di_avg = (qi - qi0) * a.inv_dt + poison;
     dr_avg = (qr - qr0) * a.inv_dt + poison; ds_avg = (qs - qs0) * a.inv_dt + poison;
 }

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kBlock) void mp1m_sources_kernel(const Mp1mConsts<F
     // NaN in → NaN out, as in the tendencies kernels (cmx_math.hpp any_nan): the clamps and the max0 gates of the point function return 0
     // for a NaN operand (for the Float32 integer form: for a NaN with the sign bit set), which would turn a NaN input into a
     // zero melt / accretion term here
-    const FT poison = any_nan(rho, q_tot, q_lcl, q_icl, q_rai, q_sno, T) ? Math<FT>::nan() : FT(0);
+    const FT poison = ((int)any_nan(rho, q_tot, q_lcl, q_icl, q_rai, q_sno, T) | (int)bad_density(rho)) ? Math<FT>::nan() : FT(0);
 #pragma unroll
     for (int k = 0; k < CMX_MP1M_NSRC; ++k)
         if (out.col[k]) out.col[k][i] = s[k] + poison;

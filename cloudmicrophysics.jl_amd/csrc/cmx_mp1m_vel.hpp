@@ -27,11 +27,11 @@ template <typename FT> struct Vel1mConsts {
 // log2 λ⁻¹ of rain / snow (CM1.lambda_inverse :126-152, get_n0 :83-86) from ρ⁺ = max(0, ρ) and q
 template <typename FT, typename VC> __device__ __forceinline__ FT vel_l2_li_rain(const VC &c, FT rp, FT q) {
     using M = Math<FT>;
-    return M::max(c.lam_floor_rai, M::fma(M::log2(rp * M::max(FT(0), q)), c.lam_a_rai, c.lam_b_rai));
+    return M::max(c.lam_floor_rai, M::fma(log2_floored(rp * M::max(FT(0), q)), c.lam_a_rai, c.lam_b_rai));
 }
 template <typename FT, typename VC> __device__ __forceinline__ FT vel_l2_li_snow(const VC &c, FT rp, FT q) {
     using M = Math<FT>;
-    const FT l2_rq = M::log2(rp * M::max(FT(0), q));
+    const FT l2_rq = log2_floored(rp * M::max(FT(0), q));
     const FT l2_n0 = q > c.eps_1m ? FT(M::fma(c.sno_nu, l2_rq, c.sno_l2_mu)) : FT(c.l2_eps);
     return M::max(c.lam_floor_sno, M::fma(l2_rq - M::max(l2_n0, c.l2_eps), c.lam_a_sno, c.lam_b_sno));
 }
@@ -39,18 +39,18 @@ template <typename FT, typename VC> __device__ __forceinline__ FT vel_l2_li_snow
 template <typename FT, typename VC> __device__ __forceinline__ FT vel_rain_blk1m(const VC &c, FT rho, FT l2_li, FT q) {
     using M = Math<FT>;
     const FT sq = M::sqrt(M::max(c.rho_w * M::rcp(rho) - FT(1), FT(0)));
-    return q > c.eps_1m ? FT((c.vt_k_rai * sq) * M::exp2(c.vt_e_rai * l2_li)) : FT(0);
+    return q > c.eps_1m ? FT((c.vt_k_rai * sq) * M::exp2_fin(c.vt_e_rai * l2_li)) : FT(0);      // l2_li: floored, finite
 }
 template <typename FT, typename VC> __device__ __forceinline__ FT vel_snow_blk1m(const VC &c, FT l2_li, FT q) {
     using M = Math<FT>;
-    return q > c.eps_1m ? FT(c.vt_k_sno * M::exp2(c.vt_e_sno * l2_li)) : FT(0);
+    return q > c.eps_1m ? FT(c.vt_k_sno * M::exp2_fin(c.vt_e_sno * l2_li)) : FT(0);
 }
 // Chen 2022 rain, mass-weighted (k = 3), diameter slope = 2 λ⁻¹ — CM1:251-270, Common.jl:290-302,414-422.  Γ(b+1) from the host-fitted
 // polynomials in ρ (NaN fall speed beyond their range, ρ > 2 kg/m³); GENERAL: run-time Γ for parameter sets the fit cannot represent
 template <typename FT, bool GENERAL = false, typename VC> __device__ __forceinline__ FT vel_rain_chen(const VC &c, FT rp, FT l2_li, FT q) {
     using M = Math<FT>;
     const FT l2_lam_inv = l2_li + FT(1);
-    const FT lam = M::exp2(-l2_lam_inv);
+    const FT lam = M::exp2_fin(-l2_lam_inv);
     const FT l2_q = c.ch_rho0_l2e * rp, l2_rho = M::log2(rp);
     FT w = FT(0);
 #pragma unroll
@@ -71,23 +71,23 @@ template <typename FT, bool GENERAL = false, typename VC> __device__ __forceinli
 // CMNonEq.terminal_velocity(::CloudLiquid, ::StokesRegimeVelType, ρ, q): Stokes at the mean-volume diameter — NonEq:250-265
 template <typename FT, typename VC> __device__ __forceinline__ FT vel_lcl_stokes(const VC &c, FT rho, FT q) {
     using M = Math<FT>;
-    const FT D2 = M::exp2(FT(2.0 / 3.0) * M::log2(c.st_D3 * rho * M::max(FT(0), q)));
+    const FT D2 = M::exp2_fin(FT(2.0 / 3.0) * log2_floored(c.st_D3 * rho * M::max(FT(0), q)));
     return q > c.eps_1m ? FT(c.st_pref * (c.st_rho_w * M::rcp(rho) - FT(1)) * D2) : FT(0);
 }
 // CMNonEq.terminal_velocity(::CloudIce, ::Chen2022VelTypeSmallIce, ρ, q): Σ aₖ D^bₖ e^{−cₖD} at that diameter — NonEq:267-281
 template <typename FT, typename VC> __device__ __forceinline__ FT vel_icl_chen(const VC &c, FT rho, FT rp, FT q) {
     using M = Math<FT>;
-    const FT l2_D = FT(1.0 / 3.0) * M::log2(c.ci_D3 * rho * M::max(FT(0), q));
-    const FT D = M::exp2(l2_D);
+    const FT l2_D = FT(1.0 / 3.0) * log2_floored(c.ci_D3 * rho * M::max(FT(0), q));
+    const FT D = M::exp2_fin(l2_D);
     const FT b = M::fma(rp, c.ci_C, c.ci_B);
     const FT common = M::exp2(c.ci_A * M::log2(rp) + b * (c.l2_1000 + l2_D));           // ρₐ^As · (1000 D)^b
-    const FT w = common * M::fma(c.ci_F, M::exp2(-c.ci_c2 * D * FT(1.4426950408889634)), c.ci_E);
+    const FT w = common * M::fma(c.ci_F, M::exp2_fin(-c.ci_c2 * D * FT(1.4426950408889634)), c.ci_E);
     return q > c.eps_1m ? FT(M::max(FT(0), w)) : FT(0);
 }
 // CM1.terminal_velocity(::Snow, ::Chen2022VelTypeLargeIce, ρ, q): mass-weighted (k = 3), λ_D⁻¹ = 2 λ⁻¹ — CM1:272-297
 template <typename FT, typename VC> __device__ __forceinline__ FT vel_snow_chen(const VC &c, FT rp, FT l2_li, FT q) {
     using M = Math<FT>;
-    const FT l2_ld = l2_li + FT(1), lam = M::exp2(-l2_ld);
+    const FT l2_ld = l2_li + FT(1), lam = M::exp2_fin(-l2_ld);
     const FT l2_ra = c.sn_A * M::log2(rp);
     // aₖ e^{−4 ln λ_D⁻¹ − (bₖ+4) ln(λ_D + cₖ)}: term 1 has c = 0 → λ_D^{−b₁}·… collapses to one power
     const FT t1 = c.sn_a1 * M::exp2(l2_ra + c.sn_b1 * l2_ld);

@@ -29,7 +29,8 @@
  *    input of a point gives NaN in every output of that point.  The air density must be positive: ρ ≤ 0 is outside the domain.  Such a
  *    point never yields a valid-looking result — the Float32 kernels reproduce the reference's own NaN / ±Inf pattern, the Float64 kernels
  *    return a non-finite value wherever the reference does and may return NaN for an output the reference still evaluates (their
- *    finite-argument elementary functions assume ρ > 0; tests/test_nan_inputs_gpu.py::test_zero_and_negative_air_density);
+ *    finite-argument elementary functions assume ρ > 0; the Float64 1-moment entries return NaN in EVERY output of such a point;
+ *    tests/test_nan_inputs_gpu.py::test_zero_and_negative_air_density);
  *  - `_f32` entry points compute in float with the reference's Float32
  *    thresholds (eps(Float32), cbrt(floatmin(Float32)) — src/Utilities.jl:318-340),
  *    `_f64` ones in double with the Float64 thresholds.

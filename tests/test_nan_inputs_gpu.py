@@ -125,7 +125,7 @@ def test_zero_and_negative_air_density(dev, sfx):
     result must not look valid: Float32 reproduces the reference's own finite / NaN / ±Inf pattern output by output (its
     hardware reciprocals and logarithms handle 0 and Inf like IEEE division); Float64 — whose finite-argument forms assume
     ρ > 0 — returns a non-finite value wherever the reference does, and may return NaN where the reference still returns a finite number
-    or a signed infinity.  The SB2006 kernel takes ρ^(-1/2) with the full form in both float types (+Inf at ρ = 0, never NaN from the seed)."""
+    or a signed infinity (the 1-moment entries: NaN in every output, test_float64_1m_entries_poison_nonpositive_air_density).  The SB2006 kernel takes ρ^(-1/2) with the full form in both float types (+Inf at ρ = 0, never NaN from the seed)."""
     import numpy as np
 
     import cmx
@@ -159,3 +159,28 @@ def test_zero_and_negative_air_density(dev, sfx):
             else:
                 assert np.all((g != 0) | (r == 0)), (k, g, r)            # non-finite wherever the reference is non-finite
                 assert np.all((g == r) | (g == 3)), (k, g, r)            # and otherwise the reference's class, or NaN
+
+
+def test_float64_1m_entries_poison_nonpositive_air_density(dev):
+    """The Float64 1-moment entries (Instantaneous, LinearizedAverage, source terms): ρ ≤ 0 → NaN in EVERY output of the point (cmx_math.hpp
+    bad_density, include/cmx.h "Conventions"); the points beside it are bit-identical to a run without it."""
+    import cmx
+    from cmx import synthetic
+    n = 4096
+    st = list(synthetic.mp1m_state(n, dtype=torch.float64, device=dev, seed=5))
+    mp, tps = P.Microphysics1MParams("f64"), P.ThermodynamicsParameters("f64")
+    calls = {"instantaneous": lambda c: tuple(cmx.bulk_microphysics_tendencies_1m(cmx.Instantaneous(), cmx.Microphysics1Moment(), mp, tps, *c)),
+             "linearized": lambda c: tuple(cmx.bulk_microphysics_tendencies_1m(cmx.LinearizedAverage(), cmx.Microphysics1Moment(), mp, tps, *c, dt=60.0, nsub=2)),
+             "source terms": lambda c: tuple(cmx.microphysics_source_terms_1m(mp, tps, *c))}
+    idx = torch.arange(3, n, 41, device=dev)
+    mask = torch.zeros(n, dtype=torch.bool, device=dev)
+    mask[idx] = True
+    for name, call in calls.items():
+        clean = call(st)
+        for bad_rho in (0.0, -1.0, -0.0):
+            cols = [c.clone() for c in st]
+            cols[0][idx] = bad_rho
+            out = call(cols)
+            for a, b in zip(out, clean):
+                assert bool(torch.isnan(a[mask]).all()), (name, bad_rho)
+                assert torch.equal(torch.nan_to_num(a[~mask], nan=-7.0), torch.nan_to_num(b[~mask], nan=-7.0)), (name, bad_rho)

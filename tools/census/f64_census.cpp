@@ -55,6 +55,7 @@ template <> struct Math<Cnt> {
     static void prepare() {}
 #define CNT_FN1(name, expr) static Cnt name(Cnt x) { tick(#name); return Cnt(expr); }
     CNT_FN1(exp2, std::exp2(x.v)) CNT_FN1(log2, std::log2(x.v)) CNT_FN1(rcp, 1.0 / x.v) CNT_FN1(exp2_fin, std::exp2(x.v)) CNT_FN1(rcp_nz, 1.0 / x.v)
+    static Cnt log2_pn(Cnt x) { tick("log2"); return Cnt(std::log2(x.v)); }   // the main path of log2: the cost the lean-cost run measures for it
     CNT_FN1(rcp_nz1, 1.0 / x.v) CNT_FN1(sqrt, std::sqrt(x.v)) CNT_FN1(rsqrt, 1.0 / std::sqrt(x.v)) CNT_FN1(sqrt_pos, std::sqrt(x.v))
     CNT_FN1(rsqrt_pos, 1.0 / std::sqrt(x.v)) CNT_FN1(log1p, std::log1p(x.v)) CNT_FN1(expm1, std::expm1(x.v))
     template <typename A, typename B> static Cnt div(A a, B b) { tick("rcp"); tick("mul"); return Cnt((double)Cnt(a) / (double)Cnt(b)); }
