@@ -83,8 +83,11 @@ __device__ __forceinline__ void diag_point(const C &c, bool w1, bool w2, bool wr
     if (wl) {   // CMD :143-163 (the three-argument method: N_lcl = 100, no rain — lh_defaults)
         const FT Nl = lh_defaults ? FT(100) : N_lcl, qr = lh_defaults ? FT(0) : q_rai, Nr = lh_defaults ? FT(0) : N_rai;
         const FT N = Nl + Nr, q = q_lcl + qr;
-        const FT r = M::exp2((M::log2(q * rho * M::rcp(N)) + c.lh_l2k) * FT(1.0 / 3.0)) * c.lh_inv_k3;
-        const FT r0 = N < c.eps_1m ? FT(0) : r;
+        // q = 0 (no condensate: the ordinary case) keeps its exact 0 through the select instead of through log2(0) = −Inf (cmx_math.hpp log2_floored)
+        const FT x = q * rho * M::rcp(N);
+        const FT r = M::exp2((log2_floored(x) + c.lh_l2k) * FT(1.0 / 3.0)) * c.lh_inv_k3;
+        const FT r1 = x > FT(0) ? r : (x == FT(0) ? FT(0) : M::nan());      // a negative argument: the reference's ^(1/3) throws — NaN here, as before
+        const FT r0 = N < c.eps_1m ? FT(0) : r1;
         reff_lh97 = (any_nan(rho, q_lcl) || any_nan(Nl, qr, Nr)) ? M::nan() : r0;
     }
 }

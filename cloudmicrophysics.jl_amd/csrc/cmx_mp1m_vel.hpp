@@ -47,19 +47,20 @@ template <typename FT, typename VC> __device__ __forceinline__ FT vel_snow_blk1m
 }
 // Chen 2022 rain, mass-weighted (k = 3), diameter slope = 2 λ⁻¹ — CM1:251-270, Common.jl:290-302,414-422.  Γ(b+1) from the host-fitted
 // polynomials in ρ (NaN fall speed beyond their range, ρ > 2 kg/m³); GENERAL: run-time Γ for parameter sets the fit cannot represent
-template <typename FT, bool GENERAL = false, typename VC> __device__ __forceinline__ FT vel_rain_chen(const VC &c, FT rp, FT l2_li, FT q) {
+// l2_rho = log2_floored(ρ⁺) (cmx_math.hpp), shared by the three Chen fall speeds of a point: with it and the floored slope parameter every exponent below is finite
+template <typename FT, bool GENERAL = false, typename VC> __device__ __forceinline__ FT vel_rain_chen(const VC &c, FT rp, FT l2_li, FT q, FT l2_rho) {
     using M = Math<FT>;
     const FT l2_lam_inv = l2_li + FT(1);
     const FT lam = M::exp2_fin(-l2_lam_inv);
-    const FT l2_q = c.ch_rho0_l2e * rp, l2_rho = M::log2(rp);
+    const FT l2_q = c.ch_rho0_l2e * rp;
     FT w = FT(0);
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const FT bi = M::fma(-c.ch_b_rho, rp, c.ch_b[k]);
         FT l2_mag = M::fma(bi, c.l2_1000, l2_q);
         if (k == 2) l2_mag = M::fma(c.ch_a3_pow, l2_rho, l2_mag);
-        const FT l2_den = M::log2(lam + c.ch_c1000[k]);
-        const FT e3 = M::exp2(l2_mag - FT(4) * l2_lam_inv - (bi + FT(4)) * l2_den);
+        const FT l2_den = M::log2_pn(lam + c.ch_c1000[k]);                  // λ = 2^finite > 0, c ≥ 0
+        const FT e3 = M::exp2_fin(l2_mag - FT(4) * l2_lam_inv - (bi + FT(4)) * l2_den);
         // Γ(b+4)/3!: the fitted polynomial in ρ, or (b+3)(b+2)(b+1)·Γ(b+1)/6 with the run-time Γ
         const FT g = GENERAL ? FT(tgamma_general<FT>(bi + FT(1)) * (bi + FT(3)) * (bi + FT(2)) * (bi + FT(1)) * FT(1.0 / 6.0)) : chen_gamma_eval<typename M::Scalar>(c.chg, k, rp);
         w = k == 0 ? FT((c.ch_a[k] * e3) * g) : M::fma(c.ch_a[k] * e3, g, w);
@@ -68,6 +69,9 @@ template <typename FT, bool GENERAL = false, typename VC> __device__ __forceinli
     if constexpr (!GENERAL) w = rp > FT(kChenGammaRhoMax) ? M::nan() : w;       // outside the range of the fitted Γ: no silent extrapolation
     return q > c.eps_1m ? w : FT(0);
 }
+template <typename FT, bool GENERAL = false, typename VC> __device__ __forceinline__ FT vel_rain_chen(const VC &c, FT rp, FT l2_li, FT q) {
+    return vel_rain_chen<FT, GENERAL>(c, rp, l2_li, q, log2_floored(rp));
+}
 // CMNonEq.terminal_velocity(::CloudLiquid, ::StokesRegimeVelType, ρ, q): Stokes at the mean-volume diameter — NonEq:250-265
 template <typename FT, typename VC> __device__ __forceinline__ FT vel_lcl_stokes(const VC &c, FT rho, FT q) {
     using M = Math<FT>;
@@ -75,24 +79,30 @@ template <typename FT, typename VC> __device__ __forceinline__ FT vel_lcl_stokes
     return q > c.eps_1m ? FT(c.st_pref * (c.st_rho_w * M::rcp(rho) - FT(1)) * D2) : FT(0);
 }
 // CMNonEq.terminal_velocity(::CloudIce, ::Chen2022VelTypeSmallIce, ρ, q): Σ aₖ D^bₖ e^{−cₖD} at that diameter — NonEq:267-281
-template <typename FT, typename VC> __device__ __forceinline__ FT vel_icl_chen(const VC &c, FT rho, FT rp, FT q) {
+template <typename FT, typename VC> __device__ __forceinline__ FT vel_icl_chen(const VC &c, FT rho, FT rp, FT q, FT l2_rho) {
     using M = Math<FT>;
     const FT l2_D = FT(1.0 / 3.0) * log2_floored(c.ci_D3 * rho * M::max(FT(0), q));
     const FT D = M::exp2_fin(l2_D);
     const FT b = M::fma(rp, c.ci_C, c.ci_B);
-    const FT common = M::exp2(c.ci_A * M::log2(rp) + b * (c.l2_1000 + l2_D));           // ρₐ^As · (1000 D)^b
+    const FT common = M::exp2_fin(c.ci_A * l2_rho + b * (c.l2_1000 + l2_D));             // ρₐ^As · (1000 D)^b
     const FT w = common * M::fma(c.ci_F, M::exp2_fin(-c.ci_c2 * D * FT(1.4426950408889634)), c.ci_E);
     return q > c.eps_1m ? FT(M::max(FT(0), w)) : FT(0);
 }
+template <typename FT, typename VC> __device__ __forceinline__ FT vel_icl_chen(const VC &c, FT rho, FT rp, FT q) {
+    return vel_icl_chen<FT>(c, rho, rp, q, log2_floored(rp));
+}
 // CM1.terminal_velocity(::Snow, ::Chen2022VelTypeLargeIce, ρ, q): mass-weighted (k = 3), λ_D⁻¹ = 2 λ⁻¹ — CM1:272-297
-template <typename FT, typename VC> __device__ __forceinline__ FT vel_snow_chen(const VC &c, FT rp, FT l2_li, FT q) {
+template <typename FT, typename VC> __device__ __forceinline__ FT vel_snow_chen(const VC &c, FT rp, FT l2_li, FT q, FT l2_rho) {
     using M = Math<FT>;
     const FT l2_ld = l2_li + FT(1), lam = M::exp2_fin(-l2_ld);
-    const FT l2_ra = c.sn_A * M::log2(rp);
+    const FT l2_ra = c.sn_A * l2_rho;
     // aₖ e^{−4 ln λ_D⁻¹ − (bₖ+4) ln(λ_D + cₖ)}: term 1 has c = 0 → λ_D^{−b₁}·… collapses to one power
-    const FT t1 = c.sn_a1 * M::exp2(l2_ra + c.sn_b1 * l2_ld);
-    const FT t2 = c.sn_a2 * M::exp2(l2_ra + c.sn_H * rp * FT(1.4426950408889634) - FT(4) * l2_ld - (c.sn_b2 + FT(4)) * M::log2(lam + c.sn_c2));
+    const FT t1 = c.sn_a1 * M::exp2_fin(l2_ra + c.sn_b1 * l2_ld);
+    const FT t2 = c.sn_a2 * M::exp2_fin(l2_ra + c.sn_H * rp * FT(1.4426950408889634) - FT(4) * l2_ld - (c.sn_b2 + FT(4)) * M::log2_pn(lam + c.sn_c2));
     return q > c.eps_1m ? FT(M::max(FT(0), t1 + t2)) : FT(0);
+}
+template <typename FT, typename VC> __device__ __forceinline__ FT vel_snow_chen(const VC &c, FT rp, FT l2_li, FT q) {
+    return vel_snow_chen<FT>(c, rp, l2_li, q, log2_floored(rp));
 }
 
 // ---- sedimentation fluxes of the fused column step (cmx_mp1m_column.hip) ------------------------------------------------------------
@@ -107,14 +117,21 @@ __device__ __forceinline__ SedFlux4<FT> mp1m_sed_fluxes(const VC &vc, FT rho, FT
     // one species after the other (consts_after: only one species' constants live where they are read through the kernel-argument pointer)
     F.f[0] = (r_ * ql) * vel_lcl_stokes<FT>(vc, r_, ql);
     const VC &v1 = consts_after(vc, F.f[0]);
-    F.f[1] = (r_ * qi) * vel_icl_chen<FT>(v1, r_, r_, qi);
+    const FT l2_rho = log2_floored(r_);      // once for the three Chen fall speeds
+    F.f[1] = (r_ * qi) * vel_icl_chen<FT>(v1, r_, r_, qi, l2_rho);
     const VC &v2 = consts_after(v1, F.f[1]);
-    F.f[2] = (r_ * qr) * vel_rain_chen<FT, GENERAL_GAMMA>(v2, r_, vel_l2_li_rain<FT>(v2, r_, qr), qr);
+    // (the general-Γ instantiation forms its own log2 ρ: with the shared one live across its run-time Γ calls the LinearizedAverage column kernel is left
+    // with a 100-byte private segment that no instruction touches — tests/test_kernel_resources.py)
+    F.f[2] = (r_ * qr) * vel_rain_chen<FT, GENERAL_GAMMA>(v2, r_, vel_l2_li_rain<FT>(v2, r_, qr), qr, GENERAL_GAMMA ? log2_floored(keep(r_)) : l2_rho);
     const VC &v3 = consts_after(v2, F.f[2]);
-    F.f[3] = (r_ * qs) * vel_snow_chen<FT>(v3, r_, vel_l2_li_snow<FT>(v3, r_, qs), qs);
-    const FT q[4] = {q_lcl, q_icl, q_rai, q_sno};
-#pragma unroll
-    for (int s = 0; s < 4; ++s) F.f[s] = nan_mask(rho, q[s]) ? M::nan() : F.f[s];
+    F.f[3] = (r_ * qs) * vel_snow_chen<FT>(v3, r_, vel_l2_li_snow<FT>(v3, r_, qs), qs, l2_rho);
+    // NaN in → NaN out per species; Float64: ρ ≤ 0 poisons the point, as in the tendencies (cmx_math.hpp bad_density)
+    auto poison = [&](FT q_s, FT f) -> FT {
+        typename M::Mask bad = nan_mask(rho, q_s);
+        if constexpr (M::IS_F64) bad = (bool)((int)bad | (int)bad_density(rho));
+        return bad ? M::nan() : f;
+    };
+    F.f[0] = poison(q_lcl, F.f[0]); F.f[1] = poison(q_icl, F.f[1]); F.f[2] = poison(q_rai, F.f[2]); F.f[3] = poison(q_sno, F.f[3]);
     return F;
 }
 
