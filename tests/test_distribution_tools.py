@@ -69,6 +69,55 @@ def test_sb2006_psd_limits_and_probability_levels(oracle, limited):
     assert 0 < cb["D_min"][0] < 2e-5 < cb["D_max"][0] < 2e-4
 
 
+def _chebyshev_gauss(f, a, b, n):
+    """P3.integrate(f, a, b, ChebyshevGauss(n)) — src/Quadrature.jl:168-175"""
+    y = np.cos(np.pi * (2 * np.arange(1, n + 1) - 1) / (2 * n))
+    return float(np.sum(np.sqrt(1 - y * y) * np.pi / n * f(0.5 * (b - a) * y + 0.5 * (b + a))) * 0.5 * (b - a))
+
+
+@pytest.mark.parametrize("limited", [True, False])
+def test_sb2006_rain_psd_integrates_to_number_and_mass(oracle, limited):
+    """test/microphysics2M_tests.jl:569-625: the rain PSD between its p = 1e-6 bounds integrates to N_r (ChebyshevGauss(1000), rtol 1e-6) and its third
+    moment to q_r (ChebyshevGauss(100), rtol 6e-4); the moment identities of :627-651 through the exponential-PSD closed forms."""
+    sb = P.SB2006(P.create_toml_dict("f64", P.SB2006_LIMITERS_OVERRIDE), limited)      # the override file of the reference's CPU tests (:26-31)
+    rho, N, q, p = 1.2, 0.5e6, 0.5e-3, 1e-6
+    one = lambda v: np.array([v])  # noqa: E731
+    b = oracle.sb2006_size_distribution(F64, None, sb.pdf_r, one(q), one(rho), one(N), limited=limited, p=p)
+    D_min, D_max = float(b["D_min"][0]), float(b["D_max"][0])
+
+    def psd(D):
+        D = np.atleast_1d(D)
+        return oracle.sb2006_size_distribution(F64, None, sb.pdf_r, np.full_like(D, q), np.full_like(D, rho), np.full_like(D, N), D=D, limited=limited, bounds=False)["n_D"]
+    pr = oracle.pdf_rain_parameters(F64, sb.pdf_r, limited, q, rho, N)
+    f_D = lambda D: pr["N0r"] * np.exp(-D / pr["Dr_mean"])  # noqa: E731 — eq. (3) of the 2M docs, written by hand like the reference's test
+    ND, ND_psd = _chebyshev_gauss(f_D, D_min, D_max, 1000), _chebyshev_gauss(psd, D_min, D_max, 1000)
+    assert ND == pytest.approx(N, rel=1e-6) and ND_psd == pytest.approx(ND, rel=1e-13)
+    k_m = np.pi * float(sb.pdf_r.rho_w) / 6
+    qD = _chebyshev_gauss(lambda D: D ** 3 * f_D(D), D_min, D_max, 100) * k_m / rho
+    qD_psd = _chebyshev_gauss(lambda D: D ** 3 * psd(D), D_min, D_max, 100) * k_m / rho
+    assert qD == pytest.approx(q, rel=6e-4) and qD_psd == pytest.approx(qD, rel=1e-13)
+    # exponential moments: M⁰ = N, k_m M³ = L (DT.exponential_Mⁿ = N D̄ⁿ Γ(n + 1))
+    assert pr["N0r"] * pr["Dr_mean"] == pytest.approx(N, rel=1e-12)
+    assert k_m * N * pr["Dr_mean"] ** 3 * 6 == pytest.approx(q * rho, rel=1e-12)
+
+
+def test_sb2006_cloud_psd_integrates_to_number_and_mass(oracle):
+    """test/microphysics2M_tests.jl:657-719: the cloud PSD (a generalized gamma in D) between its p = 1e-6 bounds integrates to N_l and its third moment to
+    q_l with ChebyshevGauss(100), at the reference's tolerances 1e-5 and 2e-5."""
+    sb = P.SB2006(P.create_toml_dict("f64", P.SB2006_LIMITERS_OVERRIDE), True)
+    rho, N, q, p = 1.2, 1e9, 1e-3, 1e-6
+    one = lambda v: np.array([v])  # noqa: E731
+    b = oracle.sb2006_size_distribution(F64, sb.pdf_c, None, one(q), one(rho), one(N), cloud=True, p=p)
+    D_min, D_max = float(b["D_min"][0]), float(b["D_max"][0])
+
+    def psd(D):
+        D = np.atleast_1d(D)
+        return oracle.sb2006_size_distribution(F64, sb.pdf_c, None, np.full_like(D, q), np.full_like(D, rho), np.full_like(D, N), D=D, cloud=True, bounds=False)["n_D"]
+    k_m = np.pi * float(sb.pdf_c.rho_w) / 6
+    assert _chebyshev_gauss(psd, D_min, D_max, 100) == pytest.approx(N, rel=1e-5)
+    assert _chebyshev_gauss(lambda D: D ** 3 * psd(D), D_min, D_max, 100) * k_m / rho == pytest.approx(q, rel=2e-5)
+
+
 # ---- device vs oracle --------------------------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def dev():

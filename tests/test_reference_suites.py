@@ -392,3 +392,71 @@ def test_weighted_fall_speeds_do_not_depend_on_the_rule(oracle):
         quad = getattr(P, rule)("f64", order)
         return oracle.p3_terminal_velocities(_abi.F64, p.c, vel, quad, flags, L, N, F, rr, rho_a, ll, p=p_)
     check_numerical_integrals(velocities)
+
+
+# ---- test/p3_tests.jl:472-511 — the two quadrature rules, on the node / weight arrays the ABI receives --------------------------------------------------
+def _integrate(f, a, b, quad):
+    """P3.integrate(f, a, b, quad) — src/Quadrature.jl: Σ wᵢ f(x(yᵢ))·(b − a)/2 over the rule's nodes yᵢ ∈ (−1, 1)"""
+    y = np.array(quad.node[:quad.n], dtype=np.float64)
+    w = np.array(quad.weight[:quad.n], dtype=np.float64)
+    return float(np.sum(w * f(0.5 * (b - a) * y + 0.5 * (b + a))) * 0.5 * (b - a))
+
+
+def test_quadrature_rules_like_the_reference():
+    x4 = lambda x: x ** 4  # noqa: E731
+    lo = _integrate(x4, 0.0, 1.0, P.ChebyshevGauss("f64", 10))
+    hi = _integrate(x4, 0.0, 1.0, P.ChebyshevGauss("f64", 100))
+    assert math.isclose(lo, 0.2, rel_tol=0.1) and abs(hi - 0.2) < abs(lo - 0.2)
+    gl16 = P.GaussLegendre("f64", 16)
+    assert math.isclose(_integrate(x4, 0.0, 1.0, gl16), 0.2, rel_tol=1e-12)
+    assert math.isclose(_integrate(lambda x: x ** 7, 0.0, 1.0, gl16), 0.125, rel_tol=1e-12)
+    ref = math.e - 1
+    assert abs(_integrate(np.exp, 0.0, 1.0, gl16) - ref) < 1e-12 and abs(_integrate(np.exp, 0.0, 1.0, P.GaussLegendre("f64", 40)) - ref) < 1e-12
+    gl32 = P.GaussLegendre("f64", 32)                                       # the nested form: consecutive sub-intervals (0, 1, 2)
+    assert math.isclose(_integrate(lambda x: x ** 2, 0.0, 1.0, gl32) + _integrate(lambda x: x ** 2, 1.0, 2.0, gl32), 8 / 3, rel_tol=1e-12)
+    gl37 = P.GaussLegendre("f64", 37)                                       # any order, not only the four the rate kernels use
+    assert math.isclose(_integrate(x4, 0.0, 1.0, gl37), 0.2, rel_tol=1e-12)
+    assert math.isclose(sum(gl37.weight[:37]), 2.0, rel_tol=1e-12)
+    q32 = P.GaussLegendre("f32", 32)                                        # eltype follows FT
+    assert q32.n == 32 and all(np.float32(v) == v for v in q32.node[:32])
+    assert isinstance(P.build_quadrature("f64", 40), type(gl16)) and P.build_quadrature("f64", 40).n == 40       # Quadrature.jl:272-278
+    cg = P.build_quadrature("f64", 100)
+    assert math.isclose(cg.node[0], math.cos(math.pi / 200), rel_tol=1e-15)                                   # Chebyshev–Gauss for every other order
+
+
+# ---- test/p3_tests.jl:14-46 — P3State creation: the thresholds of an unrimed and of a rimed state -----------------------------------------------------
+def test_p3_state_thresholds_unrimed_and_rimed(oracle):
+    p = P.ParametersP3("f64")
+    un = oracle.p3_particle_properties(_abi.F64, p.c, 0.0, 400.0, 1e-4)          # isunrimed: no graupel — D_gr = D_cr = Inf, ρ_g unused (NaN)
+    assert math.isfinite(un["D_th"]) and un["D_gr"] == math.inf and un["D_cr"] == math.inf and math.isnan(un["rho_g"])
+    ri = oracle.p3_particle_properties(_abi.F64, p.c, 0.5, 400.0, 1e-4)
+    assert ri["D_th"] < ri["D_gr"] < ri["D_cr"] and math.isfinite(ri["rho_g"])
+    assert ri["D_th"] == un["D_th"]                                              # D_th does not depend on the rime state
+
+
+# ---- test/microphysics_noneq_tests.jl:144-180 — cloud condensate sedimentation --------------------------------------------------------------------------
+CONDENSATE_SEDIMENTATION = {"liquid": {"rho": 1.1, "q": [0.0, 1e-3, 2e-3]}, "ice": {"rho": 0.75, "q": [0.0, 0.5e-3, 1e-3]}}
+
+
+def check_condensate_sedimentation(vel, ft):
+    """`vel(species, rho, q) -> w` arrays over the three q of CONDENSATE_SEDIMENTATION[species]"""
+    c = CONDENSATE_SEDIMENTATION
+    z, v, v2 = [float(x) for x in vel("liquid", c["liquid"]["rho"], c["liquid"]["q"])]
+    assert z == 0.0 and v > 0
+    assert math.isclose(v2 / v, 2.0 ** (2.0 / 3.0), rel_tol=1e-6 if ft == "f64" else 1e-5)      # Stokes: v ∝ D², D ∝ q^⅓ (rtol 1e-6 in the reference; Float32 here: eps·log2 range)
+    z, v, v2 = [float(x) for x in vel("ice", c["ice"]["rho"], c["ice"]["q"])]
+    assert z == 0.0 and v > 0 and v2 > v
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_cloud_condensate_sedimentation(oracle, ft):
+    fam = {"f64": _abi.F64, "f32": _abi.F32}[ft]
+    mp = P.Microphysics1MParams(ft)
+    vels = (P.StokesRegimeVelType(ft), P.Chen2022VelTypeRain(ft), P.Chen2022VelTypeIce(ft))
+
+    def vel(species, rho, q):
+        q = np.array(q, dtype=np.float64)
+        zero = np.zeros_like(q)
+        out = oracle.sedimentation_velocities(fam, mp.c, *vels, np.full_like(q, rho), q if species == "liquid" else zero, q if species == "ice" else zero, zero, zero)
+        return out["w_lcl" if species == "liquid" else "w_icl"]
+    check_condensate_sedimentation(vel, ft)

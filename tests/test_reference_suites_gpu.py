@@ -185,3 +185,19 @@ def test_weighted_fall_speeds_do_not_depend_on_the_rule_on_device(dev, ft):
         v = cmx.p3_terminal_velocities(p, vel, rho_a, L, N, F, rr, ll, from_state=True, aspect_ratio=False, p=p_, quad=getattr(P, rule)(ft, order))
         return v.v_n.double().cpu().numpy(), v.v_m.double().cpu().numpy()
     rs.check_numerical_integrals(velocities)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_cloud_condensate_sedimentation_on_device(dev, ft):
+    """test/microphysics_noneq_tests.jl:144-180 through cmx_sedimentation_velocities_*: zero at q = 0, Stokes scaling 2^⅔, monotone small-ice fall speed."""
+    import cmx
+    dt = torch.float64 if ft == "f64" else torch.float32
+    mp = P.Microphysics1MParams(ft)
+    vels = (P.StokesRegimeVelType(ft), P.Chen2022VelTypeRain(ft), P.Chen2022VelTypeIce(ft))
+
+    def vel(species, rho, q):
+        q = torch.tensor(q, dtype=dt, device=dev)
+        out = cmx.sedimentation_velocities(mp, *vels, torch.full_like(q, rho), **{"q_lcl" if species == "liquid" else "q_icl": q})
+        return (out.w_lcl if species == "liquid" else out.w_icl).double().cpu().numpy()
+    rs.check_condensate_sedimentation(vel, ft)
