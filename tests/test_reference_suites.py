@@ -460,3 +460,108 @@ def test_cloud_condensate_sedimentation(oracle, ft):
         out = oracle.sedimentation_velocities(fam, mp.c, *vels, np.full_like(q, rho), q if species == "liquid" else zero, q if species == "ice" else zero, zero, zero)
         return out["w_lcl" if species == "liquid" else "w_icl"]
     check_condensate_sedimentation(vel, ft)
+
+
+# ---- test/microphysics1M_tests.jl:151-198, 284-336, 337-379, 455-526, 600-675 — process-level checks through the 18 source terms ----------------------------------------------
+def check_1m_process_cases(source_terms, psat_liquid, psat_ice, ft):
+    """`source_terms(options: dict, (rho, T, q_tot, q_lcl, q_icl, q_rai, q_sno)) -> {S_*: float}`; the saturation pressures come from the oracle (the
+    reference builds its states from TDI's)."""
+    td = P.DEFAULT_PARAMETERS
+    R_d, R_v, T_fr = td["gas_constant_dry_air"], td["gas_constant_vapor"], td["temperature_water_freeze"]
+    eps_m = R_d / R_v
+    R_m = lambda q_tot, q_liq, q_ice: R_d * (1 - q_tot) + R_v * (q_tot - q_liq - q_ice)  # noqa: E731 — TDI.Rₘ
+    # MixedPhaseEvaporation (:151-173): rain evaporates in subsaturated warm air with snow present
+    T, p = T_fr + 10, 90000.0
+    ps = psat_liquid(T)
+    q_sat = eps_m * ps / (p + ps * (eps_m - 1))
+    q_rai = q_sno = 1e-4
+    q_tot, q_vap = 15e-3, 0.7 * q_sat
+    q_liq = q_tot - q_vap - q_rai - q_sno
+    rho = p / R_m(q_tot, q_liq + q_rai, q_sno) / T
+    assert source_terms({}, (rho, T, q_tot, q_liq, 0.0, q_rai, q_sno))["S_phase_change_vap_rai"] < 0
+    # MixedPhaseSublimation (:175-197): snow sublimates in air subsaturated over ice with rain present (sublimation under either option)
+    T = T_fr - 10
+    ps = psat_ice(T)
+    q_sat = eps_m * ps / (p + ps * (eps_m - 1))
+    q_vap = 0.9 * q_sat
+    q_tot = q_vap + q_sno + q_rai
+    rho = p / R_m(q_tot, q_rai, q_sno) / T
+    assert source_terms({}, (rho, T, q_tot, 0.0, 0.0, q_rai, q_sno))["S_phase_change_vap_sno"] < 0
+    # SnowAutoconversion, WithSupersaturation (:284-336)
+    ss = {"snow_autoconversion": "WithSupersaturation"}
+    rho = 1.0
+    q_sat_i = lambda T: psat_ice(T) / (rho * R_v * T)  # noqa: E731
+    acnv = lambda T, q_tot, q_lcl, q_icl: source_terms(ss, (rho, T, q_tot, q_lcl, q_icl, 1e-4, 1e-4))["S_acnv_icl_sno"]  # noqa: E731
+    q_v, q_l = 15e-3, 2e-3
+    assert acnv(T_fr + 30, q_v + q_l + 1e-3 + 2e-4, q_l, 1e-3) == 0                         # above freezing
+    assert acnv(T_fr - 30, q_v + q_l + 2e-4, q_l, 0.0) == 0                                 # no cloud ice
+    assert abs(acnv(T_fr - 5, q_sat_i(T_fr - 5), q_l, 3e-3)) < 1e-12                        # no supersaturation (≈ 0 in the reference)
+    T = T_fr - 10
+    q_v = 1.02 * q_sat_i(T)
+    q_i = 0.03 * q_v
+    got = acnv(T, q_v + q_i + 2e-4, 0.0, q_i)
+    assert math.isclose(got, 2.5408135723057333e-9, rel_tol=math.sqrt(np.finfo(np.float64).eps) if ft == "f64" else 2e-3), got       # the reference's regression value
+    # AccretionOptionAPI (:455-526): the option-dispatched accretion terms at the regression values of the "Accretion" testset, routed by temperature
+    rt = math.sqrt(np.finfo(np.float64).eps) if ft == "f64" else 1e-3
+    state = lambda T: (1.2, T, 20e-3, 5e-4, 5e-4, 5e-4, 5e-4)  # noqa: E731
+    warm, cold = source_terms({}, state(T_fr + 5)), source_terms({}, state(T_fr - 5))
+    for k, ref in (("S_accr_lcl_rai", 1.4150106417043544e-6), ("S_accr_icl_rai", 1.768763302130443e-6), ("S_accr_icl_sno", 2.453070979562392e-7),
+                   ("S_accr_lcl_sno_warm", 2.453070979562392e-7), ("S_accr_rai_sno_warm", 6.830957197816771e-5)):
+        assert math.isclose(warm[k], ref, rel_tol=rt), (k, warm[k], ref)
+    assert 0 <= warm["S_accr_melt_lcl_sno"] <= warm["S_accr_lcl_sno_warm"] and warm["S_accr_melt_rai_sno"] >= 0
+    assert warm["S_accr_lcl_sno_cold"] == 0 and warm["S_accr_rai_sno_cold"] == 0
+    assert math.isclose(cold["S_accr_lcl_sno_cold"], 2.453070979562392e-7, rel_tol=rt) and math.isclose(cold["S_accr_rai_sno_cold"], 2.466313958248222e-4, rel_tol=rt)
+    assert cold["S_accr_melt_lcl_sno"] == 0 and cold["S_accr_melt_rai_sno"] == 0 and cold["S_accr_lcl_sno_warm"] == 0 and cold["S_accr_rai_sno_warm"] == 0
+    zero = source_terms({}, (1.2, T_fr + 5, 0.0, 0.0, 0.0, 0.0, 0.0))                      # zero inputs → zero rates
+    assert all(zero[k] == 0 for k in zero if k.startswith("S_accr")), zero
+    # SnowSublimation / SnowSublimation and Deposition (:600-675): regression values at rtol 1e-2, both options
+    ref_dep = [-1.9756907119482267e-7, 1.9751292385808357e-7, -1.6641552112891826e-7, 1.663814937710236e-7]
+    cnt = 0
+    for T in (T_fr + 2, T_fr - 2):
+        ps = psat_ice(T)
+        q_sat = eps_m * ps / (90000.0 + ps * (eps_m - 1))
+        for f in (0.95, 1.05):
+            q_tot = f * q_sat + 1e-4
+            rho = 90000.0 / R_m(q_tot, 0.0, 1e-4) / T
+            cols = (rho, T, q_tot, 0.0, 0.0, 0.0, 1e-4)
+            dep = source_terms({"snow_deposition_sublimation": "DepositionAndSublimation"}, cols)["S_phase_change_vap_sno"]
+            sub = source_terms({"snow_deposition_sublimation": "SublimationOnly"}, cols)["S_phase_change_vap_sno"]
+            assert math.isclose(dep, ref_dep[cnt], rel_tol=1e-2), (T, f, dep, ref_dep[cnt])
+            assert math.isclose(sub, min(ref_dep[cnt], 0.0), rel_tol=1e-2, abs_tol=0.0), (T, f, sub)
+            cnt += 1
+    # test/microphysics_noneq_tests.jl:93-143 — the INP limiter above freezing, asymmetric deposition / sublimation timescales
+    rho, Tw = 0.8, 280.0
+    q_si_w, q_sl_w = psat_ice(Tw) / (rho * R_v * Tw), psat_liquid(Tw) / (rho * R_v * Tw)
+    nq = lambda T, q_tot, q_icl=0.0, **opt: source_terms(opt, (rho, T, q_tot, 0.0, q_icl, 0.0, 0.0))  # noqa: E731
+    assert nq(Tw, 1.5 * q_si_w)["S_phase_change_vap_icl"] == 0                              # would deposit: the limiter zeroes it
+    assert nq(Tw, 1.5 * q_sl_w)["S_phase_change_vap_lcl"] > 0                               # condensation is unaffected
+    assert nq(Tw, 0.5 * q_si_w, 1e-3)["S_phase_change_vap_icl"] <= 0                        # sublimation is not limited
+    Tc = 263.0
+    q_si = psat_ice(Tc) / (rho * R_v * Tc)
+    tau = lambda t: {"sublimation_deposition_timescale": t}  # noqa: E731
+    assert nq(Tc, 0.5 * q_si, 1e-3, _override=tau(1.0))["S_phase_change_vap_icl"] < nq(Tc, 0.5 * q_si, 1e-3, _override=tau(100.0))["S_phase_change_vap_icl"] < 0
+    dep = [nq(Tc, 1.5 * q_si, cloud_ice_formation="TemperatureDependent", _override=tau(t))["S_phase_change_vap_icl"] for t in (1.0, 100.0)]
+    assert dep[0] > 0 and math.isclose(dep[0], dep[1], rel_tol=1e-12)                         # deposition uses the Frostenberg timescale only
+    # RainLiquidAccretion (:337-379) against eq. 5b of Grabowski 1996, to 10 % (atol 0.2 below eps)
+    rho, q_liq, q_tot = 1.2, 5e-4, 20e-3
+    for q_r in np.linspace(1e-8, 5e-3, 10):
+        emp = 2.2 * (q_liq / (1 - q_tot)) * (q_r / (1 - q_tot)) ** (7 / 8)
+        got = source_terms({}, (rho, T_fr + 10, q_tot, q_liq, 0.0, float(q_r), 0.0))["S_accr_lcl_rai"]
+        assert abs(got - emp) <= 0.1 * emp, (q_r, got, emp)
+
+
+def process_case_params(ft, options):
+    """the float type, or a parameter dictionary of it with the case's overrides (`_override`: ClimaParams names)"""
+    return P.create_toml_dict(ft, options["_override"]) if options.get("_override") else ft
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_1m_process_level_checks(oracle, ft):
+    t64 = P.ThermodynamicsParameters("f64")
+    npt = {"f32": np.float32, "f64": np.float64}[ft]
+
+    def source_terms(options, cols):
+        mp = P.Microphysics1MParams(process_case_params(ft, options), **{k: getattr(P, v)() for k, v in options.items() if k != "_override"})
+        r = oracle.mp1m(FAM[ft], mp.c, P.ThermodynamicsParameters(ft), mp.flags, *[np.array([v], dtype=npt) for v in cols], want_sources=True)
+        return {k: float(v[0]) for k, v in r["sources"].items()}
+    check_1m_process_cases(source_terms, lambda T: oracle.psat_liquid(_abi.F64, t64, T), lambda T: oracle.psat_ice(_abi.F64, t64, T), ft)

@@ -201,3 +201,19 @@ def test_cloud_condensate_sedimentation_on_device(dev, ft):
         out = cmx.sedimentation_velocities(mp, *vels, torch.full_like(q, rho), **{"q_lcl" if species == "liquid" else "q_icl": q})
         return (out.w_lcl if species == "liquid" else out.w_icl).double().cpu().numpy()
     rs.check_condensate_sedimentation(vel, ft)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_1m_process_level_checks_on_device(dev, oracle, ft):
+    """test/microphysics1M_tests.jl:151-198, 284-336 (incl. the WithSupersaturation regression value 2.5408135723057333e-9), 337-379, 455-526, 600-675 through
+    cmx_microphysics_source_terms_1m_*."""
+    import cmx
+    dt = torch.float64 if ft == "f64" else torch.float32
+    t64 = P.ThermodynamicsParameters("f64")
+
+    def source_terms(options, cols):
+        mp = P.Microphysics1MParams(rs.process_case_params(ft, options), **{k: getattr(P, v)() for k, v in options.items() if k != "_override"})
+        out = cmx.microphysics_source_terms_1m(mp, P.ThermodynamicsParameters(ft), *[torch.tensor([v], dtype=dt, device=dev) for v in cols])
+        return {k: float(v.double().cpu()[0]) for k, v in out._asdict().items()}
+    rs.check_1m_process_cases(source_terms, lambda T: oracle.psat_liquid(_abi.F64, t64, T), lambda T: oracle.psat_ice(_abi.F64, t64, T), ft)
