@@ -565,3 +565,43 @@ def test_1m_process_level_checks(oracle, ft):
         r = oracle.mp1m(FAM[ft], mp.c, P.ThermodynamicsParameters(ft), mp.flags, *[np.array([v], dtype=npt) for v in cols], want_sources=True)
         return {k: float(v[0]) for k, v in r["sources"].items()}
     check_1m_process_cases(source_terms, lambda T: oracle.psat_liquid(_abi.F64, t64, T), lambda T: oracle.psat_ice(_abi.F64, t64, T), ft)
+
+
+# ---- test/common_functions_tests.jl:9-19, 35-126 — logistic function, H2SO4 solution pressure, the three water activities -----------------------------
+def check_water_activities(a_w_ice, a_w_eT, h2so4):
+    """`a_w_ice(T)`, `a_w_eT(e, T)`, `h2so4(x, T) -> (p_sol, a_w_xT)` on scalars"""
+    assert h2so4(0.1, 225.0)[0] > h2so4(0.1, 200.0)[0]                                  # p_sol higher at warmer temperatures (:35-60)
+    for x in (0.1, 0.06):
+        assert h2so4(x, 228.8)[1] < h2so4(x, 229.2)[1]                                  # a_w_xT greater at warmer temperatures (:63-86)
+    for T in (229.2, 228.8):
+        assert h2so4(0.1, T)[1] < h2so4(0.06, T)[1]                                     # … and at lower acid concentration
+    assert a_w_eT(544.0, 251.0) > a_w_eT(1088.0, 285.0)                                 # greater at higher altitudes (:88-106)
+    for T in (285.0, 251.0):
+        assert a_w_eT(544.0, T) < a_w_eT(1088.0, T)
+    assert a_w_ice(230.0) < a_w_ice(240.0)                                              # :109-124
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_water_activities_like_the_reference(oracle, ft):
+    fam, tps, prs = FAM[ft], P.ThermodynamicsParameters(ft), P.H2SO4SolutionParameters(ft)
+    one = lambda v: np.array([v])  # noqa: E731
+    check_water_activities(lambda T: float(oracle.water_activity(fam, tps, one(T))[0][0]),
+                           lambda e, T: float(oracle.water_activity(fam, tps, one(T), one(e))[1][0]),
+                           lambda x, T: tuple(float(v[0]) for v in oracle.h2so4_solution(fam, prs, tps, one(x), one(T))))
+
+
+# ---- test/heterogeneous_ice_nucleation_tests.jl:170-208 — ABIFM J: colder → larger ----------------------------------------------
+def check_abifm_orderings(J_het, a_w_eT, a_w_xT):
+    """`J_het(dust_name, T, a_w)`; the activities as in check_water_activities"""
+    for dust in ("Illite", "Kaolinite"):      # (the ABIFM fields of DesertDust are not among the parameters this repo carries)
+        assert J_het(dust, 228.8, a_w_xT(0.1, 228.8)) > J_het(dust, 229.2, a_w_xT(0.1, 229.2)) > 0
+        assert J_het(dust, 251.0, a_w_eT(544.0, 251.0)) > J_het(dust, 285.0, a_w_eT(1088.0, 285.0)) >= 0
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_abifm_orderings(oracle, ft):
+    fam, tps, prs, koop = FAM[ft], P.ThermodynamicsParameters(ft), P.H2SO4SolutionParameters(ft), P.Koop2000(ft)
+    one = lambda v: np.array([v])  # noqa: E731
+    J = lambda dust, T, a_w: float(oracle.ice_nucleation_rates(fam, tps, getattr(P, dust)(ft), koop, _abi.CMX_ICENUC_HOM_LINEAR, one(T), one(a_w), one(1e-6))["J_het"][0])  # noqa: E731
+    check_abifm_orderings(J, lambda e, T: float(oracle.water_activity(fam, tps, one(T), one(e))[1][0]),
+                          lambda x, T: float(oracle.h2so4_solution(fam, prs, tps, one(x), one(T))[1][0]))

@@ -217,3 +217,32 @@ def test_1m_process_level_checks_on_device(dev, oracle, ft):
         out = cmx.microphysics_source_terms_1m(mp, P.ThermodynamicsParameters(ft), *[torch.tensor([v], dtype=dt, device=dev) for v in cols])
         return {k: float(v.double().cpu()[0]) for k, v in out._asdict().items()}
     rs.check_1m_process_cases(source_terms, lambda T: oracle.psat_liquid(_abi.F64, t64, T), lambda T: oracle.psat_ice(_abi.F64, t64, T), ft)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_water_activities_like_the_reference_on_device(dev, ft):
+    """test/common_functions_tests.jl:35-126 through cmx_h2so4_solution_* and the two water-activity entries."""
+    from cmx import ice_nucleation as inuc
+    dt = torch.float64 if ft == "f64" else torch.float32
+    tps, prs = P.ThermodynamicsParameters(ft), P.H2SO4SolutionParameters(ft)
+    one = lambda v: torch.tensor([v], dtype=dt, device=dev)  # noqa: E731
+    rs.check_water_activities(lambda T: float(inuc.a_w_ice(tps, one(T)).cpu()[0]), lambda e, T: float(inuc.a_w_eT(tps, one(e), one(T)).cpu()[0]),
+                              lambda x, T: tuple(float(v.cpu()[0]) for v in inuc.h2so4_solution(prs, tps, one(x), one(T))))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_abifm_orderings_on_device(dev, ft):
+    """test/heterogeneous_ice_nucleation_tests.jl:170-208 through cmx_ice_nucleation_rates_* (and the xT form for the solution droplets)."""
+    from cmx import ice_nucleation as inuc
+    dt = torch.float64 if ft == "f64" else torch.float32
+    tps, prs, koop = P.ThermodynamicsParameters(ft), P.H2SO4SolutionParameters(ft), P.Koop2000(ft)
+    one = lambda v: torch.tensor([v], dtype=dt, device=dev)  # noqa: E731
+    J = lambda dust, T, a_w: float(inuc.ice_nucleation_rates(tps, getattr(P, dust)(ft), koop, one(T), one(a_w), linear=True, want=("J_het",)).J_het.cpu()[0])  # noqa: E731
+    rs.check_abifm_orderings(J, lambda e, T: float(inuc.a_w_eT(tps, one(e), one(T)).cpu()[0]),
+                             lambda x, T: float(inuc.h2so4_solution(prs, tps, one(x), one(T))[1].cpu()[0]))
+    # the same through the xT entry: the activity is formed in the kernel from the acid weight fraction
+    Jx = lambda dust, T: float(inuc.ice_nucleation_rates(tps, getattr(P, dust)(ft), koop, one(T), one(0.1), linear=True, want=("J_het",), h2so4=prs).J_het.cpu()[0])  # noqa: E731
+    for dust in ("Illite", "Kaolinite"):      # (the ABIFM fields of DesertDust are not among the parameters this repo carries)
+        assert Jx(dust, 228.8) > Jx(dust, 229.2) > 0
