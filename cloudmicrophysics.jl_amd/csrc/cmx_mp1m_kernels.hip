@@ -164,20 +164,26 @@ __global__ __launch_bounds__(kBlock) void mp1m_velocity_kernel(const Vel1mConsts
     if (i >= n) return;
     const FT rho = io.rho[i];
     const FT rp = M::max(FT(0), rho);
+    // Float64: ρ ≤ 0 (outside the domain, include/cmx.h) gives NaN in every output, as in the tendency entries — the floored logarithms of the fall
+    // speeds (cmx_math.hpp log2_floored) would otherwise return finite numbers where the reference's are ±Inf or NaN
+    auto out = [&](FT v) -> FT {
+        if constexpr (M::IS_F64) return bad_density(rho) ? M::nan() : v;
+        else return v;
+    };
     if (io.vt_rai || io.vt_chen) {
         const FT q = io.q_rai[i];
         const FT l2_li = vel_l2_li_rain<FT>(c, rp, q);
-        if (io.vt_rai) io.vt_rai[i] = vel_rain_blk1m<FT>(c, rho, l2_li, q);
-        if (io.vt_chen) io.vt_chen[i] = vel_rain_chen<FT, GENERAL_GAMMA>(c, rp, l2_li, q);
+        if (io.vt_rai) io.vt_rai[i] = out(vel_rain_blk1m<FT>(c, rho, l2_li, q));
+        if (io.vt_chen) io.vt_chen[i] = out(vel_rain_chen<FT, GENERAL_GAMMA>(c, rp, l2_li, q));
     }
     if (io.vt_sno || io.w_sno_chen) {
         const FT q = io.q_sno[i];
         const FT l2_li = vel_l2_li_snow<FT>(c, rp, q);
-        if (io.vt_sno) io.vt_sno[i] = vel_snow_blk1m<FT>(c, l2_li, q);
-        if (io.w_sno_chen) io.w_sno_chen[i] = vel_snow_chen<FT>(c, rp, l2_li, q);
+        if (io.vt_sno) io.vt_sno[i] = out(vel_snow_blk1m<FT>(c, l2_li, q));
+        if (io.w_sno_chen) io.w_sno_chen[i] = out(vel_snow_chen<FT>(c, rp, l2_li, q));
     }
-    if (io.w_lcl) io.w_lcl[i] = vel_lcl_stokes<FT>(c, rho, io.q_lcl[i]);
-    if (io.w_icl) io.w_icl[i] = vel_icl_chen<FT>(c, rho, rp, io.q_icl[i]);
+    if (io.w_lcl) io.w_lcl[i] = out(vel_lcl_stokes<FT>(c, rho, io.q_lcl[i]));
+    if (io.w_icl) io.w_icl[i] = out(vel_icl_chen<FT>(c, rho, rp, io.q_icl[i]));
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------

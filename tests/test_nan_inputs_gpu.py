@@ -184,3 +184,28 @@ def test_float64_1m_entries_poison_nonpositive_air_density(dev):
             for a, b in zip(out, clean):
                 assert bool(torch.isnan(a[mask]).all()), (name, bad_rho)
                 assert torch.equal(torch.nan_to_num(a[~mask], nan=-7.0), torch.nan_to_num(b[~mask], nan=-7.0)), (name, bad_rho)
+
+
+def test_float64_1m_fall_speed_entries_poison_nonpositive_air_density(dev):
+    """… and the 1-moment fall-speed entries (terminal_velocity_1m, sedimentation_velocities): the floored logarithms of the Float64 fall speeds would return finite
+    numbers at ρ = 0, where the reference's are ±Inf or NaN."""
+    import cmx
+    n = 512
+    g = torch.Generator(device="cpu").manual_seed(3)
+    q = [(1e-4 * torch.rand(n, dtype=torch.float64, generator=g)).to(dev) for _ in range(4)]
+    rho = (0.4 + torch.rand(n, dtype=torch.float64, generator=g)).to(dev)
+    mp = P.Microphysics1MParams("f64")
+    vels = (P.StokesRegimeVelType("f64"), P.Chen2022VelTypeRain("f64"), P.Chen2022VelTypeIce("f64"))
+    idx = torch.arange(5, n, 17, device=dev)
+    mask = torch.zeros(n, dtype=torch.bool, device=dev)
+    mask[idx] = True
+    calls = {"terminal_velocity_1m": lambda r: tuple(v for v in cmx.terminal_velocity_1m(mp, r, q[2], q[3], chen=True) if v is not None),
+             "sedimentation_velocities": lambda r: tuple(cmx.sedimentation_velocities(mp, *vels, r, *q))}
+    for name, call in calls.items():
+        clean = call(rho)
+        for bad_rho in (0.0, -1.0):
+            r = rho.clone()
+            r[idx] = bad_rho
+            for a, b in zip(call(r), clean):
+                assert bool(torch.isnan(a[mask]).all()), (name, bad_rho)
+                assert torch.equal(a[~mask], b[~mask]), (name, bad_rho)
