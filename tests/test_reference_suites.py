@@ -605,3 +605,63 @@ def test_abifm_orderings(oracle, ft):
     J = lambda dust, T, a_w: float(oracle.ice_nucleation_rates(fam, tps, getattr(P, dust)(ft), koop, _abi.CMX_ICENUC_HOM_LINEAR, one(T), one(a_w), one(1e-6))["J_het"][0])  # noqa: E731
     check_abifm_orderings(J, lambda e, T: float(oracle.water_activity(fam, tps, one(T), one(e))[1][0]),
                           lambda x, T: float(oracle.h2so4_solution(fam, prs, tps, one(x), one(T))[1][0]))
+
+
+# ---- test/microphysics1M_tests.jl:107-121 — the 1-moment snow fall speed: the near-zero edge case, zero, monotone ------------------------------------------
+def check_blk1m_snow_fall_speed(v_sno):
+    """`v_sno(rho, q) -> float`"""
+    assert not math.isnan(v_sno(0.2439843, 3.0e-45))           # 3f-45: the smallest Float32 subnormal — below ϵ, the gate returns 0
+    assert abs(v_sno(1.2, 0.0)) <= np.finfo(np.float32).eps
+    v, v2 = v_sno(1.2, 5e-4), v_sno(1.2, 1e-3)
+    assert v > 0 and v2 > v
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_blk1m_snow_fall_speed(oracle, ft):
+    mp = P.Microphysics1MParams(ft)
+    one = lambda v: np.array([v], dtype={"f32": np.float32, "f64": np.float64}[ft])  # noqa: E731
+    chen = P.Chen2022VelTypeRain(ft)
+    check_blk1m_snow_fall_speed(lambda rho, q: float(oracle.mp1m_terminal_velocity(FAM[ft], mp.c, chen, one(rho), one(0.0), one(q))["vt_sno_blk1m"][0]))
+
+
+# ---- test/bulk_tendencies_tests.jl:702-773 — the structure of the donor-based linearization in two pure cases ------------------------------------------
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_linearize_structure(oracle, ft):
+    fam, mp, tps, t64 = FAM[ft], P.Microphysics1MParams(ft), P.ThermodynamicsParameters(ft), P.ThermodynamicsParameters("f64")
+    T_fr, R_v, q_min = P.DEFAULT_PARAMETERS["temperature_water_freeze"], P.DEFAULT_PARAMETERS["gas_constant_vapor"], 1e-10
+    rho = 1.2
+    # warm, rain only: evaporation is the one process — only M33 is non-zero
+    T = T_fr + 15
+    q_sat = oracle.psat_liquid(_abi.F64, t64, T) / (rho * R_v * T)
+    L = oracle.mp1m_linearize(fam, mp.c, tps, mp.flags, q_min, rho, T, 0.5 * q_sat + 1e-3, 0.0, 0.0, 1e-3, 0.0)
+    assert L["M33"] <= 0
+    assert all(L[k] == 0 for k in ("M11", "M12", "M22", "M31", "M34", "M41", "M42", "M43", "M44", "e1", "e2", "e4")), L
+    # warm, snow only, saturated over ice: snow melts to rain — M34 > 0, M44 < 0
+    T = T_fr + 5
+    q_sat_i = oracle.psat_ice(_abi.F64, t64, T) / (rho * R_v * T)
+    L = oracle.mp1m_linearize(fam, mp.c, tps, mp.flags, q_min, rho, T, q_sat_i + 1e-3, 0.0, 0.0, 0.0, 1e-3)
+    assert L["M34"] > 0 and L["M44"] < 0
+    assert all(L[k] == 0 for k in ("M11", "M12", "M22", "M31", "M41", "M42", "M43")), L
+
+
+# ---- test/bulk_tendencies_tests.jl:815-843 — one linearized implicit step: the rain evaporation rate is damped as Δt grows ----------------------------------
+def check_evaporation_damping(implicit_step_dq_rai):
+    """`implicit_step_dq_rai(cols, dt) -> float` (LinearizedAverage with one substep)"""
+    rates = [implicit_step_dq_rai(dt) for dt in (1.0, 5.0, 10.0, 50.0, 100.0)]
+    assert all(math.isfinite(r) and r < 0 for r in rates), rates
+    assert all(abs(rates[i + 1]) <= abs(rates[i]) for i in range(len(rates) - 1)), rates
+
+
+def evaporation_damping_state(oracle):
+    t64, rho = P.ThermodynamicsParameters("f64"), 1.2
+    T = P.DEFAULT_PARAMETERS["temperature_water_freeze"] + 15
+    q_sat = oracle.psat_liquid(_abi.F64, t64, T) / (rho * P.DEFAULT_PARAMETERS["gas_constant_vapor"] * T)
+    return (rho, T, 0.5 * q_sat + 1e-3, 0.0, 0.0, 1e-3, 0.0)
+
+
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_implicit_step_damps_rain_evaporation(oracle, ft):
+    fam, mp, tps = FAM[ft], P.Microphysics1MParams(ft), P.ThermodynamicsParameters(ft)
+    npt = {"f32": np.float32, "f64": np.float64}[ft]
+    cols = [np.array([v], dtype=npt) for v in evaporation_damping_state(oracle)]
+    check_evaporation_damping(lambda dt: float(oracle.mp1m_linearized_average(fam, mp.c, tps, mp.flags, 1e-10, dt, 1, *cols)["dq_rai_dt"][0]))

@@ -246,3 +246,26 @@ def test_abifm_orderings_on_device(dev, ft):
     Jx = lambda dust, T: float(inuc.ice_nucleation_rates(tps, getattr(P, dust)(ft), koop, one(T), one(0.1), linear=True, want=("J_het",), h2so4=prs).J_het.cpu()[0])  # noqa: E731
     for dust in ("Illite", "Kaolinite"):      # (the ABIFM fields of DesertDust are not among the parameters this repo carries)
         assert Jx(dust, 228.8) > Jx(dust, 229.2) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_blk1m_snow_fall_speed_on_device(dev, ft):
+    """test/microphysics1M_tests.jl:107-121 through cmx_mp1m_terminal_velocity_*: no NaN at q = 3f-45, zero at q = 0, monotone."""
+    import cmx
+    dt = torch.float64 if ft == "f64" else torch.float32
+    mp = P.Microphysics1MParams(ft)
+    one = lambda v: torch.tensor([v], dtype=dt, device=dev)  # noqa: E731
+    rs.check_blk1m_snow_fall_speed(lambda rho, q: float(cmx.terminal_velocity_1m(mp, one(rho), q_sno=one(q))[1].double().cpu()[0]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ft", ["f64", "f32"])
+def test_implicit_step_damps_rain_evaporation_on_device(dev, oracle, ft):
+    """test/bulk_tendencies_tests.jl:815-843 through cmx_mp1m_linearized_average_* with one substep."""
+    import cmx
+    dt_ = torch.float64 if ft == "f64" else torch.float32
+    mp, tps = P.Microphysics1MParams(ft), P.ThermodynamicsParameters(ft)
+    cols = [torch.tensor([v], dtype=dt_, device=dev) for v in rs.evaporation_damping_state(oracle)]
+    rs.check_evaporation_damping(lambda dt: float(cmx.bulk_microphysics_tendencies_1m(cmx.LinearizedAverage(), cmx.Microphysics1Moment(), mp, tps, *cols, dt=dt,
+                                                                                     nsub=1).dq_rai_dt.double().cpu()[0]))
